@@ -1,0 +1,102 @@
+"""Small plain-torch models and deterministic data pools shared by the golden
+generator (tests/golden/gen_golden.py) and the parity tests.
+
+Weights and data are stored in the fixtures as tensors; these classes only give
+them a module structure (names of the decomposable layers are part of the
+decompose_config and therefore of the parity contract).
+"""
+
+from __future__ import annotations
+
+import itertools
+
+import torch
+
+
+def _unwrap(d):
+    return d["x"] if isinstance(d, dict) else d
+
+
+class MLP3(torch.nn.Module):
+    """64 -> 128 -> 96 -> 10 with ReLU; accepts a tensor (falor) or {"x": ...} (dwain)."""
+
+    def __init__(self, dims=(64, 128, 96, 10), bias=True):
+        super().__init__()
+        self.fc1 = torch.nn.Linear(dims[0], dims[1], bias=bias)
+        self.fc2 = torch.nn.Linear(dims[1], dims[2], bias=bias)
+        self.fc3 = torch.nn.Linear(dims[2], dims[3], bias=bias)
+
+    def forward(self, d):
+        x = _unwrap(d)
+        return self.fc3(torch.relu(self.fc2(torch.relu(self.fc1(x)))))
+
+
+class ConvNet(torch.nn.Module):
+    """3x3 stem, two 1x1 convs (decomposable), global pool, linear head."""
+
+    def __init__(self, c0=8, c1=48, c2=40, classes=10):
+        super().__init__()
+        self.stem = torch.nn.Conv2d(3, c0, kernel_size=3, padding=1)
+        self.pw1 = torch.nn.Conv2d(c0, c1, kernel_size=1)
+        self.pw2 = torch.nn.Conv2d(c1, c2, kernel_size=1, bias=False)
+        self.head = torch.nn.Linear(c2, classes)
+
+    def forward(self, d):
+        x = _unwrap(d)
+        x = torch.relu(self.stem(x))
+        x = torch.relu(self.pw1(x))
+        x = torch.relu(self.pw2(x))
+        return self.head(x.mean(dim=(2, 3)))
+
+
+class OneLinear(torch.nn.Module):
+    """The primitive-test network of the reference (tests/test_deco_primitives_dwain.py:35-50)."""
+
+    def __init__(self, n_in, n_out, bias=True):
+        super().__init__()
+        self.mod = torch.nn.Linear(n_in, n_out, bias=bias)
+
+    def forward(self, d):
+        x = d["inp"] if isinstance(d, dict) else d
+        return torch.flatten(self.mod(x), start_dim=1)
+
+
+class OneConv1x1(torch.nn.Module):
+    """tests/test_deco_primitives_dwain.py:53-72."""
+
+    def __init__(self, n_in, n_out, bias=True):
+        super().__init__()
+        self.mod = torch.nn.Conv2d(n_in, n_out, kernel_size=(1, 1), bias=bias)
+
+    def forward(self, d):
+        x = d["inp"] if isinstance(d, dict) else d
+        return torch.flatten(self.mod(x), start_dim=1)
+
+
+def cycle_tensors(pool):
+    """Endless iterator over a fixed pool of tensors (falor data stream)."""
+    return itertools.cycle(list(pool))
+
+
+def cycle_dicts(pool, targets=None, key="x"):
+    """Endless iterator of {"x": batch[, "targets": t]} dicts (dwain data stream)."""
+    items = []
+    for i, x in enumerate(pool):
+        d = {key: x}
+        if targets is not None:
+            d["targets"] = targets[i]
+        items.append(d)
+    return itertools.cycle(items)
+
+
+def ce_loss(batch, logits):
+    """Per-sample cross entropy; dwain exponentiates and averages it
+    (reference dwain.py:276-277 applies exp().mean() to whatever loss_fn returns)."""
+    return torch.nn.functional.cross_entropy(logits, batch["targets"], reduction="none")
+
+
+def load_state(model: torch.nn.Module, arrays, prefix: str) -> None:
+    """Copy fixture arrays named '<prefix><param name>' into the model."""
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            p.copy_(torch.from_numpy(arrays[prefix + name]))
