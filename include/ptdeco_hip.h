@@ -1,0 +1,122 @@
+/* ptdeco_hip.h -- C ABI of libptdeco_hip.so (gfx950 / MI355X).
+ *
+ * The reference (TCLResearchEurope/ptdeco v0.5.9) has no FFI layer: its hot
+ * path is a sequence of ATen calls inside src/ptdeco/{dwain,falor}/decomposition.py.
+ * Each entry point below replaces one group of those call sites; the citation
+ * after each declaration names the reference lines it stands in for
+ * (dwain.py = src/ptdeco/dwain/decomposition.py, falor.py = src/ptdeco/falor/decomposition.py,
+ * losses.py = src/ptdeco/utils/losses_primitives.py).
+ *
+ * Conventions
+ *  - plain C types only; every pointer except `stream` is a DEVICE pointer
+ *  - matrices are row-major with an explicit leading dimension in ELEMENTS
+ *  - `stream` is a hipStream_t passed as void*; every call is asynchronous on it
+ *    unless stated otherwise, and never allocates or frees device memory: the
+ *    caller passes workspaces sized by the matching *_workspace_bytes query
+ *  - return value: 0 = ok, negative = ptd_status; ptd_last_error() gives the
+ *    message of the last failing call on the calling thread
+ *  - no global mutable state besides lazily loaded code objects: re-entrant
+ *    across streams and devices
+ */
+#ifndef PTDECO_HIP_H
+#define PTDECO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PTD_ABI_VERSION 1
+
+typedef enum { PTD_F32 = 0, PTD_F64 = 1, PTD_BF16 = 2 } ptd_dtype;
+
+typedef enum {
+  PTD_OK = 0,
+  PTD_ERR_INVALID = -1,     /* bad argument (shape, stride, dtype, alignment, null) */
+  PTD_ERR_UNSUPPORTED = -2, /* dtype / layout combination not implemented */
+  PTD_ERR_WORKSPACE = -3,   /* workspace too small */
+  PTD_ERR_LAUNCH = -4,      /* HIP runtime reported an error */
+  PTD_ERR_NOCONV = -5       /* eigensolver did not converge in max sweeps */
+} ptd_status;
+
+int ptd_version(void);
+const char* ptd_last_error(void);
+
+/* ---- covariance accumulation ------------------------------------------- */
+
+/* E[i][j] += scale * sum_t Y[t][i] * Y[t][j]  for i >= j  (LOWER triangle only;
+ * ptd_cov_finalize mirrors it).  Y is [T, n] (f32 or bf16), E is [n, n] (f64 or f32).
+ * The product is accumulated in f32 on the matrix cores and promoted on the add.
+ * Replaces `Eyyt += einsum("bp,bq->pq", y, y) / T`: dwain.py:147-152, falor.py:160. */
+int ptd_syrk_accumulate(const void* y, int64_t T, int64_t n, int64_t ldy, int y_dtype,
+                        void* E, int64_t ldE, int E_dtype, double scale, void* stream);
+
+/* ey[j] += scale * sum_t Y[t][j].   Replaces `Ey += y.mean(dim=0)`: falor.py:161. */
+int ptd_colsum_accumulate(const void* y, int64_t T, int64_t n, int64_t ldy, int y_dtype,
+                          void* ey, int ey_dtype, double scale, void* stream);
+
+/* C = sym(E) / steps - (ey ? (ey / steps)(ey / steps)^T : 0);
+ * C[i][i] += damp_factor * mean(diag(C)).   C is always f64 [n, n], full symmetric.
+ * sym(E) reads the lower triangle of E; ey may be NULL, else it has E's dtype.
+ * ws needs ptd_cov_finalize_workspace_bytes(n).
+ * Replaces dwain.py:158-160, 207, 242 and falor.py:192-205. */
+size_t ptd_cov_finalize_workspace_bytes(int64_t n);
+int ptd_cov_finalize(const void* E, int64_t ldE, int E_dtype, const void* ey, int ey_dtype,
+                     int64_t n, double steps, double damp_factor, double* C, int64_t ldC,
+                     void* ws, size_t ws_bytes, void* stream);
+
+/* ---- symmetric eigendecomposition ---------------------------------------- */
+
+/* All eigenpairs of the symmetric positive semi-definite f64 matrix A [n, n]
+ * (full storage), eigenvalues ascending in evals[n], eigenvectors in the COLUMNS
+ * of evecs [n, n] (row-major, ld ldv) -- the layout torch.linalg.eigh returns.
+ * A is not modified.  One-sided block Jacobi on the matrix cores (f64 MFMA).
+ * NOT fully asynchronous: synchronises `stream` once per sweep to read the
+ * convergence flag.  sweeps_out (host pointer, may be NULL) receives the number
+ * of sweeps used.  Replaces `torch.linalg.eigh`: dwain.py:162, falor.py:207. */
+size_t ptd_eigh_workspace_bytes(int64_t n);
+int ptd_eigh(const double* A, int64_t lda, int64_t n, double* evals, double* evecs, int64_t ldv,
+             void* ws, size_t ws_bytes, int* sweeps_out, void* stream);
+
+/* ---- dense products (layer output, factor construction) ----------------- */
+
+/* C[M,N] = alpha * sum_k A(m,k) * B(k,n) (+ bias[n]),  f32 or bf16 operands,
+ * f32 accumulation on the matrix cores.  Operands are addressed with explicit
+ * element strides: A(m,k) = A[m*sam + k*sak], B(k,n) = B[k*sbk + n*sbn]; exactly
+ * one stride of each operand must be 1.  C is row-major [M, N] with ld ldc, of
+ * dtype c_dtype (f32, or bf16 when the inputs are bf16).
+ * Replaces `x @ weight.T` (dwain.py:194, 239; falor.py:159), `orig_weight.T @ uk`
+ * and `(U @ V).T` (dwain.py:427-429, 511; falor.py:347-348). */
+int ptd_gemm(const void* A, int64_t sam, int64_t sak, const void* B, int64_t sbk, int64_t sbn,
+             void* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int ab_dtype, int c_dtype,
+             double alpha, const void* bias, void* stream);
+
+/* y[T,n_o] = (x[T,n_i] @ A[r,n_i]^T) @ B[n_o,r]^T (+ bias[n_o]).  h_ws is a
+ * [T, r] scratch of the operand dtype.  The decomposed layer's forward:
+ * dwain.py:74-85 / falor.py:84-95 (two nn.Linear), dwain.py:126-144 (two 1x1 convs,
+ * x viewed as [B*H*W, C]). */
+int ptd_lowrank_forward(const void* x, int64_t ldx, int64_t T, int64_t n_i, const void* A, int64_t lda,
+                        int64_t r, const void* B, int64_t ldb, int64_t n_o, const void* bias, void* y,
+                        int64_t ldy, void* h_ws, int dtype, void* stream);
+
+/* ---- rank-selection metrics ------------------------------------------------ */
+
+/* out[0] (f64) = mean_c( mean_r (x-y)^2 / (var_r(y) + eps) ), x,y viewed as [R, C],
+ * var unbiased.  Replaces calc_per_channel_noise_to_signal_ratio (losses.py:10-22)
+ * for non_channel_dim = all leading dims. */
+size_t ptd_nsr_workspace_bytes(int64_t R, int64_t C);
+int ptd_nsr(const void* x, const void* y, int64_t R, int64_t C, int dtype, double eps, double* out,
+            void* ws, size_t ws_bytes, void* stream);
+
+/* out[0] (f64) = mean_b max(KL(t_b || s_b), KL(s_b || t_b)) over softmax(dim=-1) of
+ * logits s, t [B, C].  Replaces calc_kl_loss (losses.py:48-63). */
+size_t ptd_sym_kl_workspace_bytes(int64_t B);
+int ptd_sym_kl(const void* s, const void* t, int64_t B, int64_t C, int dtype, double* out, void* ws,
+               size_t ws_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTDECO_HIP_H */

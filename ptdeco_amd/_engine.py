@@ -1,0 +1,174 @@
+"""Shared machinery of the dwain and falor drivers: layer taps, the covariance
+accumulator that lives in HBM, factor construction and the rank-r pair builder.
+
+Data layout in HBM (one layer at a time unless the dwain precompute pass is on):
+  E     [n_out, n_out]  f64 (or f32)  lower triangle of sum_t y y^T / T, accumulated in place
+  ey    [n_out]         same dtype    falor only
+  C     [n_out, n_out]  f64           finalised full symmetric matrix handed to the eigensolver
+  u     [n_out, n_out]  f64           eigenvectors in columns, ascending eigenvalues
+  uk / U / W~           weight dtype  per candidate rank
+All arithmetic goes through ptdeco_amd.ops (libptdeco_hip.so); torch is used for
+allocation, views, dtype casts of slices and the user's own model forward.
+"""
+
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import ops
+from .lowrank import fuse_pair
+
+EIGEN_DAMPEN_FACTOR = 0.01  # reference dwain.py:14, falor.py:22
+
+
+def is_decomposeable_module(module: torch.nn.Module) -> bool:
+    """nn.Linear, or nn.Conv2d with a 1x1 kernel and groups == 1 (dwain.py:540-546, falor.py:402-408)."""
+    if isinstance(module, torch.nn.Linear):
+        return True
+    return (isinstance(module, torch.nn.Conv2d) and module.kernel_size[0] == 1 and module.kernel_size[1] == 1
+            and module.groups == 1)
+
+
+def require_device(device) -> torch.device:
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise ValueError(
+            f"ptdeco_amd runs the decomposition path on an MI355X; got device={device}. There is no CPU path.")
+    return device
+
+
+class LayerTap:
+    """Records the last input of one decomposable layer and gives a 2-D view of its weight.
+
+    Stands in for the reference's wrapper modules (dwain.py:41-144, falor.py:51-153):
+    a forward pre-hook instead of swapping the module, so the model's module tree and
+    parameter names are untouched while a layer is being analysed.
+    """
+
+    def __init__(self, root: torch.nn.Module, name: str):
+        layer = root.get_submodule(name)
+        if not is_decomposeable_module(layer):
+            raise ValueError(f"Cannot decompose {name}={layer}")
+        self.name = name
+        self.layer = layer
+        self.is_conv = isinstance(layer, torch.nn.Conv2d)
+        self._last: Optional[torch.Tensor] = None
+        self._handle = layer.register_forward_pre_hook(self._record)
+
+    def _record(self, _module, args) -> None:
+        self._last = args[0]
+
+    def close(self) -> None:
+        self._handle.remove()
+        self._last = None
+
+    @property
+    def n_in(self) -> int:
+        return self.layer.in_channels if self.is_conv else self.layer.in_features
+
+    def last_input_rows(self) -> torch.Tensor:
+        """[T, n_in] rows of the last input (NCHW -> NHWC rows for a conv: dwain.py:64, 116)."""
+        x = self._last
+        if x is None:
+            raise RuntimeError(f"layer {self.name} was not reached by the model's forward")
+        if self.is_conv:
+            return x.permute(0, 2, 3, 1).reshape(-1, self.n_in)
+        return x.reshape(-1, self.n_in)
+
+    def weight_copy(self) -> torch.Tensor:
+        w = self.layer.weight.detach()
+        return (w[..., 0, 0] if self.is_conv else w).clone()
+
+    def set_weight(self, w2d: torch.Tensor) -> None:
+        if self.is_conv:
+            self.layer.weight.copy_(w2d[:, :, None, None])
+        else:
+            self.layer.weight.copy_(w2d)
+
+
+class Covariance:
+    """sum over calibration steps of y^T y / T (and of mean_rows(y)) for one layer, in HBM."""
+
+    def __init__(self, n: int, device: torch.device, float64: bool, with_mean: bool = False):
+        dt = torch.float64 if float64 else torch.float32
+        self.E = torch.zeros((n, n), dtype=dt, device=device)
+        self.ey = torch.zeros(n, dtype=dt, device=device) if with_mean else None
+        self.steps = 0
+
+    def add_features(self, y: torch.Tensor) -> None:
+        """y: [T, n] layer output rows (dwain.py:147-152; falor.py:160-161)."""
+        t = y.shape[0]
+        ops.syrk_accumulate(self.E, y, 1.0 / t)
+        if self.ey is not None:
+            ops.colsum_accumulate(self.ey, y, 1.0 / t)
+        self.steps += 1
+
+    def add_inputs(self, x_rows: torch.Tensor, weight2d: torch.Tensor) -> torch.Tensor:
+        """x_rows [T, n_in], weight2d [n, n_in]: y = x W^T on the matrix cores, then accumulate."""
+        y = ops.matmul(x_rows, weight2d.T)
+        self.add_features(y)
+        return y
+
+    def all_reduce(self, group=None) -> None:
+        """Sum the partial statistics of all ranks (the one collective of the path: RCCL over xGMI)."""
+        import torch.distributed as dist
+
+        dist.all_reduce(self.E, op=dist.ReduceOp.SUM, group=group)
+        if self.ey is not None:
+            dist.all_reduce(self.ey, op=dist.ReduceOp.SUM, group=group)
+        steps = torch.tensor([self.steps], dtype=torch.int64, device=self.E.device)
+        dist.all_reduce(steps, op=dist.ReduceOp.SUM, group=group)
+        self.steps = int(steps.item())
+
+    def eigenvectors(self, damp_factor: float, use_mean: bool = False) -> torch.Tensor:
+        """Finalise (divide by steps, optional mean removal, Tikhonov damping) and return the
+        eigenvectors [n, n] f64, ascending (dwain.py:155-163, falor.py:192-208)."""
+        c = ops.cov_finalize(self.E, self.steps, damp_factor, self.ey if use_mean else None)
+        _, u = ops.eigh(c)
+        return u
+
+
+def build_factors(weight2d: torch.Tensor, u: torch.Tensor, rank: int, dtype: torch.dtype):
+    """Top-`rank` eigenvectors -> (uk [n, r], U [n_in, r], W~ [n, n_in]) in `dtype`.
+
+    U = W^T uk and W~ = (U uk^T)^T = uk U^T (dwain.py:424-429; falor.py:346-348)."""
+    n = u.shape[1]
+    uk = u[:, n - rank:].to(dtype).contiguous()
+    w = weight2d if weight2d.dtype == dtype else weight2d.to(dtype)
+    big_u = ops.matmul(w.T, uk)
+    w_deco = ops.matmul(uk, big_u.T)
+    return uk, big_u, w_deco
+
+
+def build_pair(layer: torch.nn.Module, big_u: torch.Tensor, uk: torch.Tensor, dtype: Optional[torch.dtype]):
+    """The rank-r replacement of `layer`: first weight U^T [r, n_in], second weight uk [n_out, r],
+    bias copied (dwain.py:69-85, 121-144).  A 1x1 conv pair takes default stride / padding /
+    dilation exactly like the reference."""
+    r = uk.shape[1]
+    has_bias = layer.bias is not None
+    dev = layer.weight.device
+    first_w = big_u.T.contiguous()
+    if isinstance(layer, torch.nn.Conv2d):
+        m1 = torch.nn.Conv2d(layer.in_channels, r, kernel_size=1, bias=False, device=dev)
+        m2 = torch.nn.Conv2d(r, layer.out_channels, kernel_size=1, bias=has_bias, device=dev)
+        first_w, second_w = first_w[:, :, None, None], uk[:, :, None, None]
+    else:
+        m1 = torch.nn.Linear(layer.in_features, r, bias=False, device=dev)
+        m2 = torch.nn.Linear(r, layer.out_features, bias=has_bias, device=dev)
+        second_w = uk
+    with torch.no_grad():
+        m1.weight.copy_(first_w)
+        m2.weight.copy_(second_w)
+        if has_bias:
+            m2.bias.copy_(layer.bias)
+    pair = torch.nn.Sequential(m1, m2)
+    if dtype is not None:
+        pair.to(dtype)
+    return fuse_pair(pair)
+
+
+def is_num_params_reduced(proportion: float, in_features: int, out_features: int) -> bool:
+    """dwain.py:569-577, falor.py:273-281."""
+    return (in_features + out_features) * proportion * min(in_features, out_features) < in_features * out_features

@@ -1,0 +1,81 @@
+"""ctypes binding of libptdeco_hip.so (C ABI: include/ptdeco_hip.h).
+
+The library is the only compute backend of this package: if it cannot be loaded
+every operation fails loudly -- there is no CPU or eager-PyTorch fallback.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_double, c_int, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libptdeco_hip.so")
+
+F32, F64, BF16 = 0, 1, 2
+ABI_VERSION = 1
+
+# name -> (restype, argtypes); must list every symbol include/ptdeco_hip.h declares
+SIGNATURES = {
+    "ptd_version": (c_int, []),
+    "ptd_last_error": (c_char_p, []),
+    "ptd_syrk_accumulate": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_int64, c_int,
+                                    c_double, c_void_p]),
+    "ptd_colsum_accumulate": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_int, c_double,
+                                      c_void_p]),
+    "ptd_cov_finalize_workspace_bytes": (c_size_t, [c_int64]),
+    "ptd_cov_finalize": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_int64, c_double, c_double, c_void_p,
+                                 c_int64, c_void_p, c_size_t, c_void_p]),
+    "ptd_eigh_workspace_bytes": (c_size_t, [c_int64]),
+    "ptd_eigh": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_size_t,
+                         ctypes.POINTER(c_int), c_void_p]),
+    "ptd_gemm": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
+                         c_int64, c_int64, c_int, c_int, c_double, c_void_p, c_void_p]),
+    "ptd_lowrank_forward": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p,
+                                    c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p]),
+    "ptd_nsr_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    "ptd_nsr": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_double, c_void_p, c_void_p, c_size_t,
+                        c_void_p]),
+    "ptd_sym_kl_workspace_bytes": (c_size_t, [c_int64]),
+    "ptd_sym_kl": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+}
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load the shared library once and bind every entry point."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryError(
+            f"{LIB_PATH} not found: build it with `make -C ptdeco_amd/csrc` (or __graft_entry__.build()). "
+            "ptdeco_amd has no CPU fallback.")
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # missing libamdhip64 etc.
+        raise HipLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise HipLibraryError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.ptd_version() != ABI_VERSION:
+        raise HipLibraryError(f"ABI version mismatch: library {lib.ptd_version()}, binding {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().ptd_last_error().decode(errors="replace")
+        raise HipLibraryError(f"{what} failed (status {rc}): {msg}")

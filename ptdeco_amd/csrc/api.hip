@@ -1,0 +1,108 @@
+// extern "C" surface of libptdeco_hip.so (declared in include/ptdeco_hip.h).
+#include <cstdarg>
+#include <cstring>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace ptd {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+}  // namespace ptd
+
+using namespace ptd;
+
+extern "C" {
+
+int ptd_version(void) { return PTD_ABI_VERSION; }
+
+const char* ptd_last_error(void) { return g_err; }
+
+int ptd_syrk_accumulate(const void* y, int64_t T, int64_t n, int64_t ldy, int y_dtype, void* E, int64_t ldE,
+                        int E_dtype, double scale, void* stream) {
+  PTD_REQUIRE(y && E, "ptd_syrk_accumulate: null pointer");
+  PTD_REQUIRE(T >= 0 && n >= 0 && ldy >= n && ldE >= n, "ptd_syrk_accumulate: bad shape T=%lld n=%lld ldy=%lld ldE=%lld",
+              (long long)T, (long long)n, (long long)ldy, (long long)ldE);
+  PTD_REQUIRE(E_dtype == PTD_F64 || E_dtype == PTD_F32, "ptd_syrk_accumulate: E must be f64 or f32");
+  PTD_REQUIRE(T < (1ll << 31) && n < (1ll << 31), "ptd_syrk_accumulate: dimension too large");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (y_dtype == PTD_F32)
+    return syrk_f32(static_cast<const float*>(y), T, n, ldy, E, ldE, E_dtype == PTD_F64, scale, st);
+  if (y_dtype == PTD_BF16)
+    return syrk_bf16(static_cast<const unsigned short*>(y), T, n, ldy, E, ldE, E_dtype == PTD_F64, scale, st);
+  set_error("ptd_syrk_accumulate: y dtype must be f32 or bf16");
+  return PTD_ERR_UNSUPPORTED;
+}
+
+int ptd_colsum_accumulate(const void* y, int64_t T, int64_t n, int64_t ldy, int y_dtype, void* ey, int ey_dtype,
+                          double scale, void* stream) {
+  return colsum_accumulate(y, T, n, ldy, y_dtype, ey, ey_dtype, scale, static_cast<hipStream_t>(stream));
+}
+
+size_t ptd_cov_finalize_workspace_bytes(int64_t n) { return cov_finalize_workspace_bytes(n); }
+
+int ptd_cov_finalize(const void* E, int64_t ldE, int E_dtype, const void* ey, int ey_dtype, int64_t n, double steps,
+                     double damp_factor, double* C, int64_t ldC, void* ws, size_t ws_bytes, void* stream) {
+  return cov_finalize(E, ldE, E_dtype, ey, ey_dtype, n, steps, damp_factor, C, ldC, ws, ws_bytes,
+                      static_cast<hipStream_t>(stream));
+}
+
+size_t ptd_eigh_workspace_bytes(int64_t n) { return eigh_workspace_bytes(n); }
+
+int ptd_eigh(const double* A, int64_t lda, int64_t n, double* evals, double* evecs, int64_t ldv, void* ws,
+             size_t ws_bytes, int* sweeps_out, void* stream) {
+  return eigh_jacobi(A, lda, n, evals, evecs, ldv, ws, ws_bytes, sweeps_out, static_cast<hipStream_t>(stream));
+}
+
+int ptd_gemm(const void* A, int64_t sam, int64_t sak, const void* B, int64_t sbk, int64_t sbn, void* C, int64_t ldc,
+             int64_t M, int64_t N, int64_t K, int ab_dtype, int c_dtype, double alpha, const void* bias,
+             void* stream) {
+  PTD_REQUIRE(A && B && C, "ptd_gemm: null pointer");
+  PTD_REQUIRE(M >= 0 && N >= 0 && K >= 0 && ldc >= N, "ptd_gemm: bad shape");
+  PTD_REQUIRE(M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31), "ptd_gemm: dimension too large");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (ab_dtype == PTD_F32 && c_dtype == PTD_F32)
+    return gemm_f32(static_cast<const float*>(A), sam, sak, static_cast<const float*>(B), sbk, sbn,
+                    static_cast<float*>(C), ldc, M, N, K, alpha, static_cast<const float*>(bias), st);
+  if (ab_dtype == PTD_BF16 && (c_dtype == PTD_BF16 || c_dtype == PTD_F32))
+    return gemm_bf16(static_cast<const unsigned short*>(A), sam, sak, static_cast<const unsigned short*>(B), sbk,
+                     sbn, C, ldc, M, N, K, c_dtype == PTD_BF16, alpha, static_cast<const unsigned short*>(bias),
+                     st);
+  set_error("ptd_gemm: unsupported dtype combination ab=%d c=%d", ab_dtype, c_dtype);
+  return PTD_ERR_UNSUPPORTED;
+}
+
+int ptd_lowrank_forward(const void* x, int64_t ldx, int64_t T, int64_t n_i, const void* A, int64_t lda, int64_t r,
+                        const void* B, int64_t ldb, int64_t n_o, const void* bias, void* y, int64_t ldy, void* h_ws,
+                        int dtype, void* stream) {
+  PTD_REQUIRE(x && A && B && y && h_ws, "ptd_lowrank_forward: null pointer");
+  PTD_REQUIRE(ldx >= n_i && lda >= n_i && ldb >= r && ldy >= n_o, "ptd_lowrank_forward: bad leading dimension");
+  // h = x A^T : A(m,k) = x[m*ldx + k], B(k,n) = A[n*lda + k];   y = h B^T + bias
+  int rc = ptd_gemm(x, ldx, 1, A, 1, lda, h_ws, r, T, r, n_i, dtype, dtype, 1.0, nullptr, stream);
+  if (rc != PTD_OK) return rc;
+  return ptd_gemm(h_ws, r, 1, B, 1, ldb, y, ldy, T, n_o, r, dtype, dtype, 1.0, bias, stream);
+}
+
+size_t ptd_nsr_workspace_bytes(int64_t R, int64_t C) { return nsr_workspace_bytes(R, C); }
+
+int ptd_nsr(const void* x, const void* y, int64_t R, int64_t C, int dtype, double eps, double* out, void* ws,
+            size_t ws_bytes, void* stream) {
+  return nsr(x, y, R, C, dtype, eps, out, ws, ws_bytes, static_cast<hipStream_t>(stream));
+}
+
+size_t ptd_sym_kl_workspace_bytes(int64_t B) { return sym_kl_workspace_bytes(B); }
+
+int ptd_sym_kl(const void* s, const void* t, int64_t B, int64_t C, int dtype, double* out, void* ws, size_t ws_bytes,
+               void* stream) {
+  return sym_kl(s, t, B, C, dtype, out, ws, ws_bytes, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,288 @@
+// bf16 dense products on the gfx950 matrix cores (v_mfma_f32_32x32x16_bf16, f32
+// accumulation, ~2.5 PFLOP/s dense peak).
+//
+//   gemm_bf16   C[M,N] = alpha * sum_k A(m,k) B(k,n) (+ bias), C bf16 or f32     -> ptd_gemm
+//   syrk_bf16   E[i,j] += scale * sum_t Y[t,i] Y[t,j], i >= j                   -> ptd_syrk_accumulate
+//
+// Same decomposition as the f32 kernel: 128x128 output tile per 256-thread
+// workgroup, 64x64 per wave as 2x2 MFMA tiles, K step 64, register-staged double
+// buffering.  The MFMA operand fragment is 8 consecutive k of one row
+// (lane l: row l & 31, k = 8 * (l >> 5) + 0..7), so the LDS image depends on
+// which index of the operand is contiguous in memory:
+//   k contiguous (x, W of nn.Linear):  image [r][k], pitch 144 B; fragment = one
+//       ds_read_b128; 144 B = 9 x 16 B puts the 16 rows of a lane group on 16
+//       different 16-B slots -> conflict free;
+//   r contiguous (Y^T of the covariance product, W^T of the factor product):
+//       image [k][r], pitch 320 B, written as is with ds_write_b128; fragment =
+//       two ds_read_b64_tr_b16 (hardware 4x16 transpose); 320 B = 256 + 64 puts
+//       the four k rows of a half wave on disjoint bank quarters -> conflict free.
+#include <algorithm>
+
+#include "common.h"
+
+namespace ptd {
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int PITCH_KC = 144;  // bytes, image [128 r][64 k]
+constexpr int PITCH_RC = 320;  // bytes, image [64 k][128 r]
+constexpr int OPER_BYTES = 64 * PITCH_RC;  // 20480 >= 128 * 144 = 18432
+
+enum { EPI_STORE_BF16 = 0, EPI_STORE_F32 = 1, EPI_ACC_F64 = 2, EPI_ACC_F32 = 3 };
+
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+struct GemmBf16Args {
+  const unsigned short* A;
+  int64_t sam, sak;
+  const unsigned short* B;
+  int64_t sbk, sbn;
+  void* C;
+  int64_t ldc;
+  int M, N, K;
+  float alpha;
+  double scale;
+  const unsigned short* bias;
+  int tiles_m;
+  int tri;
+  int kchunk;
+  int atomic;
+  int vecA, vecB;
+};
+
+__device__ __forceinline__ unsigned short f32_to_bf16(float f) {
+  // round to nearest even; NaN stays NaN (quiet bit forced)
+  unsigned int u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+
+// Fetch this thread's 4 x (8 bf16) of a 128 (r) x 64 (k) operand tile.
+//   KC:  element (r, k) at P[r * s + k];  thread -> r = idx >> 3, k = 8 * (idx & 7)
+//   !KC: element (r, k) at P[k * s + r];  thread -> k = idx >> 4, r = 8 * (idx & 15)
+template <bool KC>
+__device__ __forceinline__ void fetch_tile(const unsigned short* __restrict__ P, int64_t s, int r_lim, int k_lim,
+                                           bool vec, int tid, s16x8 (&v)[4]) {
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int idx = tid + 256 * p;
+    const int r = KC ? (idx >> 3) : (idx & 15) * 8;
+    const int k = KC ? (idx & 7) * 8 : (idx >> 4);
+    const unsigned short* q = KC ? P + (int64_t)r * s + k : P + (int64_t)k * s + r;
+    const bool full = KC ? (r < r_lim && k + 7 < k_lim) : (k < k_lim && r + 7 < r_lim);
+    if (vec && full) {
+      v[p] = *reinterpret_cast<const s16x8*>(q);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const bool ok = KC ? (r < r_lim && k + j < k_lim) : (k < k_lim && r + j < r_lim);
+        v[p][j] = ok ? (short)q[j] : (short)0;
+      }
+    }
+  }
+}
+
+template <bool KC>
+__device__ __forceinline__ void stash_tile(char* __restrict__ L, int tid, const s16x8 (&v)[4]) {
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int idx = tid + 256 * p;
+    const int off = KC ? (idx >> 3) * PITCH_KC + (idx & 7) * 16 : (idx >> 4) * PITCH_RC + (idx & 15) * 16;
+    *reinterpret_cast<s16x8*>(L + off) = v[p];
+  }
+}
+
+// MFMA operand fragment: rows r0 + (lane & 31), k = kk + 8 * (lane >> 5) + 0..7
+template <bool KC>
+__device__ __forceinline__ s16x8 frag(const char* __restrict__ L, int r0, int kk, int lane) {
+  if (KC) {
+    return *reinterpret_cast<const s16x8*>(L + (r0 + (lane & 31)) * PITCH_KC + (kk + 8 * (lane >> 5)) * 2);
+  } else {
+    // ds_read_b64_tr_b16: per 16-lane group a block of 4 rows (k) x 16 columns (r); lane 4q+p of the
+    // group supplies the address of row q, columns 4p..4p+3 and receives column (lane & 15), rows 0..3.
+    const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+    const int k = kk + 8 * (g >> 1) + q;
+    const int r = r0 + 16 * (g & 1) + 4 * p;
+    const char* a = L + k * PITCH_RC + r * 2;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a + 4 * PITCH_RC));
+    return s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  }
+}
+
+template <bool AKC, bool BKC, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmBf16Args a) {
+  __shared__ __attribute__((aligned(16))) char lds[2 * OPER_BYTES];
+  char* As = lds;
+  char* Bs = lds + OPER_BYTES;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+
+  int ti, tj;
+  if (a.tri) {
+    const int t = blockIdx.x;
+    ti = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
+    while (ti * (ti + 1) / 2 > t) --ti;
+    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+    tj = t - ti * (ti + 1) / 2;
+  } else {
+    ti = blockIdx.x % a.tiles_m;
+    tj = blockIdx.x / a.tiles_m;
+  }
+  const int m0 = ti * BM, n0 = tj * BN;
+  const int kbeg = blockIdx.y * a.kchunk;
+  const int kend = min(a.K, kbeg + a.kchunk);
+  const int nk = (kend - kbeg + BK - 1) / BK;
+
+  const unsigned short* Ap = a.A + (int64_t)m0 * a.sam + (int64_t)kbeg * a.sak;
+  const unsigned short* Bp = a.B + (int64_t)n0 * a.sbn + (int64_t)kbeg * a.sbk;
+  const int64_t sa = AKC ? a.sam : a.sak;
+  const int64_t sb = BKC ? a.sbn : a.sbk;
+  const int64_t astep = (int64_t)BK * a.sak, bstep = (int64_t)BK * a.sbk;
+  const int m_lim = a.M - m0, n_lim = a.N - n0;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  s16x8 ra[4], rb[4];
+  if (nk > 0) {
+    fetch_tile<AKC>(Ap, sa, m_lim, kend - kbeg, a.vecA, tid, ra);
+    fetch_tile<BKC>(Bp, sb, n_lim, kend - kbeg, a.vecB, tid, rb);
+    stash_tile<AKC>(As, tid, ra);
+    stash_tile<BKC>(Bs, tid, rb);
+  }
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const bool more = kt + 1 < nk;
+    if (more) {
+      const int k_lim = kend - kbeg - (kt + 1) * BK;
+      fetch_tile<AKC>(Ap + (kt + 1) * astep, sa, m_lim, k_lim, a.vecA, tid, ra);
+      fetch_tile<BKC>(Bp + (kt + 1) * bstep, sb, n_lim, k_lim, a.vecB, tid, rb);
+    }
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 16) {
+      const s16x8 a0 = frag<AKC>(As, wm * 64, kk, lane);
+      const s16x8 a1 = frag<AKC>(As, wm * 64 + 32, kk, lane);
+      const s16x8 b0 = frag<BKC>(Bs, wn * 64, kk, lane);
+      const s16x8 b1 = frag<BKC>(Bs, wn * 64 + 32, kk, lane);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    __syncthreads();
+    if (more) {
+      stash_tile<AKC>(As, tid, ra);
+      stash_tile<BKC>(Bs, tid, rb);
+      __syncthreads();
+    }
+  }
+
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row >= a.M || col >= a.N) continue;
+        if (a.tri && col > row) continue;
+        const float v = acc[i][j][r];
+        if (EPI == EPI_STORE_BF16 || EPI == EPI_STORE_F32) {
+          float o = a.alpha * v;
+          if (a.bias) o += bf16_to_f32(a.bias[col]);
+          if (EPI == EPI_STORE_BF16)
+            reinterpret_cast<unsigned short*>(a.C)[(int64_t)row * a.ldc + col] = f32_to_bf16(o);
+          else
+            reinterpret_cast<float*>(a.C)[(int64_t)row * a.ldc + col] = o;
+        } else if (EPI == EPI_ACC_F64) {
+          double* e = reinterpret_cast<double*>(a.C) + (int64_t)row * a.ldc + col;
+          const double d = a.scale * (double)v;
+          if (a.atomic) atomicAdd(e, d); else *e += d;
+        } else {
+          float* e = reinterpret_cast<float*>(a.C) + (int64_t)row * a.ldc + col;
+          const float d = (float)(a.scale * (double)v);
+          if (a.atomic) atomicAdd(e, d); else *e += d;
+        }
+      }
+    }
+}
+
+template <int EPI>
+void launch_bf16(const GemmBf16Args& a, bool akc, bool bkc, dim3 grid, hipStream_t st) {
+  if (akc && bkc) hipLaunchKernelGGL((gemm_bf16_kernel<true, true, EPI>), grid, dim3(256), 0, st, a);
+  else if (akc && !bkc) hipLaunchKernelGGL((gemm_bf16_kernel<true, false, EPI>), grid, dim3(256), 0, st, a);
+  else if (!akc && bkc) hipLaunchKernelGGL((gemm_bf16_kernel<false, true, EPI>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((gemm_bf16_kernel<false, false, EPI>), grid, dim3(256), 0, st, a);
+}
+
+}  // namespace
+
+int gemm_bf16(const unsigned short* A, int64_t sam, int64_t sak, const unsigned short* B, int64_t sbk, int64_t sbn,
+              void* C, int64_t ldc, int64_t M, int64_t N, int64_t K, bool c_bf16, double alpha,
+              const unsigned short* bias, hipStream_t st) {
+  PTD_REQUIRE((sam == 1) != (sak == 1) || (M == 1 || K == 1), "ptd_gemm: exactly one stride of A must be 1");
+  PTD_REQUIRE((sbk == 1) != (sbn == 1) || (N == 1 || K == 1), "ptd_gemm: exactly one stride of B must be 1");
+  if (M == 0 || N == 0) return PTD_OK;
+  GemmBf16Args a{};
+  a.A = A; a.sam = sam; a.sak = sak;
+  a.B = B; a.sbk = sbk; a.sbn = sbn;
+  a.C = C; a.ldc = ldc;
+  a.M = (int)M; a.N = (int)N; a.K = (int)K;
+  a.alpha = (float)alpha; a.scale = 1.0; a.bias = bias;
+  a.tiles_m = (int)ceil_div(M, BM);
+  a.tri = 0; a.kchunk = (int)align_up((size_t)(K > 0 ? K : 1), BK); a.atomic = 0;
+  const bool akc = (sak == 1), bkc = (sbk == 1);
+  a.vecA = aligned16(A) && ((akc ? sam : sak) % 8 == 0);
+  a.vecB = aligned16(B) && ((bkc ? sbn : sbk) % 8 == 0);
+  dim3 grid((unsigned)(a.tiles_m * ceil_div(N, BN)), 1);
+  if (c_bf16) launch_bf16<EPI_STORE_BF16>(a, akc, bkc, grid, st);
+  else launch_bf16<EPI_STORE_F32>(a, akc, bkc, grid, st);
+  PTD_CHECK_LAUNCH("gemm_bf16");
+  return PTD_OK;
+}
+
+int syrk_bf16(const unsigned short* Y, int64_t T, int64_t n, int64_t ldy, void* E, int64_t ldE, bool e_f64,
+              double scale, hipStream_t st) {
+  if (n == 0 || T == 0) return PTD_OK;
+  GemmBf16Args a{};
+  a.A = Y; a.sam = 1; a.sak = ldy;
+  a.B = Y; a.sbk = ldy; a.sbn = 1;
+  a.C = E; a.ldc = ldE;
+  a.M = (int)n; a.N = (int)n; a.K = (int)T;
+  a.alpha = 1.f; a.scale = scale; a.bias = nullptr;
+  const int nt = (int)ceil_div(n, BM);
+  a.tiles_m = nt;
+  a.tri = 1;
+  const int tiles = nt * (nt + 1) / 2;
+  int ksplit = 1;
+  if (tiles < 192) {
+    ksplit = (int)std::min<int64_t>(ceil_div(512, tiles), ceil_div(T, 4 * BK));
+    if (ksplit < 1) ksplit = 1;
+  }
+  a.kchunk = (int)align_up((size_t)ceil_div(T, ksplit), BK);
+  ksplit = (int)ceil_div(T, a.kchunk);
+  a.atomic = ksplit > 1;
+  a.vecA = a.vecB = aligned16(Y) && (ldy % 8 == 0);
+  dim3 grid((unsigned)tiles, (unsigned)ksplit);
+  if (e_f64) hipLaunchKernelGGL((gemm_bf16_kernel<false, false, EPI_ACC_F64>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((gemm_bf16_kernel<false, false, EPI_ACC_F32>), grid, dim3(256), 0, st, a);
+  PTD_CHECK_LAUNCH("syrk_bf16");
+  return PTD_OK;
+}
+
+}  // namespace ptd

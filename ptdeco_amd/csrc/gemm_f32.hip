@@ -1,0 +1,272 @@
+// f32 dense products on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32: exact
+// f32 fma chain, 157 TFLOP/s peak).
+//
+//   gemm_f32   C[M,N] = alpha * sum_k A(m,k) B(k,n) (+ bias)          -> ptd_gemm
+//   syrk_f32   E[i,j] += scale * sum_t Y[t,i] Y[t,j], i >= j            -> ptd_syrk_accumulate
+//
+// One 256-thread workgroup owns a 128x128 output tile; its 4 waves each own a
+// 64x64 quadrant as 2x2 MFMA tiles of 32x32 (64 accumulator VGPRs per lane).
+// The K loop runs in steps of 32: the next step's operands are fetched from HBM
+// into registers while the matrix cores consume the current step from LDS
+// (register-staged double buffering, one LDS image, two barriers per step).
+//
+// LDS image of an operand tile is [k][m] (m contiguous): the 32x32x2 MFMA wants
+// lane l to hold A[m = l & 31][k = l >> 5], i.e. 32 consecutive words per half
+// wave -> conflict free for any pitch.  The pitch is chosen for the WRITE side:
+//   k-contiguous operand (x, W of an nn.Linear): coalesced 16-B global loads
+//     along k, transposed on the way into LDS with four ds_write_b32; pitch 129
+//     spreads a half wave's (8 k-quads x 4 rows) over all 32 banks;
+//   m-contiguous operand (Y^T of the covariance product): rows of the tile are
+//     contiguous in memory, written with ds_write_b128; pitch 132 keeps 16-B
+//     alignment.
+#include <algorithm>
+
+#include "common.h"
+
+namespace ptd {
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int LDS_PITCH_MAX = 132;
+
+enum { EPI_STORE = 0, EPI_ACC_F64 = 1, EPI_ACC_F32 = 2 };
+
+struct GemmF32Args {
+  const float* A;
+  int64_t sam, sak;
+  const float* B;
+  int64_t sbk, sbn;
+  void* C;
+  int64_t ldc;
+  int M, N, K;
+  float alpha;
+  double scale;
+  const float* bias;
+  int tiles_m;
+  int tri;     // 1: blockIdx.x enumerates lower-triangle tiles (ti >= tj)
+  int kchunk;  // K range of blockIdx.y is [y*kchunk, min(K, (y+1)*kchunk)); multiple of BK
+  int atomic;  // accumulate with atomics (split K)
+  int vecA, vecB;
+};
+
+// Fetch this thread's 4 x 4 elements of a 128 x 32 operand tile.
+//   KC  (k contiguous):  element (r, k) at P[r * s + k];   thread -> row idx>>3, k-quad idx&7
+//   !KC (r contiguous):  element (r, k) at P[k * s + r];   thread -> k idx>>5, r-quad idx&31
+template <bool KC>
+__device__ __forceinline__ void fetch_tile(const float* __restrict__ P, int64_t s, int r_lim, int k_lim,
+                                           bool vec, int tid, f32x4 (&v)[4]) {
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int idx = tid + 256 * p;
+    if (KC) {
+      const int r = idx >> 3, k = (idx & 7) * 4;
+      const float* q = P + (int64_t)r * s + k;
+      if (vec && r < r_lim && k + 3 < k_lim) {
+        v[p] = *reinterpret_cast<const f32x4*>(q);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[p][j] = (r < r_lim && k + j < k_lim) ? q[j] : 0.f;
+      }
+    } else {
+      const int k = idx >> 5, r = (idx & 31) * 4;
+      const float* q = P + (int64_t)k * s + r;
+      if (vec && k < k_lim && r + 3 < r_lim) {
+        v[p] = *reinterpret_cast<const f32x4*>(q);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[p][j] = (k < k_lim && r + j < r_lim) ? q[j] : 0.f;
+      }
+    }
+  }
+}
+
+template <bool KC>
+__device__ __forceinline__ void stash_tile(float* __restrict__ L, int tid, const f32x4 (&v)[4]) {
+  constexpr int S = KC ? 129 : 132;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int idx = tid + 256 * p;
+    if (KC) {
+      const int r = idx >> 3, k = (idx & 7) * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) L[(k + j) * S + r] = v[p][j];
+    } else {
+      const int k = idx >> 5, r = (idx & 31) * 4;
+      *reinterpret_cast<f32x4*>(&L[k * S + r]) = v[p];
+    }
+  }
+}
+
+template <bool AKC, bool BKC, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmF32Args a) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * BK * LDS_PITCH_MAX];
+  float* As = lds;
+  float* Bs = lds + BK * LDS_PITCH_MAX;
+  constexpr int SA = AKC ? 129 : 132;
+  constexpr int SB = BKC ? 129 : 132;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+
+  int ti, tj;
+  if (a.tri) {
+    const int t = blockIdx.x;
+    ti = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
+    while (ti * (ti + 1) / 2 > t) --ti;
+    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+    tj = t - ti * (ti + 1) / 2;
+  } else {
+    ti = blockIdx.x % a.tiles_m;
+    tj = blockIdx.x / a.tiles_m;
+  }
+  const int m0 = ti * BM, n0 = tj * BN;
+  const int kbeg = blockIdx.y * a.kchunk;
+  const int kend = min(a.K, kbeg + a.kchunk);
+  const int nk = (kend - kbeg + BK - 1) / BK;
+
+  const float* Ap = a.A + (int64_t)m0 * a.sam + (int64_t)kbeg * a.sak;
+  const float* Bp = a.B + (int64_t)n0 * a.sbn + (int64_t)kbeg * a.sbk;
+  const int64_t sa = AKC ? a.sam : a.sak;  // stride of the non-contiguous index
+  const int64_t sb = BKC ? a.sbn : a.sbk;
+  const int64_t astep = (int64_t)BK * a.sak, bstep = (int64_t)BK * a.sbk;
+  const int m_lim = a.M - m0, n_lim = a.N - n0;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  f32x4 ra[4], rb[4];
+  if (nk > 0) {
+    fetch_tile<AKC>(Ap, sa, m_lim, kend - kbeg, a.vecA, tid, ra);
+    fetch_tile<BKC>(Bp, sb, n_lim, kend - kbeg, a.vecB, tid, rb);
+    stash_tile<AKC>(As, tid, ra);
+    stash_tile<BKC>(Bs, tid, rb);
+  }
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const bool more = kt + 1 < nk;
+    if (more) {
+      const int k_lim = kend - kbeg - (kt + 1) * BK;
+      fetch_tile<AKC>(Ap + (kt + 1) * astep, sa, m_lim, k_lim, a.vecA, tid, ra);
+      fetch_tile<BKC>(Bp + (kt + 1) * bstep, sb, n_lim, k_lim, a.vecB, tid, rb);
+    }
+    const int l31 = lane & 31, kh = lane >> 5;
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      const float* ar = As + (kk + kh) * SA + wm * 64 + l31;
+      const float* br = Bs + (kk + kh) * SB + wn * 64 + l31;
+      const float a0 = ar[0], a1 = ar[32];
+      const float b0 = br[0], b1 = br[32];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    __syncthreads();
+    if (more) {
+      stash_tile<AKC>(As, tid, ra);
+      stash_tile<BKC>(Bs, tid, rb);
+      __syncthreads();
+    }
+  }
+
+  // C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row >= a.M || col >= a.N) continue;
+        if (a.tri && col > row) continue;
+        const float v = acc[i][j][r];
+        if (EPI == EPI_STORE) {
+          float o = a.alpha * v;
+          if (a.bias) o += a.bias[col];
+          reinterpret_cast<float*>(a.C)[(int64_t)row * a.ldc + col] = o;
+        } else if (EPI == EPI_ACC_F64) {
+          double* e = reinterpret_cast<double*>(a.C) + (int64_t)row * a.ldc + col;
+          const double d = a.scale * (double)v;
+          if (a.atomic) atomicAdd(e, d); else *e += d;
+        } else {
+          float* e = reinterpret_cast<float*>(a.C) + (int64_t)row * a.ldc + col;
+          const float d = (float)(a.scale * (double)v);
+          if (a.atomic) atomicAdd(e, d); else *e += d;
+        }
+      }
+    }
+}
+
+template <int EPI>
+void launch_f32(const GemmF32Args& a, bool akc, bool bkc, dim3 grid, hipStream_t st) {
+  if (akc && bkc) hipLaunchKernelGGL((gemm_f32_kernel<true, true, EPI>), grid, dim3(256), 0, st, a);
+  else if (akc && !bkc) hipLaunchKernelGGL((gemm_f32_kernel<true, false, EPI>), grid, dim3(256), 0, st, a);
+  else if (!akc && bkc) hipLaunchKernelGGL((gemm_f32_kernel<false, true, EPI>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((gemm_f32_kernel<false, false, EPI>), grid, dim3(256), 0, st, a);
+}
+
+}  // namespace
+
+int gemm_f32(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn, float* C,
+             int64_t ldc, int64_t M, int64_t N, int64_t K, double alpha, const float* bias, hipStream_t st) {
+  PTD_REQUIRE((sam == 1) != (sak == 1) || (M == 1 || K == 1), "ptd_gemm: exactly one stride of A must be 1");
+  PTD_REQUIRE((sbk == 1) != (sbn == 1) || (N == 1 || K == 1), "ptd_gemm: exactly one stride of B must be 1");
+  if (M == 0 || N == 0) return PTD_OK;
+  GemmF32Args a{};
+  a.A = A; a.sam = sam; a.sak = sak;
+  a.B = B; a.sbk = sbk; a.sbn = sbn;
+  a.C = C; a.ldc = ldc;
+  a.M = (int)M; a.N = (int)N; a.K = (int)K;
+  a.alpha = (float)alpha; a.scale = 1.0; a.bias = bias;
+  a.tiles_m = (int)ceil_div(M, BM);
+  a.tri = 0; a.kchunk = (int)align_up((size_t)(K > 0 ? K : 1), BK); a.atomic = 0;
+  const bool akc = (sak == 1), bkc = (sbk == 1);
+  a.vecA = aligned16(A) && ((akc ? sam : sak) % 4 == 0);
+  a.vecB = aligned16(B) && ((bkc ? sbn : sbk) % 4 == 0);
+  dim3 grid((unsigned)(a.tiles_m * ceil_div(N, BN)), 1);
+  launch_f32<EPI_STORE>(a, akc, bkc, grid, st);
+  PTD_CHECK_LAUNCH("gemm_f32");
+  return PTD_OK;
+}
+
+int syrk_f32(const float* Y, int64_t T, int64_t n, int64_t ldy, void* E, int64_t ldE, bool e_f64, double scale,
+             hipStream_t st) {
+  if (n == 0 || T == 0) return PTD_OK;
+  GemmF32Args a{};
+  a.A = Y; a.sam = 1; a.sak = ldy;
+  a.B = Y; a.sbk = ldy; a.sbn = 1;
+  a.C = E; a.ldc = ldE;
+  a.M = (int)n; a.N = (int)n; a.K = (int)T;
+  a.alpha = 1.f; a.scale = scale; a.bias = nullptr;
+  const int nt = (int)ceil_div(n, BM);
+  a.tiles_m = nt;
+  a.tri = 1;
+  const int tiles = nt * (nt + 1) / 2;
+  // few output tiles (small n): split the token axis so the launch still fills 256 CUs
+  int ksplit = 1;
+  if (tiles < 192) {
+    ksplit = (int)std::min<int64_t>(ceil_div(512, tiles), ceil_div(T, 4 * BK));
+    if (ksplit < 1) ksplit = 1;
+  }
+  a.kchunk = (int)align_up((size_t)ceil_div(T, ksplit), BK);
+  ksplit = (int)ceil_div(T, a.kchunk);
+  a.atomic = ksplit > 1;
+  a.vecA = a.vecB = aligned16(Y) && (ldy % 4 == 0);
+  dim3 grid((unsigned)tiles, (unsigned)ksplit);
+  if (e_f64) hipLaunchKernelGGL((gemm_f32_kernel<false, false, EPI_ACC_F64>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((gemm_f32_kernel<false, false, EPI_ACC_F32>), grid, dim3(256), 0, st, a);
+  PTD_CHECK_LAUNCH("syrk_f32");
+  return PTD_OK;
+}
+
+}  // namespace ptd

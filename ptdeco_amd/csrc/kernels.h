@@ -1,0 +1,39 @@
+// Internal entry points behind the C ABI (one per .hip translation unit).
+#pragma once
+
+#include "common.h"
+
+namespace ptd {
+
+// gemm_f32.hip
+int gemm_f32(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn, float* C,
+             int64_t ldc, int64_t M, int64_t N, int64_t K, double alpha, const float* bias, hipStream_t st);
+int syrk_f32(const float* Y, int64_t T, int64_t n, int64_t ldy, void* E, int64_t ldE, bool e_f64, double scale,
+             hipStream_t st);
+
+// gemm_bf16.hip
+int gemm_bf16(const unsigned short* A, int64_t sam, int64_t sak, const unsigned short* B, int64_t sbk, int64_t sbn,
+              void* C, int64_t ldc, int64_t M, int64_t N, int64_t K, bool c_bf16, double alpha,
+              const unsigned short* bias, hipStream_t st);
+int syrk_bf16(const unsigned short* Y, int64_t T, int64_t n, int64_t ldy, void* E, int64_t ldE, bool e_f64,
+              double scale, hipStream_t st);
+
+// eigh_jacobi.hip
+size_t eigh_workspace_bytes(int64_t n);
+int eigh_jacobi(const double* A, int64_t lda, int64_t n, double* evals, double* evecs, int64_t ldv, void* ws,
+                size_t ws_bytes, int* sweeps_out, hipStream_t st);
+
+// reduce.hip
+size_t cov_finalize_workspace_bytes(int64_t n);
+int cov_finalize(const void* E, int64_t ldE, int E_dtype, const void* ey, int ey_dtype, int64_t n, double steps,
+                 double damp_factor, double* C, int64_t ldC, void* ws, size_t ws_bytes, hipStream_t st);
+int colsum_accumulate(const void* y, int64_t T, int64_t n, int64_t ldy, int y_dtype, void* ey, int ey_dtype,
+                      double scale, hipStream_t st);
+size_t nsr_workspace_bytes(int64_t R, int64_t C);
+int nsr(const void* x, const void* y, int64_t R, int64_t C, int dtype, double eps, double* out, void* ws,
+        size_t ws_bytes, hipStream_t st);
+size_t sym_kl_workspace_bytes(int64_t B);
+int sym_kl(const void* s, const void* t, int64_t B, int64_t C, int dtype, double* out, void* ws, size_t ws_bytes,
+           hipStream_t st);
+
+}  // namespace ptd

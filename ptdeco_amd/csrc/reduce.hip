@@ -1,0 +1,347 @@
+// HBM-bound helpers of the covariance / rank-selection path:
+//   cov_finalize   C = sym(E) / steps - mean term, Tikhonov damping on the diagonal
+//   colsum         ey += scale * column sums of Y                         (falor Ey)
+//   nsr            per-channel noise-to-signal ratio, one pass over x and y
+//   sym_kl         symmetric-max KL of two logit matrices, one wave per row
+// All accumulate in f64; inputs are f32 or bf16 and are read once, coalesced.
+#include <algorithm>
+
+#include "common.h"
+
+namespace ptd {
+
+namespace {
+
+template <typename T>
+__device__ __forceinline__ double ld(const T* p, int64_t i);
+template <>
+__device__ __forceinline__ double ld<float>(const float* p, int64_t i) { return (double)p[i]; }
+template <>
+__device__ __forceinline__ double ld<double>(const double* p, int64_t i) { return p[i]; }
+template <>
+__device__ __forceinline__ double ld<unsigned short>(const unsigned short* p, int64_t i) {
+  return (double)bf16_to_f32(p[i]);
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// ------------------------------------------------------------------ finalize
+template <typename TE, typename TY>
+__global__ void diag_mean_kernel(const TE* __restrict__ E, int64_t ldE, const TY* __restrict__ ey, int n,
+                                 double steps, double damp_factor, double* __restrict__ out) {
+  __shared__ double red[16];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    double c = ld(E, (int64_t)i * ldE + i) / steps;
+    if (ey) {
+      const double m = ld(ey, i) / steps;
+      c -= m * m;
+    }
+    s += c;
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
+    out[0] = damp_factor * (t / (double)n);
+  }
+}
+
+template <typename TE, typename TY>
+__global__ void cov_finalize_kernel(const TE* __restrict__ E, int64_t ldE, const TY* __restrict__ ey, int n,
+                                    double steps, const double* __restrict__ damp, double* __restrict__ C,
+                                    int64_t ldC) {
+  __shared__ double tile[32][33];
+  const int bi = blockIdx.y, bj = blockIdx.x;
+  const int hi = max(bi, bj), lo = min(bi, bj);  // source tile in the lower triangle
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int rr = ty; rr < 32; rr += 8) {
+    const int i = hi * 32 + rr, j = lo * 32 + tx;
+    tile[rr][tx] = (i < n && j < n) ? ld(E, (int64_t)i * ldE + j) : 0.0;
+  }
+  __syncthreads();
+  const double d = damp[0];
+  for (int rr = ty; rr < 32; rr += 8) {
+    const int i = bi * 32 + rr, j = bj * 32 + tx;
+    if (i >= n || j >= n) continue;
+    double e;
+    if (bi > bj) e = tile[rr][tx];
+    else if (bi < bj) e = tile[tx][rr];
+    else e = (rr >= tx) ? tile[rr][tx] : tile[tx][rr];
+    double c = e / steps;
+    if (ey) c -= (ld(ey, i) / steps) * (ld(ey, j) / steps);
+    if (i == j) c += d;
+    C[(int64_t)i * ldC + j] = c;
+  }
+}
+
+// -------------------------------------------------------------------- colsum
+template <typename TY, typename TO>
+__global__ void colsum_kernel(const TY* __restrict__ Y, int64_t T, int n, int64_t ldy, TO* __restrict__ ey,
+                              double scale, int rows_per_block) {
+  __shared__ double red[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + tx;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+  const int64_t r1 = min(T, r0 + rows_per_block);
+  double s = 0.0;
+  if (col < n)
+    for (int64_t r = r0 + ty; r < r1; r += 4) s += ld(Y, r * ldy + col);
+  red[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && col < n) {
+    const double t = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+    atomicAdd(&ey[col], (TO)(scale * t));
+  }
+}
+
+// ----------------------------------------------------------------------- nsr
+// Threads are laid out as Rt row lanes x Ct columns (Ct = min(C, 256), Rt = 256 / Ct) so that
+// consecutive threads touch consecutive addresses for every C, including C == 1.
+template <typename T>
+__global__ void nsr_partial_kernel(const T* __restrict__ x, const T* __restrict__ y, int64_t R, int64_t C,
+                                   int Ct, int Rt, int64_t rows_per_chunk, double* __restrict__ part) {
+  __shared__ double sm[3][256];
+  const int tid = threadIdx.x;
+  const int cl = tid % Ct, rl = tid / Ct;
+  const int64_t c = (int64_t)blockIdx.x * Ct + cl;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk;
+  const int64_t r1 = min(R, r0 + rows_per_chunk);
+  double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  const bool active = rl < Rt && c < C;
+  if (active) {
+    const double pivot = ld(y, c);  // first row: keeps the variance sum well conditioned
+    for (int64_t r = r0 + rl; r < r1; r += Rt) {
+      const double yv = ld(y, r * C + c), xv = ld(x, r * C + c);
+      const double dy = yv - pivot, dx = xv - yv;
+      s1 += dy;
+      s2 += dy * dy;
+      s3 += dx * dx;
+    }
+  }
+  sm[0][tid] = s1; sm[1][tid] = s2; sm[2][tid] = s3;
+  __syncthreads();
+  if (active && rl == 0) {
+    for (int k = 1; k < Rt; ++k) {
+      s1 += sm[0][k * Ct + cl];
+      s2 += sm[1][k * Ct + cl];
+      s3 += sm[2][k * Ct + cl];
+    }
+    double* o = part + ((int64_t)blockIdx.y * C + c) * 3;
+    o[0] = s1; o[1] = s2; o[2] = s3;
+  }
+}
+
+__global__ void nsr_final_kernel(const double* __restrict__ part, int64_t R, int64_t C, int nchunk, double eps,
+                                 double* __restrict__ out) {
+  __shared__ double red[16];
+  double acc = 0.0;
+  for (int64_t c = threadIdx.x; c < C; c += blockDim.x) {
+    double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    for (int k = 0; k < nchunk; ++k) {
+      const double* p = part + ((int64_t)k * C + c) * 3;
+      s1 += p[0]; s2 += p[1]; s3 += p[2];
+    }
+    const double n = (double)R;
+    const double var = (s2 - s1 * s1 / n) / (n - 1.0);  // unbiased, like torch.std
+    acc += (s3 / n) / (var + eps);
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
+    out[0] = t / (double)C;
+  }
+}
+
+// -------------------------------------------------------------------- sym_kl
+template <typename T>
+__global__ void sym_kl_rows_kernel(const T* __restrict__ s, const T* __restrict__ t, int64_t B, int64_t C,
+                                   double* __restrict__ rows) {
+  const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= B) return;
+  const int lane = threadIdx.x & 63;
+  const T* sr = s + row * C;
+  const T* tr = t + row * C;
+  double ms = -INFINITY, mt = -INFINITY;
+  for (int64_t c = lane; c < C; c += 64) {
+    ms = fmax(ms, ld(sr, c));
+    mt = fmax(mt, ld(tr, c));
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    ms = fmax(ms, __shfl_xor(ms, o));
+    mt = fmax(mt, __shfl_xor(mt, o));
+  }
+  double zs = 0.0, zt = 0.0;
+  for (int64_t c = lane; c < C; c += 64) {
+    zs += exp(ld(sr, c) - ms);
+    zt += exp(ld(tr, c) - mt);
+  }
+  zs = wave_sum(zs);
+  zt = wave_sum(zt);
+  const double ls = ms + log(zs), lt = mt + log(zt);
+  double kts = 0.0, kst = 0.0;  // KL(t || s), KL(s || t)
+  for (int64_t c = lane; c < C; c += 64) {
+    const double a = ld(sr, c) - ls, b = ld(tr, c) - lt;  // log-probabilities
+    kts += exp(b) * (b - a);
+    kst += exp(a) * (a - b);
+  }
+  kts = wave_sum(kts);
+  kst = wave_sum(kst);
+  if (lane == 0) rows[row] = fmax(kts, kst);
+}
+
+__global__ void mean_kernel(const double* __restrict__ v, int64_t n, double* __restrict__ out) {
+  __shared__ double red[16];
+  double s = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) s += v[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
+    out[0] = t / (double)n;
+  }
+}
+
+struct NsrPlan {
+  int Ct, Rt, coltiles, nchunk;
+  int64_t rows_per_chunk;
+};
+
+NsrPlan nsr_plan(int64_t R, int64_t C) {
+  NsrPlan p{};
+  p.Ct = (int)std::min<int64_t>(C, 256);
+  p.Rt = 256 / p.Ct;
+  p.coltiles = (int)ceil_div(C, p.Ct);
+  const int64_t want = std::max<int64_t>(1, 2048 / p.coltiles);
+  const int64_t min_rows = (int64_t)p.Rt * 16;
+  p.nchunk = (int)std::max<int64_t>(1, std::min<int64_t>(want, ceil_div(R, min_rows)));
+  p.rows_per_chunk = ceil_div(R, p.nchunk);
+  p.nchunk = (int)ceil_div(R, p.rows_per_chunk);
+  return p;
+}
+
+}  // namespace
+
+size_t cov_finalize_workspace_bytes(int64_t) { return 256; }
+
+template <typename TE, typename TY>
+static int cov_finalize_t(const TE* E, int64_t ldE, const TY* ey, int64_t n, double steps, double damp_factor,
+                          double* C, int64_t ldC, double* ws, hipStream_t st) {
+  hipLaunchKernelGGL((diag_mean_kernel<TE, TY>), dim3(1), dim3(1024), 0, st, E, ldE, ey, (int)n, steps,
+                     damp_factor, ws);
+  const unsigned nt = (unsigned)ceil_div(n, 32);
+  hipLaunchKernelGGL((cov_finalize_kernel<TE, TY>), dim3(nt, nt), dim3(256), 0, st, E, ldE, ey, (int)n, steps, ws,
+                     C, ldC);
+  PTD_CHECK_LAUNCH("cov_finalize");
+  return PTD_OK;
+}
+
+int cov_finalize(const void* E, int64_t ldE, int E_dtype, const void* ey, int ey_dtype, int64_t n, double steps,
+                 double damp_factor, double* C, int64_t ldC, void* ws, size_t ws_bytes, hipStream_t st) {
+  PTD_REQUIRE(E && C && ws && n >= 1 && ldE >= n && ldC >= n && steps > 0, "ptd_cov_finalize: bad argument");
+  PTD_REQUIRE(ws_bytes >= 256, "ptd_cov_finalize: workspace too small");
+  PTD_REQUIRE(!ey || ey_dtype == E_dtype, "ptd_cov_finalize: ey dtype must match E dtype");
+  double* w = static_cast<double*>(ws);
+  if (E_dtype == PTD_F64)
+    return cov_finalize_t((const double*)E, ldE, (const double*)ey, n, steps, damp_factor, C, ldC, w, st);
+  if (E_dtype == PTD_F32)
+    return cov_finalize_t((const float*)E, ldE, (const float*)ey, n, steps, damp_factor, C, ldC, w, st);
+  set_error("ptd_cov_finalize: E dtype must be f32 or f64");
+  return PTD_ERR_UNSUPPORTED;
+}
+
+template <typename TY, typename TO>
+static int colsum_t(const TY* y, int64_t T, int64_t n, int64_t ldy, TO* ey, double scale, hipStream_t st) {
+  const int64_t colt = ceil_div(n, 64);
+  int64_t nchunk = std::max<int64_t>(1, std::min<int64_t>(ceil_div(T, 64), ceil_div(1024, colt)));
+  const int64_t rpb = ceil_div(T, nchunk);
+  nchunk = ceil_div(T, rpb);
+  hipLaunchKernelGGL((colsum_kernel<TY, TO>), dim3((unsigned)colt, (unsigned)nchunk), dim3(256), 0, st, y, T,
+                     (int)n, ldy, ey, scale, (int)rpb);
+  PTD_CHECK_LAUNCH("colsum");
+  return PTD_OK;
+}
+
+int colsum_accumulate(const void* y, int64_t T, int64_t n, int64_t ldy, int y_dtype, void* ey, int ey_dtype,
+                      double scale, hipStream_t st) {
+  PTD_REQUIRE(y && ey && T >= 1 && n >= 1 && ldy >= n, "ptd_colsum_accumulate: bad argument");
+  if (y_dtype == PTD_F32 && ey_dtype == PTD_F64) return colsum_t((const float*)y, T, n, ldy, (double*)ey, scale, st);
+  if (y_dtype == PTD_F32 && ey_dtype == PTD_F32) return colsum_t((const float*)y, T, n, ldy, (float*)ey, scale, st);
+  if (y_dtype == PTD_BF16 && ey_dtype == PTD_F64)
+    return colsum_t((const unsigned short*)y, T, n, ldy, (double*)ey, scale, st);
+  if (y_dtype == PTD_BF16 && ey_dtype == PTD_F32)
+    return colsum_t((const unsigned short*)y, T, n, ldy, (float*)ey, scale, st);
+  set_error("ptd_colsum_accumulate: unsupported dtype combination");
+  return PTD_ERR_UNSUPPORTED;
+}
+
+size_t nsr_workspace_bytes(int64_t R, int64_t C) {
+  const NsrPlan p = nsr_plan(R, C);
+  return align_up((size_t)p.nchunk * C * 3 * 8, 256);
+}
+
+int nsr(const void* x, const void* y, int64_t R, int64_t C, int dtype, double eps, double* out, void* ws,
+        size_t ws_bytes, hipStream_t st) {
+  PTD_REQUIRE(x && y && out && ws && R >= 1 && C >= 1, "ptd_nsr: bad argument");
+  if (ws_bytes < nsr_workspace_bytes(R, C)) {
+    set_error("ptd_nsr: workspace too small");
+    return PTD_ERR_WORKSPACE;
+  }
+  const NsrPlan p = nsr_plan(R, C);
+  double* part = static_cast<double*>(ws);
+  dim3 grid((unsigned)p.coltiles, (unsigned)p.nchunk);
+  if (dtype == PTD_F32)
+    hipLaunchKernelGGL((nsr_partial_kernel<float>), grid, dim3(256), 0, st, (const float*)x, (const float*)y, R, C,
+                       p.Ct, p.Rt, p.rows_per_chunk, part);
+  else if (dtype == PTD_BF16)
+    hipLaunchKernelGGL((nsr_partial_kernel<unsigned short>), grid, dim3(256), 0, st, (const unsigned short*)x,
+                       (const unsigned short*)y, R, C, p.Ct, p.Rt, p.rows_per_chunk, part);
+  else if (dtype == PTD_F64)
+    hipLaunchKernelGGL((nsr_partial_kernel<double>), grid, dim3(256), 0, st, (const double*)x, (const double*)y, R,
+                       C, p.Ct, p.Rt, p.rows_per_chunk, part);
+  else {
+    set_error("ptd_nsr: unsupported dtype");
+    return PTD_ERR_UNSUPPORTED;
+  }
+  hipLaunchKernelGGL(nsr_final_kernel, dim3(1), dim3(1024), 0, st, part, R, C, p.nchunk, eps, out);
+  PTD_CHECK_LAUNCH("nsr");
+  return PTD_OK;
+}
+
+size_t sym_kl_workspace_bytes(int64_t B) { return align_up((size_t)std::max<int64_t>(B, 1) * 8, 256); }
+
+int sym_kl(const void* s, const void* t, int64_t B, int64_t C, int dtype, double* out, void* ws, size_t ws_bytes,
+           hipStream_t st) {
+  PTD_REQUIRE(s && t && out && ws && B >= 1 && C >= 1, "ptd_sym_kl: bad argument");
+  if (ws_bytes < sym_kl_workspace_bytes(B)) {
+    set_error("ptd_sym_kl: workspace too small");
+    return PTD_ERR_WORKSPACE;
+  }
+  double* rows = static_cast<double*>(ws);
+  const unsigned grid = (unsigned)ceil_div(B, 4);
+  if (dtype == PTD_F32)
+    hipLaunchKernelGGL((sym_kl_rows_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)s, (const float*)t,
+                       B, C, rows);
+  else if (dtype == PTD_BF16)
+    hipLaunchKernelGGL((sym_kl_rows_kernel<unsigned short>), dim3(grid), dim3(256), 0, st,
+                       (const unsigned short*)s, (const unsigned short*)t, B, C, rows);
+  else {
+    set_error("ptd_sym_kl: unsupported dtype");
+    return PTD_ERR_UNSUPPORTED;
+  }
+  hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(1024), 0, st, rows, B, out);
+  PTD_CHECK_LAUNCH("sym_kl");
+  return PTD_OK;
+}
+
+}  // namespace ptd

@@ -1,0 +1,358 @@
+"""dwain (Decomposing Weights Algorithm - an Iterative techNique) on MI355X.
+
+Keeps the keyword API, data-consumption order, rank-search decisions and return format
+of ``ptdeco.dwain.decompose_in_place`` (reference src/ptdeco/dwain/decomposition.py:677-800)
+while every contraction, the eigendecomposition and the metric reductions run in the
+HIP kernels of libptdeco_hip.so.  Reference line numbers below are in that file.
+
+Multi-GPU (optional, ``torch.distributed`` initialised with the nccl = RCCL backend, one
+process per GPU, identical model replica and identical data iterators on every rank):
+  * calibration steps are dealt round-robin to the ranks and the partial covariance sums
+    are all-reduced over xGMI -- the only collective that touches matrix data;
+  * with ``precomputing_covariance_num_splits`` the eigendecompositions of a split's
+    layers are owned round-robin by the ranks and broadcast when a layer's turn comes;
+  * the candidate ranks of a layer are evaluated on different ranks (each reads the
+    metric batches the sequential order would give that candidate) and the three
+    scalars per candidate are all-gathered, so every rank takes the same decisions.
+"""
+
+from __future__ import annotations
+
+import collections.abc
+import logging
+import time
+from typing import Any, Optional
+
+import torch
+
+from .. import _engine as eng
+from .. import ops, utils
+from ..sharding import Shard
+
+__all__ = ["decompose_in_place", "is_decomposeable_module"]
+
+EIGEN_DAMPEN_FACTOR = eng.EIGEN_DAMPEN_FACTOR
+is_decomposeable_module = eng.is_decomposeable_module
+
+logger = logging.getLogger(__name__)
+
+
+def _get_params_for_proportion(proportion: float, in_features: int, out_features: int) -> int:
+    """:319-330 -- parameter count of a rank (proportion * full) pair, int() truncated."""
+    baseline = in_features * out_features
+    proposed = (in_features + out_features) * proportion * min(in_features, out_features)
+    return int(proposed) if proposed < baseline else baseline
+
+
+def _candidate_ranks(full_rank: int, min_rank: int, reduction_factor: float) -> list[int]:
+    """:407-408 -- geometric schedule; the last candidate may fall below min_rank."""
+    ranks, r = [], full_rank
+    while r > min_rank:
+        r = int(r * reduction_factor)
+        ranks.append(r)
+    return ranks
+
+
+def _get_decomposeable_submodule_names(module: torch.nn.Module, blacklisted: list[str]) -> list[str]:
+    names = []
+    for name, mod in module.named_modules():
+        if is_decomposeable_module(mod):
+            if name in blacklisted:
+                logger.info(f"Skipping blacklisted module {name}")
+            else:
+                names.append(name)
+    return names
+
+
+class CovarianceComputingLinearModule(torch.nn.Module):
+    """Stand-in for an nn.Linear during the all-layers precompute pass (:166-208): same
+    output, and the layer's feature covariance accumulates in HBM as a side effect."""
+
+    def __init__(self, weight: torch.nn.Parameter, bias: Optional[torch.nn.Parameter], decompose_in_float64: bool):
+        super().__init__()
+        if weight.dim() != 2:
+            raise RuntimeError("covariance precompute supports nn.Linear only (2-D weight), like the reference "
+                               "whose x @ weight.T fails for a Conv2d weight")
+        self.weight = weight
+        self.bias = bias
+        self.in_features, self.out_features = weight.shape[1], weight.shape[0]
+        self.cov = eng.Covariance(self.out_features, weight.device, decompose_in_float64)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        rows = x.reshape(-1, self.in_features)
+        y = ops.matmul(rows, self.weight.T)
+        self.cov.add_features(y)
+        if self.bias is not None:
+            y += self.bias
+        return y.reshape(*x.shape[:-1], self.out_features)
+
+    def get_eigenvectors(self) -> torch.Tensor:
+        # the reference parks u on the CPU (:208); with 288 GB of HBM it stays resident
+        return self.cov.eigenvectors(EIGEN_DAMPEN_FACTOR).to(self.weight.dtype)
+
+
+def _precompute_covariance_matrix_decompositions(*, module, submodule_names, num_data_steps, data_iterator, device,
+                                                 decompose_in_float64, shard: Shard) -> dict[str, torch.Tensor]:
+    """:580-633."""
+    originals = {}
+    for name in submodule_names:
+        old = module.get_submodule(name)
+        originals[name] = old
+        logger.info(f"Replacing {name} by covariance computing wrapper")
+        utils.replace_submodule_in_place(
+            module, name, CovarianceComputingLinearModule(old.weight, old.bias, decompose_in_float64))
+    module.eval()
+    stand_ins = [module.get_submodule(n) for n in submodule_names]
+    with torch.no_grad():
+        for step in range(num_data_steps):
+            batch = next(data_iterator)  # every rank advances the stream identically
+            if not shard.mine(step):
+                continue
+            module(utils.to_device(batch, device))
+    logger.info("Computing eigenvectors ...")
+    u_dict: dict[str, torch.Tensor] = {}
+    for i, (name, m) in enumerate(zip(submodule_names, stand_ins)):
+        if shard.active:
+            m.cov.all_reduce(shard.group)
+        # eigendecompositions of a split are owned round-robin; non-owners receive u later
+        u_dict[name] = m.get_eigenvectors() if shard.owns(i) else None
+    for i, name in enumerate(submodule_names):
+        if shard.active:
+            u_dict[name] = shard.broadcast_from_owner(u_dict[name], i, (stand_ins[i].out_features,) * 2,
+                                                      stand_ins[i].weight.dtype, device)
+        logger.info(f"Replacing {name} by original linear")
+        utils.replace_submodule_in_place(module, name, originals[name])
+    del stand_ins
+    utils.free_gpu_reserved_memory()
+    return u_dict
+
+
+def _precompute_covariance_matrix_decompositions_in_splits(*, module, modules_to_decompose, num_splits,
+                                                           num_data_steps, data_iterator, device,
+                                                           decompose_in_float64, shard: Shard):
+    """:636-674 -- chunks of len // num_splits layers, each chunk consumes its own data steps."""
+    chunk = len(modules_to_decompose) // num_splits
+    if chunk == 0:
+        chunk, num_splits = 1, len(modules_to_decompose)
+    parts = num_splits if len(modules_to_decompose) % num_splits == 0 else num_splits + 1
+    u_dict: dict[str, torch.Tensor] = {}
+    for p in range(parts):
+        sub = modules_to_decompose[p * chunk:(p + 1) * chunk]
+        logger.info(f"Pre computing covariance matrices for {len(sub)} modules")
+        u_dict.update(_precompute_covariance_matrix_decompositions(
+            module=module, submodule_names=sub, num_data_steps=num_data_steps, data_iterator=data_iterator,
+            device=device, decompose_in_float64=decompose_in_float64, shard=shard))
+    assert len(u_dict) == len(modules_to_decompose)
+    return u_dict
+
+
+def _compute_covariance_matrix_decomposition(*, root_module, tap: eng.LayerTap, data_iterator, weight, num_data_steps,
+                                             device, decompose_in_float64, shard: Shard) -> torch.Tensor:
+    """:211-244 -- D model forwards, y = x W^T, Eyyt += y^T y / T, damped eigenvectors."""
+    root_module.eval()
+    logger.info("Using float64 for decomposition" if decompose_in_float64 else "Using float32 for decomposition")
+    cov = eng.Covariance(weight.shape[0], device, decompose_in_float64)
+    for step in range(num_data_steps):
+        batch = next(data_iterator)
+        if not shard.mine(step):
+            continue
+        root_module(utils.to_device(batch, device))
+        cov.add_inputs(tap.last_input_rows(), weight)
+    if shard.active:
+        cov.all_reduce(shard.group)
+    return cov.eigenvectors(EIGEN_DAMPEN_FACTOR)
+
+
+def _compute_metrics(*, input_dict, root_module, tap: eng.LayerTap, orig_weight, deco_weight, loss_fn):
+    """:247-278 -- (nsr, ppl_deco, ppl_diff) as one f64 device tensor (single host sync per step)."""
+    assert isinstance(input_dict, dict)
+    root_module.eval()
+    tap.set_weight(deco_weight)
+    y_deco = root_module(input_dict)
+    tap.set_weight(orig_weight)
+    y_orig = root_module(input_dict)
+    loss_deco = loss_fn(input_dict, y_deco)
+    loss_orig = loss_fn(input_dict, y_orig)
+    nsr = utils.calc_per_channel_noise_to_signal_ratio(y=y_orig, x=y_deco, non_channel_dim=(0, 1), mode="mean")
+    ppl_deco = torch.exp(loss_deco).mean()
+    ppl_orig = torch.exp(loss_orig).mean()
+    ppl_diff = (ppl_deco - ppl_orig) / ppl_orig  # :445, in the loss dtype like the reference
+    return torch.stack([nsr, ppl_deco.double(), ppl_diff.double()])
+
+
+def _process_module(*, root_module, decomposed_submodule_name, data_iterator, loss_fn, nsr_final_threshold,
+                    num_data_steps, num_metric_steps, device, metric_iterator, num_params, min_rank,
+                    trade_off_factor, reduction_factor, max_accepted_ppl_diff, decompose_in_float64, u_matrix,
+                    shard: Shard, trace: Optional[list] = None) -> dict[str, Any]:
+    """:333-537."""
+    indent = "    "
+    name = decomposed_submodule_name
+    tap = eng.LayerTap(root_module, name)
+    try:
+        layer = tap.layer
+        orig_device, orig_dtype = layer.weight.device, layer.weight.dtype
+        orig_weight = tap.weight_copy()
+        dim_out, dim_in = orig_weight.shape
+        full_rank = min(dim_in, dim_out)
+        msg_prefix = f"Processing {name}:"
+        if full_rank == 1:
+            logger.info(f"{msg_prefix} Module has rank 1, not decomposing")
+            return {"proportion": 1.0, "nsr_final": 0.0, "ppl_final": 0.0, "decomposed_module": None}
+        logger.info(f"{msg_prefix} {utils.get_type_name(layer)} weight_shape={tuple(orig_weight.shape)} "
+                    f"{orig_weight.dtype}")
+        logger.info(f"{msg_prefix} {nsr_final_threshold=:.4f} {max_accepted_ppl_diff=:.4f}")
+
+        if u_matrix is None:
+            u_matrix = _compute_covariance_matrix_decomposition(
+                root_module=root_module, tap=tap, data_iterator=data_iterator, weight=orig_weight,
+                num_data_steps=num_data_steps, device=device, decompose_in_float64=decompose_in_float64,
+                shard=shard)
+            logger.info(f"Computed u_matrix, {u_matrix.dtype=}")
+        else:
+            logger.info(f"Using pre-computed u_matrix, {u_matrix.dtype=}")
+
+        # candidates that change the parameter count, in schedule order (:407-421)
+        baseline_params = _get_params_for_proportion(1.0, dim_in, dim_out)
+        candidates = []
+        for rank_new in _candidate_ranks(full_rank, min_rank, reduction_factor):
+            drop = baseline_params - _get_params_for_proportion(rank_new / full_rank, dim_in, dim_out)
+            if drop == 0:
+                logger.info(f"{indent}{rank_new=} does not lead to params drop, skipping")
+                continue
+            candidates.append((rank_new, drop))
+
+        # metric batches are consumed in candidate order; with several GPUs candidate c is
+        # evaluated by rank c % G on exactly the batches the sequential order gives it
+        sums = torch.zeros((max(len(candidates), 1), 3), dtype=torch.float64, device=device)
+        for c, (rank_new, _drop) in enumerate(candidates):
+            batches = [next(metric_iterator) for _ in range(num_metric_steps)]
+            if not shard.mine(c):
+                continue
+            _, _, deco_weight = eng.build_factors(orig_weight, u_matrix, rank_new, orig_dtype)
+            for batch in batches:
+                sums[c] += _compute_metrics(input_dict=utils.to_device(batch, device), root_module=root_module,
+                                            tap=tap, orig_weight=orig_weight, deco_weight=deco_weight,
+                                            loss_fn=loss_fn)
+        if shard.active:
+            shard.all_reduce_small(sums)
+        table = (sums / num_metric_steps).tolist()  # the one host sync of the rank search
+
+        rank_best, nsr_best, ppl_deco_best = full_rank, 0.0, 0.0
+        for i, ((rank_new, drop), (nsr_new, ppl_deco_new, ppl_diff_new)) in enumerate(zip(candidates, table), 1):
+            fraction_removed = drop / num_params
+            ppl_diff_threshold = fraction_removed * trade_off_factor
+            logger.info(f"{indent}{i=} {ppl_deco_new=:.4f} {ppl_diff_new=:.4f} {ppl_diff_threshold=:.4f} "
+                        f"{fraction_removed=:.4f} {nsr_new=:.4f}")
+            # :460-470 -- three '>=' tests in this order; a NaN metric passes all of them
+            if ppl_diff_new >= ppl_diff_threshold:
+                verdict = f"REJECTING rank {rank_new}/{full_rank} {ppl_diff_new=:.2f} >= {ppl_diff_threshold=:.2f}"
+            elif ppl_diff_new >= max_accepted_ppl_diff:
+                verdict = f"REJECTING rank {rank_new}/{full_rank} {ppl_diff_new=:.3f} >= {max_accepted_ppl_diff:.3f}"
+            elif nsr_new >= nsr_final_threshold:
+                verdict = f"REJECTING rank {rank_new}/{full_rank} {nsr_new=:.4f} >= {nsr_final_threshold=:.4f}"
+            else:
+                rank_best, nsr_best, ppl_deco_best = rank_new, nsr_new, ppl_deco_new
+                verdict = f"ACCEPTING rank {rank_best}/{full_rank}"
+            logger.info(f"{indent}{i=} {verdict}")
+            if trace is not None:
+                trace.append({"layer": name, "i": i, "rank": rank_new, "nsr": nsr_new, "ppl_deco": ppl_deco_new,
+                              "ppl_diff": ppl_diff_new, "threshold": ppl_diff_threshold,
+                              "accepted": verdict.startswith("ACCEPTING")})
+
+        decomposition_occurred = len(candidates) > 0
+        proportion = rank_best / full_rank
+        decide = decomposition_occurred and eng.is_num_params_reduced(proportion, dim_in, dim_out)
+        if decomposition_occurred:
+            logger.info(f"{indent}i=FINAL rank={rank_best}/{full_rank} {proportion=:.4f} nsr={nsr_best:.6f} "
+                        f"ppl={ppl_deco_best:.6f}")
+        if decomposition_occurred and full_rank != rank_best and decide:
+            uk, big_u, _ = eng.build_factors(orig_weight, u_matrix, rank_best, orig_dtype)  # :507-511
+            new_module = eng.build_pair(layer, big_u, uk, orig_dtype).to(orig_device)
+            drop_in_params = baseline_params - _get_params_for_proportion(proportion, dim_in, dim_out)
+            return {"proportion": proportion, "nsr_final": nsr_best, "ppl_final": ppl_deco_best,
+                    "drop_in_params": drop_in_params, "decomposed_module": new_module}
+        logger.info(f"{msg_prefix} Skipping module decomposition")
+        return {"proportion": 1.0, "nsr_final": 0.0, "ppl_final": 0.0, "drop_in_params": 0,
+                "decomposed_module": None}
+    finally:
+        tap.close()
+
+
+def decompose_in_place(
+    *,
+    module: torch.nn.Module,
+    device: torch.device,
+    data_iterator: collections.abc.Iterator[dict[str, torch.Tensor]],
+    loss_fn: collections.abc.Callable[[dict[str, torch.Tensor], torch.Tensor], torch.Tensor],
+    num_data_steps: int,
+    metric_iterator: collections.abc.Iterator[dict[str, torch.Tensor]],
+    num_metric_steps: int,
+    blacklisted_module_names: Optional[list[str]] = None,
+    nsr_final_threshold: float,
+    finetune_fn: collections.abc.Callable[[torch.nn.Module, torch.device, list[str]], torch.nn.Module],
+    min_rank: int = 32,
+    trade_off_factor: float = 0.5,
+    reduction_factor: float = 0.5,
+    max_accepted_ppl_diff: float = 0.1,
+    decompose_in_float64: bool = True,
+    precomputing_covariance_num_splits: Optional[int] = None,
+    process_group: Any = None,
+    trace: Optional[list] = None,
+) -> dict[str, Any]:
+    """Same contract as ``ptdeco.dwain.decompose_in_place`` (:677-800).
+
+    Extra, optional: ``process_group`` (default: the world group when torch.distributed is
+    initialised with more than one rank) shards the work over GPUs as described in the module
+    docstring; ``trace`` receives one dict per evaluated candidate.
+    """
+    start_time = time.perf_counter()
+    device = eng.require_device(device)
+    shard = Shard.from_env(process_group)
+    num_params = utils.get_num_params(module)
+    current_params = num_params
+    blacklisted = blacklisted_module_names or []
+    modules_to_decompose = _get_decomposeable_submodule_names(module, blacklisted)
+    n = len(modules_to_decompose)
+    logger.info("\n".join([f"There are {n} linear modules that can be decomposed:"]
+                          + [f"  {i}. {name}" for i, name in enumerate(modules_to_decompose, 1)]))
+
+    if precomputing_covariance_num_splits is not None and precomputing_covariance_num_splits > 0:
+        u_dict = _precompute_covariance_matrix_decompositions_in_splits(
+            module=module, modules_to_decompose=modules_to_decompose, num_splits=precomputing_covariance_num_splits,
+            data_iterator=data_iterator, num_data_steps=num_data_steps, device=device,
+            decompose_in_float64=decompose_in_float64, shard=shard)
+    else:
+        logger.info("Skipping precomputing convariance matrices")
+        u_dict = {}
+    utils.free_gpu_reserved_memory()
+
+    decompose_config: dict[str, Any] = {}
+    decomposed_submodules: list[str] = []
+    n_decomposed = 0
+    for i, name in enumerate(reversed(modules_to_decompose), start=1):
+        logger.info(f"PROCESSING {name} MODULE {i} OUT OF {n}")
+        with torch.no_grad():
+            result = _process_module(
+                root_module=module, decomposed_submodule_name=name, data_iterator=data_iterator, loss_fn=loss_fn,
+                metric_iterator=metric_iterator, nsr_final_threshold=nsr_final_threshold,
+                num_data_steps=num_data_steps, num_metric_steps=num_metric_steps, device=device,
+                num_params=num_params, trade_off_factor=trade_off_factor, reduction_factor=reduction_factor,
+                max_accepted_ppl_diff=max_accepted_ppl_diff, min_rank=min_rank,
+                decompose_in_float64=decompose_in_float64,
+                u_matrix=u_dict.pop(name) if len(u_dict) > 0 else None, shard=shard, trace=trace)
+        current_params -= result.get("drop_in_params", 0)
+        logger.info(f"CURRENT PARAMS IN M: {current_params / 1e6}")
+        new_module = result["decomposed_module"]
+        if new_module is not None:
+            decomposed_submodules.append(name)
+            utils.replace_submodule_in_place(module, name, new_module)
+            module = finetune_fn(module, device, decomposed_submodules)
+            module_config = utils.get_module_config(new_module)
+            module_config[utils.MODCONFIG_META_KEY] = {k: v for k, v in result.items() if k != "decomposed_module"}
+            decompose_config[name] = module_config
+            logger.info(f"{name} decomposed with rank proportion={result['proportion']:.4f}")
+            n_decomposed += 1
+
+    logger.info(f"Decomposed {n_decomposed} out of {n} modules")
+    logger.info(f"Decomposition took {time.perf_counter() - start_time:.1f} seconds")
+    return decompose_config

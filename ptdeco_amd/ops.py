@@ -1,0 +1,185 @@
+"""Tensor-level front end of the HIP kernels (device memory and streams come from
+PyTorch-ROCm; all arithmetic happens in libptdeco_hip.so)."""
+
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import torch
+
+from . import _hip
+
+_DT = {torch.float32: _hip.F32, torch.float64: _hip.F64, torch.bfloat16: _hip.BF16}
+
+
+def _code(t: torch.Tensor) -> int:
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise TypeError(f"unsupported dtype {t.dtype}") from None
+
+
+def _dev(*ts: torch.Tensor) -> None:
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise ValueError("ptdeco_amd ops need tensors on a ROCm device (no CPU fallback)")
+
+
+def _stream(t: torch.Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _rows2d(t: torch.Tensor) -> torch.Tensor:
+    """Row-major 2-D view with unit inner stride (copy only if needed)."""
+    assert t.dim() == 2
+    return t if t.stride(1) == 1 and t.stride(0) >= max(1, t.shape[1]) else t.contiguous()
+
+
+def _strides(t: torch.Tensor) -> tuple[torch.Tensor, int, int]:
+    """2-D operand with exactly one unit stride -> (tensor, stride0, stride1)."""
+    assert t.dim() == 2
+    s0, s1 = t.stride()
+    if t.shape[0] == 1 or t.shape[1] == 1 or (s0 == 1) == (s1 == 1):
+        t = t.contiguous()
+        s0, s1 = t.stride()
+        if s1 != 1:  # shape (k, 1) contiguous has strides (1, 1)
+            s0, s1 = t.shape[1], 1
+    return t, s0, s1
+
+
+def syrk_accumulate(E: torch.Tensor, y: torch.Tensor, scale: float) -> None:
+    """E[i, j] += scale * (y^T y)[i, j] for i >= j  (lower triangle only)."""
+    _dev(E, y)
+    y = _rows2d(y)
+    n = y.shape[1]
+    assert E.shape == (n, n) and E.stride(1) == 1
+    with torch.cuda.device(E.device):
+        rc = _hip.load().ptd_syrk_accumulate(y.data_ptr(), y.shape[0], n, y.stride(0), _code(y), E.data_ptr(),
+                                             E.stride(0), _code(E), float(scale), _stream(E))
+    _hip.check(rc, "ptd_syrk_accumulate")
+
+
+def colsum_accumulate(ey: torch.Tensor, y: torch.Tensor, scale: float) -> None:
+    _dev(ey, y)
+    y = _rows2d(y)
+    assert ey.shape == (y.shape[1],) and ey.is_contiguous()
+    with torch.cuda.device(ey.device):
+        rc = _hip.load().ptd_colsum_accumulate(y.data_ptr(), y.shape[0], y.shape[1], y.stride(0), _code(y),
+                                               ey.data_ptr(), _code(ey), float(scale), _stream(ey))
+    _hip.check(rc, "ptd_colsum_accumulate")
+
+
+def cov_finalize(E: torch.Tensor, steps: int, damp_factor: float, ey: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """f64 full symmetric  sym(E)/steps - mean term + damping  (E holds the lower triangle)."""
+    _dev(E, ey)
+    n = E.shape[0]
+    lib = _hip.load()
+    C = torch.empty((n, n), dtype=torch.float64, device=E.device)
+    ws = torch.empty(lib.ptd_cov_finalize_workspace_bytes(n), dtype=torch.uint8, device=E.device)
+    with torch.cuda.device(E.device):
+        rc = lib.ptd_cov_finalize(E.data_ptr(), E.stride(0), _code(E), _ptr(ey), _code(ey) if ey is not None else 0,
+                                  n, float(steps), float(damp_factor), C.data_ptr(), n, ws.data_ptr(), ws.numel(),
+                                  _stream(E))
+    _hip.check(rc, "ptd_cov_finalize")
+    return C
+
+
+_EIGH_STATS = {"calls": 0, "sweeps": 0}
+
+
+def eigh(A: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+    """(eigenvalues ascending, eigenvectors in columns) of a symmetric PSD f64 matrix."""
+    _dev(A)
+    assert A.dtype == torch.float64 and A.dim() == 2 and A.shape[0] == A.shape[1] and A.stride(1) == 1
+    n = A.shape[0]
+    lib = _hip.load()
+    w = torch.empty(n, dtype=torch.float64, device=A.device)
+    v = torch.empty((n, n), dtype=torch.float64, device=A.device)
+    ws = torch.empty(lib.ptd_eigh_workspace_bytes(n), dtype=torch.uint8, device=A.device)
+    sweeps = ctypes.c_int(0)
+    with torch.cuda.device(A.device):
+        rc = lib.ptd_eigh(A.data_ptr(), A.stride(0), n, w.data_ptr(), v.data_ptr(), n, ws.data_ptr(), ws.numel(),
+                          ctypes.byref(sweeps), _stream(A))
+    _hip.check(rc, "ptd_eigh")
+    _EIGH_STATS["calls"] += 1
+    _EIGH_STATS["sweeps"] += sweeps.value
+    return w, v
+
+
+def matmul(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = None, alpha: float = 1.0,
+           out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """a [M, K] @ b [K, N] (+ bias[N]); a and b may be transposed views (no copies are made
+    for row-major or column-major operands)."""
+    _dev(a, b, bias)
+    assert a.dim() == 2 and b.dim() == 2 and a.shape[1] == b.shape[0] and a.dtype == b.dtype
+    a, sam, sak = _strides(a)
+    b, sbk, sbn = _strides(b)
+    M, K = a.shape
+    N = b.shape[1]
+    out_dtype = out_dtype or a.dtype
+    c = torch.empty((M, N), dtype=out_dtype, device=a.device)
+    if bias is not None:
+        bias = bias.to(a.dtype).contiguous()
+    with torch.cuda.device(a.device):
+        rc = _hip.load().ptd_gemm(a.data_ptr(), sam, sak, b.data_ptr(), sbk, sbn, c.data_ptr(), N, M, N, K, _code(a),
+                                  _DT[out_dtype], float(alpha), _ptr(bias), _stream(a))
+    _hip.check(rc, "ptd_gemm")
+    return c
+
+
+def lowrank_forward(x2d: torch.Tensor, A: torch.Tensor, B: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    """(x2d @ A^T) @ B^T + bias with A [r, n_i], B [n_o, r]."""
+    _dev(x2d, A, B, bias)
+    x2d, A, B = _rows2d(x2d), _rows2d(A), _rows2d(B)
+    T, n_i = x2d.shape
+    r, n_o = A.shape[0], B.shape[0]
+    assert A.shape[1] == n_i and B.shape[1] == r and x2d.dtype == A.dtype == B.dtype
+    y = torch.empty((T, n_o), dtype=x2d.dtype, device=x2d.device)
+    h = torch.empty((T, r), dtype=x2d.dtype, device=x2d.device)
+    if bias is not None:
+        bias = bias.to(x2d.dtype).contiguous()
+    with torch.cuda.device(x2d.device):
+        rc = _hip.load().ptd_lowrank_forward(x2d.data_ptr(), x2d.stride(0), T, n_i, A.data_ptr(), A.stride(0), r,
+                                             B.data_ptr(), B.stride(0), n_o, _ptr(bias), y.data_ptr(), n_o,
+                                             h.data_ptr(), _code(x2d), _stream(x2d))
+    _hip.check(rc, "ptd_lowrank_forward")
+    return y
+
+
+def nsr(x: torch.Tensor, y: torch.Tensor, channels: int, eps: float = 1e-3) -> torch.Tensor:
+    """Scalar (f64, on device): mean over the `channels` trailing-dim channels of
+    mean((x-y)^2) / (var(y) + eps), x and y viewed as [-1, channels]."""
+    _dev(x, y)
+    assert x.shape == y.shape and x.dtype == y.dtype
+    x, y = x.contiguous(), y.contiguous()
+    C = int(channels)
+    R = x.numel() // C
+    lib = _hip.load()
+    out = torch.empty(1, dtype=torch.float64, device=x.device)
+    ws = torch.empty(lib.ptd_nsr_workspace_bytes(R, C), dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.ptd_nsr(x.data_ptr(), y.data_ptr(), R, C, _code(x), float(eps), out.data_ptr(), ws.data_ptr(),
+                         ws.numel(), _stream(x))
+    _hip.check(rc, "ptd_nsr")
+    return out[0]
+
+
+def sym_kl(s: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
+    """Scalar (f64, on device): mean_b max(KL(t||s), KL(s||t)) for logits [B, C]."""
+    _dev(s, t)
+    assert s.shape == t.shape and s.dim() == 2 and s.dtype == t.dtype
+    s, t = s.contiguous(), t.contiguous()
+    B, C = s.shape
+    lib = _hip.load()
+    out = torch.empty(1, dtype=torch.float64, device=s.device)
+    ws = torch.empty(lib.ptd_sym_kl_workspace_bytes(B), dtype=torch.uint8, device=s.device)
+    with torch.cuda.device(s.device):
+        rc = lib.ptd_sym_kl(s.data_ptr(), t.data_ptr(), B, C, _code(s), out.data_ptr(), ws.data_ptr(), ws.numel(),
+                            _stream(s))
+    _hip.check(rc, "ptd_sym_kl")
+    return out[0]

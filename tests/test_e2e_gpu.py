@@ -1,0 +1,190 @@
+"""End-to-end parity on an MI355X: ptdeco_amd.{dwain,falor}.decompose_in_place against
+golden runs of the reference itself (tests/golden/e2e.*) -- identical rank decisions,
+metrics / factors / outputs within the stated f32 tolerances."""
+
+import json
+
+import numpy as np
+import pytest
+import torch
+
+import golden_io as gio
+import ptdeco_oracle as orc
+import toy_models as tm
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda")
+
+REL = 1e-4      # north_star tolerance for factors / metrics (f32 model, f64 decomposition)
+ABS_NOISE = 2e-6  # metrics that are pure f32 rounding noise in the reference (e.g. nsr ~ 1e-13, kl ~ 7e-8)
+
+
+def _to_dev_cycle(it):
+    for item in it:
+        yield item  # drivers move batches themselves (utils.to_device / .to(device))
+
+
+def _close(a, b):
+    return abs(a - b) <= REL * abs(b) + ABS_NOISE
+
+
+def _check_config(cfg, want):
+    cfg = gio.jsonable(cfg)
+    assert list(cfg.keys()) == list(want.keys())
+    for name in want:
+        got_meta, want_meta = cfg[name].pop("__meta__"), dict(want[name]["__meta__"])
+        assert {k: v for k, v in want[name].items() if k != "__meta__"} == cfg[name]
+        assert got_meta.keys() == want_meta.keys()
+        for k in want_meta:
+            if isinstance(want_meta[k], int):
+                assert got_meta[k] == want_meta[k], (name, k)
+            else:
+                assert _close(got_meta[k], want_meta[k]), (name, k, got_meta[k], want_meta[k])
+
+
+def _check_factors(model, name, decomposed, well_separated):
+    want = gio.final_state(name)
+    got = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    assert list(got.keys()) == list(want.keys())
+    for k in want:
+        assert got[k].shape == want[k].shape, k
+    for layer in decomposed:
+        a_g, b_g = got[f"{layer}.0.weight"].double(), got[f"{layer}.1.weight"].double()
+        a_w, b_w = want[f"{layer}.0.weight"].double(), want[f"{layer}.1.weight"].double()
+        if a_g.dim() == 4:
+            a_g, b_g, a_w, b_w = (t[:, :, 0, 0] for t in (a_g, b_g, a_w, b_w))
+        prod_g, prod_w = b_g @ a_g, b_w @ a_w
+        assert (prod_g - prod_w).norm().item() <= REL * prod_w.norm().item(), layer
+        if layer in well_separated:
+            # sign-canonicalise by the eigenvector columns of the second factor
+            def canon(a, b):
+                idx = b.abs().argmax(dim=0)
+                s = torch.sign(b[idx, torch.arange(b.shape[1])])
+                return a * s[:, None], b * s
+            a_gc, b_gc = canon(a_g, b_g)
+            a_wc, b_wc = canon(a_w, b_w)
+            assert (b_gc - b_wc).norm().item() <= REL * b_wc.norm().item(), layer
+            assert (a_gc - a_wc).norm().item() <= REL * a_wc.norm().item(), layer
+    for k in want:
+        if not any(k.startswith(layer + ".") for layer in decomposed):
+            assert torch.equal(got[k], want[k]), k  # untouched parameters stay bit-identical
+
+
+FALOR = {"falor_mlp_r8": {"fc1"}, "falor_mlp_r9": {"fc1", "fc3"}, "falor_mlp_mean32": set(), "falor_conv": set()}
+DWAIN = {"dwain_mlp_nosplit": {"fc1", "fc2"}, "dwain_mlp_split1": {"fc1", "fc2"}, "dwain_mlp_split2": {"fc1", "fc2"},
+         "dwain_mlp_f32acc": set(), "dwain_mlp_loose": {"fc1"}, "dwain_conv": set()}
+
+
+@pytest.mark.parametrize("name", list(FALOR))
+def test_falor_end_to_end(name):
+    import ptdeco_amd
+
+    scn = gio.e2e_meta()[name]
+    model = gio.build_model(scn).to(DEV)
+    trace = []
+    cfg = ptdeco_amd.falor.decompose_in_place(
+        module=model, device=DEV, data_iterator=tm.cycle_tensors(gio.pool(scn["pool"])), trace=trace,
+        **scn["kwargs"])
+    assert [(s["layer"], s["rank"]) for s in trace] == [(s["layer"], s["rank"]) for s in scn["steps"]]
+    m = scn["kwargs"]["num_metric_steps"]
+    want = np.array(scn["metric_samples"]).reshape(len(trace), m, 2).mean(axis=1)
+    for s, w in zip(trace, want):
+        assert _close(s["nsr"], w[0]) and _close(s["kl"], w[1]), (s, w)
+    _check_config(cfg, scn["config"])
+    _check_factors(model, name, list(cfg.keys()), FALOR[name])
+    with torch.no_grad():
+        out = model(gio.pool(scn["pool"])[0].to(DEV)).cpu()
+    ref = gio.t(gio.npz("e2e")[f"{name}.final_out"])
+    assert (out - ref).abs().max().item() <= REL * ref.abs().max().item()
+    assert all(isinstance(model.get_submodule(k), (ptdeco_amd.LowRankLinear, ptdeco_amd.LowRankConv1x1))
+               for k in cfg)
+
+
+@pytest.mark.parametrize("name", list(DWAIN))
+def test_dwain_end_to_end(name):
+    import ptdeco_amd
+
+    scn = gio.e2e_meta()[name]
+    model = gio.build_model(scn).to(DEV)
+    data, metric = gio.dwain_streams(scn)
+    trace = []
+    cfg = ptdeco_amd.dwain.decompose_in_place(
+        module=model, device=DEV, data_iterator=data, metric_iterator=metric, loss_fn=tm.ce_loss,
+        finetune_fn=lambda m, device, names: m, trace=trace, **scn["kwargs"])
+    got = [(s["layer"], s["rank"], s["accepted"]) for s in trace]
+    assert got == [(s["layer"], s["rank"], s["accepted"]) for s in scn["steps"]]
+    m = scn["kwargs"]["num_metric_steps"]
+    samples = np.array(scn["metric_samples"]).reshape(len(trace), m, 3)
+    for s, smp in zip(trace, samples):
+        assert _close(s["nsr"], smp[:, 0].mean()), (s, smp)
+        assert _close(s["ppl_deco"], smp[:, 1].mean()), (s, smp)
+        assert _close(s["ppl_diff"], ((smp[:, 1] - smp[:, 2]) / smp[:, 2]).mean()), (s, smp)
+    _check_config(cfg, scn["config"])
+    _check_factors(model, name, list(cfg.keys()), DWAIN[name])
+    with torch.no_grad():
+        out = model({"x": gio.pool(scn["pool"])[0].to(DEV)}).cpu()
+    ref = gio.t(gio.npz("e2e")[f"{name}.final_out"])
+    assert (out - ref).abs().max().item() <= REL * ref.abs().max().item()
+
+
+def test_config_round_trip_and_reload():
+    """README.md:56-105 of the reference: JSON config + state_dict reload onto a fresh model."""
+    import ptdeco_amd
+
+    scn = gio.e2e_meta()["falor_mlp_r9"]
+    model = gio.build_model(scn).to(DEV)
+    cfg = ptdeco_amd.falor.decompose_in_place(
+        module=model, device=DEV, data_iterator=tm.cycle_tensors(gio.pool(scn["pool"])), **scn["kwargs"])
+    blob = json.dumps(cfg)
+    fresh = gio.build_model(scn).to(DEV)
+    ptdeco_amd.utils.apply_decompose_config_in_place(fresh, json.loads(blob))
+    fresh.load_state_dict(model.state_dict())
+    x = gio.pool(scn["pool"])[1].to(DEV)
+    with torch.no_grad():
+        assert torch.equal(fresh(x), model(x))
+    assert isinstance(fresh.fc2, ptdeco_amd.LowRankLinear)
+
+
+def _primitive(kind, method):
+    """Port of the reference's own primitive tests (tests/test_deco_primitives_dwain.py:75-122,
+    test_deco_primitives_falor.py): full-rank factors from the HIP covariance + eigensolver must
+    reproduce the layer."""
+    from ptdeco_amd import _engine as eng
+
+    n_in, n_out, hw = 64, 32, 16
+    gen = torch.Generator().manual_seed(271828)
+    net = tm.OneLinear(n_in, n_out) if kind == "lin" else tm.OneConv1x1(n_in, n_out)
+    torch.nn.init.kaiming_uniform_(net.mod.weight, a=5**0.5, generator=gen)
+    torch.nn.init.uniform_(net.mod.bias, -(n_in**-0.5), n_in**-0.5, generator=gen)
+    net.to(DEV)
+    dgen = torch.Generator().manual_seed(1314159)
+    shape = (8, hw, hw, n_in) if kind == "lin" else (8, n_in, hw, hw)
+    batches = [torch.rand(*shape, generator=dgen) for _ in range(9)]
+    x = batches[0].to(DEV)
+    with torch.no_grad():
+        y0 = net(x)
+        tap = eng.LayerTap(net, "mod")
+        w0 = tap.weight_copy()
+        cov = eng.Covariance(n_out, DEV, True, with_mean=(method == "falor"))
+        for b in batches[1:]:
+            net(b.to(DEV))
+            cov.add_inputs(tap.last_input_rows(), w0)
+        u = cov.eigenvectors(eng.EIGEN_DAMPEN_FACTOR)
+        uk, big_u, _ = eng.build_factors(w0, u, min(n_in, n_out), torch.float32)
+        pair = eng.build_pair(tap.layer, big_u, uk, None)
+        tap.close()
+        net.mod = pair
+        y1 = net(x)
+    return y0, y1
+
+
+@pytest.mark.parametrize("method", ["dwain", "falor"])
+def test_primitive_linear_gpu(method):
+    y0, y1 = _primitive("lin", method)
+    assert (y0 - y1).abs().max().item() < 1.0e-6  # test_deco_primitives_dwain.py:174-178
+
+
+@pytest.mark.parametrize("method", ["dwain", "falor"])
+def test_primitive_conv1x1_gpu(method):
+    y0, y1 = _primitive("conv", method)
+    assert (y0 - y1).abs().max().item() < 9.0e-4  # the reference's own GPU bound (:187-192)

@@ -1,0 +1,140 @@
+"""Host logic of the drivers (schedules, decisions, stream order, config format, module
+surgery) checked on CPU against the reference's golden runs, with the HIP ops swapped for the
+oracle's arithmetic by tests/cpu_shim.py.  The GPU parity tests proper are test_e2e_gpu.py."""
+
+import json
+
+import numpy as np
+import pytest
+import torch
+
+import cpu_shim
+import golden_io as gio
+import toy_models as tm
+
+CPU = torch.device("cpu")
+FALOR = ["falor_mlp_r8", "falor_mlp_r9", "falor_mlp_mean32", "falor_conv"]
+DWAIN = ["dwain_mlp_nosplit", "dwain_mlp_split1", "dwain_mlp_split2", "dwain_mlp_f32acc", "dwain_mlp_loose",
+         "dwain_conv"]
+
+
+def _meta_close(cfg, want, rel=1e-5, abs_=1e-6):
+    cfg = gio.jsonable(cfg)
+    assert list(cfg.keys()) == list(want.keys())
+    for name in want:
+        gm, wm = cfg[name].pop("__meta__"), want[name]["__meta__"]
+        assert {k: v for k, v in want[name].items() if k != "__meta__"} == cfg[name]
+        for k in wm:
+            assert gm[k] == pytest.approx(wm[k], rel=rel, abs=abs_), (name, k)
+
+
+@pytest.mark.parametrize("name", FALOR)
+def test_falor_driver(name, monkeypatch):
+    scn = gio.e2e_meta()[name]
+    with cpu_shim.installed(monkeypatch) as pkg:
+        model = gio.build_model(scn)
+        trace = []
+        cfg = pkg.falor.decompose_in_place(module=model, device=CPU, trace=trace,
+                                           data_iterator=tm.cycle_tensors(gio.pool(scn["pool"])), **scn["kwargs"])
+    assert [(s["layer"], s["rank"]) for s in trace] == [(s["layer"], s["rank"]) for s in scn["steps"]]
+    _meta_close(cfg, scn["config"])
+    want = gio.final_state(name)
+    got = model.state_dict()
+    assert list(got.keys()) == list(want.keys())
+    with torch.no_grad():
+        out = model(gio.pool(scn["pool"])[0])
+    ref = gio.t(gio.npz("e2e")[f"{name}.final_out"])
+    assert (out - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("name", DWAIN)
+def test_dwain_driver(name, monkeypatch):
+    scn = gio.e2e_meta()[name]
+    with cpu_shim.installed(monkeypatch) as pkg:
+        model = gio.build_model(scn)
+        data, metric = gio.dwain_streams(scn)
+        trace = []
+        cfg = pkg.dwain.decompose_in_place(module=model, device=CPU, data_iterator=data, metric_iterator=metric,
+                                           loss_fn=tm.ce_loss, finetune_fn=lambda m, d, n: m, trace=trace,
+                                           **scn["kwargs"])
+    got = [(s["layer"], s["rank"], s["accepted"]) for s in trace]
+    assert got == [(s["layer"], s["rank"], s["accepted"]) for s in scn["steps"]]
+    _meta_close(cfg, scn["config"])
+    assert list(model.state_dict().keys()) == list(gio.final_state(name).keys())
+    with torch.no_grad():
+        out = model({"x": gio.pool(scn["pool"])[0]})
+    ref = gio.t(gio.npz("e2e")[f"{name}.final_out"])
+    assert (out - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+
+
+def test_finetune_fn_contract(monkeypatch):
+    """finetune_fn is called after every accepted layer with the growing list of names (dwain.py:779-786)."""
+    scn = gio.e2e_meta()["dwain_mlp_nosplit"]
+    calls = []
+
+    def ft(m, device, names):
+        calls.append(list(names))
+        return m
+
+    with cpu_shim.installed(monkeypatch) as pkg:
+        model = gio.build_model(scn)
+        data, metric = gio.dwain_streams(scn)
+        pkg.dwain.decompose_in_place(module=model, device=CPU, data_iterator=data, metric_iterator=metric,
+                                     loss_fn=tm.ce_loss, finetune_fn=ft, **scn["kwargs"])
+    assert calls == [["fc2"], ["fc2", "fc1"]]
+
+
+def test_non_decomposable_target_raises():
+    from ptdeco_amd import _engine
+    m = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3))
+    with pytest.raises(ValueError, match="Cannot decompose"):
+        _engine.LayerTap(m, "0")
+
+
+def test_utils_surface():
+    import ptdeco_amd.utils as u
+
+    assert u.MODCONFIG_META_KEY == "__meta__"
+    with pytest.raises(ValueError):
+        u.to_device([1, 2], CPU)
+    d = u.to_device({"a": torch.zeros(2), "b": 3}, CPU)
+    assert d["b"] == 3
+    lin = torch.nn.Linear(3, 4)
+    tied = torch.nn.ModuleList([lin, lin])
+    assert u.get_num_params(tied) == 16
+    assert u.split_module_parent_child_name("a.b.c") == ("a.b", "c")
+    assert u.split_module_parent_child_name("c") == ("", "c")
+    with pytest.raises(ValueError):
+        u.build_module_from_config({"type": "Nope"})
+    with pytest.raises(ValueError):
+        u.get_module_config(torch.nn.ReLU())
+    conv = torch.nn.Conv2d(4, 6, 1, stride=2)
+    cfg = json.loads(json.dumps(u.get_module_config(conv)))
+    back = u.build_module_from_config(cfg)
+    assert back.stride == (2, 2) and back.kernel_size == (1, 1)
+
+
+def test_apply_decompose_config_builds_fused_pairs():
+    import ptdeco_amd
+
+    scn = gio.e2e_meta()["falor_conv"]
+    model = gio.build_model(scn)
+    ptdeco_amd.utils.apply_decompose_config_in_place(model, scn["config"])
+    assert isinstance(model.pw2, ptdeco_amd.LowRankConv1x1)
+    assert isinstance(model.head, ptdeco_amd.LowRankLinear)
+    model.load_state_dict(gio.final_state("falor_conv"))
+    with torch.no_grad():
+        out = model(gio.pool("c")[0])  # CPU: the pair runs its two children
+    np.testing.assert_allclose(out.numpy(), gio.npz("e2e")["falor_conv.final_out"], rtol=1e-5, atol=1e-6)
+
+
+def test_candidate_schedules():
+    from ptdeco_amd.dwain import decomposition as dw
+    from ptdeco_amd.falor import decomposition as fa
+
+    assert dw._candidate_ranks(10, 4, 0.5) == [5, 2]
+    assert dw._candidate_ranks(4096, 32, 0.5) == [2048, 1024, 512, 256, 128, 64, 32]
+    assert dw._get_params_for_proportion(0.5, 64, 128) == 6144
+    assert fa._bisection_widths(96) == [48, 24, 12, 6, 3, 1]
+    assert fa._bisection_widths(10) == [5, 2, 1]
+    assert fa._batches_consumed(torch.nn.Linear(96, 10), 4, 2) == 4 + 2 * 3

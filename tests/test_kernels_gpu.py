@@ -1,0 +1,297 @@
+"""Parity of every HIP entry point (through the C ABI) against the CPU oracle /
+f64 torch-CPU arithmetic on the same seeded inputs.  Needs an MI355X."""
+
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import golden_io as gio
+import ptdeco_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from ptdeco_amd import ops as _ops
+    return _ops
+
+
+DEV = "cuda"
+
+
+def _rand(shape, seed, dtype=torch.float32, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype)
+
+
+def _lower(a):
+    return torch.tril(a)
+
+
+# ---------------------------------------------------------------- covariance accumulate
+@pytest.mark.parametrize("T,n", [(5, 10), (72, 32), (300, 100), (1024, 129), (4096, 512), (777, 1000)])
+@pytest.mark.parametrize("ydt,edt", [(torch.float32, torch.float64), (torch.float32, torch.float32),
+                                     (torch.bfloat16, torch.float64), (torch.bfloat16, torch.float32)])
+def test_syrk_accumulate(ops, T, n, ydt, edt):
+    y = _rand((T, n), 11 * T + n, ydt)
+    e0 = _rand((n, n), 5, edt)
+    ref = e0.double() + (y.double().T @ y.double()) / T
+    e = e0.to(DEV)
+    ops.syrk_accumulate(e, y.to(DEV), 1.0 / T)
+    ops.syrk_accumulate(e, y.to(DEV), 0.0)  # scale 0 adds nothing
+    got = e.cpu().double()
+    # lower triangle updated, strict upper untouched
+    assert torch.equal(torch.triu(got, 1), torch.triu(e0.double(), 1))
+    tol = 2e-6 if edt == torch.float64 else 2e-5
+    err = (_lower(got) - _lower(ref)).abs().max().item()
+    assert err <= tol * max(1.0, ref.abs().max().item()), err
+
+
+def test_syrk_matches_oracle_product_in_activation_dtype(ops):
+    """dwain.py:152: the oracle forms y^T y / T in y's dtype (f32) then adds into f64."""
+    z = gio.npz("prim")
+    w = gio.t(z["lin.weight"])
+    rows = [x.reshape(-1, 64) for x in gio.t(z["lin.batches"])][1:]
+    eyyt, _, _ = orc.dwain_eigvecs_from_batches(w, rows, float64=True)
+    e = torch.zeros((32, 32), dtype=torch.float64, device=DEV)
+    for x in rows:
+        y = ops.matmul(x.to(DEV), w.to(DEV).T)
+        ops.syrk_accumulate(e, y, 1.0 / y.shape[0])
+    err = (_lower(e.cpu()) - _lower(eyyt)).abs().max().item()
+    assert err <= 1e-6 * eyyt.abs().max().item()
+
+
+def test_syrk_strided_rows(ops):
+    big = _rand((200, 96), 3).to(DEV)
+    y = big[:, :64]  # ldy = 96
+    e = torch.zeros((64, 64), dtype=torch.float64, device=DEV)
+    ops.syrk_accumulate(e, y, 0.5)
+    ref = 0.5 * (y.cpu().double().T @ y.cpu().double())
+    assert (_lower(e.cpu()) - _lower(ref)).abs().max().item() <= 2e-6 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("T,n", [(5, 10), (300, 100), (15680, 128)])
+@pytest.mark.parametrize("ydt,edt", [(torch.float32, torch.float64), (torch.float32, torch.float32),
+                                     (torch.bfloat16, torch.float64)])
+def test_colsum_accumulate(ops, T, n, ydt, edt):
+    y = _rand((T, n), T + n, ydt) + 0.25
+    ey = torch.full((n,), 0.5, dtype=edt, device=DEV)
+    ops.colsum_accumulate(ey, y.to(DEV), 1.0 / T)
+    ref = 0.5 + y.double().mean(dim=0)
+    tol = 1e-12 if edt == torch.float64 else 1e-5
+    assert (ey.cpu().double() - ref).abs().max().item() <= tol * 4
+
+
+# ---------------------------------------------------------------- finalize
+@pytest.mark.parametrize("n", [1, 10, 33, 257])
+@pytest.mark.parametrize("edt", [torch.float64, torch.float32])
+@pytest.mark.parametrize("use_mean", [False, True])
+def test_cov_finalize(ops, n, edt, use_mean):
+    y = _rand((3 * n + 7, n), n).double()
+    full = (y.T @ y).to(edt)
+    ey = y.sum(dim=0).to(edt)
+    steps = 3
+    e_dev = torch.tril(full).to(DEV) + torch.triu(torch.full((n, n), 777.0, dtype=edt), 1).to(DEV)  # garbage above
+    c = ops.cov_finalize(e_dev, steps, orc.DAMP_FACTOR, ey.to(DEV) if use_mean else None).cpu()
+    ref = full.double() / steps
+    if use_mean:
+        m = ey.double() / steps
+        ref = ref - torch.outer(m, m)
+    ref = ref + torch.eye(n, dtype=torch.float64) * (orc.DAMP_FACTOR * torch.diag(ref).mean())
+    assert torch.equal(c, c.T)
+    assert (c - ref).abs().max().item() <= 1e-13 * max(1.0, ref.abs().max().item())
+
+
+# ---------------------------------------------------------------- eigh
+def _check_eigh(ops, a, vec_tol=None):
+    n = a.shape[0]
+    w, v = ops.eigh(a.to(DEV))
+    w, v = w.cpu(), v.cpu()
+    w_ref, v_ref = torch.linalg.eigh(a)
+    scale = max(w_ref.abs().max().item(), 1e-300)
+    assert torch.all(w[1:] >= w[:-1]), "eigenvalues not ascending"
+    assert (w - w_ref).abs().max().item() <= 1e-12 * scale
+    assert (v.T @ v - torch.eye(n, dtype=torch.float64)).abs().max().item() <= 1e-12
+    assert (a @ v - v * w).abs().max().item() <= 1e-11 * scale
+    if vec_tol is not None:
+        assert (orc.canonical_sign(v) - orc.canonical_sign(v_ref)).abs().max().item() <= vec_tol
+    return w, v
+
+
+@pytest.mark.parametrize("n", [1, 2, 5, 31, 32, 64, 65, 100, 200, 512])
+def test_eigh_random_covariance(ops, n):
+    y = _rand((2 * n + 3, n), 100 + n).double() * torch.logspace(0, -2, n, dtype=torch.float64)
+    a = y.T @ y / y.shape[0]
+    a = a + torch.eye(n, dtype=torch.float64) * (0.01 * torch.diag(a).mean())
+    _check_eigh(ops, a)
+
+
+def test_eigh_known_answer_geometric_spectrum(ops):
+    """Eigenpairs known in closed form: A = H diag(s) H with H a Householder reflector
+    (no RNG, no LAPACK in the expected values); gap at every cut."""
+    n = 256
+    x = torch.sin(torch.arange(1, n + 1, dtype=torch.float64) * 0.37) + 0.1
+    x = x / x.norm()
+    h = torch.eye(n, dtype=torch.float64) - 2.0 * torch.outer(x, x)
+    s = 2.0 ** (-torch.arange(n - 1, -1, -1, dtype=torch.float64) / 16.0)  # ascending, ratio 2^(1/16)
+    a = (h * s) @ h
+    a = 0.5 * (a + a.T)
+    w, v = _check_eigh(ops, a)
+    assert (w - s).abs().max().item() <= 1e-13
+    # eigenvector accuracy ~ eps * |A| / gap; the smallest gap here is 6.6e-7
+    assert (orc.canonical_sign(v) - orc.canonical_sign(h)).abs().max().item() <= 1e-9
+
+
+def test_eigh_rank_deficient_and_dead_feature(ops):
+    n = 96
+    y = _rand((40, n), 9).double()  # rank 40 < n, no damping
+    y[:, 17] = 0.0                  # dead feature: zero row and column
+    a = y.T @ y
+    w, v = ops.eigh(a.to(DEV))
+    w, v = w.cpu(), v.cpu()
+    w_ref = torch.linalg.eigvalsh(a)
+    assert (w - w_ref).abs().max().item() <= 1e-11 * w_ref.max().item()
+    assert (v.T @ v - torch.eye(n, dtype=torch.float64)).abs().max().item() <= 1e-11
+    assert (a @ v - v * w).abs().max().item() <= 1e-10 * w_ref.max().item()
+
+
+def test_eigh_matches_golden_eigenvectors(ops):
+    z = gio.npz("prim")
+    for kind in ("lin", "conv"):
+        e = gio.t(z[f"{kind}.dwain.f64.E"]).clone()
+        e = e + torch.eye(32, dtype=torch.float64) * (orc.DAMP_FACTOR * torch.diag(e).mean())
+        _, v = ops.eigh(e.to(DEV))
+        u_ref = gio.t(z[f"{kind}.dwain.f64.u"])
+        assert (orc.canonical_sign(v.cpu()) - u_ref).abs().max().item() <= 1e-9
+
+
+def test_eigh_mid_size_against_lapack(ops):
+    n = 1024
+    y = _rand((2048, n), 77).double() * torch.logspace(0, -2, n, dtype=torch.float64)
+    a = y.T @ y / 2048
+    a = a + torch.eye(n, dtype=torch.float64) * (0.01 * torch.diag(a).mean())
+    w, v = _check_eigh(ops, a)
+    # invariant-subspace parity at the ranks dwain would cut (projector difference)
+    _, v_ref = torch.linalg.eigh(a)
+    for r in (512, 256, 64):
+        p = v[:, n - r:] @ v[:, n - r:].T
+        p_ref = v_ref[:, n - r:] @ v_ref[:, n - r:].T
+        assert (p - p_ref).norm().item() <= 1e-6 * math.sqrt(r)
+
+
+# ---------------------------------------------------------------- dense products
+LAYOUTS = ["nn", "nt", "tn", "tt"]
+
+
+def _operands(M, N, K, layout, dtype, seed):
+    a = _rand((M, K) if layout[0] == "n" else (K, M), seed, dtype, 0.5)
+    b = _rand((K, N) if layout[1] == "n" else (N, K), seed + 1, dtype, 0.5)
+    return a, b
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 1, 1), (5, 7, 3), (64, 32, 64), (130, 257, 33), (256, 128, 512),
+                                   (1000, 10, 512), (72, 128, 8), (300, 300, 1)])
+@pytest.mark.parametrize("layout", LAYOUTS)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm(ops, M, N, K, layout, dtype):
+    a, b = _operands(M, N, K, layout, dtype, M * 7 + N * 3 + K)
+    bias = _rand((N,), 4, dtype)
+    ad, bd = a.to(DEV), b.to(DEV)
+    av = ad if layout[0] == "n" else ad.T
+    bv = bd if layout[1] == "n" else bd.T
+    got = ops.matmul(av, bv, bias=bias.to(DEV), alpha=0.75).cpu().double()
+    ar = a.double() if layout[0] == "n" else a.double().T
+    br = b.double() if layout[1] == "n" else b.double().T
+    ref = 0.75 * (ar @ br) + bias.double()
+    if dtype == torch.float32:
+        tol = 1e-5 * max(1.0, ref.abs().max().item())
+    else:
+        tol = 1.2e-2 * max(1.0, ref.abs().max().item())  # bf16 output rounding
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max().item() <= tol
+
+
+def test_gemm_bf16_f32_out_is_exact_products(ops):
+    """Integer-valued bf16 operands: the f32-accumulated product must be exact (catches
+    any operand-layout mix-up in the transposing LDS reads)."""
+    g = torch.Generator().manual_seed(1)
+    for layout in LAYOUTS:
+        M, N, K = 160, 96, 200
+        a = torch.randint(-4, 5, (M, K) if layout[0] == "n" else (K, M), generator=g).to(torch.bfloat16)
+        b = torch.randint(-4, 5, (K, N) if layout[1] == "n" else (N, K), generator=g).to(torch.bfloat16)
+        av = a.to(DEV) if layout[0] == "n" else a.to(DEV).T
+        bv = b.to(DEV) if layout[1] == "n" else b.to(DEV).T
+        got = ops.matmul(av, bv, out_dtype=torch.float32).cpu()
+        ar = a.float() if layout[0] == "n" else a.float().T
+        br = b.float() if layout[1] == "n" else b.float().T
+        assert torch.equal(got, ar @ br), layout
+
+
+def test_gemm_f32_exact_integers(ops):
+    g = torch.Generator().manual_seed(2)
+    for layout in LAYOUTS:
+        M, N, K = 131, 77, 100
+        a = torch.randint(-8, 9, (M, K) if layout[0] == "n" else (K, M), generator=g).float()
+        b = torch.randint(-8, 9, (K, N) if layout[1] == "n" else (N, K), generator=g).float()
+        av = a.to(DEV) if layout[0] == "n" else a.to(DEV).T
+        bv = b.to(DEV) if layout[1] == "n" else b.to(DEV).T
+        got = ops.matmul(av, bv).cpu()
+        ar = a if layout[0] == "n" else a.T
+        br = b if layout[1] == "n" else b.T
+        assert torch.equal(got, ar @ br), layout
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("T,ni,r,no", [(72, 64, 8, 32), (500, 256, 96, 320), (1, 10, 3, 7)])
+def test_lowrank_forward(ops, dtype, T, ni, r, no):
+    x = _rand((T, ni), 1, dtype)
+    a = _rand((r, ni), 2, dtype, ni ** -0.5)
+    b = _rand((no, r), 3, dtype, r ** -0.5)
+    bias = _rand((no,), 4, dtype)
+    got = ops.lowrank_forward(x.to(DEV), a.to(DEV), b.to(DEV), bias.to(DEV)).cpu().double()
+    h = x.double() @ a.double().T
+    if dtype == torch.bfloat16:
+        h = h.to(torch.bfloat16).double()  # the intermediate is stored in the operand dtype
+    ref = h @ b.double().T + bias.double()
+    tol = (1e-5 if dtype == torch.float32 else 1.5e-2) * max(1.0, ref.abs().max().item())
+    assert (got - ref).abs().max().item() <= tol
+
+
+# ---------------------------------------------------------------- metrics
+def test_nsr_golden(ops):
+    z = gio.npz("metrics")
+    for name, chan in (("nsr2d", 10), ("nsr2d_01", 1), ("nsr3d", 10)):
+        x, y = gio.t(z[f"{name}.x"]), gio.t(z[f"{name}.y"])
+        got = ops.nsr(x.to(DEV), y.to(DEV), chan).item()
+        assert got == pytest.approx(float(z[f"{name}.out"]), rel=2e-6)
+
+
+@pytest.mark.parametrize("shape,chan", [((4096, 4096), 4096), ((4096, 4096), 1), ((7, 300), 300), ((5, 10), 10),
+                                        ((33, 1000), 1000), ((2, 3, 50), 50)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_nsr_random(ops, shape, chan, dtype):
+    y = (_rand(shape, 1) * 2 + 0.3).to(dtype)
+    x = (y.float() + 0.1 * _rand(shape, 2)).to(dtype)
+    dims = tuple(range(len(shape) - 1)) if chan != 1 else tuple(range(len(shape)))
+    ref = orc.nsr(x=x.double(), y=y.double(), non_channel_dim=dims).item()
+    got = ops.nsr(x.to(DEV), y.to(DEV), chan).item()
+    assert got == pytest.approx(ref, rel=1e-9)
+
+
+def test_sym_kl_golden(ops):
+    z = gio.npz("metrics")
+    s, t = gio.t(z["kl.s"]), gio.t(z["kl.t"])
+    assert ops.sym_kl(s.to(DEV), t.to(DEV)).item() == pytest.approx(float(z["kl.loss"]), rel=2e-6)
+
+
+@pytest.mark.parametrize("B,C", [(1, 2), (5, 10), (64, 1000), (300, 4097)])
+def test_sym_kl_random(ops, B, C):
+    s = _rand((B, C), 1) * 3
+    t = s + 0.5 * _rand((B, C), 2)
+    ref = orc.kl_loss(s.double(), t.double()).item()
+    assert ops.sym_kl(s.to(DEV), t.to(DEV)).item() == pytest.approx(ref, rel=1e-9)
+    # identical logits: exactly zero divergence
+    assert abs(ops.sym_kl(s.to(DEV), s.to(DEV).clone()).item()) <= 1e-15
