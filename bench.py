@@ -1,0 +1,296 @@
+#!/usr/bin/env python3
+"""Headline benchmark: dwain layers decomposed per second on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+N = 1 workload (BASELINE.json configs[1], SURVEY.md 8d "C2"): dwain.decompose_in_place of one
+nn.Linear(4096, 4096, bias=False), f32 model, f64 decomposition, B=4 x S=1024 tokens per batch,
+D = 4 calibration steps, M = 2 metric steps, 7 candidate ranks (2048 .. 32), CE loss over the
+4096 outputs, identity finetune_fn.  One "step" = one full decompose_in_place call on a fresh
+copy of the layer, every input already resident in HBM.  N > 1: a chain of N such layers, one
+process per GPU (torchrun), calibration steps / eigendecompositions / candidate ranks dealt
+round-robin to the ranks, covariance sums all-reduced over RCCL (weak scaling: one layer per GPU).
+
+Prints ONE JSON line (rank 0) with the driver's contract fields plus
+  roofline       the eigensolver (dominant cost) against the f64 MFMA peak, algorithmic flops
+                 4/3 n^3 + 2 n^2 k per matrix, HIP-event timed in this process
+  kernels        per-kernel device time / executed-flop rates (Jacobi gram / inner / update,
+                 covariance SYRK, layer-output GEMM, NSR) from HIP events
+  cpu_baseline   the CPU oracle (restatement of the reference, torch-CPU/MKL) on the same
+                 workload on this box's host cores, rank 0, N = 1 only
+  decomposed_fwd rank-r two-GEMM forward vs dense 4096x4096, bf16 (BASELINE configs[4])
+"""
+
+from __future__ import annotations
+
+import argparse
+import copy
+import itertools
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_FEAT = 4096
+BATCH, SEQ = 4, 1024
+D_STEPS, M_STEPS = 4, 2
+PEAK_F64_MFMA = 78.6e12   # MI355X dense f64 matrix peak
+PEAK_F32_MFMA = 157.3e12  # /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_BF16_MFMA = 2.5e15
+PEAK_HBM = 8.0e12
+
+
+class LinearChain(torch.nn.Module):
+    def __init__(self, n_layers: int):
+        super().__init__()
+        self.layers = torch.nn.ModuleList(torch.nn.Linear(N_FEAT, N_FEAT, bias=False) for _ in range(n_layers))
+
+    def forward(self, d):
+        x = d["x"]
+        for lin in self.layers:
+            x = lin(x)
+        return x
+
+
+def ce_loss(batch, logits):
+    return torch.nn.functional.cross_entropy(logits.reshape(-1, logits.shape[-1]), batch["targets"].reshape(-1),
+                                             reduction="none")
+
+
+def make_workload(n_layers: int, device, n_data: int, n_metric: int):
+    """Seeded synthetic weights and batches: W ~ N(0, 1/4096) seed 1234,
+    x ~ N(0,1) * logspace(0,-2) feature scale, data seed 1, metric seed 2, targets = argmax of the
+    original model's logits."""
+    g = torch.Generator().manual_seed(1234)
+    model = LinearChain(n_layers)
+    with torch.no_grad():
+        for lin in model.layers:
+            lin.weight.copy_(torch.randn(N_FEAT, N_FEAT, generator=g) / N_FEAT**0.5)
+    scale = torch.logspace(0, -2, N_FEAT)
+
+    def batches(seed, count):
+        gg = torch.Generator().manual_seed(seed)
+        return [torch.randn(BATCH, SEQ, N_FEAT, generator=gg) * scale for _ in range(count)]
+
+    data, metric = batches(1, n_data), batches(2, n_metric)
+    return model, data, metric
+
+
+def with_targets(model, xs, device):
+    out = []
+    with torch.no_grad():
+        for x in xs:
+            x = x.to(device)
+            out.append({"x": x, "targets": model({"x": x}).argmax(dim=-1)})
+    return out
+
+
+DWAIN_KW = dict(num_data_steps=D_STEPS, num_metric_steps=M_STEPS, nsr_final_threshold=1.0, min_rank=32,
+                trade_off_factor=0.5, reduction_factor=0.5, max_accepted_ppl_diff=0.1, decompose_in_float64=True)
+
+
+def time_events(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+
+def kernel_lines(device):
+    """Device time of the path's individual kernels at the C2 shapes (HIP events on the launch stream)."""
+    from ptdeco_amd import ops
+
+    t_tok = BATCH * SEQ
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(t_tok, N_FEAT, generator=g).to(device)
+    w = (torch.randn(N_FEAT, N_FEAT, generator=g) / 64).to(device)
+    y = ops.matmul(x, w.T)
+    e = torch.zeros(N_FEAT, N_FEAT, dtype=torch.float64, device=device)
+    lines = {}
+    t = time_events(lambda: ops.syrk_accumulate(e, y, 1.0 / t_tok))
+    fl = t_tok * N_FEAT * (N_FEAT + 1)
+    lines["syrk_f32_f64acc"] = {"ms": t * 1e3, "algorithmic_flops": fl, "tflops": fl / t / 1e12,
+                                "frac_of_f32_mfma_peak": fl / t / PEAK_F32_MFMA}
+    t = time_events(lambda: ops.matmul(x, w.T))
+    fl = 2 * t_tok * N_FEAT * N_FEAT
+    lines["gemm_f32_nt"] = {"ms": t * 1e3, "algorithmic_flops": fl, "tflops": fl / t / 1e12,
+                            "frac_of_f32_mfma_peak": fl / t / PEAK_F32_MFMA}
+    yb, xb, wb = y.bfloat16(), x.bfloat16(), w.bfloat16()
+    t = time_events(lambda: ops.syrk_accumulate(e, yb, 1.0 / t_tok))
+    fl = t_tok * N_FEAT * (N_FEAT + 1)
+    lines["syrk_bf16_f64acc"] = {"ms": t * 1e3, "algorithmic_flops": fl, "tflops": fl / t / 1e12,
+                                 "frac_of_bf16_mfma_peak": fl / t / PEAK_BF16_MFMA}
+    t = time_events(lambda: ops.matmul(xb, wb.T))
+    fl = 2 * t_tok * N_FEAT * N_FEAT
+    lines["gemm_bf16_nt"] = {"ms": t * 1e3, "algorithmic_flops": fl, "tflops": fl / t / 1e12,
+                             "frac_of_bf16_mfma_peak": fl / t / PEAK_BF16_MFMA}
+    y2 = y + 0.01
+    t = time_events(lambda: ops.nsr(y2.view(BATCH, SEQ, N_FEAT), y.view(BATCH, SEQ, N_FEAT), N_FEAT))
+    by = 2 * y.numel() * 4
+    lines["nsr_f32"] = {"ms": t * 1e3, "algorithmic_bytes": by, "gbps": by / t / 1e9, "frac_of_hbm_peak": by / t / PEAK_HBM}
+    return lines
+
+
+def decomposed_forward_lines(device):
+    """BASELINE configs[4]: rank-r two-GEMM forward vs dense 4096x4096, bf16, T = 16384 rows."""
+    from ptdeco_amd import ops
+
+    t_rows = 16384
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(t_rows, N_FEAT, generator=g).bfloat16().to(device)
+    w = (torch.randn(N_FEAT, N_FEAT, generator=g) / 64).bfloat16().to(device)
+    dense_t = time_events(lambda: ops.matmul(x, w.T), iters=10)
+    out = {"rows": t_rows, "dense_ms": dense_t * 1e3, "dense_tflops": 2 * t_rows * N_FEAT * N_FEAT / dense_t / 1e12}
+    for r in (256, 512, 1024):
+        a = (torch.randn(r, N_FEAT, generator=g) / 64).bfloat16().to(device)
+        b = (torch.randn(N_FEAT, r, generator=g) / r**0.5).bfloat16().to(device)
+        t = time_events(lambda: ops.lowrank_forward(x, a, b, None), iters=10)
+        fl = 2 * t_rows * r * 2 * N_FEAT
+        by = 2 * (2 * t_rows * N_FEAT + 2 * r * N_FEAT)
+        out[f"r{r}"] = {"ms": t * 1e3, "gflops": fl / t / 1e9, "speedup_vs_dense": dense_t / t,
+                        "frac_of_bf16_mfma_peak": fl / t / PEAK_BF16_MFMA, "hbm_gbps_algorithmic": by / t / 1e9}
+    return out
+
+
+def cpu_baseline():
+    """The CPU oracle on the same C2 workload (1 layer), host cores of this box."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ptdeco_oracle as orc
+
+    cores = torch.get_num_threads()
+    model, data, metric = make_workload(1, "cpu", D_STEPS, 7 * M_STEPS)
+    cpu = torch.device("cpu")
+    data, metric = with_targets(model, data, cpu), with_targets(model, metric, cpu)
+    t0 = time.perf_counter()
+    cfg = orc.dwain_decompose(module=model, data_iterator=itertools.cycle(data), loss_fn=ce_loss,
+                              metric_iterator=itertools.cycle(metric), finetune_fn=None, **DWAIN_KW)
+    dt = time.perf_counter() - t0
+    prop = cfg["layers.0"]["__meta__"]["proportion"] if cfg else 1.0
+    return {"value": 1.0 / dt, "unit": "layers/s", "cores": cores, "kind": "port",
+            "sample": f"1 layer = the full N=1 workload once ({dt:.1f} s); chosen proportion {prop}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip kernel / forward / cpu side measurements")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    import ptdeco_amd
+    from ptdeco_amd import ops
+
+    n_layers = world
+    model0, data, metric = make_workload(n_layers, device, D_STEPS, 7 * M_STEPS)
+    model0.to(device)
+    data, metric = with_targets(model0, data, device), with_targets(model0, metric, device)
+
+    def one_step():
+        model = copy.deepcopy(model0)
+        return ptdeco_amd.dwain.decompose_in_place(
+            module=model, device=device, data_iterator=itertools.cycle(data), loss_fn=ce_loss,
+            metric_iterator=itertools.cycle(metric), finetune_fn=lambda m, d, names: m,
+            precomputing_covariance_num_splits=(1 if world > 1 else None), **DWAIN_KW)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        cfg = one_step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        cfg = one_step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    result = {
+        "metric": "layers decomposed/sec (incl. covariance+SVD)",
+        "value": n_layers * args.steps / dt,
+        "unit": "layers/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": "dwain decompose_in_place, chain of %d x nn.Linear(4096,4096) f32, T=4x1024 tokens/batch, "
+                               "D=4, M=2, 7 candidate ranks, f64 covariance+eigh" % n_layers,
+                   "layers_per_step": n_layers, "parallelism": f"dp{world}" if world > 1 else "single",
+                   "ranks_kept": {k: v["__meta__"]["proportion"] for k, v in cfg.items()}},
+    }
+
+    if rank == 0 and not args.no_extras:
+        # one extra, untimed, profiled step: per-phase HIP-event timings of the eigensolver
+        ops.EIGH_PROFILE = []
+        one_step()
+        torch.cuda.synchronize()
+        prof, ops.EIGH_PROFILE = ops.EIGH_PROFILE, None
+        if prof:
+            p = prof[0]
+            n = p["n"]
+            k = n // 2  # dwain needs the top floor(n * reduction_factor) vectors
+            algo = 4.0 / 3.0 * n**3 + 2.0 * n * n * k
+            t = p["total_ms"] * 1e-3
+            result["roofline"] = {"bound": "mfma", "achieved": algo / t / 1e12, "peak": PEAK_F64_MFMA / 1e12,
+                                  "unit": "TFLOP/s", "frac": algo / t / PEAK_F64_MFMA, "traffic": None,
+                                  "kernel": "ptd_eigh (one-sided block Jacobi: jac_gram + jac_inner + jac_update)",
+                                  "n": n, "sweeps": p["sweeps"], "ms": p["total_ms"],
+                                  "algorithmic_flops": algo}
+            names = ("jac_gram_kernel", "jac_inner_kernel", "jac_update_kernel")
+            kl = {}
+            for i, nm in enumerate(names):
+                ms, cnt, fl = p["ms"][i], p["launches"][i], p["flops"][i]
+                kl[nm] = {"launches": cnt, "avg_us": ms / max(cnt, 1) * 1e3, "total_ms": ms}
+                if fl:
+                    kl[nm]["executed_tflops"] = fl / (ms * 1e-3) / 1e12
+                    kl[nm]["frac_of_f64_mfma_peak"] = fl / (ms * 1e-3) / PEAK_F64_MFMA
+            result["kernels"] = kl
+        result["kernels"] = {**result.get("kernels", {}), **kernel_lines(device)}
+        result["decomposed_fwd"] = decomposed_forward_lines(device)
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline()
+
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

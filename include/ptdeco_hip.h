@@ -80,6 +80,19 @@ size_t ptd_eigh_workspace_bytes(int64_t n);
 int ptd_eigh(const double* A, int64_t lda, int64_t n, double* evals, double* evecs, int64_t ldv,
              void* ws, size_t ws_bytes, int* sweeps_out, void* stream);
 
+/* Same, with per-phase device timing (HIP events on `stream` around every launch of the
+ * three Jacobi kernels; a few percent slower, for bench.py's roofline lines).
+ * `stats` is a HOST pointer. */
+typedef struct {
+  int sweeps;
+  int launches[3];   /* gram, inner, update */
+  float ms[3];       /* summed device time of those launches */
+  float total_ms;    /* first launch to last launch of the call */
+  double flops[3];   /* f64 flops executed by gram / update launches (inner: 0) */
+} ptd_eigh_stats;
+int ptd_eigh_profiled(const double* A, int64_t lda, int64_t n, double* evals, double* evecs, int64_t ldv,
+                      void* ws, size_t ws_bytes, ptd_eigh_stats* stats, void* stream);
+
 /* ---- dense products (layer output, factor construction) ----------------- */
 
 /* C[M,N] = alpha * sum_k A(m,k) * B(k,n) (+ bias[n]),  f32 or bf16 operands,

@@ -30,6 +30,8 @@ SIGNATURES = {
     "ptd_eigh_workspace_bytes": (c_size_t, [c_int64]),
     "ptd_eigh": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_size_t,
                          ctypes.POINTER(c_int), c_void_p]),
+    "ptd_eigh_profiled": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_size_t,
+                                  c_void_p, c_void_p]),
     "ptd_gemm": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
                          c_int64, c_int64, c_int, c_int, c_double, c_void_p, c_void_p]),
     "ptd_lowrank_forward": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p,
@@ -40,6 +42,12 @@ SIGNATURES = {
     "ptd_sym_kl_workspace_bytes": (c_size_t, [c_int64]),
     "ptd_sym_kl": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
 }
+
+
+class EighStats(ctypes.Structure):
+    """ptd_eigh_stats of include/ptdeco_hip.h."""
+    _fields_ = [("sweeps", c_int), ("launches", c_int * 3), ("ms", ctypes.c_float * 3),
+                ("total_ms", ctypes.c_float), ("flops", c_double * 3)]
 
 
 class HipLibraryError(RuntimeError):

@@ -59,7 +59,14 @@ size_t ptd_eigh_workspace_bytes(int64_t n) { return eigh_workspace_bytes(n); }
 
 int ptd_eigh(const double* A, int64_t lda, int64_t n, double* evals, double* evecs, int64_t ldv, void* ws,
              size_t ws_bytes, int* sweeps_out, void* stream) {
-  return eigh_jacobi(A, lda, n, evals, evecs, ldv, ws, ws_bytes, sweeps_out, static_cast<hipStream_t>(stream));
+  return eigh_jacobi(A, lda, n, evals, evecs, ldv, ws, ws_bytes, sweeps_out, nullptr,
+                     static_cast<hipStream_t>(stream));
+}
+
+int ptd_eigh_profiled(const double* A, int64_t lda, int64_t n, double* evals, double* evecs, int64_t ldv, void* ws,
+                      size_t ws_bytes, ptd_eigh_stats* stats, void* stream) {
+  PTD_REQUIRE(stats, "ptd_eigh_profiled: stats must not be null");
+  return eigh_jacobi(A, lda, n, evals, evecs, ldv, ws, ws_bytes, nullptr, stats, static_cast<hipStream_t>(stream));
 }
 
 int ptd_gemm(const void* A, int64_t sam, int64_t sak, const void* B, int64_t sbk, int64_t sbn, void* C, int64_t ldc,

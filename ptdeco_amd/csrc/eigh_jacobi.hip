@@ -24,10 +24,15 @@
 // Infinity Cache between the three kernels of a round.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
 
 #include "common.h"
 
 namespace ptd {
+
+int cholesky_f64(double* L, int np, double* linv_ws, int* fail, hipStream_t st);  // chol.hip
 
 namespace {
 
@@ -56,13 +61,43 @@ __device__ __forceinline__ int pair_row(int blkI, int blkJ, int r) {
 }
 
 // ---------------------------------------------------------------------------
-__global__ void jac_init_kernel(const double* __restrict__ A, int64_t lda, int n, double* __restrict__ G,
-                                int np) {
+// setup: symmetric permutation by descending diagonal (largest rows first, de Rijk), the
+// padded working copy, and G0 = L^T after the Cholesky factorisation.
+__global__ void jac_perm_kernel(const double* __restrict__ A, int64_t lda, int n, int* __restrict__ perm) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double vi = A[(int64_t)i * lda + i];
+  int rank = 0;
+  for (int j = 0; j < n; ++j) {
+    const double vj = A[(int64_t)j * lda + j];
+    rank += (vj > vi) || (vj == vi && j < i);
+  }
+  perm[rank] = i;  // position `rank` of the permuted matrix holds original index i
+}
+
+// B[i][j] = A[perm[i]][perm[j]] for i, j < n; identity on the padding
+__global__ void jac_gather_kernel(const double* __restrict__ A, int64_t lda, int n, const int* __restrict__ perm,
+                                  double* __restrict__ B, int np) {
   const int64_t total = (int64_t)np * np;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
        e += (int64_t)gridDim.x * blockDim.x) {
     const int i = (int)(e / np), j = (int)(e % np);
-    G[e] = (i < n && j < n) ? A[(int64_t)i * lda + j] : 0.0;
+    B[e] = (i < n && j < n) ? A[(int64_t)perm[i] * lda + perm[j]] : (i == j ? 1.0 : 0.0);
+  }
+}
+
+// G = L^T (upper triangular): G[r][c] = c >= r ? L[c][r] : 0
+__global__ void jac_transpose_kernel(const double* __restrict__ L, double* __restrict__ G, int np) {
+  __shared__ double tile[32][33];
+  const int bx = blockIdx.x, by = blockIdx.y;  // output tile: rows by*32.., cols bx*32..
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  if (bx >= by) {
+    for (int rr = ty; rr < 32; rr += 8) tile[rr][tx] = L[(int64_t)(bx * 32 + rr) * np + by * 32 + tx];
+  }
+  __syncthreads();
+  for (int rr = ty; rr < 32; rr += 8) {
+    const int r = by * 32 + rr, c = bx * 32 + tx;
+    G[(int64_t)r * np + c] = (bx >= by && c >= r) ? tile[tx][rr] : 0.0;
   }
 }
 
@@ -150,8 +185,9 @@ __device__ __forceinline__ void atomic_max_pos_double(double* addr, double v) {
 }
 
 __global__ __launch_bounds__(IN_T) void jac_inner_kernel(const double* __restrict__ Spart, int nsplit, double tol,
-                                                         int max_inner_sweeps, double* __restrict__ Qout,
-                                                         int* __restrict__ skip, double* __restrict__ conv) {
+                                                         int max_inner_sweeps, int cross_only,
+                                                         double* __restrict__ Qout, int* __restrict__ skip,
+                                                         double* __restrict__ conv) {
   __shared__ double S[JP * SP];
   __shared__ double Q[JP * SP];
   __shared__ double rc[JB], rs[JB];
@@ -206,10 +242,19 @@ __global__ __launch_bounds__(IN_T) void jac_inner_kernel(const double* __restric
   for (int sweep = 0; sweep < max_inner_sweeps; ++sweep) {
     if (tid == 0) rotated = 0;
     __syncthreads();
-    for (int round = 0; round < JP - 1; ++round) {
+    // cross_only: the two 32-row blocks are each internally orthogonal already (they were fully
+    // treated at round 0 of this outer sweep), so only the 32 x 32 cross pairs are rotated:
+    // 32 rounds of pairs (k, 32 + (k + round) % 32) instead of the 63-round tournament.
+    const int nrounds = cross_only ? JB : JP - 1;
+    for (int round = 0; round < nrounds; ++round) {
       if (tid < JB) {
         int p, q;
-        rr_pair(JP, round, tid, p, q);
+        if (cross_only) {
+          p = tid;
+          q = JB + ((tid + round) & (JB - 1));
+        } else {
+          rr_pair(JP, round, tid, p, q);
+        }
         const double app = S[p * SP + p], aqq = S[q * SP + q], apq = S[p * SP + q];
         double c = 1.0, s = 0.0;
         if (fabs(apq) > tol * sqrt(fabs(app * aqq)) && apq != 0.0) {
@@ -336,7 +381,8 @@ __global__ __launch_bounds__(256) void jac_update_kernel(double* __restrict__ G,
 
 // ---------------------------------------------------------------------------
 // post-processing: eigenvalue = row norm, ascending order, eigenvectors to columns
-__global__ void jac_norm_kernel(const double* __restrict__ G, int np, int n, double* __restrict__ norms) {
+__global__ void jac_norm_kernel(const double* __restrict__ G, int np, int n, double* __restrict__ norms,
+                                double* __restrict__ lambdas, int squared) {
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= n) return;
   const int lane = threadIdx.x & 63;
@@ -346,11 +392,14 @@ __global__ void jac_norm_kernel(const double* __restrict__ G, int np, int n, dou
     s += v * v;
   }
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-  if (lane == 0) norms[row] = sqrt(s);
+  if (lane == 0) {
+    norms[row] = sqrt(s);
+    lambdas[row] = squared ? s : sqrt(s);  // rows of L^T carry sqrt(lambda), rows of A carry lambda
+  }
 }
 
-__global__ void jac_rank_kernel(const double* __restrict__ norms, int n, int* __restrict__ inv,
-                                double* __restrict__ evals) {
+__global__ void jac_rank_kernel(const double* __restrict__ norms, const double* __restrict__ lambdas, int n,
+                                int* __restrict__ inv, double* __restrict__ evals) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const double vi = norms[i];
@@ -360,12 +409,13 @@ __global__ void jac_rank_kernel(const double* __restrict__ norms, int n, int* __
     rank += (vj < vi) || (vj == vi && j < i);
   }
   inv[rank] = i;
-  evals[rank] = vi;
+  evals[rank] = lambdas[i];
 }
 
-// evecs[c][k] = G[inv[k]][c] / norm(inv[k]); 32 x 32 tiles through LDS
+// evecs[perm[c]][k] = G[inv[k]][c] / norm(inv[k]); 32 x 32 tiles through LDS
 __global__ void jac_scatter_kernel(const double* __restrict__ G, int np, int n, const int* __restrict__ inv,
-                                   const double* __restrict__ norms, double* __restrict__ evecs, int64_t ldv) {
+                                   const double* __restrict__ norms, const int* __restrict__ perm,
+                                   double* __restrict__ evecs, int64_t ldv) {
   __shared__ double tile[32][33];
   const int k0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: ty 0..7
@@ -382,13 +432,13 @@ __global__ void jac_scatter_kernel(const double* __restrict__ G, int np, int n, 
   __syncthreads();
   for (int cc = ty; cc < 32; cc += 8) {
     const int c = c0 + cc, k = k0 + tx;
-    if (c < n && k < n) evecs[(int64_t)c * ldv + k] = tile[tx][cc];
+    if (c < n && k < n) evecs[(int64_t)perm[c] * ldv + k] = tile[tx][cc];
   }
 }
 
 struct JacobiPlan {
   int np, nb, pairs, ksplit, kcols, chunks, tiles_per_wg;
-  size_t off_G, off_S, off_Q, off_skip, off_conv, off_norms, off_inv, total;
+  size_t off_G, off_L, off_S, off_Q, off_skip, off_conv, off_norms, off_lam, off_inv, off_perm, off_linv, total;
 };
 
 JacobiPlan make_plan(int64_t n) {
@@ -411,12 +461,16 @@ JacobiPlan make_plan(int64_t n) {
   p.chunks = (int)ceil_div(tiles, p.tiles_per_wg);
   size_t o = 0;
   p.off_G = o; o += align_up((size_t)p.np * p.np * 8, 256);
+  p.off_L = o; o += align_up((size_t)p.np * p.np * 8, 256);
   p.off_S = o; o += align_up((size_t)p.pairs * p.ksplit * JP * JP * 8, 256);
   p.off_Q = o; o += align_up((size_t)p.pairs * JP * JP * 8, 256);
   p.off_skip = o; o += align_up((size_t)p.pairs * 4, 256);
-  p.off_conv = o; o += 256;
+  p.off_conv = o; o += 256;  // [0] convergence measure (f64), [8] cholesky failure flag (int)
   p.off_norms = o; o += align_up((size_t)p.np * 8, 256);
+  p.off_lam = o; o += align_up((size_t)p.np * 8, 256);
   p.off_inv = o; o += align_up((size_t)p.np * 4, 256);
+  p.off_perm = o; o += align_up((size_t)p.np * 4, 256);
+  p.off_linv = o; o += 64 * 64 * 8;
   p.total = o;
   return p;
 }
@@ -426,7 +480,7 @@ JacobiPlan make_plan(int64_t n) {
 size_t eigh_workspace_bytes(int64_t n) { return make_plan(n).total; }
 
 int eigh_jacobi(const double* A, int64_t lda, int64_t n, double* evals, double* evecs, int64_t ldv, void* ws,
-                size_t ws_bytes, int* sweeps_out, hipStream_t st) {
+                size_t ws_bytes, int* sweeps_out, ptd_eigh_stats* stats, hipStream_t st) {
   PTD_REQUIRE(n >= 1 && n <= 32768, "ptd_eigh: n=%lld out of range [1, 32768]", (long long)n);
   PTD_REQUIRE(lda >= n && ldv >= n, "ptd_eigh: leading dimension smaller than n");
   PTD_REQUIRE(A && evals && evecs && ws, "ptd_eigh: null pointer");
@@ -447,36 +501,113 @@ int eigh_jacobi(const double* A, int64_t lda, int64_t n, double* evals, double* 
 
   const double tol = 2.0 * std::sqrt((double)p.np) * 2.220446049250313e-16;
   const int max_sweeps = 40;
+  // A sweep whose largest scaled off-diagonal entry (measured before its rotations) is below
+  // `quad` leaves entries of order quad^2 / relative gap behind (quadratic convergence of the
+  // cyclic Jacobi method): far below the rounding noise of the f64 inner products themselves
+  // (~ sqrt(n) eps), so no further "verification" sweep is run.
+  const double quad = 1e-9;
+  static const int inner_sweeps = getenv("PTD_JACOBI_INNER_SWEEPS") ? atoi(getenv("PTD_JACOBI_INNER_SWEEPS")) : 1;
+  static const bool debug = getenv("PTD_JACOBI_DEBUG") != nullptr;
+  static const bool cross_only = getenv("PTD_JACOBI_FULL_INNER") == nullptr;
 
-  hipLaunchKernelGGL(jac_init_kernel, dim3(2048), dim3(256), 0, st, A, lda, (int)n, G, p.np);
-  PTD_CHECK_LAUNCH("jac_init");
+  // optional per-phase timing: one event pair per launch, read back at the sweep's sync
+  std::vector<hipEvent_t> ev;
+  hipEvent_t ev_first = nullptr, ev_last = nullptr;
+  if (stats) {
+    memset(stats, 0, sizeof(*stats));
+    ev.resize((size_t)4 * (p.nb - 1));
+    for (auto& e : ev) PTD_CHECK_HIP(hipEventCreate(&e));
+    PTD_CHECK_HIP(hipEventCreate(&ev_first));
+    PTD_CHECK_HIP(hipEventCreate(&ev_last));
+    PTD_CHECK_HIP(hipEventRecord(ev_first, st));
+  }
+  auto mark = [&](int r, int k) {
+    if (stats) (void)hipEventRecord(ev[(size_t)4 * r + k], st);
+  };
+
+  double* Lb = reinterpret_cast<double*>(base + p.off_L);
+  double* lambdas = reinterpret_cast<double*>(base + p.off_lam);
+  int* perm = reinterpret_cast<int*>(base + p.off_perm);
+  double* linv = reinterpret_cast<double*>(base + p.off_linv);
+  int* fail = reinterpret_cast<int*>(base + p.off_conv + 8);
+  static const bool no_chol = getenv("PTD_JACOBI_NO_CHOLESKY") != nullptr;
+
+  // G0: Cholesky-preconditioned start (L^T of the diagonally sorted matrix), or the sorted
+  // matrix itself when it is not numerically positive definite
+  PTD_CHECK_HIP(hipMemsetAsync(conv, 0, 16, st));
+  hipLaunchKernelGGL(jac_perm_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, A, lda, (int)n, perm);
+  bool use_chol = !no_chol;
+  if (use_chol) {
+    hipLaunchKernelGGL(jac_gather_kernel, dim3(2048), dim3(256), 0, st, A, lda, (int)n, perm, Lb, p.np);
+    PTD_CHECK_LAUNCH("jac_gather");
+    int rc = cholesky_f64(Lb, p.np, linv, fail, st);
+    if (rc != PTD_OK) return rc;
+    int h_fail = 0;
+    PTD_CHECK_HIP(hipMemcpyAsync(&h_fail, fail, 4, hipMemcpyDeviceToHost, st));
+    PTD_CHECK_HIP(hipStreamSynchronize(st));
+    use_chol = (h_fail == 0);
+    if (debug) fprintf(stderr, "[ptd_eigh] n=%lld cholesky %s\n", (long long)n, use_chol ? "ok" : "failed -> plain start");
+  }
+  if (use_chol) {
+    hipLaunchKernelGGL(jac_transpose_kernel, dim3(p.np / 32, p.np / 32), dim3(256), 0, st, Lb, G, p.np);
+  } else {
+    hipLaunchKernelGGL(jac_gather_kernel, dim3(2048), dim3(256), 0, st, A, lda, (int)n, perm, G, p.np);
+  }
+  PTD_CHECK_LAUNCH("jac_setup");
 
   int sweeps = 0;
   bool converged = false;
   for (; sweeps < max_sweeps && !converged;) {
     PTD_CHECK_HIP(hipMemsetAsync(conv, 0, 8, st));
     for (int r = 0; r < p.nb - 1; ++r) {
+      mark(r, 0);
       hipLaunchKernelGGL(jac_gram_kernel, dim3(p.ksplit, p.pairs), dim3(256), 0, st, G, p.np, p.nb, r, p.kcols,
                          Sp);
-      hipLaunchKernelGGL(jac_inner_kernel, dim3(p.pairs), dim3(IN_T), 0, st, Sp, p.ksplit, tol, 30, Q, skip,
-                         conv);
+      mark(r, 1);
+      hipLaunchKernelGGL(jac_inner_kernel, dim3(p.pairs), dim3(IN_T), 0, st, Sp, p.ksplit, tol, inner_sweeps,
+                         (cross_only && r > 0) ? 1 : 0, Q, skip, conv);
+      mark(r, 2);
       hipLaunchKernelGGL(jac_update_kernel, dim3(p.chunks, p.pairs), dim3(256), 0, st, G, p.np, p.nb, r,
                          p.tiles_per_wg, Q, skip);
+      mark(r, 3);
     }
     PTD_CHECK_LAUNCH("jacobi sweep");
     double h_conv = 0.0;
     PTD_CHECK_HIP(hipMemcpyAsync(&h_conv, conv, 8, hipMemcpyDeviceToHost, st));
     PTD_CHECK_HIP(hipStreamSynchronize(st));
     ++sweeps;
-    converged = (h_conv <= tol);
+    converged = (h_conv <= quad);
+    if (debug) fprintf(stderr, "[ptd_eigh] n=%lld sweep %d max scaled off-diagonal %.3e\n", (long long)n, sweeps, h_conv);
+    if (stats) {
+      for (int r = 0; r < p.nb - 1; ++r)
+        for (int k = 0; k < 3; ++k) {
+          float ms = 0.f;
+          (void)hipEventElapsedTime(&ms, ev[(size_t)4 * r + k], ev[(size_t)4 * r + k + 1]);
+          stats->ms[k] += ms;
+          stats->launches[k] += 1;
+        }
+      const double pair_flops = 2.0 * JP * JP * (double)p.np;  // one 64 x 64 x np product
+      stats->flops[0] += (double)(p.nb - 1) * p.pairs * pair_flops;
+      stats->flops[2] += (double)(p.nb - 1) * p.pairs * pair_flops;  // upper bound: skipped pairs do none
+    }
+  }
+  if (stats) {
+    stats->sweeps = sweeps;
+    PTD_CHECK_HIP(hipEventRecord(ev_last, st));
+    PTD_CHECK_HIP(hipEventSynchronize(ev_last));
+    (void)hipEventElapsedTime(&stats->total_ms, ev_first, ev_last);
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    (void)hipEventDestroy(ev_first);
+    (void)hipEventDestroy(ev_last);
   }
   if (sweeps_out) *sweeps_out = sweeps;
 
-  hipLaunchKernelGGL(jac_norm_kernel, dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, st, G, p.np, (int)n, norms);
-  hipLaunchKernelGGL(jac_rank_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, norms, (int)n, inv,
-                     evals);
+  hipLaunchKernelGGL(jac_norm_kernel, dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, st, G, p.np, (int)n, norms,
+                     lambdas, use_chol ? 1 : 0);
+  hipLaunchKernelGGL(jac_rank_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, norms, lambdas, (int)n,
+                     inv, evals);
   hipLaunchKernelGGL(jac_scatter_kernel, dim3((unsigned)ceil_div(n, 32), (unsigned)ceil_div(n, 32)), dim3(256), 0,
-                     st, G, p.np, (int)n, inv, norms, evecs, ldv);
+                     st, G, p.np, (int)n, inv, norms, perm, evecs, ldv);
   PTD_CHECK_LAUNCH("jacobi post");
   if (!converged) {
     set_error("ptd_eigh: no convergence after %d sweeps", sweeps);

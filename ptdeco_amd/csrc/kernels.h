@@ -21,7 +21,7 @@ int syrk_bf16(const unsigned short* Y, int64_t T, int64_t n, int64_t ldy, void* 
 // eigh_jacobi.hip
 size_t eigh_workspace_bytes(int64_t n);
 int eigh_jacobi(const double* A, int64_t lda, int64_t n, double* evals, double* evecs, int64_t ldv, void* ws,
-                size_t ws_bytes, int* sweeps_out, hipStream_t st);
+                size_t ws_bytes, int* sweeps_out, ptd_eigh_stats* stats, hipStream_t st);
 
 // reduce.hip
 size_t cov_finalize_workspace_bytes(int64_t n);

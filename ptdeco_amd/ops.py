@@ -89,7 +89,8 @@ def cov_finalize(E: torch.Tensor, steps: int, damp_factor: float, ey: Optional[t
     return C
 
 
-_EIGH_STATS = {"calls": 0, "sweeps": 0}
+# When a list, every eigh call appends a dict of per-phase device timings (bench.py's roofline lines).
+EIGH_PROFILE: Optional[list] = None
 
 
 def eigh(A: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
@@ -101,13 +102,17 @@ def eigh(A: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
     w = torch.empty(n, dtype=torch.float64, device=A.device)
     v = torch.empty((n, n), dtype=torch.float64, device=A.device)
     ws = torch.empty(lib.ptd_eigh_workspace_bytes(n), dtype=torch.uint8, device=A.device)
-    sweeps = ctypes.c_int(0)
     with torch.cuda.device(A.device):
-        rc = lib.ptd_eigh(A.data_ptr(), A.stride(0), n, w.data_ptr(), v.data_ptr(), n, ws.data_ptr(), ws.numel(),
-                          ctypes.byref(sweeps), _stream(A))
+        if EIGH_PROFILE is None:
+            rc = lib.ptd_eigh(A.data_ptr(), A.stride(0), n, w.data_ptr(), v.data_ptr(), n, ws.data_ptr(),
+                              ws.numel(), None, _stream(A))
+        else:
+            st = _hip.EighStats()
+            rc = lib.ptd_eigh_profiled(A.data_ptr(), A.stride(0), n, w.data_ptr(), v.data_ptr(), n, ws.data_ptr(),
+                                       ws.numel(), ctypes.byref(st), _stream(A))
+            EIGH_PROFILE.append({"n": n, "sweeps": st.sweeps, "launches": list(st.launches), "ms": list(st.ms),
+                                 "total_ms": st.total_ms, "flops": list(st.flops)})
     _hip.check(rc, "ptd_eigh")
-    _EIGH_STATS["calls"] += 1
-    _EIGH_STATS["sweeps"] += sweeps.value
     return w, v
 
 
