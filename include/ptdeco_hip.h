@@ -93,13 +93,21 @@ typedef struct {
 int ptd_eigh_profiled(const double* A, int64_t lda, int64_t n, double* evals, double* evecs, int64_t ldv,
                       void* ws, size_t ws_bytes, ptd_eigh_stats* stats, void* stream);
 
+/* Diagnostic: Householder tridiagonalisation T = Q^T A Q of a symmetric f64 matrix (full
+ * storage) and the eigenvalues of T by bisection.  d[n], e[n] (e[n-1] unused), evals[n]
+ * ascending; any of the three may be NULL. */
+size_t ptd_tridiagonalize_workspace_bytes(int64_t n);
+int ptd_tridiagonalize(const double* A, int64_t lda, int64_t n, double* d, double* e, double* evals,
+                       void* ws, size_t ws_bytes, void* stream);
+
 /* ---- dense products (layer output, factor construction) ----------------- */
 
 /* C[M,N] = alpha * sum_k A(m,k) * B(k,n) (+ bias[n]),  f32 or bf16 operands,
  * f32 accumulation on the matrix cores.  Operands are addressed with explicit
  * element strides: A(m,k) = A[m*sam + k*sak], B(k,n) = B[k*sbk + n*sbn]; exactly
  * one stride of each operand must be 1.  C is row-major [M, N] with ld ldc, of
- * dtype c_dtype (f32, or bf16 when the inputs are bf16).
+ * dtype c_dtype (f32, or bf16 when the inputs are bf16; f64 x f64 -> f64 without bias
+ * is also available, it is what the eigensolver uses internally).
  * Replaces `x @ weight.T` (dwain.py:194, 239; falor.py:159), `orig_weight.T @ uk`
  * and `(U @ V).T` (dwain.py:427-429, 511; falor.py:347-348). */
 int ptd_gemm(const void* A, int64_t sam, int64_t sak, const void* B, int64_t sbk, int64_t sbn,

@@ -32,6 +32,9 @@ SIGNATURES = {
                          ctypes.POINTER(c_int), c_void_p]),
     "ptd_eigh_profiled": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_size_t,
                                   c_void_p, c_void_p]),
+    "ptd_tridiagonalize_workspace_bytes": (c_size_t, [c_int64]),
+    "ptd_tridiagonalize": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                   c_void_p]),
     "ptd_gemm": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
                          c_int64, c_int64, c_int, c_int, c_double, c_void_p, c_void_p]),
     "ptd_lowrank_forward": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p,

@@ -1,5 +1,7 @@
 // extern "C" surface of libptdeco_hip.so (declared in include/ptdeco_hip.h).
+#include <algorithm>
 #include <cstdarg>
+#include <cstdlib>
 #include <cstring>
 
 #include "common.h"
@@ -55,18 +57,50 @@ int ptd_cov_finalize(const void* E, int64_t ldE, int E_dtype, const void* ey, in
                       static_cast<hipStream_t>(stream));
 }
 
-size_t ptd_eigh_workspace_bytes(int64_t n) { return eigh_workspace_bytes(n); }
+// Solver choice.  "jacobi": one-sided block Jacobi (any symmetric PSD matrix).  "tridiag":
+// Householder tridiagonalisation + bisection + inverse iteration + back-transformation, used
+// when no two eigenvalues are closer than 1e-8 |A| (otherwise Jacobi takes over).
+static int eigh_method() {
+  static const int m = [] {
+    const char* e = getenv("PTD_EIGH_METHOD");
+    if (!e) return 0;
+    if (!strcmp(e, "tridiag")) return 1;
+    if (!strcmp(e, "auto")) return 2;
+    return 0;
+  }();
+  return m;
+}
+
+size_t ptd_eigh_workspace_bytes(int64_t n) {
+  return std::max(eigh_workspace_bytes(n), tridiag_workspace_bytes(n));
+}
 
 int ptd_eigh(const double* A, int64_t lda, int64_t n, double* evals, double* evecs, int64_t ldv, void* ws,
              size_t ws_bytes, int* sweeps_out, void* stream) {
-  return eigh_jacobi(A, lda, n, evals, evecs, ldv, ws, ws_bytes, sweeps_out, nullptr,
-                     static_cast<hipStream_t>(stream));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int method = eigh_method();
+  if (method != 0 && (method == 1 || n >= 256) && A && evals && evecs && ws && n >= 2 && lda >= n && ldv >= n) {
+    static const double ctol = getenv("PTD_EIGH_CLUSTER_TOL") ? atof(getenv("PTD_EIGH_CLUSTER_TOL")) : 1e-10;
+    const int rc = eigh_tridiag(A, lda, n, evals, evecs, ldv, ws, ws_bytes, ctol, st);
+    if (rc != PTD_ERR_UNSUPPORTED) {
+      if (sweeps_out) *sweeps_out = 0;
+      return rc;
+    }
+  }
+  return eigh_jacobi(A, lda, n, evals, evecs, ldv, ws, ws_bytes, sweeps_out, nullptr, st);
 }
 
 int ptd_eigh_profiled(const double* A, int64_t lda, int64_t n, double* evals, double* evecs, int64_t ldv, void* ws,
                       size_t ws_bytes, ptd_eigh_stats* stats, void* stream) {
   PTD_REQUIRE(stats, "ptd_eigh_profiled: stats must not be null");
   return eigh_jacobi(A, lda, n, evals, evecs, ldv, ws, ws_bytes, nullptr, stats, static_cast<hipStream_t>(stream));
+}
+
+size_t ptd_tridiagonalize_workspace_bytes(int64_t n) { return tridiag_workspace_bytes(n); }
+
+int ptd_tridiagonalize(const double* A, int64_t lda, int64_t n, double* d, double* e, double* evals, void* ws,
+                       size_t ws_bytes, void* stream) {
+  return tridiagonalize_f64(A, lda, n, d, e, evals, ws, ws_bytes, static_cast<hipStream_t>(stream));
 }
 
 int ptd_gemm(const void* A, int64_t sam, int64_t sak, const void* B, int64_t sbk, int64_t sbn, void* C, int64_t ldc,
@@ -83,6 +117,9 @@ int ptd_gemm(const void* A, int64_t sam, int64_t sak, const void* B, int64_t sbk
     return gemm_bf16(static_cast<const unsigned short*>(A), sam, sak, static_cast<const unsigned short*>(B), sbk,
                      sbn, C, ldc, M, N, K, c_dtype == PTD_BF16, alpha, static_cast<const unsigned short*>(bias),
                      st);
+  if (ab_dtype == PTD_F64 && c_dtype == PTD_F64 && !bias)
+    return gemm_f64(static_cast<const double*>(A), sam, sak, static_cast<const double*>(B), sbk, sbn,
+                    static_cast<double*>(C), ldc, M, N, K, alpha, false, 1, st);
   set_error("ptd_gemm: unsupported dtype combination ab=%d c=%d", ab_dtype, c_dtype);
   return PTD_ERR_UNSUPPORTED;
 }

@@ -63,16 +63,27 @@ __device__ __forceinline__ int pair_row(int blkI, int blkJ, int r) {
 // ---------------------------------------------------------------------------
 // setup: symmetric permutation by descending diagonal (largest rows first, de Rijk), the
 // padded working copy, and G0 = L^T after the Cholesky factorisation.
-__global__ void jac_perm_kernel(const double* __restrict__ A, int64_t lda, int n, int* __restrict__ perm) {
+__global__ void jac_diag_kernel(const double* __restrict__ A, int64_t lda, int n, double* __restrict__ diag) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const double vi = A[(int64_t)i * lda + i];
+  if (i < n) diag[i] = A[(int64_t)i * lda + i];
+}
+
+__global__ void jac_perm_kernel(const double* __restrict__ diag, int n, int* __restrict__ perm) {
+  __shared__ double tile[256];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const double vi = i < n ? diag[i] : 0.0;
   int rank = 0;
-  for (int j = 0; j < n; ++j) {
-    const double vj = A[(int64_t)j * lda + j];
-    rank += (vj > vi) || (vj == vi && j < i);
+  for (int j0 = 0; j0 < n; j0 += 256) {
+    __syncthreads();
+    tile[threadIdx.x] = (j0 + (int)threadIdx.x < n) ? diag[j0 + threadIdx.x] : -INFINITY;
+    __syncthreads();
+    const int lim = min(256, n - j0);
+    for (int jj = 0; jj < lim; ++jj) {
+      const double vj = tile[jj];
+      rank += (vj > vi) || (vj == vi && j0 + jj < i);
+    }
   }
-  perm[rank] = i;  // position `rank` of the permuted matrix holds original index i
+  if (i < n) perm[rank] = i;  // position `rank` of the permuted matrix holds original index i
 }
 
 // B[i][j] = A[perm[i]][perm[j]] for i, j < n; identity on the padding
@@ -400,16 +411,24 @@ __global__ void jac_norm_kernel(const double* __restrict__ G, int np, int n, dou
 
 __global__ void jac_rank_kernel(const double* __restrict__ norms, const double* __restrict__ lambdas, int n,
                                 int* __restrict__ inv, double* __restrict__ evals) {
+  __shared__ double tile[256];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const double vi = norms[i];
+  const double vi = i < n ? norms[i] : 0.0;
   int rank = 0;
-  for (int j = 0; j < n; ++j) {
-    const double vj = norms[j];
-    rank += (vj < vi) || (vj == vi && j < i);
+  for (int j0 = 0; j0 < n; j0 += 256) {
+    __syncthreads();
+    tile[threadIdx.x] = (j0 + (int)threadIdx.x < n) ? norms[j0 + threadIdx.x] : INFINITY;
+    __syncthreads();
+    const int lim = min(256, n - j0);
+    for (int jj = 0; jj < lim; ++jj) {
+      const double vj = tile[jj];
+      rank += (vj < vi) || (vj == vi && j0 + jj < i);
+    }
   }
-  inv[rank] = i;
-  evals[rank] = lambdas[i];
+  if (i < n) {
+    inv[rank] = i;
+    evals[rank] = lambdas[i];
+  }
 }
 
 // evecs[perm[c]][k] = G[inv[k]][c] / norm(inv[k]); 32 x 32 tiles through LDS
@@ -535,7 +554,8 @@ int eigh_jacobi(const double* A, int64_t lda, int64_t n, double* evals, double* 
   // G0: Cholesky-preconditioned start (L^T of the diagonally sorted matrix), or the sorted
   // matrix itself when it is not numerically positive definite
   PTD_CHECK_HIP(hipMemsetAsync(conv, 0, 16, st));
-  hipLaunchKernelGGL(jac_perm_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, A, lda, (int)n, perm);
+  hipLaunchKernelGGL(jac_diag_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, A, lda, (int)n, norms);
+  hipLaunchKernelGGL(jac_perm_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, norms, (int)n, perm);
   bool use_chol = !no_chol;
   if (use_chol) {
     hipLaunchKernelGGL(jac_gather_kernel, dim3(2048), dim3(256), 0, st, A, lda, (int)n, perm, Lb, p.np);

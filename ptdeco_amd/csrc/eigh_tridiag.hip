@@ -1,0 +1,791 @@
+// Symmetric eigensolver, tridiagonalisation route (f64):
+//   1. blocked Householder reduction A -> T (panels of 64 reflectors): per column one
+//      HBM / Infinity-Cache bound SYMV over the trailing matrix (the 8/3 n^3-byte stream that
+//      bounds a one-stage reduction), per panel one rank-2*64 update on the f64 matrix cores;
+//   2. eigenvalues of T by bisection on Sturm counts (one eigenvalue per thread);
+//   3. eigenvectors of T by inverse iteration (one eigenvector per thread, pivoted LU of the
+//      shifted tridiagonal), tight clusters re-orthogonalised;
+//   4. back-transformation Z = Q Y with compact-WY block reflectors (f64 MFMA GEMMs).
+// The full matrix (both triangles) is kept current, so every access is a contiguous row.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+#include "common.h"
+
+namespace ptd {
+
+int gemm_f64(const double* A, int64_t sam, int64_t sak, const double* B, int64_t sbk, int64_t sbn, double* C,
+             int64_t ldc, int64_t M, int64_t N, int64_t K, double alpha, bool beta1, int ksplit, hipStream_t st);
+
+namespace {
+
+constexpr int NB = 64;          // reflectors per panel
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// scalars of the current reflector, shared between the kernels of one column
+struct Refl {
+  double tau, beta, scale, alpha;
+};
+
+// Per column j (reflector i of its panel) three multi-workgroup launches:
+//   colupd  finalises the previous reflector's w (w += alpha2 v), forms the updated column j
+//   symv    reflector scalars + v, then  p = A[R][R] v  and  c1 = W^T v, c2 = V^T v  as extra rows
+//   wupd    w_raw = tau (p - V c1 - W c2), partial sums of w_raw . v
+// colbuf is indexed by the GLOBAL row / column index (entries j .. n-1 valid, zero padding
+// beyond n) so that 16-byte loads stay aligned.
+
+// sum of `count` partial values, computed by one full wave (call with all 64 lanes of a wave)
+__device__ __forceinline__ double wave_total(const double* __restrict__ v, int count, int lane) {
+  double t = 0.0;
+  for (int k = lane; k < count; k += 64) t += v[k];
+  return wave_sum_d(t);
+}
+
+// ---- K1: grid ceil((n - j) / 64) x 256 threads; lane = row, the four waves split the k range
+__global__ __launch_bounds__(256) void sytrd_colupd_kernel(const double* __restrict__ A, int64_t ld, int n, int j,
+                                                           int i, const double* __restrict__ Vp,
+                                                           double* __restrict__ Wp, int64_t ldv,
+                                                           const double* __restrict__ wraw,
+                                                           const double* __restrict__ partial2, int nparts2,
+                                                           const Refl* __restrict__ refl,
+                                                           double* __restrict__ colbuf, double* __restrict__ partial) {
+  __shared__ double wj[NB], vj[NB];
+  __shared__ double part[4][64];
+  __shared__ double a2s;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int r = j + blockIdx.x * 64 + lane;
+  if (i > 0) {
+    if (wid == 0) {
+      const double t = wave_total(partial2, nparts2, lane);
+      if (lane == 0) a2s = -0.5 * refl->tau * t;
+    }
+    __syncthreads();
+    const double a2 = a2s;
+    // finalise w_{i-1} on this workgroup's rows (its support is rows >= j)
+    if (wid == 0 && r < n) Wp[(int64_t)(i - 1) * ldv + r] = wraw[r] + a2 * Vp[(int64_t)(i - 1) * ldv + r];
+    if (tid < i) {
+      vj[tid] = Vp[(int64_t)tid * ldv + j];
+      wj[tid] = (tid == i - 1) ? wraw[j] + a2 * Vp[(int64_t)(i - 1) * ldv + j] : Wp[(int64_t)tid * ldv + j];
+    }
+    __syncthreads();
+  }
+  double s = 0.0;
+  if (r < n)
+    for (int k = wid; k < i; k += 4) s += Vp[(int64_t)k * ldv + r] * wj[k] + Wp[(int64_t)k * ldv + r] * vj[k];
+  part[wid][lane] = s;
+  __syncthreads();
+  if (wid == 0) {
+    double sq = 0.0;
+    if (r < n) {
+      const double a = A[(int64_t)j * ld + r] - ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]));
+      colbuf[r] = a;
+      if (r >= j + 2) sq = a * a;
+    }
+    sq = wave_sum_d(sq);
+    if (lane == 0) partial[blockIdx.x] = sq;
+  }
+}
+
+// ---- K2: rows 0 .. m-1 are matrix rows j+1 .. n-1, rows m .. m+i-1 are W_k (-> c1), rows
+// m+i .. m+2i-1 are V_k (-> c2).  Every row's result is  row[j+1] + scale * sum_{c >= j+2} row[c] x[c].
+constexpr int SROWS = 4;  // rows per workgroup; its four waves split the columns
+
+__global__ __launch_bounds__(256) void sytrd_symv_kernel(const double* __restrict__ A, int64_t ld, int n, int j,
+                                                         int i, int nparts, const double* __restrict__ colbuf,
+                                                         const double* __restrict__ partial,
+                                                         double* __restrict__ Vp, const double* __restrict__ Wp,
+                                                         int64_t ldv, double* __restrict__ pbuf,
+                                                         double* __restrict__ cbuf, Refl* __restrict__ refl) {
+  __shared__ Refl sh;
+  __shared__ double part[4][SROWS];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  if (wid == 0) {
+    const double xn2 = wave_total(partial, nparts, lane);
+    if (lane == 0) {
+    const double alpha = colbuf[j + 1];
+    Refl r;
+    r.alpha = alpha;
+    if (xn2 == 0.0) {
+      r.tau = 0.0; r.beta = alpha; r.scale = 0.0;
+    } else {
+      const double nrm = sqrt(alpha * alpha + xn2);
+      r.beta = alpha >= 0.0 ? -nrm : nrm;
+      r.tau = (r.beta - alpha) / r.beta;
+      r.scale = 1.0 / (alpha - r.beta);
+    }
+    sh = r;
+    if (blockIdx.x == 0) *refl = r;
+    }
+  }
+  const int m = n - j - 1;
+  const int total = m + 2 * i;
+  const int g0 = blockIdx.x * SROWS;
+  const double* rp[SROWS];
+  double acc[SROWS];
+#pragma unroll
+  for (int t = 0; t < SROWS; ++t) {
+    const int g = min(g0 + t, total - 1);
+    rp[t] = g < m ? A + (int64_t)(j + 1 + g) * ld : (g < m + i ? Wp + (int64_t)(g - m) * ldv : Vp + (int64_t)(g - m - i) * ldv);
+    acc[t] = 0.0;
+  }
+  const int cs = (j + 2) & ~1;  // even start: 16-byte aligned loads
+  // wave `wid` takes every fourth 128-column slab; two slabs are in flight per iteration
+  int c = cs + 2 * lane + 128 * wid;
+  for (; c + 512 < n; c += 1024) {
+    double2 xa = *reinterpret_cast<const double2*>(colbuf + c);
+    const double2 xb = *reinterpret_cast<const double2*>(colbuf + c + 512);
+    if (c < j + 2) xa.x = 0.0;
+    double2 ra[SROWS], rb[SROWS];
+#pragma unroll
+    for (int t = 0; t < SROWS; ++t) {
+      ra[t] = *reinterpret_cast<const double2*>(rp[t] + c);
+      rb[t] = *reinterpret_cast<const double2*>(rp[t] + c + 512);
+    }
+#pragma unroll
+    for (int t = 0; t < SROWS; ++t) acc[t] += (ra[t].x * xa.x + ra[t].y * xa.y) + (rb[t].x * xb.x + rb[t].y * xb.y);
+  }
+  for (; c < n; c += 512) {
+    double2 xa = *reinterpret_cast<const double2*>(colbuf + c);
+    if (c < j + 2) xa.x = 0.0;
+#pragma unroll
+    for (int t = 0; t < SROWS; ++t) {
+      const double2 r2 = *reinterpret_cast<const double2*>(rp[t] + c);
+      acc[t] += r2.x * xa.x + r2.y * xa.y;
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < SROWS; ++t) {
+    const double sdot = wave_sum_d(acc[t]);
+    if (lane == 0) part[wid][t] = sdot;
+  }
+  __syncthreads();
+  if (tid < SROWS) {
+    const int t = tid, g = g0 + t;
+    if (g < total) {
+      const double scale = sh.scale;
+      const double sdot = (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
+      const double* row = g < m ? A + (int64_t)(j + 1 + g) * ld
+                                : (g < m + i ? Wp + (int64_t)(g - m) * ldv : Vp + (int64_t)(g - m - i) * ldv);
+      const double res = row[j + 1] + scale * sdot;
+      if (g < m) {
+        const int rrow = j + 1 + g;
+        pbuf[rrow] = res;
+        Vp[(int64_t)i * ldv + rrow] = (rrow == j + 1) ? 1.0 : colbuf[rrow] * scale;  // v
+      } else {
+        cbuf[g < m + i ? (g - m) : NB + (g - m - i)] = res;
+      }
+    }
+  }
+}
+
+// ---- K3: grid ceil(m / 64) x 256 threads; lane = row, waves split k
+__global__ __launch_bounds__(256) void sytrd_wupd_kernel(int n, int j, int i, const double* __restrict__ colbuf,
+                                                         const double* __restrict__ pbuf,
+                                                         const double* __restrict__ cbuf,
+                                                         const double* __restrict__ Vp, const double* __restrict__ Wp,
+                                                         int64_t ldv, const Refl* __restrict__ refl,
+                                                         double* __restrict__ wraw, double* __restrict__ partial2,
+                                                         double* __restrict__ d, double* __restrict__ e,
+                                                         double* __restrict__ taus) {
+  __shared__ double c1[NB], c2[NB];
+  __shared__ double part[4][64];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  if (tid < i) { c1[tid] = cbuf[tid]; c2[tid] = cbuf[NB + tid]; }
+  __syncthreads();
+  const int r = j + 1 + blockIdx.x * 64 + lane;
+  double s = 0.0;
+  if (r < n)
+    for (int k = wid; k < i; k += 4) s += Vp[(int64_t)k * ldv + r] * c1[k] + Wp[(int64_t)k * ldv + r] * c2[k];
+  part[wid][lane] = s;
+  __syncthreads();
+  if (wid == 0) {
+    const double tau = refl->tau;
+    double dot = 0.0;
+    if (r < n) {
+      const double wr = tau * (pbuf[r] - ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane])));
+      wraw[r] = wr;
+      dot = wr * Vp[(int64_t)i * ldv + r];
+    }
+    dot = wave_sum_d(dot);
+    if (lane == 0) partial2[blockIdx.x] = dot;
+    if (blockIdx.x == 0 && lane == 0) {
+      d[j] = colbuf[j];
+      e[j] = refl->beta;
+      taus[j] = tau;
+    }
+  }
+}
+
+// ---- end of panel: finalise the last reflector's w before the rank-2k update
+__global__ void sytrd_wfix_kernel(int n, int j_next, int ilast, const double* __restrict__ Vp,
+                                  double* __restrict__ Wp, int64_t ldv, const double* __restrict__ wraw,
+                                  const double* __restrict__ partial2, int nparts2, const Refl* __restrict__ refl) {
+  __shared__ double a2s;
+  if (threadIdx.x < 64) {
+    const double t = wave_total(partial2, nparts2, threadIdx.x);
+    if (threadIdx.x == 0) a2s = -0.5 * refl->tau * t;
+  }
+  __syncthreads();
+  const int r = j_next + blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n) Wp[(int64_t)ilast * ldv + r] = wraw[r] + a2s * Vp[(int64_t)ilast * ldv + r];
+}
+
+// ---- Sturm-count bisection: thread k finds the k-th smallest eigenvalue of T(d, e)
+__global__ void tridiag_bounds_kernel(const double* __restrict__ d, const double* __restrict__ e, int n,
+                                      double* __restrict__ out /* gl, gu, pivmin, tnorm */) {
+  __shared__ double rl[16], ru[16], re[16];
+  const int tid = threadIdx.x;
+  double gl = INFINITY, gu = -INFINITY, emax = 0.0;
+  for (int k = tid; k < n; k += blockDim.x) {
+    const double el = k > 0 ? fabs(e[k - 1]) : 0.0, er = k < n - 1 ? fabs(e[k]) : 0.0;
+    gl = fmin(gl, d[k] - el - er);
+    gu = fmax(gu, d[k] + el + er);
+    emax = fmax(emax, er);
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    gl = fmin(gl, __shfl_xor(gl, o));
+    gu = fmax(gu, __shfl_xor(gu, o));
+    emax = fmax(emax, __shfl_xor(emax, o));
+  }
+  if ((tid & 63) == 0) { rl[tid >> 6] = gl; ru[tid >> 6] = gu; re[tid >> 6] = emax; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) {
+      gl = fmin(gl, rl[w]); gu = fmax(gu, ru[w]); emax = fmax(emax, re[w]);
+    }
+    const double tnorm = fmax(fabs(gl), fabs(gu));
+    const double eps = 2.220446049250313e-16;
+    gl -= 2.0 * tnorm * eps * n + 2.0 * 2.2250738585072014e-308;
+    gu += 2.0 * tnorm * eps * n + 2.0 * 2.2250738585072014e-308;
+    out[0] = gl; out[1] = gu;
+    out[2] = 2.2250738585072014e-308 * fmax(1.0, emax * emax);
+    out[3] = tnorm;
+  }
+}
+
+// Number of eigenvalues of T below x (Sturm sequence).  The quotient uses the hardware
+// reciprocal refined by one Newton step (full f64 precision up to the last bit or two): only the
+// SIGN of q enters the count, and the bracket is re-centred every round, so this costs nothing
+// in accuracy and halves the instruction count of an IEEE division.
+__device__ __forceinline__ int sturm_count(const double* __restrict__ d, const double* __restrict__ e2, int n,
+                                           double x, double pivmin) {
+  double q = d[0] - x;
+  if (fabs(q) < pivmin) q = -pivmin;
+  int cnt = q < 0.0;
+  for (int k = 1; k < n; ++k) {
+    double r = __builtin_amdgcn_rcp(q);
+    r = r * (2.0 - q * r);
+    q = (d[k] - x) - e2[k - 1] * r;
+    if (fabs(q) < pivmin) q = -pivmin;
+    cnt += q < 0.0;
+  }
+  return cnt;
+}
+
+// One wave per eigenvalue index k: every round the 64 lanes count the eigenvalues below 64
+// interior points of the current bracket (multisection), which shrinks it 65-fold -- 9 rounds
+// from the Gershgorin interval to machine precision instead of 53 bisection steps.
+__global__ __launch_bounds__(256) void tridiag_bisect_kernel(const double* __restrict__ d,
+                                                             const double* __restrict__ e2, int n,
+                                                             const double* __restrict__ bounds,
+                                                             double* __restrict__ lam) {
+  const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (k >= n) return;
+  double lo = bounds[0], hi = bounds[1];
+  const double pivmin = bounds[2];
+  const double eps = 2.220446049250313e-16;
+  for (int round = 0; round < 16; ++round) {
+    const double h = (hi - lo) / 65.0;
+    if (hi - lo <= 2.0 * eps * fmax(fabs(lo), fabs(hi)) + 2.0 * pivmin || !(h > 0.0)) break;
+    const double x = lo + (double)(lane + 1) * h;
+    const int cnt = sturm_count(d, e2, n, x, pivmin);
+    // lanes whose point is still <= lambda_k form a prefix (the count is monotone in x)
+    const int c = __popcll(__ballot(cnt <= k));
+    const double nlo = lo + (double)c * h;
+    hi = (c == 64) ? hi : fmin(hi, lo + (double)(c + 1) * h);
+    lo = fmax(lo, nlo);
+  }
+  if (lane == 0) lam[k] = 0.5 * (lo + hi);
+}
+
+// ---- inverse iteration: thread k computes the eigenvector of T for lam[k].
+// (T - lam I) = P L U with partial pivoting between neighbouring rows (U has two
+// superdiagonals); the factors of all vectors are interleaved [row][vector] so that the 64
+// lanes of a wave touch consecutive addresses.  Three solves from a hashed start vector, the
+// iterate lives in the output matrix Y [n][ldy] (column k), normalised to unit 2-norm.
+struct InvitWs {
+  double* U1i;  // reciprocal pivots
+  double* U2;
+  double* U3;
+  double* Lm;
+  unsigned char* sw;
+};
+
+__device__ __forceinline__ double hash_uniform(unsigned int i, unsigned int k) {
+  unsigned long long z = ((unsigned long long)i << 32 | k) + 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (double)(z >> 11) * (2.0 / 9007199254740992.0) - 1.0;  // uniform in [-1, 1)
+}
+
+__global__ __launch_bounds__(64) void tridiag_invit_kernel(const double* __restrict__ d, const double* __restrict__ e,
+                                                          int n, const double* __restrict__ lam,
+                                                          const double* __restrict__ bounds, int nvec, InvitWs ws,
+                                                          double* __restrict__ Y, int64_t ldy) {
+  const int k = blockIdx.x * 64 + threadIdx.x;
+  if (k >= nvec) return;
+  const double tnorm = bounds[3];
+  const double tiny = fmax(2.220446049250313e-16 * tnorm, 2.2250738585072014e-308 * 4.0);
+  const double lk = lam[k];
+  const int64_t S = nvec;  // stride between consecutive rows of the interleaved factor arrays
+  double* __restrict__ U1i = ws.U1i + k;
+  double* __restrict__ U2 = ws.U2 + k;
+  double* __restrict__ U3 = ws.U3 + k;
+  double* __restrict__ Lm = ws.Lm + k;
+  unsigned char* __restrict__ sw = ws.sw + k;
+  double* __restrict__ y = Y + k;
+
+  // factorisation
+  double u = d[0] - lk, v = n > 1 ? e[0] : 0.0, w = 0.0;
+  for (int i = 0; i < n - 1; ++i) {
+    const double b = e[i], a1 = d[i + 1] - lk, c1 = (i + 2 < n) ? e[i + 1] : 0.0;
+    if (fabs(u) >= fabs(b)) {
+      if (fabs(u) < tiny) u = (u < 0.0) ? -tiny : tiny;
+      const double ui = 1.0 / u, m = b * ui;
+      U1i[i * S] = ui; U2[i * S] = v; U3[i * S] = w; Lm[i * S] = m; sw[i * S] = 0;
+      u = a1 - m * v; v = c1 - m * w; w = 0.0;
+    } else {
+      const double bi = 1.0 / b, m = u * bi;
+      U1i[i * S] = bi; U2[i * S] = a1; U3[i * S] = c1; Lm[i * S] = m; sw[i * S] = 1;
+      u = v - m * a1; v = w - m * c1; w = 0.0;
+    }
+  }
+  if (fabs(u) < tiny) u = (u < 0.0) ? -tiny : tiny;
+  U1i[(int64_t)(n - 1) * S] = 1.0 / u;
+
+  for (int i = 0; i < n; ++i) y[(int64_t)i * ldy] = hash_uniform((unsigned)i, (unsigned)k);
+
+  // Each step of the two substitution sweeps depends on the previous one only through one
+  // register, so the operands of 8 steps are fetched together (one latency per 8 steps).
+  constexpr int UB = 8;
+  double carry = 1.0;  // scale of the iterate in memory, applied on the next read
+  for (int it = 0; it < 3; ++it) {
+    // forward: apply the row interchanges and L^-1
+    double cur = y[0] * carry;
+    for (int i0 = 0; i0 < n - 1; i0 += UB) {
+      double yn[UB], lm[UB];
+      unsigned char s8[UB];
+#pragma unroll
+      for (int q = 0; q < UB; ++q) {
+        const int i = min(i0 + q, n - 2);
+        yn[q] = y[(int64_t)(i + 1) * ldy];
+        lm[q] = Lm[i * S];
+        s8[q] = sw[i * S];
+      }
+#pragma unroll
+      for (int q = 0; q < UB; ++q) {
+        const int i = i0 + q;
+        if (i < n - 1) {
+          double nxt = yn[q] * carry;
+          if (s8[q]) { const double t = cur; cur = nxt; nxt = t; }
+          y[(int64_t)i * ldy] = cur;
+          cur = nxt - lm[q] * cur;
+        }
+      }
+    }
+    // backward: U x = y
+    double x2 = 0.0, x1 = cur * U1i[(int64_t)(n - 1) * S];
+    y[(int64_t)(n - 1) * ldy] = x1;
+    double ss = x1 * x1, big = fabs(x1);
+    for (int i0 = n - 2; i0 >= 0; i0 -= UB) {
+      double yv[UB], u1[UB], u2[UB], u3[UB];
+#pragma unroll
+      for (int q = 0; q < UB; ++q) {
+        const int i = max(i0 - q, 0);
+        yv[q] = y[(int64_t)i * ldy];
+        u1[q] = U1i[i * S];
+        u2[q] = U2[i * S];
+        u3[q] = U3[i * S];
+      }
+#pragma unroll
+      for (int q = 0; q < UB; ++q) {
+        const int i = i0 - q;
+        if (i >= 0) {
+          const double x0 = (yv[q] - u2[q] * x1 - u3[q] * x2) * u1[q];
+          y[(int64_t)i * ldy] = x0;
+          x2 = x1; x1 = x0;
+          big = fmax(big, fabs(x0));
+          ss += x0 * x0;
+        }
+      }
+    }
+    // normalisation factor (guard the sum of squares against overflow through the max entry)
+    if (big > 1e140 || !(ss < INFINITY)) {
+      double s2 = 0.0;
+      for (int i = 0; i < n; ++i) { const double t = y[(int64_t)i * ldy] / big; s2 += t * t; }
+      carry = 1.0 / (big * sqrt(s2));
+    } else {
+      carry = ss > 0.0 ? 1.0 / sqrt(ss) : 0.0;
+    }
+  }
+  for (int i0 = 0; i0 < n; i0 += UB) {
+    double yv[UB];
+#pragma unroll
+    for (int q = 0; q < UB; ++q) yv[q] = y[(int64_t)min(i0 + q, n - 1) * ldy];
+#pragma unroll
+    for (int q = 0; q < UB; ++q)
+      if (i0 + q < n) y[(int64_t)(i0 + q) * ldy] = yv[q] * carry;
+  }
+}
+
+// smallest gap between consecutive eigenvalues relative to |T| and the number of gaps below
+// `ortol`: decides whether inverse iteration + chain re-orthogonalisation is safe and cheap
+__global__ void min_gap_kernel(const double* __restrict__ lam, int n, const double* __restrict__ bounds,
+                               double ortol, double* __restrict__ out) {
+  __shared__ double red[16];
+  __shared__ int redc[16];
+  const double tnorm = fmax(bounds[3], 2.2250738585072014e-308);
+  double g = INFINITY;
+  int close = 0;
+  for (int k = threadIdx.x + 1; k < n; k += blockDim.x) {
+    const double gap = lam[k] - lam[k - 1];
+    g = fmin(g, gap);
+    close += gap < ortol * tnorm;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    g = fmin(g, __shfl_xor(g, o));
+    close += __shfl_xor(close, o);
+  }
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = g; redc[threadIdx.x >> 6] = close; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) { g = fmin(g, red[w]); close += redc[w]; }
+    out[0] = g / tnorm;
+    out[1] = (double)close;
+  }
+}
+
+// Chains of consecutive eigenvalues closer than ortol |T|: inverse iteration leaves their
+// vectors non-orthogonal at the level eps / gap, so they are orthogonalised explicitly
+// (modified Gram-Schmidt along the chain; one workgroup per chain, chains are rare and short).
+__global__ __launch_bounds__(256) void tridiag_chain_mgs_kernel(const double* __restrict__ lam, int n,
+                                                                const double* __restrict__ bounds, double ortol,
+                                                                double* __restrict__ Y, int64_t ldy) {
+  __shared__ double red[4];
+  __shared__ double bc;
+  const int k = blockIdx.x, tid = threadIdx.x;
+  const double thr = ortol * fmax(bounds[3], 2.2250738585072014e-308);
+  const bool closeL = k > 0 && (lam[k] - lam[k - 1]) < thr;
+  const bool closeR = k < n - 1 && (lam[k + 1] - lam[k]) < thr;
+  if (closeL || !closeR) return;  // not the first member of a chain
+  for (int kk = k + 1; kk < n && (lam[kk] - lam[kk - 1]) < thr; ++kk) {
+    for (int p = k; p <= kk; ++p) {  // p == kk: normalisation pass
+      double s = 0.0;
+      for (int i = tid; i < n; i += 256) s += Y[(int64_t)i * ldy + p] * Y[(int64_t)i * ldy + kk];
+      s = wave_sum_d(s);
+      if ((tid & 63) == 0) red[tid >> 6] = s;
+      __syncthreads();
+      if (tid == 0) bc = (red[0] + red[1]) + (red[2] + red[3]);
+      __syncthreads();
+      const double dot = bc;
+      if (p < kk) {
+        for (int i = tid; i < n; i += 256) Y[(int64_t)i * ldy + kk] -= dot * Y[(int64_t)i * ldy + p];
+      } else {
+        const double sc = dot > 0.0 ? 1.0 / sqrt(dot) : 0.0;
+        for (int i = tid; i < n; i += 256) Y[(int64_t)i * ldy + kk] *= sc;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// ---- compact WY: T factor of a panel's block reflector from G = V V^T (nb x nb) and tau
+__global__ __launch_bounds__(64) void larft_kernel(const double* __restrict__ G, const double* __restrict__ tau,
+                                                  int cols, double* __restrict__ Tm) {
+  __shared__ double T[NB][NB + 1];
+  __shared__ double Gs[NB][NB + 1];
+  const int r = threadIdx.x;
+  for (int c = 0; c < NB; ++c) {
+    T[r][c] = 0.0;
+    Gs[c][r] = G[c * NB + r];  // coalesced read of row c
+  }
+  __syncthreads();
+  for (int i = 0; i < cols; ++i) {
+    const double ti = tau[i];
+    if (r < i) {
+      double s = 0.0;
+      for (int q = r; q < i; ++q) s += T[r][q] * Gs[q][i];
+      T[r][i] = -ti * s;
+    } else if (r == i) {
+      T[r][i] = ti;
+    }
+    __syncthreads();
+  }
+  for (int c = 0; c < NB; ++c) Tm[c * NB + r] = T[c][r];
+}
+
+__global__ void square_kernel(const double* __restrict__ e, int n, double* __restrict__ e2) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) e2[k] = e[k] * e[k];
+}
+
+__global__ void copy_pad_kernel(const double* __restrict__ A, int64_t lda, int n, double* __restrict__ B,
+                                int64_t ldb) {
+  const int64_t total = (int64_t)n * n;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int i = (int)(t / n), jj = (int)(t % n);
+    B[(int64_t)i * ldb + jj] = A[(int64_t)i * lda + jj];
+  }
+}
+
+}  // namespace
+
+struct TridiagPlan {
+  int n;
+  int64_t ld;      // leading dimension of the working copy and of the V / W panels
+  int npanels;
+  size_t off_A, off_V, off_W, off_col, off_p, off_part, off_refl, off_d, off_e, off_e2, off_tau, off_bounds, off_lam;
+  size_t off_u1, off_u2, off_u3, off_lm, off_sw, off_G, off_T, off_W1, off_W2, off_wraw, off_part2, off_cbuf;
+  size_t total;
+};
+
+TridiagPlan tridiag_plan(int64_t n) {
+  TridiagPlan p{};
+  p.n = (int)n;
+  p.ld = (int64_t)align_up((size_t)n, 8);
+  p.npanels = (int)ceil_div(n, NB);
+  size_t o = 0;
+  auto take = [&](size_t bytes) { size_t at = o; o += align_up(bytes, 256); return at; };
+  p.off_A = take((size_t)n * p.ld * 8);
+  p.off_V = take((size_t)p.npanels * NB * p.ld * 8);
+  p.off_W = take((size_t)NB * p.ld * 8);
+  p.off_col = take((size_t)(n + 8) * 8);
+  p.off_p = take((size_t)(n + 8) * 8);
+  p.off_part = take((size_t)(ceil_div(n, 64) + 8) * 8);
+  p.off_refl = take(sizeof(Refl));
+  p.off_d = take((size_t)n * 8);
+  p.off_e = take((size_t)n * 8);
+  p.off_e2 = take((size_t)n * 8);
+  p.off_tau = take((size_t)n * 8);
+  p.off_bounds = take(64);
+  p.off_lam = take((size_t)n * 8);
+  // inverse-iteration factors alias the (dead by then) working copy of A when they fit; they
+  // are n x n each, the same size as A
+  p.off_u1 = take((size_t)n * n * 8);
+  p.off_u2 = take((size_t)n * n * 8);
+  p.off_u3 = take((size_t)n * n * 8);
+  p.off_lm = take((size_t)n * n * 8);
+  p.off_sw = take((size_t)n * n);
+  p.off_G = take((size_t)NB * NB * 8);
+  p.off_T = take((size_t)NB * NB * 8);
+  p.off_W1 = take((size_t)NB * n * 8);
+  p.off_W2 = take((size_t)NB * n * 8);
+  p.off_wraw = take((size_t)(n + 8) * 8);
+  p.off_part2 = take((size_t)(ceil_div(n, 64) + 8) * 8);
+  p.off_cbuf = take((size_t)2 * NB * 8);
+  p.total = o;
+  return p;
+}
+
+// A (n x n, full symmetric) -> d, e, tau and the reflector panels in the workspace
+int sytrd_f64(const TridiagPlan& p, char* base, hipStream_t st) {
+  const int n = p.n;
+  const int64_t ld = p.ld;
+  double* Aw = reinterpret_cast<double*>(base + p.off_A);
+  double* Vall = reinterpret_cast<double*>(base + p.off_V);
+  double* Wp = reinterpret_cast<double*>(base + p.off_W);
+  double* colbuf = reinterpret_cast<double*>(base + p.off_col);
+  double* pbuf = reinterpret_cast<double*>(base + p.off_p);
+  double* partial = reinterpret_cast<double*>(base + p.off_part);
+  Refl* refl = reinterpret_cast<Refl*>(base + p.off_refl);
+  double* d = reinterpret_cast<double*>(base + p.off_d);
+  double* e = reinterpret_cast<double*>(base + p.off_e);
+  double* taus = reinterpret_cast<double*>(base + p.off_tau);
+
+  double* wraw = reinterpret_cast<double*>(base + p.off_wraw);
+  double* partial2 = reinterpret_cast<double*>(base + p.off_part2);
+  double* cbuf = reinterpret_cast<double*>(base + p.off_cbuf);
+  PTD_CHECK_HIP(hipMemsetAsync(Vall, 0, (size_t)p.npanels * NB * ld * 8, st));
+  PTD_CHECK_HIP(hipMemsetAsync(taus, 0, (size_t)n * 8, st));
+  PTD_CHECK_HIP(hipMemsetAsync(e, 0, (size_t)n * 8, st));
+  PTD_CHECK_HIP(hipMemsetAsync(colbuf, 0, (size_t)(n + 8) * 8, st));
+  for (int pn = 0; pn < p.npanels; ++pn) {
+    const int j0 = pn * NB;
+    const int cols = std::min(NB, n - j0);
+    double* Vp = Vall + (size_t)pn * NB * ld;
+    PTD_CHECK_HIP(hipMemsetAsync(Wp, 0, (size_t)NB * ld * 8, st));
+    int nparts2 = 0;
+    for (int i = 0; i < cols; ++i) {
+      const int j = j0 + i;
+      const int nparts = (int)ceil_div(n - j, 64);
+      hipLaunchKernelGGL(sytrd_colupd_kernel, dim3(nparts), dim3(256), 0, st, Aw, ld, n, j, i, Vp, Wp, ld, wraw,
+                         partial2, nparts2, refl, colbuf, partial);
+      const int m = n - j - 1;
+      if (m > 0) {
+        const int rows = m + 2 * i;
+        hipLaunchKernelGGL(sytrd_symv_kernel, dim3((unsigned)ceil_div(rows, SROWS)), dim3(256), 0, st, Aw, ld, n,
+                           j, i, nparts, colbuf, partial, Vp, Wp, ld, pbuf, cbuf, refl);
+        nparts2 = (int)ceil_div(m, 64);
+        hipLaunchKernelGGL(sytrd_wupd_kernel, dim3(nparts2), dim3(256), 0, st, n, j, i, colbuf, pbuf, cbuf, Vp, Wp,
+                           ld, refl, wraw, partial2, d, e, taus);
+      } else {
+        PTD_CHECK_HIP(hipMemcpyAsync(d + j, colbuf + j, 8, hipMemcpyDeviceToDevice, st));
+        nparts2 = 0;
+      }
+    }
+    // trailing update A[T0:, T0:] -= V W^T + W V^T  (T0 = first row / column after the panel)
+    const int t0 = j0 + cols;
+    const int mt = n - t0;
+    if (mt > 0) {
+      hipLaunchKernelGGL(sytrd_wfix_kernel, dim3((unsigned)ceil_div(mt, 256)), dim3(256), 0, st, n, t0, cols - 1, Vp,
+                         Wp, ld, wraw, partial2, nparts2, refl);
+      double* At = Aw + (int64_t)t0 * ld + t0;
+      int rc = gemm_f64(Vp + t0, 1, ld, Wp + t0, ld, 1, At, ld, mt, mt, cols, -1.0, true, 1, st);
+      if (rc != PTD_OK) return rc;
+      rc = gemm_f64(Wp + t0, 1, ld, Vp + t0, ld, 1, At, ld, mt, mt, cols, -1.0, true, 1, st);
+      if (rc != PTD_OK) return rc;
+    }
+  }
+  PTD_CHECK_LAUNCH("sytrd_f64");
+  return PTD_OK;
+}
+
+int tridiag_eigenvalues(const TridiagPlan& p, char* base, hipStream_t st) {
+  const int n = p.n;
+  double* d = reinterpret_cast<double*>(base + p.off_d);
+  double* e = reinterpret_cast<double*>(base + p.off_e);
+  double* e2 = reinterpret_cast<double*>(base + p.off_e2);
+  double* bounds = reinterpret_cast<double*>(base + p.off_bounds);
+  double* lam = reinterpret_cast<double*>(base + p.off_lam);
+  hipLaunchKernelGGL(square_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, e, n, e2);
+  hipLaunchKernelGGL(tridiag_bounds_kernel, dim3(1), dim3(1024), 0, st, d, e, n, bounds);
+  hipLaunchKernelGGL(tridiag_bisect_kernel, dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, st, d, e2, n, bounds, lam);
+  PTD_CHECK_LAUNCH("tridiag_eigenvalues");
+  return PTD_OK;
+}
+
+
+// eigenvectors of T for all eigenvalues into Y (= evecs, [n][ldv]), then Y <- Q Y
+int tridiag_vectors_and_backtransform(const TridiagPlan& p, char* base, double* Y, int64_t ldy, double ortol,
+                                      hipStream_t st) {
+  const int n = p.n;
+  const int64_t ld = p.ld;
+  double* d = reinterpret_cast<double*>(base + p.off_d);
+  double* e = reinterpret_cast<double*>(base + p.off_e);
+  double* lam = reinterpret_cast<double*>(base + p.off_lam);
+  double* bounds = reinterpret_cast<double*>(base + p.off_bounds);
+  double* taus = reinterpret_cast<double*>(base + p.off_tau);
+  double* Vall = reinterpret_cast<double*>(base + p.off_V);
+  double* G = reinterpret_cast<double*>(base + p.off_G);
+  double* Tm = reinterpret_cast<double*>(base + p.off_T);
+  double* W1 = reinterpret_cast<double*>(base + p.off_W1);
+  double* W2 = reinterpret_cast<double*>(base + p.off_W2);
+  InvitWs ws;
+  ws.U1i = reinterpret_cast<double*>(base + p.off_u1);
+  ws.U2 = reinterpret_cast<double*>(base + p.off_u2);
+  ws.U3 = reinterpret_cast<double*>(base + p.off_u3);
+  ws.Lm = reinterpret_cast<double*>(base + p.off_lm);
+  ws.sw = reinterpret_cast<unsigned char*>(base + p.off_sw);
+  hipLaunchKernelGGL(tridiag_invit_kernel, dim3((unsigned)ceil_div(n, 64)), dim3(64), 0, st, d, e, n, lam, bounds, n,
+                     ws, Y, ldy);
+  if (ortol > 0.0)
+    hipLaunchKernelGGL(tridiag_chain_mgs_kernel, dim3((unsigned)n), dim3(256), 0, st, lam, n, bounds, ortol, Y, ldy);
+  PTD_CHECK_LAUNCH("tridiag_invit");
+  // Y <- Q_0 Q_1 ... Q_last Y : apply the panels' block reflectors from the last to the first
+  for (int pn = p.npanels - 1; pn >= 0; --pn) {
+    const int j0 = pn * NB;
+    const int cols = std::min(NB, n - j0);
+    const int r0 = j0 + 1;          // first row any reflector of this panel touches
+    const int mr = n - r0;
+    if (mr <= 0) continue;
+    const double* Vp = Vall + (size_t)pn * NB * ld;
+    // G = V V^T over rows r0..n-1 (cols x cols, stored NB x NB)
+    PTD_CHECK_HIP(hipMemsetAsync(G, 0, (size_t)NB * NB * 8, st));
+    int rc = gemm_f64(Vp + r0, ld, 1, Vp + r0, 1, ld, G, NB, cols, cols, mr, 1.0, true, 64, st);
+    if (rc != PTD_OK) return rc;
+    hipLaunchKernelGGL(larft_kernel, dim3(1), dim3(64), 0, st, G, taus + j0, cols, Tm);
+    // W1 = V Y  (cols x n)
+    PTD_CHECK_HIP(hipMemsetAsync(W1, 0, (size_t)NB * n * 8, st));
+    rc = gemm_f64(Vp + r0, ld, 1, Y + (int64_t)r0 * ldy, ldy, 1, W1, n, cols, n, mr, 1.0, true, 16, st);
+    if (rc != PTD_OK) return rc;
+    // W2 = T W1
+    rc = gemm_f64(Tm, NB, 1, W1, n, 1, W2, n, cols, n, cols, 1.0, false, 1, st);
+    if (rc != PTD_OK) return rc;
+    // Y[r0:, :] -= V^T W2
+    rc = gemm_f64(Vp + r0, 1, ld, W2, n, 1, Y + (int64_t)r0 * ldy, ldy, mr, n, cols, -1.0, true, 1, st);
+    if (rc != PTD_OK) return rc;
+  }
+  PTD_CHECK_LAUNCH("tridiag_backtransform");
+  return PTD_OK;
+}
+
+// Full eigendecomposition through the tridiagonal route.  Returns PTD_ERR_UNSUPPORTED (and
+// leaves the outputs untouched) when two eigenvalues are closer than `cluster_tol` * |T|: the
+// caller then uses the Jacobi solver, which needs no gap.
+int eigh_tridiag(const double* A, int64_t lda, int64_t n, double* evals, double* evecs, int64_t ldv, void* ws,
+                 size_t ws_bytes, double cluster_tol, hipStream_t st) {
+  const TridiagPlan p = tridiag_plan(n);
+  if (ws_bytes < p.total) {
+    set_error("eigh_tridiag: workspace %zu < required %zu bytes", ws_bytes, p.total);
+    return PTD_ERR_WORKSPACE;
+  }
+  char* base = static_cast<char*>(ws);
+  double* Aw = reinterpret_cast<double*>(base + p.off_A);
+  hipLaunchKernelGGL(copy_pad_kernel, dim3(2048), dim3(256), 0, st, A, lda, (int)n, Aw, p.ld);
+  int rc = sytrd_f64(p, base, st);
+  if (rc != PTD_OK) return rc;
+  rc = tridiag_eigenvalues(p, base, st);
+  if (rc != PTD_OK) return rc;
+  double* lam = reinterpret_cast<double*>(base + p.off_lam);
+  double* bounds = reinterpret_cast<double*>(base + p.off_bounds);
+  const double ortol = 1e-7;  // neighbours closer than this (relative to |T|) are re-orthogonalised
+  hipLaunchKernelGGL(min_gap_kernel, dim3(1), dim3(1024), 0, st, lam, (int)n, bounds, ortol, bounds + 4);
+  double h_gap[2] = {0.0, 0.0};
+  PTD_CHECK_HIP(hipMemcpyAsync(h_gap, bounds + 4, 16, hipMemcpyDeviceToHost, st));
+  PTD_CHECK_HIP(hipStreamSynchronize(st));
+  if (getenv("PTD_JACOBI_DEBUG"))
+    fprintf(stderr, "[eigh_tridiag] n=%lld min relative gap %.3e, %d gaps below %.0e\n", (long long)n, h_gap[0],
+            (int)h_gap[1], ortol);
+  if (n > 1 && (!(h_gap[0] > cluster_tol) || h_gap[1] > 64.0 + (double)n / 64.0)) {
+    set_error("eigh_tridiag: clustered eigenvalues (min relative gap %.3e, %d close pairs)", h_gap[0], (int)h_gap[1]);
+    return PTD_ERR_UNSUPPORTED;
+  }
+  rc = tridiag_vectors_and_backtransform(p, base, evecs, ldv, h_gap[1] > 0.0 ? ortol : 0.0, st);
+  if (rc != PTD_OK) return rc;
+  PTD_CHECK_HIP(hipMemcpyAsync(evals, lam, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
+  return PTD_OK;
+}
+
+size_t tridiag_workspace_bytes(int64_t n) { return tridiag_plan(n).total; }
+
+// Diagnostic entry: tridiagonalise A and return (d, e, tau) and the eigenvalues of T.
+int tridiagonalize_f64(const double* A, int64_t lda, int64_t n, double* d_out, double* e_out, double* evals_out,
+                       void* ws, size_t ws_bytes, hipStream_t st) {
+  PTD_REQUIRE(A && ws && n >= 1 && lda >= n, "ptd_tridiagonalize: bad argument");
+  const TridiagPlan p = tridiag_plan(n);
+  if (ws_bytes < p.total) {
+    set_error("ptd_tridiagonalize: workspace %zu < required %zu bytes", ws_bytes, p.total);
+    return PTD_ERR_WORKSPACE;
+  }
+  char* base = static_cast<char*>(ws);
+  double* Aw = reinterpret_cast<double*>(base + p.off_A);
+  hipLaunchKernelGGL(copy_pad_kernel, dim3(2048), dim3(256), 0, st, A, lda, (int)n, Aw, p.ld);
+  int rc = sytrd_f64(p, base, st);
+  if (rc != PTD_OK) return rc;
+  rc = tridiag_eigenvalues(p, base, st);
+  if (rc != PTD_OK) return rc;
+  if (d_out) PTD_CHECK_HIP(hipMemcpyAsync(d_out, base + p.off_d, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
+  if (e_out) PTD_CHECK_HIP(hipMemcpyAsync(e_out, base + p.off_e, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
+  if (evals_out) PTD_CHECK_HIP(hipMemcpyAsync(evals_out, base + p.off_lam, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
+  return PTD_OK;
+}
+
+}  // namespace ptd

@@ -23,6 +23,17 @@ size_t eigh_workspace_bytes(int64_t n);
 int eigh_jacobi(const double* A, int64_t lda, int64_t n, double* evals, double* evecs, int64_t ldv, void* ws,
                 size_t ws_bytes, int* sweeps_out, ptd_eigh_stats* stats, hipStream_t st);
 
+// gemm_f64.hip
+int gemm_f64(const double* A, int64_t sam, int64_t sak, const double* B, int64_t sbk, int64_t sbn, double* C,
+             int64_t ldc, int64_t M, int64_t N, int64_t K, double alpha, bool beta1, int ksplit, hipStream_t st);
+
+// eigh_tridiag.hip
+size_t tridiag_workspace_bytes(int64_t n);
+int eigh_tridiag(const double* A, int64_t lda, int64_t n, double* evals, double* evecs, int64_t ldv, void* ws,
+                 size_t ws_bytes, double cluster_tol, hipStream_t st);
+int tridiagonalize_f64(const double* A, int64_t lda, int64_t n, double* d_out, double* e_out, double* evals_out,
+                       void* ws, size_t ws_bytes, hipStream_t st);
+
 // reduce.hip
 size_t cov_finalize_workspace_bytes(int64_t n);
 int cov_finalize(const void* E, int64_t ldE, int E_dtype, const void* ey, int ey_dtype, int64_t n, double steps,

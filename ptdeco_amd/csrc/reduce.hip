@@ -137,11 +137,13 @@ __global__ void nsr_partial_kernel(const T* __restrict__ x, const T* __restrict_
   }
 }
 
+// one thread per channel; every block leaves the sum of its channels' ratios in blocksum[blockIdx.x]
 __global__ void nsr_final_kernel(const double* __restrict__ part, int64_t R, int64_t C, int nchunk, double eps,
-                                 double* __restrict__ out) {
+                                 double* __restrict__ blocksum) {
   __shared__ double red[16];
   double acc = 0.0;
-  for (int64_t c = threadIdx.x; c < C; c += blockDim.x) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) {
     double s1 = 0.0, s2 = 0.0, s3 = 0.0;
     for (int k = 0; k < nchunk; ++k) {
       const double* p = part + ((int64_t)k * C + c) * 3;
@@ -149,7 +151,7 @@ __global__ void nsr_final_kernel(const double* __restrict__ part, int64_t R, int
     }
     const double n = (double)R;
     const double var = (s2 - s1 * s1 / n) / (n - 1.0);  // unbiased, like torch.std
-    acc += (s3 / n) / (var + eps);
+    acc = (s3 / n) / (var + eps);
   }
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
@@ -157,7 +159,21 @@ __global__ void nsr_final_kernel(const double* __restrict__ part, int64_t R, int
   if (threadIdx.x == 0) {
     double t = 0.0;
     for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
-    out[0] = t / (double)C;
+    blocksum[blockIdx.x] = t;
+  }
+}
+
+__global__ void sum_scale_kernel(const double* __restrict__ v, int64_t n, double scale, double* __restrict__ out) {
+  __shared__ double red[16];
+  double s = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) s += v[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
+    out[0] = t * scale;
   }
 }
 
@@ -222,7 +238,7 @@ NsrPlan nsr_plan(int64_t R, int64_t C) {
   p.Ct = (int)std::min<int64_t>(C, 256);
   p.Rt = 256 / p.Ct;
   p.coltiles = (int)ceil_div(C, p.Ct);
-  const int64_t want = std::max<int64_t>(1, 2048 / p.coltiles);
+  const int64_t want = std::max<int64_t>(1, 1024 / p.coltiles);
   const int64_t min_rows = (int64_t)p.Rt * 16;
   p.nchunk = (int)std::max<int64_t>(1, std::min<int64_t>(want, ceil_div(R, min_rows)));
   p.rows_per_chunk = ceil_div(R, p.nchunk);
@@ -287,7 +303,7 @@ int colsum_accumulate(const void* y, int64_t T, int64_t n, int64_t ldy, int y_dt
 
 size_t nsr_workspace_bytes(int64_t R, int64_t C) {
   const NsrPlan p = nsr_plan(R, C);
-  return align_up((size_t)p.nchunk * C * 3 * 8, 256);
+  return align_up((size_t)p.nchunk * C * 3 * 8, 256) + align_up((size_t)ceil_div(C, 256) * 8, 256);
 }
 
 int nsr(const void* x, const void* y, int64_t R, int64_t C, int dtype, double eps, double* out, void* ws,
@@ -313,7 +329,10 @@ int nsr(const void* x, const void* y, int64_t R, int64_t C, int dtype, double ep
     set_error("ptd_nsr: unsupported dtype");
     return PTD_ERR_UNSUPPORTED;
   }
-  hipLaunchKernelGGL(nsr_final_kernel, dim3(1), dim3(1024), 0, st, part, R, C, p.nchunk, eps, out);
+  double* blocksum = part + align_up((size_t)p.nchunk * C * 3 * 8, 256) / 8;
+  const unsigned fblocks = (unsigned)ceil_div(C, 256);
+  hipLaunchKernelGGL(nsr_final_kernel, dim3(fblocks), dim3(256), 0, st, part, R, C, p.nchunk, eps, blocksum);
+  hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(256), 0, st, blocksum, (int64_t)fblocks, 1.0 / (double)C, out);
   PTD_CHECK_LAUNCH("nsr");
   return PTD_OK;
 }

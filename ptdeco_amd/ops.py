@@ -116,6 +116,21 @@ def eigh(A: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
     return w, v
 
 
+def tridiagonalize(A: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """Diagnostic: (d, e, eigenvalues of T) of the Householder tridiagonalisation of symmetric f64 A."""
+    _dev(A)
+    assert A.dtype == torch.float64 and A.dim() == 2 and A.shape[0] == A.shape[1] and A.stride(1) == 1
+    n = A.shape[0]
+    lib = _hip.load()
+    d, e, w = (torch.empty(n, dtype=torch.float64, device=A.device) for _ in range(3))
+    ws = torch.empty(lib.ptd_tridiagonalize_workspace_bytes(n), dtype=torch.uint8, device=A.device)
+    with torch.cuda.device(A.device):
+        rc = lib.ptd_tridiagonalize(A.data_ptr(), A.stride(0), n, d.data_ptr(), e.data_ptr(), w.data_ptr(),
+                                    ws.data_ptr(), ws.numel(), _stream(A))
+    _hip.check(rc, "ptd_tridiagonalize")
+    return d, e, w
+
+
 def matmul(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = None, alpha: float = 1.0,
            out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
     """a [M, K] @ b [K, N] (+ bias[N]); a and b may be transposed views (no copies are made

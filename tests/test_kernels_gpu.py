@@ -2,6 +2,7 @@
 f64 torch-CPU arithmetic on the same seeded inputs.  Needs an MI355X."""
 
 import math
+import os
 
 import numpy as np
 import pytest
@@ -106,6 +107,11 @@ def test_cov_finalize(ops, n, edt, use_mean):
 
 
 # ---------------------------------------------------------------- eigh
+# The Jacobi solver orthogonalises to ~sqrt(n) eps; the tridiagonal route (inverse iteration)
+# leaves eps / relative-gap between neighbours (re-orthogonalised below a gap of 1e-5).
+ORTH_TOL = 1e-12 if os.environ.get("PTD_EIGH_METHOD", "jacobi") == "jacobi" else 2e-9
+
+
 def _check_eigh(ops, a, vec_tol=None):
     n = a.shape[0]
     w, v = ops.eigh(a.to(DEV))
@@ -114,7 +120,7 @@ def _check_eigh(ops, a, vec_tol=None):
     scale = max(w_ref.abs().max().item(), 1e-300)
     assert torch.all(w[1:] >= w[:-1]), "eigenvalues not ascending"
     assert (w - w_ref).abs().max().item() <= 1e-12 * scale
-    assert (v.T @ v - torch.eye(n, dtype=torch.float64)).abs().max().item() <= 1e-12
+    assert (v.T @ v - torch.eye(n, dtype=torch.float64)).abs().max().item() <= ORTH_TOL
     assert (a @ v - v * w).abs().max().item() <= 1e-11 * scale
     if vec_tol is not None:
         assert (orc.canonical_sign(v) - orc.canonical_sign(v_ref)).abs().max().item() <= vec_tol
