@@ -72,26 +72,44 @@ int ptd_cov_finalize(const void* E, int64_t ldE, int E_dtype, const void* ey, in
 /* All eigenpairs of the symmetric positive semi-definite f64 matrix A [n, n]
  * (full storage), eigenvalues ascending in evals[n], eigenvectors in the COLUMNS
  * of evecs [n, n] (row-major, ld ldv) -- the layout torch.linalg.eigh returns.
- * A is not modified.  One-sided block Jacobi on the matrix cores (f64 MFMA).
- * NOT fully asynchronous: synchronises `stream` once per sweep to read the
- * convergence flag.  sweeps_out (host pointer, may be NULL) receives the number
- * of sweeps used.  Replaces `torch.linalg.eigh`: dwain.py:162, falor.py:207. */
+ * A is not modified.  Two solvers (env PTD_EIGH_METHOD = auto | tridiag | jacobi, default auto):
+ *   tridiagonal route (n >= 256 in auto): blocked Householder reduction whose per-column
+ *     SYMV streams the trailing matrix from HBM / Infinity Cache, eigenvalues by multisection,
+ *     eigenvectors by inverse iteration, compact-WY back-transformation on the f64 matrix
+ *     cores; used unless two eigenvalues are closer than 1e-10 |A| (or too many than 1e-7 |A|);
+ *   one-sided block Jacobi on the f64 matrix cores: any PSD matrix, incl. rank deficient.
+ * NOT fully asynchronous: synchronises `stream` to read small decisions back (cluster
+ * check, Jacobi convergence flag).  sweeps_out (host pointer, may be NULL) receives the number
+ * of Jacobi sweeps (0 for the tridiagonal route).
+ * Replaces `torch.linalg.eigh`: dwain.py:162, falor.py:207. */
 size_t ptd_eigh_workspace_bytes(int64_t n);
 int ptd_eigh(const double* A, int64_t lda, int64_t n, double* evals, double* evecs, int64_t ldv,
              void* ws, size_t ws_bytes, int* sweeps_out, void* stream);
 
-/* Same, with per-phase device timing (HIP events on `stream` around every launch of the
- * three Jacobi kernels; a few percent slower, for bench.py's roofline lines).
- * `stats` is a HOST pointer. */
+/* Same, but only the eigenvectors of the k LARGEST eigenvalues are formed: evecs is [n, k]
+ * (ld ldv >= k), column c holds the eigenvector of evals[n - k + c]; evals still has all n
+ * entries.  dwain never looks below rank floor(n * reduction_factor) (dwain.py:407-408, 424-426),
+ * so half of the inverse iterations and of the back-transformation are skipped, and a dense
+ * cluster at the low end of the spectrum no longer forces the Jacobi fallback. */
+int ptd_eigh_topk(const double* A, int64_t lda, int64_t n, int64_t k, double* evals, double* evecs,
+                  int64_t ldv, void* ws, size_t ws_bytes, int* sweeps_out, void* stream);
+
+/* Same, with per-phase device timing (HIP events on `stream` around the launches of each
+ * phase; a few percent slower, for bench.py's roofline lines).  `stats` is a HOST pointer.
+ *   method 0 (Jacobi):       phase 0 jac_gram, 1 jac_inner, 2 jac_update            (work = f64 flops executed)
+ *   method 1 (tridiagonal):  phase 0 sytrd_symv (work = BYTES of the trailing matrix streamed),
+ *                            1 the other per-column kernels, 2 rank-2k trailing updates (flops),
+ *                            3 eigenvalues + inverse iteration + back-transformation */
 typedef struct {
-  int sweeps;
-  int launches[3];   /* gram, inner, update */
-  float ms[3];       /* summed device time of those launches */
+  int method;
+  int sweeps;        /* Jacobi sweeps; 0 for the tridiagonal route */
+  int launches[4];
+  float ms[4];       /* summed device time of the phase's launches */
+  double work[4];
   float total_ms;    /* first launch to last launch of the call */
-  double flops[3];   /* f64 flops executed by gram / update launches (inner: 0) */
 } ptd_eigh_stats;
-int ptd_eigh_profiled(const double* A, int64_t lda, int64_t n, double* evals, double* evecs, int64_t ldv,
-                      void* ws, size_t ws_bytes, ptd_eigh_stats* stats, void* stream);
+int ptd_eigh_profiled(const double* A, int64_t lda, int64_t n, int64_t k, double* evals, double* evecs,
+                      int64_t ldv, void* ws, size_t ws_bytes, ptd_eigh_stats* stats, void* stream);
 
 /* Diagnostic: Householder tridiagonalisation T = Q^T A Q of a symmetric f64 matrix (full
  * storage) and the eigenvalues of T by bisection.  d[n], e[n] (e[n-1] unused), evals[n]

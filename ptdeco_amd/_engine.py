@@ -122,11 +122,12 @@ class Covariance:
         dist.all_reduce(steps, op=dist.ReduceOp.SUM, group=group)
         self.steps = int(steps.item())
 
-    def eigenvectors(self, damp_factor: float, use_mean: bool = False) -> torch.Tensor:
+    def eigenvectors(self, damp_factor: float, use_mean: bool = False, top_k: Optional[int] = None) -> torch.Tensor:
         """Finalise (divide by steps, optional mean removal, Tikhonov damping) and return the
-        eigenvectors [n, n] f64, ascending (dwain.py:155-163, falor.py:192-208)."""
+        eigenvectors in columns, ascending, f64 (dwain.py:155-163, falor.py:192-208).  With
+        ``top_k`` only the last top_k columns (largest eigenvalues) are formed: [n, top_k]."""
         c = ops.cov_finalize(self.E, self.steps, damp_factor, self.ey if use_mean else None)
-        _, u = ops.eigh(c)
+        _, u = ops.eigh(c, top_k)
         return u
 
 

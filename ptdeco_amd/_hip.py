@@ -30,8 +30,10 @@ SIGNATURES = {
     "ptd_eigh_workspace_bytes": (c_size_t, [c_int64]),
     "ptd_eigh": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_size_t,
                          ctypes.POINTER(c_int), c_void_p]),
-    "ptd_eigh_profiled": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_size_t,
-                                  c_void_p, c_void_p]),
+    "ptd_eigh_topk": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_size_t,
+                              ctypes.POINTER(c_int), c_void_p]),
+    "ptd_eigh_profiled": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p,
+                                  c_size_t, c_void_p, c_void_p]),
     "ptd_tridiagonalize_workspace_bytes": (c_size_t, [c_int64]),
     "ptd_tridiagonalize": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                    c_void_p]),
@@ -49,8 +51,8 @@ SIGNATURES = {
 
 class EighStats(ctypes.Structure):
     """ptd_eigh_stats of include/ptdeco_hip.h."""
-    _fields_ = [("sweeps", c_int), ("launches", c_int * 3), ("ms", ctypes.c_float * 3),
-                ("total_ms", ctypes.c_float), ("flops", c_double * 3)]
+    _fields_ = [("method", c_int), ("sweeps", c_int), ("launches", c_int * 4), ("ms", ctypes.c_float * 4),
+                ("work", c_double * 4), ("total_ms", ctypes.c_float)]
 
 
 class HipLibraryError(RuntimeError):

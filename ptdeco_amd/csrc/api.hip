@@ -57,43 +57,51 @@ int ptd_cov_finalize(const void* E, int64_t ldE, int E_dtype, const void* ey, in
                       static_cast<hipStream_t>(stream));
 }
 
-// Solver choice.  "jacobi": one-sided block Jacobi (any symmetric PSD matrix).  "tridiag":
-// Householder tridiagonalisation + bisection + inverse iteration + back-transformation, used
-// when no two eigenvalues are closer than 1e-8 |A| (otherwise Jacobi takes over).
+// Solver choice (see include/ptdeco_hip.h).  Read on every call so a process can switch.
 static int eigh_method() {
-  static const int m = [] {
-    const char* e = getenv("PTD_EIGH_METHOD");
-    if (!e) return 0;
-    if (!strcmp(e, "tridiag")) return 1;
-    if (!strcmp(e, "auto")) return 2;
-    return 0;
-  }();
-  return m;
+  const char* e = getenv("PTD_EIGH_METHOD");
+  if (!e || !strcmp(e, "auto")) return 2;
+  if (!strcmp(e, "tridiag")) return 1;
+  return 0;
 }
 
 size_t ptd_eigh_workspace_bytes(int64_t n) {
   return std::max(eigh_workspace_bytes(n), tridiag_workspace_bytes(n));
 }
 
-int ptd_eigh(const double* A, int64_t lda, int64_t n, double* evals, double* evecs, int64_t ldv, void* ws,
-             size_t ws_bytes, int* sweeps_out, void* stream) {
-  hipStream_t st = static_cast<hipStream_t>(stream);
+static int eigh_dispatch(const double* A, int64_t lda, int64_t n, int64_t k, double* evals, double* evecs,
+                         int64_t ldv, void* ws, size_t ws_bytes, int* sweeps_out, ptd_eigh_stats* stats,
+                         hipStream_t st) {
   const int method = eigh_method();
-  if (method != 0 && (method == 1 || n >= 256) && A && evals && evecs && ws && n >= 2 && lda >= n && ldv >= n) {
-    static const double ctol = getenv("PTD_EIGH_CLUSTER_TOL") ? atof(getenv("PTD_EIGH_CLUSTER_TOL")) : 1e-10;
-    const int rc = eigh_tridiag(A, lda, n, evals, evecs, ldv, ws, ws_bytes, ctol, st);
+  if (method != 0 && (method == 1 || n >= 256) && A && evals && evecs && ws && n >= 2 && lda >= n && k >= 1 &&
+      k <= n && ldv >= k) {
+    const char* ct = getenv("PTD_EIGH_CLUSTER_TOL");
+    const int rc = eigh_tridiag(A, lda, n, k, evals, evecs, ldv, ws, ws_bytes, ct ? atof(ct) : 1e-10, stats, st);
     if (rc != PTD_ERR_UNSUPPORTED) {
       if (sweeps_out) *sweeps_out = 0;
       return rc;
     }
   }
-  return eigh_jacobi(A, lda, n, evals, evecs, ldv, ws, ws_bytes, sweeps_out, nullptr, st);
+  return eigh_jacobi(A, lda, n, k, evals, evecs, ldv, ws, ws_bytes, sweeps_out, stats, st);
 }
 
-int ptd_eigh_profiled(const double* A, int64_t lda, int64_t n, double* evals, double* evecs, int64_t ldv, void* ws,
-                      size_t ws_bytes, ptd_eigh_stats* stats, void* stream) {
+int ptd_eigh(const double* A, int64_t lda, int64_t n, double* evals, double* evecs, int64_t ldv, void* ws,
+             size_t ws_bytes, int* sweeps_out, void* stream) {
+  return eigh_dispatch(A, lda, n, n, evals, evecs, ldv, ws, ws_bytes, sweeps_out, nullptr,
+                       static_cast<hipStream_t>(stream));
+}
+
+int ptd_eigh_topk(const double* A, int64_t lda, int64_t n, int64_t k, double* evals, double* evecs, int64_t ldv,
+                  void* ws, size_t ws_bytes, int* sweeps_out, void* stream) {
+  return eigh_dispatch(A, lda, n, k, evals, evecs, ldv, ws, ws_bytes, sweeps_out, nullptr,
+                       static_cast<hipStream_t>(stream));
+}
+
+int ptd_eigh_profiled(const double* A, int64_t lda, int64_t n, int64_t k, double* evals, double* evecs, int64_t ldv,
+                      void* ws, size_t ws_bytes, ptd_eigh_stats* stats, void* stream) {
   PTD_REQUIRE(stats, "ptd_eigh_profiled: stats must not be null");
-  return eigh_jacobi(A, lda, n, evals, evecs, ldv, ws, ws_bytes, nullptr, stats, static_cast<hipStream_t>(stream));
+  return eigh_dispatch(A, lda, n, k, evals, evecs, ldv, ws, ws_bytes, nullptr, stats,
+                       static_cast<hipStream_t>(stream));
 }
 
 size_t ptd_tridiagonalize_workspace_bytes(int64_t n) { return tridiag_workspace_bytes(n); }

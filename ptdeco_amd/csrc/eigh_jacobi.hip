@@ -432,17 +432,18 @@ __global__ void jac_rank_kernel(const double* __restrict__ norms, const double* 
 }
 
 // evecs[perm[c]][k] = G[inv[k]][c] / norm(inv[k]); 32 x 32 tiles through LDS
-__global__ void jac_scatter_kernel(const double* __restrict__ G, int np, int n, const int* __restrict__ inv,
-                                   const double* __restrict__ norms, const int* __restrict__ perm,
-                                   double* __restrict__ evecs, int64_t ldv) {
+__global__ void jac_scatter_kernel(const double* __restrict__ G, int np, int n, int kvec,
+                                   const int* __restrict__ inv, const double* __restrict__ norms,
+                                   const int* __restrict__ perm, double* __restrict__ evecs, int64_t ldv) {
   __shared__ double tile[32][33];
+  const int koff = n - kvec;  // output column kk holds the eigenvector of sorted index koff + kk
   const int k0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: ty 0..7
   for (int kk = ty; kk < 32; kk += 8) {
     const int k = k0 + kk, c = c0 + tx;
     double v = 0.0;
-    if (k < n && c < n) {
-      const int src = inv[k];
+    if (k < kvec && c < n) {
+      const int src = inv[koff + k];
       const double nr = norms[src];
       v = nr > 0.0 ? G[(int64_t)src * np + c] / nr : (c == src ? 1.0 : 0.0);
     }
@@ -451,7 +452,7 @@ __global__ void jac_scatter_kernel(const double* __restrict__ G, int np, int n, 
   __syncthreads();
   for (int cc = ty; cc < 32; cc += 8) {
     const int c = c0 + cc, k = k0 + tx;
-    if (c < n && k < n) evecs[(int64_t)perm[c] * ldv + k] = tile[tx][cc];
+    if (c < n && k < kvec) evecs[(int64_t)perm[c] * ldv + k] = tile[tx][cc];
   }
 }
 
@@ -498,10 +499,11 @@ JacobiPlan make_plan(int64_t n) {
 
 size_t eigh_workspace_bytes(int64_t n) { return make_plan(n).total; }
 
-int eigh_jacobi(const double* A, int64_t lda, int64_t n, double* evals, double* evecs, int64_t ldv, void* ws,
-                size_t ws_bytes, int* sweeps_out, ptd_eigh_stats* stats, hipStream_t st) {
+int eigh_jacobi(const double* A, int64_t lda, int64_t n, int64_t k, double* evals, double* evecs, int64_t ldv,
+                void* ws, size_t ws_bytes, int* sweeps_out, ptd_eigh_stats* stats, hipStream_t st) {
   PTD_REQUIRE(n >= 1 && n <= 32768, "ptd_eigh: n=%lld out of range [1, 32768]", (long long)n);
-  PTD_REQUIRE(lda >= n && ldv >= n, "ptd_eigh: leading dimension smaller than n");
+  PTD_REQUIRE(k >= 1 && k <= n, "ptd_eigh: k=%lld out of range [1, n]", (long long)k);
+  PTD_REQUIRE(lda >= n && ldv >= k, "ptd_eigh: leading dimension too small");
   PTD_REQUIRE(A && evals && evecs && ws, "ptd_eigh: null pointer");
   PTD_REQUIRE(aligned16(ws), "ptd_eigh: workspace must be 16-byte aligned");
   const JacobiPlan p = make_plan(n);
@@ -607,12 +609,13 @@ int eigh_jacobi(const double* A, int64_t lda, int64_t n, double* evals, double* 
           stats->launches[k] += 1;
         }
       const double pair_flops = 2.0 * JP * JP * (double)p.np;  // one 64 x 64 x np product
-      stats->flops[0] += (double)(p.nb - 1) * p.pairs * pair_flops;
-      stats->flops[2] += (double)(p.nb - 1) * p.pairs * pair_flops;  // upper bound: skipped pairs do none
+      stats->work[0] += (double)(p.nb - 1) * p.pairs * pair_flops;
+      stats->work[2] += (double)(p.nb - 1) * p.pairs * pair_flops;  // upper bound: skipped pairs do none
     }
   }
   if (stats) {
     stats->sweeps = sweeps;
+    stats->method = 0;
     PTD_CHECK_HIP(hipEventRecord(ev_last, st));
     PTD_CHECK_HIP(hipEventSynchronize(ev_last));
     (void)hipEventElapsedTime(&stats->total_ms, ev_first, ev_last);
@@ -626,8 +629,8 @@ int eigh_jacobi(const double* A, int64_t lda, int64_t n, double* evals, double* 
                      lambdas, use_chol ? 1 : 0);
   hipLaunchKernelGGL(jac_rank_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, norms, lambdas, (int)n,
                      inv, evals);
-  hipLaunchKernelGGL(jac_scatter_kernel, dim3((unsigned)ceil_div(n, 32), (unsigned)ceil_div(n, 32)), dim3(256), 0,
-                     st, G, p.np, (int)n, inv, norms, perm, evecs, ldv);
+  hipLaunchKernelGGL(jac_scatter_kernel, dim3((unsigned)ceil_div(k, 32), (unsigned)ceil_div(n, 32)), dim3(256), 0,
+                     st, G, p.np, (int)n, (int)k, inv, norms, perm, evecs, ldv);
   PTD_CHECK_LAUNCH("jacobi post");
   if (!converged) {
     set_error("ptd_eigh: no convergence after %d sweeps", sweeps);

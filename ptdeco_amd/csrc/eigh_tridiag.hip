@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #include "common.h"
 
@@ -476,7 +477,7 @@ __global__ void min_gap_kernel(const double* __restrict__ lam, int n, const doub
 // Chains of consecutive eigenvalues closer than ortol |T|: inverse iteration leaves their
 // vectors non-orthogonal at the level eps / gap, so they are orthogonalised explicitly
 // (modified Gram-Schmidt along the chain; one workgroup per chain, chains are rare and short).
-__global__ __launch_bounds__(256) void tridiag_chain_mgs_kernel(const double* __restrict__ lam, int n,
+__global__ __launch_bounds__(256) void tridiag_chain_mgs_kernel(const double* __restrict__ lam, int n, int nvec,
                                                                 const double* __restrict__ bounds, double ortol,
                                                                 double* __restrict__ Y, int64_t ldy) {
   __shared__ double red[4];
@@ -484,9 +485,9 @@ __global__ __launch_bounds__(256) void tridiag_chain_mgs_kernel(const double* __
   const int k = blockIdx.x, tid = threadIdx.x;
   const double thr = ortol * fmax(bounds[3], 2.2250738585072014e-308);
   const bool closeL = k > 0 && (lam[k] - lam[k - 1]) < thr;
-  const bool closeR = k < n - 1 && (lam[k + 1] - lam[k]) < thr;
+  const bool closeR = k < nvec - 1 && (lam[k + 1] - lam[k]) < thr;
   if (closeL || !closeR) return;  // not the first member of a chain
-  for (int kk = k + 1; kk < n && (lam[kk] - lam[kk - 1]) < thr; ++kk) {
+  for (int kk = k + 1; kk < nvec && (lam[kk] - lam[kk - 1]) < thr; ++kk) {
     for (int p = k; p <= kk; ++p) {  // p == kk: normalisation pass
       double s = 0.0;
       for (int i = tid; i < n; i += 256) s += Y[(int64_t)i * ldy + p] * Y[(int64_t)i * ldy + kk];
@@ -596,7 +597,12 @@ TridiagPlan tridiag_plan(int64_t n) {
 }
 
 // A (n x n, full symmetric) -> d, e, tau and the reflector panels in the workspace
-int sytrd_f64(const TridiagPlan& p, char* base, hipStream_t st) {
+// optional event timing of the SYMV launches (two events per column, summed by the caller)
+struct SymvTimer {
+  std::vector<hipEvent_t> ev;
+};
+
+int sytrd_f64(const TridiagPlan& p, char* base, SymvTimer* timer, hipStream_t st) {
   const int n = p.n;
   const int64_t ld = p.ld;
   double* Aw = reinterpret_cast<double*>(base + p.off_A);
@@ -631,8 +637,10 @@ int sytrd_f64(const TridiagPlan& p, char* base, hipStream_t st) {
       const int m = n - j - 1;
       if (m > 0) {
         const int rows = m + 2 * i;
+        if (timer) (void)hipEventRecord(timer->ev[2 * (size_t)j], st);
         hipLaunchKernelGGL(sytrd_symv_kernel, dim3((unsigned)ceil_div(rows, SROWS)), dim3(256), 0, st, Aw, ld, n,
                            j, i, nparts, colbuf, partial, Vp, Wp, ld, pbuf, cbuf, refl);
+        if (timer) (void)hipEventRecord(timer->ev[2 * (size_t)j + 1], st);
         nparts2 = (int)ceil_div(m, 64);
         hipLaunchKernelGGL(sytrd_wupd_kernel, dim3(nparts2), dim3(256), 0, st, n, j, i, colbuf, pbuf, cbuf, Vp, Wp,
                            ld, refl, wraw, partial2, d, e, taus);
@@ -674,8 +682,8 @@ int tridiag_eigenvalues(const TridiagPlan& p, char* base, hipStream_t st) {
 
 
 // eigenvectors of T for all eigenvalues into Y (= evecs, [n][ldv]), then Y <- Q Y
-int tridiag_vectors_and_backtransform(const TridiagPlan& p, char* base, double* Y, int64_t ldy, double ortol,
-                                      hipStream_t st) {
+int tridiag_vectors_and_backtransform(const TridiagPlan& p, char* base, int nvec, double* Y, int64_t ldy,
+                                      double ortol, hipStream_t st) {
   const int n = p.n;
   const int64_t ld = p.ld;
   double* d = reinterpret_cast<double*>(base + p.off_d);
@@ -694,10 +702,12 @@ int tridiag_vectors_and_backtransform(const TridiagPlan& p, char* base, double* 
   ws.U3 = reinterpret_cast<double*>(base + p.off_u3);
   ws.Lm = reinterpret_cast<double*>(base + p.off_lm);
   ws.sw = reinterpret_cast<unsigned char*>(base + p.off_sw);
-  hipLaunchKernelGGL(tridiag_invit_kernel, dim3((unsigned)ceil_div(n, 64)), dim3(64), 0, st, d, e, n, lam, bounds, n,
-                     ws, Y, ldy);
+  const double* lamk = lam + (n - nvec);  // the nvec largest eigenvalues, ascending
+  hipLaunchKernelGGL(tridiag_invit_kernel, dim3((unsigned)ceil_div(nvec, 64)), dim3(64), 0, st, d, e, n, lamk, bounds,
+                     nvec, ws, Y, ldy);
   if (ortol > 0.0)
-    hipLaunchKernelGGL(tridiag_chain_mgs_kernel, dim3((unsigned)n), dim3(256), 0, st, lam, n, bounds, ortol, Y, ldy);
+    hipLaunchKernelGGL(tridiag_chain_mgs_kernel, dim3((unsigned)nvec), dim3(256), 0, st, lamk, n, nvec, bounds, ortol,
+                       Y, ldy);
   PTD_CHECK_LAUNCH("tridiag_invit");
   // Y <- Q_0 Q_1 ... Q_last Y : apply the panels' block reflectors from the last to the first
   for (int pn = p.npanels - 1; pn >= 0; --pn) {
@@ -713,25 +723,26 @@ int tridiag_vectors_and_backtransform(const TridiagPlan& p, char* base, double* 
     if (rc != PTD_OK) return rc;
     hipLaunchKernelGGL(larft_kernel, dim3(1), dim3(64), 0, st, G, taus + j0, cols, Tm);
     // W1 = V Y  (cols x n)
-    PTD_CHECK_HIP(hipMemsetAsync(W1, 0, (size_t)NB * n * 8, st));
-    rc = gemm_f64(Vp + r0, ld, 1, Y + (int64_t)r0 * ldy, ldy, 1, W1, n, cols, n, mr, 1.0, true, 16, st);
+    PTD_CHECK_HIP(hipMemsetAsync(W1, 0, (size_t)NB * nvec * 8, st));
+    rc = gemm_f64(Vp + r0, ld, 1, Y + (int64_t)r0 * ldy, ldy, 1, W1, nvec, cols, nvec, mr, 1.0, true, 16, st);
     if (rc != PTD_OK) return rc;
     // W2 = T W1
-    rc = gemm_f64(Tm, NB, 1, W1, n, 1, W2, n, cols, n, cols, 1.0, false, 1, st);
+    rc = gemm_f64(Tm, NB, 1, W1, nvec, 1, W2, nvec, cols, nvec, cols, 1.0, false, 1, st);
     if (rc != PTD_OK) return rc;
     // Y[r0:, :] -= V^T W2
-    rc = gemm_f64(Vp + r0, 1, ld, W2, n, 1, Y + (int64_t)r0 * ldy, ldy, mr, n, cols, -1.0, true, 1, st);
+    rc = gemm_f64(Vp + r0, 1, ld, W2, nvec, 1, Y + (int64_t)r0 * ldy, ldy, mr, nvec, cols, -1.0, true, 1, st);
     if (rc != PTD_OK) return rc;
   }
   PTD_CHECK_LAUNCH("tridiag_backtransform");
   return PTD_OK;
 }
 
-// Full eigendecomposition through the tridiagonal route.  Returns PTD_ERR_UNSUPPORTED (and
+// Eigenvalues (all n) and the eigenvectors of the k largest ones ([n][k], ascending) through
+// the tridiagonal route.  Returns PTD_ERR_UNSUPPORTED (and
 // leaves the outputs untouched) when two eigenvalues are closer than `cluster_tol` * |T|: the
 // caller then uses the Jacobi solver, which needs no gap.
-int eigh_tridiag(const double* A, int64_t lda, int64_t n, double* evals, double* evecs, int64_t ldv, void* ws,
-                 size_t ws_bytes, double cluster_tol, hipStream_t st) {
+int eigh_tridiag(const double* A, int64_t lda, int64_t n, int64_t k, double* evals, double* evecs, int64_t ldv,
+                 void* ws, size_t ws_bytes, double cluster_tol, ptd_eigh_stats* stats, hipStream_t st) {
   const TridiagPlan p = tridiag_plan(n);
   if (ws_bytes < p.total) {
     set_error("eigh_tridiag: workspace %zu < required %zu bytes", ws_bytes, p.total);
@@ -739,28 +750,70 @@ int eigh_tridiag(const double* A, int64_t lda, int64_t n, double* evals, double*
   }
   char* base = static_cast<char*>(ws);
   double* Aw = reinterpret_cast<double*>(base + p.off_A);
+  SymvTimer timer;
+  hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+  if (stats) {
+    memset(stats, 0, sizeof(*stats));
+    stats->method = 1;
+    timer.ev.resize(2 * (size_t)n);
+    for (auto& e : timer.ev) PTD_CHECK_HIP(hipEventCreate(&e));
+    PTD_CHECK_HIP(hipEventCreate(&e0));
+    PTD_CHECK_HIP(hipEventCreate(&e1));
+    PTD_CHECK_HIP(hipEventCreate(&e2));
+    PTD_CHECK_HIP(hipEventRecord(e0, st));
+  }
+  auto cleanup = [&]() {
+    for (auto& e : timer.ev) (void)hipEventDestroy(e);
+    if (e0) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2); }
+  };
   hipLaunchKernelGGL(copy_pad_kernel, dim3(2048), dim3(256), 0, st, A, lda, (int)n, Aw, p.ld);
-  int rc = sytrd_f64(p, base, st);
-  if (rc != PTD_OK) return rc;
+  int rc = sytrd_f64(p, base, stats ? &timer : nullptr, st);
+  if (rc != PTD_OK) { cleanup(); return rc; }
+  if (stats) PTD_CHECK_HIP(hipEventRecord(e1, st));
   rc = tridiag_eigenvalues(p, base, st);
-  if (rc != PTD_OK) return rc;
+  if (rc != PTD_OK) { cleanup(); return rc; }
   double* lam = reinterpret_cast<double*>(base + p.off_lam);
   double* bounds = reinterpret_cast<double*>(base + p.off_bounds);
   const double ortol = 1e-7;  // neighbours closer than this (relative to |T|) are re-orthogonalised
-  hipLaunchKernelGGL(min_gap_kernel, dim3(1), dim3(1024), 0, st, lam, (int)n, bounds, ortol, bounds + 4);
+  // only the gaps that touch one of the k requested (largest) eigenvalues matter
+  const int first = (int)std::max<int64_t>(0, n - k - 1);
+  hipLaunchKernelGGL(min_gap_kernel, dim3(1), dim3(1024), 0, st, lam + first, (int)n - first, bounds, ortol,
+                     bounds + 4);
   double h_gap[2] = {0.0, 0.0};
   PTD_CHECK_HIP(hipMemcpyAsync(h_gap, bounds + 4, 16, hipMemcpyDeviceToHost, st));
   PTD_CHECK_HIP(hipStreamSynchronize(st));
   if (getenv("PTD_JACOBI_DEBUG"))
     fprintf(stderr, "[eigh_tridiag] n=%lld min relative gap %.3e, %d gaps below %.0e\n", (long long)n, h_gap[0],
             (int)h_gap[1], ortol);
-  if (n > 1 && (!(h_gap[0] > cluster_tol) || h_gap[1] > 64.0 + (double)n / 64.0)) {
+  if (n > 1 && (!(h_gap[0] > cluster_tol) || h_gap[1] > 64.0 + (double)n / 16.0)) {
     set_error("eigh_tridiag: clustered eigenvalues (min relative gap %.3e, %d close pairs)", h_gap[0], (int)h_gap[1]);
+    cleanup();
     return PTD_ERR_UNSUPPORTED;
   }
-  rc = tridiag_vectors_and_backtransform(p, base, evecs, ldv, h_gap[1] > 0.0 ? ortol : 0.0, st);
-  if (rc != PTD_OK) return rc;
+  rc = tridiag_vectors_and_backtransform(p, base, (int)k, evecs, ldv, h_gap[1] > 0.0 ? ortol : 0.0, st);
+  if (rc != PTD_OK) { cleanup(); return rc; }
   PTD_CHECK_HIP(hipMemcpyAsync(evals, lam, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
+  if (stats) {
+    PTD_CHECK_HIP(hipEventRecord(e2, st));
+    PTD_CHECK_HIP(hipEventSynchronize(e2));
+    float t_red = 0.f, t_tail = 0.f;
+    (void)hipEventElapsedTime(&t_red, e0, e1);
+    (void)hipEventElapsedTime(&t_tail, e1, e2);
+    stats->total_ms = t_red + t_tail;
+    for (int64_t j = 0; j + 1 < n; ++j) {
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, timer.ev[2 * (size_t)j], timer.ev[2 * (size_t)j + 1]);
+      stats->ms[0] += ms;
+      stats->launches[0] += 1;
+      const double m = (double)(n - j - 1);
+      stats->work[0] += 8.0 * m * (m - 1.0);  // trailing rows j+1.., columns j+2..: the bytes the SYMV must read
+    }
+    stats->ms[1] = t_red - stats->ms[0];   // per-column vector kernels + rank-2k updates + launch gaps
+    stats->launches[1] = 2 * (int)n;
+    stats->ms[3] = t_tail;
+    stats->work[2] = 4.0 / 3.0 * (double)n * (double)n * (double)n;  // rank-2k updates of the full trailing square
+    cleanup();
+  }
   return PTD_OK;
 }
 
@@ -778,7 +831,7 @@ int tridiagonalize_f64(const double* A, int64_t lda, int64_t n, double* d_out, d
   char* base = static_cast<char*>(ws);
   double* Aw = reinterpret_cast<double*>(base + p.off_A);
   hipLaunchKernelGGL(copy_pad_kernel, dim3(2048), dim3(256), 0, st, A, lda, (int)n, Aw, p.ld);
-  int rc = sytrd_f64(p, base, st);
+  int rc = sytrd_f64(p, base, nullptr, st);
   if (rc != PTD_OK) return rc;
   rc = tridiag_eigenvalues(p, base, st);
   if (rc != PTD_OK) return rc;

@@ -68,7 +68,8 @@ class CovarianceComputingLinearModule(torch.nn.Module):
     """Stand-in for an nn.Linear during the all-layers precompute pass (:166-208): same
     output, and the layer's feature covariance accumulates in HBM as a side effect."""
 
-    def __init__(self, weight: torch.nn.Parameter, bias: Optional[torch.nn.Parameter], decompose_in_float64: bool):
+    def __init__(self, weight: torch.nn.Parameter, bias: Optional[torch.nn.Parameter], decompose_in_float64: bool,
+                 top_k: Optional[int] = None):
         super().__init__()
         if weight.dim() != 2:
             raise RuntimeError("covariance precompute supports nn.Linear only (2-D weight), like the reference "
@@ -77,6 +78,7 @@ class CovarianceComputingLinearModule(torch.nn.Module):
         self.bias = bias
         self.in_features, self.out_features = weight.shape[1], weight.shape[0]
         self.cov = eng.Covariance(self.out_features, weight.device, decompose_in_float64)
+        self.top_k = top_k  # largest rank the search can ask for; None = all eigenvectors
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         rows = x.reshape(-1, self.in_features)
@@ -88,19 +90,27 @@ class CovarianceComputingLinearModule(torch.nn.Module):
 
     def get_eigenvectors(self) -> torch.Tensor:
         # the reference parks u on the CPU (:208); with 288 GB of HBM it stays resident
-        return self.cov.eigenvectors(EIGEN_DAMPEN_FACTOR).to(self.weight.dtype)
+        return self.cov.eigenvectors(EIGEN_DAMPEN_FACTOR, top_k=self.top_k).to(self.weight.dtype)
+
+
+def _max_candidate_rank(dim_in: int, dim_out: int, min_rank: int, reduction_factor: float) -> int:
+    """Largest rank the search of :407-408 can try (>= 1): eigenvectors below it are never read."""
+    ranks = _candidate_ranks(min(dim_in, dim_out), min_rank, reduction_factor)
+    return max(1, max(ranks)) if ranks else 1
 
 
 def _precompute_covariance_matrix_decompositions(*, module, submodule_names, num_data_steps, data_iterator, device,
-                                                 decompose_in_float64, shard: Shard) -> dict[str, torch.Tensor]:
+                                                 decompose_in_float64, shard: Shard, min_rank: int,
+                                                 reduction_factor: float) -> dict[str, torch.Tensor]:
     """:580-633."""
     originals = {}
     for name in submodule_names:
         old = module.get_submodule(name)
         originals[name] = old
         logger.info(f"Replacing {name} by covariance computing wrapper")
+        top_k = _max_candidate_rank(old.weight.shape[1], old.weight.shape[0], min_rank, reduction_factor)
         utils.replace_submodule_in_place(
-            module, name, CovarianceComputingLinearModule(old.weight, old.bias, decompose_in_float64))
+            module, name, CovarianceComputingLinearModule(old.weight, old.bias, decompose_in_float64, top_k))
     module.eval()
     stand_ins = [module.get_submodule(n) for n in submodule_names]
     with torch.no_grad():
@@ -118,8 +128,9 @@ def _precompute_covariance_matrix_decompositions(*, module, submodule_names, num
         u_dict[name] = m.get_eigenvectors() if shard.owns(i) else None
     for i, name in enumerate(submodule_names):
         if shard.active:
-            u_dict[name] = shard.broadcast_from_owner(u_dict[name], i, (stand_ins[i].out_features,) * 2,
-                                                      stand_ins[i].weight.dtype, device)
+            u_dict[name] = shard.broadcast_from_owner(
+                u_dict[name], i, (stand_ins[i].out_features, min(stand_ins[i].top_k, stand_ins[i].out_features)),
+                stand_ins[i].weight.dtype, device)
         logger.info(f"Replacing {name} by original linear")
         utils.replace_submodule_in_place(module, name, originals[name])
     del stand_ins
@@ -129,7 +140,8 @@ def _precompute_covariance_matrix_decompositions(*, module, submodule_names, num
 
 def _precompute_covariance_matrix_decompositions_in_splits(*, module, modules_to_decompose, num_splits,
                                                            num_data_steps, data_iterator, device,
-                                                           decompose_in_float64, shard: Shard):
+                                                           decompose_in_float64, shard: Shard, min_rank: int,
+                                                           reduction_factor: float):
     """:636-674 -- chunks of len // num_splits layers, each chunk consumes its own data steps."""
     chunk = len(modules_to_decompose) // num_splits
     if chunk == 0:
@@ -141,13 +153,15 @@ def _precompute_covariance_matrix_decompositions_in_splits(*, module, modules_to
         logger.info(f"Pre computing covariance matrices for {len(sub)} modules")
         u_dict.update(_precompute_covariance_matrix_decompositions(
             module=module, submodule_names=sub, num_data_steps=num_data_steps, data_iterator=data_iterator,
-            device=device, decompose_in_float64=decompose_in_float64, shard=shard))
+            device=device, decompose_in_float64=decompose_in_float64, shard=shard, min_rank=min_rank,
+            reduction_factor=reduction_factor))
     assert len(u_dict) == len(modules_to_decompose)
     return u_dict
 
 
 def _compute_covariance_matrix_decomposition(*, root_module, tap: eng.LayerTap, data_iterator, weight, num_data_steps,
-                                             device, decompose_in_float64, shard: Shard) -> torch.Tensor:
+                                             device, decompose_in_float64, shard: Shard,
+                                             top_k: Optional[int] = None) -> torch.Tensor:
     """:211-244 -- D model forwards, y = x W^T, Eyyt += y^T y / T, damped eigenvectors."""
     root_module.eval()
     logger.info("Using float64 for decomposition" if decompose_in_float64 else "Using float32 for decomposition")
@@ -160,7 +174,7 @@ def _compute_covariance_matrix_decomposition(*, root_module, tap: eng.LayerTap, 
         cov.add_inputs(tap.last_input_rows(), weight)
     if shard.active:
         cov.all_reduce(shard.group)
-    return cov.eigenvectors(EIGEN_DAMPEN_FACTOR)
+    return cov.eigenvectors(EIGEN_DAMPEN_FACTOR, top_k=top_k)
 
 
 def _compute_metrics(*, input_dict, root_module, tap: eng.LayerTap, orig_weight, deco_weight, loss_fn):
@@ -206,7 +220,7 @@ def _process_module(*, root_module, decomposed_submodule_name, data_iterator, lo
             u_matrix = _compute_covariance_matrix_decomposition(
                 root_module=root_module, tap=tap, data_iterator=data_iterator, weight=orig_weight,
                 num_data_steps=num_data_steps, device=device, decompose_in_float64=decompose_in_float64,
-                shard=shard)
+                shard=shard, top_k=_max_candidate_rank(dim_in, dim_out, min_rank, reduction_factor))
             logger.info(f"Computed u_matrix, {u_matrix.dtype=}")
         else:
             logger.info(f"Using pre-computed u_matrix, {u_matrix.dtype=}")
@@ -320,7 +334,8 @@ def decompose_in_place(
         u_dict = _precompute_covariance_matrix_decompositions_in_splits(
             module=module, modules_to_decompose=modules_to_decompose, num_splits=precomputing_covariance_num_splits,
             data_iterator=data_iterator, num_data_steps=num_data_steps, device=device,
-            decompose_in_float64=decompose_in_float64, shard=shard)
+            decompose_in_float64=decompose_in_float64, shard=shard, min_rank=min_rank,
+            reduction_factor=reduction_factor)
     else:
         logger.info("Skipping precomputing convariance matrices")
         u_dict = {}

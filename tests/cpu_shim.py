@@ -36,8 +36,9 @@ def cov_finalize(E, steps, damp_factor, ey=None):
     return full
 
 
-def eigh(A):
-    return torch.linalg.eigh(A)
+def eigh(A, k=None):
+    w, v = torch.linalg.eigh(A)
+    return (w, v) if k is None else (w, v[:, v.shape[1] - max(1, min(int(k), v.shape[1])):])
 
 
 def matmul(a, b, bias=None, alpha=1.0, out_dtype=None):

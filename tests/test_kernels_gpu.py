@@ -108,19 +108,26 @@ def test_cov_finalize(ops, n, edt, use_mean):
 
 # ---------------------------------------------------------------- eigh
 # The Jacobi solver orthogonalises to ~sqrt(n) eps; the tridiagonal route (inverse iteration)
-# leaves eps / relative-gap between neighbours (re-orthogonalised below a gap of 1e-5).
-ORTH_TOL = 1e-12 if os.environ.get("PTD_EIGH_METHOD", "jacobi") == "jacobi" else 2e-9
+# leaves eps / relative-gap between neighbours (re-orthogonalised below a gap of 1e-7 |A|).
+ORTH_TOL = {"jacobi": 1e-12, "tridiag": 5e-9, "auto": 5e-9}
+
+
+@pytest.fixture(params=["jacobi", "tridiag", "auto"])
+def method(request, monkeypatch):
+    monkeypatch.setenv("PTD_EIGH_METHOD", request.param)
+    return request.param
 
 
 def _check_eigh(ops, a, vec_tol=None):
     n = a.shape[0]
+    orth_tol = ORTH_TOL[os.environ.get("PTD_EIGH_METHOD", "auto")]
     w, v = ops.eigh(a.to(DEV))
     w, v = w.cpu(), v.cpu()
     w_ref, v_ref = torch.linalg.eigh(a)
     scale = max(w_ref.abs().max().item(), 1e-300)
     assert torch.all(w[1:] >= w[:-1]), "eigenvalues not ascending"
     assert (w - w_ref).abs().max().item() <= 1e-12 * scale
-    assert (v.T @ v - torch.eye(n, dtype=torch.float64)).abs().max().item() <= ORTH_TOL
+    assert (v.T @ v - torch.eye(n, dtype=torch.float64)).abs().max().item() <= orth_tol
     assert (a @ v - v * w).abs().max().item() <= 1e-11 * scale
     if vec_tol is not None:
         assert (orc.canonical_sign(v) - orc.canonical_sign(v_ref)).abs().max().item() <= vec_tol
@@ -128,14 +135,14 @@ def _check_eigh(ops, a, vec_tol=None):
 
 
 @pytest.mark.parametrize("n", [1, 2, 5, 31, 32, 64, 65, 100, 200, 512])
-def test_eigh_random_covariance(ops, n):
+def test_eigh_random_covariance(ops, n, method):
     y = _rand((2 * n + 3, n), 100 + n).double() * torch.logspace(0, -2, n, dtype=torch.float64)
     a = y.T @ y / y.shape[0]
     a = a + torch.eye(n, dtype=torch.float64) * (0.01 * torch.diag(a).mean())
     _check_eigh(ops, a)
 
 
-def test_eigh_known_answer_geometric_spectrum(ops):
+def test_eigh_known_answer_geometric_spectrum(ops, method):
     """Eigenpairs known in closed form: A = H diag(s) H with H a Householder reflector
     (no RNG, no LAPACK in the expected values); gap at every cut."""
     n = 256
@@ -148,10 +155,11 @@ def test_eigh_known_answer_geometric_spectrum(ops):
     w, v = _check_eigh(ops, a)
     assert (w - s).abs().max().item() <= 1e-13
     # eigenvector accuracy ~ eps * |A| / gap; the smallest gap here is 6.6e-7
-    assert (orc.canonical_sign(v) - orc.canonical_sign(h)).abs().max().item() <= 1e-9
+    assert (orc.canonical_sign(v) - orc.canonical_sign(h)).abs().max().item() <= (1e-9 if method == "jacobi" else 1e-7)
 
 
-def test_eigh_rank_deficient_and_dead_feature(ops):
+def test_eigh_rank_deficient_and_dead_feature(ops, method):
+    # 56-fold zero eigenvalue: the tridiagonal route must detect the cluster and hand over to Jacobi
     n = 96
     y = _rand((40, n), 9).double()  # rank 40 < n, no damping
     y[:, 17] = 0.0                  # dead feature: zero row and column
@@ -164,17 +172,58 @@ def test_eigh_rank_deficient_and_dead_feature(ops):
     assert (a @ v - v * w).abs().max().item() <= 1e-10 * w_ref.max().item()
 
 
-def test_eigh_matches_golden_eigenvectors(ops):
+def test_eigh_matches_golden_eigenvectors(ops, method):
     z = gio.npz("prim")
     for kind in ("lin", "conv"):
         e = gio.t(z[f"{kind}.dwain.f64.E"]).clone()
         e = e + torch.eye(32, dtype=torch.float64) * (orc.DAMP_FACTOR * torch.diag(e).mean())
         _, v = ops.eigh(e.to(DEV))
         u_ref = gio.t(z[f"{kind}.dwain.f64.u"])
-        assert (orc.canonical_sign(v.cpu()) - u_ref).abs().max().item() <= 1e-9
+        assert (orc.canonical_sign(v.cpu()) - u_ref).abs().max().item() <= 1e-8
 
 
-def test_eigh_mid_size_against_lapack(ops):
+@pytest.mark.parametrize("n,k", [(64, 1), (100, 37), (512, 256), (1024, 512), (1024, 1024)])
+def test_eigh_topk(ops, n, k, method):
+    """Only the k largest eigenpairs' vectors: same columns as the tail of the full decomposition."""
+    y = _rand((2 * n + 3, n), 300 + n).double() * torch.logspace(0, -2, n, dtype=torch.float64)
+    a = y.T @ y / y.shape[0]
+    a = a + torch.eye(n, dtype=torch.float64) * (0.01 * torch.diag(a).mean())
+    w, v = ops.eigh(a.to(DEV), k)
+    w, v = w.cpu(), v.cpu()
+    assert v.shape == (n, k)
+    w_ref, v_ref = torch.linalg.eigh(a)
+    assert (w - w_ref).abs().max().item() <= 1e-12 * w_ref.max().item()
+    tol = ORTH_TOL[method]
+    assert (v.T @ v - torch.eye(k, dtype=torch.float64)).abs().max().item() <= tol
+    assert (a @ v - v * w[n - k:]).abs().max().item() <= 1e-11 * w_ref.max().item()
+    p, p_ref = v @ v.T, v_ref[:, n - k:] @ v_ref[:, n - k:].T
+    assert (p - p_ref).norm().item() <= 1e-6 * math.sqrt(k)
+
+
+def test_eigh_dense_low_end_uses_tridiagonal_route_for_top_half(ops, monkeypatch):
+    """C2-like spectrum: hundreds of eigenvalue pairs closer than 1e-7 |A| at the LOW end only.
+    Asking for the top half must stay on the tridiagonal route (and be accurate)."""
+    monkeypatch.setenv("PTD_EIGH_METHOD", "tridiag")
+    n = 1024
+    g = torch.Generator().manual_seed(5)
+    q, _ = torch.linalg.qr(torch.randn(n, n, generator=g, dtype=torch.float64))
+    lam = torch.cat([1e-3 + 1e-9 * torch.arange(n // 2, dtype=torch.float64),      # dense cluster
+                     torch.logspace(-2, 0, n // 2, dtype=torch.float64)])           # separated top half
+    a = (q * lam) @ q.T
+    a = 0.5 * (a + a.T)
+    ops.EIGH_PROFILE = []
+    try:
+        w, v = ops.eigh(a.to(DEV), n // 2)
+        prof = ops.EIGH_PROFILE[0]
+    finally:
+        ops.EIGH_PROFILE = None
+    assert prof["method"] == 1, "fell back to Jacobi"
+    v = v.cpu()
+    assert (v.T @ v - torch.eye(n // 2, dtype=torch.float64)).abs().max().item() <= 5e-9
+    assert (a @ v - v * w.cpu()[n // 2:]).abs().max().item() <= 1e-11
+
+
+def test_eigh_mid_size_against_lapack(ops, method):
     n = 1024
     y = _rand((2048, n), 77).double() * torch.logspace(0, -2, n, dtype=torch.float64)
     a = y.T @ y / 2048
