@@ -55,12 +55,14 @@ class LayerTap:
         self.layer = layer
         self.is_conv = isinstance(layer, torch.nn.Conv2d)
         self._last: Optional[torch.Tensor] = None
+        self.last_features: Optional[torch.Tensor] = None  # [T, n_out] of the last use_dense forward
         self._handle = layer.register_forward_pre_hook(self._record)
 
     def _record(self, _module, args) -> None:
         self._last = args[0]
 
     def close(self) -> None:
+        self.use_module_forward()
         self._handle.remove()
         self._last = None
 
@@ -86,6 +88,68 @@ class LayerTap:
             self.layer.weight.copy_(w2d[:, :, None, None])
         else:
             self.layer.weight.copy_(w2d)
+
+    # -- the tapped layer's own forward on the HIP kernels ---------------------------------
+    # The reference evaluates a candidate by copying W~ = (U V)^T into the live layer and
+    # running the model, then copying W back and running it again (dwain.py:263-267,
+    # falor.py:223-227).  The same two functions are evaluated here without touching the
+    # weight: the candidate through its rank-r pair (x U) uk^T + b -- exactly what will be
+    # deployed, 2 T r (n_in + n_out) instead of 2 T n_in n_out flops and no W~ product -- and
+    # the original through the f32/bf16 MFMA GEMM.  Only plain Linear / stride-1 1x1 conv
+    # layers in f32 or bf16 qualify; anything else keeps the module's own forward.
+    def _plain(self) -> bool:
+        l = self.layer
+        if l.weight.dtype not in (torch.float32, torch.bfloat16) or not l.weight.is_cuda:
+            return False
+        if self.is_conv:
+            return (tuple(l.stride) == (1, 1) and tuple(l.dilation) == (1, 1) and l.padding_mode == "zeros"
+                    and l.padding in ((0, 0), 0, "valid"))
+        return True
+
+    def _rows_in(self, x: torch.Tensor) -> torch.Tensor:
+        return x.permute(0, 2, 3, 1).reshape(-1, self.n_in) if self.is_conv else x.reshape(-1, self.n_in)
+
+    def _rows_out(self, y: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+        if self.is_conv:
+            b, _, h, w = x.shape
+            return y.reshape(b, h, w, y.shape[-1]).permute(0, 3, 1, 2)
+        return y.reshape(*x.shape[:-1], y.shape[-1])
+
+    def use_dense(self, weight2d: torch.Tensor) -> bool:
+        """Layer forward = x weight2d^T + bias on the matrix cores.  Returns False if unsupported."""
+        if not self._plain():
+            return False
+        bias = self.layer.bias
+
+        def fwd(x):
+            if x.dtype != weight2d.dtype:
+                self.last_features = None
+                return type(self.layer).forward(self.layer, x)
+            y = ops.matmul(self._rows_in(x), weight2d.T)
+            self.last_features = y  # x W^T without bias: what the covariance accumulates
+            return self._rows_out(y + bias if bias is not None else y, x)
+
+        self.layer.forward = fwd
+        return True
+
+    def use_pair(self, big_u: torch.Tensor, uk: torch.Tensor) -> bool:
+        """Layer forward = (x U) uk^T + bias (the rank-r candidate).  Returns False if unsupported."""
+        if not self._plain():
+            return False
+        first = big_u.T.contiguous()  # [r, n_in]
+        bias = self.layer.bias
+
+        def fwd(x):
+            if x.dtype != first.dtype:
+                return type(self.layer).forward(self.layer, x)
+            return self._rows_out(ops.lowrank_forward(self._rows_in(x), first, uk, bias), x)
+
+        self.layer.forward = fwd
+        return True
+
+    def use_module_forward(self) -> None:
+        self.layer.__dict__.pop("forward", None)
+        self.last_features = None
 
 
 class Covariance:
@@ -131,15 +195,16 @@ class Covariance:
         return u
 
 
-def build_factors(weight2d: torch.Tensor, u: torch.Tensor, rank: int, dtype: torch.dtype):
-    """Top-`rank` eigenvectors -> (uk [n, r], U [n_in, r], W~ [n, n_in]) in `dtype`.
+def build_factors(weight2d: torch.Tensor, u: torch.Tensor, rank: int, dtype: torch.dtype, dense: bool = True):
+    """Top-`rank` eigenvectors -> (uk [n, r], U [n_in, r], W~ [n, n_in] or None) in `dtype`.
 
-    U = W^T uk and W~ = (U uk^T)^T = uk U^T (dwain.py:424-429; falor.py:346-348)."""
+    U = W^T uk and W~ = (U uk^T)^T = uk U^T (dwain.py:424-429; falor.py:346-348); W~ is only
+    formed when the candidate cannot be evaluated through the pair (`dense`)."""
     n = u.shape[1]
     uk = u[:, n - rank:].to(dtype).contiguous()
     w = weight2d if weight2d.dtype == dtype else weight2d.to(dtype)
     big_u = ops.matmul(w.T, uk)
-    w_deco = ops.matmul(uk, big_u.T)
+    w_deco = ops.matmul(uk, big_u.T) if dense else None
     return uk, big_u, w_deco
 
 

@@ -508,29 +508,37 @@ __global__ __launch_bounds__(256) void tridiag_chain_mgs_kernel(const double* __
   }
 }
 
-// ---- compact WY: T factor of a panel's block reflector from G = V V^T (nb x nb) and tau
-__global__ __launch_bounds__(64) void larft_kernel(const double* __restrict__ G, const double* __restrict__ tau,
-                                                  int cols, double* __restrict__ Tm) {
-  __shared__ double T[NB][NB + 1];
-  __shared__ double Gs[NB][NB + 1];
-  const int r = threadIdx.x;
-  for (int c = 0; c < NB; ++c) {
-    T[r][c] = 0.0;
-    Gs[c][r] = G[c * NB + r];  // coalesced read of row c
+// ---- compact WY without forming T:  the block reflector of a panel is I - V^T T V with
+// T^-1 = striu(V V^T) + diag(1 / tau)  (Joffrain et al., "Accumulating Householder
+// transformations, revisited"), so W2 = T W1 is one 64-row upper-triangular solve per column
+// of W1.  One thread per column, the column lives in registers, the 64 x 64 matrix in LDS
+// (every lane reads the same entry: broadcast).  tau_i == 0 (identity reflector) gives a zero row.
+__global__ __launch_bounds__(256) void wy_solve_kernel(const double* __restrict__ G, const double* __restrict__ tau,
+                                                      int cols, const double* __restrict__ W1,
+                                                      double* __restrict__ W2, int nvec) {
+  __shared__ double Ti[NB][NB + 1];
+  __shared__ double tl[NB];
+  const int tid = threadIdx.x;
+  for (int e = tid; e < NB * NB; e += 256) {
+    const int r = e >> 6, c = e & 63;
+    Ti[r][c] = (r < cols && c < cols && c > r) ? G[r * NB + c] : 0.0;
   }
+  if (tid < NB) tl[tid] = tid < cols ? tau[tid] : 0.0;
   __syncthreads();
-  for (int i = 0; i < cols; ++i) {
-    const double ti = tau[i];
-    if (r < i) {
-      double s = 0.0;
-      for (int q = r; q < i; ++q) s += T[r][q] * Gs[q][i];
-      T[r][i] = -ti * s;
-    } else if (r == i) {
-      T[r][i] = ti;
-    }
-    __syncthreads();
+  const int c = blockIdx.x * 256 + tid;
+  if (c >= nvec) return;
+  double x[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) x[i] = W1[(int64_t)i * nvec + c];
+#pragma unroll
+  for (int i = NB - 1; i >= 0; --i) {
+    double sacc = x[i];
+#pragma unroll
+    for (int q = i + 1; q < NB; ++q) sacc -= Ti[i][q] * x[q];
+    x[i] = sacc * tl[i];  // (1 / tau_i)^-1; rows >= cols and tau == 0 give 0
   }
-  for (int c = 0; c < NB; ++c) Tm[c * NB + r] = T[c][r];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) W2[(int64_t)i * nvec + c] = x[i];
 }
 
 __global__ void square_kernel(const double* __restrict__ e, int n, double* __restrict__ e2) {
@@ -693,7 +701,6 @@ int tridiag_vectors_and_backtransform(const TridiagPlan& p, char* base, int nvec
   double* taus = reinterpret_cast<double*>(base + p.off_tau);
   double* Vall = reinterpret_cast<double*>(base + p.off_V);
   double* G = reinterpret_cast<double*>(base + p.off_G);
-  double* Tm = reinterpret_cast<double*>(base + p.off_T);
   double* W1 = reinterpret_cast<double*>(base + p.off_W1);
   double* W2 = reinterpret_cast<double*>(base + p.off_W2);
   InvitWs ws;
@@ -721,14 +728,14 @@ int tridiag_vectors_and_backtransform(const TridiagPlan& p, char* base, int nvec
     PTD_CHECK_HIP(hipMemsetAsync(G, 0, (size_t)NB * NB * 8, st));
     int rc = gemm_f64(Vp + r0, ld, 1, Vp + r0, 1, ld, G, NB, cols, cols, mr, 1.0, true, 64, st);
     if (rc != PTD_OK) return rc;
-    hipLaunchKernelGGL(larft_kernel, dim3(1), dim3(64), 0, st, G, taus + j0, cols, Tm);
+
     // W1 = V Y  (cols x n)
     PTD_CHECK_HIP(hipMemsetAsync(W1, 0, (size_t)NB * nvec * 8, st));
     rc = gemm_f64(Vp + r0, ld, 1, Y + (int64_t)r0 * ldy, ldy, 1, W1, nvec, cols, nvec, mr, 1.0, true, 16, st);
     if (rc != PTD_OK) return rc;
-    // W2 = T W1
-    rc = gemm_f64(Tm, NB, 1, W1, nvec, 1, W2, nvec, cols, nvec, cols, 1.0, false, 1, st);
-    if (rc != PTD_OK) return rc;
+    // W2 = T W1 by the triangular solve with T^-1 = striu(G) + diag(1 / tau)
+    hipLaunchKernelGGL(wy_solve_kernel, dim3((unsigned)ceil_div(nvec, 256)), dim3(256), 0, st, G, taus + j0, cols, W1,
+                       W2, nvec);
     // Y[r0:, :] -= V^T W2
     rc = gemm_f64(Vp + r0, 1, ld, W2, nvec, 1, Y + (int64_t)r0 * ldy, ldy, mr, nvec, cols, -1.0, true, 1, st);
     if (rc != PTD_OK) return rc;

@@ -134,7 +134,6 @@ def _precompute_covariance_matrix_decompositions(*, module, submodule_names, num
         logger.info(f"Replacing {name} by original linear")
         utils.replace_submodule_in_place(module, name, originals[name])
     del stand_ins
-    utils.free_gpu_reserved_memory()
     return u_dict
 
 
@@ -166,25 +165,38 @@ def _compute_covariance_matrix_decomposition(*, root_module, tap: eng.LayerTap, 
     root_module.eval()
     logger.info("Using float64 for decomposition" if decompose_in_float64 else "Using float32 for decomposition")
     cov = eng.Covariance(weight.shape[0], device, decompose_in_float64)
+    tap.use_dense(weight)
     for step in range(num_data_steps):
         batch = next(data_iterator)
         if not shard.mine(step):
             continue
         root_module(utils.to_device(batch, device))
-        cov.add_inputs(tap.last_input_rows(), weight)
+        if tap.last_features is not None:  # the layer's forward already formed y = x W^T on the GPU
+            cov.add_features(tap.last_features)
+        else:
+            cov.add_inputs(tap.last_input_rows(), weight)
     if shard.active:
         cov.all_reduce(shard.group)
     return cov.eigenvectors(EIGEN_DAMPEN_FACTOR, top_k=top_k)
 
 
-def _compute_metrics(*, input_dict, root_module, tap: eng.LayerTap, orig_weight, deco_weight, loss_fn):
-    """:247-278 -- (nsr, ppl_deco, ppl_diff) as one f64 device tensor (single host sync per step)."""
+def _compute_metrics(*, input_dict, root_module, tap: eng.LayerTap, orig_weight, candidate, loss_fn):
+    """:247-278 -- (nsr, ppl_deco, ppl_diff) as one f64 device tensor (single host sync per step).
+    `candidate` = (uk, U, W~): evaluated through the rank-r pair when the layer qualifies
+    (LayerTap.use_pair), else by copying W~ into the layer like the reference."""
     assert isinstance(input_dict, dict)
     root_module.eval()
-    tap.set_weight(deco_weight)
-    y_deco = root_module(input_dict)
-    tap.set_weight(orig_weight)
-    y_orig = root_module(input_dict)
+    uk, big_u, deco_weight = candidate
+    if deco_weight is None:
+        tap.use_pair(big_u, uk)
+        y_deco = root_module(input_dict)
+        tap.use_dense(orig_weight)
+        y_orig = root_module(input_dict)
+    else:
+        tap.set_weight(deco_weight)
+        y_deco = root_module(input_dict)
+        tap.set_weight(orig_weight)
+        y_orig = root_module(input_dict)
     loss_deco = loss_fn(input_dict, y_deco)
     loss_orig = loss_fn(input_dict, y_orig)
     nsr = utils.calc_per_channel_noise_to_signal_ratio(y=y_orig, x=y_deco, non_channel_dim=(0, 1), mode="mean")
@@ -225,6 +237,7 @@ def _process_module(*, root_module, decomposed_submodule_name, data_iterator, lo
         else:
             logger.info(f"Using pre-computed u_matrix, {u_matrix.dtype=}")
 
+        tap.use_module_forward()
         # candidates that change the parameter count, in schedule order (:407-421)
         baseline_params = _get_params_for_proportion(1.0, dim_in, dim_out)
         candidates = []
@@ -235,6 +248,7 @@ def _process_module(*, root_module, decomposed_submodule_name, data_iterator, lo
                 continue
             candidates.append((rank_new, drop))
 
+        fast = tap.use_dense(orig_weight)  # the tapped layer runs on the HIP GEMMs while it is analysed
         # metric batches are consumed in candidate order; with several GPUs candidate c is
         # evaluated by rank c % G on exactly the batches the sequential order gives it
         sums = torch.zeros((max(len(candidates), 1), 3), dtype=torch.float64, device=device)
@@ -242,11 +256,10 @@ def _process_module(*, root_module, decomposed_submodule_name, data_iterator, lo
             batches = [next(metric_iterator) for _ in range(num_metric_steps)]
             if not shard.mine(c):
                 continue
-            _, _, deco_weight = eng.build_factors(orig_weight, u_matrix, rank_new, orig_dtype)
+            candidate = eng.build_factors(orig_weight, u_matrix, rank_new, orig_dtype, dense=not fast)
             for batch in batches:
                 sums[c] += _compute_metrics(input_dict=utils.to_device(batch, device), root_module=root_module,
-                                            tap=tap, orig_weight=orig_weight, deco_weight=deco_weight,
-                                            loss_fn=loss_fn)
+                                            tap=tap, orig_weight=orig_weight, candidate=candidate, loss_fn=loss_fn)
         if shard.active:
             shard.all_reduce_small(sums)
         table = (sums / num_metric_steps).tolist()  # the one host sync of the rank search
@@ -339,7 +352,9 @@ def decompose_in_place(
     else:
         logger.info("Skipping precomputing convariance matrices")
         u_dict = {}
-    utils.free_gpu_reserved_memory()
+    # the reference calls free_gpu_reserved_memory() (gc.collect + empty_cache, ~25 ms and a
+    # re-malloc of every workspace) here and after every layer (:737, 787, 795); with 288 GB of
+    # HBM the caching allocator simply keeps the workspaces.
 
     decompose_config: dict[str, Any] = {}
     decomposed_submodules: list[str] = []

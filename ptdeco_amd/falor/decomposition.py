@@ -70,13 +70,21 @@ def _compute_decompositon_of_covariance_matrix(*, root_module, tap: eng.LayerTap
     return cov.eigenvectors(damp, use_mean=use_mean)
 
 
-def _compute_metrics(*, x, root_module, tap: eng.LayerTap, orig_weight, deco_weight) -> torch.Tensor:
-    """:211-233 -- (nsr, kl) as one f64 device tensor."""
+def _compute_metrics(*, x, root_module, tap: eng.LayerTap, orig_weight, candidate) -> torch.Tensor:
+    """:211-233 -- (nsr, kl) as one f64 device tensor.  `candidate` = (uk, U, W~); W~ None means
+    "evaluate through the rank-r pair" (see LayerTap.use_pair)."""
     root_module.eval()
-    tap.set_weight(deco_weight)
-    y_deco = root_module(x)
-    tap.set_weight(orig_weight)
-    y_orig = root_module(x)
+    uk, big_u, deco_weight = candidate
+    if deco_weight is None:
+        tap.use_pair(big_u, uk)
+        y_deco = root_module(x)
+        tap.use_dense(orig_weight)
+        y_orig = root_module(x)
+    else:
+        tap.set_weight(deco_weight)
+        y_deco = root_module(x)
+        tap.set_weight(orig_weight)
+        y_orig = root_module(x)
     nsr = utils.calc_per_channel_noise_to_signal_ratio(y=y_orig, x=y_deco, non_channel_dim=(0,))
     kl = utils.calc_kl_loss(y_deco, y_orig)
     return torch.stack([nsr, kl])
@@ -106,17 +114,21 @@ def _process_module(*, root_module, decomposed_submodule_name, data_iterator, ns
             num_data_steps=num_data_steps, device=device, use_float64=use_float64, use_mean=use_mean,
             use_damping=use_damping)
 
+        # the tapped layer runs on the HIP GEMMs while it is analysed (f32 models only: falor builds
+        # its factors in float32, falor.py:346)
+        fast = orig_weight.dtype == torch.float32 and tap.use_dense(orig_weight)
         # bisection: each decision feeds the next candidate, so one host sync per candidate
         rank_best = full_rank
         nsr_best = kl_best = nsr_new = kl_new = 0.0
         uk = big_u = None
         for i, rank_width in enumerate(_bisection_widths(full_rank), start=1):
             rank_new = rank_best - rank_width
-            uk, big_u, deco_weight = eng.build_factors(orig_weight, u, rank_new, torch.float32)  # :346-348
+            candidate = eng.build_factors(orig_weight, u, rank_new, torch.float32, dense=not fast)  # :346-348
+            uk, big_u, _ = candidate
             acc = torch.zeros(2, dtype=torch.float64, device=device)
             for _ in range(num_metric_steps):
                 acc += _compute_metrics(x=next(data_iterator).to(device), root_module=root_module, tap=tap,
-                                        orig_weight=orig_weight, deco_weight=deco_weight)
+                                        orig_weight=orig_weight, candidate=candidate)
             nsr_new, kl_new = (acc / num_metric_steps).tolist()
             accepted = nsr_new < nsr_final_threshold and kl_new < kl_final_threshold
             if accepted:
@@ -127,6 +139,7 @@ def _process_module(*, root_module, decomposed_submodule_name, data_iterator, ns
                 trace.append({"layer": name, "i": i, "width": rank_width, "rank": rank_new, "nsr": nsr_new,
                               "kl": kl_new, "accepted": accepted})
         assert uk is not None
+        tap.use_module_forward()
         tap.set_weight(orig_weight)
 
         proportion = rank_best / full_rank
