@@ -29,17 +29,20 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   return v;
 }
 
-// scalars of the current reflector, shared between the kernels of one column
-struct Refl {
-  double tau, beta, scale, alpha;
-};
-
-// Per column j (reflector i of its panel) three multi-workgroup launches:
-//   colupd  finalises the previous reflector's w (w += alpha2 v), forms the updated column j
-//   symv    reflector scalars + v, then  p = A[R][R] v  and  c1 = W^T v, c2 = V^T v  as extra rows
-//   wupd    w_raw = tau (p - V c1 - W c2), partial sums of w_raw . v
-// colbuf is indexed by the GLOBAL row / column index (entries j .. n-1 valid, zero padding
-// beyond n) so that 16-byte loads stay aligned.
+// Per column j (reflector i of its panel) TWO multi-workgroup launches:
+//   symv(j)     x_j = base_j - delta_j v_{j-1} on the fly;  unscaled products  sd[r] = A[r][j+2:] . x_j[j+2:]
+//               for the trailing rows r and, as extra rows of the same product, for W_k and V_k;
+//               q[r] = row[j+1];  partial sums of x_j^2  (the reflector's norm)
+//   alpha(j+1)  everything between two SYMVs: reflector scalars of column j, v_j, the finalised
+//               w_{j-1}, w_raw_j = tau (p - V c1 - W c2), partial sums of w_raw_j . v_j, and the
+//               updated column j+1 ("base", see below)
+// Global dependencies per column are thereby cut to two (the norm and W^T v / V^T v), the third
+// one (alpha2 = -tau/2 w_raw.v, which turns w_raw into w) is deferred algebraically:
+//   w_j = w_raw_j + alpha2_j v_j  enters column j+1 as  x_{j+1} = base_{j+1} - 2 alpha2_j v_j
+// (v_j[j+1] = 1), and enters W^T v as  c1[i-1] = w_raw . v + alpha2 (v_{j-1} . v);  both
+// corrections are applied by the consumer, which can sum the producer's partial dot products.
+// colbuf is indexed by the GLOBAL row / column index (zero padding beyond n keeps 16-byte loads
+// aligned and harmless).
 
 // sum of `count` partial values, computed by one full wave (call with all 64 lanes of a wave)
 __device__ __forceinline__ double wave_total(const double* __restrict__ v, int count, int lane) {
@@ -48,82 +51,46 @@ __device__ __forceinline__ double wave_total(const double* __restrict__ v, int c
   return wave_sum_d(t);
 }
 
-// ---- K1: grid ceil((n - j) / 64) x 256 threads; lane = row, the four waves split the k range
-__global__ __launch_bounds__(256) void sytrd_colupd_kernel(const double* __restrict__ A, int64_t ld, int n, int j,
-                                                           int i, const double* __restrict__ Vp,
-                                                           double* __restrict__ Wp, int64_t ldv,
-                                                           const double* __restrict__ wraw,
-                                                           const double* __restrict__ partial2, int nparts2,
-                                                           const Refl* __restrict__ refl,
-                                                           double* __restrict__ colbuf, double* __restrict__ partial) {
-  __shared__ double wj[NB], vj[NB];
-  __shared__ double part[4][64];
-  __shared__ double a2s;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int r = j + blockIdx.x * 64 + lane;
-  if (i > 0) {
-    if (wid == 0) {
-      const double t = wave_total(partial2, nparts2, lane);
-      if (lane == 0) a2s = -0.5 * refl->tau * t;
-    }
-    __syncthreads();
-    const double a2 = a2s;
-    // finalise w_{i-1} on this workgroup's rows (its support is rows >= j)
-    if (wid == 0 && r < n) Wp[(int64_t)(i - 1) * ldv + r] = wraw[r] + a2 * Vp[(int64_t)(i - 1) * ldv + r];
-    if (tid < i) {
-      vj[tid] = Vp[(int64_t)tid * ldv + j];
-      wj[tid] = (tid == i - 1) ? wraw[j] + a2 * Vp[(int64_t)(i - 1) * ldv + j] : Wp[(int64_t)tid * ldv + j];
-    }
-    __syncthreads();
-  }
-  double s = 0.0;
-  if (r < n)
-    for (int k = wid; k < i; k += 4) s += Vp[(int64_t)k * ldv + r] * wj[k] + Wp[(int64_t)k * ldv + r] * vj[k];
-  part[wid][lane] = s;
-  __syncthreads();
-  if (wid == 0) {
-    double sq = 0.0;
-    if (r < n) {
-      const double a = A[(int64_t)j * ld + r] - ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]));
-      colbuf[r] = a;
-      if (r >= j + 2) sq = a * a;
-    }
-    sq = wave_sum_d(sq);
-    if (lane == 0) partial[blockIdx.x] = sq;
-  }
+struct ColState {
+  double delta;  // 2 alpha2 of the previous column of the panel (0 for the panel's first column)
+  double alpha;  // x_j[j+1]
+};
+
+// first column of a panel: base = A[j][j:]
+__global__ void sytrd_colinit_kernel(const double* __restrict__ A, int64_t ld, int n, int j,
+                                     double* __restrict__ colbuf) {
+  const int r = j + blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n) colbuf[r] = A[(int64_t)j * ld + r];
 }
 
-// ---- K2: rows 0 .. m-1 are matrix rows j+1 .. n-1, rows m .. m+i-1 are W_k (-> c1), rows
-// m+i .. m+2i-1 are V_k (-> c2).  Every row's result is  row[j+1] + scale * sum_{c >= j+2} row[c] x[c].
 constexpr int SROWS = 4;  // rows per workgroup; its four waves split the columns
 
+// symv: rows 0 .. m-1 are matrix rows j+1 .. n-1, rows m .. m+i-1 are W_k (k = i-1: w_raw of the
+// previous column), rows m+i .. m+2i-1 are V_k.
 __global__ __launch_bounds__(256) void sytrd_symv_kernel(const double* __restrict__ A, int64_t ld, int n, int j,
-                                                         int i, int nparts, const double* __restrict__ colbuf,
-                                                         const double* __restrict__ partial,
-                                                         double* __restrict__ Vp, const double* __restrict__ Wp,
-                                                         int64_t ldv, double* __restrict__ pbuf,
-                                                         double* __restrict__ cbuf, Refl* __restrict__ refl) {
-  __shared__ Refl sh;
+                                                         int i, const double* __restrict__ colbuf,
+                                                         const double* __restrict__ Vp,
+                                                         const double* __restrict__ Wp, int64_t ldv,
+                                                         const double* __restrict__ wraw_prev,
+                                                         const double* __restrict__ partial2, int nparts2,
+                                                         const double* __restrict__ taus,
+                                                         double* __restrict__ sd, double* __restrict__ qv,
+                                                         double* __restrict__ cb, double* __restrict__ px2,
+                                                         ColState* __restrict__ cs) {
   __shared__ double part[4][SROWS];
+  __shared__ double delta_s;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   if (wid == 0) {
-    const double xn2 = wave_total(partial, nparts, lane);
-    if (lane == 0) {
-    const double alpha = colbuf[j + 1];
-    Refl r;
-    r.alpha = alpha;
-    if (xn2 == 0.0) {
-      r.tau = 0.0; r.beta = alpha; r.scale = 0.0;
-    } else {
-      const double nrm = sqrt(alpha * alpha + xn2);
-      r.beta = alpha >= 0.0 ? -nrm : nrm;
-      r.tau = (r.beta - alpha) / r.beta;
-      r.scale = 1.0 / (alpha - r.beta);
+    double dl = 0.0;
+    if (i > 0) {
+      const double t = wave_total(partial2, nparts2, lane);
+      dl = -taus[j - 1] * t;  // 2 * alpha2_{j-1}
     }
-    sh = r;
-    if (blockIdx.x == 0) *refl = r;
-    }
+    if (lane == 0) delta_s = dl;
   }
+  __syncthreads();
+  const double delta = delta_s;
+  const double* vprev = Vp + (int64_t)max(i - 1, 0) * ldv;  // multiplied by delta == 0 when i == 0
   const int m = n - j - 1;
   const int total = m + 2 * i;
   const int g0 = blockIdx.x * SROWS;
@@ -132,15 +99,20 @@ __global__ __launch_bounds__(256) void sytrd_symv_kernel(const double* __restric
 #pragma unroll
   for (int t = 0; t < SROWS; ++t) {
     const int g = min(g0 + t, total - 1);
-    rp[t] = g < m ? A + (int64_t)(j + 1 + g) * ld : (g < m + i ? Wp + (int64_t)(g - m) * ldv : Vp + (int64_t)(g - m - i) * ldv);
+    if (g < m) rp[t] = A + (int64_t)(j + 1 + g) * ld;
+    else if (g < m + i) rp[t] = (g - m == i - 1) ? wraw_prev : Wp + (int64_t)(g - m) * ldv;
+    else rp[t] = Vp + (int64_t)(g - m - i) * ldv;
     acc[t] = 0.0;
   }
-  const int cs = (j + 2) & ~1;  // even start: 16-byte aligned loads
-  // wave `wid` takes every fourth 128-column slab; two slabs are in flight per iteration
-  int c = cs + 2 * lane + 128 * wid;
+  const int cstart = (j + 2) & ~1;  // even start: 16-byte aligned loads
+  int c = cstart + 2 * lane + 128 * wid;
   for (; c + 512 < n; c += 1024) {
     double2 xa = *reinterpret_cast<const double2*>(colbuf + c);
-    const double2 xb = *reinterpret_cast<const double2*>(colbuf + c + 512);
+    double2 xb = *reinterpret_cast<const double2*>(colbuf + c + 512);
+    const double2 va = *reinterpret_cast<const double2*>(vprev + c);
+    const double2 vb = *reinterpret_cast<const double2*>(vprev + c + 512);
+    xa.x -= delta * va.x; xa.y -= delta * va.y;
+    xb.x -= delta * vb.x; xb.y -= delta * vb.y;
     if (c < j + 2) xa.x = 0.0;
     double2 ra[SROWS], rb[SROWS];
 #pragma unroll
@@ -153,7 +125,10 @@ __global__ __launch_bounds__(256) void sytrd_symv_kernel(const double* __restric
   }
   for (; c < n; c += 512) {
     double2 xa = *reinterpret_cast<const double2*>(colbuf + c);
+    const double2 va = *reinterpret_cast<const double2*>(vprev + c);
+    xa.x -= delta * va.x; xa.y -= delta * va.y;
     if (c < j + 2) xa.x = 0.0;
+    if (c + 1 >= n) xa.y = 0.0;
 #pragma unroll
     for (int t = 0; t < SROWS; ++t) {
       const double2 r2 = *reinterpret_cast<const double2*>(rp[t] + c);
@@ -166,75 +141,171 @@ __global__ __launch_bounds__(256) void sytrd_symv_kernel(const double* __restric
     if (lane == 0) part[wid][t] = sdot;
   }
   __syncthreads();
-  if (tid < SROWS) {
-    const int t = tid, g = g0 + t;
-    if (g < total) {
-      const double scale = sh.scale;
-      const double sdot = (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
-      const double* row = g < m ? A + (int64_t)(j + 1 + g) * ld
-                                : (g < m + i ? Wp + (int64_t)(g - m) * ldv : Vp + (int64_t)(g - m - i) * ldv);
-      const double res = row[j + 1] + scale * sdot;
-      if (g < m) {
-        const int rrow = j + 1 + g;
-        pbuf[rrow] = res;
-        Vp[(int64_t)i * ldv + rrow] = (rrow == j + 1) ? 1.0 : colbuf[rrow] * scale;  // v
-      } else {
-        cbuf[g < m + i ? (g - m) : NB + (g - m - i)] = res;
+  if (wid == 0) {
+    double x2 = 0.0;
+    if (lane < SROWS) {
+      const int t = lane, g = g0 + t;
+      if (g < total) {
+        const double sdot = (part[0][t] + part[1][t]) + (part[2][t] + part[3][t]);
+        if (g < m) {
+          const int row = j + 1 + g;
+          sd[row] = sdot;
+          qv[row] = A[(int64_t)row * ld + j + 1];
+          if (row >= j + 2) {
+            const double xr = colbuf[row] - delta * vprev[row];
+            x2 = xr * xr;
+          }
+        } else if (g < m + i) {
+          const int k = g - m;
+          const double* row = (k == i - 1) ? wraw_prev : Wp + (int64_t)k * ldv;
+          cb[k] = sdot;
+          cb[NB + k] = row[j + 1];
+        } else {
+          const int k = g - m - i;
+          cb[2 * NB + k] = sdot;
+          cb[3 * NB + k] = Vp[(int64_t)k * ldv + j + 1];
+        }
+      }
+    }
+    x2 = wave_sum_d(x2);
+    if (lane == 0) {
+      px2[blockIdx.x] = x2;
+      if (blockIdx.x == 0) {
+        cs->delta = delta;
+        cs->alpha = colbuf[j + 1] - delta * vprev[j + 1];
       }
     }
   }
 }
 
-// ---- K3: grid ceil(m / 64) x 256 threads; lane = row, waves split k
-__global__ __launch_bounds__(256) void sytrd_wupd_kernel(int n, int j, int i, const double* __restrict__ colbuf,
-                                                         const double* __restrict__ pbuf,
-                                                         const double* __restrict__ cbuf,
-                                                         const double* __restrict__ Vp, const double* __restrict__ Wp,
-                                                         int64_t ldv, const Refl* __restrict__ refl,
-                                                         double* __restrict__ wraw, double* __restrict__ partial2,
-                                                         double* __restrict__ d, double* __restrict__ e,
-                                                         double* __restrict__ taus) {
-  __shared__ double c1[NB], c2[NB];
-  __shared__ double part[4][64];
+// alpha(jn): finishes column j = jn - 1 (panel index i = in - 1 >= 0) and, if do_next, forms the
+// updated column jn.  Grid ceil((n - jn) / 64) x 256 threads; lane = row, the four waves split k.
+__global__ __launch_bounds__(256) void sytrd_alpha_kernel(const double* __restrict__ A, int64_t ld, int n, int jn,
+                                                          int in, int do_next, double* __restrict__ Vp,
+                                                          double* __restrict__ Wp, int64_t ldv,
+                                                          const double* __restrict__ wraw_prev,
+                                                          double* __restrict__ wraw_cur,
+                                                          double* __restrict__ colbuf, const double* __restrict__ sd,
+                                                          const double* __restrict__ qv,
+                                                          const double* __restrict__ cb,
+                                                          const double* __restrict__ px2, int npx2,
+                                                          const ColState* __restrict__ cs,
+                                                          double* __restrict__ partial2, double* __restrict__ d,
+                                                          double* __restrict__ e, double* __restrict__ taus) {
+  __shared__ double c1[NB], c2[NB], wj1[NB], vj1[NB];
+  __shared__ double part1[4][64], part2[4][64];
+  __shared__ double vs[64], wfs[64];
+  __shared__ double sc[8];  // tau, scale, delta, a2prev, wraw_j[jn]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  if (tid < i) { c1[tid] = cbuf[tid]; c2[tid] = cbuf[NB + tid]; }
+  const int j = jn - 1, i = in - 1;
+  if (wid == 0) {
+    const double xn2 = wave_total(px2, npx2, lane);
+    if (lane == 0) {
+      const double delta = cs->delta, alpha = cs->alpha;
+      double tau, beta, scale;
+      if (xn2 == 0.0) {
+        tau = 0.0; beta = alpha; scale = 0.0;
+      } else {
+        const double nrm = sqrt(alpha * alpha + xn2);
+        beta = alpha >= 0.0 ? -nrm : nrm;
+        tau = (beta - alpha) / beta;
+        scale = 1.0 / (alpha - beta);
+      }
+      sc[0] = tau; sc[1] = scale; sc[2] = delta; sc[3] = 0.5 * delta;
+      if (blockIdx.x == 0) {
+        taus[j] = tau;
+        e[j] = beta;
+        d[j] = colbuf[j] - delta;  // x_j[j] = base_j[j] - delta v_{j-1}[j], v_{j-1}[j] = 1 (delta = 0 if i == 0)
+      }
+    }
+  }
   __syncthreads();
-  const int r = j + 1 + blockIdx.x * 64 + lane;
-  double s = 0.0;
-  if (r < n)
-    for (int k = wid; k < i; k += 4) s += Vp[(int64_t)k * ldv + r] * c1[k] + Wp[(int64_t)k * ldv + r] * c2[k];
-  part[wid][lane] = s;
+  const double tau = sc[0], scale = sc[1], delta = sc[2], a2prev = sc[3];
+  if (tid < i) {
+    const double c2v = cb[3 * NB + tid] + scale * cb[2 * NB + tid];
+    double c1v = cb[NB + tid] + scale * cb[tid];
+    if (tid == i - 1) c1v += a2prev * c2v;  // W_{i-1} = w_raw + alpha2 v_{j-1}
+    c1[tid] = c1v;
+    c2[tid] = c2v;
+    vj1[tid] = Vp[(int64_t)tid * ldv + jn];
+    wj1[tid] = (tid == i - 1) ? wraw_prev[jn] + a2prev * Vp[(int64_t)(i - 1) * ldv + jn]
+                              : Wp[(int64_t)tid * ldv + jn];
+  }
+  __syncthreads();
+  if (wid == 1) {  // w_raw_j[jn], needed by every row of the next column
+    double s = 0.0;
+    for (int k = lane; k < i; k += 64) s += vj1[k] * c1[k] + wj1[k] * c2[k];
+    s = wave_sum_d(s);
+    if (lane == 0) sc[4] = tau * ((qv[jn] + scale * sd[jn]) - s);
+  }
+  const int r = jn + blockIdx.x * 64 + lane;
+  if (wid == 0) {
+    double vr = 0.0, wf = 0.0;
+    if (r < n) {
+      const double vprev = i > 0 ? Vp[(int64_t)(i - 1) * ldv + r] : 0.0;
+      const double xr = colbuf[r] - delta * vprev;
+      vr = (r == jn) ? 1.0 : xr * scale;
+      Vp[(int64_t)i * ldv + r] = vr;
+      if (i > 0) {
+        wf = wraw_prev[r] + a2prev * vprev;
+        Wp[(int64_t)(i - 1) * ldv + r] = wf;
+      }
+    }
+    vs[lane] = vr;
+    wfs[lane] = wf;
+  }
+  __syncthreads();
+  double a1 = 0.0, a2 = 0.0;
+  if (r < n) {
+    for (int k = wid; k < i; k += 4) {
+      const double vk = Vp[(int64_t)k * ldv + r];
+      const double wk = (k == i - 1) ? wfs[lane] : Wp[(int64_t)k * ldv + r];
+      a1 += vk * c1[k] + wk * c2[k];
+      a2 += vk * wj1[k] + wk * vj1[k];
+    }
+  }
+  part1[wid][lane] = a1;
+  part2[wid][lane] = a2;
   __syncthreads();
   if (wid == 0) {
-    const double tau = refl->tau;
     double dot = 0.0;
     if (r < n) {
-      const double wr = tau * (pbuf[r] - ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane])));
-      wraw[r] = wr;
-      dot = wr * Vp[(int64_t)i * ldv + r];
+      const double s1 = (part1[0][lane] + part1[1][lane]) + (part1[2][lane] + part1[3][lane]);
+      const double wr = tau * ((qv[r] + scale * sd[r]) - s1);
+      wraw_cur[r] = wr;
+      dot = wr * vs[lane];
+      if (do_next) {
+        const double s2 = (part2[0][lane] + part2[1][lane]) + (part2[2][lane] + part2[3][lane]);
+        colbuf[r] = A[(int64_t)jn * ld + r] - s2 - (vs[lane] * sc[4] + wr);
+      }
     }
     dot = wave_sum_d(dot);
     if (lane == 0) partial2[blockIdx.x] = dot;
-    if (blockIdx.x == 0 && lane == 0) {
-      d[j] = colbuf[j];
-      e[j] = refl->beta;
-      taus[j] = tau;
-    }
   }
 }
 
-// ---- end of panel: finalise the last reflector's w before the rank-2k update
-__global__ void sytrd_wfix_kernel(int n, int j_next, int ilast, const double* __restrict__ Vp,
+// end of panel: w_last = w_raw + alpha2 v_last on the rows the rank-2k update reads
+__global__ void sytrd_wfix_kernel(int n, int r0, int ilast, int jlast, const double* __restrict__ Vp,
                                   double* __restrict__ Wp, int64_t ldv, const double* __restrict__ wraw,
-                                  const double* __restrict__ partial2, int nparts2, const Refl* __restrict__ refl) {
+                                  const double* __restrict__ partial2, int nparts2,
+                                  const double* __restrict__ taus) {
   __shared__ double a2s;
   if (threadIdx.x < 64) {
     const double t = wave_total(partial2, nparts2, threadIdx.x);
-    if (threadIdx.x == 0) a2s = -0.5 * refl->tau * t;
+    if (threadIdx.x == 0) a2s = -0.5 * taus[jlast] * t;
   }
   __syncthreads();
-  const int r = j_next + blockIdx.x * blockDim.x + threadIdx.x;
+  const int r = r0 + blockIdx.x * blockDim.x + threadIdx.x;
   if (r < n) Wp[(int64_t)ilast * ldv + r] = wraw[r] + a2s * Vp[(int64_t)ilast * ldv + r];
+}
+
+// very last diagonal entry: d[n-1] = base[n-1] - delta (delta = 0 if the column opens a panel)
+__global__ void sytrd_last_kernel(int n, int i, const double* __restrict__ colbuf,
+                                  const double* __restrict__ partial2, int nparts2,
+                                  const double* __restrict__ taus, double* __restrict__ d) {
+  double dl = 0.0;
+  if (i > 0) dl = -taus[n - 2] * wave_total(partial2, nparts2, threadIdx.x);
+  if (threadIdx.x == 0) d[n - 1] = colbuf[n - 1] - dl;
 }
 
 // ---- Sturm-count bisection: thread k finds the k-th smallest eigenvalue of T(d, e)
@@ -562,7 +633,8 @@ struct TridiagPlan {
   int64_t ld;      // leading dimension of the working copy and of the V / W panels
   int npanels;
   size_t off_A, off_V, off_W, off_col, off_p, off_part, off_refl, off_d, off_e, off_e2, off_tau, off_bounds, off_lam;
-  size_t off_u1, off_u2, off_u3, off_lm, off_sw, off_G, off_T, off_W1, off_W2, off_wraw, off_part2, off_cbuf;
+  size_t off_u1, off_u2, off_u3, off_lm, off_sw, off_G, off_T, off_W1, off_W2, off_wraw, off_wraw2, off_part2, off_cbuf;
+  size_t off_qv, off_px2;
   size_t total;
 };
 
@@ -579,7 +651,7 @@ TridiagPlan tridiag_plan(int64_t n) {
   p.off_col = take((size_t)(n + 8) * 8);
   p.off_p = take((size_t)(n + 8) * 8);
   p.off_part = take((size_t)(ceil_div(n, 64) + 8) * 8);
-  p.off_refl = take(sizeof(Refl));
+  p.off_refl = take(256);
   p.off_d = take((size_t)n * 8);
   p.off_e = take((size_t)n * 8);
   p.off_e2 = take((size_t)n * 8);
@@ -598,8 +670,11 @@ TridiagPlan tridiag_plan(int64_t n) {
   p.off_W1 = take((size_t)NB * n * 8);
   p.off_W2 = take((size_t)NB * n * 8);
   p.off_wraw = take((size_t)(n + 8) * 8);
+  p.off_wraw2 = take((size_t)(n + 8) * 8);
   p.off_part2 = take((size_t)(ceil_div(n, 64) + 8) * 8);
-  p.off_cbuf = take((size_t)2 * NB * 8);
+  p.off_cbuf = take((size_t)4 * NB * 8);
+  p.off_qv = take((size_t)(n + 8) * 8);
+  p.off_px2 = take((size_t)(ceil_div(n + 2 * NB, SROWS) + 8) * 8);
   p.total = o;
   return p;
 }
@@ -618,56 +693,73 @@ int sytrd_f64(const TridiagPlan& p, char* base, SymvTimer* timer, hipStream_t st
   double* Wp = reinterpret_cast<double*>(base + p.off_W);
   double* colbuf = reinterpret_cast<double*>(base + p.off_col);
   double* pbuf = reinterpret_cast<double*>(base + p.off_p);
-  double* partial = reinterpret_cast<double*>(base + p.off_part);
-  Refl* refl = reinterpret_cast<Refl*>(base + p.off_refl);
   double* d = reinterpret_cast<double*>(base + p.off_d);
   double* e = reinterpret_cast<double*>(base + p.off_e);
   double* taus = reinterpret_cast<double*>(base + p.off_tau);
 
-  double* wraw = reinterpret_cast<double*>(base + p.off_wraw);
+  double* wr[2] = {reinterpret_cast<double*>(base + p.off_wraw), reinterpret_cast<double*>(base + p.off_wraw2)};
   double* partial2 = reinterpret_cast<double*>(base + p.off_part2);
   double* cbuf = reinterpret_cast<double*>(base + p.off_cbuf);
+  double* sd = pbuf;                                             // unscaled SYMV products
+  double* qv = reinterpret_cast<double*>(base + p.off_qv);       // A[r][j+1]
+  double* px2 = reinterpret_cast<double*>(base + p.off_px2);
+  ColState* cs = reinterpret_cast<ColState*>(base + p.off_refl);
   PTD_CHECK_HIP(hipMemsetAsync(Vall, 0, (size_t)p.npanels * NB * ld * 8, st));
   PTD_CHECK_HIP(hipMemsetAsync(taus, 0, (size_t)n * 8, st));
   PTD_CHECK_HIP(hipMemsetAsync(e, 0, (size_t)n * 8, st));
   PTD_CHECK_HIP(hipMemsetAsync(colbuf, 0, (size_t)(n + 8) * 8, st));
+  PTD_CHECK_HIP(hipMemsetAsync(wr[0], 0, (size_t)(n + 8) * 8, st));
+  PTD_CHECK_HIP(hipMemsetAsync(wr[1], 0, (size_t)(n + 8) * 8, st));
   for (int pn = 0; pn < p.npanels; ++pn) {
     const int j0 = pn * NB;
     const int cols = std::min(NB, n - j0);
     double* Vp = Vall + (size_t)pn * NB * ld;
     PTD_CHECK_HIP(hipMemsetAsync(Wp, 0, (size_t)NB * ld * 8, st));
-    int nparts2 = 0;
+    int nparts2 = 0, npx2 = 0;
+    bool open = false;  // a column whose SYMV ran and whose reflector is not finished yet
     for (int i = 0; i < cols; ++i) {
       const int j = j0 + i;
-      const int nparts = (int)ceil_div(n - j, 64);
-      hipLaunchKernelGGL(sytrd_colupd_kernel, dim3(nparts), dim3(256), 0, st, Aw, ld, n, j, i, Vp, Wp, ld, wraw,
-                         partial2, nparts2, refl, colbuf, partial);
+      if (i == 0) {
+        hipLaunchKernelGGL(sytrd_colinit_kernel, dim3((unsigned)ceil_div(n - j, 256)), dim3(256), 0, st, Aw, ld, n,
+                           j, colbuf);
+      } else {
+        const int blocks = (int)ceil_div(n - j, 64);
+        hipLaunchKernelGGL(sytrd_alpha_kernel, dim3(blocks), dim3(256), 0, st, Aw, ld, n, j, i, 1, Vp, Wp, ld,
+                           wr[(i & 1)], wr[(i - 1) & 1], colbuf, sd, qv, cbuf, px2, npx2, cs, partial2, d, e, taus);
+        nparts2 = blocks;
+      }
       const int m = n - j - 1;
       if (m > 0) {
         const int rows = m + 2 * i;
+        npx2 = (int)ceil_div(rows, SROWS);
         if (timer) (void)hipEventRecord(timer->ev[2 * (size_t)j], st);
-        hipLaunchKernelGGL(sytrd_symv_kernel, dim3((unsigned)ceil_div(rows, SROWS)), dim3(256), 0, st, Aw, ld, n,
-                           j, i, nparts, colbuf, partial, Vp, Wp, ld, pbuf, cbuf, refl);
+        hipLaunchKernelGGL(sytrd_symv_kernel, dim3(npx2), dim3(256), 0, st, Aw, ld, n, j, i, colbuf, Vp, Wp, ld,
+                           wr[(i + 1) & 1], partial2, nparts2, taus, sd, qv, cbuf, px2, cs);
         if (timer) (void)hipEventRecord(timer->ev[2 * (size_t)j + 1], st);
-        nparts2 = (int)ceil_div(m, 64);
-        hipLaunchKernelGGL(sytrd_wupd_kernel, dim3(nparts2), dim3(256), 0, st, n, j, i, colbuf, pbuf, cbuf, Vp, Wp,
-                           ld, refl, wraw, partial2, d, e, taus);
+        open = true;
       } else {
-        PTD_CHECK_HIP(hipMemcpyAsync(d + j, colbuf + j, 8, hipMemcpyDeviceToDevice, st));
-        nparts2 = 0;
+        hipLaunchKernelGGL(sytrd_last_kernel, dim3(1), dim3(64), 0, st, n, i, colbuf, partial2, nparts2, taus, d);
+        open = false;
       }
     }
-    // trailing update A[T0:, T0:] -= V W^T + W V^T  (T0 = first row / column after the panel)
-    const int t0 = j0 + cols;
-    const int mt = n - t0;
-    if (mt > 0) {
-      hipLaunchKernelGGL(sytrd_wfix_kernel, dim3((unsigned)ceil_div(mt, 256)), dim3(256), 0, st, n, t0, cols - 1, Vp,
-                         Wp, ld, wraw, partial2, nparts2, refl);
-      double* At = Aw + (int64_t)t0 * ld + t0;
-      int rc = gemm_f64(Vp + t0, 1, ld, Wp + t0, ld, 1, At, ld, mt, mt, cols, -1.0, true, 1, st);
-      if (rc != PTD_OK) return rc;
-      rc = gemm_f64(Wp + t0, 1, ld, Vp + t0, ld, 1, At, ld, mt, mt, cols, -1.0, true, 1, st);
-      if (rc != PTD_OK) return rc;
+    const int t0 = j0 + cols;  // first row / column after the panel
+    if (open) {
+      // finish the panel's last column (no next column to form), then finalise its w
+      const int blocks = (int)ceil_div(n - t0, 64);
+      hipLaunchKernelGGL(sytrd_alpha_kernel, dim3(std::max(blocks, 1)), dim3(256), 0, st, Aw, ld, n, t0, cols, 0, Vp,
+                         Wp, ld, wr[(cols & 1)], wr[(cols - 1) & 1], colbuf, sd, qv, cbuf, px2, npx2, cs, partial2,
+                         d, e, taus);
+      const int mt = n - t0;
+      if (mt > 0) {
+        hipLaunchKernelGGL(sytrd_wfix_kernel, dim3((unsigned)ceil_div(mt, 256)), dim3(256), 0, st, n, t0, cols - 1,
+                           t0 - 1, Vp, Wp, ld, wr[(cols - 1) & 1], partial2, std::max(blocks, 1), taus);
+        // trailing update A[T0:, T0:] -= V W^T + W V^T
+        double* At = Aw + (int64_t)t0 * ld + t0;
+        int rc = gemm_f64(Vp + t0, 1, ld, Wp + t0, ld, 1, At, ld, mt, mt, cols, -1.0, true, 1, st);
+        if (rc != PTD_OK) return rc;
+        rc = gemm_f64(Wp + t0, 1, ld, Vp + t0, ld, 1, At, ld, mt, mt, cols, -1.0, true, 1, st);
+        if (rc != PTD_OK) return rc;
+      }
     }
   }
   PTD_CHECK_LAUNCH("sytrd_f64");
