@@ -94,6 +94,20 @@ int ptd_eigh(const double* A, int64_t lda, int64_t n, double* evals, double* eve
 int ptd_eigh_topk(const double* A, int64_t lda, int64_t n, int64_t k, double* evals, double* evecs,
                   int64_t ldv, void* ws, size_t ws_bytes, int* sweeps_out, void* stream);
 
+/* Top-k eigenpairs of C = W Ex W^T without forming C, for a layer that widens its input
+ * (n_o > n_i; Llama gate / up: 4096 -> 14336): W [n_o, n_i] (f32, bf16 or f64, ld ldw),
+ * Ex [n_i, n_i] f64 full symmetric = sum over steps of x^T x / T / steps (the INPUT second
+ * moment; C is then exactly the feature covariance the reference accumulates, dwain.py:147-152,
+ * since y = x W^T).  U [n_o, k] f64 gets the eigenvectors of the k largest eigenvalues
+ * (ascending, same convention as ptd_eigh_topk), evals_k[k] (may be NULL) the eigenvalues of C.
+ * G = W^T W = L L^T, B = L^T Ex L, B s = lambda s, u = W L^-T s: a n_i^2 eigenproblem plus
+ * five f64 MFMA products.  Returns PTD_ERR_UNSUPPORTED if W^T W is not numerically positive
+ * definite (then accumulate Y^T Y and call ptd_eigh_topk). */
+size_t ptd_eigh_factored_workspace_bytes(int64_t n_o, int64_t n_i, int64_t k);
+int ptd_eigh_factored(const void* W, int64_t ldw, int w_dtype, int64_t n_o, int64_t n_i,
+                      const double* Ex, int64_t ldx, int64_t k, double* evals_k, double* U, int64_t ldu,
+                      void* ws, size_t ws_bytes, void* stream);
+
 /* Same, with per-phase device timing (HIP events on `stream` around the launches of each
  * phase; a few percent slower, for bench.py's roofline lines).  `stats` is a HOST pointer.
  *   method 0 (Jacobi):       phase 0 jac_gram, 1 jac_inner, 2 jac_update            (work = f64 flops executed)

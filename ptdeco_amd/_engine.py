@@ -152,28 +152,55 @@ class LayerTap:
         self.last_features = None
 
 
-class Covariance:
-    """sum over calibration steps of y^T y / T (and of mean_rows(y)) for one layer, in HBM."""
+def _input_route_wanted(n_out: int, n_in: int, top_k: Optional[int], with_mean: bool) -> bool:
+    """Layers that widen their input (n_out > n_in, e.g. Llama gate / up 4096 -> 14336): the feature
+    covariance W Ex W^T has rank <= n_in, so its leading eigenvectors come from an n_in-sized problem
+    (ptd_eigh_factored).  PTD_INPUT_COVARIANCE=0 disables the route, =1 forces it when legal."""
+    import os
 
-    def __init__(self, n: int, device: torch.device, float64: bool, with_mean: bool = False):
+    if with_mean or top_k is None or top_k > n_in or n_out <= n_in:
+        return False
+    flag = os.environ.get("PTD_INPUT_COVARIANCE", "auto")
+    if flag == "0":
+        return False
+    return True if flag == "1" else n_out >= n_in + n_in // 2
+
+
+class Covariance:
+    """sum over calibration steps of y^T y / T (and of mean_rows(y)) for one layer, in HBM.
+
+    With ``weight`` and ``top_k`` given and n_out sufficiently larger than n_in the INPUT second
+    moment x^T x / T is accumulated instead (n_in^2 instead of n_out^2 entries, no layer-output GEMM
+    needed) and the eigenvectors of W Ex W^T -- the same matrix -- are obtained through
+    ``ops.eigh_factored``."""
+
+    def __init__(self, n: int, device: torch.device, float64: bool, with_mean: bool = False,
+                 weight: Optional[torch.Tensor] = None, top_k: Optional[int] = None):
         dt = torch.float64 if float64 else torch.float32
-        self.E = torch.zeros((n, n), dtype=dt, device=device)
+        self.weight = weight
+        self.input_route = weight is not None and _input_route_wanted(n, weight.shape[1], top_k, with_mean)
+        m = weight.shape[1] if self.input_route else n
+        self.E = torch.zeros((m, m), dtype=dt, device=device)
         self.ey = torch.zeros(n, dtype=dt, device=device) if with_mean else None
         self.steps = 0
 
     def add_features(self, y: torch.Tensor) -> None:
         """y: [T, n] layer output rows (dwain.py:147-152; falor.py:160-161)."""
+        assert not self.input_route
         t = y.shape[0]
         ops.syrk_accumulate(self.E, y, 1.0 / t)
         if self.ey is not None:
             ops.colsum_accumulate(self.ey, y, 1.0 / t)
         self.steps += 1
 
-    def add_inputs(self, x_rows: torch.Tensor, weight2d: torch.Tensor) -> torch.Tensor:
-        """x_rows [T, n_in], weight2d [n, n_in]: y = x W^T on the matrix cores, then accumulate."""
-        y = ops.matmul(x_rows, weight2d.T)
-        self.add_features(y)
-        return y
+    def add_inputs(self, x_rows: torch.Tensor, weight2d: torch.Tensor, features: Optional[torch.Tensor] = None):
+        """x_rows [T, n_in], weight2d [n, n_in].  Direct route: y = x W^T on the matrix cores (or the
+        caller's `features` if it already has them), then Y^T Y.  Input route: X^T X only."""
+        if self.input_route:
+            ops.syrk_accumulate(self.E, x_rows, 1.0 / x_rows.shape[0])
+            self.steps += 1
+            return
+        self.add_features(features if features is not None else ops.matmul(x_rows, weight2d.T))
 
     def all_reduce(self, group=None) -> None:
         """Sum the partial statistics of all ranks (the one collective of the path: RCCL over xGMI)."""
@@ -190,6 +217,18 @@ class Covariance:
         """Finalise (divide by steps, optional mean removal, Tikhonov damping) and return the
         eigenvectors in columns, ascending, f64 (dwain.py:155-163, falor.py:192-208).  With
         ``top_k`` only the last top_k columns (largest eigenvalues) are formed: [n, top_k]."""
+        if self.input_route:
+            ex = ops.cov_finalize(self.E, self.steps, 0.0, None)  # damping only shifts eigenvalues
+            w2d = self.weight if self.weight.dim() == 2 else self.weight[..., 0, 0]
+            got = ops.eigh_factored(w2d, ex, top_k)
+            if got is not None:
+                return got[1]
+            # W^T W not positive definite: form C = W Ex W^T explicitly and take the direct route
+            w64 = w2d.double()
+            c = ops.matmul(ops.matmul(w64, ex), w64.T)
+            c = 0.5 * (c + c.T)
+            c.diagonal().add_(damp_factor * c.diagonal().mean())
+            return ops.eigh(c, top_k)[1]
         c = ops.cov_finalize(self.E, self.steps, damp_factor, self.ey if use_mean else None)
         _, u = ops.eigh(c, top_k)
         return u

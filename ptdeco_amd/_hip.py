@@ -37,6 +37,9 @@ SIGNATURES = {
     "ptd_tridiagonalize_workspace_bytes": (c_size_t, [c_int64]),
     "ptd_tridiagonalize": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                    c_void_p]),
+    "ptd_eigh_factored_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int64]),
+    "ptd_eigh_factored": (c_int, [c_void_p, c_int64, c_int, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p,
+                                  c_void_p, c_int64, c_void_p, c_size_t, c_void_p]),
     "ptd_gemm": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
                          c_int64, c_int64, c_int, c_int, c_double, c_void_p, c_void_p]),
     "ptd_lowrank_forward": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p,

@@ -85,6 +85,17 @@ static int eigh_dispatch(const double* A, int64_t lda, int64_t n, int64_t k, dou
   return eigh_jacobi(A, lda, n, k, evals, evecs, ldv, ws, ws_bytes, sweeps_out, stats, st);
 }
 
+size_t ptd_eigh_factored_workspace_bytes(int64_t n_o, int64_t n_i, int64_t k) {
+  return eigh_factored_workspace_bytes(n_o, n_i, k);
+}
+
+int ptd_eigh_factored(const void* W, int64_t ldw, int w_dtype, int64_t n_o, int64_t n_i, const double* Ex,
+                      int64_t ldx, int64_t k, double* evals_k, double* U, int64_t ldu, void* ws, size_t ws_bytes,
+                      void* stream) {
+  return eigh_factored(W, ldw, w_dtype, n_o, n_i, Ex, ldx, k, evals_k, U, ldu, ws, ws_bytes,
+                       static_cast<hipStream_t>(stream));
+}
+
 int ptd_eigh(const double* A, int64_t lda, int64_t n, double* evals, double* evecs, int64_t ldv, void* ws,
              size_t ws_bytes, int* sweeps_out, void* stream) {
   return eigh_dispatch(A, lda, n, n, evals, evecs, ldv, ws, ws_bytes, sweeps_out, nullptr,
@@ -158,3 +169,12 @@ int ptd_sym_kl(const void* s, const void* t, int64_t B, int64_t C, int dtype, do
 }
 
 }  // extern "C"
+
+// C++-linkage views of the solver selection for the other translation units (eigh_factored.hip)
+namespace ptd {
+size_t eigh_select_workspace_bytes(int64_t n) { return ptd_eigh_workspace_bytes(n); }
+int eigh_select(const double* A, int64_t lda, int64_t n, int64_t k, double* evals, double* evecs, int64_t ldv,
+                void* ws, size_t ws_bytes, int* sweeps_out, ptd_eigh_stats* stats, hipStream_t st) {
+  return eigh_dispatch(A, lda, n, k, evals, evecs, ldv, ws, ws_bytes, sweeps_out, stats, st);
+}
+}  // namespace ptd

@@ -162,14 +162,17 @@ __global__ __launch_bounds__(256) void chol_update_kernel(double* __restrict__ L
 }  // namespace
 
 // In-place blocked Cholesky of the lower triangle of L (np x np, np % 64 == 0).
-// linv_ws: 64 x 64 doubles; fail: device int, must be zero on entry.
-int cholesky_f64(double* L, int np, double* linv_ws, int* fail, hipStream_t st) {
+// linv_ws: 64 x 64 doubles per diagonal block when linv_stride == 4096 (all inverses L_kk^-1
+// are kept, for a later triangular solve), or one reused 64 x 64 buffer when linv_stride == 0;
+// fail: device int, must be zero on entry.
+int cholesky_f64(double* L, int np, double* linv_ws, int linv_stride, int* fail, hipStream_t st) {
   const int nblk = np / CB;
   for (int k = 0; k < nblk; ++k) {
-    hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), 0, st, L, np, k, linv_ws, fail);
+    double* linv = linv_ws + (size_t)k * linv_stride;
+    hipLaunchKernelGGL(chol_diag_kernel, dim3(1), dim3(256), 0, st, L, np, k, linv, fail);
     const int below = nblk - k - 1;
     if (below > 0) {
-      hipLaunchKernelGGL(chol_trsm_kernel, dim3(below), dim3(256), 0, st, L, np, k, linv_ws);
+      hipLaunchKernelGGL(chol_trsm_kernel, dim3(below), dim3(256), 0, st, L, np, k, linv);
       hipLaunchKernelGGL(chol_update_kernel, dim3(below * (below + 1) / 2), dim3(256), 0, st, L, np, k);
     }
   }

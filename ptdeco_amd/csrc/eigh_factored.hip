@@ -1,0 +1,219 @@
+// Top-k eigenvectors of  C = W Ex W^T  (W [n_o, n_i], n_o > n_i, Ex [n_i, n_i] symmetric PSD)
+// without ever forming the n_o x n_o matrix -- the covariance of y = x W^T for a layer that
+// widens its input (Llama gate / up: 4096 -> 14336).  Exact algebra, all in f64:
+//     G = W^T W = L L^T                       (blocked Cholesky, chol.hip)
+//     B = L^T Ex L                            (n_i x n_i, symmetric)
+//     B s = lambda s                          (ptd_eigh route, top k)
+//     u = W L^-T s                            => C u = lambda u,  |u| = |s| = 1
+// so a 14336^2 eigenproblem (1.6 GB matrix, 8/3 n^3 = 7.9e12 bytes of SYMV traffic) becomes a
+// 4096^2 one plus five f64 MFMA products.  Damping C + damp I shifts eigenvalues only.
+// Fails with PTD_ERR_UNSUPPORTED when G is not numerically positive definite (W rank deficient):
+// the caller then decomposes C directly.
+#include <algorithm>
+#include <cstring>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace ptd {
+
+int cholesky_f64(double* L, int np, double* linv_ws, int linv_stride, int* fail, hipStream_t st);
+int eigh_select(const double* A, int64_t lda, int64_t n, int64_t k, double* evals, double* evecs, int64_t ldv,
+                void* ws, size_t ws_bytes, int* sweeps_out, ptd_eigh_stats* stats, hipStream_t st);  // api.hip
+size_t eigh_select_workspace_bytes(int64_t n);
+
+namespace {
+
+constexpr int FB = 64;
+
+template <typename T>
+__device__ __forceinline__ double to_f64(T v);
+template <>
+__device__ __forceinline__ double to_f64<float>(float v) { return (double)v; }
+template <>
+__device__ __forceinline__ double to_f64<double>(double v) { return v; }
+template <>
+__device__ __forceinline__ double to_f64<unsigned short>(unsigned short v) { return (double)bf16_to_f32(v); }
+
+// D[r][c] = (r < rows && c < cols) ? S[r][c] : (r == c ? diag_pad : 0)
+template <typename T>
+__global__ void widen_pad_kernel(const T* __restrict__ S, int64_t lds, int rows, int cols, double* __restrict__ D,
+                                 int64_t ldd, int prow, int pcol, double diag_pad) {
+  const int64_t total = (int64_t)prow * pcol;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(e / pcol), c = (int)(e % pcol);
+    D[(int64_t)r * ldd + c] = (r < rows && c < cols) ? to_f64(S[(int64_t)r * lds + c]) : (r == c ? diag_pad : 0.0);
+  }
+}
+
+// zero the strict upper triangle (the Cholesky kernels leave stale values of G there)
+__global__ void tril_kernel(double* __restrict__ L, int np) {
+  const int64_t total = (int64_t)np * np;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(e / np), c = (int)(e % np);
+    if (c > r) L[e] = 0.0;
+  }
+}
+
+// B <- (B + B^T) / 2 on the n x n leading block; identity on the padding (keeps B PSD, the
+// padded eigenvalues are exact and tiny so they never reach the top k)
+__global__ void symmetrize_kernel(double* __restrict__ B, int np, int n, double pad_diag) {
+  const int64_t total = (int64_t)np * np;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(e / np), c = (int)(e % np);
+    if (r >= n || c >= n) {
+      B[e] = (r == c) ? pad_diag : 0.0;
+    } else if (c > r) {
+      const double v = 0.5 * (B[e] + B[(int64_t)c * np + r]);
+      B[e] = v;
+      B[(int64_t)c * np + r] = v;
+    }
+  }
+}
+
+// min and max of diag(L): max / min bounds cond(L) = cond(W) from below
+__global__ void diag_range_kernel(const double* __restrict__ L, int np, int n, double* __restrict__ out) {
+  __shared__ double rmin[16], rmax[16];
+  double lo = INFINITY, hi = 0.0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const double v = L[(int64_t)i * np + i];
+    lo = fmin(lo, v);
+    hi = fmax(hi, v);
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    lo = fmin(lo, __shfl_xor(lo, o));
+    hi = fmax(hi, __shfl_xor(hi, o));
+  }
+  if ((threadIdx.x & 63) == 0) { rmin[threadIdx.x >> 6] = lo; rmax[threadIdx.x >> 6] = hi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) { lo = fmin(lo, rmin[w]); hi = fmax(hi, rmax[w]); }
+    out[0] = lo;
+    out[1] = hi;
+  }
+}
+
+}  // namespace
+
+struct FactoredPlan {
+  int np;  // n_i rounded up to 64
+  size_t off_W, off_G, off_P, off_B, off_linv, off_fail, off_S, off_T, off_evals, off_eigh, total;
+  size_t eigh_bytes;
+};
+
+static FactoredPlan factored_plan(int64_t n_o, int64_t n_i, int64_t k) {
+  FactoredPlan p{};
+  p.np = (int)align_up((size_t)n_i, FB);
+  size_t o = 0;
+  auto take = [&](size_t bytes) { size_t at = o; o += align_up(bytes, 256); return at; };
+  p.off_W = take((size_t)n_o * p.np * 8);
+  p.off_G = take((size_t)p.np * p.np * 8);
+  p.off_P = take((size_t)p.np * p.np * 8);
+  p.off_B = take((size_t)p.np * p.np * 8);
+  p.off_linv = take((size_t)(p.np / FB) * FB * FB * 8);
+  p.off_fail = take(256);
+  p.off_S = take((size_t)p.np * k * 8);
+  p.off_T = take((size_t)p.np * k * 8);
+  p.off_evals = take((size_t)p.np * 8);
+  p.eigh_bytes = eigh_select_workspace_bytes(p.np);
+  p.off_eigh = take(p.eigh_bytes);
+  p.total = o;
+  return p;
+}
+
+size_t eigh_factored_workspace_bytes(int64_t n_o, int64_t n_i, int64_t k) { return factored_plan(n_o, n_i, k).total; }
+
+int eigh_factored(const void* W, int64_t ldw, int w_dtype, int64_t n_o, int64_t n_i, const double* Ex, int64_t ldx,
+                  int64_t k, double* evals_k, double* U, int64_t ldu, void* ws, size_t ws_bytes, hipStream_t st) {
+  PTD_REQUIRE(W && Ex && U && ws, "ptd_eigh_factored: null pointer");
+  PTD_REQUIRE(n_i >= 1 && n_o >= n_i && k >= 1 && k <= n_i && ldw >= n_i && ldx >= n_i && ldu >= k,
+              "ptd_eigh_factored: bad shape n_o=%lld n_i=%lld k=%lld", (long long)n_o, (long long)n_i, (long long)k);
+  const FactoredPlan p = factored_plan(n_o, n_i, k);
+  if (ws_bytes < p.total) {
+    set_error("ptd_eigh_factored: workspace %zu < required %zu bytes", ws_bytes, p.total);
+    return PTD_ERR_WORKSPACE;
+  }
+  char* base = static_cast<char*>(ws);
+  const int np = p.np;
+  double* W64 = reinterpret_cast<double*>(base + p.off_W);   // [n_o][np], zero padded columns
+  double* G = reinterpret_cast<double*>(base + p.off_G);     // G, then L (lower)
+  double* P = reinterpret_cast<double*>(base + p.off_P);
+  double* B = reinterpret_cast<double*>(base + p.off_B);
+  double* linv = reinterpret_cast<double*>(base + p.off_linv);
+  int* fail = reinterpret_cast<int*>(base + p.off_fail);
+  double* S = reinterpret_cast<double*>(base + p.off_S);     // [np][k] eigenvectors of B
+  double* T = reinterpret_cast<double*>(base + p.off_T);     // [np][k] L^-T S
+  double* evals = reinterpret_cast<double*>(base + p.off_evals);
+
+  // W in f64 (zero padded to np columns)
+  if (w_dtype == PTD_F32)
+    hipLaunchKernelGGL((widen_pad_kernel<float>), dim3(4096), dim3(256), 0, st, (const float*)W, ldw, (int)n_o,
+                       (int)n_i, W64, (int64_t)np, (int)n_o, np, 0.0);
+  else if (w_dtype == PTD_BF16)
+    hipLaunchKernelGGL((widen_pad_kernel<unsigned short>), dim3(4096), dim3(256), 0, st, (const unsigned short*)W,
+                       ldw, (int)n_o, (int)n_i, W64, (int64_t)np, (int)n_o, np, 0.0);
+  else if (w_dtype == PTD_F64)
+    hipLaunchKernelGGL((widen_pad_kernel<double>), dim3(4096), dim3(256), 0, st, (const double*)W, ldw, (int)n_o,
+                       (int)n_i, W64, (int64_t)np, (int)n_o, np, 0.0);
+  else {
+    set_error("ptd_eigh_factored: unsupported weight dtype");
+    return PTD_ERR_UNSUPPORTED;
+  }
+  PTD_CHECK_LAUNCH("widen W");
+  // G = W^T W  (+ identity on the padding so the Cholesky stays positive definite)
+  int rc = gemm_f64(W64, 1, np, W64, np, 1, G, np, np, np, n_o, 1.0, false, 1, st);
+  if (rc != PTD_OK) return rc;
+  if (np > n_i) hipLaunchKernelGGL(symmetrize_kernel, dim3(2048), dim3(256), 0, st, G, np, (int)n_i, 1.0);
+  PTD_CHECK_HIP(hipMemsetAsync(fail, 0, 16, st));
+  rc = cholesky_f64(G, np, linv, FB * FB, fail, st);
+  if (rc != PTD_OK) return rc;
+  double* drange = reinterpret_cast<double*>(base + p.off_fail + 16);
+  hipLaunchKernelGGL(diag_range_kernel, dim3(1), dim3(1024), 0, st, G, np, (int)n_i, drange);
+  struct { int fail; int pad; double pad2; double lo, hi; } h{};
+  PTD_CHECK_HIP(hipMemcpyAsync(&h, fail, 32, hipMemcpyDeviceToHost, st));
+  PTD_CHECK_HIP(hipStreamSynchronize(st));
+  // the eigenvectors inherit an error of order eps * cond(W)^2 from G = W^T W: refuse beyond
+  // cond(W) ~ 1e4 (diag(L) ratio is a lower bound of it), the caller then takes the direct route
+  if (h.fail || !(h.lo > 1e-4 * h.hi)) {
+    set_error("ptd_eigh_factored: W^T W is not safely positive definite (diag(L) range %.3e .. %.3e)", h.lo, h.hi);
+    return PTD_ERR_UNSUPPORTED;
+  }
+  hipLaunchKernelGGL(tril_kernel, dim3(2048), dim3(256), 0, st, G, np);  // G now holds L, upper = 0
+  // Ex (n_i x n_i) widened into B's buffer first, P = Ex L, B = L^T P
+  hipLaunchKernelGGL((widen_pad_kernel<double>), dim3(4096), dim3(256), 0, st, Ex, ldx, (int)n_i, (int)n_i, B,
+                     (int64_t)np, np, np, 0.0);
+  rc = gemm_f64(B, np, 1, G, np, 1, P, np, np, np, np, 1.0, false, 1, st);   // P = Ex L
+  if (rc != PTD_OK) return rc;
+  rc = gemm_f64(G, 1, np, P, np, 1, B, np, np, np, np, 1.0, false, 1, st);   // B = L^T P
+  if (rc != PTD_OK) return rc;
+  hipLaunchKernelGGL(symmetrize_kernel, dim3(2048), dim3(256), 0, st, B, np, (int)n_i, 0.0);
+  PTD_CHECK_LAUNCH("factored products");
+  // top-k eigenvectors of B
+  rc = eigh_select(B, np, np, k, evals, S, k, base + p.off_eigh, p.eigh_bytes, nullptr, nullptr, st);
+  if (rc != PTD_OK) return rc;
+  // T = L^-T S : blocked back substitution with the stored inverses of the diagonal blocks
+  const int nblk = np / FB;
+  for (int b = nblk - 1; b >= 0; --b) {
+    // T_b = (L_bb^-1)^T S_b
+    rc = gemm_f64(linv + (size_t)b * FB * FB, 1, FB, S + (size_t)b * FB * k, k, 1, T + (size_t)b * FB * k, k, FB, k, FB,
+                  1.0, false, 1, st);
+    if (rc != PTD_OK) return rc;
+    // S[0 : b*64] -= L[b-block rows, 0 : b*64]^T T_b
+    if (b > 0) {
+      rc = gemm_f64(G + (size_t)b * FB * np, 1, np, T + (size_t)b * FB * k, k, 1, S, k, (int64_t)b * FB, k, FB, -1.0,
+                    true, 1, st);
+      if (rc != PTD_OK) return rc;
+    }
+  }
+  // U = W T  [n_o, k]
+  rc = gemm_f64(W64, np, 1, T, k, 1, U, ldu, n_o, k, np, 1.0, false, 1, st);
+  if (rc != PTD_OK) return rc;
+  if (evals_k)
+    PTD_CHECK_HIP(hipMemcpyAsync(evals_k, evals + (np - k), (size_t)k * 8, hipMemcpyDeviceToDevice, st));
+  return PTD_OK;
+}
+
+}  // namespace ptd

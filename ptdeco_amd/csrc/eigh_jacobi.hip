@@ -32,7 +32,7 @@
 
 namespace ptd {
 
-int cholesky_f64(double* L, int np, double* linv_ws, int* fail, hipStream_t st);  // chol.hip
+int cholesky_f64(double* L, int np, double* linv_ws, int linv_stride, int* fail, hipStream_t st);  // chol.hip
 
 namespace {
 
@@ -562,7 +562,7 @@ int eigh_jacobi(const double* A, int64_t lda, int64_t n, int64_t k, double* eval
   if (use_chol) {
     hipLaunchKernelGGL(jac_gather_kernel, dim3(2048), dim3(256), 0, st, A, lda, (int)n, perm, Lb, p.np);
     PTD_CHECK_LAUNCH("jac_gather");
-    int rc = cholesky_f64(Lb, p.np, linv, fail, st);
+    int rc = cholesky_f64(Lb, p.np, linv, 0, fail, st);
     if (rc != PTD_OK) return rc;
     int h_fail = 0;
     PTD_CHECK_HIP(hipMemcpyAsync(&h_fail, fail, 4, hipMemcpyDeviceToHost, st));

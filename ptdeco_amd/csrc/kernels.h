@@ -34,6 +34,11 @@ int eigh_tridiag(const double* A, int64_t lda, int64_t n, int64_t k, double* eva
 int tridiagonalize_f64(const double* A, int64_t lda, int64_t n, double* d_out, double* e_out, double* evals_out,
                        void* ws, size_t ws_bytes, hipStream_t st);
 
+// eigh_factored.hip
+size_t eigh_factored_workspace_bytes(int64_t n_o, int64_t n_i, int64_t k);
+int eigh_factored(const void* W, int64_t ldw, int w_dtype, int64_t n_o, int64_t n_i, const double* Ex, int64_t ldx,
+                  int64_t k, double* evals_k, double* U, int64_t ldu, void* ws, size_t ws_bytes, hipStream_t st);
+
 // reduce.hip
 size_t cov_finalize_workspace_bytes(int64_t n);
 int cov_finalize(const void* E, int64_t ldE, int E_dtype, const void* ey, int ey_dtype, int64_t n, double steps,

@@ -77,13 +77,14 @@ class CovarianceComputingLinearModule(torch.nn.Module):
         self.weight = weight
         self.bias = bias
         self.in_features, self.out_features = weight.shape[1], weight.shape[0]
-        self.cov = eng.Covariance(self.out_features, weight.device, decompose_in_float64)
         self.top_k = top_k  # largest rank the search can ask for; None = all eigenvectors
+        self.cov = eng.Covariance(self.out_features, weight.device, decompose_in_float64, weight=weight.detach(),
+                                  top_k=top_k)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         rows = x.reshape(-1, self.in_features)
         y = ops.matmul(rows, self.weight.T)
-        self.cov.add_features(y)
+        self.cov.add_inputs(rows, self.weight, features=y)
         if self.bias is not None:
             y += self.bias
         return y.reshape(*x.shape[:-1], self.out_features)
@@ -164,17 +165,15 @@ def _compute_covariance_matrix_decomposition(*, root_module, tap: eng.LayerTap, 
     """:211-244 -- D model forwards, y = x W^T, Eyyt += y^T y / T, damped eigenvectors."""
     root_module.eval()
     logger.info("Using float64 for decomposition" if decompose_in_float64 else "Using float32 for decomposition")
-    cov = eng.Covariance(weight.shape[0], device, decompose_in_float64)
+    cov = eng.Covariance(weight.shape[0], device, decompose_in_float64, weight=weight, top_k=top_k)
     tap.use_dense(weight)
     for step in range(num_data_steps):
         batch = next(data_iterator)
         if not shard.mine(step):
             continue
         root_module(utils.to_device(batch, device))
-        if tap.last_features is not None:  # the layer's forward already formed y = x W^T on the GPU
-            cov.add_features(tap.last_features)
-        else:
-            cov.add_inputs(tap.last_input_rows(), weight)
+        # (the layer's own forward may already have formed y = x W^T on the GPU: tap.last_features)
+        cov.add_inputs(tap.last_input_rows(), weight, features=tap.last_features)
     if shard.active:
         cov.all_reduce(shard.group)
     return cov.eigenvectors(EIGEN_DAMPEN_FACTOR, top_k=top_k)

@@ -122,6 +122,28 @@ def eigh(A: torch.Tensor, k: Optional[int] = None) -> tuple[torch.Tensor, torch.
     return w, v
 
 
+def eigh_factored(W: torch.Tensor, Ex: torch.Tensor, k: int) -> Optional[tuple[torch.Tensor, torch.Tensor]]:
+    """Top-k eigenpairs (eigenvalues [k] ascending, eigenvectors [n_o, k] f64) of W Ex W^T for
+    W [n_o, n_i] with n_o > n_i and Ex [n_i, n_i] f64 symmetric.  Returns None when W^T W is not
+    numerically positive definite (the caller then works on the n_o x n_o matrix)."""
+    _dev(W, Ex)
+    assert W.dim() == 2 and Ex.dtype == torch.float64 and Ex.shape == (W.shape[1], W.shape[1])
+    W, Ex = _rows2d(W), _rows2d(Ex)
+    n_o, n_i = W.shape
+    k = max(1, min(int(k), n_i))
+    lib = _hip.load()
+    w = torch.empty(k, dtype=torch.float64, device=W.device)
+    u = torch.empty((n_o, k), dtype=torch.float64, device=W.device)
+    ws = torch.empty(lib.ptd_eigh_factored_workspace_bytes(n_o, n_i, k), dtype=torch.uint8, device=W.device)
+    with torch.cuda.device(W.device):
+        rc = lib.ptd_eigh_factored(W.data_ptr(), W.stride(0), _code(W), n_o, n_i, Ex.data_ptr(), Ex.stride(0), k,
+                                   w.data_ptr(), u.data_ptr(), k, ws.data_ptr(), ws.numel(), _stream(W))
+    if rc == -2:  # PTD_ERR_UNSUPPORTED
+        return None
+    _hip.check(rc, "ptd_eigh_factored")
+    return w, u
+
+
 def tridiagonalize(A: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """Diagnostic: (d, e, eigenvalues of T) of the Householder tridiagonalisation of symmetric f64 A."""
     _dev(A)

@@ -41,6 +41,18 @@ def eigh(A, k=None):
     return (w, v) if k is None else (w, v[:, v.shape[1] - max(1, min(int(k), v.shape[1])):])
 
 
+def eigh_factored(W, Ex, k):
+    """Same contract as ops.eigh_factored, through the same algebra the kernel uses
+    (G = W^T W = L L^T, B = L^T Ex L, u = W L^-T s) in f64 LAPACK."""
+    w = W.double()
+    ell = torch.linalg.cholesky(w.T @ w)
+    b = ell.T @ Ex @ ell
+    lam, s = torch.linalg.eigh(0.5 * (b + b.T))
+    k = max(1, min(int(k), s.shape[1]))
+    t = torch.linalg.solve_triangular(ell.T, s[:, s.shape[1] - k:], upper=True)
+    return lam[lam.shape[0] - k:], w @ t
+
+
 def matmul(a, b, bias=None, alpha=1.0, out_dtype=None):
     c = (a @ b) * alpha if alpha != 1.0 else a @ b
     if bias is not None:
@@ -68,8 +80,8 @@ def installed(monkeypatch):
     import ptdeco_amd
     from ptdeco_amd import _engine, ops
 
-    for name in ("syrk_accumulate", "colsum_accumulate", "cov_finalize", "eigh", "matmul", "lowrank_forward",
-                 "nsr", "sym_kl"):
+    for name in ("syrk_accumulate", "colsum_accumulate", "cov_finalize", "eigh", "eigh_factored", "matmul",
+                 "lowrank_forward", "nsr", "sym_kl"):
         monkeypatch.setattr(ops, name, globals()[name])
     monkeypatch.setattr(_engine, "require_device", lambda d: torch.device(d))
     yield ptdeco_amd

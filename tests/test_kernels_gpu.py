@@ -223,6 +223,34 @@ def test_eigh_dense_low_end_uses_tridiagonal_route_for_top_half(ops, monkeypatch
     assert (a @ v - v * w.cpu()[n // 2:]).abs().max().item() <= 1e-11
 
 
+@pytest.mark.parametrize("n_o,n_i,k,wdt", [(700, 300, 120, torch.float32), (1792, 512, 256, torch.float32),
+                                           (300, 100, 100, torch.float64), (640, 256, 128, torch.bfloat16)])
+def test_eigh_factored_matches_direct(ops, n_o, n_i, k, wdt):
+    """Top-k eigenvectors of W Ex W^T through the n_i-sized problem == LAPACK on the n_o-sized matrix."""
+    g = torch.Generator().manual_seed(n_o + n_i)
+    w = (torch.randn(n_o, n_i, generator=g) / n_i**0.5).to(wdt)
+    x = torch.randn(3 * n_i, n_i, generator=g, dtype=torch.float64) * torch.logspace(0, -1.5, n_i, dtype=torch.float64)
+    ex = x.T @ x / x.shape[0]
+    got = ops.eigh_factored(w.to(DEV), ex.to(DEV), k)
+    assert got is not None
+    lam, u = got[0].cpu(), got[1].cpu()
+    c = w.double() @ ex @ w.double().T
+    w_ref, v_ref = torch.linalg.eigh(c)
+    assert (lam - w_ref[n_o - k:]).abs().max().item() <= 1e-10 * w_ref.max().item()
+    assert (u.T @ u - torch.eye(k, dtype=torch.float64)).abs().max().item() <= 5e-9
+    assert (c @ u - u * lam).abs().max().item() <= 1e-10 * w_ref.max().item()
+    p, p_ref = u @ u.T, v_ref[:, n_o - k:] @ v_ref[:, n_o - k:].T
+    assert (p - p_ref).norm().item() <= 1e-6 * math.sqrt(k)
+
+
+def test_eigh_factored_rank_deficient_weight_is_refused(ops):
+    g = torch.Generator().manual_seed(3)
+    a, b = torch.randn(200, 40, generator=g), torch.randn(40, 64, generator=g)
+    w = a @ b  # rank 40 < n_i = 64: W^T W singular
+    ex = torch.eye(64, dtype=torch.float64)
+    assert ops.eigh_factored(w.to(DEV), ex.to(DEV), 16) is None
+
+
 def test_eigh_mid_size_against_lapack(ops, method):
     n = 1024
     y = _rand((2048, n), 77).double() * torch.logspace(0, -2, n, dtype=torch.float64)
