@@ -3,7 +3,7 @@ synthetic calibration ([1, 2048, n_in] tokens, D = 8 data steps, M = 2 metric st
 decomposition), one MI355X.  Prints a JSON object; the 224-layer figure is an extrapolation
 (32 blocks x {q, o: 4096->4096; k, v: 4096->1024; gate, up: 4096->14336; down: 14336->4096})."""
 import copy, itertools, json, sys, time, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import ptdeco_amd
 from ptdeco_amd import ops
 

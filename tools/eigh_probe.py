@@ -1,6 +1,6 @@
 """Developer probe (not part of the product): time / accuracy of ptd_eigh on a C2-like matrix."""
 import os, sys, time, torch
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ptdeco_amd import ops
 
 def make(n, T, seed=0):

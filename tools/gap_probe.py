@@ -1,8 +1,9 @@
 import sys, torch
 sys.path.insert(0, "/root/repo")
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from ptdeco_amd import ops
-from tools_eigh_probe import make
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.abspath(__file__)))
+from eigh_probe import make
 c = make(4096, 4096)
 w = torch.linalg.eigvalsh(c.cpu())
 g = (w[1:] - w[:-1]) / w.max()

@@ -1,6 +1,6 @@
 """Developer probe: host-side profile of one bench step (cProfile) + phase wall times."""
 import cProfile, copy, itertools, pstats, sys, time, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import bench, ptdeco_amd
 dev = torch.device("cuda", 0)
 model0, data, metric = bench.make_workload(1, dev, bench.D_STEPS, 7 * bench.M_STEPS)

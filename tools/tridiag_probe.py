@@ -1,6 +1,6 @@
 """Developer probe: tridiagonalisation + bisection vs LAPACK."""
 import sys, time, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from ptdeco_amd import ops
 
 def cov(n, seed=0):
