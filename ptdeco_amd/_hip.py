@@ -71,6 +71,14 @@ def load() -> ctypes.CDLL:
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH):
+        # a fresh checkout: build the library in tree (hipcc cross-compiles gfx950 without a GPU)
+        import shutil
+        import subprocess
+
+        if shutil.which("make") and shutil.which(os.environ.get("HIPCC", "hipcc")):
+            subprocess.run(["make", "-C", os.path.join(_HERE, "csrc"), "-j8"], check=False,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    if not os.path.exists(LIB_PATH):
         raise HipLibraryError(
             f"{LIB_PATH} not found: build it with `make -C ptdeco_amd/csrc` (or __graft_entry__.build()). "
             "ptdeco_amd has no CPU fallback.")

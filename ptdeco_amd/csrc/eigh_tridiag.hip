@@ -197,59 +197,68 @@ __global__ __launch_bounds__(256) void sytrd_alpha_kernel(const double* __restri
   __shared__ double c1[NB], c2[NB], wj1[NB], vj1[NB];
   __shared__ double part1[4][64], part2[4][64];
   __shared__ double vs[64], wfs[64];
-  __shared__ double sc[8];  // tau, scale, delta, a2prev, wraw_j[jn]
+  __shared__ double red[4];
+  __shared__ double wrj_s;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int j = jn - 1, i = in - 1;
-  if (wid == 0) {
-    const double xn2 = wave_total(px2, npx2, lane);
-    if (lane == 0) {
-      const double delta = cs->delta, alpha = cs->alpha;
-      double tau, beta, scale;
-      if (xn2 == 0.0) {
-        tau = 0.0; beta = alpha; scale = 0.0;
-      } else {
-        const double nrm = sqrt(alpha * alpha + xn2);
-        beta = alpha >= 0.0 ? -nrm : nrm;
-        tau = (beta - alpha) / beta;
-        scale = 1.0 / (alpha - beta);
-      }
-      sc[0] = tau; sc[1] = scale; sc[2] = delta; sc[3] = 0.5 * delta;
-      if (blockIdx.x == 0) {
-        taus[j] = tau;
-        e[j] = beta;
-        d[j] = colbuf[j] - delta;  // x_j[j] = base_j[j] - delta v_{j-1}[j], v_{j-1}[j] = 1 (delta = 0 if i == 0)
-      }
-    }
-  }
-  __syncthreads();
-  const double tau = sc[0], scale = sc[1], delta = sc[2], a2prev = sc[3];
-  if (tid < i) {
-    const double c2v = cb[3 * NB + tid] + scale * cb[2 * NB + tid];
-    double c1v = cb[NB + tid] + scale * cb[tid];
-    if (tid == i - 1) c1v += a2prev * c2v;  // W_{i-1} = w_raw + alpha2 v_{j-1}
-    c1[tid] = c1v;
-    c2[tid] = c2v;
-    vj1[tid] = Vp[(int64_t)tid * ldv + jn];
-    wj1[tid] = (tid == i - 1) ? wraw_prev[jn] + a2prev * Vp[(int64_t)(i - 1) * ldv + jn]
-                              : Wp[(int64_t)tid * ldv + jn];
-  }
-  __syncthreads();
-  if (wid == 1) {  // w_raw_j[jn], needed by every row of the next column
-    double s = 0.0;
-    for (int k = lane; k < i; k += 64) s += vj1[k] * c1[k] + wj1[k] * c2[k];
-    s = wave_sum_d(s);
-    if (lane == 0) sc[4] = tau * ((qv[jn] + scale * sd[jn]) - s);
-  }
   const int r = jn + blockIdx.x * 64 + lane;
+  // ---- phase 0: every global operand of the prologue is requested up front (one latency)
+  double px = 0.0;
+  for (int q = tid; q < npx2; q += 256) px += px2[q];
+  const double delta = cs->delta, alpha = cs->alpha;
+  double r_sdW = 0.0, r_qW = 0.0, r_sdV = 0.0, r_qV = 0.0, r_vj1 = 0.0, r_wj1 = 0.0, r_vpjn = 0.0;
+  if (tid < i) {
+    r_sdW = cb[tid]; r_qW = cb[NB + tid]; r_sdV = cb[2 * NB + tid]; r_qV = cb[3 * NB + tid];
+    r_vj1 = Vp[(int64_t)tid * ldv + jn];
+    r_wj1 = (tid == i - 1) ? wraw_prev[jn] : Wp[(int64_t)tid * ldv + jn];
+    if (tid == i - 1) r_vpjn = Vp[(int64_t)(i - 1) * ldv + jn];
+  }
+  double r_col = 0.0, r_vprev = 0.0, r_wprev = 0.0, r_qv = 0.0, r_sd = 0.0, r_a = 0.0;
+  if (wid == 0 && r < n) {
+    r_col = colbuf[r];
+    if (i > 0) { r_vprev = Vp[(int64_t)(i - 1) * ldv + r]; r_wprev = wraw_prev[r]; }
+    r_qv = qv[r]; r_sd = sd[r];
+    if (do_next) r_a = A[(int64_t)jn * ld + r];
+  }
+  const double qv_jn = qv[jn], sd_jn = sd[jn];
+  px = wave_sum_d(px);
+  if (lane == 0) red[wid] = px;
+  __syncthreads();
+  // ---- reflector scalars of column j (every thread computes the same values)
+  const double xn2 = (red[0] + red[1]) + (red[2] + red[3]);
+  double tau, beta, scale;
+  if (xn2 == 0.0) {
+    tau = 0.0; beta = alpha; scale = 0.0;
+  } else {
+    const double nrm = sqrt(alpha * alpha + xn2);
+    beta = alpha >= 0.0 ? -nrm : nrm;
+    tau = (beta - alpha) / beta;
+    scale = 1.0 / (alpha - beta);
+  }
+  const double a2prev = 0.5 * delta;
+  if (blockIdx.x == 0 && tid == 0) {
+    taus[j] = tau;
+    e[j] = beta;
+    d[j] = colbuf[j] - delta;  // x_j[j] = base_j[j] - delta v_{j-1}[j], v_{j-1}[j] = 1 (delta = 0 if i == 0)
+  }
+  if (tid < i) {
+    const double c2v = r_qV + scale * r_sdV;
+    double c1v = r_qW + scale * r_sdW;
+    double wj = r_wj1;
+    if (tid == i - 1) {  // W_{i-1} = w_raw + alpha2 v_{j-1}
+      c1v += a2prev * c2v;
+      wj += a2prev * r_vpjn;
+    }
+    c1[tid] = c1v; c2[tid] = c2v; vj1[tid] = r_vj1; wj1[tid] = wj;
+  }
   if (wid == 0) {
     double vr = 0.0, wf = 0.0;
     if (r < n) {
-      const double vprev = i > 0 ? Vp[(int64_t)(i - 1) * ldv + r] : 0.0;
-      const double xr = colbuf[r] - delta * vprev;
+      const double xr = r_col - delta * r_vprev;
       vr = (r == jn) ? 1.0 : xr * scale;
       Vp[(int64_t)i * ldv + r] = vr;
       if (i > 0) {
-        wf = wraw_prev[r] + a2prev * vprev;
+        wf = r_wprev + a2prev * r_vprev;
         Wp[(int64_t)(i - 1) * ldv + r] = wf;
       }
     }
@@ -257,6 +266,12 @@ __global__ __launch_bounds__(256) void sytrd_alpha_kernel(const double* __restri
     wfs[lane] = wf;
   }
   __syncthreads();
+  if (wid == 1) {  // w_raw_j[jn], needed by every row of the next column
+    double sacc = 0.0;
+    for (int k = lane; k < i; k += 64) sacc += vj1[k] * c1[k] + wj1[k] * c2[k];
+    sacc = wave_sum_d(sacc);
+    if (lane == 0) wrj_s = tau * ((qv_jn + scale * sd_jn) - sacc);
+  }
   double a1 = 0.0, a2 = 0.0;
   if (r < n) {
     for (int k = wid; k < i; k += 4) {
@@ -273,12 +288,12 @@ __global__ __launch_bounds__(256) void sytrd_alpha_kernel(const double* __restri
     double dot = 0.0;
     if (r < n) {
       const double s1 = (part1[0][lane] + part1[1][lane]) + (part1[2][lane] + part1[3][lane]);
-      const double wr = tau * ((qv[r] + scale * sd[r]) - s1);
+      const double wr = tau * ((r_qv + scale * r_sd) - s1);
       wraw_cur[r] = wr;
       dot = wr * vs[lane];
       if (do_next) {
         const double s2 = (part2[0][lane] + part2[1][lane]) + (part2[2][lane] + part2[3][lane]);
-        colbuf[r] = A[(int64_t)jn * ld + r] - s2 - (vs[lane] * sc[4] + wr);
+        colbuf[r] = r_a - s2 - (vs[lane] * wrj_s + wr);
       }
     }
     dot = wave_sum_d(dot);
