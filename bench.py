@@ -255,12 +255,15 @@ def main():
                    "ranks_kept": {k: v["__meta__"]["proportion"] for k, v in cfg.items()}},
     }
 
-    if rank == 0 and not args.no_extras:
-        # one extra, untimed, profiled step: per-phase HIP-event timings of the eigensolver
+    prof = []
+    if not args.no_extras:
+        # one extra, untimed, profiled step: per-phase HIP-event timings of the eigensolver.
+        # Every rank takes part (the step contains collectives); rank 0 keeps the profile.
         ops.EIGH_PROFILE = []
         one_step()
-        torch.cuda.synchronize()
+        barrier()
         prof, ops.EIGH_PROFILE = ops.EIGH_PROFILE, None
+    if rank == 0 and not args.no_extras:
         if prof:
             p = prof[0]
             n = p["n"]

@@ -17,6 +17,7 @@
 //       two ds_read_b64_tr_b16 (hardware 4x16 transpose); 320 B = 256 + 64 puts
 //       the four k rows of a half wave on disjoint bank quarters -> conflict free.
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -222,6 +223,106 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmBf16Args a)
     }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Fast path for the nn.Linear layout (both operands k-contiguous, M % 128 == N % 128 == 0,
+// K % 64 == 0): the operand tiles go HBM -> LDS directly (global_load_lds_dwordx4, no VGPR
+// round trip, no ds_write), double buffered, one barrier per K step (the CDNA4 guide's
+// "minimum 2-phase" pipeline).  An LDS-DMA wave instruction writes 1 KiB contiguously
+// (8 rows x 128 B), so the image is unpadded [row][64 bf16]; bank conflicts of the
+// ds_read_b128 fragment reads are removed by an XOR swizzle applied on the per-lane SOURCE
+// address and again on the read: 16-byte chunk c of row r lives at position c ^ ((r >> 1) & 7).
+// (Even/odd rows occupy the two halves of a 256-B bank row; XOR-ing with (r >> 1) & 7 gives
+// the 16 rows of every ds_read_b128 lane group 16 distinct 16-B slots.)
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_nt_glds_kernel(const GemmBf16Args a) {
+  __shared__ __attribute__((aligned(16))) char lds[2 * 2 * 16384];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 1, wn = wid & 1;
+  // XCD-aware tile order: blocks b and b + 8 share an XCD (and its L2); give each XCD a
+  // contiguous run of tiles (bijective for any grid size)
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int ti = wg % a.tiles_m, tj = wg / a.tiles_m;
+  const int m0 = ti * BM, n0 = tj * BN;
+  const int nk = a.K / BK;
+  const unsigned short* Ag = a.A + (int64_t)m0 * a.sam;
+  const unsigned short* Bg = a.B + (int64_t)n0 * a.sbn;
+
+  // this lane's share of a staging instruction: row (lane >> 3) of an 8-row group, position lane & 7
+  const int srow = lane >> 3, spos = lane & 7;
+  auto stage = [&](int buf, int kt) {
+    char* As = lds + buf * 32768;
+    char* Bs = As + 16384;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r0 = (wid * 4 + q) * 8;          // wave-uniform first row of this 1-KiB piece
+      const int r = r0 + srow;
+      const int c = spos ^ ((r >> 1) & 7);       // source chunk that belongs at position spos
+      const unsigned short* sa = Ag + (int64_t)r * a.sam + kt * BK + c * 8;
+      const unsigned short* sb = Bg + (int64_t)r * a.sbn + kt * BK + c * 8;
+      __builtin_amdgcn_global_load_lds((glb_void*)sa, (lds_void*)(As + r0 * 128), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_void*)sb, (lds_void*)(Bs + r0 * 128), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  stage(0, 0);
+  __syncthreads();
+  const int fr = lane & 31, fh = lane >> 5;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+    const char* As = lds + cur * 32768;
+    const char* Bs = As + 16384;
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 16) {
+      const int c = (kk >> 3) + fh;
+      s16x8 af[2], bf[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int ra = wm * 64 + i * 32 + fr, rb = wn * 64 + i * 32 + fr;
+        af[i] = *reinterpret_cast<const s16x8*>(As + ra * 128 + ((c ^ ((ra >> 1) & 7)) << 4));
+        bf[i] = *reinterpret_cast<const s16x8*>(Bs + rb * 128 + ((c ^ ((rb >> 1) & 7)) << 4));
+      }
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[0], acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[1], acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[0], acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[1], acc[1][1], 0, 0, 0);
+    }
+    __syncthreads();  // retires this step's LDS-DMA (vmcnt(0)) and the reads of buffer `cur`
+  }
+
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        float o = a.alpha * acc[i][j][r];
+        if (a.bias) o += bf16_to_f32(a.bias[col]);
+        if (EPI == EPI_STORE_BF16)
+          reinterpret_cast<unsigned short*>(a.C)[(int64_t)row * a.ldc + col] = f32_to_bf16(o);
+        else
+          reinterpret_cast<float*>(a.C)[(int64_t)row * a.ldc + col] = o;
+      }
+    }
+}
+
 template <int EPI>
 void launch_bf16(const GemmBf16Args& a, bool akc, bool bkc, dim3 grid, hipStream_t st) {
   if (akc && bkc) hipLaunchKernelGGL((gemm_bf16_kernel<true, true, EPI>), grid, dim3(256), 0, st, a);
@@ -250,7 +351,11 @@ int gemm_bf16(const unsigned short* A, int64_t sam, int64_t sak, const unsigned 
   a.vecA = aligned16(A) && ((akc ? sam : sak) % 8 == 0);
   a.vecB = aligned16(B) && ((bkc ? sbn : sbk) % 8 == 0);
   dim3 grid((unsigned)(a.tiles_m * ceil_div(N, BN)), 1);
-  if (c_bf16) launch_bf16<EPI_STORE_BF16>(a, akc, bkc, grid, st);
+  static const bool no_glds = getenv("PTD_GEMM_NO_GLDS") != nullptr;
+  if (!no_glds && akc && bkc && a.vecA && a.vecB && M % BM == 0 && N % BN == 0 && K % BK == 0 && K >= BK) {
+    if (c_bf16) hipLaunchKernelGGL((gemm_bf16_nt_glds_kernel<EPI_STORE_BF16>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((gemm_bf16_nt_glds_kernel<EPI_STORE_F32>), grid, dim3(256), 0, st, a);
+  } else if (c_bf16) launch_bf16<EPI_STORE_BF16>(a, akc, bkc, grid, st);
   else launch_bf16<EPI_STORE_F32>(a, akc, bkc, grid, st);
   PTD_CHECK_LAUNCH("gemm_bf16");
   return PTD_OK;

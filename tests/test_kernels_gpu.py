@@ -313,6 +313,20 @@ def test_gemm_bf16_f32_out_is_exact_products(ops):
         assert torch.equal(got, ar @ br), layout
 
 
+def test_gemm_bf16_direct_to_lds_path_exact(ops):
+    """Tile-aligned nn.Linear layout takes the LDS-DMA kernel with the XOR-swizzled image: exact
+    integer products catch any mistake in the source / read swizzle pair or the XCD tile remap."""
+    g = torch.Generator().manual_seed(7)
+    for (M, N, K) in [(128, 128, 64), (256, 384, 192), (1024, 640, 512)]:
+        a = torch.randint(-4, 5, (M, K), generator=g).to(torch.bfloat16)
+        b = torch.randint(-4, 5, (N, K), generator=g).to(torch.bfloat16)
+        bias = torch.randint(-3, 4, (N,), generator=g).to(torch.bfloat16)
+        got = ops.matmul(a.to(DEV), b.to(DEV).T, bias=bias.to(DEV), out_dtype=torch.float32).cpu()
+        assert torch.equal(got, a.float() @ b.float().T + bias.float()), (M, N, K)
+        got16 = ops.matmul(a.to(DEV), b.to(DEV).T).cpu()
+        assert torch.equal(got16.float(), (a.float() @ b.float().T).to(torch.bfloat16).float()), (M, N, K)
+
+
 def test_gemm_f32_exact_integers(ops):
     g = torch.Generator().manual_seed(2)
     for layout in LAYOUTS:

@@ -1,0 +1,71 @@
+"""C4 (BASELINE configs[3]) end to end at reduced depth: dwain.decompose_in_place on a
+Llama-3-8B-shaped stack with FULL layer widths (4096 / 1024 / 14336) and `blocks` blocks, synthetic
+calibration [1, 2048, 4096], D = 8, M = 2, precomputing_covariance_num_splits = 4, one MI355X.
+Usage: python tools/c4_stack.py [blocks] [bf16]"""
+import itertools, json, os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ptdeco_amd
+
+dev = torch.device("cuda", 0)
+blocks = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+dtype = torch.bfloat16 if "bf16" in sys.argv else torch.float32
+D, KV, FF = 4096, 1024, 14336
+
+
+class Block(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        mk = lambda i, o: torch.nn.Linear(i, o, bias=False)
+        self.q, self.k, self.v, self.o = mk(D, D), mk(D, KV), mk(D, KV), mk(D, D)
+        self.gate, self.up, self.down = mk(D, FF), mk(D, FF), mk(FF, D)
+
+    @staticmethod
+    def norm(x):
+        return x * torch.rsqrt(x.float().pow(2).mean(-1, keepdim=True) + 1e-6).to(x.dtype)
+
+    def forward(self, x):
+        h = self.norm(x)
+        x = x + self.o(self.q(h) + self.k(h).repeat(1, 1, D // KV) + self.v(h).repeat(1, 1, D // KV))
+        h = self.norm(x)
+        return x + self.down(torch.nn.functional.silu(self.gate(h)) * self.up(h))
+
+
+class Stack(torch.nn.Module):
+    def __init__(self, n):
+        super().__init__()
+        self.blocks = torch.nn.ModuleList(Block() for _ in range(n))
+        self.head = torch.nn.Linear(D, D, bias=False)
+
+    def forward(self, b):
+        x = b["x"]
+        for blk in self.blocks:
+            x = blk(x)
+        return self.head(x)
+
+
+def ce(b, y):
+    return torch.nn.functional.cross_entropy(y.float().reshape(-1, y.shape[-1]), b["targets"].reshape(-1), reduction="none")
+
+
+g = torch.Generator().manual_seed(0)
+model = Stack(blocks)
+with torch.no_grad():
+    for p in model.parameters():
+        p.copy_(torch.randn(p.shape, generator=g) / p.shape[1] ** 0.5)
+model.to(dev).to(dtype)
+xs = [torch.randn(1, 2048, D, generator=g).to(dev).to(dtype) for _ in range(12)]
+with torch.no_grad():
+    bt = [{"x": x, "targets": model({"x": x}).argmax(-1)} for x in xs]
+torch.cuda.synchronize()
+trace = []
+t0 = time.perf_counter()
+cfg = ptdeco_amd.dwain.decompose_in_place(
+    module=model, device=dev, data_iterator=itertools.cycle(bt), loss_fn=ce, metric_iterator=itertools.cycle(bt[8:]),
+    num_data_steps=8, num_metric_steps=2, nsr_final_threshold=1.0, finetune_fn=lambda m, d, n: m,
+    blacklisted_module_names=["head"], precomputing_covariance_num_splits=4, trace=trace)
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+layers = 7 * blocks
+print(json.dumps({"blocks": blocks, "dtype": str(dtype), "layers": layers, "seconds": dt, "layers_per_s": layers / dt,
+                  "candidates_evaluated": len(trace), "decomposed": {k: v["__meta__"]["proportion"] for k, v in cfg.items()},
+                  "max_mem_gb": torch.cuda.max_memory_allocated() / 2**30}))

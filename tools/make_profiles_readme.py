@@ -69,5 +69,17 @@ if os.path.exists(c4p):
         o.append(f"| {k} | {v['n_in']} -> {v['n_out']} | {v['ms_per_layer']:.0f} | {desc} |\n")
     o.append(f"\nExtrapolated to the 224 layers of the 32-block stack: {c4['extrapolated_224_layers_s']:.0f} s on one GPU "
              f"({c4['extrapolated_layers_per_s_1gpu']:.1f} layers/s).\n")
+c4b = os.path.join(root, f"c4_shapes_bf16_r{rnd}.json")
+if os.path.exists(c4b):
+    cb16 = json.load(open(c4b))
+    o.append(f"\nSame in bf16 (`c4_shapes_bf16_r{rnd}.json`): " + ", ".join(f"{k} {cb16[k]['ms_per_layer']:.0f} ms" for k in ("q_o", "k_v", "gate_up", "down"))
+             + f"; 224 layers extrapolated {cb16['extrapolated_224_layers_s']:.0f} s.\n")
+stk = os.path.join(root, f"c4_stack_2blocks_r{rnd}.json")
+if os.path.exists(stk):
+    st = json.load(open(stk))
+    o.append(f"\nEnd to end on a 2-block full-width stack (`c4_stack_2blocks_r{rnd}.json`, `python tools/c4_stack.py 2`): "
+             f"f32 {st['f32']['seconds']:.1f} s, bf16 {st['bf16']['seconds']:.1f} s for 14 layers ({st['f32']['candidates_evaluated']} candidates); "
+             "here the user model's own forwards (two per metric step through the whole stack, torch / hipBLASLt) dominate, "
+             "as SURVEY 3.5 predicts for real LLM configs.\n")
 open(os.path.join(root, "README.md"), "w").write("".join(o))
 print("".join(o))
