@@ -34,7 +34,19 @@ if e:
     o.append(f"* whole eigensolver ({e['method']}, n = {e['n']}): {e['ms_per_matrix']:.0f} ms per matrix = "
              f"{e['algorithmic_tflops']:.2f} TFLOP/s on the algorithmic 4/3 n^3 + 2 n^2 k flops "
              f"({100 * e['frac_of_f64_mfma_peak_on_algorithmic_flops']:.1f} % of the f64 MFMA peak: a one-stage reduction is bandwidth-bound).\n")
-o.append("* `roofline.traffic` is null: `rocprofv3 --pmc FETCH_SIZE` segfaulted on this workload (python process, ROCm 7.2) on the gpurun box.\n\n")
+pmc = os.path.join(root, f"pmc_symv_r{rnd}.json")
+if os.path.exists(pmc):
+    pm = json.load(open(pmc))
+    o.append(f"* `roofline.traffic` (`pmc_symv_r{rnd}.json` / `.csv`, one row per launch): HBM-side bytes of `sytrd_symv_kernel` from separate "
+             "`rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes over `tools/pmc_driver 4096` (torch-free, counter collection restricted "
+             "with `--kernel-include-regex sytrd_symv`; an unrestricted pass over a python process segfaulted or stalled), FETCH_SIZE doubled as the "
+             f"microarchitecture guide prescribes for gfx950: **{pm['traffic_bytes_per_launch'] / 1e6:.1f} MB per launch = "
+             f"{pm['traffic_over_algorithmic']:.3f} x the algorithmic {pm['algorithmic_bytes_per_launch'] / 1e6:.1f} MB** "
+             f"(first launch {pm['first_launch']['read'] / 1e6:.1f} MB read for {pm['first_launch']['algorithmic'] / 1e6:.1f} MB); "
+             f"L2 hit rate {pm['l2_hit_rate']:.2f} (the x vector; the matrix itself is re-fetched from the memory side every launch, "
+             "also when it would fit in L2, because L2 does not keep lines across kernel boundaries).\n\n")
+else:
+    o.append("* `roofline.traffic` is null: no PMC pass committed for this round.\n\n")
 o.append("## Top kernels (rocprofv3 --stats)\n\n| kernel | calls | avg us | % of GPU time |\n|---|---|---|---|\n")
 for x in rows[:14]:
     o.append(f"| `{short(x['Name'])}` | {x['Calls']} | {float(x['AverageNs']) / 1e3:.1f} | {float(x['Percentage']):.2f} |\n")
