@@ -180,6 +180,225 @@ __global__ __launch_bounds__(256) void sytrd_symv_kernel(const double* __restric
   }
 }
 
+// ---- symmetric SYMV: only the lower triangle of the trailing matrix is read.
+// The trailing square is cut on an ABSOLUTE grid of TR x TC tiles; a lower-triangle tile (I, J)
+// contributes  A_IJ x_J  to the rows of I ("row part", reduced over the lanes of a wave) and
+// A_IJ^T x_I  to the columns of J ("column part", accumulated per lane), strictly below the
+// diagonal for the latter.  Partial results go to rowpart[J][r] / colpart[I][c]; the consumer
+// (alpha kernel) adds, for row r, rowpart[J0 .. r/TC][r] + colpart[r/TR .. nI-1][r] in a fixed
+// order, so the result does not depend on scheduling.  Tile rows come in groups of TQ that share
+// their range of J; group u (counted from the first group that touches row j+1) has TQ (u+1) tiles.
+// Behind the tiles the same launch carries the V_k / W_k dot products (4 rows per workgroup) and
+// the strided column read q[r] = A[r][j+1] with the partial sums of x^2 (256 rows per workgroup).
+constexpr int TR = 64, TC = 256, TQ = TC / TR;
+
+struct SymPart {
+  double* rowpart;
+  double* colpart;
+  int64_t ldp;
+  int nI;       // tile rows: ceil(n / TR)
+  int enabled;
+};
+
+// p[16] per lane -> sum over the 64 lanes of row (lane >> 2), returned in every lane
+__device__ __forceinline__ double transpose_reduce16(double (&p)[16], int lane) {
+  {
+    const bool hi = lane & 32;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const double send = hi ? p[t] : p[t + 8];
+      const double keep = hi ? p[t + 8] : p[t];
+      p[t] = keep + __shfl_xor(send, 32);
+    }
+  }
+  {
+    const bool hi = lane & 16;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const double send = hi ? p[t] : p[t + 4];
+      const double keep = hi ? p[t + 4] : p[t];
+      p[t] = keep + __shfl_xor(send, 16);
+    }
+  }
+  {
+    const bool hi = lane & 8;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const double send = hi ? p[t] : p[t + 2];
+      const double keep = hi ? p[t + 2] : p[t];
+      p[t] = keep + __shfl_xor(send, 8);
+    }
+  }
+  {
+    const bool hi = lane & 4;
+    const double send = hi ? p[0] : p[1];
+    const double keep = hi ? p[1] : p[0];
+    p[0] = keep + __shfl_xor(send, 4);
+  }
+  p[0] += __shfl_xor(p[0], 2);
+  p[0] += __shfl_xor(p[0], 1);
+  return p[0];
+}
+
+template <bool GEN>
+__device__ __forceinline__ void symv2_tile_body(const double2 (&a0)[16], const double2 (&a1)[16], const double2 xa,
+                                                const double2 xb, const double* __restrict__ xs, int rbase, int nclamp,
+                                                int cA, int cB, double (&p)[16], double (&acc)[4]) {
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const double xr = xs[t];
+    double r0 = a0[t].x, r1 = a0[t].y, r2 = a1[t].x, r3 = a1[t].y;  // row part: c <= R
+    double c0 = r0, c1 = r1, c2 = r2, c3 = r3;                      // column part: c < R
+    if (GEN) {
+      const int R = min(rbase + t, nclamp);
+      r0 = (cA <= R) ? r0 : 0.0;     c0 = (cA < R) ? c0 : 0.0;
+      r1 = (cA + 1 <= R) ? r1 : 0.0; c1 = (cA + 1 < R) ? c1 : 0.0;
+      r2 = (cB <= R) ? r2 : 0.0;     c2 = (cB < R) ? c2 : 0.0;
+      r3 = (cB + 1 <= R) ? r3 : 0.0; c3 = (cB + 1 < R) ? c3 : 0.0;
+    }
+    p[t] = (r0 * xa.x + r1 * xa.y) + (r2 * xb.x + r3 * xb.y);
+    acc[0] += c0 * xr; acc[1] += c1 * xr; acc[2] += c2 * xr; acc[3] += c3 * xr;
+  }
+}
+
+__global__ __launch_bounds__(256) void sytrd_symv2_kernel(const double* __restrict__ A, int64_t ld, int n, int j, int i,
+                                                          const double* __restrict__ colbuf,
+                                                          const double* __restrict__ Vp,
+                                                          const double* __restrict__ Wp, int64_t ldv,
+                                                          const double* __restrict__ wraw_prev,
+                                                          const double* __restrict__ partial2, int nparts2,
+                                                          const double* __restrict__ taus, SymPart sp, int ntiles,
+                                                          int nextra, double* __restrict__ qv,
+                                                          double* __restrict__ cb, double* __restrict__ px2,
+                                                          ColState* __restrict__ cs) {
+  __shared__ __attribute__((aligned(16))) double xs[TR];
+  __shared__ __attribute__((aligned(16))) double colred[4][TC];
+  __shared__ double part[4][SROWS];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int b = blockIdx.x;
+  const double* vprev = Vp + (int64_t)max(i - 1, 0) * ldv;  // multiplied by delta == 0 when i == 0
+  if (b < ntiles) {
+    // ---- tile (I, J)
+    const int g0 = (j + 1) / TC;
+    int u = (int)((sqrtf(2.f * (float)b + 1.f) - 1.f) * 0.5f);
+    while (TQ / 2 * u * (u + 1) > b) --u;
+    while (TQ / 2 * (u + 1) * (u + 2) <= b) ++u;
+    const int rem = b - TQ / 2 * u * (u + 1);
+    const int I = TQ * (g0 + u) + rem / (u + 1), J = g0 + rem % (u + 1);
+    const int R0 = I * TR, C0 = J * TC;
+    if (R0 + TR - 1 < j + 1 || R0 >= n) return;
+    const int cA = C0 + 2 * lane, cB = cA + 128;
+    const int rbase = R0 + 16 * wid;
+    double2 a0[16], a1[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const double* rowp = A + (int64_t)min(rbase + t, n - 1) * ld;
+      a0[t] = *reinterpret_cast<const double2*>(rowp + cA);
+      a1[t] = *reinterpret_cast<const double2*>(rowp + cB);
+    }
+    double2 xa = *reinterpret_cast<const double2*>(colbuf + cA);
+    double2 xb = *reinterpret_cast<const double2*>(colbuf + cB);
+    const double2 va = *reinterpret_cast<const double2*>(vprev + cA);
+    const double2 vb = *reinterpret_cast<const double2*>(vprev + cB);
+    double xrow = 0.0, vrow = 0.0;
+    const int Rx = R0 + tid;
+    const bool rowok = tid < TR && Rx >= j + 2 && Rx < n;
+    if (rowok) { xrow = colbuf[Rx]; vrow = vprev[Rx]; }
+    double delta = 0.0;
+    if (i > 0) delta = -taus[j - 1] * wave_total(partial2, nparts2, lane);  // 2 * alpha2_{j-1}
+    if (tid < TR) xs[tid] = rowok ? xrow - delta * vrow : 0.0;
+    xa.x = (cA >= j + 2) ? xa.x - delta * va.x : 0.0;
+    xa.y = (cA + 1 >= j + 2) ? xa.y - delta * va.y : 0.0;
+    xb.x = (cB >= j + 2) ? xb.x - delta * vb.x : 0.0;
+    xb.y = (cB + 1 >= j + 2) ? xb.y - delta * vb.y : 0.0;
+    __syncthreads();
+    double p[16], acc[4] = {0.0, 0.0, 0.0, 0.0};
+    const bool general = (C0 + TC - 1 > R0) || (C0 + TC > n);
+    if (general) symv2_tile_body<true>(a0, a1, xa, xb, xs + 16 * wid, rbase, n - 1, cA, cB, p, acc);
+    else symv2_tile_body<false>(a0, a1, xa, xb, xs + 16 * wid, rbase, n - 1, cA, cB, p, acc);
+    const double rowsum = transpose_reduce16(p, lane);
+    if ((lane & 3) == 0) sp.rowpart[(int64_t)J * sp.ldp + rbase + (lane >> 2)] = rowsum;
+    *reinterpret_cast<double2*>(&colred[wid][2 * lane]) = double2{acc[0], acc[1]};
+    *reinterpret_cast<double2*>(&colred[wid][128 + 2 * lane]) = double2{acc[2], acc[3]};
+    __syncthreads();
+    sp.colpart[(int64_t)I * sp.ldp + C0 + tid] =
+        (colred[0][tid] + colred[1][tid]) + (colred[2][tid] + colred[3][tid]);
+    return;
+  }
+  double delta = 0.0;
+  if (i > 0) delta = -taus[j - 1] * wave_total(partial2, nparts2, lane);
+  if (b < ntiles + nextra) {
+    // ---- dot products of W_k (k < i; k == i-1 is w_raw of the previous column) and V_k with x
+    const int total = 2 * i;
+    const int g0 = (b - ntiles) * SROWS;
+    const double* rp[SROWS];
+    double acc[SROWS];
+#pragma unroll
+    for (int t = 0; t < SROWS; ++t) {
+      const int g = min(g0 + t, total - 1);
+      if (g < i) rp[t] = (g == i - 1) ? wraw_prev : Wp + (int64_t)g * ldv;
+      else rp[t] = Vp + (int64_t)(g - i) * ldv;
+      acc[t] = 0.0;
+    }
+    const int cstart = (j + 2) & ~1;
+    for (int c = cstart + 2 * lane + 128 * wid; c < n; c += 512) {
+      double2 xa = *reinterpret_cast<const double2*>(colbuf + c);
+      const double2 va = *reinterpret_cast<const double2*>(vprev + c);
+      xa.x -= delta * va.x; xa.y -= delta * va.y;
+      if (c < j + 2) xa.x = 0.0;
+      if (c + 1 >= n) xa.y = 0.0;
+#pragma unroll
+      for (int t = 0; t < SROWS; ++t) {
+        const double2 r2 = *reinterpret_cast<const double2*>(rp[t] + c);
+        acc[t] += r2.x * xa.x + r2.y * xa.y;
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < SROWS; ++t) {
+      const double sdot = wave_sum_d(acc[t]);
+      if (lane == 0) part[wid][t] = sdot;
+    }
+    __syncthreads();
+    if (tid < SROWS && g0 + tid < total) {
+      const int g = g0 + tid;
+      const double sdot = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+      if (g < i) {
+        const double* row = (g == i - 1) ? wraw_prev : Wp + (int64_t)g * ldv;
+        cb[g] = sdot;
+        cb[NB + g] = row[j + 1];
+      } else {
+        const int k = g - i;
+        cb[2 * NB + k] = sdot;
+        cb[3 * NB + k] = Vp[(int64_t)k * ldv + j + 1];
+      }
+    }
+    return;
+  }
+  // ---- q[r] = A[r][j+1] and the partial sums of x^2 over 256 rows
+  {
+    const int chunk = b - ntiles - nextra;
+    const int r = j + 1 + chunk * 256 + tid;
+    double x2 = 0.0;
+    if (r < n) {
+      qv[r] = A[(int64_t)r * ld + j + 1];
+      if (r >= j + 2) {
+        const double xr = colbuf[r] - delta * vprev[r];
+        x2 = xr * xr;
+      }
+    }
+    x2 = wave_sum_d(x2);
+    if (lane == 0) part[wid][0] = x2;
+    __syncthreads();
+    if (tid == 0) {
+      px2[chunk] = (part[0][0] + part[1][0]) + (part[2][0] + part[3][0]);
+      if (chunk == 0) {
+        cs->delta = delta;
+        cs->alpha = colbuf[j + 1] - delta * vprev[j + 1];
+      }
+    }
+  }
+}
+
 // alpha(jn): finishes column j = jn - 1 (panel index i = in - 1 >= 0) and, if do_next, forms the
 // updated column jn.  Grid ceil((n - jn) / 64) x 256 threads; lane = row, the four waves split k.
 __global__ __launch_bounds__(256) void sytrd_alpha_kernel(const double* __restrict__ A, int64_t ld, int n, int jn,
@@ -193,11 +412,13 @@ __global__ __launch_bounds__(256) void sytrd_alpha_kernel(const double* __restri
                                                           const double* __restrict__ px2, int npx2,
                                                           const ColState* __restrict__ cs,
                                                           double* __restrict__ partial2, double* __restrict__ d,
-                                                          double* __restrict__ e, double* __restrict__ taus) {
+                                                          double* __restrict__ e, double* __restrict__ taus,
+                                                          SymPart sp) {
   __shared__ double c1[NB], c2[NB], wj1[NB], vj1[NB];
   __shared__ double part1[4][64], part2[4][64];
   __shared__ double vs[64], wfs[64];
-  __shared__ double red[4];
+  __shared__ double red[4], red2[4];
+  __shared__ double sdp[4][64];
   __shared__ double wrj_s;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int j = jn - 1, i = in - 1;
@@ -213,17 +434,61 @@ __global__ __launch_bounds__(256) void sytrd_alpha_kernel(const double* __restri
     r_wj1 = (tid == i - 1) ? wraw_prev[jn] : Wp[(int64_t)tid * ldv + jn];
     if (tid == i - 1) r_vpjn = Vp[(int64_t)(i - 1) * ldv + jn];
   }
-  double r_col = 0.0, r_vprev = 0.0, r_wprev = 0.0, r_qv = 0.0, r_sd = 0.0, r_a = 0.0;
+  double r_col = 0.0, r_vprev = 0.0, r_wprev = 0.0, r_qv = 0.0, r_a = 0.0;
   if (wid == 0 && r < n) {
     r_col = colbuf[r];
     if (i > 0) { r_vprev = Vp[(int64_t)(i - 1) * ldv + r]; r_wprev = wraw_prev[r]; }
-    r_qv = qv[r]; r_sd = sd[r];
+    r_qv = qv[r];
     if (do_next) r_a = A[(int64_t)jn * ld + r];
   }
-  const double qv_jn = qv[jn], sd_jn = sd[jn];
+  // the panel rows V_k[r], W_k[r] of the two corrections (wave wid takes k = wid, wid + 4, ...):
+  // requested here, used after the second barrier (W_{i-1} is finalised in this launch: wfs)
+  double pv[NB / 4], pw[NB / 4];
+#pragma unroll
+  for (int q = 0; q < NB / 4; ++q) {
+    const int k = wid + 4 * q;
+    pv[q] = 0.0; pw[q] = 0.0;
+    if (k < i && r < n) {
+      pv[q] = Vp[(int64_t)k * ldv + r];
+      if (k < i - 1) pw[q] = Wp[(int64_t)k * ldv + r];
+    }
+  }
+  // unscaled SYMV products of this workgroup's rows and of row jn: either sd[] itself or, after a
+  // symmetric SYMV, the fixed-order sum of its row / column partials (the four waves split the list)
+  double sdacc = 0.0, sdjn = 0.0;
+  if (sp.enabled) {
+    const int J0 = jn / TC;
+    if (r < n) {
+      const int nrow = r / TC - J0 + 1, i0 = r / TR, cnt = nrow + sp.nI - i0;
+      constexpr int SDU = 8;
+      for (int k0 = wid; k0 < cnt; k0 += 4 * SDU) {
+        double v[SDU];
+#pragma unroll
+        for (int q = 0; q < SDU; ++q) {
+          const int k = k0 + 4 * q;
+          v[q] = 0.0;
+          if (k < cnt)
+            v[q] = (k < nrow) ? sp.rowpart[(int64_t)(J0 + k) * sp.ldp + r]
+                              : sp.colpart[(int64_t)(i0 + k - nrow) * sp.ldp + r];
+        }
+        sdacc += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+      }
+    }
+    const int i0 = jn / TR, cnt = 1 + sp.nI - i0;
+    for (int k = tid; k < cnt; k += 256)
+      sdjn += (k == 0) ? sp.rowpart[(int64_t)J0 * sp.ldp + jn] : sp.colpart[(int64_t)(i0 + k - 1) * sp.ldp + jn];
+  } else {
+    if (wid == 0 && r < n) sdacc = sd[r];
+    if (tid == 0) sdjn = sd[jn];
+  }
+  const double qv_jn = qv[jn];
   px = wave_sum_d(px);
-  if (lane == 0) red[wid] = px;
+  sdjn = wave_sum_d(sdjn);
+  if (lane == 0) { red[wid] = px; red2[wid] = sdjn; }
+  sdp[wid][lane] = sdacc;
   __syncthreads();
+  const double sd_jn = (red2[0] + red2[1]) + (red2[2] + red2[3]);
+  const double r_sd = (sdp[0][lane] + sdp[1][lane]) + (sdp[2][lane] + sdp[3][lane]);
   // ---- reflector scalars of column j (every thread computes the same values)
   const double xn2 = (red[0] + red[1]) + (red[2] + red[3]);
   double tau, beta, scale;
@@ -273,10 +538,12 @@ __global__ __launch_bounds__(256) void sytrd_alpha_kernel(const double* __restri
     if (lane == 0) wrj_s = tau * ((qv_jn + scale * sd_jn) - sacc);
   }
   double a1 = 0.0, a2 = 0.0;
-  if (r < n) {
-    for (int k = wid; k < i; k += 4) {
-      const double vk = Vp[(int64_t)k * ldv + r];
-      const double wk = (k == i - 1) ? wfs[lane] : Wp[(int64_t)k * ldv + r];
+#pragma unroll
+  for (int q = 0; q < NB / 4; ++q) {
+    const int k = wid + 4 * q;
+    if (k < i) {
+      const double vk = pv[q];
+      const double wk = (k == i - 1) ? wfs[lane] : pw[q];
       a1 += vk * c1[k] + wk * c2[k];
       a2 += vk * wj1[k] + wk * vj1[k];
     }
@@ -665,21 +932,29 @@ struct TridiagPlan {
   int npanels;
   size_t off_A, off_V, off_W, off_col, off_p, off_part, off_refl, off_d, off_e, off_e2, off_tau, off_bounds, off_lam;
   size_t off_u1, off_u2, off_u3, off_lm, off_sw, off_G, off_T, off_W1, off_W2, off_wraw, off_wraw2, off_part2, off_cbuf;
-  size_t off_qv, off_px2;
+  size_t off_qv, off_px2, off_rowpart, off_colpart;
+  int64_t ldp;     // leading dimension of the symmetric SYMV's partial-result arrays
   size_t total;
 };
 
 TridiagPlan tridiag_plan(int64_t n) {
   TridiagPlan p{};
   p.n = (int)n;
-  p.ld = (int64_t)align_up((size_t)n, 8);
+  // rows padded to whole SYMV tiles (the symmetric kernel reads TC-wide segments) once the matrix is
+  // large enough for it to be used
+  p.ld = (int64_t)align_up((size_t)n, n >= 512 ? TC : 8);
+  if (n >= 512) {
+    const char* pad = getenv("PTD_LD_PAD");
+    p.ld += pad ? atoi(pad) / 2 * 2 : 64;  // rows rotate over the memory channels
+  }
+  p.ldp = (int64_t)align_up((size_t)n, TC);
   p.npanels = (int)ceil_div(n, NB);
   size_t o = 0;
   auto take = [&](size_t bytes) { size_t at = o; o += align_up(bytes, 256); return at; };
   p.off_A = take((size_t)n * p.ld * 8);
   p.off_V = take((size_t)p.npanels * NB * p.ld * 8);
   p.off_W = take((size_t)NB * p.ld * 8);
-  p.off_col = take((size_t)(n + 8) * 8);
+  p.off_col = take((size_t)(p.ldp + 8) * 8);
   p.off_p = take((size_t)(n + 8) * 8);
   p.off_part = take((size_t)(ceil_div(n, 64) + 8) * 8);
   p.off_refl = take(256);
@@ -706,6 +981,8 @@ TridiagPlan tridiag_plan(int64_t n) {
   p.off_cbuf = take((size_t)4 * NB * 8);
   p.off_qv = take((size_t)(n + 8) * 8);
   p.off_px2 = take((size_t)(ceil_div(n + 2 * NB, SROWS) + 8) * 8);
+  p.off_rowpart = take((size_t)ceil_div(n, TC) * p.ldp * 8);
+  p.off_colpart = take((size_t)ceil_div(n, TR) * p.ldp * 8);
   p.total = o;
   return p;
 }
@@ -735,10 +1012,18 @@ int sytrd_f64(const TridiagPlan& p, char* base, SymvTimer* timer, hipStream_t st
   double* qv = reinterpret_cast<double*>(base + p.off_qv);       // A[r][j+1]
   double* px2 = reinterpret_cast<double*>(base + p.off_px2);
   ColState* cs = reinterpret_cast<ColState*>(base + p.off_refl);
+  // symmetric (lower-triangle) SYMV for trailing orders >= sym_min; PTD_SYMV=full switches it off
+  SymPart sp{reinterpret_cast<double*>(base + p.off_rowpart), reinterpret_cast<double*>(base + p.off_colpart), p.ldp,
+             (int)ceil_div(n, TR), 0};
+  const char* symv_env = getenv("PTD_SYMV");
+  const char* symv_min_env = getenv("PTD_SYMV_MIN");
+  const int sym_min = (symv_env && !strcmp(symv_env, "full")) ? INT32_MAX
+                      : std::max(512, symv_min_env ? atoi(symv_min_env) : 1024);
+  bool prev_sym = false;  // how the open column's SYMV was computed
   PTD_CHECK_HIP(hipMemsetAsync(Vall, 0, (size_t)p.npanels * NB * ld * 8, st));
   PTD_CHECK_HIP(hipMemsetAsync(taus, 0, (size_t)n * 8, st));
   PTD_CHECK_HIP(hipMemsetAsync(e, 0, (size_t)n * 8, st));
-  PTD_CHECK_HIP(hipMemsetAsync(colbuf, 0, (size_t)(n + 8) * 8, st));
+  PTD_CHECK_HIP(hipMemsetAsync(colbuf, 0, (size_t)(p.ldp + 8) * 8, st));
   PTD_CHECK_HIP(hipMemsetAsync(wr[0], 0, (size_t)(n + 8) * 8, st));
   PTD_CHECK_HIP(hipMemsetAsync(wr[1], 0, (size_t)(n + 8) * 8, st));
   for (int pn = 0; pn < p.npanels; ++pn) {
@@ -755,12 +1040,27 @@ int sytrd_f64(const TridiagPlan& p, char* base, SymvTimer* timer, hipStream_t st
                            j, colbuf);
       } else {
         const int blocks = (int)ceil_div(n - j, 64);
+        SymPart spa = sp;
+        spa.enabled = prev_sym;
         hipLaunchKernelGGL(sytrd_alpha_kernel, dim3(blocks), dim3(256), 0, st, Aw, ld, n, j, i, 1, Vp, Wp, ld,
-                           wr[(i & 1)], wr[(i - 1) & 1], colbuf, sd, qv, cbuf, px2, npx2, cs, partial2, d, e, taus);
+                           wr[(i & 1)], wr[(i - 1) & 1], colbuf, sd, qv, cbuf, px2, npx2, cs, partial2, d, e, taus,
+                           spa);
         nparts2 = blocks;
       }
       const int m = n - j - 1;
-      if (m > 0) {
+      if (m >= sym_min && n >= 512) {
+        const int U = (int)ceil_div(n, TC) - (j + 1) / TC;  // groups of tile rows from the one holding row j+1
+        const int ntiles = TQ / 2 * U * (U + 1);
+        const int nextra = (int)ceil_div(2 * i, SROWS);
+        npx2 = (int)ceil_div(m, 256);
+        const dim3 grid((unsigned)(ntiles + nextra + npx2));
+        hipEvent_t ev0 = timer ? timer->ev[2 * (size_t)j] : nullptr, ev1 = timer ? timer->ev[2 * (size_t)j + 1] : nullptr;
+        hipExtLaunchKernelGGL(sytrd_symv2_kernel, grid, dim3(256), 0, st, ev0, ev1, 0, Aw, ld, n, j, i, colbuf, Vp, Wp,
+                              ld, wr[(i + 1) & 1], partial2, nparts2, taus, sp, ntiles, nextra, qv, cbuf, px2, cs);
+        prev_sym = true;
+        open = true;
+      } else if (m > 0) {
+        prev_sym = false;
         const int rows = m + 2 * i;
         npx2 = (int)ceil_div(rows, SROWS);
         if (timer) {
@@ -783,9 +1083,11 @@ int sytrd_f64(const TridiagPlan& p, char* base, SymvTimer* timer, hipStream_t st
     if (open) {
       // finish the panel's last column (no next column to form), then finalise its w
       const int blocks = (int)ceil_div(n - t0, 64);
+      SymPart spa = sp;
+      spa.enabled = prev_sym;
       hipLaunchKernelGGL(sytrd_alpha_kernel, dim3(std::max(blocks, 1)), dim3(256), 0, st, Aw, ld, n, t0, cols, 0, Vp,
                          Wp, ld, wr[(cols & 1)], wr[(cols - 1) & 1], colbuf, sd, qv, cbuf, px2, npx2, cs, partial2,
-                         d, e, taus);
+                         d, e, taus, spa);
       const int mt = n - t0;
       if (mt > 0) {
         hipLaunchKernelGGL(sytrd_wfix_kernel, dim3((unsigned)ceil_div(mt, 256)), dim3(256), 0, st, n, t0, cols - 1,
