@@ -146,13 +146,15 @@ int ptd_gemm(const void* A, int64_t sam, int64_t sak, const void* B, int64_t sbk
              void* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int ab_dtype, int c_dtype,
              double alpha, const void* bias, void* stream);
 
-/* y[T,n_o] = (x[T,n_i] @ A[r,n_i]^T) @ B[n_o,r]^T (+ bias[n_o]).  h_ws is a
- * [T, r] scratch of the operand dtype.  The decomposed layer's forward:
- * dwain.py:74-85 / falor.py:84-95 (two nn.Linear), dwain.py:126-144 (two 1x1 convs,
- * x viewed as [B*H*W, C]). */
+/* y[T,n_o] = (x[T,n_i] @ A[r,n_i]^T) @ B[n_o,r]^T (+ bias[n_o]).  The workspace holds the
+ * [T, r] intermediate of the operand dtype and, for f32 operands with a small rank, the partial
+ * tiles of the first product's K split (added in a fixed order: results do not depend on
+ * scheduling).  The decomposed layer's forward: dwain.py:74-85 / falor.py:84-95 (two nn.Linear),
+ * dwain.py:126-144 (two 1x1 convs, x viewed as [B*H*W, C]). */
+size_t ptd_lowrank_forward_workspace_bytes(int64_t T, int64_t n_i, int64_t r, int dtype);
 int ptd_lowrank_forward(const void* x, int64_t ldx, int64_t T, int64_t n_i, const void* A, int64_t lda,
                         int64_t r, const void* B, int64_t ldb, int64_t n_o, const void* bias, void* y,
-                        int64_t ldy, void* h_ws, int dtype, void* stream);
+                        int64_t ldy, void* ws, size_t ws_bytes, int dtype, void* stream);
 
 /* ---- rank-selection metrics ------------------------------------------------ */
 

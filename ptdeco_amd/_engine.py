@@ -247,6 +247,30 @@ def build_factors(weight2d: torch.Tensor, u: torch.Tensor, rank: int, dtype: tor
     return uk, big_u, w_deco
 
 
+class FactorBank:
+    """The factors of every candidate rank of one layer from ONE product: U_max = W^T u_max for the
+    largest rank that can be asked for; a rank-r candidate takes the trailing r columns of u_max and
+    U_max (the eigenvectors are sorted by ascending eigenvalue), which are the very dot products
+    ``build_factors`` would form for that rank."""
+
+    def __init__(self, weight2d: torch.Tensor, u: torch.Tensor, max_rank: int, dtype: torch.dtype):
+        n = u.shape[1]
+        self.max_rank = max(1, min(int(max_rank), n))
+        self.uk = u[:, n - self.max_rank:].to(dtype).contiguous()
+        self.weight = weight2d if weight2d.dtype == dtype else weight2d.to(dtype)
+        self.big_u = ops.matmul(self.weight.T, self.uk)
+
+    def get(self, rank: int, dense: bool = False):
+        """(uk [n, r], U [n_in, r] (a column slice), W~ or None) like ``build_factors``."""
+        if rank > self.max_rank:
+            raise ValueError(f"rank {rank} above the bank's {self.max_rank}")
+        lo = self.max_rank - rank
+        uk = self.uk[:, lo:].contiguous()
+        big_u = self.big_u[:, lo:]
+        w_deco = ops.matmul(uk, big_u.T) if dense else None
+        return uk, big_u, w_deco
+
+
 def build_pair(layer: torch.nn.Module, big_u: torch.Tensor, uk: torch.Tensor, dtype: Optional[torch.dtype]):
     """The rank-r replacement of `layer`: first weight U^T [r, n_in], second weight uk [n_out, r],
     bias copied (dwain.py:69-85, 121-144).  A 1x1 conv pair takes default stride / padding /

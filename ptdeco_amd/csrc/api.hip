@@ -131,7 +131,7 @@ int ptd_gemm(const void* A, int64_t sam, int64_t sak, const void* B, int64_t sbk
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (ab_dtype == PTD_F32 && c_dtype == PTD_F32)
     return gemm_f32(static_cast<const float*>(A), sam, sak, static_cast<const float*>(B), sbk, sbn,
-                    static_cast<float*>(C), ldc, M, N, K, alpha, static_cast<const float*>(bias), st);
+                    static_cast<float*>(C), ldc, M, N, K, alpha, static_cast<const float*>(bias), nullptr, 0, st);
   if (ab_dtype == PTD_BF16 && (c_dtype == PTD_BF16 || c_dtype == PTD_F32))
     return gemm_bf16(static_cast<const unsigned short*>(A), sam, sak, static_cast<const unsigned short*>(B), sbk,
                      sbn, C, ldc, M, N, K, c_dtype == PTD_BF16, alpha, static_cast<const unsigned short*>(bias),
@@ -143,15 +143,39 @@ int ptd_gemm(const void* A, int64_t sam, int64_t sak, const void* B, int64_t sbk
   return PTD_ERR_UNSUPPORTED;
 }
 
+static size_t elt_bytes(int dtype) { return dtype == PTD_F32 ? 4 : 2; }
+
+size_t ptd_lowrank_forward_workspace_bytes(int64_t T, int64_t n_i, int64_t r, int dtype) {
+  size_t b = align_up((size_t)T * (size_t)r * elt_bytes(dtype), 256);
+  if (dtype == PTD_F32) b += gemm_f32_workspace_bytes(T, r, n_i);
+  return b;
+}
+
 int ptd_lowrank_forward(const void* x, int64_t ldx, int64_t T, int64_t n_i, const void* A, int64_t lda, int64_t r,
-                        const void* B, int64_t ldb, int64_t n_o, const void* bias, void* y, int64_t ldy, void* h_ws,
-                        int dtype, void* stream) {
-  PTD_REQUIRE(x && A && B && y && h_ws, "ptd_lowrank_forward: null pointer");
+                        const void* B, int64_t ldb, int64_t n_o, const void* bias, void* y, int64_t ldy, void* ws,
+                        size_t ws_bytes, int dtype, void* stream) {
+  PTD_REQUIRE(x && A && B && y && ws, "ptd_lowrank_forward: null pointer");
   PTD_REQUIRE(ldx >= n_i && lda >= n_i && ldb >= r && ldy >= n_o, "ptd_lowrank_forward: bad leading dimension");
+  PTD_REQUIRE(dtype == PTD_F32 || dtype == PTD_BF16, "ptd_lowrank_forward: dtype must be f32 or bf16");
+  const size_t h_bytes = align_up((size_t)T * (size_t)r * elt_bytes(dtype), 256);
+  if (ws_bytes < h_bytes) {
+    set_error("ptd_lowrank_forward: workspace %zu < required %zu bytes", ws_bytes, h_bytes);
+    return PTD_ERR_WORKSPACE;
+  }
+  void* h = ws;
   // h = x A^T : A(m,k) = x[m*ldx + k], B(k,n) = A[n*lda + k];   y = h B^T + bias
-  int rc = ptd_gemm(x, ldx, 1, A, 1, lda, h_ws, r, T, r, n_i, dtype, dtype, 1.0, nullptr, stream);
+  int rc;
+  if (dtype == PTD_F32) {
+    // a small rank leaves the first product with few output tiles: its K range is split over
+    // workgroups through the rest of the workspace (deterministic two-pass reduction)
+    rc = gemm_f32(static_cast<const float*>(x), ldx, 1, static_cast<const float*>(A), 1, lda, static_cast<float*>(h), r,
+                  T, r, n_i, 1.0, nullptr, static_cast<char*>(ws) + h_bytes, ws_bytes - h_bytes,
+                  static_cast<hipStream_t>(stream));
+  } else {
+    rc = ptd_gemm(x, ldx, 1, A, 1, lda, h, r, T, r, n_i, dtype, dtype, 1.0, nullptr, stream);
+  }
   if (rc != PTD_OK) return rc;
-  return ptd_gemm(h_ws, r, 1, B, 1, ldb, y, ldy, T, n_o, r, dtype, dtype, 1.0, bias, stream);
+  return ptd_gemm(h, r, 1, B, 1, ldb, y, ldy, T, n_o, r, dtype, dtype, 1.0, bias, stream);
 }
 
 size_t ptd_nsr_workspace_bytes(int64_t R, int64_t C) { return nsr_workspace_bytes(R, C); }

@@ -48,6 +48,7 @@ struct GemmF32Args {
   int kchunk;  // K range of blockIdx.y is [y*kchunk, min(K, (y+1)*kchunk)); multiple of BK
   int atomic;  // accumulate with atomics (split K)
   int vecA, vecB;
+  int64_t cslab;  // EPI_STORE split K: blockIdx.y writes its partial tile to C + y * cslab
 };
 
 // Fetch this thread's 4 x 4 elements of a 128 x 32 operand tile.
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmF32Args a) {
         if (EPI == EPI_STORE) {
           float o = a.alpha * v;
           if (a.bias) o += a.bias[col];
-          reinterpret_cast<float*>(a.C)[(int64_t)row * a.ldc + col] = o;
+          reinterpret_cast<float*>(a.C)[(int64_t)blockIdx.y * a.cslab + (int64_t)row * a.ldc + col] = o;
         } else if (EPI == EPI_ACC_F64) {
           double* e = reinterpret_cast<double*>(a.C) + (int64_t)row * a.ldc + col;
           const double d = a.scale * (double)v;
@@ -207,6 +208,39 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmF32Args a) {
     }
 }
 
+// second pass of the EPI_STORE split K: C = alpha * (slab_0 + slab_1 + ...) + bias, slabs added in
+// index order (deterministic), four outputs per thread
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, int ksplit, int64_t cslab,
+                                                            int M, int N, float alpha, const float* __restrict__ bias,
+                                                            float* __restrict__ C, int64_t ldc) {
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;  // quad index over M x ceil(N/4)
+  const int nq = (N + 3) >> 2;
+  const int row = (int)(q / nq), c0 = (int)(q % nq) * 4;
+  if (row >= M) return;
+  const float* p = slabs + (int64_t)row * N + c0;
+  if (c0 + 3 < N && (N & 3) == 0) {
+    f32x4 acc = *reinterpret_cast<const f32x4*>(p);
+    for (int s = 1; s < ksplit; ++s) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(p + (int64_t)s * cslab);
+      acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float o = alpha * acc[j];
+      if (bias) o += bias[c0 + j];
+      C[(int64_t)row * ldc + c0 + j] = o;
+    }
+  } else {
+    for (int j = 0; j < 4 && c0 + j < N; ++j) {
+      float acc = p[j];
+      for (int s = 1; s < ksplit; ++s) acc += p[(int64_t)s * cslab + j];
+      float o = alpha * acc;
+      if (bias) o += bias[c0 + j];
+      C[(int64_t)row * ldc + c0 + j] = o;
+    }
+  }
+}
+
 template <int EPI>
 void launch_f32(const GemmF32Args& a, bool akc, bool bkc, dim3 grid, hipStream_t st) {
   if (akc && bkc) hipLaunchKernelGGL((gemm_f32_kernel<true, true, EPI>), grid, dim3(256), 0, st, a);
@@ -217,8 +251,24 @@ void launch_f32(const GemmF32Args& a, bool akc, bool bkc, dim3 grid, hipStream_t
 
 }  // namespace
 
+// K split of a product with few output tiles (a skinny operand, e.g. x U with a small rank): the
+// partial tiles go to slabs in a caller-provided workspace and a second launch adds them in a fixed
+// order, so the result does not depend on scheduling.  Returns 1 when splitting does not pay.
+int gemm_f32_ksplit(int64_t M, int64_t N, int64_t K) {
+  const int64_t tiles = ceil_div(M, BM) * ceil_div(N, BN);
+  if (tiles >= 160 || K < 16 * BK) return 1;
+  const int64_t ks = std::min<int64_t>(std::min<int64_t>(ceil_div(256, tiles), K / (8 * BK)), 16);
+  return (int)std::max<int64_t>(ks, 1);
+}
+
+size_t gemm_f32_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+  const int ks = gemm_f32_ksplit(M, N, K);
+  return ks > 1 ? (size_t)ks * (size_t)M * (size_t)N * sizeof(float) : 0;
+}
+
 int gemm_f32(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn, float* C,
-             int64_t ldc, int64_t M, int64_t N, int64_t K, double alpha, const float* bias, hipStream_t st) {
+             int64_t ldc, int64_t M, int64_t N, int64_t K, double alpha, const float* bias, void* ws, size_t ws_bytes,
+             hipStream_t st) {
   PTD_REQUIRE((sam == 1) != (sak == 1) || (M == 1 || K == 1), "ptd_gemm: exactly one stride of A must be 1");
   PTD_REQUIRE((sbk == 1) != (sbn == 1) || (N == 1 || K == 1), "ptd_gemm: exactly one stride of B must be 1");
   if (M == 0 || N == 0) return PTD_OK;
@@ -233,8 +283,23 @@ int gemm_f32(const float* A, int64_t sam, int64_t sak, const float* B, int64_t s
   const bool akc = (sak == 1), bkc = (sbk == 1);
   a.vecA = aligned16(A) && ((akc ? sam : sak) % 4 == 0);
   a.vecB = aligned16(B) && ((bkc ? sbn : sbk) % 4 == 0);
-  dim3 grid((unsigned)(a.tiles_m * ceil_div(N, BN)), 1);
-  launch_f32<EPI_STORE>(a, akc, bkc, grid, st);
+  const int tiles = (int)(a.tiles_m * ceil_div(N, BN));
+  int ksplit = ws ? gemm_f32_ksplit(M, N, K) : 1;
+  if (ksplit > 1 && (size_t)ksplit * (size_t)M * (size_t)N * sizeof(float) > ws_bytes) ksplit = 1;
+  if (ksplit > 1) {
+    a.kchunk = (int)align_up((size_t)ceil_div(K, ksplit), BK);
+    ksplit = (int)ceil_div(K, a.kchunk);
+  }
+  if (ksplit > 1) {
+    a.C = ws; a.ldc = N; a.cslab = (int64_t)M * N;
+    a.alpha = 1.f; a.bias = nullptr;
+    launch_f32<EPI_STORE>(a, akc, bkc, dim3((unsigned)tiles, (unsigned)ksplit), st);
+    const int64_t quads = M * ceil_div(N, 4);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)ceil_div(quads, 256)), dim3(256), 0, st,
+                       static_cast<const float*>(ws), ksplit, a.cslab, (int)M, (int)N, (float)alpha, bias, C, ldc);
+  } else {
+    launch_f32<EPI_STORE>(a, akc, bkc, dim3((unsigned)tiles, 1), st);
+  }
   PTD_CHECK_LAUNCH("gemm_f32");
   return PTD_OK;
 }

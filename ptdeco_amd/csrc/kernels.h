@@ -7,7 +7,9 @@ namespace ptd {
 
 // gemm_f32.hip
 int gemm_f32(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbk, int64_t sbn, float* C,
-             int64_t ldc, int64_t M, int64_t N, int64_t K, double alpha, const float* bias, hipStream_t st);
+             int64_t ldc, int64_t M, int64_t N, int64_t K, double alpha, const float* bias, void* ws, size_t ws_bytes,
+             hipStream_t st);
+size_t gemm_f32_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int syrk_f32(const float* Y, int64_t T, int64_t n, int64_t ldy, void* E, int64_t ldE, bool e_f64, double scale,
              hipStream_t st);
 

@@ -251,11 +251,13 @@ def _process_module(*, root_module, decomposed_submodule_name, data_iterator, lo
         # metric batches are consumed in candidate order; with several GPUs candidate c is
         # evaluated by rank c % G on exactly the batches the sequential order gives it
         sums = torch.zeros((max(len(candidates), 1), 3), dtype=torch.float64, device=device)
+        # U = W^T uk once for the largest candidate; smaller ranks are column slices of it (:424-429)
+        bank = eng.FactorBank(orig_weight, u_matrix, candidates[0][0], orig_dtype) if candidates else None
         for c, (rank_new, _drop) in enumerate(candidates):
             batches = [next(metric_iterator) for _ in range(num_metric_steps)]
             if not shard.mine(c):
                 continue
-            candidate = eng.build_factors(orig_weight, u_matrix, rank_new, orig_dtype, dense=not fast)
+            candidate = bank.get(rank_new, dense=not fast)
             for batch in batches:
                 sums[c] += _compute_metrics(input_dict=utils.to_device(batch, device), root_module=root_module,
                                             tap=tap, orig_weight=orig_weight, candidate=candidate, loss_fn=loss_fn)
@@ -292,7 +294,7 @@ def _process_module(*, root_module, decomposed_submodule_name, data_iterator, lo
             logger.info(f"{indent}i=FINAL rank={rank_best}/{full_rank} {proportion=:.4f} nsr={nsr_best:.6f} "
                         f"ppl={ppl_deco_best:.6f}")
         if decomposition_occurred and full_rank != rank_best and decide:
-            uk, big_u, _ = eng.build_factors(orig_weight, u_matrix, rank_best, orig_dtype)  # :507-511
+            uk, big_u, _ = bank.get(rank_best)  # :507-511
             new_module = eng.build_pair(layer, big_u, uk, orig_dtype).to(orig_device)
             drop_in_params = baseline_params - _get_params_for_proportion(proportion, dim_in, dim_out)
             return {"proportion": proportion, "nsr_final": nsr_best, "ppl_final": ppl_deco_best,

@@ -121,9 +121,10 @@ def _process_module(*, root_module, decomposed_submodule_name, data_iterator, ns
         rank_best = full_rank
         nsr_best = kl_best = nsr_new = kl_new = 0.0
         uk = big_u = None
+        bank = eng.FactorBank(orig_weight, u, full_rank, torch.float32)  # U = W^T u once (:346-348)
         for i, rank_width in enumerate(_bisection_widths(full_rank), start=1):
             rank_new = rank_best - rank_width
-            candidate = eng.build_factors(orig_weight, u, rank_new, torch.float32, dense=not fast)  # :346-348
+            candidate = bank.get(rank_new, dense=not fast)
             uk, big_u, _ = candidate
             acc = torch.zeros(2, dtype=torch.float64, device=device)
             for _ in range(num_metric_steps):

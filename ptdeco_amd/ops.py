@@ -188,13 +188,15 @@ def lowrank_forward(x2d: torch.Tensor, A: torch.Tensor, B: torch.Tensor, bias: O
     r, n_o = A.shape[0], B.shape[0]
     assert A.shape[1] == n_i and B.shape[1] == r and x2d.dtype == A.dtype == B.dtype
     y = torch.empty((T, n_o), dtype=x2d.dtype, device=x2d.device)
-    h = torch.empty((T, r), dtype=x2d.dtype, device=x2d.device)
+    lib = _hip.load()
+    ws_bytes = lib.ptd_lowrank_forward_workspace_bytes(T, n_i, r, _code(x2d))
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=x2d.device)
     if bias is not None:
         bias = bias.to(x2d.dtype).contiguous()
     with torch.cuda.device(x2d.device):
-        rc = _hip.load().ptd_lowrank_forward(x2d.data_ptr(), x2d.stride(0), T, n_i, A.data_ptr(), A.stride(0), r,
-                                             B.data_ptr(), B.stride(0), n_o, _ptr(bias), y.data_ptr(), n_o,
-                                             h.data_ptr(), _code(x2d), _stream(x2d))
+        rc = lib.ptd_lowrank_forward(x2d.data_ptr(), x2d.stride(0), T, n_i, A.data_ptr(), A.stride(0), r,
+                                     B.data_ptr(), B.stride(0), n_o, _ptr(bias), y.data_ptr(), n_o,
+                                     ws.data_ptr(), ws_bytes, _code(x2d), _stream(x2d))
     _hip.check(rc, "ptd_lowrank_forward")
     return y
 

@@ -342,7 +342,8 @@ def test_gemm_f32_exact_integers(ops):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("T,ni,r,no", [(72, 64, 8, 32), (500, 256, 96, 320), (1, 10, 3, 7)])
+@pytest.mark.parametrize("T,ni,r,no", [(72, 64, 8, 32), (500, 256, 96, 320), (1, 10, 3, 7), (1000, 1536, 40, 130),
+                                       (2048, 4096, 256, 64)])
 def test_lowrank_forward(ops, dtype, T, ni, r, no):
     x = _rand((T, ni), 1, dtype)
     a = _rand((r, ni), 2, dtype, ni ** -0.5)
@@ -355,6 +356,24 @@ def test_lowrank_forward(ops, dtype, T, ni, r, no):
     ref = h @ b.double().T + bias.double()
     tol = (1e-5 if dtype == torch.float32 else 1.5e-2) * max(1.0, ref.abs().max().item())
     assert (got - ref).abs().max().item() <= tol
+
+
+def test_lowrank_forward_split_k_exact_and_repeatable(ops):
+    """Small rank: the first product's K range is split over workgroups and the partial tiles are
+    added in a fixed order -- exact on small integers, bit-identical from run to run."""
+    g = torch.Generator().manual_seed(9)
+    T, ni, r, no = 1030, 2048, 24, 96
+    x = torch.randint(-4, 5, (T, ni), generator=g).float()
+    a = torch.randint(-4, 5, (r, ni), generator=g).float()
+    b = torch.randint(-2, 3, (no, r), generator=g).float()
+    got = ops.lowrank_forward(x.to(DEV), a.to(DEV), b.to(DEV), None).cpu()
+    assert torch.equal(got, (x @ a.T) @ b.T)
+    xr = _rand((T, ni), 1, torch.float32)
+    ar = _rand((r, ni), 2, torch.float32, ni ** -0.5)
+    br = _rand((no, r), 3, torch.float32, r ** -0.5)
+    y1 = ops.lowrank_forward(xr.to(DEV), ar.to(DEV), br.to(DEV), None)
+    y2 = ops.lowrank_forward(xr.to(DEV), ar.to(DEV), br.to(DEV), None)
+    assert torch.equal(y1, y2)
 
 
 # ---------------------------------------------------------------- metrics

@@ -100,3 +100,58 @@ def load_state(model: torch.nn.Module, arrays, prefix: str) -> None:
     with torch.no_grad():
         for name, p in model.named_parameters():
             p.copy_(torch.from_numpy(arrays[prefix + name]))
+
+
+class ViTBlock(torch.nn.Module):
+    def __init__(self, d, heads, mlp):
+        super().__init__()
+        self.heads = heads
+        self.norm1 = torch.nn.LayerNorm(d)
+        self.qkv = torch.nn.Linear(d, 3 * d)
+        self.proj = torch.nn.Linear(d, d)
+        self.norm2 = torch.nn.LayerNorm(d)
+        self.fc1 = torch.nn.Linear(d, mlp)
+        self.fc2 = torch.nn.Linear(mlp, d)
+
+    def forward(self, x):
+        b, t, d = x.shape
+        q, k, v = self.qkv(self.norm1(x)).reshape(b, t, 3, self.heads, d // self.heads).permute(2, 0, 3, 1, 4)
+        a = torch.nn.functional.scaled_dot_product_attention(q, k, v)
+        x = x + self.proj(a.transpose(1, 2).reshape(b, t, d))
+        return x + self.fc2(torch.nn.functional.gelu(self.fc1(self.norm2(x))))
+
+
+class ViT(torch.nn.Module):
+    """ViT-B/16 layout (timm vit_base_patch16_224 layer names and shapes at the default arguments):
+    a 16x16 patch convolution (not decomposable), class token, `depth` pre-norm blocks with
+    qkv / proj / fc1 / fc2 Linear layers, final norm, classification head."""
+
+    def __init__(self, img=224, patch=16, d=768, depth=12, heads=12, mlp=3072, classes=1000):
+        super().__init__()
+        self.patch_embed = torch.nn.Conv2d(3, d, kernel_size=patch, stride=patch)
+        self.cls_token = torch.nn.Parameter(torch.zeros(1, 1, d))
+        self.pos_embed = torch.nn.Parameter(torch.zeros(1, (img // patch) ** 2 + 1, d))
+        self.blocks = torch.nn.ModuleList(ViTBlock(d, heads, mlp) for _ in range(depth))
+        self.norm = torch.nn.LayerNorm(d)
+        self.head = torch.nn.Linear(d, classes)
+
+    def forward(self, d):
+        x = self.patch_embed(_unwrap(d)).flatten(2).transpose(1, 2)
+        x = torch.cat([self.cls_token.expand(x.shape[0], -1, -1), x], dim=1) + self.pos_embed
+        for blk in self.blocks:
+            x = blk(x)
+        return self.head(self.norm(x)[:, 0])
+
+
+def init_randn(model: torch.nn.Module, seed: int) -> None:
+    """weights ~ N(0, 1/fan_in), biases and embeddings small, LayerNorm left at identity"""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if "norm" in name:
+                continue
+            if p.ndim >= 2 and "embed" not in name and "token" not in name:
+                fan_in = p[0].numel()
+                p.copy_(torch.randn(p.shape, generator=g) / fan_in ** 0.5)
+            else:
+                p.copy_(0.02 * torch.randn(p.shape, generator=g))
