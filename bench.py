@@ -294,12 +294,14 @@ def main():
                 result["roofline"] = {
                     "bound": "hbm", "achieved": byts / (ms * 1e-3) / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
                     "frac": byts / (ms * 1e-3) / PEAK_HBM, **pmc_traffic(n),
-                    "kernel": "sytrd_symv_kernel (Householder tridiagonalisation, one launch per column)",
+                    "kernel": "sytrd_symv2_kernel / sytrd_symv_kernel (Householder tridiagonalisation, one SYMV launch "
+                              "per column; symmetric lower-triangle tiles for trailing orders >= 1024)",
                     "n": n, "launches": cnt, "avg_launch_us": ms / max(cnt, 1) * 1e3,
                     "algorithmic_bytes_per_launch": byts / max(cnt, 1),
                     "note": "algorithmic bytes = 8 (n-j-1)(n-j-2) per column j (rows j+1.., columns j+2.. of the "
-                            "trailing matrix, f64), summed = 8/3 n^3; the 134 MB matrix is Infinity-Cache resident"}
-                kl["sytrd_symv_kernel"] = {"launches": cnt, "avg_us": ms / max(cnt, 1) * 1e3, "total_ms": ms,
+                            "trailing matrix, f64), summed = 8/3 n^3 (SURVEY 8d: the stream of a one-stage SYMV); the "
+                            "symmetric kernel reads only the lower triangle, so its measured traffic is below that figure"}
+                kl["sytrd_symv_kernels"] = {"launches": cnt, "avg_us": ms / max(cnt, 1) * 1e3, "total_ms": ms,
                                            "gbps": byts / (ms * 1e-3) / 1e9}
                 kl["sytrd_other_per_column"] = {"total_ms": p["ms"][1],
                                                 "note": "colupd + wupd + rank-2k updates + launch gaps"}

@@ -20,6 +20,7 @@
 //     contiguous in memory, written with ds_write_b128; pitch 132 keeps 16-B
 //     alignment.
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -51,14 +52,14 @@ struct GemmF32Args {
   int64_t cslab;  // EPI_STORE split K: blockIdx.y writes its partial tile to C + y * cslab
 };
 
-// Fetch this thread's 4 x 4 elements of a 128 x 32 operand tile.
+// Fetch this thread's share of a TS x 32 operand tile (TS = 128: four 4-element groups, TS = 64: two).
 //   KC  (k contiguous):  element (r, k) at P[r * s + k];   thread -> row idx>>3, k-quad idx&7
-//   !KC (r contiguous):  element (r, k) at P[k * s + r];   thread -> k idx>>5, r-quad idx&31
-template <bool KC>
+//   !KC (r contiguous):  element (r, k) at P[k * s + r];   thread -> k idx / (TS/4), r-quad idx % (TS/4)
+template <bool KC, int TS>
 __device__ __forceinline__ void fetch_tile(const float* __restrict__ P, int64_t s, int r_lim, int k_lim,
-                                           bool vec, int tid, f32x4 (&v)[4]) {
+                                           bool vec, int tid, f32x4 (&v)[TS / 32]) {
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
+  for (int p = 0; p < TS / 32; ++p) {
     const int idx = tid + 256 * p;
     if (KC) {
       const int r = idx >> 3, k = (idx & 7) * 4;
@@ -70,7 +71,7 @@ __device__ __forceinline__ void fetch_tile(const float* __restrict__ P, int64_t 
         for (int j = 0; j < 4; ++j) v[p][j] = (r < r_lim && k + j < k_lim) ? q[j] : 0.f;
       }
     } else {
-      const int k = idx >> 5, r = (idx & 31) * 4;
+      const int k = idx / (TS / 4), r = (idx % (TS / 4)) * 4;
       const float* q = P + (int64_t)k * s + r;
       if (vec && k < k_lim && r + 3 < r_lim) {
         v[p] = *reinterpret_cast<const f32x4*>(q);
@@ -82,26 +83,28 @@ __device__ __forceinline__ void fetch_tile(const float* __restrict__ P, int64_t 
   }
 }
 
-template <bool KC>
-__device__ __forceinline__ void stash_tile(float* __restrict__ L, int tid, const f32x4 (&v)[4]) {
+template <bool KC, int TS>
+__device__ __forceinline__ void stash_tile(float* __restrict__ L, int tid, const f32x4 (&v)[TS / 32]) {
   constexpr int S = KC ? 129 : 132;
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
+  for (int p = 0; p < TS / 32; ++p) {
     const int idx = tid + 256 * p;
     if (KC) {
       const int r = idx >> 3, k = (idx & 7) * 4;
 #pragma unroll
       for (int j = 0; j < 4; ++j) L[(k + j) * S + r] = v[p][j];
     } else {
-      const int k = idx >> 5, r = (idx & 31) * 4;
+      const int k = idx / (TS / 4), r = (idx % (TS / 4)) * 4;
       *reinterpret_cast<f32x4*>(&L[k * S + r]) = v[p];
     }
   }
 }
 
-template <bool AKC, bool BKC, int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmF32Args a) {
-  __shared__ __attribute__((aligned(16))) float lds[2 * BK * LDS_PITCH_MAX];
+// One TS x TS output tile (ti, tj in units of TS) by the 4 waves of a workgroup: TS = 128 -> 64 x 64
+// per wave (2 x 2 MFMA tiles), TS = 64 -> 32 x 32 per wave.
+template <bool AKC, bool BKC, int EPI, int TS>
+__device__ __forceinline__ void gemm_f32_tile(const GemmF32Args& a, const int ti, const int tj, float* lds) {
+  constexpr int MI = TS / 64;
   float* As = lds;
   float* Bs = lds + BK * LDS_PITCH_MAX;
   constexpr int SA = AKC ? 129 : 132;
@@ -112,18 +115,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmF32Args a) {
   const int wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
 
-  int ti, tj;
-  if (a.tri) {
-    const int t = blockIdx.x;
-    ti = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
-    while (ti * (ti + 1) / 2 > t) --ti;
-    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
-    tj = t - ti * (ti + 1) / 2;
-  } else {
-    ti = blockIdx.x % a.tiles_m;
-    tj = blockIdx.x / a.tiles_m;
-  }
-  const int m0 = ti * BM, n0 = tj * BN;
+  const int m0 = ti * TS, n0 = tj * TS;
   const int kbeg = blockIdx.y * a.kchunk;
   const int kend = min(a.K, kbeg + a.kchunk);
   const int nk = (kend - kbeg + BK - 1) / BK;
@@ -135,20 +127,20 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmF32Args a) {
   const int64_t astep = (int64_t)BK * a.sak, bstep = (int64_t)BK * a.sbk;
   const int m_lim = a.M - m0, n_lim = a.N - n0;
 
-  f32x16 acc[2][2];
+  f32x16 acc[MI][MI];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < MI; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  f32x4 ra[4], rb[4];
+  f32x4 ra[TS / 32], rb[TS / 32];
   if (nk > 0) {
-    fetch_tile<AKC>(Ap, sa, m_lim, kend - kbeg, a.vecA, tid, ra);
-    fetch_tile<BKC>(Bp, sb, n_lim, kend - kbeg, a.vecB, tid, rb);
-    stash_tile<AKC>(As, tid, ra);
-    stash_tile<BKC>(Bs, tid, rb);
+    fetch_tile<AKC, TS>(Ap, sa, m_lim, kend - kbeg, a.vecA, tid, ra);
+    fetch_tile<BKC, TS>(Bp, sb, n_lim, kend - kbeg, a.vecB, tid, rb);
+    stash_tile<AKC, TS>(As, tid, ra);
+    stash_tile<BKC, TS>(Bs, tid, rb);
   }
   __syncthreads();
 
@@ -156,38 +148,39 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmF32Args a) {
     const bool more = kt + 1 < nk;
     if (more) {
       const int k_lim = kend - kbeg - (kt + 1) * BK;
-      fetch_tile<AKC>(Ap + (kt + 1) * astep, sa, m_lim, k_lim, a.vecA, tid, ra);
-      fetch_tile<BKC>(Bp + (kt + 1) * bstep, sb, n_lim, k_lim, a.vecB, tid, rb);
+      fetch_tile<AKC, TS>(Ap + (kt + 1) * astep, sa, m_lim, k_lim, a.vecA, tid, ra);
+      fetch_tile<BKC, TS>(Bp + (kt + 1) * bstep, sb, n_lim, k_lim, a.vecB, tid, rb);
     }
     const int l31 = lane & 31, kh = lane >> 5;
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 2) {
-      const float* ar = As + (kk + kh) * SA + wm * 64 + l31;
-      const float* br = Bs + (kk + kh) * SB + wn * 64 + l31;
-      const float a0 = ar[0], a1 = ar[32];
-      const float b0 = br[0], b1 = br[32];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      const float* ar = As + (kk + kh) * SA + wm * (TS / 2) + l31;
+      const float* br = Bs + (kk + kh) * SB + wn * (TS / 2) + l31;
+      float av[MI], bv[MI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) { av[i] = ar[32 * i]; bv[i] = br[32 * i]; }
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < MI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
     }
     __syncthreads();
     if (more) {
-      stash_tile<AKC>(As, tid, ra);
-      stash_tile<BKC>(Bs, tid, rb);
+      stash_tile<AKC, TS>(As, tid, ra);
+      stash_tile<BKC, TS>(Bs, tid, rb);
       __syncthreads();
     }
   }
 
   // C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+    for (int j = 0; j < MI; ++j) {
+      const int col = n0 + wn * (TS / 2) + j * 32 + (lane & 31);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int row = m0 + wm * (TS / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (row >= a.M || col >= a.N) continue;
         if (a.tri && col > row) continue;
         const float v = acc[i][j][r];
@@ -206,6 +199,48 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmF32Args a) {
         }
       }
     }
+}
+
+template <bool AKC, bool BKC, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmF32Args a) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * BK * LDS_PITCH_MAX];
+  int ti, tj;
+  if (a.tri) {
+    const int t = blockIdx.x;
+    ti = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
+    while (ti * (ti + 1) / 2 > t) --ti;
+    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+    tj = t - ti * (ti + 1) / 2;
+  } else {
+    ti = blockIdx.x % a.tiles_m;
+    tj = blockIdx.x / a.tiles_m;
+  }
+  gemm_f32_tile<AKC, BKC, EPI, 128>(a, ti, tj, lds);
+}
+
+// Covariance product with a two-size tile schedule: the strictly-lower 128 x 128 tiles first, then
+// every diagonal tile as its three lower 64 x 64 quarters.  n = 4096 has 528 lower tiles for 512
+// resident workgroups (256 CUs x 2): with equal tiles the last 16 run alone after everyone else; the
+// small workgroups instead queue behind the large ones and finish inside their shadow.
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void syrk_f32_mixed_kernel(const GemmF32Args a, const int nbig, const int ndiag) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * BK * LDS_PITCH_MAX];
+  const int b = blockIdx.x;
+  if (b >= nbig && b < nbig + ndiag) {  // diagonal tiles kept whole
+    gemm_f32_tile<false, false, EPI, 128>(a, b - nbig, b - nbig, lds);
+  } else if (b < nbig) {
+    // strictly lower: ti > tj, t = ti (ti - 1) / 2 + tj
+    int ti = (int)((sqrtf(8.f * (float)b + 1.f) + 1.f) * 0.5f);
+    while (ti * (ti - 1) / 2 > b) --ti;
+    while ((ti + 1) * ti / 2 <= b) ++ti;
+    const int tj = b - ti * (ti - 1) / 2;
+    gemm_f32_tile<false, false, EPI, 128>(a, ti, tj, lds);
+  } else {
+    const int s = b - nbig - ndiag, d = ndiag + s / 3, q = s % 3;
+    const int si = 2 * d + (q > 0), sj = 2 * d + (q > 1);
+    if (si * 64 >= a.M) return;
+    gemm_f32_tile<false, false, EPI, 64>(a, si, sj, lds);
+  }
 }
 
 // second pass of the EPI_STORE split K: C = alpha * (slab_0 + slab_1 + ...) + bias, slabs added in
@@ -327,6 +362,18 @@ int syrk_f32(const float* Y, int64_t T, int64_t n, int64_t ldy, void* E, int64_t
   ksplit = (int)ceil_div(T, a.kchunk);
   a.atomic = ksplit > 1;
   a.vecA = a.vecB = aligned16(Y) && (ldy % 4 == 0);
+  if (ksplit == 1 && !getenv("PTD_SYRK_UNIFORM")) {
+    // as many diagonal tiles are quartered as exceed a whole number of resident rounds (512 = 256 CUs x 2)
+    const int nbig = nt * (nt - 1) / 2;
+    const char* pe = getenv("PTD_SYRK_PEEL");
+    const int npeel = std::min(nt, pe ? atoi(pe) : tiles % 512);
+    const int ndiag = nt - npeel;
+    dim3 grid((unsigned)(nbig + ndiag + 3 * npeel), 1);
+    if (e_f64) hipLaunchKernelGGL((syrk_f32_mixed_kernel<EPI_ACC_F64>), grid, dim3(256), 0, st, a, nbig, ndiag);
+    else hipLaunchKernelGGL((syrk_f32_mixed_kernel<EPI_ACC_F32>), grid, dim3(256), 0, st, a, nbig, ndiag);
+    PTD_CHECK_LAUNCH("syrk_f32");
+    return PTD_OK;
+  }
   dim3 grid((unsigned)tiles, (unsigned)ksplit);
   if (e_f64) hipLaunchKernelGGL((gemm_f32_kernel<false, false, EPI_ACC_F64>), grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL((gemm_f32_kernel<false, false, EPI_ACC_F32>), grid, dim3(256), 0, st, a);

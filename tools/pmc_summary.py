@@ -45,7 +45,8 @@ tot_rd = sum(r[3] for r in rows)
 tot_wr = sum(r[4] for r in rows)
 big = [r for r in rows if r[1] >= 2048]
 summary = {
-    "kernel": "sytrd_symv_kernel", "n": n, "launches": L,
+    "kernel": "sytrd_symv2_kernel (trailing order >= 1024: lower triangle only) + sytrd_symv_kernel (smaller trailing orders)",
+    "n": n, "launches": L,
     "command": "rocprofv3 --pmc <COUNTER> --kernel-include-regex sytrd_symv --kernel-trace --output-format csv -- tools/pmc_driver %d (separate passes: FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum)" % n,
     "correction": "read bytes = 2 x FETCH_SIZE KiB x 1024 (gfx950 tallies 128-B requests at 64 B); WRITE_SIZE exact",
     "algorithmic_bytes_per_launch": tot_alg / L,
