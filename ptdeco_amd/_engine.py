@@ -234,6 +234,66 @@ class Covariance:
         return u
 
 
+def run_concurrently(jobs, device: torch.device, max_streams: Optional[int] = None) -> list:
+    """Run independent device-side jobs (callables returning tensors) from separate host threads, each on
+    its own HIP stream, and return their results in order.
+
+    One eigendecomposition is a chain of ~8000 short dependent launches that leaves most of the GPU
+    idle; chains of different layers issued on different streams interleave on the device (two
+    n = 4096 matrices: 1.5x the throughput of running them back to back, three: 1.9x).  The C ABI keeps
+    no shared mutable state and releases the GIL, so the host side is plain threads.  Stream order:
+    every side stream first waits for the caller's stream (inputs), the caller's stream waits for all
+    of them at the end (outputs).  PTD_EIGH_STREAMS overrides the stream count (1 = sequential)."""
+    import os
+    import threading
+
+    jobs = list(jobs)
+    device = torch.device(device)
+    want = int(os.environ.get("PTD_EIGH_STREAMS", "3")) if max_streams is None else max_streams
+    workers = max(1, min(len(jobs), want))
+    if workers == 1 or device.type != "cuda":
+        return [job() for job in jobs]
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    device = torch.device("cuda", index)
+    main = torch.cuda.current_stream(device)
+    streams = [torch.cuda.Stream(device=device) for _ in range(workers)]
+    for st in streams:
+        st.wait_stream(main)
+    out: list = [None] * len(jobs)
+    errors: list = []
+    lock = threading.Lock()
+    cursor = [0]
+
+    def worker(w: int) -> None:
+        try:
+            torch.cuda.set_device(device)
+            with torch.no_grad(), torch.cuda.stream(streams[w]):
+                while not errors:
+                    with lock:
+                        i = cursor[0]
+                        cursor[0] += 1
+                    if i >= len(jobs):
+                        break
+                    out[i] = jobs[i]()
+        except BaseException as exc:  # re-raised on the calling thread
+            errors.append(exc)
+
+    threads = [threading.Thread(target=worker, args=(w,), name=f"ptdeco-eigh-{w}") for w in range(workers)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    for st in streams:
+        main.wait_stream(st)
+    for res in out:  # the results were allocated on a side stream and live on under the caller's
+        for t in (res if isinstance(res, (tuple, list)) else (res,)):
+            if isinstance(t, torch.Tensor) and t.is_cuda:
+                t.record_stream(main)
+    if errors:
+        raise errors[0]
+    return out
+
+
 def build_factors(weight2d: torch.Tensor, u: torch.Tensor, rank: int, dtype: torch.dtype, dense: bool = True):
     """Top-`rank` eigenvectors -> (uk [n, r], U [n_in, r], W~ [n, n_in] or None) in `dtype`.
 

@@ -122,11 +122,17 @@ def _precompute_covariance_matrix_decompositions(*, module, submodule_names, num
             module(utils.to_device(batch, device))
     logger.info("Computing eigenvectors ...")
     u_dict: dict[str, torch.Tensor] = {}
-    for i, (name, m) in enumerate(zip(submodule_names, stand_ins)):
-        if shard.active:
+    if shard.active:
+        for m in stand_ins:
             m.cov.all_reduce(shard.group)
-        # eigendecompositions of a split are owned round-robin; non-owners receive u later
-        u_dict[name] = m.get_eigenvectors() if shard.owns(i) else None
+    # eigendecompositions of a split are owned round-robin (non-owners receive u later); the ones
+    # this rank owns are independent and run concurrently on separate streams
+    owned = [i for i in range(len(stand_ins)) if shard.owns(i)]
+    got = eng.run_concurrently([stand_ins[i].get_eigenvectors for i in owned], device)
+    for name in submodule_names:
+        u_dict[name] = None
+    for i, u in zip(owned, got):
+        u_dict[submodule_names[i]] = u
     for i, name in enumerate(submodule_names):
         if shard.active:
             u_dict[name] = shard.broadcast_from_owner(

@@ -138,3 +138,18 @@ def test_candidate_schedules():
     assert fa._bisection_widths(96) == [48, 24, 12, 6, 3, 1]
     assert fa._bisection_widths(10) == [5, 2, 1]
     assert fa._batches_consumed(torch.nn.Linear(96, 10), 4, 2) == 4 + 2 * 3
+
+
+def test_run_concurrently_keeps_order_and_raises():
+    """Without a GPU the jobs run in the calling thread, in order; an exception propagates."""
+    from ptdeco_amd import _engine as eng
+
+    cpu = torch.device("cpu")
+    assert eng.run_concurrently([lambda i=i: torch.tensor([i]) for i in range(5)], cpu) == [torch.tensor([i]) for i in range(5)]
+    assert eng.run_concurrently([], cpu) == []
+
+    def boom():
+        raise RuntimeError("job failed")
+
+    with pytest.raises(RuntimeError, match="job failed"):
+        eng.run_concurrently([lambda: torch.zeros(1), boom], cpu)

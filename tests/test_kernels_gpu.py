@@ -411,3 +411,24 @@ def test_sym_kl_random(ops, B, C):
     assert ops.sym_kl(s.to(DEV), t.to(DEV)).item() == pytest.approx(ref, rel=1e-9)
     # identical logits: exactly zero divergence
     assert abs(ops.sym_kl(s.to(DEV), s.to(DEV).clone()).item()) <= 1e-15
+
+
+def test_eigendecompositions_on_concurrent_streams_match_sequential(ops):
+    """Independent layers' eigensolves issued from separate host threads / streams
+    (_engine.run_concurrently) return what the sequential calls return, in order; a failing job
+    raises on the calling thread."""
+    from ptdeco_amd import _engine as eng
+
+    def spd(n, seed):
+        y = _rand((2 * n + 3, n), seed).double() * torch.logspace(0, -2, n, dtype=torch.float64)
+        a = y.T @ y / y.shape[0]
+        return a + torch.eye(n, dtype=torch.float64) * (0.01 * torch.diag(a).mean())
+
+    mats = [spd(n, 40 + i).to(DEV) for i, n in enumerate((300, 512, 300, 640, 96))]
+    seq = [ops.eigh(m, m.shape[0] // 2) for m in mats]
+    par = eng.run_concurrently([lambda m=m: ops.eigh(m, m.shape[0] // 2) for m in mats], torch.device("cuda"))
+    for (w0, v0), (w1, v1) in zip(seq, par):
+        assert torch.allclose(w0, w1, rtol=0, atol=1e-12 * w0.abs().max().item())
+        assert (v0 - v1).abs().max().item() < 1e-9
+    with pytest.raises(ValueError):
+        eng.run_concurrently([lambda: ops.eigh(mats[0], 5), lambda: (_ for _ in ()).throw(ValueError("x"))], DEV)
