@@ -304,7 +304,8 @@ def main():
                 kl["sytrd_symv_kernels"] = {"launches": cnt, "avg_us": ms / max(cnt, 1) * 1e3, "total_ms": ms,
                                            "gbps": byts / (ms * 1e-3) / 1e9}
                 kl["sytrd_other_per_column"] = {"total_ms": p["ms"][1],
-                                                "note": "colupd + wupd + rank-2k updates + launch gaps"}
+                                                "note": "alpha kernels + rank-2k updates + launch gaps, incl. what "
+                                                        "the per-launch event timing of this profiled pass adds"}
                 kl["eigvals_invit_backtransform"] = {"total_ms": p["ms"][3]}
             else:
                 names = ("jac_gram_kernel", "jac_inner_kernel", "jac_update_kernel")

@@ -46,14 +46,15 @@ for name, n_in, n_out, count in (("q_o", 4096, 4096, 64), ("k_v", 4096, 1024, 64
                                                    metric_iterator=itertools.cycle(bt[8:]),
                                                    finetune_fn=lambda mm, d, n: mm, **kw)
     step(); torch.cuda.synchronize()
-    ops.EIGH_PROFILE = []
     t0 = time.perf_counter(); cfg = step(); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    ops.EIGH_PROFILE = []  # one more, untimed, pass with per-launch events for the eigensolver line
+    step(); torch.cuda.synchronize()
     prof, ops.EIGH_PROFILE = ops.EIGH_PROFILE, None
     line = {"n_in": n_in, "n_out": n_out, "ms_per_layer": dt * 1e3, "layers_per_s": 1.0 / dt}
     if prof:
         p = prof[0]
         line["eigh"] = {"n": p["n"], "k": p["k"], "method": "tridiagonal" if p["method"] == 1 else "jacobi",
-                        "ms": p["total_ms"]}
+                        "ms_in_profiled_pass": p["total_ms"]}
         if p["method"] == 1:
             line["eigh"]["symv_gbps"] = p["work"][0] / (p["ms"][0] * 1e-3) / 1e9
             line["eigh"]["symv_ms"] = p["ms"][0]
