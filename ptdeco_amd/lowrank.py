@@ -5,9 +5,10 @@ Both classes ARE ``torch.nn.Sequential`` containers of two ``nn.Linear`` / 1x1
 ``nn.Conv2d`` children, exactly what the reference builds (dwain.py:69-85, 121-144;
 falor.py:79-95, 131-153), so ``get_module_config``, ``state_dict`` keys
 ('0.weight' [r, n_in], '1.weight' [n_out, r], '1.bias') and ``load_state_dict`` are
-unchanged.  Only ``forward`` differs: under ``torch.no_grad()`` on a ROCm device it
-calls the HIP kernel; when autograd is recording (a user ``finetune_fn``) it runs the
-two children so gradients flow -- backward kernels are a later scope row.
+unchanged.  Only ``forward`` differs: on a ROCm device it calls the HIP kernels, also when
+autograd is recording (a user ``finetune_fn``, dwain.py:779-786): ``_LowRankFunction`` forms
+dx, dA, dB with the same strided GEMM entry (``ptd_gemm``), so fine-tuning trains the fused
+pair.
 """
 
 from __future__ import annotations
@@ -20,9 +21,44 @@ _HIP_DTYPES = (torch.float32, torch.bfloat16)
 
 
 def _use_hip(x: torch.Tensor, w: torch.Tensor) -> bool:
-    if not x.is_cuda or x.dtype not in _HIP_DTYPES or x.dtype != w.dtype:
-        return False
-    return not (torch.is_grad_enabled() and (x.requires_grad or w.requires_grad))
+    return x.is_cuda and x.dtype in _HIP_DTYPES and x.dtype == w.dtype
+
+
+class _LowRankFunction(torch.autograd.Function):
+    """y = (x A^T) B^T + bias with x [T, n_i], A [r, n_i], B [n_o, r]; every product on ptd_gemm.
+
+    backward:  dh = dy B,  dx = dh A,  dB = dy^T h,  dA = dh^T x,  dbias = sum_t dy   (h = x A^T is
+    recomputed: one [T, r] product instead of keeping it alive between forward and backward)."""
+
+    @staticmethod
+    def forward(ctx, x2d, a, b, bias):
+        ctx.save_for_backward(x2d, a, b)
+        ctx.has_bias = bias is not None
+        return ops.lowrank_forward(x2d, a, b, bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2d, a, b = ctx.saved_tensors
+        dy = dy.contiguous()
+        need_x, need_a, need_b, need_bias = ctx.needs_input_grad
+        dx = da = db = dbias = None
+        dh = ops.matmul(dy, b) if (need_x or need_a) else None
+        if need_x:
+            dx = ops.matmul(dh, a)
+        if need_a:
+            da = ops.matmul(dh.T, x2d)
+        if need_b:
+            db = ops.matmul(dy.T, ops.matmul(x2d, a.T))
+        if need_bias and ctx.has_bias:
+            dbias = dy.sum(dim=0)
+        return dx, da, db, dbias
+
+
+def _pair_forward(x2d: torch.Tensor, a: torch.Tensor, b: torch.Tensor, bias) -> torch.Tensor:
+    if torch.is_grad_enabled() and (x2d.requires_grad or a.requires_grad or b.requires_grad
+                                    or (bias is not None and bias.requires_grad)):
+        return _LowRankFunction.apply(x2d, a, b, bias)
+    return ops.lowrank_forward(x2d, a, b, bias)
 
 
 class LowRankLinear(torch.nn.Sequential):
@@ -30,7 +66,7 @@ class LowRankLinear(torch.nn.Sequential):
         first, second = self[0], self[1]
         if not _use_hip(x, first.weight):
             return second(first(x))
-        y = ops.lowrank_forward(x.reshape(-1, first.in_features), first.weight, second.weight, second.bias)
+        y = _pair_forward(x.reshape(-1, first.in_features), first.weight, second.weight, second.bias)
         return y.reshape(*x.shape[:-1], second.out_features)
 
 
@@ -41,7 +77,7 @@ class LowRankConv1x1(torch.nn.Sequential):
             return second(first(x))
         b, c, h, w = x.shape
         rows = x.permute(0, 2, 3, 1).reshape(-1, c)  # NHWC rows; free for channels_last inputs
-        y = ops.lowrank_forward(rows, first.weight[:, :, 0, 0], second.weight[:, :, 0, 0], second.bias)
+        y = _pair_forward(rows, first.weight[:, :, 0, 0], second.weight[:, :, 0, 0], second.bias)
         return y.reshape(b, h, w, second.out_channels).permute(0, 3, 1, 2)
 
 

@@ -188,3 +188,75 @@ def test_primitive_linear_gpu(method):
 def test_primitive_conv1x1_gpu(method):
     y0, y1 = _primitive("conv", method)
     assert (y0 - y1).abs().max().item() < 9.0e-4  # the reference's own GPU bound (:187-192)
+
+
+def test_dwain_with_a_training_finetune_fn_tracks_the_oracle():
+    """dwain.py:779-786: after each accepted layer the caller's finetune_fn trains the model.  Here it
+    takes two SGD steps on the already decomposed layers; on the GPU those are the fused pairs, whose
+    backward runs on the HIP GEMMs.  Same decisions as the CPU oracle running the same callback on
+    plain nn.Sequential pairs, metrics and final outputs within 1e-4."""
+    import copy
+    import itertools
+
+    import ptdeco_amd
+
+    scn = gio.e2e_meta()["dwain_mlp_nosplit"]
+    pool = gio.pool(scn["pool"])
+    targets = {}
+    grad_norms = []
+
+    def make_finetune(device):
+        def finetune(model, dev, names):
+            params = [p for n in names for p in model.get_submodule(n).parameters()]
+            if not params:
+                return model
+            for p in model.parameters():
+                p.requires_grad_(False)
+            for p in params:
+                p.requires_grad_(True)
+            opt = torch.optim.SGD(params, lr=0.05)
+            model.train()
+            with torch.enable_grad():
+                for i in range(2):
+                    x = pool[i].to(device)
+                    if i not in targets:
+                        targets[i] = base(pool[i]).argmax(-1)
+                    loss = torch.nn.functional.cross_entropy(model({"x": x}), targets[i].to(device))
+                    opt.zero_grad()
+                    loss.backward()
+                    grad_norms.append(sum(float(p.grad.norm()) for p in params))
+                    opt.step()
+            model.eval()
+            return model
+        return finetune
+
+    base_model = gio.build_model(scn).eval()
+
+    def base(x):
+        with torch.no_grad():
+            return base_model({"x": x})
+
+    with torch.no_grad():
+        for i in range(2):
+            targets[i] = base(pool[i]).argmax(-1)
+
+    ref_model, ref_trace = gio.build_model(scn), []
+    data, metric = gio.dwain_streams(scn)
+    ref_cfg = orc.dwain_decompose(module=ref_model, data_iterator=data, metric_iterator=metric, loss_fn=tm.ce_loss,
+                                  finetune_fn=make_finetune(torch.device("cpu")), trace=ref_trace, **scn["kwargs"])
+    model, trace = gio.build_model(scn).to(DEV), []
+    data, metric = gio.dwain_streams(scn)
+    cfg = ptdeco_amd.dwain.decompose_in_place(module=model, device=DEV, data_iterator=data, metric_iterator=metric,
+                                              loss_fn=tm.ce_loss, finetune_fn=make_finetune(DEV), trace=trace,
+                                              **scn["kwargs"])
+    assert len(cfg) >= 1 and list(cfg.keys()) == list(ref_cfg.keys())
+    assert [(s["layer"], s["rank"], s["accepted"]) for s in trace] == \
+           [(s["layer"], s["rank"], s["accepted"]) for s in ref_trace]
+    for s, r in zip(trace, ref_trace):
+        assert _close(s["nsr"], r["nsr"]) and _close(s["ppl_deco"], r["ppl_deco"]), (s, r)
+    with torch.no_grad():
+        out = model({"x": pool[0].to(DEV)}).cpu()
+        ref = ref_model({"x": pool[0]})
+    assert (out - ref).abs().max().item() <= REL * ref.abs().max().item()
+    # the callback really trained something, on both sides
+    assert len(grad_norms) >= 4 and all(g > 0.0 for g in grad_norms)

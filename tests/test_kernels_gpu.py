@@ -432,3 +432,46 @@ def test_eigendecompositions_on_concurrent_streams_match_sequential(ops):
         assert (v0 - v1).abs().max().item() < 1e-9
     with pytest.raises(ValueError):
         eng.run_concurrently([lambda: ops.eigh(mats[0], 5), lambda: (_ for _ in ()).throw(ValueError("x"))], DEV)
+
+
+@pytest.mark.parametrize("kind", ["linear", "conv"])
+def test_lowrank_pair_backward_matches_autograd_of_the_two_layers(ops, kind):
+    """A user finetune_fn trains the fused pair: dx, dA, dB, dbias from the strided GEMM
+    entry agree with torch autograd through the two reference layers."""
+    from ptdeco_amd.lowrank import fuse_pair
+
+    g = torch.Generator().manual_seed(21)
+    n_i, r, n_o = 96, 24, 80
+    if kind == "linear":
+        ref = torch.nn.Sequential(torch.nn.Linear(n_i, r, bias=False), torch.nn.Linear(r, n_o, bias=True))
+        x = torch.randn(3, 50, n_i, generator=g)
+    else:
+        ref = torch.nn.Sequential(torch.nn.Conv2d(n_i, r, 1, bias=False), torch.nn.Conv2d(r, n_o, 1, bias=True))
+        x = torch.randn(2, n_i, 7, 9, generator=g)
+    with torch.no_grad():
+        for p in ref.parameters():
+            p.copy_(torch.randn(p.shape, generator=g) / p.shape[1 if p.dim() > 1 else 0] ** 0.5)
+    import copy as _copy
+    fused = fuse_pair(_copy.deepcopy(ref)).to(DEV)
+    assert type(fused).__name__.startswith("LowRank")
+    xr = x.clone().double().requires_grad_(True)
+    ref64 = _copy.deepcopy(ref).double()
+    tgt = torch.randn(ref64(xr).shape, generator=g).double()
+    (ref64(xr) * tgt).sum().backward()
+    xg = x.clone().to(DEV).requires_grad_(True)
+    out = fused(xg)
+    assert out.requires_grad
+    (out * tgt.float().to(DEV)).sum().backward()
+    def close(a, b):
+        return (a.double().cpu() - b).abs().max().item() <= 2e-5 * max(1.0, b.abs().max().item())
+    assert close(out.detach(), ref64(xr).detach())
+    assert close(xg.grad, xr.grad)
+    for (_, pf), (_, pr) in zip(fused.named_parameters(), ref64.named_parameters()):
+        assert pf.grad is not None and close(pf.grad, pr.grad)
+    # one optimiser step lowers a regression loss (the pair is trainable end to end)
+    opt = torch.optim.SGD(fused.parameters(), lr=1e-2)
+    opt.zero_grad()
+    y0 = (fused(x.to(DEV)) - tgt.float().to(DEV)).pow(2).mean()
+    y0.backward(); opt.step()
+    with torch.no_grad():
+        assert (fused(x.to(DEV)) - tgt.float().to(DEV)).pow(2).mean().item() < y0.item()
