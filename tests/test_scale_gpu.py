@@ -248,3 +248,39 @@ def test_falor_vit_shaped_mini_matches_oracle():
             out = model(pool[0].to(DEV)).cpu()
             ref = ref_model(pool[0])
         assert (out - ref).abs().max().item() <= 1e-4 * ref.abs().max().item() + 1e-6
+
+
+def test_falor_resnet18_shaped_matches_oracle():
+    """BASELINE configs[0]: falor on a resnet18-shaped clone, one fixed calibration batch (5, 3, 224, 224),
+    D = M = 1, use_mean=False, use_damping=True, thresholds 0.01, proportion_threshold 0.9.  The three
+    decomposable convolutions are the stride-2 downsample 1x1s: evaluated by swapping the dense W~ in
+    (the pair would drop the stride, SURVEY quirk 5 -- reproduced: the replacement pair has stride 1)."""
+    import ptdeco_amd
+
+    torch.manual_seed(271828)
+    model = tm.ResNet18().eval()
+    g = torch.Generator().manual_seed(1314159)
+    x = torch.rand(5, 3, 224, 224, generator=g)
+    kw = dict(proportion_threshold=0.9, nsr_final_threshold=0.01, kl_final_threshold=0.01, num_data_steps=1,
+              num_metric_steps=1, use_float64=True, use_mean=False, use_damping=True)
+    ref_model, ref_trace = copy.deepcopy(model), []
+    ref_cfg = orc.falor_decompose(module=ref_model, data_iterator=itertools.repeat(x), trace=ref_trace, **kw)
+    model.to(DEV)
+    trace = []
+    cfg = ptdeco_amd.falor.decompose_in_place(module=model, device=DEV, data_iterator=itertools.repeat(x.to(DEV)),
+                                              trace=trace, **kw)
+    assert [t["layer"] for t in ref_trace[::8]][:1] == ["layer2.0.downsample.0"] and len(ref_trace) == 30
+    assert [(t["layer"], t["rank"], t["accepted"]) for t in trace] == \
+           [(t["layer"], t["rank"], t["accepted"]) for t in ref_trace]
+    for t, r in zip(trace, ref_trace):
+        assert abs(t["nsr"] - r["nsr"]) <= 1e-4 * abs(r["nsr"]) + 2e-6, (t, r)
+        assert abs(t["kl"] - r["kl"]) <= 1e-4 * abs(r["kl"]) + 2e-6, (t, r)
+    assert list(cfg.keys()) == list(ref_cfg.keys()) == ["layer2.0.downsample.0", "layer3.0.downsample.0",
+                                                        "layer4.0.downsample.0", "fc"]
+    for k in cfg:
+        assert cfg[k]["modules"] == ref_cfg[k]["modules"]
+        assert cfg[k]["__meta__"]["proportion"] == ref_cfg[k]["__meta__"]["proportion"]
+    assert tuple(model.get_submodule("layer2.0.downsample.0")[0].stride) == (1, 1)  # quirk 5
+    w_g = model.fc[1].weight.detach().cpu().double() @ model.fc[0].weight.detach().cpu().double()
+    w_r = ref_model.fc[1].weight.detach().double() @ ref_model.fc[0].weight.detach().double()
+    assert (w_g - w_r).norm().item() <= 1e-4 * w_r.norm().item()

@@ -102,23 +102,43 @@ def load_state(model: torch.nn.Module, arrays, prefix: str) -> None:
             p.copy_(torch.from_numpy(arrays[prefix + name]))
 
 
-class ViTBlock(torch.nn.Module):
-    def __init__(self, d, heads, mlp):
+class _ViTAttention(torch.nn.Module):
+    def __init__(self, d, heads):
         super().__init__()
         self.heads = heads
-        self.norm1 = torch.nn.LayerNorm(d)
         self.qkv = torch.nn.Linear(d, 3 * d)
         self.proj = torch.nn.Linear(d, d)
-        self.norm2 = torch.nn.LayerNorm(d)
-        self.fc1 = torch.nn.Linear(d, mlp)
-        self.fc2 = torch.nn.Linear(mlp, d)
 
     def forward(self, x):
         b, t, d = x.shape
-        q, k, v = self.qkv(self.norm1(x)).reshape(b, t, 3, self.heads, d // self.heads).permute(2, 0, 3, 1, 4)
+        q, k, v = self.qkv(x).reshape(b, t, 3, self.heads, d // self.heads).permute(2, 0, 3, 1, 4)
         a = torch.nn.functional.scaled_dot_product_attention(q, k, v)
-        x = x + self.proj(a.transpose(1, 2).reshape(b, t, d))
-        return x + self.fc2(torch.nn.functional.gelu(self.fc1(self.norm2(x))))
+        return self.proj(a.transpose(1, 2).reshape(b, t, d))
+
+
+class _ViTMlp(torch.nn.Module):
+    def __init__(self, d, hidden):
+        super().__init__()
+        self.fc1 = torch.nn.Linear(d, hidden)
+        self.fc2 = torch.nn.Linear(hidden, d)
+
+    def forward(self, x):
+        return self.fc2(torch.nn.functional.gelu(self.fc1(x)))
+
+
+class ViTBlock(torch.nn.Module):
+    """timm naming: blocks.N.attn.qkv / attn.proj / mlp.fc1 / mlp.fc2"""
+
+    def __init__(self, d, heads, mlp):
+        super().__init__()
+        self.norm1 = torch.nn.LayerNorm(d)
+        self.attn = _ViTAttention(d, heads)
+        self.norm2 = torch.nn.LayerNorm(d)
+        self.mlp = _ViTMlp(d, mlp)
+
+    def forward(self, x):
+        x = x + self.attn(self.norm1(x))
+        return x + self.mlp(self.norm2(x))
 
 
 class ViT(torch.nn.Module):
@@ -155,3 +175,43 @@ def init_randn(model: torch.nn.Module, seed: int) -> None:
                 p.copy_(torch.randn(p.shape, generator=g) / fan_in ** 0.5)
             else:
                 p.copy_(0.02 * torch.randn(p.shape, generator=g))
+
+
+class _BasicBlock(torch.nn.Module):
+    def __init__(self, c_in, c_out, stride):
+        super().__init__()
+        self.conv1 = torch.nn.Conv2d(c_in, c_out, 3, stride=stride, padding=1, bias=False)
+        self.bn1 = torch.nn.BatchNorm2d(c_out)
+        self.conv2 = torch.nn.Conv2d(c_out, c_out, 3, padding=1, bias=False)
+        self.bn2 = torch.nn.BatchNorm2d(c_out)
+        self.downsample = None
+        if stride != 1 or c_in != c_out:
+            self.downsample = torch.nn.Sequential(torch.nn.Conv2d(c_in, c_out, 1, stride=stride, bias=False),
+                                                  torch.nn.BatchNorm2d(c_out))
+
+    def forward(self, x):
+        idt = x if self.downsample is None else self.downsample(x)
+        y = torch.relu(self.bn1(self.conv1(x)))
+        return torch.relu(self.bn2(self.conv2(y)) + idt)
+
+
+class ResNet18(torch.nn.Module):
+    """torchvision resnet18 layout and layer names; decomposable layers (BASELINE configs[0]):
+    layer{2,3,4}.0.downsample.0 (1x1, stride 2: SURVEY quirk 5) and fc."""
+
+    def __init__(self, classes=1000, width=64):
+        super().__init__()
+        w = width
+        self.conv1 = torch.nn.Conv2d(3, w, 7, stride=2, padding=3, bias=False)
+        self.bn1 = torch.nn.BatchNorm2d(w)
+        self.maxpool = torch.nn.MaxPool2d(3, stride=2, padding=1)
+        self.layer1 = torch.nn.Sequential(_BasicBlock(w, w, 1), _BasicBlock(w, w, 1))
+        self.layer2 = torch.nn.Sequential(_BasicBlock(w, 2 * w, 2), _BasicBlock(2 * w, 2 * w, 1))
+        self.layer3 = torch.nn.Sequential(_BasicBlock(2 * w, 4 * w, 2), _BasicBlock(4 * w, 4 * w, 1))
+        self.layer4 = torch.nn.Sequential(_BasicBlock(4 * w, 8 * w, 2), _BasicBlock(8 * w, 8 * w, 1))
+        self.fc = torch.nn.Linear(8 * w, classes)
+
+    def forward(self, d):
+        x = self.maxpool(torch.relu(self.bn1(self.conv1(_unwrap(d)))))
+        x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
+        return self.fc(x.mean(dim=(2, 3)))
