@@ -213,11 +213,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    device = torch.device("cuda", local)
+    # PTD_BENCH_REHEARSE=1: rehearsal of the N > 1 code path on a one-GPU box -- every rank on cuda:0,
+    # gloo transport (RCCL refuses two ranks on one device).  Not a measurement.
+    rehearse = os.environ.get("PTD_BENCH_REHEARSE") == "1"
+    device = torch.device("cuda", 0 if rehearse else local)
     torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     import ptdeco_amd
     from ptdeco_amd import ops
