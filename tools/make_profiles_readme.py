@@ -42,9 +42,9 @@ if sv:
     gbps = r.get("algorithmic_bytes_per_launch", 0) / (avg_us * 1e-6) / 1e9
     o.append(f"* the same launches in the rocprofv3 trace below ({' + '.join(short(x['Name']) for x in sv)}): weighted average "
              f"{avg_us:.2f} us -> {gbps:.0f} GB/s = **{100 * gbps / r['peak']:.0f} %** of peak on the same algorithmic bytes "
-             "(the per-launch events of the profiled pass inside bench.py read about 1 us higher than the profiler; the bench line quotes the lower fraction).\n")
+             "(dispatch-attached HIP events read about 1 us more per launch than the profiler's kernel begin / end timestamps, also when only every 8th launch is timed; the bench line quotes the lower fraction).\n")
 if e:
-    o.append(f"* whole eigensolver ({e['method']}, n = {e['n']}): {e['ms_per_matrix']:.0f} ms per matrix in the profiled pass (per-launch events; about 81 ms without them, `tools/op_log.py`) = "
+    o.append(f"* whole eigensolver ({e['method']}, n = {e['n']}): {e['ms_per_matrix']:.0f} ms per matrix (HIP events around the call; every 8th SYMV launch also carries dispatch-attached events) = "
              f"{e['algorithmic_tflops']:.2f} TFLOP/s on the algorithmic 4/3 n^3 + 2 n^2 k flops "
              f"({100 * e['frac_of_f64_mfma_peak_on_algorithmic_flops']:.1f} % of the f64 MFMA peak: a one-stage reduction is bandwidth-bound).\n")
 pmc = os.path.join(root, f"pmc_symv_r{rnd}.json")
