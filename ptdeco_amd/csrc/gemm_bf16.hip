@@ -239,7 +239,7 @@ typedef const __attribute__((address_space(1))) void glb_void;
 
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_glds_kernel(const GemmBf16Args a) {
-  __shared__ __attribute__((aligned(16))) char lds[2 * 2 * 16384];
+  __shared__ __attribute__((aligned(16))) char lds[2 * 2 * 16384 + 2048];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid >> 1, wn = wid & 1;
@@ -305,22 +305,36 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_glds_kernel(const GemmBf1
     __syncthreads();  // retires this step's LDS-DMA (vmcnt(0)) and the reads of buffer `cur`
   }
 
+  // Epilogue through LDS (the staging buffers are free after the loop's last barrier): the MFMA
+  // result layout gives each lane single elements of 64 different rows, which as global stores are
+  // 2- or 4-byte scatters; staged as a [128][128] tile they leave as 16-byte row-contiguous stores.
+  constexpr int ES = (EPI == EPI_STORE_BF16) ? 2 : 4;       // bytes per output element
+  constexpr int CP = 128 * ES + 16;                          // LDS pitch of a tile row (+16 B: rows rotate banks)
+  static_assert(128 * (128 * 4 + 16) <= 2 * 2 * 16384 + 2048, "C tile must fit the staging buffers");
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+      const int lc = wn * 64 + j * 32 + (lane & 31);
+      const float bv = a.bias ? bf16_to_f32(a.bias[n0 + lc]) : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        float o = a.alpha * acc[i][j][r];
-        if (a.bias) o += bf16_to_f32(a.bias[col]);
-        if (EPI == EPI_STORE_BF16)
-          reinterpret_cast<unsigned short*>(a.C)[(int64_t)row * a.ldc + col] = f32_to_bf16(o);
-        else
-          reinterpret_cast<float*>(a.C)[(int64_t)row * a.ldc + col] = o;
+        const int lr = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const float o = a.alpha * acc[i][j][r] + bv;
+        if (EPI == EPI_STORE_BF16) *reinterpret_cast<unsigned short*>(lds + lr * CP + lc * 2) = f32_to_bf16(o);
+        else *reinterpret_cast<float*>(lds + lr * CP + lc * 4) = o;
       }
     }
+  __syncthreads();
+  constexpr int CHUNKS = 128 * ES / 16;                      // 16-byte chunks per tile row
+#pragma unroll
+  for (int p = 0; p < 128 * CHUNKS / 256; ++p) {
+    const int q = tid + 256 * p;
+    const int lr = q / CHUNKS, ch = q % CHUNKS;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(lds + lr * CP + ch * 16);
+    char* dst = reinterpret_cast<char*>(a.C) + ((int64_t)(m0 + lr) * a.ldc + n0) * ES + ch * 16;
+    *reinterpret_cast<f32x4*>(dst) = v;
+  }
 }
 
 template <int EPI>
@@ -352,7 +366,8 @@ int gemm_bf16(const unsigned short* A, int64_t sam, int64_t sak, const unsigned 
   a.vecB = aligned16(B) && ((bkc ? sbn : sbk) % 8 == 0);
   dim3 grid((unsigned)(a.tiles_m * ceil_div(N, BN)), 1);
   static const bool no_glds = getenv("PTD_GEMM_NO_GLDS") != nullptr;
-  if (!no_glds && akc && bkc && a.vecA && a.vecB && M % BM == 0 && N % BN == 0 && K % BK == 0 && K >= BK) {
+  const bool c_vec = aligned16(C) && (ldc * (c_bf16 ? 2 : 4)) % 16 == 0;  // 16-byte row-contiguous output stores
+  if (!no_glds && akc && bkc && a.vecA && a.vecB && c_vec && M % BM == 0 && N % BN == 0 && K % BK == 0 && K >= BK) {
     if (c_bf16) hipLaunchKernelGGL((gemm_bf16_nt_glds_kernel<EPI_STORE_BF16>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((gemm_bf16_nt_glds_kernel<EPI_STORE_F32>), grid, dim3(256), 0, st, a);
   } else if (c_bf16) launch_bf16<EPI_STORE_BF16>(a, akc, bkc, grid, st);
