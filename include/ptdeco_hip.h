@@ -111,9 +111,12 @@ int ptd_eigh_factored(const void* W, int64_t ldw, int w_dtype, int64_t n_o, int6
 /* Same, with per-phase device timing (HIP events on `stream` around the launches of each
  * phase; a few percent slower, for bench.py's roofline lines).  `stats` is a HOST pointer.
  *   method 0 (Jacobi):       phase 0 jac_gram, 1 jac_inner, 2 jac_update            (work = f64 flops executed)
- *   method 1 (tridiagonal):  phase 0 sytrd_symv (work = BYTES of the trailing matrix streamed),
- *                            1 the other per-column kernels, 2 rank-2k trailing updates (flops),
- *                            3 eigenvalues + inverse iteration + back-transformation */
+ *   method 1 (tridiagonal):  phase 0 the per-column SYMV launches (work = algorithmic BYTES: the full
+ *                            trailing square a one-stage SYMV streams, 8/3 n^3 in total; ms from
+ *                            dispatch-attached events on every 8th launch, scaled), 1 the rest of the
+ *                            reduction (alpha kernels, rank-2k updates, launch gaps), 2 work only
+ *                            (flops of the rank-2k updates), 3 eigenvalues + inverse iteration +
+ *                            back-transformation */
 typedef struct {
   int method;
   int sweeps;        /* Jacobi sweeps; 0 for the tridiagonal route */

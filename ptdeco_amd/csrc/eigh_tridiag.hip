@@ -1,12 +1,13 @@
 // Symmetric eigensolver, tridiagonalisation route (f64):
 //   1. blocked Householder reduction A -> T (panels of 64 reflectors): per column one
-//      HBM / Infinity-Cache bound SYMV over the trailing matrix (the 8/3 n^3-byte stream that
-//      bounds a one-stage reduction), per panel one rank-2*64 update on the f64 matrix cores;
-//   2. eigenvalues of T by bisection on Sturm counts (one eigenvalue per thread);
+//      HBM / Infinity-Cache bound SYMV over the trailing matrix (a one-stage reduction streams
+//      8/3 n^3 bytes; the symmetric kernel reads the lower triangle only) and one small kernel
+//      for everything between two SYMVs, per panel one rank-2*64 update on the f64 matrix cores;
+//   2. eigenvalues of T by multisection on Sturm counts (one wave per eigenvalue);
 //   3. eigenvectors of T by inverse iteration (one eigenvector per thread, pivoted LU of the
 //      shifted tridiagonal), tight clusters re-orthogonalised;
 //   4. back-transformation Z = Q Y with compact-WY block reflectors (f64 MFMA GEMMs).
-// The full matrix (both triangles) is kept current, so every access is a contiguous row.
+// The full matrix (both triangles) is kept current, so the column a panel step needs is a contiguous row.
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
