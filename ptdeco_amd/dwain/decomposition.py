@@ -11,9 +11,9 @@ process per GPU, identical model replica and identical data iterators on every r
     are all-reduced over xGMI -- the only collective that touches matrix data;
   * with ``precomputing_covariance_num_splits`` the eigendecompositions of a split's
     layers are owned round-robin by the ranks and broadcast when a layer's turn comes;
-  * the candidate ranks of a layer are evaluated on different ranks (each reads the
-    metric batches the sequential order would give that candidate) and the three
-    scalars per candidate are all-gathered, so every rank takes the same decisions.
+  * the (candidate rank, metric batch) pairs of a layer are dealt round-robin to the ranks
+    (each pair reads the batch the sequential order would give it) and the three metric
+    sums per candidate are all-reduced, so every rank takes the same decisions.
 """
 
 from __future__ import annotations
@@ -254,17 +254,21 @@ def _process_module(*, root_module, decomposed_submodule_name, data_iterator, lo
             candidates.append((rank_new, drop))
 
         fast = tap.use_dense(orig_weight)  # the tapped layer runs on the HIP GEMMs while it is analysed
-        # metric batches are consumed in candidate order; with several GPUs candidate c is
-        # evaluated by rank c % G on exactly the batches the sequential order gives it
+        # metric batches are consumed in candidate order; with several GPUs pair (c, m) is evaluated by
+        # rank (c M + m) % G on exactly the batch the sequential order gives it
         sums = torch.zeros((max(len(candidates), 1), 3), dtype=torch.float64, device=device)
         # U = W^T uk once for the largest candidate; smaller ranks are column slices of it (:424-429)
         bank = eng.FactorBank(orig_weight, u_matrix, candidates[0][0], orig_dtype) if candidates else None
         for c, (rank_new, _drop) in enumerate(candidates):
             batches = [next(metric_iterator) for _ in range(num_metric_steps)]
-            if not shard.mine(c):
-                continue
-            candidate = bank.get(rank_new, dense=not fast)
-            for batch in batches:
+            candidate = None
+            for m, batch in enumerate(batches):
+                # (candidate, metric batch) pairs are dealt round-robin: finer than whole candidates, so 4 ranks
+                # share 6 x 2 pairs 3/3/3/3 instead of 2/2/1/1 candidates
+                if not shard.mine(c * num_metric_steps + m):
+                    continue
+                if candidate is None:
+                    candidate = bank.get(rank_new, dense=not fast)
                 sums[c] += _compute_metrics(input_dict=utils.to_device(batch, device), root_module=root_module,
                                             tap=tap, orig_weight=orig_weight, candidate=candidate, loss_fn=loss_fn)
         if shard.active:
