@@ -337,6 +337,131 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_glds_kernel(const GemmBf1
   }
 }
 
+// ---- short-K product C[M,N] = A[M,K] B[N,K]^T, K <= 256 (the second product of the decomposed
+// forward, K = rank).  With 128 x 128 tiles such a product re-stages both operands for every output
+// tile and never fills its pipeline (4 K-steps): it runs at the global->LDS staging rate (82 us for
+// T = 16384, N = 4096, K = 256, 4096 tiles x 128 KiB).  Here a workgroup is persistent over N: it owns
+// a 128-row panel of A, kept in REGISTERS as MFMA fragments for the whole launch (K/4 VGPRs), and
+// streams 64-column B tiles (all of K) through a double-buffered LDS-DMA image; a wave multiplies its
+// 32 rows by the tile's 64 columns.  The stores of a step are issued after the next step's staging
+// so that they retire behind its MFMAs.  N is cut into `nsplit` ranges so the grid has ~2 workgroups
+// per CU; block -> (panel = b / nsplit, range = b % nsplit) keeps one B range per XCD's L2.
+template <int KC, int EPI>   // KC = K / 64
+__global__ __launch_bounds__(256, 2) void gemm_bf16_shortk_kernel(const GemmBf16Args a, const int nsplit,
+                                                                  const int cols_per_split) {
+  __shared__ __attribute__((aligned(16))) char lds[2 * KC * 8192 + 4 * 32 * (32 * (EPI == EPI_STORE_BF16 ? 2 : 4) + 16)];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int panel = blockIdx.x / nsplit, split = blockIdx.x % nsplit;
+  const int m0 = panel * 128;
+  const int nbeg = split * cols_per_split, nend = min(a.N, nbeg + cols_per_split);
+  const int fr = lane & 31, fh = lane >> 5;
+
+  const int srow = lane >> 3, spos = lane & 7;
+  // this wave's 32 rows of A as fragments (lane -> row fr, 8 consecutive k of chunk 2 kk + fh).  The
+  // panel comes in through the LDS image in whole 128-byte row pieces (it is exactly as large as the
+  // two B buffers): fragment-shaped loads straight from memory would fetch 32-byte pieces of 32 rows.
+  s16x8 af[KC * 4];
+  {
+#pragma unroll
+    for (int p = 0; p < KC * 4; ++p) {
+      const int q = wid + 4 * p;                 // piece q: image q >> 3 = (row half) * KC + sub-tile, rows (q & 7) * 8 ...
+      const int img = q >> 3, half = img / KC, sub = img % KC, r0 = (q & 7) * 8;
+      const int r = r0 + srow;
+      const int c = spos ^ ((r >> 1) & 7);
+      const unsigned short* sa = a.A + (int64_t)(m0 + half * 64 + r) * a.sam + sub * 64 + c * 8;
+      __builtin_amdgcn_global_load_lds((glb_void*)sa, (lds_void*)(lds + img * 8192 + r0 * 128), 16, 0, 0);
+    }
+    __syncthreads();
+    const int half = wid >> 1, rr = (wid & 1) * 32 + fr;
+#pragma unroll
+    for (int kk = 0; kk < KC * 4; ++kk) {
+      const int sub = kk >> 2, c = ((kk & 3) << 1) + fh;
+      af[kk] = *reinterpret_cast<const s16x8*>(lds + (half * KC + sub) * 8192 + rr * 128 + ((c ^ ((rr >> 1) & 7)) << 4));
+    }
+    __syncthreads();  // the image is free for the B tiles
+  }
+
+  auto stage = [&](int buf, int n0) {
+    char* Bs = lds + buf * (KC * 8192);
+#pragma unroll
+    for (int p = 0; p < KC * 2; ++p) {
+      const int q = wid + 4 * p;                 // piece: sub-tile q >> 3 (64 k), rows (q & 7) * 8 ...
+      const int sub = q >> 3, r0 = (q & 7) * 8;
+      const int r = r0 + srow;
+      const int c = spos ^ ((r >> 1) & 7);       // source chunk that belongs at position spos
+      const unsigned short* sb = a.B + (int64_t)(n0 + r) * a.sbn + sub * 64 + c * 8;
+      __builtin_amdgcn_global_load_lds((glb_void*)sb, (lds_void*)(Bs + sub * 8192 + r0 * 128), 16, 0, 0);
+    }
+  };
+
+  // Output: the MFMA layout gives a lane single elements of 16 rows.  Each wave turns its 32 x 32
+  // block around in a private LDS patch (no workgroup barrier: the wave reads back only what it wrote)
+  // and stores 16-byte row-contiguous pieces.
+  constexpr int ES = (EPI == EPI_STORE_BF16) ? 2 : 4;
+  constexpr int PP = 32 * ES + 16;                           // patch pitch (bytes)
+  char* patch = lds + 2 * KC * 8192 + wid * (32 * PP);
+  auto store = [&](const f32x16 (&acc)[2], int n0) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const float bv = a.bias ? bf16_to_f32(a.bias[n0 + j * 32 + fr]) : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int lr = (r & 3) + 8 * (r >> 2) + 4 * fh;
+        const float o = a.alpha * acc[j][r] + bv;
+        if (EPI == EPI_STORE_BF16) *reinterpret_cast<unsigned short*>(patch + lr * PP + fr * 2) = f32_to_bf16(o);
+        else *reinterpret_cast<float*>(patch + lr * PP + fr * 4) = o;
+      }
+      constexpr int CH = 32 * ES / 16;                       // 16-byte chunks per block row (4 or 8)
+#pragma unroll
+      for (int p = 0; p < 32 * CH / 64; ++p) {
+        const int q = lane + 64 * p;
+        const int lr = q / CH, ch = q % CH;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(patch + lr * PP + ch * 16);
+        char* dst = reinterpret_cast<char*>(a.C) + ((int64_t)(m0 + wid * 32 + lr) * a.ldc + n0 + j * 32) * ES + ch * 16;
+        *reinterpret_cast<f32x4*>(dst) = v;
+      }
+    }
+  };
+
+  f32x16 prev[2];
+  bool have_prev = false;
+  int prev_n0 = 0;
+  stage(0, nbeg);
+  int buf = 0;
+  for (int n0 = nbeg; n0 < nend; n0 += 64, buf ^= 1) {
+    __syncthreads();  // tile n0 has landed (vmcnt(0) + barrier); every wave is done reading the other buffer
+    if (n0 + 64 < nend) stage(buf ^ 1, n0 + 64);
+    if (have_prev) store(prev, prev_n0);
+    const char* Bs = lds + buf * (KC * 8192);
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < KC * 4; ++kk) {
+      const int sub = kk >> 2, c = ((kk & 3) << 1) + fh;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int rb = j * 32 + fr;
+        const s16x8 bf = *reinterpret_cast<const s16x8*>(Bs + sub * 8192 + rb * 128 + ((c ^ ((rb >> 1) & 7)) << 4));
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk], bf, acc[j], 0, 0, 0);
+      }
+    }
+    prev[0] = acc[0]; prev[1] = acc[1];
+    prev_n0 = n0;
+    have_prev = true;
+  }
+  if (have_prev) store(prev, prev_n0);
+}
+
+template <int KC>
+void launch_shortk(const GemmBf16Args& a, bool c_bf16, int nsplit, int cols_per_split, dim3 grid, hipStream_t st) {
+  if (c_bf16) hipLaunchKernelGGL((gemm_bf16_shortk_kernel<KC, EPI_STORE_BF16>), grid, dim3(256), 0, st, a, nsplit, cols_per_split);
+  else hipLaunchKernelGGL((gemm_bf16_shortk_kernel<KC, EPI_STORE_F32>), grid, dim3(256), 0, st, a, nsplit, cols_per_split);
+}
+
 template <int EPI>
 void launch_bf16(const GemmBf16Args& a, bool akc, bool bkc, dim3 grid, hipStream_t st) {
   if (akc && bkc) hipLaunchKernelGGL((gemm_bf16_kernel<true, true, EPI>), grid, dim3(256), 0, st, a);
@@ -366,6 +491,24 @@ int gemm_bf16(const unsigned short* A, int64_t sam, int64_t sak, const unsigned 
   a.vecB = aligned16(B) && ((bkc ? sbn : sbk) % 8 == 0);
   dim3 grid((unsigned)(a.tiles_m * ceil_div(N, BN)), 1);
   static const bool no_glds = getenv("PTD_GEMM_NO_GLDS") != nullptr;
+  static const bool no_shortk = getenv("PTD_GEMM_NO_SHORTK") != nullptr;
+  if (!no_glds && !no_shortk && akc && bkc && a.vecA && a.vecB && M % 128 == 0 && N % 64 == 0 && N >= 256 &&
+      K % 64 == 0 && K >= 64 && K <= 256 && M >= 1024 && aligned16(C) && (ldc * (c_bf16 ? 2 : 4)) % 16 == 0) {
+    // persistent-over-N short-K kernel: ~2 workgroups per CU
+    const int panels = (int)(M / 128);
+    int nsplit = (int)std::max<int64_t>(1, std::min<int64_t>(512 / panels, N / 64));
+    int cols_per_split = (int)align_up((size_t)ceil_div(N, nsplit), 64);
+    nsplit = (int)ceil_div(N, cols_per_split);
+    dim3 g((unsigned)(panels * nsplit), 1);
+    switch (K / 64) {
+      case 1: launch_shortk<1>(a, c_bf16, nsplit, cols_per_split, g, st); break;
+      case 2: launch_shortk<2>(a, c_bf16, nsplit, cols_per_split, g, st); break;
+      case 3: launch_shortk<3>(a, c_bf16, nsplit, cols_per_split, g, st); break;
+      default: launch_shortk<4>(a, c_bf16, nsplit, cols_per_split, g, st); break;
+    }
+    PTD_CHECK_LAUNCH("gemm_bf16 (short K)");
+    return PTD_OK;
+  }
   const bool c_vec = aligned16(C) && (ldc * (c_bf16 ? 2 : 4)) % 16 == 0;  // 16-byte row-contiguous output stores
   if (!no_glds && akc && bkc && a.vecA && a.vecB && c_vec && M % BM == 0 && N % BN == 0 && K % BK == 0 && K >= BK) {
     if (c_bf16) hipLaunchKernelGGL((gemm_bf16_nt_glds_kernel<EPI_STORE_BF16>), grid, dim3(256), 0, st, a);

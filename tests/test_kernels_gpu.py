@@ -327,6 +327,30 @@ def test_gemm_bf16_direct_to_lds_path_exact(ops):
         assert torch.equal(got16.float(), (a.float() @ b.float().T).to(torch.bfloat16).float()), (M, N, K)
 
 
+def test_gemm_bf16_short_k_persistent_path_exact(ops):
+    """K <= 256 with M >= 1024: the persistent-over-N kernel (A panel as register fragments, B tiles
+    streamed through the swizzled LDS-DMA image, N cut into ranges).  Exact integer products for every
+    K / 64 instantiation, ragged range ends and a leading dimension larger than N."""
+    g = torch.Generator().manual_seed(8)
+    for (M, N, K) in [(1024, 256, 64), (1024, 320, 128), (1152, 4096, 256), (2048, 448, 192), (1024, 1024, 320),
+                      (16384, 4096, 256)]:
+        a = torch.randint(-4, 5, (M, K), generator=g).to(torch.bfloat16)
+        b = torch.randint(-4, 5, (N, K), generator=g).to(torch.bfloat16)
+        bias = torch.randint(-3, 4, (N,), generator=g).to(torch.bfloat16)
+        ref = a.float() @ b.float().T
+        got = ops.matmul(a.to(DEV), b.to(DEV).T, bias=bias.to(DEV), out_dtype=torch.float32).cpu()
+        assert torch.equal(got, ref + bias.float()), (M, N, K)
+        got16 = ops.matmul(a.to(DEV), b.to(DEV).T).cpu()
+        assert torch.equal(got16.float(), ref.to(torch.bfloat16).float()), (M, N, K)
+    # the pair forward takes it for its second product
+    x = torch.randint(-2, 3, (2048, 512), generator=g).to(torch.bfloat16)
+    a1 = torch.randint(-2, 3, (128, 512), generator=g).to(torch.bfloat16)
+    b1 = torch.randint(-1, 2, (384, 128), generator=g).to(torch.bfloat16)
+    y = ops.lowrank_forward(x.to(DEV), a1.to(DEV), b1.to(DEV), None).cpu().float()
+    h = (x.float() @ a1.float().T).to(torch.bfloat16).float()
+    assert torch.equal(y, (h @ b1.float().T).to(torch.bfloat16).float())
+
+
 def test_gemm_f32_exact_integers(ops):
     g = torch.Generator().manual_seed(2)
     for layout in LAYOUTS:
