@@ -337,7 +337,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_glds_kernel(const GemmBf1
   }
 }
 
-// ---- short-K product C[M,N] = A[M,K] B[N,K]^T, K <= 256 (the second product of the decomposed
+// ---- short-K product C[M,N] = A[M,K] B[N,K]^T, K <= 512 (the second product of the decomposed
 // forward, K = rank).  With 128 x 128 tiles such a product re-stages both operands for every output
 // tile and never fills its pipeline (4 K-steps): it runs at the global->LDS staging rate (82 us for
 // T = 16384, N = 4096, K = 256, 4096 tiles x 128 KiB).  Here a workgroup is persistent over N: it owns
@@ -346,64 +346,71 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_glds_kernel(const GemmBf1
 // 32 rows by the tile's 64 columns.  The stores of a step are issued after the next step's staging
 // so that they retire behind its MFMAs.  N is cut into `nsplit` ranges so the grid has ~2 workgroups
 // per CU; block -> (panel = b / nsplit, range = b % nsplit) keeps one B range per XCD's L2.
-template <int KC, int EPI>   // KC = K / 64
+template <int KC, int NB, int EPI>   // KC = K / 64; NB = 32-column blocks per wave and step (B tile = 32 NB columns)
 __global__ __launch_bounds__(256, 2) void gemm_bf16_shortk_kernel(const GemmBf16Args a, const int nsplit,
                                                                   const int cols_per_split) {
-  __shared__ __attribute__((aligned(16))) char lds[2 * KC * 8192 + 4 * 32 * (32 * (EPI == EPI_STORE_BF16 ? 2 : 4) + 16)];
+  constexpr int TW = 32 * NB;                 // B tile width (output columns per step)
+  constexpr int SUB = TW * 128;               // bytes of one [TW rows][64 k] sub-tile
+  constexpr int BUF = KC * SUB;               // one B buffer: all of K
+  constexpr int ES = (EPI == EPI_STORE_BF16) ? 2 : 4;
+  constexpr int PP = 32 * ES + 16;            // pitch of a wave's output patch (bytes)
+  static_assert(2 * BUF >= KC * 8192, "the B buffers must hold half an A panel");
+  __shared__ __attribute__((aligned(16))) char lds[2 * BUF + 4 * 32 * PP];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int panel = blockIdx.x / nsplit, split = blockIdx.x % nsplit;
   const int m0 = panel * 128;
   const int nbeg = split * cols_per_split, nend = min(a.N, nbeg + cols_per_split);
   const int fr = lane & 31, fh = lane >> 5;
-
   const int srow = lane >> 3, spos = lane & 7;
+
   // this wave's 32 rows of A as fragments (lane -> row fr, 8 consecutive k of chunk 2 kk + fh).  The
-  // panel comes in through the LDS image in whole 128-byte row pieces (it is exactly as large as the
-  // two B buffers): fragment-shaped loads straight from memory would fetch 32-byte pieces of 32 rows.
+  // panel comes in through the LDS image in whole 128-byte row pieces, 64 rows at a time:
+  // fragment-shaped loads straight from memory would fetch 32-byte pieces of 32 rows.
   s16x8 af[KC * 4];
-  {
 #pragma unroll
-    for (int p = 0; p < KC * 4; ++p) {
-      const int q = wid + 4 * p;                 // piece q: image q >> 3 = (row half) * KC + sub-tile, rows (q & 7) * 8 ...
-      const int img = q >> 3, half = img / KC, sub = img % KC, r0 = (q & 7) * 8;
+  for (int half = 0; half < 2; ++half) {
+#pragma unroll
+    for (int p = 0; p < KC * 2; ++p) {
+      const int q = wid + 4 * p;               // piece q: sub-tile q >> 3 (64 k), rows (q & 7) * 8 ...
+      const int sub = q >> 3, r0 = (q & 7) * 8;
       const int r = r0 + srow;
-      const int c = spos ^ ((r >> 1) & 7);
+      const int c = spos ^ ((r >> 1) & 7);     // source chunk that belongs at position spos
       const unsigned short* sa = a.A + (int64_t)(m0 + half * 64 + r) * a.sam + sub * 64 + c * 8;
-      __builtin_amdgcn_global_load_lds((glb_void*)sa, (lds_void*)(lds + img * 8192 + r0 * 128), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_void*)sa, (lds_void*)(lds + sub * 8192 + r0 * 128), 16, 0, 0);
     }
     __syncthreads();
-    const int half = wid >> 1, rr = (wid & 1) * 32 + fr;
+    if ((wid >> 1) == half) {
+      const int rr = (wid & 1) * 32 + fr;
 #pragma unroll
-    for (int kk = 0; kk < KC * 4; ++kk) {
-      const int sub = kk >> 2, c = ((kk & 3) << 1) + fh;
-      af[kk] = *reinterpret_cast<const s16x8*>(lds + (half * KC + sub) * 8192 + rr * 128 + ((c ^ ((rr >> 1) & 7)) << 4));
+      for (int kk = 0; kk < KC * 4; ++kk) {
+        const int sub = kk >> 2, c = ((kk & 3) << 1) + fh;
+        af[kk] = *reinterpret_cast<const s16x8*>(lds + sub * 8192 + rr * 128 + ((c ^ ((rr >> 1) & 7)) << 4));
+      }
     }
-    __syncthreads();  // the image is free for the B tiles
+    __syncthreads();  // the image is free again
   }
 
   auto stage = [&](int buf, int n0) {
-    char* Bs = lds + buf * (KC * 8192);
+    char* Bs = lds + buf * BUF;
 #pragma unroll
-    for (int p = 0; p < KC * 2; ++p) {
-      const int q = wid + 4 * p;                 // piece: sub-tile q >> 3 (64 k), rows (q & 7) * 8 ...
-      const int sub = q >> 3, r0 = (q & 7) * 8;
+    for (int p = 0; p < KC * TW / 32; ++p) {
+      const int q = wid + 4 * p;               // piece q: sub-tile q / (TW / 8), rows (q % (TW / 8)) * 8 ...
+      const int sub = q / (TW / 8), r0 = (q % (TW / 8)) * 8;
       const int r = r0 + srow;
-      const int c = spos ^ ((r >> 1) & 7);       // source chunk that belongs at position spos
+      const int c = spos ^ ((r >> 1) & 7);
       const unsigned short* sb = a.B + (int64_t)(n0 + r) * a.sbn + sub * 64 + c * 8;
-      __builtin_amdgcn_global_load_lds((glb_void*)sb, (lds_void*)(Bs + sub * 8192 + r0 * 128), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_void*)sb, (lds_void*)(Bs + sub * SUB + r0 * 128), 16, 0, 0);
     }
   };
 
   // Output: the MFMA layout gives a lane single elements of 16 rows.  Each wave turns its 32 x 32
   // block around in a private LDS patch (no workgroup barrier: the wave reads back only what it wrote)
   // and stores 16-byte row-contiguous pieces.
-  constexpr int ES = (EPI == EPI_STORE_BF16) ? 2 : 4;
-  constexpr int PP = 32 * ES + 16;                           // patch pitch (bytes)
-  char* patch = lds + 2 * KC * 8192 + wid * (32 * PP);
-  auto store = [&](const f32x16 (&acc)[2], int n0) {
+  char* patch = lds + 2 * BUF + wid * (32 * PP);
+  auto store = [&](const f32x16 (&acc)[NB], int n0) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NB; ++j) {
       const float bv = a.bias ? bf16_to_f32(a.bias[n0 + j * 32 + fr]) : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -412,7 +419,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_shortk_kernel(const GemmBf16
         if (EPI == EPI_STORE_BF16) *reinterpret_cast<unsigned short*>(patch + lr * PP + fr * 2) = f32_to_bf16(o);
         else *reinterpret_cast<float*>(patch + lr * PP + fr * 4) = o;
       }
-      constexpr int CH = 32 * ES / 16;                       // 16-byte chunks per block row (4 or 8)
+      constexpr int CH = 32 * ES / 16;         // 16-byte chunks per block row (4 or 8)
 #pragma unroll
       for (int p = 0; p < 32 * CH / 64; ++p) {
         const int q = lane + 64 * p;
@@ -424,32 +431,33 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_shortk_kernel(const GemmBf16
     }
   };
 
-  f32x16 prev[2];
+  f32x16 prev[NB];
   bool have_prev = false;
   int prev_n0 = 0;
   stage(0, nbeg);
   int buf = 0;
-  for (int n0 = nbeg; n0 < nend; n0 += 64, buf ^= 1) {
+  for (int n0 = nbeg; n0 < nend; n0 += TW, buf ^= 1) {
     __syncthreads();  // tile n0 has landed (vmcnt(0) + barrier); every wave is done reading the other buffer
-    if (n0 + 64 < nend) stage(buf ^ 1, n0 + 64);
+    if (n0 + TW < nend) stage(buf ^ 1, n0 + TW);
     if (have_prev) store(prev, prev_n0);
-    const char* Bs = lds + buf * (KC * 8192);
-    f32x16 acc[2];
+    const char* Bs = lds + buf * BUF;
+    f32x16 acc[NB];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NB; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 #pragma unroll
     for (int kk = 0; kk < KC * 4; ++kk) {
       const int sub = kk >> 2, c = ((kk & 3) << 1) + fh;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < NB; ++j) {
         const int rb = j * 32 + fr;
-        const s16x8 bf = *reinterpret_cast<const s16x8*>(Bs + sub * 8192 + rb * 128 + ((c ^ ((rb >> 1) & 7)) << 4));
+        const s16x8 bf = *reinterpret_cast<const s16x8*>(Bs + sub * SUB + rb * 128 + ((c ^ ((rb >> 1) & 7)) << 4));
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk], bf, acc[j], 0, 0, 0);
       }
     }
-    prev[0] = acc[0]; prev[1] = acc[1];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) prev[j] = acc[j];
     prev_n0 = n0;
     have_prev = true;
   }
@@ -458,8 +466,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_shortk_kernel(const GemmBf16
 
 template <int KC>
 void launch_shortk(const GemmBf16Args& a, bool c_bf16, int nsplit, int cols_per_split, dim3 grid, hipStream_t st) {
-  if (c_bf16) hipLaunchKernelGGL((gemm_bf16_shortk_kernel<KC, EPI_STORE_BF16>), grid, dim3(256), 0, st, a, nsplit, cols_per_split);
-  else hipLaunchKernelGGL((gemm_bf16_shortk_kernel<KC, EPI_STORE_F32>), grid, dim3(256), 0, st, a, nsplit, cols_per_split);
+  constexpr int NB = KC <= 4 ? 2 : 1;  // K > 256: narrower B tiles keep two workgroups per CU in LDS
+  if (c_bf16)
+    hipLaunchKernelGGL((gemm_bf16_shortk_kernel<KC, NB, EPI_STORE_BF16>), grid, dim3(256), 0, st, a, nsplit, cols_per_split);
+  else
+    hipLaunchKernelGGL((gemm_bf16_shortk_kernel<KC, NB, EPI_STORE_F32>), grid, dim3(256), 0, st, a, nsplit, cols_per_split);
 }
 
 template <int EPI>
@@ -493,7 +504,7 @@ int gemm_bf16(const unsigned short* A, int64_t sam, int64_t sak, const unsigned 
   static const bool no_glds = getenv("PTD_GEMM_NO_GLDS") != nullptr;
   static const bool no_shortk = getenv("PTD_GEMM_NO_SHORTK") != nullptr;
   if (!no_glds && !no_shortk && akc && bkc && a.vecA && a.vecB && M % 128 == 0 && N % 64 == 0 && N >= 256 &&
-      K % 64 == 0 && K >= 64 && K <= 256 && M >= 1024 && aligned16(C) && (ldc * (c_bf16 ? 2 : 4)) % 16 == 0) {
+      K % 64 == 0 && K >= 64 && K <= 512 && M >= 1024 && aligned16(C) && (ldc * (c_bf16 ? 2 : 4)) % 16 == 0) {
     // persistent-over-N short-K kernel: ~2 workgroups per CU
     const int panels = (int)(M / 128);
     int nsplit = (int)std::max<int64_t>(1, std::min<int64_t>(512 / panels, N / 64));
@@ -504,7 +515,11 @@ int gemm_bf16(const unsigned short* A, int64_t sam, int64_t sak, const unsigned 
       case 1: launch_shortk<1>(a, c_bf16, nsplit, cols_per_split, g, st); break;
       case 2: launch_shortk<2>(a, c_bf16, nsplit, cols_per_split, g, st); break;
       case 3: launch_shortk<3>(a, c_bf16, nsplit, cols_per_split, g, st); break;
-      default: launch_shortk<4>(a, c_bf16, nsplit, cols_per_split, g, st); break;
+      case 4: launch_shortk<4>(a, c_bf16, nsplit, cols_per_split, g, st); break;
+      case 5: launch_shortk<5>(a, c_bf16, nsplit, cols_per_split, g, st); break;
+      case 6: launch_shortk<6>(a, c_bf16, nsplit, cols_per_split, g, st); break;
+      case 7: launch_shortk<7>(a, c_bf16, nsplit, cols_per_split, g, st); break;
+      default: launch_shortk<8>(a, c_bf16, nsplit, cols_per_split, g, st); break;
     }
     PTD_CHECK_LAUNCH("gemm_bf16 (short K)");
     return PTD_OK;

@@ -328,12 +328,12 @@ def test_gemm_bf16_direct_to_lds_path_exact(ops):
 
 
 def test_gemm_bf16_short_k_persistent_path_exact(ops):
-    """K <= 256 with M >= 1024: the persistent-over-N kernel (A panel as register fragments, B tiles
+    """K <= 512 with M >= 1024: the persistent-over-N kernel (A panel as register fragments, B tiles
     streamed through the swizzled LDS-DMA image, N cut into ranges).  Exact integer products for every
     K / 64 instantiation, ragged range ends and a leading dimension larger than N."""
     g = torch.Generator().manual_seed(8)
     for (M, N, K) in [(1024, 256, 64), (1024, 320, 128), (1152, 4096, 256), (2048, 448, 192), (1024, 1024, 320),
-                      (16384, 4096, 256)]:
+                      (1024, 256, 384), (1280, 576, 448), (2048, 256, 512), (16384, 4096, 256)]:
         a = torch.randint(-4, 5, (M, K), generator=g).to(torch.bfloat16)
         b = torch.randint(-4, 5, (N, K), generator=g).to(torch.bfloat16)
         bias = torch.randint(-3, 4, (N,), generator=g).to(torch.bfloat16)
