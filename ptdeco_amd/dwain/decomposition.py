@@ -95,8 +95,14 @@ class CovarianceComputingLinearModule(torch.nn.Module):
 
 
 def _max_candidate_rank(dim_in: int, dim_out: int, min_rank: int, reduction_factor: float) -> int:
-    """Largest rank the search of :407-408 can try (>= 1): eigenvectors below it are never read."""
-    ranks = _candidate_ranks(min(dim_in, dim_out), min_rank, reduction_factor)
+    """Largest rank the search of :407-421 can EVALUATE (>= 1): eigenvectors below it are never read.
+    Candidates that do not lower the parameter count are skipped before any factor is formed
+    (:418-421) -- for a square layer that is every rank >= full / 2, so the default schedule
+    (2048, 1024, ... at 4096 x 4096) needs the top 1024 eigenvectors, not 2048."""
+    full = min(dim_in, dim_out)
+    baseline = _get_params_for_proportion(1.0, dim_in, dim_out)
+    ranks = [r for r in _candidate_ranks(full, min_rank, reduction_factor)
+             if baseline - _get_params_for_proportion(r / full, dim_in, dim_out) != 0]
     return max(1, max(ranks)) if ranks else 1
 
 
