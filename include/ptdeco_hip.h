@@ -87,12 +87,15 @@ int ptd_eigh(const double* A, int64_t lda, int64_t n, double* evals, double* eve
              void* ws, size_t ws_bytes, int* sweeps_out, void* stream);
 
 /* Same, but only the eigenvectors of the k LARGEST eigenvalues are formed: evecs is [n, k]
- * (ld ldv >= k), column c holds the eigenvector of evals[n - k + c]; evals still has all n
- * entries.  dwain never looks below rank floor(n * reduction_factor) (dwain.py:407-408, 424-426),
- * so half of the inverse iterations and of the back-transformation are skipped, and a dense
- * cluster at the low end of the spectrum no longer forces the Jacobi fallback. */
-int ptd_eigh_topk(const double* A, int64_t lda, int64_t n, int64_t k, double* evals, double* evecs,
-                  int64_t ldv, void* ws, size_t ws_bytes, int* sweeps_out, void* stream);
+ * (ld ldv >= k), column c holds the eigenvector of evals[n - k + c].  evals always has n entries:
+ * with all_values != 0 every eigenvalue is computed; with all_values == 0 the tridiagonal route
+ * computes only evals[n - k - 1 .. n) and fills the rest with NaN (the Jacobi route always
+ * returns all of them) -- the drivers never read eigenvalues.  dwain never looks above the largest
+ * candidate rank it evaluates (dwain.py:407-421, 424-426), so most of the inverse iterations and of
+ * the back-transformation are skipped, and a dense cluster at the low end of the spectrum no
+ * longer forces the Jacobi fallback. */
+int ptd_eigh_topk(const double* A, int64_t lda, int64_t n, int64_t k, int all_values, double* evals,
+                  double* evecs, int64_t ldv, void* ws, size_t ws_bytes, int* sweeps_out, void* stream);
 
 /* Top-k eigenpairs of C = W Ex W^T without forming C, for a layer that widens its input
  * (n_o > n_i; Llama gate / up: 4096 -> 14336): W [n_o, n_i] (f32, bf16 or f64, ld ldw),
@@ -125,8 +128,8 @@ typedef struct {
   double work[4];
   float total_ms;    /* first launch to last launch of the call */
 } ptd_eigh_stats;
-int ptd_eigh_profiled(const double* A, int64_t lda, int64_t n, int64_t k, double* evals, double* evecs,
-                      int64_t ldv, void* ws, size_t ws_bytes, ptd_eigh_stats* stats, void* stream);
+int ptd_eigh_profiled(const double* A, int64_t lda, int64_t n, int64_t k, int all_values, double* evals,
+                      double* evecs, int64_t ldv, void* ws, size_t ws_bytes, ptd_eigh_stats* stats, void* stream);
 
 /* Diagnostic: Householder tridiagonalisation T = Q^T A Q of a symmetric f64 matrix (full
  * storage) and the eigenvalues of T by bisection.  d[n], e[n] (e[n-1] unused), evals[n]

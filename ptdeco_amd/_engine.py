@@ -228,9 +228,9 @@ class Covariance:
             c = ops.matmul(ops.matmul(w64, ex), w64.T)
             c = 0.5 * (c + c.T)
             c.diagonal().add_(damp_factor * c.diagonal().mean())
-            return ops.eigh(c, top_k)[1]
+            return ops.eigh(c, top_k, all_values=False)[1]
         c = ops.cov_finalize(self.E, self.steps, damp_factor, self.ey if use_mean else None)
-        _, u = ops.eigh(c, top_k)
+        _, u = ops.eigh(c, top_k, all_values=False)
         return u
 
 

@@ -30,9 +30,9 @@ SIGNATURES = {
     "ptd_eigh_workspace_bytes": (c_size_t, [c_int64]),
     "ptd_eigh": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_size_t,
                          ctypes.POINTER(c_int), c_void_p]),
-    "ptd_eigh_topk": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_size_t,
-                              ctypes.POINTER(c_int), c_void_p]),
-    "ptd_eigh_profiled": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p,
+    "ptd_eigh_topk": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int64, c_void_p,
+                              c_size_t, ctypes.POINTER(c_int), c_void_p]),
+    "ptd_eigh_profiled": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int64, c_void_p,
                                   c_size_t, c_void_p, c_void_p]),
     "ptd_tridiagonalize_workspace_bytes": (c_size_t, [c_int64]),
     "ptd_tridiagonalize": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,

@@ -70,13 +70,13 @@ size_t ptd_eigh_workspace_bytes(int64_t n) {
 }
 
 static int eigh_dispatch(const double* A, int64_t lda, int64_t n, int64_t k, double* evals, double* evecs,
-                         int64_t ldv, void* ws, size_t ws_bytes, int* sweeps_out, ptd_eigh_stats* stats,
-                         hipStream_t st) {
+                         int64_t ldv, void* ws, size_t ws_bytes, int* sweeps_out, bool all_values,
+                         ptd_eigh_stats* stats, hipStream_t st) {
   const int method = eigh_method();
   if (method != 0 && (method == 1 || n >= 256) && A && evals && evecs && ws && n >= 2 && lda >= n && k >= 1 &&
       k <= n && ldv >= k) {
     const char* ct = getenv("PTD_EIGH_CLUSTER_TOL");
-    const int rc = eigh_tridiag(A, lda, n, k, evals, evecs, ldv, ws, ws_bytes, ct ? atof(ct) : 1e-10, stats, st);
+    const int rc = eigh_tridiag(A, lda, n, k, evals, evecs, ldv, ws, ws_bytes, ct ? atof(ct) : 1e-10, all_values, stats, st);
     if (rc != PTD_ERR_UNSUPPORTED) {
       if (sweeps_out) *sweeps_out = 0;
       return rc;
@@ -98,20 +98,20 @@ int ptd_eigh_factored(const void* W, int64_t ldw, int w_dtype, int64_t n_o, int6
 
 int ptd_eigh(const double* A, int64_t lda, int64_t n, double* evals, double* evecs, int64_t ldv, void* ws,
              size_t ws_bytes, int* sweeps_out, void* stream) {
-  return eigh_dispatch(A, lda, n, n, evals, evecs, ldv, ws, ws_bytes, sweeps_out, nullptr,
+  return eigh_dispatch(A, lda, n, n, evals, evecs, ldv, ws, ws_bytes, sweeps_out, true, nullptr,
                        static_cast<hipStream_t>(stream));
 }
 
-int ptd_eigh_topk(const double* A, int64_t lda, int64_t n, int64_t k, double* evals, double* evecs, int64_t ldv,
-                  void* ws, size_t ws_bytes, int* sweeps_out, void* stream) {
-  return eigh_dispatch(A, lda, n, k, evals, evecs, ldv, ws, ws_bytes, sweeps_out, nullptr,
+int ptd_eigh_topk(const double* A, int64_t lda, int64_t n, int64_t k, int all_values, double* evals, double* evecs,
+                  int64_t ldv, void* ws, size_t ws_bytes, int* sweeps_out, void* stream) {
+  return eigh_dispatch(A, lda, n, k, evals, evecs, ldv, ws, ws_bytes, sweeps_out, all_values != 0, nullptr,
                        static_cast<hipStream_t>(stream));
 }
 
-int ptd_eigh_profiled(const double* A, int64_t lda, int64_t n, int64_t k, double* evals, double* evecs, int64_t ldv,
-                      void* ws, size_t ws_bytes, ptd_eigh_stats* stats, void* stream) {
+int ptd_eigh_profiled(const double* A, int64_t lda, int64_t n, int64_t k, int all_values, double* evals,
+                      double* evecs, int64_t ldv, void* ws, size_t ws_bytes, ptd_eigh_stats* stats, void* stream) {
   PTD_REQUIRE(stats, "ptd_eigh_profiled: stats must not be null");
-  return eigh_dispatch(A, lda, n, k, evals, evecs, ldv, ws, ws_bytes, nullptr, stats,
+  return eigh_dispatch(A, lda, n, k, evals, evecs, ldv, ws, ws_bytes, nullptr, all_values != 0, stats,
                        static_cast<hipStream_t>(stream));
 }
 
@@ -199,6 +199,7 @@ namespace ptd {
 size_t eigh_select_workspace_bytes(int64_t n) { return ptd_eigh_workspace_bytes(n); }
 int eigh_select(const double* A, int64_t lda, int64_t n, int64_t k, double* evals, double* evecs, int64_t ldv,
                 void* ws, size_t ws_bytes, int* sweeps_out, ptd_eigh_stats* stats, hipStream_t st) {
-  return eigh_dispatch(A, lda, n, k, evals, evecs, ldv, ws, ws_bytes, sweeps_out, stats, st);
+  // the factored route reads only the k largest eigenvalues of its reduced problem
+  return eigh_dispatch(A, lda, n, k, evals, evecs, ldv, ws, ws_bytes, sweeps_out, false, stats, st);
 }
 }  // namespace ptd

@@ -346,8 +346,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_glds_kernel(const GemmBf1
 // 32 rows by the tile's 64 columns.  The stores of a step are issued after the next step's staging
 // so that they retire behind its MFMAs.  N is cut into `nsplit` ranges so the grid has ~2 workgroups
 // per CU; block -> (panel = b / nsplit, range = b % nsplit) keeps one B range per XCD's L2.
+constexpr int shortk_lds_bytes(int kc, int nb, int epi) {
+  return 2 * kc * 32 * nb * 128 + 4 * 32 * (32 * (epi == EPI_STORE_BF16 ? 2 : 4) + 16);
+}
+
 template <int KC, int NB, int EPI>   // KC = K / 64; NB = 32-column blocks per wave and step (B tile = 32 NB columns)
-__global__ __launch_bounds__(256, 2) void gemm_bf16_shortk_kernel(const GemmBf16Args a, const int nsplit,
+__global__ __launch_bounds__(256, (shortk_lds_bytes(KC, NB, EPI) <= 80 * 1024 ? 2 : 1)) void gemm_bf16_shortk_kernel(const GemmBf16Args a, const int nsplit,
                                                                   const int cols_per_split) {
   constexpr int TW = 32 * NB;                 // B tile width (output columns per step)
   constexpr int SUB = TW * 128;               // bytes of one [TW rows][64 k] sub-tile

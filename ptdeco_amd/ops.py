@@ -93,12 +93,14 @@ def cov_finalize(E: torch.Tensor, steps: int, damp_factor: float, ey: Optional[t
 EIGH_PROFILE: Optional[list] = None
 
 
-def eigh(A: torch.Tensor, k: Optional[int] = None) -> tuple[torch.Tensor, torch.Tensor]:
+def eigh(A: torch.Tensor, k: Optional[int] = None, all_values: bool = True) -> tuple[torch.Tensor, torch.Tensor]:
     """(eigenvalues [n] ascending, eigenvectors in columns) of a symmetric PSD f64 matrix.
 
     With ``k`` only the eigenvectors of the k largest eigenvalues are formed: the second result is
     [n, k] and its column c belongs to eigenvalue n - k + c, so ``v[:, v.shape[1] - r:]`` is the
-    top-r block for every r <= k exactly as with the full matrix."""
+    top-r block for every r <= k exactly as with the full matrix.  ``all_values=False`` lets the
+    solver skip the eigenvalues below the k + 1 largest (those entries of the first result are NaN
+    then, unless the Jacobi route ran); the decomposition drivers never read eigenvalues."""
     _dev(A)
     assert A.dtype == torch.float64 and A.dim() == 2 and A.shape[0] == A.shape[1] and A.stride(1) == 1
     n = A.shape[0]
@@ -109,11 +111,11 @@ def eigh(A: torch.Tensor, k: Optional[int] = None) -> tuple[torch.Tensor, torch.
     ws = torch.empty(lib.ptd_eigh_workspace_bytes(n), dtype=torch.uint8, device=A.device)
     with torch.cuda.device(A.device):
         if EIGH_PROFILE is None:
-            rc = lib.ptd_eigh_topk(A.data_ptr(), A.stride(0), n, k, w.data_ptr(), v.data_ptr(), k, ws.data_ptr(),
-                                   ws.numel(), None, _stream(A))
+            rc = lib.ptd_eigh_topk(A.data_ptr(), A.stride(0), n, k, int(all_values), w.data_ptr(), v.data_ptr(), k,
+                                   ws.data_ptr(), ws.numel(), None, _stream(A))
         else:
             st = _hip.EighStats()
-            rc = lib.ptd_eigh_profiled(A.data_ptr(), A.stride(0), n, k, w.data_ptr(), v.data_ptr(), k,
+            rc = lib.ptd_eigh_profiled(A.data_ptr(), A.stride(0), n, k, int(all_values), w.data_ptr(), v.data_ptr(), k,
                                        ws.data_ptr(), ws.numel(), ctypes.byref(st), _stream(A))
             EIGH_PROFILE.append({"n": n, "k": k, "method": st.method, "sweeps": st.sweeps,
                                  "launches": list(st.launches), "ms": list(st.ms), "total_ms": st.total_ms,

@@ -36,7 +36,7 @@ def cov_finalize(E, steps, damp_factor, ey=None):
     return full
 
 
-def eigh(A, k=None):
+def eigh(A, k=None, all_values=True):
     w, v = torch.linalg.eigh(A)
     return (w, v) if k is None else (w, v[:, v.shape[1] - max(1, min(int(k), v.shape[1])):])
 
