@@ -883,32 +883,111 @@ __global__ __launch_bounds__(256) void tridiag_chain_mgs_kernel(const double* __
 // transformations, revisited"), so W2 = T W1 is one 64-row upper-triangular solve per column
 // of W1.  One thread per column, the column lives in registers, the 64 x 64 matrix in LDS
 // (every lane reads the same entry: broadcast).  tau_i == 0 (identity reflector) gives a zero row.
-__global__ __launch_bounds__(256) void wy_solve_kernel(const double* __restrict__ G, const double* __restrict__ tau,
-                                                      int cols, const double* __restrict__ W1,
-                                                      double* __restrict__ W2, int nvec) {
-  __shared__ double Ti[NB][NB + 1];
+// ---- compact-WY factors of ALL panels in three launches (they depend only on V and tau):
+//   wy_gram      partial Gram matrices  G_p = V_p V_p^T  (V_p: the panel's 64 reflectors as rows)
+//   wy_tfactor   T_p = (striu(G_p) + diag(1 / tau))^-1  (upper triangular; tau_i = 0 gives a zero row / column)
+//   wy_tv        TV_p = T_p V_p
+// so that the back-transformation of a panel is  Y -= V_p^T (TV_p Y): two products instead of a Gram
+// product, a product, a triangular solve and a product.
+constexpr int GCH = 1024;  // columns of V_p per wy_gram workgroup
+
+__global__ __launch_bounds__(256) void wy_gram_kernel(const double* __restrict__ Vall, int64_t ld, int n,
+                                                      double* __restrict__ Gpart, int nchunks) {
+  __shared__ double Vs[NB][129];
+  const int panel = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+  const int r0 = panel * NB + 1;
+  const double* Vp = Vall + (int64_t)panel * NB * ld;
+  const int ti = tid >> 4, tj = tid & 15;
+  double acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+  const int cbeg = r0 + chunk * GCH, cend = min(n, cbeg + GCH);
+  for (int c0 = cbeg; c0 < cend; c0 += 128) {
+    for (int e = tid; e < NB * 128; e += 256) {
+      const int r = e >> 7, c = e & 127;
+      Vs[r][c] = (c0 + c < cend) ? Vp[(int64_t)r * ld + c0 + c] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int c = 0; c < 128; ++c) {
+      double va[4], vb[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) { va[a] = Vs[4 * ti + a][c]; vb[a] = Vs[4 * tj + a][c]; }
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] += va[a] * vb[b];
+    }
+    __syncthreads();
+  }
+  double* out = Gpart + ((int64_t)panel * nchunks + chunk) * NB * NB;
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) out[(4 * ti + a) * NB + 4 * tj + b] = acc[a][b];
+}
+
+__global__ __launch_bounds__(256) void wy_tfactor_kernel(const double* __restrict__ Gpart, int nchunks,
+                                                         const double* __restrict__ taus, int n,
+                                                         double* __restrict__ Tall) {
+  __shared__ double Ti[NB][NB + 1];  // striu(G), then the inverse is built column by column in registers
   __shared__ double tl[NB];
-  const int tid = threadIdx.x;
+  const int panel = blockIdx.x, tid = threadIdx.x;
+  const int j0 = panel * NB, cols = min(NB, n - j0);
   for (int e = tid; e < NB * NB; e += 256) {
-    const int r = e >> 6, c = e & 63;
-    Ti[r][c] = (r < cols && c < cols && c > r) ? G[r * NB + c] : 0.0;
+    double g = 0.0;
+    for (int c = 0; c < nchunks; ++c) g += Gpart[((int64_t)panel * nchunks + c) * NB * NB + e];  // fixed order
+    const int r = e >> 6, q = e & 63;
+    Ti[r][q] = (r < cols && q < cols && q > r) ? g : 0.0;
   }
-  if (tid < NB) tl[tid] = tid < cols ? tau[tid] : 0.0;
+  if (tid < NB) tl[tid] = tid < cols ? taus[j0 + tid] : 0.0;
   __syncthreads();
-  const int c = blockIdx.x * 256 + tid;
-  if (c >= nvec) return;
-  double x[NB];
+  if (tid < NB) {
+    // column j of T solves (striu(G) + diag(1 / tau)) t = e_j by back substitution
+    const int j = tid;
+    double t[NB];
 #pragma unroll
-  for (int i = 0; i < NB; ++i) x[i] = W1[(int64_t)i * nvec + c];
+    for (int i = 0; i < NB; ++i) t[i] = 0.0;
 #pragma unroll
-  for (int i = NB - 1; i >= 0; --i) {
-    double sacc = x[i];
+    for (int i = NB - 1; i >= 0; --i) {
+      if (i <= j) {
+        double sacc = (i == j) ? 1.0 : 0.0;
 #pragma unroll
-    for (int q = i + 1; q < NB; ++q) sacc -= Ti[i][q] * x[q];
-    x[i] = sacc * tl[i];  // (1 / tau_i)^-1; rows >= cols and tau == 0 give 0
+        for (int q = i + 1; q < NB; ++q) sacc -= Ti[i][q] * t[q];
+        t[i] = sacc * tl[i];
+      }
+    }
+    double* out = Tall + (int64_t)panel * NB * NB;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) out[i * NB + j] = t[i];
   }
-#pragma unroll
-  for (int i = 0; i < NB; ++i) W2[(int64_t)i * nvec + c] = x[i];
+}
+
+__global__ __launch_bounds__(256) void wy_tv_kernel(const double* __restrict__ Vall, int64_t ld, int n,
+                                                    const double* __restrict__ Tall, double* __restrict__ TVall) {
+  __shared__ double Ts[NB][NB + 1];
+  __shared__ double Vs[NB][129];
+  const int panel = blockIdx.y, tid = threadIdx.x;
+  const int r0 = panel * NB + 1;
+  const int c0 = r0 + blockIdx.x * 128;
+  if (c0 >= n) return;
+  const double* Vp = Vall + (int64_t)panel * NB * ld;
+  for (int e = tid; e < NB * NB; e += 256) Ts[e >> 6][e & 63] = Tall[(int64_t)panel * NB * NB + e];
+  for (int e = tid; e < NB * 128; e += 256) {
+    const int r = e >> 7, c = e & 127;
+    Vs[r][c] = (c0 + c < n) ? Vp[(int64_t)r * ld + c0 + c] : 0.0;
+  }
+  __syncthreads();
+  const int c = tid & 127, half = tid >> 7;
+  if (c0 + c >= n) return;
+  double* out = TVall + (int64_t)panel * NB * ld + c0 + c;
+  for (int i = half * 32; i < half * 32 + 32; ++i) {
+    double sacc = 0.0;
+    for (int q = i; q < NB; ++q) sacc += Ts[i][q] * Vs[q][c];  // T is upper triangular
+    out[(int64_t)i * ld] = sacc;
+  }
 }
 
 __global__ void square_kernel(const double* __restrict__ e, int n, double* __restrict__ e2) {
@@ -933,7 +1012,7 @@ struct TridiagPlan {
   int npanels;
   size_t off_A, off_V, off_W, off_col, off_p, off_part, off_refl, off_d, off_e, off_e2, off_tau, off_bounds, off_lam;
   size_t off_u1, off_u2, off_u3, off_lm, off_sw, off_G, off_T, off_W1, off_W2, off_wraw, off_wraw2, off_part2, off_cbuf;
-  size_t off_qv, off_px2, off_rowpart, off_colpart;
+  size_t off_qv, off_px2, off_rowpart, off_colpart, off_gpart, off_tall;
   int64_t ldp;     // leading dimension of the symmetric SYMV's partial-result arrays
   size_t total;
 };
@@ -952,7 +1031,8 @@ TridiagPlan tridiag_plan(int64_t n) {
   p.npanels = (int)ceil_div(n, NB);
   size_t o = 0;
   auto take = [&](size_t bytes) { size_t at = o; o += align_up(bytes, 256); return at; };
-  p.off_A = take((size_t)n * p.ld * 8);
+  // working copy of A; once the reduction is done it holds TV_p = T_p V_p of every panel (npanels * 64 rows)
+  p.off_A = take((size_t)p.npanels * NB * p.ld * 8);
   p.off_V = take((size_t)p.npanels * NB * p.ld * 8);
   p.off_W = take((size_t)NB * p.ld * 8);
   p.off_col = take((size_t)(p.ldp + 8) * 8);
@@ -984,6 +1064,8 @@ TridiagPlan tridiag_plan(int64_t n) {
   p.off_px2 = take((size_t)(ceil_div(n + 2 * NB, SROWS) + 8) * 8);
   p.off_rowpart = take((size_t)ceil_div(n, TC) * p.ldp * 8);
   p.off_colpart = take((size_t)ceil_div(n, TR) * p.ldp * 8);
+  p.off_gpart = take((size_t)p.npanels * ceil_div(n, GCH) * NB * NB * 8);
+  p.off_tall = take((size_t)p.npanels * NB * NB * 8);
   p.total = o;
   return p;
 }
@@ -1140,8 +1222,6 @@ int tridiag_vectors_and_backtransform(const TridiagPlan& p, char* base, int nvec
   double* bounds = reinterpret_cast<double*>(base + p.off_bounds);
   double* taus = reinterpret_cast<double*>(base + p.off_tau);
   double* Vall = reinterpret_cast<double*>(base + p.off_V);
-  double* G = reinterpret_cast<double*>(base + p.off_G);
-  double* W1 = reinterpret_cast<double*>(base + p.off_W1);
   double* W2 = reinterpret_cast<double*>(base + p.off_W2);
   InvitWs ws;
   ws.U1i = reinterpret_cast<double*>(base + p.off_u1);
@@ -1156,7 +1236,20 @@ int tridiag_vectors_and_backtransform(const TridiagPlan& p, char* base, int nvec
     hipLaunchKernelGGL(tridiag_chain_mgs_kernel, dim3((unsigned)nvec), dim3(256), 0, st, lamk, n, nvec, bounds, ortol,
                        Y, ldy);
   PTD_CHECK_LAUNCH("tridiag_invit");
-  // Y <- Q_0 Q_1 ... Q_last Y : apply the panels' block reflectors from the last to the first
+  // Y <- Q_0 Q_1 ... Q_last Y : apply the panels' block reflectors from the last to the first,
+  // Q_p Y = Y - V_p^T (TV_p Y) with TV_p = T_p V_p formed for all panels up front
+  double* TVall = reinterpret_cast<double*>(base + p.off_A);  // the working copy of A is dead by now
+  {
+    double* Gpart = reinterpret_cast<double*>(base + p.off_gpart);
+    double* Tall = reinterpret_cast<double*>(base + p.off_tall);
+    const int nchunks = (int)ceil_div(n, GCH);
+    hipLaunchKernelGGL(wy_gram_kernel, dim3((unsigned)nchunks, (unsigned)p.npanels), dim3(256), 0, st, Vall, ld, n,
+                       Gpart, nchunks);
+    hipLaunchKernelGGL(wy_tfactor_kernel, dim3((unsigned)p.npanels), dim3(256), 0, st, Gpart, nchunks, taus, n, Tall);
+    hipLaunchKernelGGL(wy_tv_kernel, dim3((unsigned)ceil_div(n, 128), (unsigned)p.npanels), dim3(256), 0, st, Vall, ld,
+                       n, Tall, TVall);
+    PTD_CHECK_LAUNCH("wy factors");
+  }
   for (int pn = p.npanels - 1; pn >= 0; --pn) {
     const int j0 = pn * NB;
     const int cols = std::min(NB, n - j0);
@@ -1164,18 +1257,11 @@ int tridiag_vectors_and_backtransform(const TridiagPlan& p, char* base, int nvec
     const int mr = n - r0;
     if (mr <= 0) continue;
     const double* Vp = Vall + (size_t)pn * NB * ld;
-    // G = V V^T over rows r0..n-1 (cols x cols, stored NB x NB)
-    PTD_CHECK_HIP(hipMemsetAsync(G, 0, (size_t)NB * NB * 8, st));
-    int rc = gemm_f64(Vp + r0, ld, 1, Vp + r0, 1, ld, G, NB, cols, cols, mr, 1.0, true, 64, st);
+    const double* TVp = TVall + (size_t)pn * NB * ld;
+    // W2 = TV_p Y  (cols x nvec)
+    PTD_CHECK_HIP(hipMemsetAsync(W2, 0, (size_t)NB * nvec * 8, st));
+    int rc = gemm_f64(TVp + r0, ld, 1, Y + (int64_t)r0 * ldy, ldy, 1, W2, nvec, cols, nvec, mr, 1.0, true, 16, st);
     if (rc != PTD_OK) return rc;
-
-    // W1 = V Y  (cols x n)
-    PTD_CHECK_HIP(hipMemsetAsync(W1, 0, (size_t)NB * nvec * 8, st));
-    rc = gemm_f64(Vp + r0, ld, 1, Y + (int64_t)r0 * ldy, ldy, 1, W1, nvec, cols, nvec, mr, 1.0, true, 16, st);
-    if (rc != PTD_OK) return rc;
-    // W2 = T W1 by the triangular solve with T^-1 = striu(G) + diag(1 / tau)
-    hipLaunchKernelGGL(wy_solve_kernel, dim3((unsigned)ceil_div(nvec, 256)), dim3(256), 0, st, G, taus + j0, cols, W1,
-                       W2, nvec);
     // Y[r0:, :] -= V^T W2
     rc = gemm_f64(Vp + r0, 1, ld, W2, nvec, 1, Y + (int64_t)r0 * ldy, ldy, mr, nvec, cols, -1.0, true, 1, st);
     if (rc != PTD_OK) return rc;
