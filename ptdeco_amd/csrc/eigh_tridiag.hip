@@ -22,6 +22,9 @@ namespace ptd {
 
 int gemm_f64(const double* A, int64_t sam, int64_t sak, const double* B, int64_t sbk, int64_t sbn, double* C,
              int64_t ldc, int64_t M, int64_t N, int64_t K, double alpha, bool beta1, int ksplit, hipStream_t st);
+int gemm_f64_pair(const double* A, const double* B, const double* A2, const double* B2, int64_t sam, int64_t sak,
+                  int64_t sbk, int64_t sbn, double* C, int64_t ldc, int64_t M, int64_t N, int64_t K, double alpha,
+                  hipStream_t st);
 
 namespace {
 
@@ -1182,9 +1185,7 @@ int sytrd_f64(const TridiagPlan& p, char* base, SymvTimer* timer, hipStream_t st
                            t0 - 1, Vp, Wp, ld, wr[(cols - 1) & 1], partial2, std::max(blocks, 1), taus);
         // trailing update A[T0:, T0:] -= V W^T + W V^T
         double* At = Aw + (int64_t)t0 * ld + t0;
-        int rc = gemm_f64(Vp + t0, 1, ld, Wp + t0, ld, 1, At, ld, mt, mt, cols, -1.0, true, 1, st);
-        if (rc != PTD_OK) return rc;
-        rc = gemm_f64(Wp + t0, 1, ld, Vp + t0, ld, 1, At, ld, mt, mt, cols, -1.0, true, 1, st);
+        const int rc = gemm_f64_pair(Vp + t0, Wp + t0, Wp + t0, Vp + t0, 1, ld, ld, 1, At, ld, mt, mt, cols, -1.0, st);
         if (rc != PTD_OK) return rc;
       }
     }

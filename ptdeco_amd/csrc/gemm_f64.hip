@@ -32,6 +32,8 @@ struct GemmF64Args {
   int atomic;  // 1: split K, accumulate with atomics (requires beta1)
   int kchunk;
   int tiles_m;
+  const double* A2;  // optional second operand pair with the same strides: C gets A B + A2 B2 in one pass
+  const double* B2;  // over C (the symmetric rank-2k update V^T W + W^T V)
 };
 
 // this thread's 2 x (2 doubles) of a 64 (r) x 16 (k) operand tile
@@ -91,6 +93,13 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(const GemmF64Args a) {
     for (int j = 0; j < 2; ++j) acc[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
 
   double2 ra[2], rb[2];
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int npass = a.A2 ? 2 : 1;
+  for (int pass = 0; pass < npass; ++pass) {
+  if (pass == 1) {
+    Ap = a.A2 + (int64_t)m0 * a.sam + (int64_t)kbeg * a.sak;
+    Bp = a.B2 + (int64_t)n0 * a.sbn + (int64_t)kbeg * a.sbk;
+  }
   if (nk > 0) {
     fetch64<AKC>(Ap, sa, m_lim, kend - kbeg, tid, ra);
     fetch64<BKC>(Bp, sb, n_lim, kend - kbeg, tid, rb);
@@ -98,7 +107,6 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(const GemmF64Args a) {
     stash64<BKC>(Bs, tid, rb);
   }
   __syncthreads();
-  const int l15 = lane & 15, l4 = lane >> 4;
   for (int kt = 0; kt < nk; ++kt) {
     const bool more = kt + 1 < nk;
     if (more) {
@@ -124,6 +132,7 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(const GemmF64Args a) {
       __syncthreads();
     }
   }
+  }
   // C/D map of the f64 MFMA: col = lane & 15, row = (lane >> 4) + 4 * reg
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -145,12 +154,30 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(const GemmF64Args a) {
 }  // namespace
 
 // C = alpha * op(A) op(B) + (beta1 ? C : 0).  ksplit > 1 needs beta1 (C must hold the addend).
+static int gemm_f64_impl(const double* A, int64_t sam, int64_t sak, const double* B, int64_t sbk, int64_t sbn,
+                         const double* A2, const double* B2, double* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
+                         double alpha, bool beta1, int ksplit, hipStream_t st);
+
 int gemm_f64(const double* A, int64_t sam, int64_t sak, const double* B, int64_t sbk, int64_t sbn, double* C,
              int64_t ldc, int64_t M, int64_t N, int64_t K, double alpha, bool beta1, int ksplit, hipStream_t st) {
+  return gemm_f64_impl(A, sam, sak, B, sbk, sbn, nullptr, nullptr, C, ldc, M, N, K, alpha, beta1, ksplit, st);
+}
+
+// C += alpha * (A B + A2 B2), both pairs with the same strides, in ONE pass over C
+int gemm_f64_pair(const double* A, const double* B, const double* A2, const double* B2, int64_t sam, int64_t sak,
+                  int64_t sbk, int64_t sbn, double* C, int64_t ldc, int64_t M, int64_t N, int64_t K, double alpha,
+                  hipStream_t st) {
+  return gemm_f64_impl(A, sam, sak, B, sbk, sbn, A2, B2, C, ldc, M, N, K, alpha, true, 1, st);
+}
+
+static int gemm_f64_impl(const double* A, int64_t sam, int64_t sak, const double* B, int64_t sbk, int64_t sbn,
+                         const double* A2, const double* B2, double* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
+                         double alpha, bool beta1, int ksplit, hipStream_t st) {
   if (M <= 0 || N <= 0) return PTD_OK;
   GemmF64Args a{};
   a.A = A; a.sam = sam; a.sak = sak;
   a.B = B; a.sbk = sbk; a.sbn = sbn;
+  a.A2 = A2; a.B2 = B2;
   a.C = C; a.ldc = ldc;
   a.M = (int)M; a.N = (int)N; a.K = (int)K;
   a.alpha = alpha; a.beta1 = beta1 ? 1 : 0;
