@@ -27,8 +27,7 @@ rank decisions one by one.
 
 from __future__ import annotations
 
-import collections.abc
-from typing import Any, Callable, Iterator, Optional
+from typing import Any, Optional
 
 import torch
 

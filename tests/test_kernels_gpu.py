@@ -4,7 +4,6 @@ f64 torch-CPU arithmetic on the same seeded inputs.  Needs an MI355X."""
 import math
 import os
 
-import numpy as np
 import pytest
 import torch
 

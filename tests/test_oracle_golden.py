@@ -1,7 +1,6 @@
 """Pins the CPU oracle (oracle/ptdeco_oracle.py) against golden vectors that
 were produced by running the reference itself (tests/golden/gen_golden.py)."""
 
-import copy
 
 import numpy as np
 import pytest

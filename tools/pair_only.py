@@ -1,4 +1,4 @@
-import sys, os, torch
+import sys, torch
 sys.path.insert(0, "/root/repo")
 from ptdeco_amd import ops
 dev = torch.device("cuda")
