@@ -337,6 +337,7 @@ def main():
     if rank == 0:
         print(json.dumps(result))
     if world > 1:
+        dist.barrier()  # rank 0 may still be in its side measurements
         dist.destroy_process_group()
 
 
