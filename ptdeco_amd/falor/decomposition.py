@@ -57,7 +57,8 @@ def _batches_consumed(layer: torch.nn.Module, num_data_steps: int, num_metric_st
 
 
 def _compute_decompositon_of_covariance_matrix(*, root_module, tap: eng.LayerTap, data_iterator, weight,
-                                               num_data_steps, device, use_float64, use_mean, use_damping):
+                                               num_data_steps, device, use_float64, use_mean, use_damping,
+                                               top_k=None):
     """:165-208.  Quirk kept: damping is applied to Eyyt after cov was formed, so with
     use_mean=True it never reaches the matrix that is decomposed (:196-205)."""
     root_module.eval()
@@ -67,7 +68,7 @@ def _compute_decompositon_of_covariance_matrix(*, root_module, tap: eng.LayerTap
         cov.add_inputs(tap.last_input_rows(), weight)
     logger.info("Using mean for covariance" if use_mean else "Not using mean for covariance")
     damp = EIGEN_DAMPEN_FACTOR if (use_damping and not use_mean) else 0.0
-    return cov.eigenvectors(damp, use_mean=use_mean)
+    return cov.eigenvectors(damp, use_mean=use_mean, top_k=top_k)
 
 
 def _compute_metrics(*, x, root_module, tap: eng.LayerTap, orig_weight, candidate) -> torch.Tensor:
@@ -109,10 +110,14 @@ def _process_module(*, root_module, decomposed_submodule_name, data_iterator, ns
         logger.info(f"{msg_prefix} {utils.get_type_name(layer)} weight_shape={tuple(orig_weight.shape)}")
         logger.info(f"{msg_prefix} {nsr_final_threshold=:.6f} {kl_final_threshold=:.6f}")
 
+        # The bisection (:340-375) only ever tries ranks <= full_rank - 1, so the eigenvectors below the
+        # top full_rank - 1 are never read.  For a widening layer (n_out > n_in: qkv, fc1, a classifier
+        # head) that is decisive: y = x W^T has a feature covariance of rank <= n_in, i.e. an (n_out - n_in)
+        # fold zero eigenvalue, and asking for its eigenvectors would push the solver to its Jacobi fallback.
         u = _compute_decompositon_of_covariance_matrix(
             root_module=root_module, tap=tap, data_iterator=data_iterator, weight=orig_weight,
             num_data_steps=num_data_steps, device=device, use_float64=use_float64, use_mean=use_mean,
-            use_damping=use_damping)
+            use_damping=use_damping, top_k=full_rank - 1)
 
         # the tapped layer runs on the HIP GEMMs while it is analysed (f32 models only: falor builds
         # its factors in float32, falor.py:346)

@@ -107,5 +107,12 @@ if os.path.exists(stk):
              f"f32 {st['f32']['seconds']:.1f} s, bf16 {st['bf16']['seconds']:.1f} s for 14 layers ({st['f32']['candidates_evaluated']} candidates); "
              "here the user model's own forwards (two per metric step through the whole stack, torch / hipBLASLt) dominate, "
              "as SURVEY 3.5 predicts for real LLM configs.\n")
+c3 = os.path.join(root, f"c3_vit_falor_r{rnd}.json")
+if os.path.exists(c3):
+    v = json.loads(open(c3).read().strip().splitlines()[-1])
+    o.append(f"\n## ViT-B/16-shaped falor run (C3)\n\n`python tools/c3_vit.py`: {v['layers']} Linear layers, {v['candidates_evaluated']} bisection steps, "
+             f"**{v['seconds']:.1f} s = {v['layers_per_s']:.2f} layers/s** on one GPU ({v['decomposed']} layers replaced). The run is dominated by the "
+             "user model's own forwards (two per bisection step and metric batch); the widening layers (qkv, fc1, head: rank-deficient feature "
+             "covariance) only ask for the eigenvectors the bisection can use, which keeps them on the tridiagonal route (23.6 s before).\n")
 open(os.path.join(root, "README.md"), "w").write("".join(o))
 print("".join(o))
