@@ -152,13 +152,13 @@ class LayerTap:
         self.last_features = None
 
 
-def _input_route_wanted(n_out: int, n_in: int, top_k: Optional[int], with_mean: bool) -> bool:
+def _input_route_wanted(n_out: int, n_in: int, top_k: Optional[int]) -> bool:
     """Layers that widen their input (n_out > n_in, e.g. Llama gate / up 4096 -> 14336): the feature
     covariance W Ex W^T has rank <= n_in, so its leading eigenvectors come from an n_in-sized problem
     (ptd_eigh_factored).  PTD_INPUT_COVARIANCE=0 disables the route, =1 forces it when legal."""
     import os
 
-    if with_mean or top_k is None or top_k > n_in or n_out <= n_in:
+    if top_k is None or top_k > n_in or n_out <= n_in:
         return False
     flag = os.environ.get("PTD_INPUT_COVARIANCE", "auto")
     if flag == "0":
@@ -178,10 +178,11 @@ class Covariance:
                  weight: Optional[torch.Tensor] = None, top_k: Optional[int] = None):
         dt = torch.float64 if float64 else torch.float32
         self.weight = weight
-        self.input_route = weight is not None and _input_route_wanted(n, weight.shape[1], top_k, with_mean)
+        self.input_route = weight is not None and _input_route_wanted(n, weight.shape[1], top_k)
         m = weight.shape[1] if self.input_route else n
         self.E = torch.zeros((m, m), dtype=dt, device=device)
-        self.ey = torch.zeros(n, dtype=dt, device=device) if with_mean else None
+        # mean of the accumulated rows (falor): of y, or of x on the input route (Ey = W mean(x))
+        self.ey = torch.zeros(m, dtype=dt, device=device) if with_mean else None
         self.steps = 0
 
     def add_features(self, y: torch.Tensor) -> None:
@@ -198,6 +199,8 @@ class Covariance:
         caller's `features` if it already has them), then Y^T Y.  Input route: X^T X only."""
         if self.input_route:
             ops.syrk_accumulate(self.E, x_rows, 1.0 / x_rows.shape[0])
+            if self.ey is not None:
+                ops.colsum_accumulate(self.ey, x_rows, 1.0 / x_rows.shape[0])
             self.steps += 1
             return
         self.add_features(features if features is not None else ops.matmul(x_rows, weight2d.T))
@@ -218,7 +221,8 @@ class Covariance:
         eigenvectors in columns, ascending, f64 (dwain.py:155-163, falor.py:192-208).  With
         ``top_k`` only the last top_k columns (largest eigenvalues) are formed: [n, top_k]."""
         if self.input_route:
-            ex = ops.cov_finalize(self.E, self.steps, 0.0, None)  # damping only shifts eigenvalues
+            # cov = W (Ex - mx mx^T) W^T when the mean is removed (falor.py:196-199); damping only shifts eigenvalues
+            ex = ops.cov_finalize(self.E, self.steps, 0.0, self.ey if use_mean else None)
             w2d = self.weight if self.weight.dim() == 2 else self.weight[..., 0, 0]
             got = ops.eigh_factored(w2d, ex, top_k)
             if got is not None:

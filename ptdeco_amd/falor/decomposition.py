@@ -62,7 +62,7 @@ def _compute_decompositon_of_covariance_matrix(*, root_module, tap: eng.LayerTap
     """:165-208.  Quirk kept: damping is applied to Eyyt after cov was formed, so with
     use_mean=True it never reaches the matrix that is decomposed (:196-205)."""
     root_module.eval()
-    cov = eng.Covariance(weight.shape[0], device, use_float64, with_mean=True)
+    cov = eng.Covariance(weight.shape[0], device, use_float64, with_mean=True, weight=weight, top_k=top_k)
     for _ in range(num_data_steps):
         root_module(next(data_iterator).to(device))
         cov.add_inputs(tap.last_input_rows(), weight)
