@@ -986,10 +986,17 @@ __global__ __launch_bounds__(256) void wy_tv_kernel(const double* __restrict__ V
   const int c = tid & 127, half = tid >> 7;
   if (c0 + c >= n) return;
   double* out = TVall + (int64_t)panel * NB * ld + c0 + c;
-  for (int i = half * 32; i < half * 32 + 32; ++i) {
-    double sacc = 0.0;
-    for (int q = i; q < NB; ++q) sacc += Ts[i][q] * Vs[q][c];  // T is upper triangular
-    out[(int64_t)i * ld] = sacc;
+  // four output rows at a time over the full q range (T is upper triangular: the entries below the
+  // diagonal are stored as zeros), so that the LDS reads pipeline instead of feeding one dependent chain
+  for (int i0 = half * 32; i0 < half * 32 + 32; i0 += 4) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll 8
+    for (int q = 0; q < NB; ++q) {
+      const double v = Vs[q][c];
+      s0 += Ts[i0][q] * v; s1 += Ts[i0 + 1][q] * v; s2 += Ts[i0 + 2][q] * v; s3 += Ts[i0 + 3][q] * v;
+    }
+    out[(int64_t)i0 * ld] = s0; out[(int64_t)(i0 + 1) * ld] = s1;
+    out[(int64_t)(i0 + 2) * ld] = s2; out[(int64_t)(i0 + 3) * ld] = s3;
   }
 }
 
