@@ -498,3 +498,36 @@ def test_lowrank_pair_backward_matches_autograd_of_the_two_layers(ops, kind):
     y0.backward(); opt.step()
     with torch.no_grad():
         assert (fused(x.to(DEV)) - tgt.float().to(DEV)).pow(2).mean().item() < y0.item()
+
+
+def test_eigh_topk_without_all_values_skips_the_low_eigenvalues(ops, monkeypatch):
+    """all_values=False (what the drivers pass): the k + 1 largest eigenvalues and the k eigenvectors are
+    those of the full solve; the entries below are NaN on the tridiagonal route."""
+    monkeypatch.setenv("PTD_EIGH_METHOD", "tridiag")
+    n, k = 640, 150
+    y = _rand((2 * n + 3, n), 77).double() * torch.logspace(0, -2, n, dtype=torch.float64)
+    a = y.T @ y / y.shape[0]
+    a = a + torch.eye(n, dtype=torch.float64) * (0.01 * torch.diag(a).mean())
+    w_all, v_all = ops.eigh(a.to(DEV), k, all_values=True)
+    w_top, v_top = ops.eigh(a.to(DEV), k, all_values=False)
+    assert torch.isnan(w_top[: n - k - 1]).all() and not torch.isnan(w_top[n - k - 1:]).any()
+    assert torch.equal(w_top[n - k - 1:], w_all[n - k - 1:])
+    assert (v_top - v_all).abs().max().item() < 1e-12
+    w_ref = torch.linalg.eigvalsh(a)
+    assert (w_top[n - k - 1:].cpu() - w_ref[n - k - 1:]).abs().max().item() <= 1e-12 * w_ref.max().item()
+
+
+def test_factor_bank_slices_equal_per_rank_products(ops):
+    """_engine.FactorBank: the factors of a smaller rank are the trailing columns of the largest one's."""
+    from ptdeco_amd import _engine as eng
+
+    g = torch.Generator().manual_seed(5)
+    w = (torch.randn(96, 160, generator=g) / 12.0).to(DEV)
+    u = torch.linalg.qr(torch.randn(96, 96, generator=g, dtype=torch.float64))[0].to(DEV)
+    bank = eng.FactorBank(w, u, 64, torch.float32)
+    for r in (64, 40, 7, 1):
+        uk, big_u, w_deco = bank.get(r, dense=True)
+        uk2, big_u2, w_deco2 = eng.build_factors(w, u, r, torch.float32, dense=True)
+        assert torch.equal(uk, uk2) and torch.equal(big_u.contiguous(), big_u2) and torch.equal(w_deco, w_deco2)
+    with pytest.raises(ValueError):
+        bank.get(65)
