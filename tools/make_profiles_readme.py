@@ -61,6 +61,12 @@ if os.path.exists(pmc):
              "also when it would fit in L2 (L2 does not keep lines across kernel boundaries).\n\n")
 else:
     o.append("* `roofline.traffic` is null: no PMC pass committed for this round.\n\n")
+mf = os.path.join(root, f"pmc_mfma_r{rnd}.json")
+if os.path.exists(mf):
+    mk = json.load(open(mf))["kernels"]
+    o.append("* MFMA utilisation from the counters (`pmc_mfma_r%s.json`, `tools/pmc_driver mfma`): " % rnd
+             + "; ".join(f"`{k}` MfmaUtil {v.get('MfmaUtil', float('nan')):.0f} % (busy cycles {100 * v.get('busy_fraction', float('nan')):.0f} %)" for k, v in mk.items())
+             + " -- in line with the event-timed rates below.\n\n")
 o.append("## Top kernels (rocprofv3 --stats)\n\n| kernel | calls | avg us | % of GPU time |\n|---|---|---|---|\n")
 for x in rows[:14]:
     o.append(f"| `{short(x['Name'])}` | {x['Calls']} | {float(x['AverageNs']) / 1e3:.1f} | {float(x['Percentage']):.2f} |\n")

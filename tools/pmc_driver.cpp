@@ -7,11 +7,41 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "ptdeco_hip.h"
 
+// mode "mfma": the f32 covariance SYRK, the f32 layer-output GEMM and the bf16 GEMM at 4096^3, for
+//   rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-include-regex "syrk|gemm" -- tools/pmc_driver mfma
+static int run_mfma() {
+  const int64_t n = 4096;
+  std::vector<float> h((size_t)n * n);
+  unsigned long long s = 0x9E3779B97F4A7C15ull;
+  for (auto& v : h) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; v = (float)((double)(s >> 11) * (2.0 / 9007199254740992.0) - 1.0); }
+  std::vector<unsigned short> hb(h.size());
+  for (size_t i = 0; i < h.size(); ++i) { unsigned u; memcpy(&u, &h[i], 4); hb[i] = (unsigned short)((u + 0x7FFF + ((u >> 16) & 1)) >> 16); }
+  float *X, *W, *Y; double* E; unsigned short *Xb, *Wb, *Yb;
+  if (hipMalloc(&X, n * n * 4) || hipMalloc(&W, n * n * 4) || hipMalloc(&Y, n * n * 4) || hipMalloc(&E, n * n * 8) ||
+      hipMalloc(&Xb, n * n * 2) || hipMalloc(&Wb, n * n * 2) || hipMalloc(&Yb, n * n * 2)) return 2;
+  (void)hipMemcpy(X, h.data(), n * n * 4, hipMemcpyHostToDevice);
+  (void)hipMemcpy(W, h.data(), n * n * 4, hipMemcpyHostToDevice);
+  (void)hipMemcpy(Xb, hb.data(), n * n * 2, hipMemcpyHostToDevice);
+  (void)hipMemcpy(Wb, hb.data(), n * n * 2, hipMemcpyHostToDevice);
+  (void)hipMemset(E, 0, n * n * 8);
+  for (int r = 0; r < 3; ++r) {
+    int rc = ptd_syrk_accumulate(X, n, n, n, 0, E, n, 1, 1.0 / n, nullptr);
+    rc |= ptd_gemm(X, n, 1, W, 1, n, Y, n, n, n, n, 0, 0, 1.0, nullptr, nullptr);      // y = x W^T, f32
+    rc |= ptd_gemm(Xb, n, 1, Wb, 1, n, Yb, n, n, n, n, 2, 2, 1.0, nullptr, nullptr);    // bf16
+    if (rc) { fprintf(stderr, "mfma mode rc=%d: %s\n", rc, ptd_last_error()); return 1; }
+  }
+  (void)hipDeviceSynchronize();
+  printf("mfma mode done\n");
+  return 0;
+}
+
 int main(int argc, char** argv) {
+  if (argc > 1 && !strcmp(argv[1], "mfma")) return run_mfma();
   const int64_t n = argc > 1 ? atoll(argv[1]) : 4096;
   const int reps = argc > 2 ? atoi(argv[2]) : 1;
   std::vector<double> h((size_t)n * n);
