@@ -139,6 +139,18 @@ def kernel_lines(device):
     t = time_events(lambda: ops.nsr(y2.view(BATCH, SEQ, N_FEAT), y.view(BATCH, SEQ, N_FEAT), N_FEAT))
     by = 2 * y.numel() * 4
     lines["nsr_f32"] = {"ms": t * 1e3, "algorithmic_bytes": by, "gbps": by / t / 1e9, "frac_of_hbm_peak": by / t / PEAK_HBM}
+    # MFMA utilisation from the committed rocprofv3 PMC pass over the same kernels (tools/pmc_driver mfma)
+    import glob
+    here = os.path.dirname(os.path.abspath(__file__))
+    pmc = sorted(glob.glob(os.path.join(here, "profiles", "pmc_mfma_r*.json")))
+    if pmc:
+        kern = json.load(open(pmc[-1]))["kernels"]
+        for line, key in (("syrk_f32_f64acc", "syrk_f32_mixed_kernel"), ("gemm_f32_nt", "gemm_f32_kernel"),
+                          ("gemm_bf16_nt", "gemm_bf16_nt_glds_kernel")):
+            for name, c in kern.items():
+                if name.startswith(key) and "MfmaUtil" in c and line in lines:
+                    lines[line]["mfma_util_pmc_percent"] = c["MfmaUtil"]
+                    lines[line]["mfma_util_source"] = "profiles/" + os.path.basename(pmc[-1])
     return lines
 
 
