@@ -1121,13 +1121,15 @@ int sytrd_f64(const TridiagPlan& p, char* base, SymvTimer* timer, hipStream_t st
   PTD_CHECK_HIP(hipMemsetAsync(taus, 0, (size_t)n * 8, st));
   PTD_CHECK_HIP(hipMemsetAsync(e, 0, (size_t)n * 8, st));
   PTD_CHECK_HIP(hipMemsetAsync(colbuf, 0, (size_t)(p.ldp + 8) * 8, st));
+  // W panel: entries below a row's first written column are multiplied by zero but must be finite;
+  // later panels find the previous panel's (finite) values there
+  PTD_CHECK_HIP(hipMemsetAsync(Wp, 0, (size_t)NB * ld * 8, st));
   PTD_CHECK_HIP(hipMemsetAsync(wr[0], 0, (size_t)(n + 8) * 8, st));
   PTD_CHECK_HIP(hipMemsetAsync(wr[1], 0, (size_t)(n + 8) * 8, st));
   for (int pn = 0; pn < p.npanels; ++pn) {
     const int j0 = pn * NB;
     const int cols = std::min(NB, n - j0);
     double* Vp = Vall + (size_t)pn * NB * ld;
-    PTD_CHECK_HIP(hipMemsetAsync(Wp, 0, (size_t)NB * ld * 8, st));
     int nparts2 = 0, npx2 = 0;
     bool open = false;  // a column whose SYMV ran and whose reflector is not finished yet
     for (int i = 0; i < cols; ++i) {
