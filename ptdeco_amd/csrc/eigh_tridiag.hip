@@ -24,7 +24,7 @@ int gemm_f64(const double* A, int64_t sam, int64_t sak, const double* B, int64_t
              int64_t ldc, int64_t M, int64_t N, int64_t K, double alpha, bool beta1, int ksplit, hipStream_t st);
 int gemm_f64_pair(const double* A, const double* B, const double* A2, const double* B2, int64_t sam, int64_t sak,
                   int64_t sbk, int64_t sbn, double* C, int64_t ldc, int64_t M, int64_t N, int64_t K, double alpha,
-                  hipStream_t st);
+                  double* row0_out, hipStream_t st);
 
 namespace {
 
@@ -1126,6 +1126,7 @@ int sytrd_f64(const TridiagPlan& p, char* base, SymvTimer* timer, hipStream_t st
   PTD_CHECK_HIP(hipMemsetAsync(Wp, 0, (size_t)NB * ld * 8, st));
   PTD_CHECK_HIP(hipMemsetAsync(wr[0], 0, (size_t)(n + 8) * 8, st));
   PTD_CHECK_HIP(hipMemsetAsync(wr[1], 0, (size_t)(n + 8) * 8, st));
+  bool colbuf_ready = false;
   for (int pn = 0; pn < p.npanels; ++pn) {
     const int j0 = pn * NB;
     const int cols = std::min(NB, n - j0);
@@ -1135,8 +1136,10 @@ int sytrd_f64(const TridiagPlan& p, char* base, SymvTimer* timer, hipStream_t st
     for (int i = 0; i < cols; ++i) {
       const int j = j0 + i;
       if (i == 0) {
-        hipLaunchKernelGGL(sytrd_colinit_kernel, dim3((unsigned)ceil_div(n - j, 256)), dim3(256), 0, st, Aw, ld, n,
-                           j, colbuf);
+        if (!colbuf_ready)  // the previous panel's trailing update has already left row j in colbuf
+          hipLaunchKernelGGL(sytrd_colinit_kernel, dim3((unsigned)ceil_div(n - j, 256)), dim3(256), 0, st, Aw, ld, n,
+                             j, colbuf);
+        colbuf_ready = false;
       } else {
         const int blocks = (int)ceil_div(n - j, 64);
         SymPart spa = sp;
@@ -1194,7 +1197,10 @@ int sytrd_f64(const TridiagPlan& p, char* base, SymvTimer* timer, hipStream_t st
                            t0 - 1, Vp, Wp, ld, wr[(cols - 1) & 1], partial2, std::max(blocks, 1), taus);
         // trailing update A[T0:, T0:] -= V W^T + W V^T
         double* At = Aw + (int64_t)t0 * ld + t0;
-        const int rc = gemm_f64_pair(Vp + t0, Wp + t0, Wp + t0, Vp + t0, 1, ld, ld, 1, At, ld, mt, mt, cols, -1.0, st);
+        // ... and the updated row t0 goes straight into colbuf: the next panel's first column (colinit)
+        const int rc = gemm_f64_pair(Vp + t0, Wp + t0, Wp + t0, Vp + t0, 1, ld, ld, 1, At, ld, mt, mt, cols, -1.0,
+                                     colbuf + t0, st);
+        colbuf_ready = true;
         if (rc != PTD_OK) return rc;
       }
     }

@@ -34,6 +34,7 @@ struct GemmF64Args {
   int tiles_m;
   const double* A2;  // optional second operand pair with the same strides: C gets A B + A2 B2 in one pass
   const double* B2;  // over C (the symmetric rank-2k update V^T W + W^T V)
+  double* row0_out;  // optional: the updated first row of C is also written here (the next panel's first column)
 };
 
 // this thread's 2 x (2 doubles) of a 64 (r) x 16 (k) operand tile
@@ -145,9 +146,13 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(const GemmF64Args a) {
         if (row >= a.M || col >= a.N) continue;
         double* c = a.C + (int64_t)row * a.ldc + col;
         const double v = a.alpha * acc[i][j][r];
-        if (a.atomic) atomicAdd(c, v);
-        else if (a.beta1) *c += v;
-        else *c = v;
+        if (a.atomic) {
+          atomicAdd(c, v);
+        } else {
+          const double nv = a.beta1 ? *c + v : v;
+          *c = nv;
+          if (a.row0_out && row == 0) a.row0_out[col] = nv;
+        }
       }
 }
 
@@ -156,28 +161,29 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(const GemmF64Args a) {
 // C = alpha * op(A) op(B) + (beta1 ? C : 0).  ksplit > 1 needs beta1 (C must hold the addend).
 static int gemm_f64_impl(const double* A, int64_t sam, int64_t sak, const double* B, int64_t sbk, int64_t sbn,
                          const double* A2, const double* B2, double* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
-                         double alpha, bool beta1, int ksplit, hipStream_t st);
+                         double alpha, bool beta1, int ksplit, double* row0_out, hipStream_t st);
 
 int gemm_f64(const double* A, int64_t sam, int64_t sak, const double* B, int64_t sbk, int64_t sbn, double* C,
              int64_t ldc, int64_t M, int64_t N, int64_t K, double alpha, bool beta1, int ksplit, hipStream_t st) {
-  return gemm_f64_impl(A, sam, sak, B, sbk, sbn, nullptr, nullptr, C, ldc, M, N, K, alpha, beta1, ksplit, st);
+  return gemm_f64_impl(A, sam, sak, B, sbk, sbn, nullptr, nullptr, C, ldc, M, N, K, alpha, beta1, ksplit, nullptr, st);
 }
 
 // C += alpha * (A B + A2 B2), both pairs with the same strides, in ONE pass over C
 int gemm_f64_pair(const double* A, const double* B, const double* A2, const double* B2, int64_t sam, int64_t sak,
                   int64_t sbk, int64_t sbn, double* C, int64_t ldc, int64_t M, int64_t N, int64_t K, double alpha,
-                  hipStream_t st) {
-  return gemm_f64_impl(A, sam, sak, B, sbk, sbn, A2, B2, C, ldc, M, N, K, alpha, true, 1, st);
+                  double* row0_out, hipStream_t st) {
+  return gemm_f64_impl(A, sam, sak, B, sbk, sbn, A2, B2, C, ldc, M, N, K, alpha, true, 1, row0_out, st);
 }
 
 static int gemm_f64_impl(const double* A, int64_t sam, int64_t sak, const double* B, int64_t sbk, int64_t sbn,
                          const double* A2, const double* B2, double* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
-                         double alpha, bool beta1, int ksplit, hipStream_t st) {
+                         double alpha, bool beta1, int ksplit, double* row0_out, hipStream_t st) {
   if (M <= 0 || N <= 0) return PTD_OK;
   GemmF64Args a{};
   a.A = A; a.sam = sam; a.sak = sak;
   a.B = B; a.sbk = sbk; a.sbn = sbn;
   a.A2 = A2; a.B2 = B2;
+  a.row0_out = row0_out;
   a.C = C; a.ldc = ldc;
   a.M = (int)M; a.N = (int)N; a.K = (int)K;
   a.alpha = alpha; a.beta1 = beta1 ? 1 : 0;
