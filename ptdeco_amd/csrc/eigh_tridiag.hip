@@ -892,7 +892,7 @@ __global__ __launch_bounds__(256) void tridiag_chain_mgs_kernel(const double* __
 //   wy_tv        TV_p = T_p V_p
 // so that the back-transformation of a panel is  Y -= V_p^T (TV_p Y): two products instead of a Gram
 // product, a product, a triangular solve and a product.
-constexpr int GCH = 1024;  // columns of V_p per wy_gram workgroup
+constexpr int GCH = 512;  // columns of V_p per wy_gram workgroup
 
 __global__ __launch_bounds__(256) void wy_gram_kernel(const double* __restrict__ Vall, int64_t ld, int n,
                                                       double* __restrict__ Gpart, int nchunks) {
