@@ -337,6 +337,189 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_glds_kernel(const GemmBf1
   }
 }
 
+// ---- 256 x 256 tile, 8 waves, 8 phases per two K steps (the CDNA4 guide's deep-pipelined schedule) ----
+// For big nn.Linear-layout products (M, N multiples of 256, K of 128, enough tiles to fill the chip).
+// The 128^2 kernel above stalls every K step on the vmcnt(0) of its one barrier (~900 TFLOP/s ceiling).
+// Here a workgroup owns a 256 x 256 tile at one workgroup per CU; the operands of a K step are four
+// 16-KiB "half tiles" (A rows 0-127 / 128-255, B columns 0-127 / 128-255, 64 k each) in a double
+// buffered LDS image (128 KiB), filled by LDS-DMA that stays in flight ACROSS raw s_barriers and is
+// retired by counted s_waitcnt vmcnt(N), never 0 in the steady state.
+//
+// Wave (wr, wc) of the 2 x 4 wave grid owns rows wr*64..+64 of BOTH A halves and columns wc*32..+32 of
+// BOTH B halves: its 128 x 64 outputs are four 64 x 32 quadrants Q(i, j) = A half i x B half j, one per
+// phase (8 MFMA 32x32x16 each), so every wave reads every half tile and a half tile's last reader is
+// known by phase:
+//   phase 0: read B0 (4 x b128), A0 (8 x b128)   Q00      stage (t+1).B1
+//   phase 1: read B1 (4)                          Q01      stage (t+1).A1
+//   phase 2: read A1 (8, into A0's registers)     Q11      stage (t+2).B0
+//   phase 3: -                                    Q10      stage (t+2).A0
+// A phase is { ds_reads; 2 x global_load_lds; s_waitcnt vmcnt; s_barrier; lgkmcnt(0); MFMAs; s_barrier }.
+// Hazards (waves wr = 1 run one barrier behind waves wr = 0, so that one wave of each SIMD reads LDS
+// while the other issues MFMAs):
+//   RAW  the wait of phase g retires the half tile read in phase g + 1: five staged phases back, so
+//        four half tiles (8 instructions per wave) may stay in flight -> vmcnt(8); the reader has
+//        passed a barrier that the (possibly lagging) issuer reached after its wait;
+//   WAR  a slot last read in phase p is restaged in phase p + 2 or later (B0, A0 read in 0 -> staged
+//        in 2, 3; B1 read in 1 -> staged in 4; A1 read in 2 -> staged in 5): the lagging group has
+//        retired those reads (lgkmcnt(0) of phase p) before the barrier that opens phase p + 2.
+// The last pair of K steps stages nothing new and counts its waits down 6, 4, 2, 0.
+template <int EPI, bool STAGGER>
+__global__ __launch_bounds__(512, 1) void gemm_bf16_nt_8ph_kernel(const GemmBf16Args a) {
+  __shared__ __attribute__((aligned(16))) char lds[8 * 16384];  // slot ((op*2 + d)*2 + h) * 16 KiB: A below 64 KiB, B above
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wid >> 2, wc = wid & 3;
+  // XCD-aware order (blocks b, b + 8, ... share an L2): each XCD gets a contiguous run of tiles, and
+  // runs walk 8-tile-tall column groups so a run covers a squarish patch (8 A panels x 4 B panels)
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int tiles_m = a.tiles_m, tiles_n = nwg / tiles_m;
+  const int width = 8 * tiles_n, first = (wg / width) * 8;
+  const int gsz = min(tiles_m - first, 8);
+  const int ti = first + (wg % width) % gsz, tj = (wg % width) / gsz;
+  const int m0 = ti * 256, n0 = tj * 256;
+  const int nk = a.K / 64;
+
+  // staging: a wave instruction moves 8 rows x 128 B; wave w owns pieces 2w, 2w + 1 of every half tile.
+  // 16-byte chunk c of row r is stored at position c ^ ((r >> 1) & 7) (swizzle on the source address)
+  const int srow = lane >> 3, spos = lane & 7;
+  const unsigned short *sa0, *sa1, *sb0, *sb1;
+  {
+    const int r0 = wid * 16 + srow, r1 = r0 + 8;
+    const int c0 = spos ^ ((r0 >> 1) & 7), c1 = spos ^ ((r1 >> 1) & 7);
+    sa0 = a.A + (int64_t)(m0 + r0) * a.sam + c0 * 8;
+    sa1 = a.A + (int64_t)(m0 + r1) * a.sam + c1 * 8;
+    sb0 = a.B + (int64_t)(n0 + r0) * a.sbn + c0 * 8;
+    sb1 = a.B + (int64_t)(n0 + r1) * a.sbn + c1 * 8;
+  }
+  const int64_t halfA = 128 * a.sam, halfB = 128 * a.sbn;
+  char* const mypiece = lds + wid * 2048;
+#define PTD_STAGE(D, OP, H, KT)                                                                          \
+  do {                                                                                                   \
+    char* slot_ = mypiece + ((((OP) * 2 + (D)) * 2 + (H)) << 14);                                        \
+    const unsigned short* s0_ = ((OP) ? sb0 + (H) * halfB : sa0 + (H) * halfA) + (int64_t)(KT) * 64;     \
+    const unsigned short* s1_ = ((OP) ? sb1 + (H) * halfB : sa1 + (H) * halfA) + (int64_t)(KT) * 64;     \
+    __builtin_amdgcn_global_load_lds((glb_void*)s0_, (lds_void*)slot_, 16, 0, 0);                        \
+    __builtin_amdgcn_global_load_lds((glb_void*)s1_, (lds_void*)(slot_ + 1024), 16, 0, 0);               \
+  } while (0)
+
+  // fragment reads: lane -> row fr of a 32-row block, 8 consecutive k of chunk 2 ks + fh
+  const int fr = lane & 31, fh = lane >> 5, sw = (fr >> 1) & 7;
+  int offA[4], offB[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const int ch = ((2 * ks + fh) ^ sw) << 4;
+    offA[ks] = (wr * 64 + fr) * 128 + ch;
+    offB[ks] = 65536 + (wc * 32 + fr) * 128 + ch;  // ds_read immediates stay below 64 KiB
+  }
+  s16x8 af[2][4], b0[4], b1[4];
+  f32x16 acc[2][2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][mt][r] = 0.f;
+
+#define PTD_READ_A(D, H)                                                                                 \
+  _Pragma("unroll") for (int mt_ = 0; mt_ < 2; ++mt_) _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_) \
+      af[mt_][ks_] = *reinterpret_cast<const s16x8*>(lds + (((D) * 2 + (H)) << 14) + mt_ * 4096 + offA[ks_])
+#define PTD_READ_B(D, H, DST)                                                                            \
+  _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_)                                                     \
+      DST[ks_] = *reinterpret_cast<const s16x8*>(lds + (((D) * 2 + (H)) << 14) + offB[ks_])
+#define PTD_QUAD(I, J, BREG)                                                                             \
+  do {                                                                                                   \
+    __builtin_amdgcn_s_setprio(1);                                                                       \
+    _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_) _Pragma("unroll") for (int mt_ = 0; mt_ < 2; ++mt_) \
+        acc[I][J][mt_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt_][ks_], BREG[ks_], acc[I][J][mt_], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                                       \
+  } while (0)
+#define PTD_SYNC_IN(WAIT)                                                                                \
+  do {                                                                                                   \
+    asm volatile("s_waitcnt vmcnt(" #WAIT ")" ::: "memory");                                             \
+    __builtin_amdgcn_s_barrier();                                                                        \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                   \
+  } while (0)
+#define PTD_SYNC_OUT()                                                                                   \
+  do {                                                                                                   \
+    asm volatile("" ::: "memory");                                                                       \
+    __builtin_amdgcn_s_barrier();                                                                        \
+  } while (0)
+
+  // prologue: K step 0 complete, (1).B0 and (1).A0 in flight
+  PTD_STAGE(0, 1, 0, 0); PTD_STAGE(0, 0, 0, 0); PTD_STAGE(0, 1, 1, 0); PTD_STAGE(0, 0, 1, 0);
+  PTD_STAGE(1, 1, 0, 1); PTD_STAGE(1, 0, 0, 1);
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (STAGGER && wr == 1) __builtin_amdgcn_s_barrier();
+
+  int kt = 0;
+  for (; kt + 2 < nk; kt += 2) {
+    // K step kt (buffer 0)
+    PTD_READ_B(0, 0, b0); PTD_READ_A(0, 0); PTD_STAGE(1, 1, 1, kt + 1); PTD_SYNC_IN(8); PTD_QUAD(0, 0, b0); PTD_SYNC_OUT();
+    PTD_READ_B(0, 1, b1);                   PTD_STAGE(1, 0, 1, kt + 1); PTD_SYNC_IN(8); PTD_QUAD(0, 1, b1); PTD_SYNC_OUT();
+    PTD_READ_A(0, 1);                       PTD_STAGE(0, 1, 0, kt + 2); PTD_SYNC_IN(8); PTD_QUAD(1, 1, b1); PTD_SYNC_OUT();
+                                            PTD_STAGE(0, 0, 0, kt + 2); PTD_SYNC_IN(8); PTD_QUAD(1, 0, b0); PTD_SYNC_OUT();
+    // K step kt + 1 (buffer 1)
+    PTD_READ_B(1, 0, b0); PTD_READ_A(1, 0); PTD_STAGE(0, 1, 1, kt + 2); PTD_SYNC_IN(8); PTD_QUAD(0, 0, b0); PTD_SYNC_OUT();
+    PTD_READ_B(1, 1, b1);                   PTD_STAGE(0, 0, 1, kt + 2); PTD_SYNC_IN(8); PTD_QUAD(0, 1, b1); PTD_SYNC_OUT();
+    PTD_READ_A(1, 1);                       PTD_STAGE(1, 1, 0, kt + 3); PTD_SYNC_IN(8); PTD_QUAD(1, 1, b1); PTD_SYNC_OUT();
+                                            PTD_STAGE(1, 0, 0, kt + 3); PTD_SYNC_IN(8); PTD_QUAD(1, 0, b0); PTD_SYNC_OUT();
+  }
+  {  // last pair: nothing new to stage after (kt + 1).A1; waits count the queue down
+    PTD_READ_B(0, 0, b0); PTD_READ_A(0, 0); PTD_STAGE(1, 1, 1, kt + 1); PTD_SYNC_IN(8); PTD_QUAD(0, 0, b0); PTD_SYNC_OUT();
+    PTD_READ_B(0, 1, b1);                   PTD_STAGE(1, 0, 1, kt + 1); PTD_SYNC_IN(8); PTD_QUAD(0, 1, b1); PTD_SYNC_OUT();
+    PTD_READ_A(0, 1);                                                   PTD_SYNC_IN(6); PTD_QUAD(1, 1, b1); PTD_SYNC_OUT();
+                                                                        PTD_SYNC_IN(4); PTD_QUAD(1, 0, b0); PTD_SYNC_OUT();
+    PTD_READ_B(1, 0, b0); PTD_READ_A(1, 0);                             PTD_SYNC_IN(2); PTD_QUAD(0, 0, b0); PTD_SYNC_OUT();
+    PTD_READ_B(1, 1, b1);                                               PTD_SYNC_IN(0); PTD_QUAD(0, 1, b1); PTD_SYNC_OUT();
+    PTD_READ_A(1, 1);                                                   PTD_SYNC_IN(0); PTD_QUAD(1, 1, b1); PTD_SYNC_OUT();
+                                                                        PTD_SYNC_IN(0); PTD_QUAD(1, 0, b0); PTD_SYNC_OUT();
+  }
+  if (STAGGER && wr == 0) __builtin_amdgcn_s_barrier();
+#undef PTD_STAGE
+#undef PTD_READ_A
+#undef PTD_READ_B
+#undef PTD_QUAD
+#undef PTD_SYNC_IN
+#undef PTD_SYNC_OUT
+
+  // epilogue: the four 128 x 128 quadrants of the tile leave through an LDS image as 16-byte row pieces
+  constexpr int ES = (EPI == EPI_STORE_BF16) ? 2 : 4;
+  constexpr int CP = 128 * ES + 16;
+  static_assert(128 * (128 * 4 + 16) <= 8 * 16384, "C quadrant must fit the staging buffers");
+  constexpr int CHUNKS = 128 * ES / 16;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      if (i + j) __syncthreads();  // the previous quadrant's image has been read
+      const int lc = wc * 32 + (lane & 31);
+      const float bv = a.bias ? bf16_to_f32(a.bias[n0 + j * 128 + lc]) : 0.f;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int lr = wr * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          const float o = a.alpha * acc[i][j][mt][r] + bv;
+          if (EPI == EPI_STORE_BF16) *reinterpret_cast<unsigned short*>(lds + lr * CP + lc * 2) = f32_to_bf16(o);
+          else *reinterpret_cast<float*>(lds + lr * CP + lc * 4) = o;
+        }
+      __syncthreads();
+#pragma unroll
+      for (int p = 0; p < 128 * CHUNKS / 512; ++p) {
+        const int q = tid + 512 * p;
+        const int lr = q / CHUNKS, ch = q % CHUNKS;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(lds + lr * CP + ch * 16);
+        char* dst = reinterpret_cast<char*>(a.C) + ((int64_t)(m0 + i * 128 + lr) * a.ldc + n0 + j * 128) * ES + ch * 16;
+        *reinterpret_cast<f32x4*>(dst) = v;
+      }
+    }
+}
+
 // ---- short-K product C[M,N] = A[M,K] B[N,K]^T, K <= 512 (the second product of the decomposed
 // forward, K = rank).  With 128 x 128 tiles such a product re-stages both operands for every output
 // tile and never fills its pipeline (4 K-steps): it runs at the global->LDS staging rate (82 us for
@@ -529,6 +712,21 @@ int gemm_bf16(const unsigned short* A, int64_t sam, int64_t sak, const unsigned 
     return PTD_OK;
   }
   const bool c_vec = aligned16(C) && (ldc * (c_bf16 ? 2 : 4)) % 16 == 0;  // 16-byte row-contiguous output stores
+  static const int mode_8ph = getenv("PTD_GEMM_8PH") ? atoi(getenv("PTD_GEMM_8PH")) : 2;  // 0 off, 1 lockstep, 2 staggered
+  if (!no_glds && mode_8ph && akc && bkc && a.vecA && a.vecB && c_vec && M % 256 == 0 && N % 256 == 0 && K % 128 == 0 &&
+      K >= 256 && (M / 256) * (N / 256) >= 192) {
+    a.tiles_m = (int)(M / 256);
+    dim3 g8((unsigned)((M / 256) * (N / 256)), 1);
+    if (mode_8ph == 1) {
+      if (c_bf16) hipLaunchKernelGGL((gemm_bf16_nt_8ph_kernel<EPI_STORE_BF16, false>), g8, dim3(512), 0, st, a);
+      else hipLaunchKernelGGL((gemm_bf16_nt_8ph_kernel<EPI_STORE_F32, false>), g8, dim3(512), 0, st, a);
+    } else {
+      if (c_bf16) hipLaunchKernelGGL((gemm_bf16_nt_8ph_kernel<EPI_STORE_BF16, true>), g8, dim3(512), 0, st, a);
+      else hipLaunchKernelGGL((gemm_bf16_nt_8ph_kernel<EPI_STORE_F32, true>), g8, dim3(512), 0, st, a);
+    }
+    PTD_CHECK_LAUNCH("gemm_bf16 (256x256)");
+    return PTD_OK;
+  }
   if (!no_glds && akc && bkc && a.vecA && a.vecB && c_vec && M % BM == 0 && N % BN == 0 && K % BK == 0 && K >= BK) {
     if (c_bf16) hipLaunchKernelGGL((gemm_bf16_nt_glds_kernel<EPI_STORE_BF16>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((gemm_bf16_nt_glds_kernel<EPI_STORE_F32>), grid, dim3(256), 0, st, a);

@@ -350,6 +350,32 @@ def test_gemm_bf16_short_k_persistent_path_exact(ops):
     assert torch.equal(y, (h @ b1.float().T).to(torch.bfloat16).float())
 
 
+def test_gemm_bf16_256_tile_deep_pipeline_exact_and_repeatable(ops):
+    """M, N multiples of 256, K of 128 and >= 192 tiles: the 256 x 256 / 8-wave kernel whose LDS-DMA
+    stays in flight across raw barriers (counted vmcnt).  Exact integer products over whole tiles catch a
+    half tile read before it landed or restaged before its last read; repeats screen for races that
+    only show under a different arrival order.  The reference is the f32 product of the same integers."""
+    g = torch.Generator().manual_seed(9)
+    for (M, N, K) in [(4096, 4096, 256), (3584, 4096, 384), (4096, 3584, 1024), (16384, 1024, 4096), (4096, 4096, 4096)]:
+        a = torch.randint(-2, 3, (M, K), generator=g).to(torch.bfloat16)
+        b = torch.randint(-2, 3, (N, K), generator=g).to(torch.bfloat16)
+        bias = torch.randint(-3, 4, (N,), generator=g).to(torch.bfloat16)
+        ad, bd, biasd = a.to(DEV), b.to(DEV), bias.to(DEV)
+        ref = (ad.float() @ bd.float().T)  # exact: |sum| <= 4 K < 2^24
+        got = ops.matmul(ad, bd.T, bias=biasd, out_dtype=torch.float32)
+        assert torch.equal(got, ref + biasd.float()), (M, N, K)
+        want16 = ref.to(torch.bfloat16)
+        for rep in range(6):
+            got16 = ops.matmul(ad, bd.T)
+            assert torch.equal(got16, want16), (M, N, K, rep)
+    # operands that are column slices of wider matrices (row pitch != K)
+    big = torch.randint(-2, 3, (4096, 512 + 256), generator=g).to(torch.bfloat16).to(DEV)
+    w = torch.randint(-2, 3, (4096, 512 + 256), generator=g).to(torch.bfloat16).to(DEV)
+    x_v, w_v = big[:, 256:], w[:, :512]
+    got = ops.matmul(x_v, w_v.T)
+    assert torch.equal(got.float(), (x_v.float() @ w_v.float().T).to(torch.bfloat16).float())
+
+
 def test_gemm_f32_exact_integers(ops):
     g = torch.Generator().manual_seed(2)
     for layout in LAYOUTS:
