@@ -237,9 +237,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmBf16Args a)
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_nt_glds_kernel(const GemmBf16Args a) {
-  __shared__ __attribute__((aligned(16))) char lds[2 * 2 * 16384 + 2048];
+// NBUF = 2: one barrier per K step that also drains the DMA (two workgroups per CU overlap each other).
+// NBUF = 4: for grids of at most one workgroup per CU (skinny outputs such as x A^T with N = rank 256),
+// where nothing else hides the staging latency: three K steps stay in flight across raw barriers and a
+// counted vmcnt retires only the step about to be read.
+template <int EPI, int NBUF>
+__global__ __launch_bounds__(256, NBUF == 2 ? 2 : 1) void gemm_bf16_nt_glds_kernel(const GemmBf16Args a) {
+  __shared__ __attribute__((aligned(16))) char lds[NBUF * 2 * 16384 + (NBUF == 2 ? 2048 : 0)];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid >> 1, wn = wid & 1;
@@ -248,7 +252,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_glds_kernel(const GemmBf1
   const int nwg = gridDim.x, bid = blockIdx.x;
   const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
   const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  const int ti = wg % a.tiles_m, tj = wg / a.tiles_m;
+  // runs walk 8-tile-tall column groups: an XCD's run covers a squarish patch, and for a skinny output
+  // (N = rank: two tile columns) both tiles of an A panel sit on the same L2, so x leaves HBM once
+  const int tiles_n = nwg / a.tiles_m, width = 8 * tiles_n, first = (wg / width) * 8;
+  const int gsz = min(a.tiles_m - first, 8);
+  const int ti = first + (wg % width) % gsz, tj = (wg % width) / gsz;
   const int m0 = ti * BM, n0 = tj * BN;
   const int nk = a.K / BK;
   const unsigned short* Ag = a.A + (int64_t)m0 * a.sam;
@@ -279,12 +287,30 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_glds_kernel(const GemmBf1
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  stage(0, 0);
-  __syncthreads();
   const int fr = lane & 31, fh = lane >> 5;
+  if (NBUF == 2) {
+    stage(0, 0);
+    __syncthreads();
+  } else {
+    stage(0, 0);
+    if (1 < nk) stage(1, 1);
+    if (2 < nk) stage(2, 2);
+  }
   for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+    const int cur = kt & (NBUF - 1);
+    if (NBUF == 2) {
+      if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+    } else {
+      // retire this wave's pieces of step kt (8 DMA instructions per step), then the barrier: every
+      // piece of step kt has landed, and every wave has finished reading step kt - 1, whose buffer
+      // the stage below refills
+      if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (kt + 3 < nk) stage((kt + 3) & 3, kt + 3);
+    }
     const char* As = lds + cur * 32768;
     const char* Bs = As + 16384;
 #pragma unroll
@@ -302,15 +328,16 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_nt_glds_kernel(const GemmBf1
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[0], acc[1][0], 0, 0, 0);
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[1], acc[1][1], 0, 0, 0);
     }
-    __syncthreads();  // retires this step's LDS-DMA (vmcnt(0)) and the reads of buffer `cur`
+    if (NBUF == 2) __syncthreads();  // retires this step's LDS-DMA (vmcnt(0)) and the reads of buffer `cur`
   }
+  if (NBUF != 2) __syncthreads();    // the last reads, before the epilogue reuses the image
 
   // Epilogue through LDS (the staging buffers are free after the loop's last barrier): the MFMA
   // result layout gives each lane single elements of 64 different rows, which as global stores are
   // 2- or 4-byte scatters; staged as a [128][128] tile they leave as 16-byte row-contiguous stores.
   constexpr int ES = (EPI == EPI_STORE_BF16) ? 2 : 4;       // bytes per output element
   constexpr int CP = 128 * ES + 16;                          // LDS pitch of a tile row (+16 B: rows rotate banks)
-  static_assert(128 * (128 * 4 + 16) <= 2 * 2 * 16384 + 2048, "C tile must fit the staging buffers");
+  static_assert(128 * (128 * 4 + 16) <= sizeof(lds), "C tile must fit the staging buffers");
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -728,8 +755,12 @@ int gemm_bf16(const unsigned short* A, int64_t sam, int64_t sak, const unsigned 
     return PTD_OK;
   }
   if (!no_glds && akc && bkc && a.vecA && a.vecB && c_vec && M % BM == 0 && N % BN == 0 && K % BK == 0 && K >= BK) {
-    if (c_bf16) hipLaunchKernelGGL((gemm_bf16_nt_glds_kernel<EPI_STORE_BF16>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((gemm_bf16_nt_glds_kernel<EPI_STORE_F32>), grid, dim3(256), 0, st, a);
+    static const bool no_deep = getenv("PTD_GEMM_NO_DEEP") != nullptr;
+    if (grid.x <= 256 && K >= 4 * BK && !no_deep) {  // at most one workgroup per CU: deep prefetch
+      if (c_bf16) hipLaunchKernelGGL((gemm_bf16_nt_glds_kernel<EPI_STORE_BF16, 4>), grid, dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((gemm_bf16_nt_glds_kernel<EPI_STORE_F32, 4>), grid, dim3(256), 0, st, a);
+    } else if (c_bf16) hipLaunchKernelGGL((gemm_bf16_nt_glds_kernel<EPI_STORE_BF16, 2>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((gemm_bf16_nt_glds_kernel<EPI_STORE_F32, 2>), grid, dim3(256), 0, st, a);
   } else if (c_bf16) launch_bf16<EPI_STORE_BF16>(a, akc, bkc, grid, st);
   else launch_bf16<EPI_STORE_F32>(a, akc, bkc, grid, st);
   PTD_CHECK_LAUNCH("gemm_bf16");

@@ -316,7 +316,9 @@ def test_gemm_bf16_direct_to_lds_path_exact(ops):
     """Tile-aligned nn.Linear layout takes the LDS-DMA kernel with the XOR-swizzled image: exact
     integer products catch any mistake in the source / read swizzle pair or the XCD tile remap."""
     g = torch.Generator().manual_seed(7)
-    for (M, N, K) in [(128, 128, 64), (256, 384, 192), (1024, 640, 512)]:
+    # K >= 256 on a grid of <= 256 tiles takes the 4-buffer variant (three K steps in flight, counted vmcnt)
+    for (M, N, K) in [(128, 128, 64), (256, 384, 192), (1024, 640, 512), (256, 256, 256), (384, 128, 320), (128, 256, 384),
+                      (256, 128, 448), (2048, 2048, 4096), (16384, 256, 4096)]:
         a = torch.randint(-4, 5, (M, K), generator=g).to(torch.bfloat16)
         b = torch.randint(-4, 5, (N, K), generator=g).to(torch.bfloat16)
         bias = torch.randint(-3, 4, (N,), generator=g).to(torch.bfloat16)
