@@ -54,13 +54,16 @@ struct GemmBf16Args {
   int vecA, vecB;
 };
 
-__device__ __forceinline__ unsigned short f32_to_bf16(float f) {
-  // round to nearest even; NaN stays NaN (quiet bit forced)
-  unsigned int u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (unsigned short)(u >> 16);
+// f32 -> bf16, round to nearest even, NaN stays NaN: gfx950's v_cvt_pk_bf16_f32 (one VALU instruction
+// per pair).  The bit-twiddling form costs ~12 VALU per element -- on a short-K product that is more
+// cycles than the MFMAs that produced the value (measured: 2,550 of a step's 6,200 cycles).
+typedef __bf16 hw_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned int pack2_bf16(float lo, float hi) {
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, hw_bf16x2));
 }
+__device__ __forceinline__ unsigned short f32_to_bf16(float f) { return (unsigned short)(pack2_bf16(f, 0.f) & 0xffffu); }
 
 // Fetch this thread's 4 x (8 bf16) of a 128 (r) x 64 (k) operand tile.
 //   KC:  element (r, k) at P[r * s + k];  thread -> r = idx >> 3, k = 8 * (idx & 7)
@@ -323,18 +326,20 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 1) void gemm_bf16_nt_glds_kern
         af[i] = *reinterpret_cast<const s16x8*>(As + ra * 128 + ((c ^ ((ra >> 1) & 7)) << 4));
         bf[i] = *reinterpret_cast<const s16x8*>(Bs + rb * 128 + ((c ^ ((rb >> 1) & 7)) << 4));
       }
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[0], acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[1], acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[0], acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[1], acc[1][1], 0, 0, 0);
+      // B fragment first: the accumulator is the transposed block (see the epilogue)
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[0], af[0], acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[1], af[0], acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[0], af[1], acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[1], af[1], acc[1][1], 0, 0, 0);
     }
     if (NBUF == 2) __syncthreads();  // retires this step's LDS-DMA (vmcnt(0)) and the reads of buffer `cur`
   }
   if (NBUF != 2) __syncthreads();    // the last reads, before the epilogue reuses the image
 
-  // Epilogue through LDS (the staging buffers are free after the loop's last barrier): the MFMA
-  // result layout gives each lane single elements of 64 different rows, which as global stores are
-  // 2- or 4-byte scatters; staged as a [128][128] tile they leave as 16-byte row-contiguous stores.
+  // Epilogue through LDS (the staging buffers are free after the loop's last barrier).  With the B
+  // fragment as first MFMA operand lane l holds output row (l & 31) and, per group of four registers,
+  // four consecutive output columns: one 8-byte (bf16, v_cvt_pk_bf16_f32) or 16-byte (f32) LDS write per
+  // group; staged as a [128][128] tile they leave as 16-byte row-contiguous global stores.
   constexpr int ES = (EPI == EPI_STORE_BF16) ? 2 : 4;       // bytes per output element
   constexpr int CP = 128 * ES + 16;                          // LDS pitch of a tile row (+16 B: rows rotate banks)
   static_assert(128 * (128 * 4 + 16) <= sizeof(lds), "C tile must fit the staging buffers");
@@ -342,14 +347,22 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 1) void gemm_bf16_nt_glds_kern
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int lc = wn * 64 + j * 32 + (lane & 31);
-      const float bv = a.bias ? bf16_to_f32(a.bias[n0 + lc]) : 0.f;
+      const int lr = wm * 64 + i * 32 + (lane & 31);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int lr = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const float o = a.alpha * acc[i][j][r] + bv;
-        if (EPI == EPI_STORE_BF16) *reinterpret_cast<unsigned short*>(lds + lr * CP + lc * 2) = f32_to_bf16(o);
-        else *reinterpret_cast<float*>(lds + lr * CP + lc * 4) = o;
+      for (int g = 0; g < 4; ++g) {
+        const int lc = wn * 64 + j * 32 + 8 * g + 4 * (lane >> 5);
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          o[e] = a.alpha * acc[i][j][4 * g + e] + (a.bias ? bf16_to_f32(a.bias[n0 + lc + e]) : 0.f);
+        if (EPI == EPI_STORE_BF16) {
+          typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+          const u32x2 pk = {pack2_bf16(o[0], o[1]), pack2_bf16(o[2], o[3])};
+          *reinterpret_cast<u32x2*>(lds + lr * CP + lc * 2) = pk;
+        } else {
+          const f32x4 v = {o[0], o[1], o[2], o[3]};
+          *reinterpret_cast<f32x4*>(lds + lr * CP + lc * 4) = v;
+        }
       }
     }
   __syncthreads();
@@ -461,7 +474,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_8ph_kernel(const GemmBf16
   do {                                                                                                   \
     __builtin_amdgcn_s_setprio(1);                                                                       \
     _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_) _Pragma("unroll") for (int mt_ = 0; mt_ < 2; ++mt_) \
-        acc[I][J][mt_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt_][ks_], BREG[ks_], acc[I][J][mt_], 0, 0, 0); \
+        acc[I][J][mt_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BREG[ks_], af[mt_][ks_], acc[I][J][mt_], 0, 0, 0); \
     __builtin_amdgcn_s_setprio(0);                                                                       \
   } while (0)
 #define PTD_SYNC_IN(WAIT)                                                                                \
@@ -514,34 +527,56 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_8ph_kernel(const GemmBf16
 #undef PTD_SYNC_IN
 #undef PTD_SYNC_OUT
 
-  // epilogue: the four 128 x 128 quadrants of the tile leave through an LDS image as 16-byte row pieces
+  // epilogue.  The MFMAs above take the B fragment as their first operand, so an accumulator tile is
+  // the TRANSPOSE of the output block: lane l holds output row (l & 31) and, per group of four
+  // registers, four CONSECUTIVE output columns -- one 8-byte (bf16) or 16-byte (f32) LDS write instead
+  // of four scalar ones.  The tile leaves through an LDS image, 128 rows x (256 bf16 | 128 f32) columns
+  // per pass, as 16-byte row-contiguous global stores.
   constexpr int ES = (EPI == EPI_STORE_BF16) ? 2 : 4;
-  constexpr int CP = 128 * ES + 16;
-  static_assert(128 * (128 * 4 + 16) <= 8 * 16384, "C quadrant must fit the staging buffers");
-  constexpr int CHUNKS = 128 * ES / 16;
+  constexpr int JW = (EPI == EPI_STORE_BF16) ? 2 : 1;       // column quadrants per pass
+  constexpr int CP = JW * 128 * ES + 16;                     // image pitch (+16 B: rows rotate banks)
+  static_assert(128 * CP <= 8 * 16384, "the C image must fit the staging buffers");
+  constexpr int CHUNKS = JW * 128 * ES / 16;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      if (i + j) __syncthreads();  // the previous quadrant's image has been read
-      const int lc = wc * 32 + (lane & 31);
-      const float bv = a.bias ? bf16_to_f32(a.bias[n0 + j * 128 + lc]) : 0.f;
+    for (int jp = 0; jp < 2 / JW; ++jp) {
+      if (i + jp) __syncthreads();  // the previous pass's image has been read
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+      for (int jj = 0; jj < JW; ++jj) {
+        const int j = jp * JW + jj;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int lr = wr * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          const float o = a.alpha * acc[i][j][mt][r] + bv;
-          if (EPI == EPI_STORE_BF16) *reinterpret_cast<unsigned short*>(lds + lr * CP + lc * 2) = f32_to_bf16(o);
-          else *reinterpret_cast<float*>(lds + lr * CP + lc * 4) = o;
+        for (int mt = 0; mt < 2; ++mt) {
+          const int lr = wr * 64 + mt * 32 + (lane & 31);
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int lc = wc * 32 + 8 * g + 4 * (lane >> 5);  // first of 4 consecutive columns
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float bv = a.bias ? bf16_to_f32(a.bias[n0 + j * 128 + lc + e]) : 0.f;
+              o[e] = a.alpha * acc[i][j][mt][4 * g + e] + bv;
+            }
+            char* dst = lds + lr * CP + (jj * 128 + lc) * ES;
+            if (EPI == EPI_STORE_BF16) {
+              typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+              const u32x2 pk = {pack2_bf16(o[0], o[1]), pack2_bf16(o[2], o[3])};
+              const s16x4 v = __builtin_bit_cast(s16x4, pk);
+              *reinterpret_cast<s16x4*>(dst) = v;
+            } else {
+              f32x4 v = {o[0], o[1], o[2], o[3]};
+              *reinterpret_cast<f32x4*>(dst) = v;
+            }
+          }
         }
+      }
       __syncthreads();
 #pragma unroll
       for (int p = 0; p < 128 * CHUNKS / 512; ++p) {
         const int q = tid + 512 * p;
         const int lr = q / CHUNKS, ch = q % CHUNKS;
         const f32x4 v = *reinterpret_cast<const f32x4*>(lds + lr * CP + ch * 16);
-        char* dst = reinterpret_cast<char*>(a.C) + ((int64_t)(m0 + i * 128 + lr) * a.ldc + n0 + j * 128) * ES + ch * 16;
+        char* dst = reinterpret_cast<char*>(a.C) + ((int64_t)(m0 + i * 128 + lr) * a.ldc + n0 + jp * JW * 128) * ES + ch * 16;
         *reinterpret_cast<f32x4*>(dst) = v;
       }
     }
@@ -678,6 +713,330 @@ __global__ __launch_bounds__(256, (shortk_lds_bytes(KC, NB, EPI) <= 80 * 1024 ? 
   if (have_prev) store(prev, prev_n0);
 }
 
+// K <= 256 variant with the roles turned round: the workgroup keeps a 128-COLUMN panel of B (the factor
+// matrix) in registers and is persistent over M, streaming 64-row tiles of A through the LDS image.
+// A wave owns 32 rows x 64 columns of each step (2 x 2 wave grid):
+//  * one A fragment read from LDS feeds two MFMAs (in the kernel above every MFMA needs its own
+//    ds_read_b128);
+//  * its output rows are 128 bytes (bf16) wide: every global store instruction writes whole 128-byte
+//    lines, 8 rows x 128 B.  Stores of 64-byte half lines (a 32-column block) held the kernel above at
+//    ~2.3 TB/s of output however the LDS side was arranged.
+// MFMA operands are swapped (B fragment first): the accumulator is the transposed block, lane l holds
+// output row l & 31 and four consecutive columns per register group, which go to the wave's private
+// patch (32 rows x 128 B, XOR-swizzled instead of padded so that two workgroups fit a CU) as one
+// 8- or 16-byte write.  Blocks of one XCD share row ranges, so a range of A is read into one L2.
+template <int KC, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_shortk2_kernel(const GemmBf16Args a, const int msplit,
+                                                                   const int rows_per_split) {
+  constexpr int SUB = 64 * 128;               // bytes of one [64 rows][64 k] sub-tile
+  constexpr int BUF = KC * SUB;               // one A buffer: 64 rows, all of K
+  constexpr int ES = (EPI == EPI_STORE_BF16) ? 2 : 4;
+  static_assert(2 * BUF + 4 * 4096 <= 80 * 1024, "two workgroups per CU");
+  __shared__ __attribute__((aligned(16))) char lds[2 * BUF + 4 * 4096];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wrb = wid >> 1, wc = wid & 1;
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int npanel = nwg / msplit;
+  const int panel = wg % npanel, split = wg / npanel;
+  const int n0 = panel * 128;
+  const int mbeg = split * rows_per_split, mend = min(a.M, mbeg + rows_per_split);
+  const int fr = lane & 31, fh = lane >> 5;
+  const int srow = lane >> 3, spos = lane & 7;
+
+  // this wave's 64 columns of B as fragments, through the LDS image 64 panel rows at a time
+  s16x8 bfr[2][KC * 4];
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+#pragma unroll
+    for (int p = 0; p < KC * 2; ++p) {
+      const int q = wid + 4 * p;               // piece q: sub-tile q >> 3 (64 k), rows (q & 7) * 8 ...
+      const int sub = q >> 3, r0 = (q & 7) * 8;
+      const int r = r0 + srow;
+      const int c = spos ^ ((r >> 1) & 7);
+      const unsigned short* sb = a.B + (int64_t)(n0 + half * 64 + r) * a.sbn + sub * 64 + c * 8;
+      __builtin_amdgcn_global_load_lds((glb_void*)sb, (lds_void*)(lds + sub * 8192 + r0 * 128), 16, 0, 0);
+    }
+    __syncthreads();
+    if (wc == half) {
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        const int rr = nb * 32 + fr;
+#pragma unroll
+        for (int kk = 0; kk < KC * 4; ++kk) {
+          const int sub = kk >> 2, c = ((kk & 3) << 1) + fh;
+          bfr[nb][kk] = *reinterpret_cast<const s16x8*>(lds + sub * 8192 + rr * 128 + ((c ^ ((rr >> 1) & 7)) << 4));
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  auto stage = [&](int buf, int m) {
+    char* As = lds + buf * BUF;
+#pragma unroll
+    for (int p = 0; p < KC * 2; ++p) {
+      const int q = wid + 4 * p;
+      const int sub = q >> 3, r0 = (q & 7) * 8;
+      const int r = r0 + srow;
+      const int c = spos ^ ((r >> 1) & 7);
+      const unsigned short* sa = a.A + (int64_t)(m + r) * a.sam + sub * 64 + c * 8;
+      __builtin_amdgcn_global_load_lds((glb_void*)sa, (lds_void*)(As + sub * SUB + r0 * 128), 16, 0, 0);
+    }
+  };
+
+  char* patch = lds + 2 * BUF + wid * 4096;
+  const int psw = (fr >> 1) & 7;               // write-side swizzle of patch row fr
+  auto flush = [&](int m, int cb) {            // patch rows -> 128-byte row pieces at columns cb ...
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int q = lane + 64 * p;
+      const int lr = q >> 3, ch = q & 7;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(patch + lr * 128 + ((ch ^ ((lr >> 1) & 7)) << 4));
+      char* dst = reinterpret_cast<char*>(a.C) + ((int64_t)(m + wrb * 32 + lr) * a.ldc + cb) * ES + ch * 16;
+      *reinterpret_cast<f32x4*>(dst) = v;
+    }
+  };
+  // bias of this lane's 32 output columns, packed bf16 (zeros without a bias): loaded once, so that no
+  // ordinary load sits among the DMA and the stores of the loop (it would be waited for with vmcnt(0))
+  const int cb = n0 + wc * 64;                 // first output column of this wave's block
+  s16x4 bq[2][4];
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bq[nb][g][e] = 0;
+  if (a.bias) {
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bq[nb][g][e] = (short)a.bias[cb + nb * 32 + 8 * g + 4 * fh + e];
+  }
+  auto store = [&](const f32x16 (&acc)[2], int m) {
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          o[e] = a.alpha * acc[nb][4 * g + e] + bf16_to_f32((unsigned short)bq[nb][g][e]);
+        if (EPI == EPI_STORE_BF16) {
+          typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+          const u32x2 pk = {pack2_bf16(o[0], o[1]), pack2_bf16(o[2], o[3])};
+          const s16x4 v = __builtin_bit_cast(s16x4, pk);
+          *reinterpret_cast<s16x4*>(patch + fr * 128 + (((nb * 4 + g) ^ psw) << 4) + 8 * fh) = v;
+        } else {
+          f32x4 v = {o[0], o[1], o[2], o[3]};
+          *reinterpret_cast<f32x4*>(patch + fr * 128 + (((2 * g + fh) ^ psw) << 4)) = v;
+        }
+      }
+      if (EPI != EPI_STORE_BF16) flush(m, cb + nb * 32);   // f32: a 32-column block is a 128-byte row
+    }
+    if (EPI == EPI_STORE_BF16) flush(m, cb);
+  };
+
+  stage(0, mbeg);
+  int buf = 0;
+  for (int m = mbeg; m < mend; m += 64, buf ^= 1) {
+    // tile m has landed: its DMA was issued BEFORE the previous step's stores, and vmcnt retires in issue
+    // order (loads, stores and LDS-DMA together), so leaving that step's stores outstanding waits for the
+    // DMA and not for their acknowledgement (~3 us under load, several times a step's MFMAs)
+    if (m == mbeg) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (EPI == EPI_STORE_BF16) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // every piece of tile m is in LDS; every wave is done reading the other buffer
+    asm volatile("" ::: "memory");
+    if (m + 64 < mend) stage(buf ^ 1, m + 64);
+    const char* As = lds + buf * BUF;
+    f32x16 acc[2];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+    const int ra = wrb * 32 + fr;
+#pragma unroll
+    for (int kk = 0; kk < KC * 4; ++kk) {
+      const int sub = kk >> 2, c = ((kk & 3) << 1) + fh;
+      const s16x8 af = *reinterpret_cast<const s16x8*>(As + sub * SUB + ra * 128 + ((c ^ ((ra >> 1) & 7)) << 4));
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[0][kk], af, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[1][kk], af, acc[1], 0, 0, 0);
+    }
+    store(acc, m);
+  }
+}
+
+// The same product with ONE 8-wave workgroup per CU (2 x 4 wave grid): a 256-column panel of B in
+// registers, 64-row tiles of A through FOUR LDS buffers.  Measured on the 4-wave form above: with the
+// MFMAs and the stores removed it still takes 2/3 of its time -- it runs at the L2 -> LDS fill rate a CU
+// reaches with 2 x 32 KiB in flight (~33 GB/s per CU).  Here every DMA byte feeds twice the columns and
+// three tiles (96 KiB) are in flight.  One raw barrier per step; vmcnt retires in issue order (loads,
+// stores, LDS-DMA alike), so the wait before step k leaves outstanding exactly what was issued after
+// tile k's DMA: the stores of the last min(k, 3) steps (S each) and the DMA of up to two later tiles (G
+// each) -- the stores get three steps to be acknowledged instead of stalling the barrier.
+template <int KC, int EPI>
+__global__ __launch_bounds__(512, 1) void gemm_bf16_shortk3_kernel(const GemmBf16Args a, const int msplit,
+                                                                   const int rows_per_split) {
+  constexpr int SUB = 64 * 128;               // bytes of one [64 rows][64 k] sub-tile
+  constexpr int BUF = KC * SUB;               // one A buffer: 64 rows, all of K
+  constexpr int ES = (EPI == EPI_STORE_BF16) ? 2 : 4;
+  static_assert(4 * BUF + 8 * 4096 <= 160 * 1024, "LDS of one CU");
+  __shared__ __attribute__((aligned(16))) char lds[4 * BUF + 8 * 4096];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wrb = wid >> 2, wc = wid & 3;
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int npanel = nwg / msplit;
+  const int panel = wg % npanel, split = wg / npanel;
+  const int n0 = panel * 256;
+  const int mbeg = split * rows_per_split, mend = min(a.M, mbeg + rows_per_split);
+  const int nsteps = (mend - mbeg) / 64;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int srow = lane >> 3, spos = lane & 7;
+
+  // this wave's 64 columns of B as fragments, through the LDS image 64 panel rows at a time
+  s16x8 bfr[2][KC * 4];
+#pragma unroll
+  for (int chunk = 0; chunk < 4; ++chunk) {
+#pragma unroll
+    for (int p = 0; p < KC; ++p) {
+      const int q = wid + 8 * p;               // piece q: sub-tile q >> 3 (64 k), rows (q & 7) * 8 ...
+      const int sub = q >> 3, r0 = (q & 7) * 8;
+      const int r = r0 + srow;
+      const int c = spos ^ ((r >> 1) & 7);
+      const unsigned short* sb = a.B + (int64_t)(n0 + chunk * 64 + r) * a.sbn + sub * 64 + c * 8;
+      __builtin_amdgcn_global_load_lds((glb_void*)sb, (lds_void*)(lds + sub * 8192 + r0 * 128), 16, 0, 0);
+    }
+    __syncthreads();
+    if (wc == chunk) {
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        const int rr = nb * 32 + fr;
+#pragma unroll
+        for (int kk = 0; kk < KC * 4; ++kk) {
+          const int sub = kk >> 2, c = ((kk & 3) << 1) + fh;
+          bfr[nb][kk] = *reinterpret_cast<const s16x8*>(lds + sub * 8192 + rr * 128 + ((c ^ ((rr >> 1) & 7)) << 4));
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  auto stage = [&](int buf, int m) {           // G = KC DMA instructions per lane
+    char* As = lds + buf * BUF;
+#pragma unroll
+    for (int p = 0; p < KC; ++p) {
+      const int q = wid + 8 * p;
+      const int sub = q >> 3, r0 = (q & 7) * 8;
+      const int r = r0 + srow;
+      const int c = spos ^ ((r >> 1) & 7);
+      const unsigned short* sa = a.A + (int64_t)(m + r) * a.sam + sub * 64 + c * 8;
+      __builtin_amdgcn_global_load_lds((glb_void*)sa, (lds_void*)(As + sub * SUB + r0 * 128), 16, 0, 0);
+    }
+  };
+
+  char* patch = lds + 4 * BUF + wid * 4096;
+  const int psw = (fr >> 1) & 7;
+  const int cb = n0 + wc * 64;                 // first output column of this wave's block
+  auto flush = [&](int m, int c0) {            // patch rows -> 128-byte row pieces at columns c0 ...
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int q = lane + 64 * p;
+      const int lr = q >> 3, ch = q & 7;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(patch + lr * 128 + ((ch ^ ((lr >> 1) & 7)) << 4));
+      char* dst = reinterpret_cast<char*>(a.C) + ((int64_t)(m + wrb * 32 + lr) * a.ldc + c0) * ES + ch * 16;
+      *reinterpret_cast<f32x4*>(dst) = v;
+    }
+  };
+  s16x4 bq[2][4];                              // bias of this lane's 32 columns (see the 4-wave form)
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bq[nb][g][e] = 0;
+  if (a.bias) {
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bq[nb][g][e] = (short)a.bias[cb + nb * 32 + 8 * g + 4 * fh + e];
+  }
+  auto store = [&](const f32x16 (&acc)[2], int m) {   // S = 4 (bf16) or 8 (f32) store instructions per lane
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          o[e] = a.alpha * acc[nb][4 * g + e] + bf16_to_f32((unsigned short)bq[nb][g][e]);
+        if (EPI == EPI_STORE_BF16) {
+          typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+          const u32x2 pk = {pack2_bf16(o[0], o[1]), pack2_bf16(o[2], o[3])};
+          const s16x4 v = __builtin_bit_cast(s16x4, pk);
+          *reinterpret_cast<s16x4*>(patch + fr * 128 + (((nb * 4 + g) ^ psw) << 4) + 8 * fh) = v;
+        } else {
+          f32x4 v = {o[0], o[1], o[2], o[3]};
+          *reinterpret_cast<f32x4*>(patch + fr * 128 + (((2 * g + fh) ^ psw) << 4)) = v;
+        }
+      }
+      if (EPI != EPI_STORE_BF16) flush(m, cb + nb * 32);
+    }
+    if (EPI == EPI_STORE_BF16) flush(m, cb);
+  };
+
+  // the B-panel preload has drained (its last __syncthreads waited vmcnt(0))
+  constexpr int G4 = KC;                       // DMA instructions per tile, S4 = stores per step, in units of ...
+  constexpr int S1 = (EPI == EPI_STORE_BF16) ? 4 : 8;
+  stage(0, mbeg);
+  if (nsteps > 1) stage(1, mbeg + 64);
+  if (nsteps > 2) stage(2, mbeg + 128);
+  for (int k = 0; k < nsteps; ++k) {
+    const int m = mbeg + k * 64;
+    // outstanding after tile k's DMA: stores of min(k, 3) steps, DMA of the tiles k + 1, k + 2 that exist
+    const int later = (k + 1 < nsteps) + (k + 2 < nsteps);
+    const int cnt = S1 * min(k, 3) + G4 * later;
+#define PTD_WAIT_CASE(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+    switch (cnt) {
+      PTD_WAIT_CASE(0) PTD_WAIT_CASE(1) PTD_WAIT_CASE(2) PTD_WAIT_CASE(3) PTD_WAIT_CASE(4) PTD_WAIT_CASE(5)
+      PTD_WAIT_CASE(6) PTD_WAIT_CASE(7) PTD_WAIT_CASE(8) PTD_WAIT_CASE(9) PTD_WAIT_CASE(10) PTD_WAIT_CASE(11)
+      PTD_WAIT_CASE(12) PTD_WAIT_CASE(13) PTD_WAIT_CASE(14) PTD_WAIT_CASE(15) PTD_WAIT_CASE(16) PTD_WAIT_CASE(17)
+      PTD_WAIT_CASE(18) PTD_WAIT_CASE(19) PTD_WAIT_CASE(20) PTD_WAIT_CASE(21) PTD_WAIT_CASE(22) PTD_WAIT_CASE(23)
+      PTD_WAIT_CASE(24) PTD_WAIT_CASE(25) PTD_WAIT_CASE(26) PTD_WAIT_CASE(27) PTD_WAIT_CASE(28) PTD_WAIT_CASE(29)
+      PTD_WAIT_CASE(30) PTD_WAIT_CASE(31) PTD_WAIT_CASE(32)
+      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+#undef PTD_WAIT_CASE
+    __builtin_amdgcn_s_barrier();   // every piece of tile k is in LDS; every wave is done reading tile k - 1
+    asm volatile("" ::: "memory");
+    if (k + 3 < nsteps) stage((k + 3) & 3, m + 192);
+    const char* As = lds + (k & 3) * BUF;
+    f32x16 acc[2];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+    const int ra = wrb * 32 + fr;
+#pragma unroll
+    for (int kk = 0; kk < KC * 4; ++kk) {
+      const int sub = kk >> 2, c = ((kk & 3) << 1) + fh;
+      const s16x8 af = *reinterpret_cast<const s16x8*>(As + sub * SUB + ra * 128 + ((c ^ ((ra >> 1) & 7)) << 4));
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[0][kk], af, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[1][kk], af, acc[1], 0, 0, 0);
+    }
+    store(acc, m);
+  }
+}
+
 template <int KC>
 void launch_shortk(const GemmBf16Args& a, bool c_bf16, int nsplit, int cols_per_split, dim3 grid, hipStream_t st) {
   constexpr int NB = KC <= 4 ? 2 : 1;  // K > 256: narrower B tiles keep two workgroups per CU in LDS
@@ -685,6 +1044,22 @@ void launch_shortk(const GemmBf16Args& a, bool c_bf16, int nsplit, int cols_per_
     hipLaunchKernelGGL((gemm_bf16_shortk_kernel<KC, NB, EPI_STORE_BF16>), grid, dim3(256), 0, st, a, nsplit, cols_per_split);
   else
     hipLaunchKernelGGL((gemm_bf16_shortk_kernel<KC, NB, EPI_STORE_F32>), grid, dim3(256), 0, st, a, nsplit, cols_per_split);
+}
+
+template <int KC>
+void launch_shortk2(const GemmBf16Args& a, bool c_bf16, int msplit, int rows_per_split, dim3 grid, hipStream_t st) {
+  if (c_bf16)
+    hipLaunchKernelGGL((gemm_bf16_shortk2_kernel<KC, EPI_STORE_BF16>), grid, dim3(256), 0, st, a, msplit, rows_per_split);
+  else
+    hipLaunchKernelGGL((gemm_bf16_shortk2_kernel<KC, EPI_STORE_F32>), grid, dim3(256), 0, st, a, msplit, rows_per_split);
+}
+
+template <int KC>
+void launch_shortk3(const GemmBf16Args& a, bool c_bf16, int msplit, int rows_per_split, dim3 grid, hipStream_t st) {
+  if (c_bf16)
+    hipLaunchKernelGGL((gemm_bf16_shortk3_kernel<KC, EPI_STORE_BF16>), grid, dim3(512), 0, st, a, msplit, rows_per_split);
+  else
+    hipLaunchKernelGGL((gemm_bf16_shortk3_kernel<KC, EPI_STORE_F32>), grid, dim3(512), 0, st, a, msplit, rows_per_split);
 }
 
 template <int EPI>
@@ -717,6 +1092,42 @@ int gemm_bf16(const unsigned short* A, int64_t sam, int64_t sak, const unsigned 
   dim3 grid((unsigned)(a.tiles_m * ceil_div(N, BN)), 1);
   static const bool no_glds = getenv("PTD_GEMM_NO_GLDS") != nullptr;
   static const bool no_shortk = getenv("PTD_GEMM_NO_SHORTK") != nullptr;
+  static const bool shortk_old = getenv("PTD_GEMM_SHORTK_OLD") != nullptr;
+  static const bool shortk_4w = getenv("PTD_GEMM_SHORTK_4W") != nullptr;
+  if (!no_glds && !no_shortk && !shortk_old && !shortk_4w && akc && bkc && a.vecA && a.vecB && N % 256 == 0 && M % 64 == 0 &&
+      M >= 2048 && K % 64 == 0 && K >= 64 && K <= 256 && aligned16(C) && (ldc * (c_bf16 ? 2 : 4)) % 16 == 0) {
+    // 256-column B panel in registers, one 8-wave workgroup per CU, persistent over M
+    const int npanel = (int)(N / 256);
+    int msplit = (int)std::max<int64_t>(1, std::min<int64_t>(256 / npanel, M / 64));
+    int rows_per_split = (int)align_up((size_t)ceil_div(M, msplit), 64);
+    msplit = (int)ceil_div(M, rows_per_split);
+    dim3 g((unsigned)(npanel * msplit), 1);
+    switch (K / 64) {
+      case 1: launch_shortk3<1>(a, c_bf16, msplit, rows_per_split, g, st); break;
+      case 2: launch_shortk3<2>(a, c_bf16, msplit, rows_per_split, g, st); break;
+      case 3: launch_shortk3<3>(a, c_bf16, msplit, rows_per_split, g, st); break;
+      default: launch_shortk3<4>(a, c_bf16, msplit, rows_per_split, g, st); break;
+    }
+    PTD_CHECK_LAUNCH("gemm_bf16 (short K, 256-column B panel resident)");
+    return PTD_OK;
+  }
+  if (!no_glds && !no_shortk && !shortk_old && akc && bkc && a.vecA && a.vecB && N % 128 == 0 && M % 64 == 0 && M >= 1024 &&
+      K % 64 == 0 && K >= 64 && K <= 256 && aligned16(C) && (ldc * (c_bf16 ? 2 : 4)) % 16 == 0) {
+    // B panel in registers, persistent over M: ~2 workgroups per CU
+    const int npanel = (int)(N / 128);
+    int msplit = (int)std::max<int64_t>(1, std::min<int64_t>(512 / npanel, M / 64));
+    int rows_per_split = (int)align_up((size_t)ceil_div(M, msplit), 64);
+    msplit = (int)ceil_div(M, rows_per_split);
+    dim3 g((unsigned)(npanel * msplit), 1);
+    switch (K / 64) {
+      case 1: launch_shortk2<1>(a, c_bf16, msplit, rows_per_split, g, st); break;
+      case 2: launch_shortk2<2>(a, c_bf16, msplit, rows_per_split, g, st); break;
+      case 3: launch_shortk2<3>(a, c_bf16, msplit, rows_per_split, g, st); break;
+      default: launch_shortk2<4>(a, c_bf16, msplit, rows_per_split, g, st); break;
+    }
+    PTD_CHECK_LAUNCH("gemm_bf16 (short K, B panel resident)");
+    return PTD_OK;
+  }
   if (!no_glds && !no_shortk && akc && bkc && a.vecA && a.vecB && M % 128 == 0 && N % 64 == 0 && N >= 256 &&
       K % 64 == 0 && K >= 64 && K <= 512 && M >= 1024 && aligned16(C) && (ldc * (c_bf16 ? 2 : 4)) % 16 == 0) {
     // persistent-over-N short-K kernel: ~2 workgroups per CU

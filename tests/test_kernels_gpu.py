@@ -333,8 +333,13 @@ def test_gemm_bf16_short_k_persistent_path_exact(ops):
     streamed through the swizzled LDS-DMA image, N cut into ranges).  Exact integer products for every
     K / 64 instantiation, ragged range ends and a leading dimension larger than N."""
     g = torch.Generator().manual_seed(8)
+    # (K <= 256 with N % 128 == 0 takes the form with the B panel resident and the workgroup persistent over M)
     for (M, N, K) in [(1024, 256, 64), (1024, 320, 128), (1152, 4096, 256), (2048, 448, 192), (1024, 1024, 320),
-                      (1024, 256, 384), (1280, 576, 448), (2048, 256, 512), (16384, 4096, 256)]:
+                      (1024, 256, 384), (1280, 576, 448), (2048, 256, 512), (16384, 4096, 256), (1088, 384, 192),
+                      (1024, 128, 128), (4160, 1152, 256),
+                      # N % 256 == 0, M >= 2048: 8-wave form, 1 .. 16 steps per workgroup (prologue / tail wait counts)
+                      (2048, 256, 64), (2112, 512, 128), (4160, 1024, 192), (2048, 4096, 256), (3072, 4096, 256),
+                      (4096, 4096, 256), (8192, 4096, 256), (6144, 8192, 128), (5120, 4096, 192)]:
         a = torch.randint(-4, 5, (M, K), generator=g).to(torch.bfloat16)
         b = torch.randint(-4, 5, (N, K), generator=g).to(torch.bfloat16)
         bias = torch.randint(-3, 4, (N,), generator=g).to(torch.bfloat16)
