@@ -901,7 +901,8 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_shortk3_kernel(const GemmBf1
   const int fr = lane & 31, fh = lane >> 5;
   const int srow = lane >> 3, spos = lane & 7;
 
-  // this wave's 64 columns of B as fragments, through the LDS image 64 panel rows at a time
+  // this wave's 64 columns of B as fragments, through the LDS image: the four 64-row chunks of the panel
+  // go into the four A buffers with one DMA round trip
   s16x8 bfr[2][KC * 4];
 #pragma unroll
   for (int chunk = 0; chunk < 4; ++chunk) {
@@ -912,47 +913,65 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_shortk3_kernel(const GemmBf1
       const int r = r0 + srow;
       const int c = spos ^ ((r >> 1) & 7);
       const unsigned short* sb = a.B + (int64_t)(n0 + chunk * 64 + r) * a.sbn + sub * 64 + c * 8;
-      __builtin_amdgcn_global_load_lds((glb_void*)sb, (lds_void*)(lds + sub * 8192 + r0 * 128), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_void*)sb, (lds_void*)(lds + chunk * BUF + sub * SUB + r0 * 128), 16, 0, 0);
     }
-    __syncthreads();
-    if (wc == chunk) {
-#pragma unroll
-      for (int nb = 0; nb < 2; ++nb) {
-        const int rr = nb * 32 + fr;
-#pragma unroll
-        for (int kk = 0; kk < KC * 4; ++kk) {
-          const int sub = kk >> 2, c = ((kk & 3) << 1) + fh;
-          bfr[nb][kk] = *reinterpret_cast<const s16x8*>(lds + sub * 8192 + rr * 128 + ((c ^ ((rr >> 1) & 7)) << 4));
-        }
-      }
-    }
-    __syncthreads();
   }
+  __syncthreads();
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) {
+    const int rr = nb * 32 + fr;
+#pragma unroll
+    for (int kk = 0; kk < KC * 4; ++kk) {
+      const int sub = kk >> 2, c = ((kk & 3) << 1) + fh;
+      bfr[nb][kk] = *reinterpret_cast<const s16x8*>(lds + wc * BUF + sub * SUB + rr * 128 + ((c ^ ((rr >> 1) & 7)) << 4));
+    }
+  }
+  // pin the reads above the barrier: their values are first used inside the main loop, and hipcc
+  // (ROCm 7.2) otherwise sinks them below the second barrier, behind the DMA that refills the image
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+    for (int kk = 0; kk < KC * 4; ++kk) asm volatile("" : "+v"(bfr[nb][kk]));
+  __syncthreads();
 
+  // per-lane element offsets of this wave's DMA pieces, computed once: inside the loop a piece's source
+  // is a wave-uniform base (scalar arithmetic) plus this offset, not a 64-bit multiply per lane
+  int aoff[KC];
+#pragma unroll
+  for (int p = 0; p < KC; ++p) {
+    const int q = wid + 8 * p;
+    const int sub = q >> 3, r = (q & 7) * 8 + srow;
+    aoff[p] = r * (int)a.sam + sub * 64 + (spos ^ ((r >> 1) & 7)) * 8;
+  }
   auto stage = [&](int buf, int m) {           // G = KC DMA instructions per lane
     char* As = lds + buf * BUF;
+    const unsigned short* base = a.A + (int64_t)m * a.sam;
 #pragma unroll
     for (int p = 0; p < KC; ++p) {
       const int q = wid + 8 * p;
       const int sub = q >> 3, r0 = (q & 7) * 8;
-      const int r = r0 + srow;
-      const int c = spos ^ ((r >> 1) & 7);
-      const unsigned short* sa = a.A + (int64_t)(m + r) * a.sam + sub * 64 + c * 8;
-      __builtin_amdgcn_global_load_lds((glb_void*)sa, (lds_void*)(As + sub * SUB + r0 * 128), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_void*)(base + aoff[p]), (lds_void*)(As + sub * SUB + r0 * 128), 16, 0, 0);
     }
   };
 
   char* patch = lds + 4 * BUF + wid * 4096;
   const int psw = (fr >> 1) & 7;
   const int cb = n0 + wc * 64;                 // first output column of this wave's block
+  int coff[4], poff[4];                        // this lane's four 16-byte pieces of a flushed patch
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int q = lane + 64 * p;
+    const int lr = q >> 3, ch = q & 7;
+    poff[p] = lr * 128 + ((ch ^ ((lr >> 1) & 7)) << 4);
+    coff[p] = lr * (int)a.ldc * ES + ch * 16;
+  }
   auto flush = [&](int m, int c0) {            // patch rows -> 128-byte row pieces at columns c0 ...
+    char* base = reinterpret_cast<char*>(a.C) + ((int64_t)(m + wrb * 32) * a.ldc + c0) * ES;   // wave-uniform
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-      const int q = lane + 64 * p;
-      const int lr = q >> 3, ch = q & 7;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(patch + lr * 128 + ((ch ^ ((lr >> 1) & 7)) << 4));
-      char* dst = reinterpret_cast<char*>(a.C) + ((int64_t)(m + wrb * 32 + lr) * a.ldc + c0) * ES + ch * 16;
-      *reinterpret_cast<f32x4*>(dst) = v;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(patch + poff[p]);
+      *reinterpret_cast<f32x4*>(base + coff[p]) = v;
     }
   };
   s16x4 bq[2][4];                              // bias of this lane's 32 columns (see the 4-wave form)
@@ -970,20 +989,25 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_shortk3_kernel(const GemmBf1
 #pragma unroll
         for (int e = 0; e < 4; ++e) bq[nb][g][e] = (short)a.bias[cb + nb * 32 + 8 * g + 4 * fh + e];
   }
+  const bool plain = (a.bias == nullptr) && (a.alpha == 1.0f);   // nothing to apply: convert and go
   auto store = [&](const f32x16 (&acc)[2], int m) {   // S = 4 (bf16) or 8 (f32) store instructions per lane
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         float o[4];
+        if (plain) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          o[e] = a.alpha * acc[nb][4 * g + e] + bf16_to_f32((unsigned short)bq[nb][g][e]);
+          for (int e = 0; e < 4; ++e) o[e] = acc[nb][4 * g + e];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            o[e] = a.alpha * acc[nb][4 * g + e] + bf16_to_f32((unsigned short)bq[nb][g][e]);
+        }
         if (EPI == EPI_STORE_BF16) {
           typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
           const u32x2 pk = {pack2_bf16(o[0], o[1]), pack2_bf16(o[2], o[3])};
-          const s16x4 v = __builtin_bit_cast(s16x4, pk);
-          *reinterpret_cast<s16x4*>(patch + fr * 128 + (((nb * 4 + g) ^ psw) << 4) + 8 * fh) = v;
+          *reinterpret_cast<u32x2*>(patch + fr * 128 + (((nb * 4 + g) ^ psw) << 4) + 8 * fh) = pk;
         } else {
           f32x4 v = {o[0], o[1], o[2], o[3]};
           *reinterpret_cast<f32x4*>(patch + fr * 128 + (((2 * g + fh) ^ psw) << 4)) = v;
@@ -994,38 +1018,49 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_shortk3_kernel(const GemmBf1
     if (EPI == EPI_STORE_BF16) flush(m, cb);
   };
 
-  // the B-panel preload has drained (its last __syncthreads waited vmcnt(0))
-  constexpr int G4 = KC;                       // DMA instructions per tile, S4 = stores per step, in units of ...
-  constexpr int S1 = (EPI == EPI_STORE_BF16) ? 4 : 8;
+  // Main loop.  A step is two phases with a raw barrier after each: A(k) = fragment reads + MFMAs of
+  // tile k; B(k) = DMA of tile k + 3, then conversion + stores of step k.  The waves of row block 1 run
+  // ONE BARRIER behind those of row block 0 (the two waves of a SIMD belong to different row blocks), so
+  // on every SIMD one wave's MFMAs overlap the other's VALU / LDS / store phase instead of both waves
+  // queueing for the matrix pipe and then both for the VALU.
+  //  * WAR: tile k + 3 goes into the buffer of tile k - 1, staged in B(k); the lagging group read tile
+  //    k - 1 in its A(k - 1), two barriers earlier.
+  //  * RAW: a wave waits for its own pieces of tile k + 1 at the END of its A(k), before the barrier the
+  //    leading group passes into A(k + 1).  vmcnt retires in issue order, so the wait leaves outstanding
+  //    what was issued after that DMA: for k >= 2 the stores of steps k - 2 and k - 1 (S each) and the
+  //    DMA of tile k + 2 (G, if it exists); the prologue cases are spelled out below.
+  constexpr int G4 = KC;                       // DMA instructions per lane and tile
+  constexpr int S1 = (EPI == EPI_STORE_BF16) ? 4 : 8;   // store instructions per lane and step
+#define PTD_WAIT_CASE(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+#define PTD_WAIT_COUNTED(CNT)                                                                              \
+  switch (CNT) {                                                                                           \
+    PTD_WAIT_CASE(0) PTD_WAIT_CASE(1) PTD_WAIT_CASE(2) PTD_WAIT_CASE(3) PTD_WAIT_CASE(4) PTD_WAIT_CASE(5)  \
+    PTD_WAIT_CASE(6) PTD_WAIT_CASE(7) PTD_WAIT_CASE(8) PTD_WAIT_CASE(9) PTD_WAIT_CASE(10) PTD_WAIT_CASE(11) \
+    PTD_WAIT_CASE(12) PTD_WAIT_CASE(13) PTD_WAIT_CASE(14) PTD_WAIT_CASE(15) PTD_WAIT_CASE(16)               \
+    PTD_WAIT_CASE(17) PTD_WAIT_CASE(18) PTD_WAIT_CASE(19) PTD_WAIT_CASE(20)                                  \
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;                                       \
+  }
   stage(0, mbeg);
   if (nsteps > 1) stage(1, mbeg + 64);
   if (nsteps > 2) stage(2, mbeg + 128);
+  {
+    const int cnt0 = G4 * ((nsteps > 1) + (nsteps > 2));
+    PTD_WAIT_COUNTED(cnt0)
+  }
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  if (wrb == 1) __builtin_amdgcn_s_barrier();
+  const int ra = wrb * 32 + fr;
   for (int k = 0; k < nsteps; ++k) {
     const int m = mbeg + k * 64;
-    // outstanding after tile k's DMA: stores of min(k, 3) steps, DMA of the tiles k + 1, k + 2 that exist
-    const int later = (k + 1 < nsteps) + (k + 2 < nsteps);
-    const int cnt = S1 * min(k, 3) + G4 * later;
-#define PTD_WAIT_CASE(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
-    switch (cnt) {
-      PTD_WAIT_CASE(0) PTD_WAIT_CASE(1) PTD_WAIT_CASE(2) PTD_WAIT_CASE(3) PTD_WAIT_CASE(4) PTD_WAIT_CASE(5)
-      PTD_WAIT_CASE(6) PTD_WAIT_CASE(7) PTD_WAIT_CASE(8) PTD_WAIT_CASE(9) PTD_WAIT_CASE(10) PTD_WAIT_CASE(11)
-      PTD_WAIT_CASE(12) PTD_WAIT_CASE(13) PTD_WAIT_CASE(14) PTD_WAIT_CASE(15) PTD_WAIT_CASE(16) PTD_WAIT_CASE(17)
-      PTD_WAIT_CASE(18) PTD_WAIT_CASE(19) PTD_WAIT_CASE(20) PTD_WAIT_CASE(21) PTD_WAIT_CASE(22) PTD_WAIT_CASE(23)
-      PTD_WAIT_CASE(24) PTD_WAIT_CASE(25) PTD_WAIT_CASE(26) PTD_WAIT_CASE(27) PTD_WAIT_CASE(28) PTD_WAIT_CASE(29)
-      PTD_WAIT_CASE(30) PTD_WAIT_CASE(31) PTD_WAIT_CASE(32)
-      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    }
-#undef PTD_WAIT_CASE
-    __builtin_amdgcn_s_barrier();   // every piece of tile k is in LDS; every wave is done reading tile k - 1
-    asm volatile("" ::: "memory");
-    if (k + 3 < nsteps) stage((k + 3) & 3, m + 192);
+    // ---- phase A(k)
     const char* As = lds + (k & 3) * BUF;
     f32x16 acc[2];
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
-    const int ra = wrb * 32 + fr;
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int kk = 0; kk < KC * 4; ++kk) {
       const int sub = kk >> 2, c = ((kk & 3) << 1) + fh;
@@ -1033,8 +1068,26 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_shortk3_kernel(const GemmBf1
       acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[0][kk], af, acc[0], 0, 0, 0);
       acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[1][kk], af, acc[1], 0, 0, 0);
     }
+    __builtin_amdgcn_s_setprio(0);
+    if (k + 1 < nsteps) {
+      const int cnt = (k >= 2) ? 2 * S1 + G4 * (k + 2 < nsteps)
+                    : (k == 1) ? S1 + G4 * (3 < nsteps)
+                               : G4 * (2 < nsteps);
+      PTD_WAIT_COUNTED(cnt)
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    // ---- phase B(k)
+    if (k + 3 < nsteps) stage((k + 3) & 3, m + 192);
     store(acc, m);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
   }
+  if (wrb == 0) __builtin_amdgcn_s_barrier();
+#undef PTD_WAIT_COUNTED
+#undef PTD_WAIT_CASE
 }
 
 template <int KC>
@@ -1095,7 +1148,8 @@ int gemm_bf16(const unsigned short* A, int64_t sam, int64_t sak, const unsigned 
   static const bool shortk_old = getenv("PTD_GEMM_SHORTK_OLD") != nullptr;
   static const bool shortk_4w = getenv("PTD_GEMM_SHORTK_4W") != nullptr;
   if (!no_glds && !no_shortk && !shortk_old && !shortk_4w && akc && bkc && a.vecA && a.vecB && N % 256 == 0 && M % 64 == 0 &&
-      M >= 2048 && K % 64 == 0 && K >= 64 && K <= 256 && aligned16(C) && (ldc * (c_bf16 ? 2 : 4)) % 16 == 0) {
+      M >= 2048 && K % 64 == 0 && K >= 64 && K <= 256 && aligned16(C) && (ldc * (c_bf16 ? 2 : 4)) % 16 == 0 &&
+      sam < (1 << 24) && ldc < (1 << 23)) {   // (the kernel keeps 32-bit per-lane offsets of up to 64 rows)
     // 256-column B panel in registers, one 8-wave workgroup per CU, persistent over M
     const int npanel = (int)(N / 256);
     int msplit = (int)std::max<int64_t>(1, std::min<int64_t>(256 / npanel, M / 64));

@@ -9,7 +9,7 @@ def t(fn, n=20):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
 for mb in (134, 537, 2148):
-    n = mb * 1000 * 1000 // 2
+    n = (mb * 1000 * 1000 // 2) // 4096 * 4096
     y = torch.empty(n, dtype=torch.bfloat16, device=dev); x = torch.randn(n, device=dev, dtype=torch.float32).to(torch.bfloat16)
     ms = t(lambda: y.zero_()); print(f"{mb} MB zero_: {ms*1e3:.0f} us  {mb/ms/1e3:.2f} TB/s written")
     ms = t(lambda: y.fill_(1.5)); print(f"{mb} MB fill_: {ms*1e3:.0f} us  {mb/ms/1e3:.2f} TB/s written")
