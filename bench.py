@@ -146,7 +146,7 @@ def kernel_lines(device):
     if pmc:
         kern = json.load(open(pmc[-1]))["kernels"]
         for line, key in (("syrk_f32_f64acc", "syrk_f32_mixed_kernel"), ("gemm_f32_nt", "gemm_f32_kernel"),
-                          ("gemm_bf16_nt", "gemm_bf16_nt_glds_kernel")):
+                          ("gemm_bf16_nt", "gemm_bf16_nt_8ph_kernel")):
             for name, c in kern.items():
                 if name.startswith(key) and "MfmaUtil" in c and line in lines:
                     lines[line]["mfma_util_pmc_percent"] = c["MfmaUtil"]
@@ -172,6 +172,15 @@ def decomposed_forward_lines(device):
         by = 2 * (2 * t_rows * N_FEAT + 2 * r * N_FEAT)
         out[f"r{r}"] = {"ms": t * 1e3, "gflops": fl / t / 1e9, "speedup_vs_dense": dense_t / t,
                         "frac_of_bf16_mfma_peak": fl / t / PEAK_BF16_MFMA, "hbm_gbps_algorithmic": by / t / 1e9}
+    # MFMA utilisation of the two rank-256 kernels from the committed counter pass (tools/pmc_driver mfma)
+    import glob
+    pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc_mfma_r*.json")))
+    if pmc:
+        kern = json.load(open(pmc[-1]))["kernels"]
+        for label, key in (("x_At", "gemm_bf16_nt_glds_kernel<0, 4>"), ("h_Bt", "gemm_bf16_shortk3_kernel<4, 0>")):
+            if key in kern and "MfmaUtil" in kern[key]:
+                out["r256"][f"mfma_util_pmc_percent_{label}"] = kern[key]["MfmaUtil"]
+        out["r256"]["mfma_util_source"] = "profiles/" + os.path.basename(pmc[-1])
     return out
 
 

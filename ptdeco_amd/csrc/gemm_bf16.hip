@@ -1145,6 +1145,7 @@ int gemm_bf16(const unsigned short* A, int64_t sam, int64_t sak, const unsigned 
   dim3 grid((unsigned)(a.tiles_m * ceil_div(N, BN)), 1);
   static const bool no_glds = getenv("PTD_GEMM_NO_GLDS") != nullptr;
   static const bool no_shortk = getenv("PTD_GEMM_NO_SHORTK") != nullptr;
+  const bool c_vec = aligned16(C) && (ldc * (c_bf16 ? 2 : 4)) % 16 == 0;  // 16-byte row-contiguous output stores
   static const bool shortk_old = getenv("PTD_GEMM_SHORTK_OLD") != nullptr;
   static const bool shortk_4w = getenv("PTD_GEMM_SHORTK_4W") != nullptr;
   if (!no_glds && !no_shortk && !shortk_old && !shortk_4w && akc && bkc && a.vecA && a.vecB && N % 256 == 0 && M % 64 == 0 &&
@@ -1182,6 +1183,22 @@ int gemm_bf16(const unsigned short* A, int64_t sam, int64_t sak, const unsigned 
     PTD_CHECK_LAUNCH("gemm_bf16 (short K, B panel resident)");
     return PTD_OK;
   }
+  // (K of 384 / 512 on 256-aligned shapes: the 256^2 kernel below matches or beats the A-panel-resident short-K form)
+  static const int mode_8ph = getenv("PTD_GEMM_8PH") ? atoi(getenv("PTD_GEMM_8PH")) : 2;  // 0 off, 1 lockstep, 2 staggered
+  if (!no_glds && mode_8ph && akc && bkc && a.vecA && a.vecB && c_vec && M % 256 == 0 && N % 256 == 0 && K % 128 == 0 &&
+      K >= 256 && (M / 256) * (N / 256) >= 192) {
+    a.tiles_m = (int)(M / 256);
+    dim3 g8((unsigned)((M / 256) * (N / 256)), 1);
+    if (mode_8ph == 1) {
+      if (c_bf16) hipLaunchKernelGGL((gemm_bf16_nt_8ph_kernel<EPI_STORE_BF16, false>), g8, dim3(512), 0, st, a);
+      else hipLaunchKernelGGL((gemm_bf16_nt_8ph_kernel<EPI_STORE_F32, false>), g8, dim3(512), 0, st, a);
+    } else {
+      if (c_bf16) hipLaunchKernelGGL((gemm_bf16_nt_8ph_kernel<EPI_STORE_BF16, true>), g8, dim3(512), 0, st, a);
+      else hipLaunchKernelGGL((gemm_bf16_nt_8ph_kernel<EPI_STORE_F32, true>), g8, dim3(512), 0, st, a);
+    }
+    PTD_CHECK_LAUNCH("gemm_bf16 (256x256)");
+    return PTD_OK;
+  }
   if (!no_glds && !no_shortk && akc && bkc && a.vecA && a.vecB && M % 128 == 0 && N % 64 == 0 && N >= 256 &&
       K % 64 == 0 && K >= 64 && K <= 512 && M >= 1024 && aligned16(C) && (ldc * (c_bf16 ? 2 : 4)) % 16 == 0) {
     // persistent-over-N short-K kernel: ~2 workgroups per CU
@@ -1201,22 +1218,6 @@ int gemm_bf16(const unsigned short* A, int64_t sam, int64_t sak, const unsigned 
       default: launch_shortk<8>(a, c_bf16, nsplit, cols_per_split, g, st); break;
     }
     PTD_CHECK_LAUNCH("gemm_bf16 (short K)");
-    return PTD_OK;
-  }
-  const bool c_vec = aligned16(C) && (ldc * (c_bf16 ? 2 : 4)) % 16 == 0;  // 16-byte row-contiguous output stores
-  static const int mode_8ph = getenv("PTD_GEMM_8PH") ? atoi(getenv("PTD_GEMM_8PH")) : 2;  // 0 off, 1 lockstep, 2 staggered
-  if (!no_glds && mode_8ph && akc && bkc && a.vecA && a.vecB && c_vec && M % 256 == 0 && N % 256 == 0 && K % 128 == 0 &&
-      K >= 256 && (M / 256) * (N / 256) >= 192) {
-    a.tiles_m = (int)(M / 256);
-    dim3 g8((unsigned)((M / 256) * (N / 256)), 1);
-    if (mode_8ph == 1) {
-      if (c_bf16) hipLaunchKernelGGL((gemm_bf16_nt_8ph_kernel<EPI_STORE_BF16, false>), g8, dim3(512), 0, st, a);
-      else hipLaunchKernelGGL((gemm_bf16_nt_8ph_kernel<EPI_STORE_F32, false>), g8, dim3(512), 0, st, a);
-    } else {
-      if (c_bf16) hipLaunchKernelGGL((gemm_bf16_nt_8ph_kernel<EPI_STORE_BF16, true>), g8, dim3(512), 0, st, a);
-      else hipLaunchKernelGGL((gemm_bf16_nt_8ph_kernel<EPI_STORE_F32, true>), g8, dim3(512), 0, st, a);
-    }
-    PTD_CHECK_LAUNCH("gemm_bf16 (256x256)");
     return PTD_OK;
   }
   if (!no_glds && akc && bkc && a.vecA && a.vecB && c_vec && M % BM == 0 && N % BN == 0 && K % BK == 0 && K >= BK) {

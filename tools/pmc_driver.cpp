@@ -35,6 +35,19 @@ static int run_mfma() {
     rc |= ptd_gemm(Xb, n, 1, Wb, 1, n, Yb, n, n, n, n, 2, 2, 1.0, nullptr, nullptr);    // bf16
     if (rc) { fprintf(stderr, "mfma mode rc=%d: %s\n", rc, ptd_last_error()); return 1; }
   }
+  // the bf16 decomposed forward at rank 256 (BASELINE configs[4]): h = x A^T (16384 x 256 x 4096), y = h B^T (16384 x 4096 x 256)
+  const int64_t T = 16384, r = 256;
+  unsigned short *Xf, *Af, *Hf, *Bf, *Yf;
+  if (hipMalloc(&Xf, T * n * 2) || hipMalloc(&Af, r * n * 2) || hipMalloc(&Hf, T * r * 2) || hipMalloc(&Bf, n * r * 2) ||
+      hipMalloc(&Yf, T * n * 2)) return 2;
+  for (int64_t off = 0; off < T * n; off += n * n) (void)hipMemcpy(Xf + off, hb.data(), n * n * 2, hipMemcpyHostToDevice);
+  (void)hipMemcpy(Af, hb.data(), r * n * 2, hipMemcpyHostToDevice);
+  (void)hipMemcpy(Bf, hb.data(), n * r * 2, hipMemcpyHostToDevice);
+  for (int rep = 0; rep < 3; ++rep) {
+    int rc = ptd_gemm(Xf, n, 1, Af, 1, n, Hf, r, T, r, n, 2, 2, 1.0 / 64, nullptr, nullptr);
+    rc |= ptd_gemm(Hf, r, 1, Bf, 1, r, Yf, n, T, n, r, 2, 2, 1.0 / 16, nullptr, nullptr);
+    if (rc) { fprintf(stderr, "mfma mode (forward) rc=%d: %s\n", rc, ptd_last_error()); return 1; }
+  }
   (void)hipDeviceSynchronize();
   printf("mfma mode done\n");
   return 0;
