@@ -288,6 +288,171 @@ void launch_f32(const GemmF32Args& a, bool akc, bool bkc, dim3 grid, hipStream_t
 
 // K split of a product with few output tiles (a skinny operand, e.g. x U with a small rank): the
 // partial tiles go to slabs in a caller-provided workspace and a second launch adds them in a fixed
+// ---- 256 x 256 tile, 8 waves, LDS-DMA in flight across raw barriers: the schedule of
+// gemm_bf16_nt_8ph_kernel (gemm_bf16.hip, hazard analysis there) with 4-byte elements.  For the
+// nn.Linear layout (both operands k-contiguous) with M, N % 256 = 0, K % 64 = 0 and >= 192 tiles: the
+// layer's own y = x W^T of the rank search.  A K step is 32 deep, so an image row is the same 128
+// bytes and the half tiles, the swizzle and the wait counts carry over unchanged; a 16-byte fragment
+// is 4 consecutive k of one row and feeds FOUR v_mfma_f32_32x32x2_f32 (lanes 0-31 hold k 0..3 of an
+// 8-k group, lanes 32-63 k 4..7; A and B use the same map, and the order of the k sum is free).  A
+// phase is 32 MFMAs of 16 passes (2048 cycles) against the same handful of LDS / DMA instructions as
+// in the bf16 kernel, so the matrix pipe stays busy.  B fragment first: transposed accumulators, 16-byte
+// epilogue writes.  The 128^2 register-staged kernel above reaches 125 TFLOP/s at 4096^3 (two barriers
+// and a write pass per K step).
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+
+template <bool STAGGER>
+__global__ __launch_bounds__(512, 1) void gemm_f32_nt_8ph_kernel(const GemmF32Args a) {
+  __shared__ __attribute__((aligned(16))) char lds[8 * 16384];  // slot ((op*2 + d)*2 + h) * 16 KiB: A below 64 KiB, B above
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wid >> 2, wc = wid & 3;
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int tiles_m = a.tiles_m, tiles_n = nwg / tiles_m;
+  const int width = 8 * tiles_n, first = (wg / width) * 8;
+  const int gsz = min(tiles_m - first, 8);
+  const int ti = first + (wg % width) % gsz, tj = (wg % width) / gsz;
+  const int m0 = ti * 256, n0 = tj * 256;
+  const int nk = a.K / 32;
+
+  const int srow = lane >> 3, spos = lane & 7;
+  const float *sa0, *sa1, *sb0, *sb1;
+  {
+    const int r0 = wid * 16 + srow, r1 = r0 + 8;
+    const int c0 = spos ^ ((r0 >> 1) & 7), c1 = spos ^ ((r1 >> 1) & 7);
+    sa0 = a.A + (int64_t)(m0 + r0) * a.sam + c0 * 4;
+    sa1 = a.A + (int64_t)(m0 + r1) * a.sam + c1 * 4;
+    sb0 = a.B + (int64_t)(n0 + r0) * a.sbn + c0 * 4;
+    sb1 = a.B + (int64_t)(n0 + r1) * a.sbn + c1 * 4;
+  }
+  const int64_t halfA = 128 * a.sam, halfB = 128 * a.sbn;
+  char* const mypiece = lds + wid * 2048;
+#define PTD_STAGE(D, OP, H, KT)                                                                          \
+  do {                                                                                                   \
+    char* slot_ = mypiece + ((((OP) * 2 + (D)) * 2 + (H)) << 14);                                        \
+    const float* s0_ = ((OP) ? sb0 + (H) * halfB : sa0 + (H) * halfA) + (int64_t)(KT) * 32;              \
+    const float* s1_ = ((OP) ? sb1 + (H) * halfB : sa1 + (H) * halfA) + (int64_t)(KT) * 32;              \
+    __builtin_amdgcn_global_load_lds((glb_void_t*)s0_, (lds_void_t*)slot_, 16, 0, 0);                    \
+    __builtin_amdgcn_global_load_lds((glb_void_t*)s1_, (lds_void_t*)(slot_ + 1024), 16, 0, 0);           \
+  } while (0)
+
+  const int fr = lane & 31, fh = lane >> 5, sw = (fr >> 1) & 7;
+  int offA[4], offB[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const int ch = ((2 * ks + fh) ^ sw) << 4;
+    offA[ks] = (wr * 64 + fr) * 128 + ch;
+    offB[ks] = 65536 + (wc * 32 + fr) * 128 + ch;
+  }
+  f32x4 af[2][4], b0[4], b1[4];
+  f32x16 acc[2][2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][mt][r] = 0.f;
+
+#define PTD_READ_A(D, H)                                                                                 \
+  _Pragma("unroll") for (int mt_ = 0; mt_ < 2; ++mt_) _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_) \
+      af[mt_][ks_] = *reinterpret_cast<const f32x4*>(lds + (((D) * 2 + (H)) << 14) + mt_ * 4096 + offA[ks_])
+#define PTD_READ_B(D, H, DST)                                                                            \
+  _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_)                                                     \
+      DST[ks_] = *reinterpret_cast<const f32x4*>(lds + (((D) * 2 + (H)) << 14) + offB[ks_])
+#define PTD_QUAD(I, J, BREG)                                                                             \
+  do {                                                                                                   \
+    __builtin_amdgcn_s_setprio(1);                                                                       \
+    _Pragma("unroll") for (int ks_ = 0; ks_ < 4; ++ks_) _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_)  \
+        _Pragma("unroll") for (int mt_ = 0; mt_ < 2; ++mt_)                                              \
+            acc[I][J][mt_] = __builtin_amdgcn_mfma_f32_32x32x2f32(BREG[ks_][e_], af[mt_][ks_][e_], acc[I][J][mt_], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                                       \
+  } while (0)
+#define PTD_SYNC_IN(WAIT)                                                                                \
+  do {                                                                                                   \
+    asm volatile("s_waitcnt vmcnt(" #WAIT ")" ::: "memory");                                             \
+    __builtin_amdgcn_s_barrier();                                                                        \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                   \
+  } while (0)
+#define PTD_SYNC_OUT()                                                                                   \
+  do {                                                                                                   \
+    asm volatile("" ::: "memory");                                                                       \
+    __builtin_amdgcn_s_barrier();                                                                        \
+  } while (0)
+
+  PTD_STAGE(0, 1, 0, 0); PTD_STAGE(0, 0, 0, 0); PTD_STAGE(0, 1, 1, 0); PTD_STAGE(0, 0, 1, 0);
+  PTD_STAGE(1, 1, 0, 1); PTD_STAGE(1, 0, 0, 1);
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (STAGGER && wr == 1) __builtin_amdgcn_s_barrier();
+
+  int kt = 0;
+  for (; kt + 2 < nk; kt += 2) {
+    PTD_READ_B(0, 0, b0); PTD_READ_A(0, 0); PTD_STAGE(1, 1, 1, kt + 1); PTD_SYNC_IN(8); PTD_QUAD(0, 0, b0); PTD_SYNC_OUT();
+    PTD_READ_B(0, 1, b1);                   PTD_STAGE(1, 0, 1, kt + 1); PTD_SYNC_IN(8); PTD_QUAD(0, 1, b1); PTD_SYNC_OUT();
+    PTD_READ_A(0, 1);                       PTD_STAGE(0, 1, 0, kt + 2); PTD_SYNC_IN(8); PTD_QUAD(1, 1, b1); PTD_SYNC_OUT();
+                                            PTD_STAGE(0, 0, 0, kt + 2); PTD_SYNC_IN(8); PTD_QUAD(1, 0, b0); PTD_SYNC_OUT();
+    PTD_READ_B(1, 0, b0); PTD_READ_A(1, 0); PTD_STAGE(0, 1, 1, kt + 2); PTD_SYNC_IN(8); PTD_QUAD(0, 0, b0); PTD_SYNC_OUT();
+    PTD_READ_B(1, 1, b1);                   PTD_STAGE(0, 0, 1, kt + 2); PTD_SYNC_IN(8); PTD_QUAD(0, 1, b1); PTD_SYNC_OUT();
+    PTD_READ_A(1, 1);                       PTD_STAGE(1, 1, 0, kt + 3); PTD_SYNC_IN(8); PTD_QUAD(1, 1, b1); PTD_SYNC_OUT();
+                                            PTD_STAGE(1, 0, 0, kt + 3); PTD_SYNC_IN(8); PTD_QUAD(1, 0, b0); PTD_SYNC_OUT();
+  }
+  {
+    PTD_READ_B(0, 0, b0); PTD_READ_A(0, 0); PTD_STAGE(1, 1, 1, kt + 1); PTD_SYNC_IN(8); PTD_QUAD(0, 0, b0); PTD_SYNC_OUT();
+    PTD_READ_B(0, 1, b1);                   PTD_STAGE(1, 0, 1, kt + 1); PTD_SYNC_IN(8); PTD_QUAD(0, 1, b1); PTD_SYNC_OUT();
+    PTD_READ_A(0, 1);                                                   PTD_SYNC_IN(6); PTD_QUAD(1, 1, b1); PTD_SYNC_OUT();
+                                                                        PTD_SYNC_IN(4); PTD_QUAD(1, 0, b0); PTD_SYNC_OUT();
+    PTD_READ_B(1, 0, b0); PTD_READ_A(1, 0);                             PTD_SYNC_IN(2); PTD_QUAD(0, 0, b0); PTD_SYNC_OUT();
+    PTD_READ_B(1, 1, b1);                                               PTD_SYNC_IN(0); PTD_QUAD(0, 1, b1); PTD_SYNC_OUT();
+    PTD_READ_A(1, 1);                                                   PTD_SYNC_IN(0); PTD_QUAD(1, 1, b1); PTD_SYNC_OUT();
+                                                                        PTD_SYNC_IN(0); PTD_QUAD(1, 0, b0); PTD_SYNC_OUT();
+  }
+  if (STAGGER && wr == 0) __builtin_amdgcn_s_barrier();
+#undef PTD_STAGE
+#undef PTD_READ_A
+#undef PTD_READ_B
+#undef PTD_QUAD
+#undef PTD_SYNC_IN
+#undef PTD_SYNC_OUT
+
+  // epilogue: lane l holds output row (l & 31) and four consecutive columns per register group; the four
+  // 128 x 128 quadrants leave through an LDS image as 16-byte row-contiguous stores
+  constexpr int CP = 128 * 4 + 16;
+  static_assert(128 * CP <= 8 * 16384, "the C image must fit the staging buffers");
+  float* Cp = static_cast<float*>(a.C);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      if (i + j) __syncthreads();
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const int lr = wr * 64 + mt * 32 + (lane & 31);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int lc = wc * 32 + 8 * g + 4 * (lane >> 5);
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            v[e] = a.alpha * acc[i][j][mt][4 * g + e] + (a.bias ? a.bias[n0 + j * 128 + lc + e] : 0.f);
+          *reinterpret_cast<f32x4*>(lds + lr * CP + lc * 4) = v;
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int p = 0; p < 128 * 32 / 512; ++p) {
+        const int q = tid + 512 * p;
+        const int lr = q >> 5, ch = q & 31;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(lds + lr * CP + ch * 16);
+        *reinterpret_cast<f32x4*>(Cp + (int64_t)(m0 + i * 128 + lr) * a.ldc + n0 + j * 128 + ch * 4) = v;
+      }
+    }
+}
+
 // order, so the result does not depend on scheduling.  Returns 1 when splitting does not pay.
 int gemm_f32_ksplit(int64_t M, int64_t N, int64_t K) {
   const int64_t tiles = ceil_div(M, BM) * ceil_div(N, BN);
@@ -318,6 +483,16 @@ int gemm_f32(const float* A, int64_t sam, int64_t sak, const float* B, int64_t s
   const bool akc = (sak == 1), bkc = (sbk == 1);
   a.vecA = aligned16(A) && ((akc ? sam : sak) % 4 == 0);
   a.vecB = aligned16(B) && ((bkc ? sbn : sbk) % 4 == 0);
+  static const int mode_8ph = getenv("PTD_GEMM_8PH") ? atoi(getenv("PTD_GEMM_8PH")) : 2;  // 0 off, 1 lockstep, 2 staggered
+  if (mode_8ph && akc && bkc && a.vecA && a.vecB && aligned16(C) && ldc % 4 == 0 && M % 256 == 0 && N % 256 == 0 &&
+      K % 64 == 0 && K >= 128 && (M / 256) * (N / 256) >= 192) {
+    a.tiles_m = (int)(M / 256);
+    dim3 g8((unsigned)((M / 256) * (N / 256)), 1);
+    if (mode_8ph == 1) hipLaunchKernelGGL((gemm_f32_nt_8ph_kernel<false>), g8, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((gemm_f32_nt_8ph_kernel<true>), g8, dim3(512), 0, st, a);
+    PTD_CHECK_LAUNCH("gemm_f32 (256x256)");
+    return PTD_OK;
+  }
   const int tiles = (int)(a.tiles_m * ceil_div(N, BN));
   int ksplit = ws ? gemm_f32_ksplit(M, N, K) : 1;
   if (ksplit > 1 && (size_t)ksplit * (size_t)M * (size_t)N * sizeof(float) > ws_bytes) ksplit = 1;

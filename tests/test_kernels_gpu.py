@@ -383,6 +383,28 @@ def test_gemm_bf16_256_tile_deep_pipeline_exact_and_repeatable(ops):
     assert torch.equal(got.float(), (x_v.float() @ w_v.float().T).to(torch.bfloat16).float())
 
 
+def test_gemm_f32_256_tile_deep_pipeline_exact_and_repeatable(ops):
+    """f32 nn.Linear layout, M, N % 256 == 0, K % 64 == 0, >= 192 tiles: the 256 x 256 / 8-wave kernel with the
+    bf16 kernel's LDS-DMA schedule and four 32x32x2 MFMAs per 16-byte fragment.  Integer operands: every
+    product and partial sum is exact in f32 in any order, so a stale or torn half tile shows."""
+    g = torch.Generator().manual_seed(10)
+    for (M, N, K) in [(4096, 4096, 128), (3584, 4096, 192), (4096, 3584, 1024), (4096, 4096, 4096)]:
+        a = torch.randint(-8, 9, (M, K), generator=g).float().to(DEV)
+        b = torch.randint(-8, 9, (N, K), generator=g).float().to(DEV)
+        bias = torch.randint(-3, 4, (N,), generator=g).float().to(DEV)
+        ref = (a.double() @ b.double().T + bias.double()).float()
+        for rep in range(4):
+            got = ops.matmul(a, b.T, bias=bias)
+            assert torch.equal(got, ref), (M, N, K, rep)
+    # operands that are column slices of wider matrices, random data against f64
+    big = torch.randn(4096, 1024 + 256, generator=g).to(DEV)
+    w = torch.randn(4096, 1024 + 256, generator=g).to(DEV)
+    x_v, w_v = big[:, 256:], w[:, :1024]
+    got = ops.matmul(x_v, w_v.T)
+    ref = x_v.double() @ w_v.double().T
+    assert (got.double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+
+
 def test_gemm_f32_exact_integers(ops):
     g = torch.Generator().manual_seed(2)
     for layout in LAYOUTS:
