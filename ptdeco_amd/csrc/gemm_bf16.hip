@@ -1090,6 +1090,202 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_shortk3_kernel(const GemmBf1
 #undef PTD_WAIT_CASE
 }
 
+// The plain case of the product above (bf16 output, alpha = 1, no bias -- the second product of a pair
+// without bias) with the epilogue of step k - 1 issued INSIDE the MFMA stream of step k.  In the
+// two-phase form a wave alternates 32 MFMAs (1,650 cycles measured) and ~110 conversion / LDS / store
+// instructions (2,200 cycles): the two waves of a SIMD overlap each other, but each wave still needs both
+// phases per step, 30 % MFMA utilisation.  Here the accumulators ping-pong between two register sets:
+// while the matrix pipe works on tile k into one set, the wave converts, patches and stores the other
+// set in the shadow of those MFMAs, one slice (a pack + 8-byte patch write, a patch read, or a global
+// store) per fragment.  One raw barrier per step; the wait before step k leaves outstanding what was
+// issued after tile k's DMA (vmcnt retires in issue order): the DMA of the two later tiles and the
+// stores of up to three steps.
+template <int KC>
+__global__ __launch_bounds__(512, 1) void gemm_bf16_shortk4_kernel(const GemmBf16Args a, const int msplit,
+                                                                   const int rows_per_split) {
+  constexpr int SUB = 64 * 128;
+  constexpr int BUF = KC * SUB;
+  constexpr int NKK = KC * 4;                 // fragments (and slice slots) per step
+  static_assert(4 * BUF + 8 * 4096 <= 160 * 1024, "LDS of one CU");
+  __shared__ __attribute__((aligned(16))) char lds[4 * BUF + 8 * 4096];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wrb = wid >> 2, wc = wid & 3;
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int npanel = nwg / msplit;
+  const int panel = wg % npanel, split = wg / npanel;
+  const int n0 = panel * 256;
+  const int mbeg = split * rows_per_split, mend = min(a.M, mbeg + rows_per_split);
+  const int nsteps = (mend - mbeg) / 64;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int srow = lane >> 3, spos = lane & 7;
+
+  s16x8 bfr[2][NKK];
+#pragma unroll
+  for (int chunk = 0; chunk < 4; ++chunk) {
+#pragma unroll
+    for (int p = 0; p < KC; ++p) {
+      const int q = wid + 8 * p;
+      const int sub = q >> 3, r0 = (q & 7) * 8;
+      const int r = r0 + srow;
+      const int c = spos ^ ((r >> 1) & 7);
+      const unsigned short* sb = a.B + (int64_t)(n0 + chunk * 64 + r) * a.sbn + sub * 64 + c * 8;
+      __builtin_amdgcn_global_load_lds((glb_void*)sb, (lds_void*)(lds + chunk * BUF + sub * SUB + r0 * 128), 16, 0, 0);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) {
+    const int rr = nb * 32 + fr;
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) {
+      const int sub = kk >> 2, c = ((kk & 3) << 1) + fh;
+      bfr[nb][kk] = *reinterpret_cast<const s16x8*>(lds + wc * BUF + sub * SUB + rr * 128 + ((c ^ ((rr >> 1) & 7)) << 4));
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // pin the reads above the barrier (see shortk3)
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) asm volatile("" : "+v"(bfr[nb][kk]));
+  __syncthreads();
+
+  int aoff[KC];
+#pragma unroll
+  for (int p = 0; p < KC; ++p) {
+    const int q = wid + 8 * p;
+    const int sub = q >> 3, r = (q & 7) * 8 + srow;
+    aoff[p] = r * (int)a.sam + sub * 64 + (spos ^ ((r >> 1) & 7)) * 8;
+  }
+  auto stage = [&](int buf, int m) {
+    char* As = lds + buf * BUF;
+    const unsigned short* base = a.A + (int64_t)m * a.sam;
+#pragma unroll
+    for (int p = 0; p < KC; ++p) {
+      const int q = wid + 8 * p;
+      const int sub = q >> 3, r0 = (q & 7) * 8;
+      __builtin_amdgcn_global_load_lds((glb_void*)(base + aoff[p]), (lds_void*)(As + sub * SUB + r0 * 128), 16, 0, 0);
+    }
+  };
+
+  char* patch = lds + 4 * BUF + wid * 4096;
+  const int psw = (fr >> 1) & 7;
+  const int cb = n0 + wc * 64;
+  int coff[4], poff[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int q = lane + 64 * p;
+    const int lr = q >> 3, ch = q & 7;
+    poff[p] = lr * 128 + ((ch ^ ((lr >> 1) & 7)) << 4);
+    coff[p] = lr * (int)a.ldc * 2 + ch * 16;
+  }
+  // Every LDS operation of the main loop is issued by hand (inline asm) so that the waits can be COUNTED:
+  // LDS returns in order, `s_waitcnt lgkmcnt(3)` before the MFMAs of fragment kk leaves the three
+  // younger fragment requests in flight (hipcc waits lgkmcnt(0) around each fragment as soon as patch
+  // traffic shares the queue: one exposed LDS latency per fragment, ~4,000 cycles per step for 1,024
+  // cycles of MFMA).  Ops the queue holds besides the counted ones only make a wait stricter.
+  const unsigned lds0 = (unsigned)(uintptr_t)(lds_void*)lds;   // LDS byte address of the array
+  unsigned fo[4];                              // fragment offsets of k-chunk pair j = kk & 3 (row ra)
+  const int ra = wrb * 32 + fr;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) fo[j] = lds0 + ra * 128 + ((((j << 1) + fh) ^ ((ra >> 1) & 7)) << 4);
+  const unsigned pw = lds0 + 4 * BUF + wid * 4096 + fr * 128 + 8 * fh;   // this lane's patch row (write side)
+  unsigned pr[4];                              // this lane's four 16-byte pieces (read side)
+#pragma unroll
+  for (int p = 0; p < 4; ++p) pr[p] = lds0 + 4 * BUF + wid * 4096 + poff[p];
+  f32x4 piece[4];
+  typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+  constexpr int G4 = KC, S1 = 4;
+#define PTD_WAIT_CASE(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+#define PTD_FRAG(DST, KK)                                                                                    \
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(fbase[(KK) & 3]), "n"(((KK) >> 2) * SUB))
+  auto step = [&](f32x16 (&cur)[2], const f32x16 (&prv)[2], int k, bool have_prev) {
+    const int m = mbeg + k * 64;
+    const int cnt = G4 * ((k + 1 < nsteps) + (k + 2 < nsteps)) + S1 * min(max(k - 1, 0), 3);
+    switch (cnt) {
+      PTD_WAIT_CASE(0) PTD_WAIT_CASE(1) PTD_WAIT_CASE(2) PTD_WAIT_CASE(3) PTD_WAIT_CASE(4) PTD_WAIT_CASE(5)
+      PTD_WAIT_CASE(6) PTD_WAIT_CASE(7) PTD_WAIT_CASE(8) PTD_WAIT_CASE(9) PTD_WAIT_CASE(10) PTD_WAIT_CASE(11)
+      PTD_WAIT_CASE(12) PTD_WAIT_CASE(13) PTD_WAIT_CASE(14) PTD_WAIT_CASE(15) PTD_WAIT_CASE(16) PTD_WAIT_CASE(17)
+      PTD_WAIT_CASE(18) PTD_WAIT_CASE(19) PTD_WAIT_CASE(20)
+      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+    __builtin_amdgcn_s_barrier();   // tile k is in LDS; every wave is done reading tile k - 1
+    asm volatile("" ::: "memory");
+    if (k + 3 < nsteps) stage((k + 3) & 3, m + 192);
+    unsigned fbase[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fbase[j] = fo[j] + (k & 3) * BUF;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) cur[nb][r] = 0.f;
+    s16x8 ring[4];
+    PTD_FRAG(ring[0], 0); PTD_FRAG(ring[1], 1); PTD_FRAG(ring[2], 2); PTD_FRAG(ring[3], 3);
+    char* cbase = reinterpret_cast<char*>(a.C) + ((int64_t)(m - 64 + wrb * 32) * a.ldc + cb) * 2;
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) {
+      // fragment kk has landed once at most min(3, NKK - 1 - kk) of the younger requests are outstanding
+      if (kk + 3 < NKK) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+      else if (kk + 2 < NKK) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+      else if (kk + 1 < NKK) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
+      else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      const s16x8 af = ring[kk & 3];
+      cur[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[0][kk], af, cur[0], 0, 0, 0);
+      cur[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[1][kk], af, cur[1], 0, 0, 0);
+      if (have_prev && kk >= 12) {   // piece kk - 12 was requested four fragments ago: >= 3 younger requests, so it is in
+        *reinterpret_cast<f32x4*>(cbase + coff[kk - 12]) = piece[kk - 12];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (kk + 4 < NKK) PTD_FRAG(ring[kk & 3], kk + 4);
+      if (have_prev) {
+        if (kk < 8) {                // pack + 8-byte patch write of register group (nb, g)
+          const int nb = kk >> 2, g = kk & 3;
+          const u32x2 pk = {pack2_bf16(prv[nb][4 * g], prv[nb][4 * g + 1]), pack2_bf16(prv[nb][4 * g + 2], prv[nb][4 * g + 3])};
+          const unsigned wa = pw + (((nb * 4 + g) ^ psw) << 4);
+          asm volatile("ds_write_b64 %0, %1" :: "v"(wa), "v"(pk) : "memory");
+        } else if (kk < 12) {        // patch read of piece kk - 8 (behind all eight writes: LDS is in order)
+          asm volatile("ds_read_b128 %0, %1" : "=v"(piece[kk - 8]) : "v"(pr[kk - 8]) : "memory");
+        }
+      }
+    }
+  };
+#undef PTD_WAIT_CASE
+
+  stage(0, mbeg);
+  if (nsteps > 1) stage(1, mbeg + 64);
+  if (nsteps > 2) stage(2, mbeg + 128);
+  f32x16 acc_a[2], acc_b[2];
+  step(acc_a, acc_b, 0, false);
+  int k = 1;
+  for (; k + 1 < nsteps; k += 2) {
+    step(acc_b, acc_a, k, true);
+    step(acc_a, acc_b, k + 1, true);
+  }
+  auto drain = [&](const f32x16 (&acc)[2], int m) {   // the last step's results: nothing left to overlap with
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int nb = u >> 2, g = u & 3;
+      const u32x2 pk = {pack2_bf16(acc[nb][4 * g], acc[nb][4 * g + 1]), pack2_bf16(acc[nb][4 * g + 2], acc[nb][4 * g + 3])};
+      *reinterpret_cast<u32x2*>(patch + (fr * 128 + 8 * fh) + (((nb * 4 + g) ^ psw) << 4)) = pk;
+    }
+    char* cbase = reinterpret_cast<char*>(a.C) + ((int64_t)(m + wrb * 32) * a.ldc + cb) * 2;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4*>(cbase + coff[p]) = *reinterpret_cast<const f32x4*>(patch + poff[p]);
+  };
+  if (k < nsteps) {             // one more step: results end in acc_b
+    step(acc_b, acc_a, k, true);
+    drain(acc_b, mbeg + k * 64);
+  } else {
+    drain(acc_a, mbeg + (k - 1) * 64);
+  }
+}
+#undef PTD_FRAG
+
 template <int KC>
 void launch_shortk(const GemmBf16Args& a, bool c_bf16, int nsplit, int cols_per_split, dim3 grid, hipStream_t st) {
   constexpr int NB = KC <= 4 ? 2 : 1;  // K > 256: narrower B tiles keep two workgroups per CU in LDS
@@ -1157,6 +1353,12 @@ int gemm_bf16(const unsigned short* A, int64_t sam, int64_t sak, const unsigned 
     int rows_per_split = (int)align_up((size_t)ceil_div(M, msplit), 64);
     msplit = (int)ceil_div(M, rows_per_split);
     dim3 g((unsigned)(npanel * msplit), 1);
+    static const bool no_sk4 = getenv("PTD_GEMM_NO_SHORTK4") != nullptr;
+    if (c_bf16 && !bias && alpha == 1.0 && !no_sk4 && K == 256) {   // plain case: epilogue inside the next step's MFMA stream
+      hipLaunchKernelGGL((gemm_bf16_shortk4_kernel<4>), g, dim3(512), 0, st, a, msplit, rows_per_split);
+      PTD_CHECK_LAUNCH("gemm_bf16 (short K, epilogue interleaved)");
+      return PTD_OK;
+    }
     switch (K / 64) {
       case 1: launch_shortk3<1>(a, c_bf16, msplit, rows_per_split, g, st); break;
       case 2: launch_shortk3<2>(a, c_bf16, msplit, rows_per_split, g, st); break;
