@@ -163,7 +163,11 @@ def decomposed_forward_lines(device):
     x = torch.randn(t_rows, N_FEAT, generator=g).bfloat16().to(device)
     w = (torch.randn(N_FEAT, N_FEAT, generator=g) / 64).bfloat16().to(device)
     dense_t = time_events(lambda: ops.matmul(x, w.T), iters=10)
-    out = {"rows": t_rows, "dense_ms": dense_t * 1e3, "dense_tflops": 2 * t_rows * N_FEAT * N_FEAT / dense_t / 1e12}
+    # the same dense layer through torch (hipBLASLt): the baseline a user of the reference would have
+    lib_t = time_events(lambda: torch.nn.functional.linear(x, w), iters=10)
+    out = {"rows": t_rows, "dense_ms": dense_t * 1e3, "dense_tflops": 2 * t_rows * N_FEAT * N_FEAT / dense_t / 1e12,
+           "dense_torch_hipblaslt_ms": lib_t * 1e3,
+           "dense_torch_hipblaslt_tflops": 2 * t_rows * N_FEAT * N_FEAT / lib_t / 1e12}
     for r in (256, 512, 1024):
         a = (torch.randn(r, N_FEAT, generator=g) / 64).bfloat16().to(device)
         b = (torch.randn(N_FEAT, r, generator=g) / r**0.5).bfloat16().to(device)
@@ -171,6 +175,7 @@ def decomposed_forward_lines(device):
         fl = 2 * t_rows * r * 2 * N_FEAT
         by = 2 * (2 * t_rows * N_FEAT + 2 * r * N_FEAT)
         out[f"r{r}"] = {"ms": t * 1e3, "gflops": fl / t / 1e9, "speedup_vs_dense": dense_t / t,
+                        "speedup_vs_dense_torch_hipblaslt": lib_t / t,
                         "frac_of_bf16_mfma_peak": fl / t / PEAK_BF16_MFMA, "hbm_gbps_algorithmic": by / t / 1e9}
     # MFMA utilisation of the two rank-256 kernels from the committed counter pass (tools/pmc_driver mfma)
     import glob
