@@ -1,0 +1,66 @@
+"""Guards on the generated gfx950 code of the LDS-DMA kernels (hipcc cross-compiles without a GPU).
+
+ROCm 7.2's hipcc once sank the LDS reads of a register-resident operand panel below the barrier that
+protects the image they read (their values are first used in the main loop), leaving two `s_barrier`
+back to back and the refill DMA racing the reads.  The sources pin those reads; this test fails if a
+toolchain or source change brings the pattern back, or spills the deep-pipelined kernels to scratch."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "ptdeco_amd", "csrc")
+
+
+def _device_asm(src, tmp_path):
+    hipcc = shutil.which(os.environ.get("HIPCC", "hipcc"))
+    if hipcc is None:
+        pytest.skip("hipcc not on PATH")
+    out = tmp_path / (src + ".s")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", str(out),
+                    os.path.join(CSRC, src)], check=True, capture_output=True, timeout=300)
+    return out.read_text().split("\n")
+
+
+def _functions(lines):
+    name, body = None, []
+    for line in lines:
+        m = re.match(r"^(_Z\S+):", line)
+        if m:
+            name, body = m.group(1), []
+        elif line.startswith(".Lfunc_end") and name:
+            yield name, body
+            name = None
+        elif name:
+            body.append(line)
+
+
+def test_lds_dma_kernels_keep_their_barrier_structure(tmp_path):
+    lines = _device_asm("gemm_bf16.hip", tmp_path)
+    seen = 0
+    for name, body in _functions(lines):
+        code = [l.strip() for l in body if l.strip() and not l.strip().startswith(";")]
+        for a, b in zip(code, code[1:]):
+            assert not (a.startswith("s_barrier") and b.startswith("s_barrier")), f"adjacent barriers in {name}"
+        if "shortk" in name:
+            seen += 1
+            # preload: [DMA ...] barrier [fragment reads] barrier -- the reads must sit between the first two barriers
+            bars = [i for i, l in enumerate(code) if l.startswith("s_barrier")]
+            assert len(bars) >= 2, name
+            between = code[bars[0]:bars[1]]
+            assert any(l.startswith("ds_read_b128") for l in between), f"panel reads left the barrier pair in {name}"
+            assert not any(l.startswith("global_load_lds") for l in between), name
+    assert seen >= 8
+
+
+def test_deep_pipelined_kernels_do_not_spill(tmp_path):
+    for src in ("gemm_bf16.hip", "gemm_f32.hip"):
+        text = "\n".join(_device_asm(src, tmp_path))
+        found = 0
+        for m in re.finditer(r"\.set (\S*(?:8ph|shortk[34])\S*)\.private_seg_size, (\d+)", text):
+            found += 1
+            assert int(m.group(2)) == 0, f"{m.group(1)} spills {m.group(2)} bytes of scratch"
+        assert found >= 2, src
