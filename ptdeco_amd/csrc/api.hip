@@ -135,7 +135,7 @@ int ptd_gemm(const void* A, int64_t sam, int64_t sak, const void* B, int64_t sbk
   if (ab_dtype == PTD_BF16 && (c_dtype == PTD_BF16 || c_dtype == PTD_F32))
     return gemm_bf16(static_cast<const unsigned short*>(A), sam, sak, static_cast<const unsigned short*>(B), sbk,
                      sbn, C, ldc, M, N, K, c_dtype == PTD_BF16, alpha, static_cast<const unsigned short*>(bias),
-                     st);
+                     nullptr, 0, st);
   if (ab_dtype == PTD_F64 && c_dtype == PTD_F64 && !bias)
     return gemm_f64(static_cast<const double*>(A), sam, sak, static_cast<const double*>(B), sbk, sbn,
                     static_cast<double*>(C), ldc, M, N, K, alpha, false, 1, st);
@@ -148,6 +148,7 @@ static size_t elt_bytes(int dtype) { return dtype == PTD_F32 ? 4 : 2; }
 size_t ptd_lowrank_forward_workspace_bytes(int64_t T, int64_t n_i, int64_t r, int dtype) {
   size_t b = align_up((size_t)T * (size_t)r * elt_bytes(dtype), 256);
   if (dtype == PTD_F32) b += gemm_f32_workspace_bytes(T, r, n_i);
+  else b += gemm_bf16_workspace_bytes(T, r, n_i);
   return b;
 }
 
@@ -172,7 +173,9 @@ int ptd_lowrank_forward(const void* x, int64_t ldx, int64_t T, int64_t n_i, cons
                   T, r, n_i, 1.0, nullptr, static_cast<char*>(ws) + h_bytes, ws_bytes - h_bytes,
                   static_cast<hipStream_t>(stream));
   } else {
-    rc = ptd_gemm(x, ldx, 1, A, 1, lda, h, r, T, r, n_i, dtype, dtype, 1.0, nullptr, stream);
+    rc = gemm_bf16(static_cast<const unsigned short*>(x), ldx, 1, static_cast<const unsigned short*>(A), 1, lda, h, r,
+                   T, r, n_i, true, 1.0, nullptr, static_cast<char*>(ws) + h_bytes, ws_bytes - h_bytes,
+                   static_cast<hipStream_t>(stream));
   }
   if (rc != PTD_OK) return rc;
   return ptd_gemm(h, r, 1, B, 1, ldb, y, ldy, T, n_o, r, dtype, dtype, 1.0, bias, stream);

@@ -52,6 +52,7 @@ struct GemmBf16Args {
   int kchunk;
   int atomic;
   int vecA, vecB;
+  int64_t cslab;  // split K of the LDS-DMA kernel: blockIdx.y writes its f32 partial tile to C + y * cslab
 };
 
 // f32 -> bf16, round to nearest even, NaN stays NaN: gfx950's v_cvt_pk_bf16_f32 (one VALU instruction
@@ -261,9 +262,9 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 1) void gemm_bf16_nt_glds_kern
   const int gsz = min(a.tiles_m - first, 8);
   const int ti = first + (wg % width) % gsz, tj = (wg % width) / gsz;
   const int m0 = ti * BM, n0 = tj * BN;
-  const int nk = a.K / BK;
-  const unsigned short* Ag = a.A + (int64_t)m0 * a.sam;
-  const unsigned short* Bg = a.B + (int64_t)n0 * a.sbn;
+  const int nk = a.kchunk / BK;                 // blockIdx.y = K range (split K: partial tiles to f32 slabs)
+  const unsigned short* Ag = a.A + (int64_t)m0 * a.sam + (int64_t)blockIdx.y * a.kchunk;
+  const unsigned short* Bg = a.B + (int64_t)n0 * a.sbn + (int64_t)blockIdx.y * a.kchunk;
 
   // this lane's share of a staging instruction: row (lane >> 3) of an 8-row group, position lane & 7
   const int srow = lane >> 3, spos = lane & 7;
@@ -372,7 +373,7 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 1) void gemm_bf16_nt_glds_kern
     const int q = tid + 256 * p;
     const int lr = q / CHUNKS, ch = q % CHUNKS;
     const f32x4 v = *reinterpret_cast<const f32x4*>(lds + lr * CP + ch * 16);
-    char* dst = reinterpret_cast<char*>(a.C) + ((int64_t)(m0 + lr) * a.ldc + n0) * ES + ch * 16;
+    char* dst = reinterpret_cast<char*>(a.C) + ((int64_t)blockIdx.y * a.cslab + (int64_t)(m0 + lr) * a.ldc + n0) * ES + ch * 16;
     *reinterpret_cast<f32x4*>(dst) = v;
   }
 }
@@ -1286,6 +1287,52 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_shortk4_kernel(const GemmBf1
 }
 #undef PTD_FRAG
 
+// second pass of the split K: C = alpha * (slab_0 + slab_1 + ...) + bias, slabs added in index order
+// (deterministic); a thread owns 8 consecutive columns of one row
+template <bool C_BF16>
+__global__ __launch_bounds__(256) void splitk_reduce_bf16_kernel(const float* __restrict__ slabs, int ksplit, int64_t cslab,
+                                                                 int M, int N, float alpha,
+                                                                 const unsigned short* __restrict__ bias,
+                                                                 void* __restrict__ C, int64_t ldc) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int n8 = N / 8;
+  if (idx >= (int64_t)M * n8) return;
+  const int row = (int)(idx / n8), c0 = (int)(idx % n8) * 8;
+  const float* p = slabs + (int64_t)row * N + c0;
+  f32x4 lo = *reinterpret_cast<const f32x4*>(p), hi = *reinterpret_cast<const f32x4*>(p + 4);
+  for (int z = 1; z < ksplit; ++z) {
+    lo += *reinterpret_cast<const f32x4*>(p + z * cslab);
+    hi += *reinterpret_cast<const f32x4*>(p + z * cslab + 4);
+  }
+  float o[8];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { o[e] = alpha * lo[e]; o[4 + e] = alpha * hi[e]; }
+  if (bias) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] += bf16_to_f32(bias[c0 + e]);
+  }
+  if (C_BF16) {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 v = {pack2_bf16(o[0], o[1]), pack2_bf16(o[2], o[3]), pack2_bf16(o[4], o[5]), pack2_bf16(o[6], o[7])};
+    *reinterpret_cast<u32x4*>(static_cast<unsigned short*>(C) + (int64_t)row * ldc + c0) = v;
+  } else {
+    float* q = static_cast<float*>(C) + (int64_t)row * ldc + c0;
+    *reinterpret_cast<f32x4*>(q) = f32x4{o[0], o[1], o[2], o[3]};
+    *reinterpret_cast<f32x4*>(q + 4) = f32x4{o[4], o[5], o[6], o[7]};
+  }
+}
+
+// K split of a skinny nn.Linear-layout product (x A^T at a few thousand rows: 64 tiles for T = 4096, r = 256 leave
+// three quarters of the CUs idle): 1 = no split
+int gemm_bf16_ksplit(int64_t M, int64_t N, int64_t K) {
+  if (M % BM || N % BN || K % BK || K < 1024) return 1;
+  const int64_t tiles = (M / BM) * (N / BN);
+  if (tiles > 128) return 1;
+  int ks = 1;
+  while (ks * 2 * tiles <= 256 && K % (ks * 2 * BK) == 0 && K / (ks * 2) >= 512) ks *= 2;
+  return ks;
+}
+
 template <int KC>
 void launch_shortk(const GemmBf16Args& a, bool c_bf16, int nsplit, int cols_per_split, dim3 grid, hipStream_t st) {
   constexpr int NB = KC <= 4 ? 2 : 1;  // K > 256: narrower B tiles keep two workgroups per CU in LDS
@@ -1321,9 +1368,14 @@ void launch_bf16(const GemmBf16Args& a, bool akc, bool bkc, dim3 grid, hipStream
 
 }  // namespace
 
+size_t gemm_bf16_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+  const int ks = gemm_bf16_ksplit(M, N, K);
+  return ks > 1 ? (size_t)ks * (size_t)M * (size_t)N * sizeof(float) : 0;
+}
+
 int gemm_bf16(const unsigned short* A, int64_t sam, int64_t sak, const unsigned short* B, int64_t sbk, int64_t sbn,
               void* C, int64_t ldc, int64_t M, int64_t N, int64_t K, bool c_bf16, double alpha,
-              const unsigned short* bias, hipStream_t st) {
+              const unsigned short* bias, void* ws, size_t ws_bytes, hipStream_t st) {
   PTD_REQUIRE((sam == 1) != (sak == 1) || (M == 1 || K == 1), "ptd_gemm: exactly one stride of A must be 1");
   PTD_REQUIRE((sbk == 1) != (sbn == 1) || (N == 1 || K == 1), "ptd_gemm: exactly one stride of B must be 1");
   if (M == 0 || N == 0) return PTD_OK;
@@ -1342,6 +1394,27 @@ int gemm_bf16(const unsigned short* A, int64_t sam, int64_t sak, const unsigned 
   static const bool no_glds = getenv("PTD_GEMM_NO_GLDS") != nullptr;
   static const bool no_shortk = getenv("PTD_GEMM_NO_SHORTK") != nullptr;
   const bool c_vec = aligned16(C) && (ldc * (c_bf16 ? 2 : 4)) % 16 == 0;  // 16-byte row-contiguous output stores
+  a.cslab = 0;
+  if (ws && !no_glds && akc && bkc && a.vecA && a.vecB && c_vec && ldc % 8 == 0) {
+    const int ks = gemm_bf16_ksplit(M, N, K);
+    if (ks > 1 && (size_t)ks * (size_t)M * (size_t)N * sizeof(float) <= ws_bytes && aligned16(ws)) {
+      // few output tiles: K range over blockIdx.y into f32 slabs, then the slabs are added in index order
+      GemmBf16Args p = a;
+      p.C = ws; p.ldc = N; p.cslab = M * N; p.kchunk = (int)(K / ks); p.alpha = 1.f; p.bias = nullptr;
+      dim3 g2(grid.x, (unsigned)ks);
+      if (K / ks >= 4 * BK) hipLaunchKernelGGL((gemm_bf16_nt_glds_kernel<EPI_STORE_F32, 4>), g2, dim3(256), 0, st, p);
+      else hipLaunchKernelGGL((gemm_bf16_nt_glds_kernel<EPI_STORE_F32, 2>), g2, dim3(256), 0, st, p);
+      const int64_t items = M * (N / 8);
+      if (c_bf16)
+        hipLaunchKernelGGL((splitk_reduce_bf16_kernel<true>), dim3((unsigned)ceil_div(items, 256)), dim3(256), 0, st,
+                           static_cast<const float*>(ws), ks, p.cslab, (int)M, (int)N, (float)alpha, bias, C, ldc);
+      else
+        hipLaunchKernelGGL((splitk_reduce_bf16_kernel<false>), dim3((unsigned)ceil_div(items, 256)), dim3(256), 0, st,
+                           static_cast<const float*>(ws), ks, p.cslab, (int)M, (int)N, (float)alpha, bias, C, ldc);
+      PTD_CHECK_LAUNCH("gemm_bf16 (split K)");
+      return PTD_OK;
+    }
+  }
   static const bool shortk_old = getenv("PTD_GEMM_SHORTK_OLD") != nullptr;
   static const bool shortk_4w = getenv("PTD_GEMM_SHORTK_4W") != nullptr;
   if (!no_glds && !no_shortk && !shortk_old && !shortk_4w && akc && bkc && a.vecA && a.vecB && N % 256 == 0 && M % 64 == 0 &&

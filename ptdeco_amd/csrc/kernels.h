@@ -16,7 +16,8 @@ int syrk_f32(const float* Y, int64_t T, int64_t n, int64_t ldy, void* E, int64_t
 // gemm_bf16.hip
 int gemm_bf16(const unsigned short* A, int64_t sam, int64_t sak, const unsigned short* B, int64_t sbk, int64_t sbn,
               void* C, int64_t ldc, int64_t M, int64_t N, int64_t K, bool c_bf16, double alpha,
-              const unsigned short* bias, hipStream_t st);
+              const unsigned short* bias, void* ws, size_t ws_bytes, hipStream_t st);
+size_t gemm_bf16_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int syrk_bf16(const unsigned short* Y, int64_t T, int64_t n, int64_t ldy, void* E, int64_t ldE, bool e_f64,
               double scale, hipStream_t st);
 

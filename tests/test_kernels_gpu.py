@@ -383,6 +383,23 @@ def test_gemm_bf16_256_tile_deep_pipeline_exact_and_repeatable(ops):
     assert torch.equal(got.float(), (x_v.float() @ w_v.float().T).to(torch.bfloat16).float())
 
 
+def test_lowrank_forward_bf16_split_k_first_product_exact(ops):
+    """Few rows (T = 4096 and below): x A^T has at most 128 output tiles, so its K range is split over
+    blockIdx.y into f32 slabs of the workspace and a second launch adds them in index order.  Integer
+    operands: every partial sum is exact, the result must equal the unsplit product bit for bit."""
+    g = torch.Generator().manual_seed(12)
+    for (T, n_i, r, n_o) in [(4096, 4096, 256, 4096), (1024, 4096, 128, 512), (2048, 2048, 512, 1024), (4096, 1024, 256, 256)]:
+        x = torch.randint(-2, 3, (T, n_i), generator=g).to(torch.bfloat16).to(DEV)
+        a = torch.randint(-2, 3, (r, n_i), generator=g).to(torch.bfloat16).to(DEV)
+        b = torch.randint(-1, 2, (n_o, r), generator=g).to(torch.bfloat16).to(DEV)
+        bias = torch.randint(-3, 4, (n_o,), generator=g).to(torch.bfloat16).to(DEV)
+        h = (x.float() @ a.float().T).to(torch.bfloat16).float()
+        want = (h @ b.float().T + bias.float()).to(torch.bfloat16)
+        for rep in range(3):
+            got = ops.lowrank_forward(x, a, b, bias)
+            assert torch.equal(got, want), (T, n_i, r, n_o, rep)
+
+
 def test_gemm_f32_256_tile_deep_pipeline_exact_and_repeatable(ops):
     """f32 nn.Linear layout, M, N % 256 == 0, K % 64 == 0, >= 192 tiles: the 256 x 256 / 8-wave kernel with the
     bf16 kernel's LDS-DMA schedule and four 32x32x2 MFMAs per 16-byte fragment.  Integer operands: every

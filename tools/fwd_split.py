@@ -20,5 +20,8 @@ for T in (4096, 16384, 65536):
         b = torch.randn(4096, r, device=dev, dtype=torch.bfloat16) / r ** 0.5
         h = ops.matmul(x, a.T)
         t1 = t(lambda: ops.matmul(x, a.T)); t2 = t(lambda: ops.matmul(h, b.T)); tf = t(lambda: ops.lowrank_forward(x, a, b, None))
+        F = torch.nn.functional
+        l1 = t(lambda: F.linear(x, a)); l2 = t(lambda: F.linear(h, b)); lf = t(lambda: F.linear(F.linear(x, a), b))
+        print(f"  r={r}: torch/hipBLASLt x@A^T {l1*1e3:.0f} us, h@B^T {l2*1e3:.0f} us, pair {lf*1e3:.0f} us")
         mem = 2 * (T * 4096 * 2) / 5.0e12 * 1e6
         print(f"  r={r}: x@A^T {t1*1e3:.0f} us, h@B^T {t2*1e3:.0f} us, pair {tf*1e3:.0f} us (HBM floor ~{mem:.0f} us, MFMA floor {2*T*r*8192/2.5e15*1e6:.0f} us)")
