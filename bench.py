@@ -174,8 +174,11 @@ def decomposed_forward_lines(device):
         t = time_events(lambda: ops.lowrank_forward(x, a, b, None), iters=10)
         fl = 2 * t_rows * r * 2 * N_FEAT
         by = 2 * (2 * t_rows * N_FEAT + 2 * r * N_FEAT)
+        # the same pair as two torch.nn.functional.linear calls (hipBLASLt): what apply_decompose_config_in_place's
+        # Sequential(Linear, Linear) costs without the fused module
+        lib_pair = time_events(lambda: torch.nn.functional.linear(torch.nn.functional.linear(x, a), b), iters=10)
         out[f"r{r}"] = {"ms": t * 1e3, "gflops": fl / t / 1e9, "speedup_vs_dense": dense_t / t,
-                        "speedup_vs_dense_torch_hipblaslt": lib_t / t,
+                        "speedup_vs_dense_torch_hipblaslt": lib_t / t, "torch_hipblaslt_pair_ms": lib_pair * 1e3,
                         "frac_of_bf16_mfma_peak": fl / t / PEAK_BF16_MFMA, "hbm_gbps_algorithmic": by / t / 1e9}
     # MFMA utilisation of the two rank-256 kernels from the committed counter pass (tools/pmc_driver mfma)
     import glob
