@@ -726,7 +726,7 @@ __global__ __launch_bounds__(64) void tridiag_invit_kernel(const double* __restr
                                                           int n, const double* __restrict__ lam,
                                                           const double* __restrict__ bounds, int nvec, InvitWs ws,
                                                           double* __restrict__ Y, int64_t ldy) {
-  const int k = blockIdx.x * 64 + threadIdx.x;
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= nvec) return;
   const double tnorm = bounds[3];
   const double tiny = fmax(2.220446049250313e-16 * tnorm, 2.2250738585072014e-308 * 4.0);
@@ -761,7 +761,7 @@ __global__ __launch_bounds__(64) void tridiag_invit_kernel(const double* __restr
 
   // Each step of the two substitution sweeps depends on the previous one only through one
   // register, so the operands of 8 steps are fetched together (one latency per 8 steps).
-  constexpr int UB = 8;
+  constexpr int UB = 12;  // 4 arrays x 12 rows = 48 loads per lane in flight (the counter holds 63; 16 rows stall, 15 = 12)
   double carry = 1.0;  // scale of the iterate in memory, applied on the next read
   for (int it = 0; it < 3; ++it) {
     // forward: apply the row interchanges and L^-1
@@ -1272,6 +1272,8 @@ int tridiag_vectors_and_backtransform(const TridiagPlan& p, char* base, int nvec
   ws.Lm = reinterpret_cast<double*>(base + p.off_lm);
   ws.sw = reinterpret_cast<unsigned char*>(base + p.off_sw);
   const double* lamk = lam + (n - nvec);  // the nvec largest eigenvalues, ascending
+  // (the recurrences are sequential in the row index and latency bound -- one round trip per 12 rows --, every wave
+  // runs the same chain, so fewer lanes per wave / more waves do not shorten the launch: measured 64 = 32 = 16 = 8)
   hipLaunchKernelGGL(tridiag_invit_kernel, dim3((unsigned)ceil_div(nvec, 64)), dim3(64), 0, st, d, e, n, lamk, bounds,
                      nvec, ws, Y, ldy);
   if (ortol > 0.0)
