@@ -510,7 +510,10 @@ __global__ __launch_bounds__(256) void sytrd_alpha_kernel(const double* __restri
     e[j] = beta;
     d[j] = colbuf[j] - delta;  // x_j[j] = base_j[j] - delta v_{j-1}[j], v_{j-1}[j] = 1 (delta = 0 if i == 0)
   }
-  if (tid < i) {
+  if (tid < NB) {
+    // coefficient k is stored at (k & 3) * 16 + (k >> 2): the sixteen a wave needs below (k = wid, wid + 4, ...)
+    // are contiguous, and the entries k >= i are ZERO (their registers were initialised to zero), so the panel
+    // dot products need neither a bound check nor a branch per term
     const double c2v = r_qV + scale * r_sdV;
     double c1v = r_qW + scale * r_sdW;
     double wj = r_wj1;
@@ -518,7 +521,8 @@ __global__ __launch_bounds__(256) void sytrd_alpha_kernel(const double* __restri
       c1v += a2prev * c2v;
       wj += a2prev * r_vpjn;
     }
-    c1[tid] = c1v; c2[tid] = c2v; vj1[tid] = r_vj1; wj1[tid] = wj;
+    const int pos = (tid & 3) * 16 + (tid >> 2);
+    c1[pos] = c1v; c2[pos] = c2v; vj1[pos] = r_vj1; wj1[pos] = wj;
   }
   if (wid == 0) {
     double vr = 0.0, wf = 0.0;
@@ -537,20 +541,27 @@ __global__ __launch_bounds__(256) void sytrd_alpha_kernel(const double* __restri
   __syncthreads();
   if (wid == 1) {  // w_raw_j[jn], needed by every row of the next column
     double sacc = 0.0;
-    for (int k = lane; k < i; k += 64) sacc += vj1[k] * c1[k] + wj1[k] * c2[k];
+    static_assert(NB == 64, "one coefficient per lane");
+    const int pos = (lane & 3) * 16 + (lane >> 2);   // lane = k; zeros beyond k = i - 1
+    sacc = vj1[pos] * c1[pos] + wj1[pos] * c2[pos];
     sacc = wave_sum_d(sacc);
     if (lane == 0) wrj_s = tau * ((qv_jn + scale * sd_jn) - sacc);
   }
+  // straight-line: with a bound check per term the sixteen iterations each paid an LDS round trip behind a
+  // branch (2,467 of the launch's ~13,000 cycles, clock64); here the 64 coefficient reads issue back to back
   double a1 = 0.0, a2 = 0.0;
+  const double wfl = wfs[lane];
+  const double* cc1 = c1 + wid * 16;
+  const double* cc2 = c2 + wid * 16;
+  const double* cw = wj1 + wid * 16;
+  const double* cv = vj1 + wid * 16;
 #pragma unroll
   for (int q = 0; q < NB / 4; ++q) {
     const int k = wid + 4 * q;
-    if (k < i) {
-      const double vk = pv[q];
-      const double wk = (k == i - 1) ? wfs[lane] : pw[q];
-      a1 += vk * c1[k] + wk * c2[k];
-      a2 += vk * wj1[k] + wk * vj1[k];
-    }
+    const double vk = pv[q];                           // zero for k >= i
+    const double wk = (k == i - 1) ? wfl : pw[q];      // pw is zero for k >= i - 1
+    a1 += vk * cc1[q] + wk * cc2[q];
+    a2 += vk * cw[q] + wk * cv[q];
   }
   part1[wid][lane] = a1;
   part2[wid][lane] = a2;
