@@ -736,7 +736,7 @@ __device__ __forceinline__ double hash_uniform(unsigned int i, unsigned int k) {
 __global__ __launch_bounds__(64) void tridiag_invit_kernel(const double* __restrict__ d, const double* __restrict__ e,
                                                           int n, const double* __restrict__ lam,
                                                           const double* __restrict__ bounds, int nvec, InvitWs ws,
-                                                          double* __restrict__ Y, int64_t ldy) {
+                                                          double* __restrict__ Y, int64_t ldy, const int niter) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= nvec) return;
   const double tnorm = bounds[3];
@@ -774,7 +774,7 @@ __global__ __launch_bounds__(64) void tridiag_invit_kernel(const double* __restr
   // register, so the operands of 8 steps are fetched together (one latency per 8 steps).
   constexpr int UB = 12;  // 4 arrays x 12 rows = 48 loads per lane in flight (the counter holds 63; 16 rows stall, 15 = 12)
   double carry = 1.0;  // scale of the iterate in memory, applied on the next read
-  for (int it = 0; it < 3; ++it) {
+  for (int it = 0; it < niter; ++it) {
     // forward: apply the row interchanges and L^-1
     double cur = y[0] * carry;
     for (int i0 = 0; i0 < n - 1; i0 += UB) {
@@ -1266,7 +1266,7 @@ int tridiag_eigenvalues(const TridiagPlan& p, char* base, int first, hipStream_t
 
 // eigenvectors of T for all eigenvalues into Y (= evecs, [n][ldv]), then Y <- Q Y
 int tridiag_vectors_and_backtransform(const TridiagPlan& p, char* base, int nvec, double* Y, int64_t ldy,
-                                      double ortol, hipStream_t st) {
+                                      double ortol, int niter, hipStream_t st) {
   const int n = p.n;
   const int64_t ld = p.ld;
   double* d = reinterpret_cast<double*>(base + p.off_d);
@@ -1286,7 +1286,7 @@ int tridiag_vectors_and_backtransform(const TridiagPlan& p, char* base, int nvec
   // (the recurrences are sequential in the row index and latency bound -- one round trip per 12 rows --, every wave
   // runs the same chain, so fewer lanes per wave / more waves do not shorten the launch: measured 64 = 32 = 16 = 8)
   hipLaunchKernelGGL(tridiag_invit_kernel, dim3((unsigned)ceil_div(nvec, 64)), dim3(64), 0, st, d, e, n, lamk, bounds,
-                     nvec, ws, Y, ldy);
+                     nvec, ws, Y, ldy, niter);
   if (ortol > 0.0)
     hipLaunchKernelGGL(tridiag_chain_mgs_kernel, dim3((unsigned)nvec), dim3(256), 0, st, lamk, n, nvec, bounds, ortol,
                        Y, ldy);
@@ -1381,7 +1381,12 @@ int eigh_tridiag(const double* A, int64_t lda, int64_t n, int64_t k, double* eva
     cleanup();
     return PTD_ERR_UNSUPPORTED;
   }
-  rc = tridiag_vectors_and_backtransform(p, base, (int)k, evecs, ldv, h_gap[1] > 0.0 ? ortol : 0.0, st);
+  // Inverse iteration from a random start with eigenvalues exact to working precision: an iteration damps the
+  // component along a neighbour by ~eps |T| / gap, so with every relative gap above 1e-5 two iterations leave it
+  // below 1e-21; closer spectra keep the third (and the re-orthogonalisation above 1e-7)
+  static const int force_iter = getenv("PTD_INVIT_ITERS") ? atoi(getenv("PTD_INVIT_ITERS")) : 0;
+  const int niter = force_iter > 0 ? force_iter : (h_gap[0] > 1e-5 ? 2 : 3);
+  rc = tridiag_vectors_and_backtransform(p, base, (int)k, evecs, ldv, h_gap[1] > 0.0 ? ortol : 0.0, niter, st);
   if (rc != PTD_OK) { cleanup(); return rc; }
   PTD_CHECK_HIP(hipMemcpyAsync(evals, lam, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
   if (stats) {
