@@ -646,20 +646,19 @@ __global__ void tridiag_bounds_kernel(const double* __restrict__ d, const double
 // clamp on the critical path of every row (~210 cycles per row measured: 3.7 ms per matrix with the chip
 // idle behind one wave per eigenvalue); here the dependent chain is ONE fma per row, everything else
 // (d_k - x, e^2 p_{k-1}, the sign bookkeeping) is off it.  Entries are scaled by 1 / ||T|| so that a minor
-// grows by at most ~3x per row, and both running minors are renormalised by a power of two every 8 rows
+// grows by at most ~3x per row (scale_tridiag_kernel prepares d / ||T|| and (e / ||T||)^2 once), and both running minors are renormalised by a power of two every 8 rows
 // (exponent arithmetic only: no rounding).  An exactly zero minor counts as positive, which gives the
 // same total as LAPACK's "pivot = -pivmin" rule (the next minor then has the sign opposite to the one
 // before the zero).
-__device__ __forceinline__ int sturm_count(const double* __restrict__ d, const double* __restrict__ e2, int n,
-                                           double x, double s) {
-  double pm = 1.0, p = (d[0] - x) * s;
+__device__ __forceinline__ int sturm_count(const double* __restrict__ ds, const double* __restrict__ es2, int n,
+                                           double xs) {
+  double pm = 1.0, p = ds[0] - xs;
   int cnt = p < 0.0;
   int k = 1;
   for (; k + 8 <= n; k += 8) {
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      const double a = (d[k + u] - x) * s, b = (e2[k + u - 1] * s) * s;   // (e^2 s) s: no underflow of s^2 alone
-      const double pn = fma(a, p, -(b * pm));
+      const double pn = fma(ds[k + u] - xs, p, -(es2[k + u - 1] * pm));
       cnt += (pn < 0.0) != (p < 0.0);
       pm = p; p = pn;
     }
@@ -673,8 +672,7 @@ __device__ __forceinline__ int sturm_count(const double* __restrict__ d, const d
     }
   }
   for (; k < n; ++k) {
-    const double a = (d[k] - x) * s, b = (e2[k - 1] * s) * s;
-    const double pn = fma(a, p, -(b * pm));
+    const double pn = fma(ds[k] - xs, p, -(es2[k - 1] * pm));
     cnt += (pn < 0.0) != (p < 0.0);
     pm = p; p = pn;
   }
@@ -684,8 +682,8 @@ __device__ __forceinline__ int sturm_count(const double* __restrict__ d, const d
 // One wave per eigenvalue index k: every round the 64 lanes count the eigenvalues below 64
 // interior points of the current bracket (multisection), which shrinks it 65-fold -- 9 rounds
 // from the Gershgorin interval to machine precision instead of 53 bisection steps.
-__global__ __launch_bounds__(256) void tridiag_bisect_kernel(const double* __restrict__ d,
-                                                             const double* __restrict__ e2, int n,
+__global__ __launch_bounds__(256) void tridiag_bisect_kernel(const double* __restrict__ ds,
+                                                             const double* __restrict__ es2, int n,
                                                              const double* __restrict__ bounds,
                                                              double* __restrict__ lam, const int first) {
   const int k = first + blockIdx.x * 4 + (threadIdx.x >> 6);  // eigenvalue indices first .. n-1
@@ -700,7 +698,7 @@ __global__ __launch_bounds__(256) void tridiag_bisect_kernel(const double* __res
     const double h = (hi - lo) / 65.0;
     if (hi - lo <= 2.0 * eps * fmax(fabs(lo), fabs(hi)) + 2.0 * pivmin || !(h > 0.0)) break;
     const double x = lo + (double)(lane + 1) * h;
-    const int cnt = sturm_count(d, e2, n, x, sc);
+    const int cnt = sturm_count(ds, es2, n, x * sc);
     // lanes whose point is still <= lambda_k form a prefix; only the prefix is trusted (in floating point
     // the count of the product form need not be monotone within rounding distance of an eigenvalue)
     const unsigned long long ok = __ballot(cnt <= k);
@@ -1037,9 +1035,18 @@ __global__ __launch_bounds__(256) void wy_tv_kernel(const double* __restrict__ V
   }
 }
 
-__global__ void square_kernel(const double* __restrict__ e, int n, double* __restrict__ e2) {
+// T / ||T|| for the Sturm counts: ds = d / ||T||, es2 = (e / ||T||)^2 (bounds[3] = ||T|| from tridiag_bounds_kernel)
+__global__ void scale_tridiag_kernel(const double* __restrict__ d, const double* __restrict__ e, int n,
+                                     const double* __restrict__ bounds, double* __restrict__ ds,
+                                     double* __restrict__ es2) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k < n) e2[k] = e[k] * e[k];
+  const double tnorm = bounds[3];
+  const double s = tnorm > 0.0 ? 1.0 / tnorm : 1.0;
+  if (k < n) {
+    ds[k] = d[k] * s;
+    const double es = e[k] * s;
+    es2[k] = es * es;
+  }
 }
 
 __global__ void copy_pad_kernel(const double* __restrict__ A, int64_t lda, int n, double* __restrict__ B,
@@ -1057,7 +1064,7 @@ struct TridiagPlan {
   int n;
   int64_t ld;      // leading dimension of the working copy and of the V / W panels
   int npanels;
-  size_t off_A, off_V, off_W, off_col, off_p, off_part, off_refl, off_d, off_e, off_e2, off_tau, off_bounds, off_lam;
+  size_t off_A, off_V, off_W, off_col, off_p, off_part, off_refl, off_d, off_e, off_e2, off_ds, off_tau, off_bounds, off_lam;
   size_t off_u1, off_u2, off_u3, off_lm, off_sw, off_G, off_T, off_W1, off_W2, off_wraw, off_wraw2, off_part2, off_cbuf;
   size_t off_qv, off_px2, off_rowpart, off_colpart, off_gpart, off_tall;
   int64_t ldp;     // leading dimension of the symmetric SYMV's partial-result arrays
@@ -1089,6 +1096,7 @@ TridiagPlan tridiag_plan(int64_t n) {
   p.off_d = take((size_t)n * 8);
   p.off_e = take((size_t)n * 8);
   p.off_e2 = take((size_t)n * 8);
+  p.off_ds = take((size_t)n * 8);
   p.off_tau = take((size_t)n * 8);
   p.off_bounds = take(64);
   p.off_lam = take((size_t)n * 8);
@@ -1254,10 +1262,11 @@ int tridiag_eigenvalues(const TridiagPlan& p, char* base, int first, hipStream_t
   double* e2 = reinterpret_cast<double*>(base + p.off_e2);
   double* bounds = reinterpret_cast<double*>(base + p.off_bounds);
   double* lam = reinterpret_cast<double*>(base + p.off_lam);
-  hipLaunchKernelGGL(square_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, e, n, e2);
+  double* ds = reinterpret_cast<double*>(base + p.off_ds);
   hipLaunchKernelGGL(tridiag_bounds_kernel, dim3(1), dim3(1024), 0, st, d, e, n, bounds);
+  hipLaunchKernelGGL(scale_tridiag_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, d, e, n, bounds, ds, e2);
   if (first > 0) PTD_CHECK_HIP(hipMemsetAsync(lam, 0xFF, (size_t)first * 8, st));  // all-ones = NaN
-  hipLaunchKernelGGL(tridiag_bisect_kernel, dim3((unsigned)ceil_div(n - first, 4)), dim3(256), 0, st, d, e2, n, bounds,
+  hipLaunchKernelGGL(tridiag_bisect_kernel, dim3((unsigned)ceil_div(n - first, 4)), dim3(256), 0, st, ds, e2, n, bounds,
                      lam, first);
   PTD_CHECK_LAUNCH("tridiag_eigenvalues");
   return PTD_OK;
