@@ -748,34 +748,41 @@ __global__ __launch_bounds__(64) void tridiag_invit_kernel(const double* __restr
   unsigned char* __restrict__ sw = ws.sw + k;
   double* __restrict__ y = Y + k;
 
-  // factorisation
+  // factorisation, with the forward sweep of the FIRST iteration riding along: the start vector is a hash of
+  // (row, vector), so P L^-1 y0 needs nothing from memory and a separate latency-bound pass is saved
   double u = d[0] - lk, v = n > 1 ? e[0] : 0.0, w = 0.0;
+  double cur0 = hash_uniform(0u, (unsigned)k);
   for (int i = 0; i < n - 1; ++i) {
     const double b = e[i], a1 = d[i + 1] - lk, c1 = (i + 2 < n) ? e[i + 1] : 0.0;
+    double nxt = hash_uniform((unsigned)(i + 1), (unsigned)k);
+    double m;
     if (fabs(u) >= fabs(b)) {
       if (fabs(u) < tiny) u = (u < 0.0) ? -tiny : tiny;
-      const double ui = 1.0 / u, m = b * ui;
+      const double ui = 1.0 / u;
+      m = b * ui;
       U1i[i * S] = ui; U2[i * S] = v; U3[i * S] = w; Lm[i * S] = m; sw[i * S] = 0;
       u = a1 - m * v; v = c1 - m * w; w = 0.0;
     } else {
-      const double bi = 1.0 / b, m = u * bi;
+      const double bi = 1.0 / b;
+      m = u * bi;
       U1i[i * S] = bi; U2[i * S] = a1; U3[i * S] = c1; Lm[i * S] = m; sw[i * S] = 1;
       u = v - m * a1; v = w - m * c1; w = 0.0;
+      const double t = cur0; cur0 = nxt; nxt = t;
     }
+    y[(int64_t)i * ldy] = cur0;
+    cur0 = nxt - m * cur0;
   }
   if (fabs(u) < tiny) u = (u < 0.0) ? -tiny : tiny;
   U1i[(int64_t)(n - 1) * S] = 1.0 / u;
-
-  for (int i = 0; i < n; ++i) y[(int64_t)i * ldy] = hash_uniform((unsigned)i, (unsigned)k);
 
   // Each step of the two substitution sweeps depends on the previous one only through one
   // register, so the operands of 8 steps are fetched together (one latency per 8 steps).
   constexpr int UB = 12;  // 4 arrays x 12 rows = 48 loads per lane in flight (the counter holds 63; 16 rows stall, 15 = 12)
   double carry = 1.0;  // scale of the iterate in memory, applied on the next read
   for (int it = 0; it < niter; ++it) {
-    // forward: apply the row interchanges and L^-1
-    double cur = y[0] * carry;
-    for (int i0 = 0; i0 < n - 1; i0 += UB) {
+    // forward: apply the row interchanges and L^-1 (done above for the first iteration)
+    double cur = (it == 0) ? cur0 : y[0] * carry;
+    for (int i0 = (it == 0) ? n : 0; i0 < n - 1; i0 += UB) {
       double yn[UB], lm[UB];
       unsigned char s8[UB];
 #pragma unroll
@@ -831,14 +838,17 @@ __global__ __launch_bounds__(64) void tridiag_invit_kernel(const double* __restr
       carry = ss > 0.0 ? 1.0 / sqrt(ss) : 0.0;
     }
   }
-  for (int i0 = 0; i0 < n; i0 += UB) {
-    double yv[UB];
-#pragma unroll
-    for (int q = 0; q < UB; ++q) yv[q] = y[(int64_t)min(i0 + q, n - 1) * ldy];
-#pragma unroll
-    for (int q = 0; q < UB; ++q)
-      if (i0 + q < n) y[(int64_t)(i0 + q) * ldy] = yv[q] * carry;
-  }
+  // the final scaling is left to invit_scale_kernel (fully parallel over the matrix; done here it is one more
+  // latency-bound pass of n / UB round trips per lane): the factor goes to row 0 of this vector's Lm column
+  Lm[0] = carry;
+}
+
+// Y[:, k] *= scale[k]: the normalisation of the inverse-iteration vectors
+__global__ void invit_scale_kernel(double* __restrict__ Y, int64_t ldy, int n, int nvec, const double* __restrict__ scale) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nvec) return;
+  const double c = scale[k];
+  for (int i = blockIdx.y; i < n; i += gridDim.y) Y[(int64_t)i * ldy + k] *= c;
 }
 
 // smallest gap between consecutive eigenvalues relative to |T|, and the longest chain of
@@ -1296,6 +1306,8 @@ int tridiag_vectors_and_backtransform(const TridiagPlan& p, char* base, int nvec
   // runs the same chain, so fewer lanes per wave / more waves do not shorten the launch: measured 64 = 32 = 16 = 8)
   hipLaunchKernelGGL(tridiag_invit_kernel, dim3((unsigned)ceil_div(nvec, 64)), dim3(64), 0, st, d, e, n, lamk, bounds,
                      nvec, ws, Y, ldy, niter);
+  hipLaunchKernelGGL(invit_scale_kernel, dim3((unsigned)ceil_div(nvec, 256), 256), dim3(256), 0, st, Y, ldy, n, nvec,
+                     ws.Lm);
   if (ortol > 0.0)
     hipLaunchKernelGGL(tridiag_chain_mgs_kernel, dim3((unsigned)nvec), dim3(256), 0, st, lamk, n, nvec, bounds, ortol,
                        Y, ldy);
