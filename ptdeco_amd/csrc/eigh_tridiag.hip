@@ -650,15 +650,16 @@ __global__ void tridiag_bounds_kernel(const double* __restrict__ d, const double
 // (exponent arithmetic only: no rounding).  An exactly zero minor counts as positive, which gives the
 // same total as LAPACK's "pivot = -pivmin" rule (the next minor then has the sign opposite to the one
 // before the zero).
-__device__ __forceinline__ int sturm_count(const double* __restrict__ ds, const double* __restrict__ es2, int n,
-                                           double xs) {
-  double pm = 1.0, p = ds[0] - xs;
+template <typename Row>   // Row(k) -> {d_k / |T|, (e_{k-1} / |T|)^2}
+__device__ __forceinline__ int sturm_count(Row row, int n, double xs) {
+  double pm = 1.0, p = row(0).x - xs;
   int cnt = p < 0.0;
   int k = 1;
   for (; k + 8 <= n; k += 8) {
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      const double pn = fma(ds[k + u] - xs, p, -(es2[k + u - 1] * pm));
+      const double2 t = row(k + u);
+      const double pn = fma(t.x - xs, p, -(t.y * pm));
       cnt += (pn < 0.0) != (p < 0.0);
       pm = p; p = pn;
     }
@@ -672,7 +673,8 @@ __device__ __forceinline__ int sturm_count(const double* __restrict__ ds, const 
     }
   }
   for (; k < n; ++k) {
-    const double pn = fma(ds[k] - xs, p, -(es2[k - 1] * pm));
+    const double2 t = row(k);
+    const double pn = fma(t.x - xs, p, -(t.y * pm));
     cnt += (pn < 0.0) != (p < 0.0);
     pm = p; p = pn;
   }
@@ -682,10 +684,19 @@ __device__ __forceinline__ int sturm_count(const double* __restrict__ ds, const 
 // One wave per eigenvalue index k: every round the 64 lanes count the eigenvalues below 64
 // interior points of the current bracket (multisection), which shrinks it 65-fold -- 9 rounds
 // from the Gershgorin interval to machine precision instead of 53 bisection steps.
+// With LDS = true (n <= 4096) the workgroup first copies the scaled tridiagonal into LDS as {d_k, e_{k-1}^2} pairs
+// and the four waves read every row from there (one broadcast ds_read_b128, pipelined by the compiler): read as
+// wave-uniform scalar loads from memory, every batch of 8 rows waited for a scalar-memory round trip.
+template <bool LDS>
 __global__ __launch_bounds__(256) void tridiag_bisect_kernel(const double* __restrict__ ds,
                                                              const double* __restrict__ es2, int n,
                                                              const double* __restrict__ bounds,
                                                              double* __restrict__ lam, const int first) {
+  extern __shared__ double2 tri[];
+  if (LDS) {
+    for (int r = threadIdx.x; r < n; r += 256) tri[r] = double2{ds[r], r > 0 ? es2[r - 1] : 0.0};
+    __syncthreads();
+  }
   const int k = first + blockIdx.x * 4 + (threadIdx.x >> 6);  // eigenvalue indices first .. n-1
   const int lane = threadIdx.x & 63;
   if (k >= n) return;
@@ -698,7 +709,9 @@ __global__ __launch_bounds__(256) void tridiag_bisect_kernel(const double* __res
     const double h = (hi - lo) / 65.0;
     if (hi - lo <= 2.0 * eps * fmax(fabs(lo), fabs(hi)) + 2.0 * pivmin || !(h > 0.0)) break;
     const double x = lo + (double)(lane + 1) * h;
-    const int cnt = sturm_count(ds, es2, n, x * sc);
+    int cnt;
+    if (LDS) cnt = sturm_count([&](int r) { return tri[r]; }, n, x * sc);
+    else cnt = sturm_count([&](int r) { return double2{ds[r], r > 0 ? es2[r - 1] : 0.0}; }, n, x * sc);
     // lanes whose point is still <= lambda_k form a prefix; only the prefix is trusted (in floating point
     // the count of the product form need not be monotone within rounding distance of an eigenvalue)
     const unsigned long long ok = __ballot(cnt <= k);
@@ -1276,8 +1289,12 @@ int tridiag_eigenvalues(const TridiagPlan& p, char* base, int first, hipStream_t
   hipLaunchKernelGGL(tridiag_bounds_kernel, dim3(1), dim3(1024), 0, st, d, e, n, bounds);
   hipLaunchKernelGGL(scale_tridiag_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, d, e, n, bounds, ds, e2);
   if (first > 0) PTD_CHECK_HIP(hipMemsetAsync(lam, 0xFF, (size_t)first * 8, st));  // all-ones = NaN
-  hipLaunchKernelGGL(tridiag_bisect_kernel, dim3((unsigned)ceil_div(n - first, 4)), dim3(256), 0, st, ds, e2, n, bounds,
-                     lam, first);
+  if (n <= 4096)
+    hipLaunchKernelGGL((tridiag_bisect_kernel<true>), dim3((unsigned)ceil_div(n - first, 4)), dim3(256), (size_t)n * 16, st,
+                       ds, e2, n, bounds, lam, first);
+  else
+    hipLaunchKernelGGL((tridiag_bisect_kernel<false>), dim3((unsigned)ceil_div(n - first, 4)), dim3(256), 0, st, ds, e2,
+                       n, bounds, lam, first);
   PTD_CHECK_LAUNCH("tridiag_eigenvalues");
   return PTD_OK;
 }
