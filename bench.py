@@ -145,7 +145,7 @@ def kernel_lines(device):
     pmc = sorted(glob.glob(os.path.join(here, "profiles", "pmc_mfma_r*.json")))
     if pmc:
         kern = json.load(open(pmc[-1]))["kernels"]
-        for line, key in (("syrk_f32_f64acc", "syrk_f32_mixed_kernel"), ("gemm_f32_nt", "gemm_f32_kernel"),
+        for line, key in (("syrk_f32_f64acc", "syrk_f32_mixed_kernel"), ("gemm_f32_nt", "gemm_f32_nt_8ph_kernel"),
                           ("gemm_bf16_nt", "gemm_bf16_nt_8ph_kernel")):
             for name, c in kern.items():
                 if name.startswith(key) and "MfmaUtil" in c and line in lines:
@@ -185,7 +185,7 @@ def decomposed_forward_lines(device):
     pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc_mfma_r*.json")))
     if pmc:
         kern = json.load(open(pmc[-1]))["kernels"]
-        for label, key in (("x_At", "gemm_bf16_nt_glds_kernel<0, 4>"), ("h_Bt", "gemm_bf16_shortk3_kernel<4, 0>")):
+        for label, key in (("x_At", "gemm_bf16_nt_glds_kernel<0, 4>"), ("h_Bt", "gemm_bf16_shortk4_kernel<4>")):
             if key in kern and "MfmaUtil" in kern[key]:
                 out["r256"][f"mfma_util_pmc_percent_{label}"] = kern[key]["MfmaUtil"]
         out["r256"]["mfma_util_source"] = "profiles/" + os.path.basename(pmc[-1])

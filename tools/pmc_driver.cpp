@@ -45,7 +45,7 @@ static int run_mfma() {
   (void)hipMemcpy(Bf, hb.data(), n * r * 2, hipMemcpyHostToDevice);
   for (int rep = 0; rep < 3; ++rep) {
     int rc = ptd_gemm(Xf, n, 1, Af, 1, n, Hf, r, T, r, n, 2, 2, 1.0 / 64, nullptr, nullptr);
-    rc |= ptd_gemm(Hf, r, 1, Bf, 1, r, Yf, n, T, n, r, 2, 2, 1.0 / 16, nullptr, nullptr);
+    rc |= ptd_gemm(Hf, r, 1, Bf, 1, r, Yf, n, T, n, r, 2, 2, 1.0, nullptr, nullptr);   // alpha 1, no bias: the plain path
     if (rc) { fprintf(stderr, "mfma mode (forward) rc=%d: %s\n", rc, ptd_last_error()); return 1; }
   }
   (void)hipDeviceSynchronize();

@@ -14,7 +14,7 @@ for d in ("pmc_mfma", "pmc_mfma2"):
     f = sorted(glob.glob(os.path.join(root, "gpurun_out", d, "*", "*counter_collection.csv")), key=os.path.getmtime)[-1]
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f)):
-        nm = r["Kernel_Name"].replace("ptd::(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+        nm = r["Kernel_Name"].replace("ptd::(anonymous namespace)::", "").replace("ptd::", "").replace("void ", "").split("(")[0]
         agg[nm][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for nm, c in agg.items():
         out["kernels"].setdefault(nm, {}).update({k: sum(v) / len(v) for k, v in c.items()})
