@@ -162,6 +162,16 @@ int ptd_lowrank_forward(const void* x, int64_t ldx, int64_t T, int64_t n_i, cons
                         int64_t r, const void* B, int64_t ldb, int64_t n_o, const void* bias, void* y,
                         int64_t ldy, void* ws, size_t ws_bytes, int dtype, void* stream);
 
+/* The same pair for a 1x1-convolution input in NCHW layout, without the NHWC copy the reference makes
+ * (`permute(0,2,3,1).reshape(-1,C)`, dwain.py:116; falor.py:126): per image b, x_b = x + b*n_i*hw is an
+ * [n_i, hw] matrix with the hw = H*W pixels contiguous; h_b[r,hw] = A x_b, y_b[n_o,hw] = B h_b + bias[:,None],
+ * y written straight into NCHW (contiguous [batch, n_o, hw]).  The workspace holds h.  Replaces the two
+ * nn.Conv2d(kernel_size=1) of dwain.py:126-144 / falor.py:136-153. */
+size_t ptd_lowrank_forward_nchw_workspace_bytes(int64_t batch, int64_t hw, int64_t r, int dtype);
+int ptd_lowrank_forward_nchw(const void* x, int64_t batch, int64_t n_i, int64_t hw, const void* A, int64_t lda,
+                             int64_t r, const void* B, int64_t ldb, int64_t n_o, const void* bias, void* y,
+                             void* ws, size_t ws_bytes, int dtype, void* stream);
+
 /* ---- rank-selection metrics ------------------------------------------------ */
 
 /* out[0] (f64) = mean_c( mean_r (x-y)^2 / (var_r(y) + eps) ), x,y viewed as [R, C],
@@ -176,6 +186,10 @@ int ptd_nsr(const void* x, const void* y, int64_t R, int64_t C, int dtype, doubl
 size_t ptd_sym_kl_workspace_bytes(int64_t B);
 int ptd_sym_kl(const void* s, const void* t, int64_t B, int64_t C, int dtype, double* out, void* ws,
                size_t ws_bytes, void* stream);
+
+/* rows[b] (f64) = KL(p_b || q_b) = sum_c p log(p / q) over softmax(dim=-1) of logits q, p [B, C].
+ * Replaces calc_kl_divergence(q_logits, p_logits) (losses.py:48-54). */
+int ptd_kl_rows(const void* q, const void* p, int64_t B, int64_t C, int dtype, double* rows, void* stream);
 
 #ifdef __cplusplus
 }

@@ -18,7 +18,7 @@ from typing import Optional
 import torch
 
 from . import ops
-from .lowrank import fuse_pair
+from .lowrank import fuse_pair, warn_once
 
 EIGEN_DAMPEN_FACTOR = 0.01  # reference dwain.py:14, falor.py:22
 
@@ -122,7 +122,9 @@ class LayerTap:
         bias = self.layer.bias
 
         def fwd(x):
-            if x.dtype != weight2d.dtype:
+            if x.dtype != weight2d.dtype:  # e.g. autocast: not a HIP GEMM input, say so and let torch run the layer
+                warn_once(f"tap-dense:{x.dtype}", f"ptdeco_amd: layer {self.name} received {x.dtype} inputs for "
+                          f"{weight2d.dtype} weights; its forward stays in torch for this run")
                 self.last_features = None
                 return type(self.layer).forward(self.layer, x)
             y = ops.matmul(self._rows_in(x), weight2d.T)
@@ -141,7 +143,8 @@ class LayerTap:
 
         def fwd(x):
             if x.dtype != first.dtype:
-                return type(self.layer).forward(self.layer, x)
+                raise TypeError(f"ptdeco_amd: layer {self.name} received {x.dtype} inputs but its candidate factors are "
+                                f"{first.dtype}; the rank-r candidate cannot be evaluated through the pair")
             return self._rows_out(ops.lowrank_forward(self._rows_in(x), first, uk, bias), x)
 
         self.layer.forward = fwd
@@ -223,19 +226,203 @@ class Covariance:
         if self.input_route:
             # cov = W (Ex - mx mx^T) W^T when the mean is removed (falor.py:196-199); damping only shifts eigenvalues
             ex = ops.cov_finalize(self.E, self.steps, 0.0, self.ey if use_mean else None)
-            w2d = self.weight if self.weight.dim() == 2 else self.weight[..., 0, 0]
-            got = ops.eigh_factored(w2d, ex, top_k)
-            if got is not None:
-                return got[1]
-            # W^T W not positive definite: form C = W Ex W^T explicitly and take the direct route
-            w64 = w2d.double()
-            c = ops.matmul(ops.matmul(w64, ex), w64.T)
-            c = 0.5 * (c + c.T)
-            c.diagonal().add_(damp_factor * c.diagonal().mean())
-            return ops.eigh(c, top_k, all_values=False)[1]
+            return eigenvectors_from_input_moment(self.weight, ex, damp_factor, top_k, factored=True)
         c = ops.cov_finalize(self.E, self.steps, damp_factor, self.ey if use_mean else None)
         _, u = ops.eigh(c, top_k, all_values=False)
         return u
+
+
+def eigenvectors_from_input_moment(weight: torch.Tensor, ex: torch.Tensor, damp_factor: float, top_k: Optional[int],
+                                   factored: bool) -> torch.Tensor:
+    """Eigenvectors (columns, ascending, f64) of the feature covariance C = W Ex W^T of y = x W^T, given the
+    finalised INPUT second moment Ex [n_in, n_in] (f64, full symmetric).  ``factored``: through the n_in-sized
+    problem of ``ops.eigh_factored`` (legal for top_k <= n_in); otherwise, or when W^T W is not safely positive
+    definite, C is formed explicitly by two f64 MFMA products and decomposed directly."""
+    w2d = weight if weight.dim() == 2 else weight[..., 0, 0]
+    if factored and top_k is not None and top_k <= w2d.shape[1]:
+        got = ops.eigh_factored(w2d, ex, top_k)
+        if got is not None:
+            return got[1]
+        warn_once("factored-refused", "ptdeco_amd: W^T W of a widening layer is not safely positive definite; "
+                  "its feature covariance W Ex W^T is decomposed directly (n_out-sized eigenproblem)")
+    w64 = w2d.double()
+    # ptd_cov_finalize mirrors the lower triangle (exact symmetry) and adds the damping
+    c = ops.cov_finalize(ops.matmul(ops.matmul(w64, ex), w64.T), 1, damp_factor)
+    return ops.eigh(c, top_k, all_values=False)[1]
+
+
+class InputMoment:
+    """sum over calibration steps of x^T x / T for ONE input tensor that several layers read (q/k/v, gate/up of
+    a transformer block): accumulated once per step, whoever of the sharing layers runs first."""
+
+    def __init__(self, n_in: int, device: torch.device, float64: bool):
+        self.E = torch.zeros((n_in, n_in), dtype=torch.float64 if float64 else torch.float32, device=device)
+        self.steps = 0
+        self.ex: Optional[torch.Tensor] = None
+        self.step_id = -1     # the pool's step in which the moment was last added to
+        self.step_key = None  # identity of that step's input tensor
+
+    def add(self, x_rows: torch.Tensor) -> None:
+        ops.syrk_accumulate(self.E, x_rows, 1.0 / x_rows.shape[0])
+        self.steps += 1
+
+    def all_reduce(self, group=None) -> None:
+        import torch.distributed as dist
+
+        dist.all_reduce(self.E, op=dist.ReduceOp.SUM, group=group)
+        steps = torch.tensor([self.steps], dtype=torch.int64, device=self.E.device)
+        dist.all_reduce(steps, op=dist.ReduceOp.SUM, group=group)
+        self.steps = int(steps.item())
+
+    def finalize(self) -> None:
+        self.ex = ops.cov_finalize(self.E, self.steps, 0.0)
+
+
+class MomentCovariance:
+    """A layer's feature covariance expressed through a (shared) input moment: C = W Ex W^T."""
+
+    def __init__(self, weight: torch.Tensor, moment: InputMoment, factored: bool):
+        self.weight, self.moment, self.factored = weight, moment, factored
+
+    def eigenvectors(self, damp_factor: float, use_mean: bool = False, top_k: Optional[int] = None) -> torch.Tensor:
+        assert not use_mean and self.moment.ex is not None, "SharedInputPool.finalize() must run first"
+        return eigenvectors_from_input_moment(self.weight, self.moment.ex, damp_factor, top_k, self.factored)
+
+
+def _tensor_key(t: torch.Tensor):
+    return (t.data_ptr(), tuple(t.shape), tuple(t.stride()), t.dtype, t._version)
+
+
+class SharedInputPool:
+    """Covariance statistics of all stand-in layers of one precompute pass (dwain.py:580-633), with ONE x^T x
+    per distinct input tensor.
+
+    Sigma_y = W Sigma_x W^T, so layers that read the same tensor (q / k / v, gate / up) can share one input
+    moment; a layer then gets its eigenvectors either through the n_in-sized factored problem (widening layers)
+    or from the explicit product W Ex W^T.  Which layers share is discovered on the first forward: every stand-in
+    reports (its input rows, its output rows); identical tensors (same storage, shape, strides, version -- the
+    references are held until the step ends, so an address cannot be reused meanwhile) form a group.
+
+    ``mode`` (PTD_SHARE_INPUT_COVARIANCE): "off" = every layer on its own (widening layers still use their own
+    x^T x); "all" = every group of >= 2 layers shares; "auto" (default) = widening layers of a group always share,
+    the others only when the f64 products W Ex W^T cost less than their D output-side SYRKs (they do for the
+    D >= ~32 calibration steps of real runs; with a handful of steps y^T y is cheaper)."""
+
+    RATE_F32 = 100e12  # measured covariance SYRK rate (f32 in, f64 accumulate) on MI355X
+    RATE_F64 = 45e12   # measured f64 MFMA GEMM rate
+
+    def __init__(self, num_data_steps: int, float64: bool, device: torch.device, mode: Optional[str] = None):
+        import os
+
+        self.mode = (mode or os.environ.get("PTD_SHARE_INPUT_COVARIANCE", "auto")).lower()
+        if self.mode not in ("off", "all", "auto"):
+            raise ValueError(f"PTD_SHARE_INPUT_COVARIANCE={self.mode!r}: expected off, all or auto")
+        self.num_data_steps, self.float64, self.device = num_data_steps, float64, device
+        self.members: list = []
+        self.discovered = False
+        self.groups: list[list] = []    # for introspection / tests: lists of member names
+        self._pending: list = []
+        self._accumulate = True
+        self._step = -1
+
+    def register(self, member) -> None:
+        """member: has .weight [n_out, n_in], .top_k, .name; receives .cov (Covariance | MomentCovariance)
+        and .moment (InputMoment | None)."""
+        member.cov, member.moment = None, None
+        self.members.append(member)
+
+    def begin_step(self, accumulate: bool = True) -> None:
+        self._step += 1
+        self._accumulate = accumulate
+
+    def observe(self, member, x_rows: torch.Tensor, y_rows: torch.Tensor) -> None:
+        if not self.discovered:
+            self._pending.append((member, x_rows, y_rows))  # held until end_step
+            return
+        if self._accumulate:
+            self._add(member, x_rows, y_rows)
+
+    def _add(self, member, x_rows, y_rows) -> None:
+        mom = member.moment
+        if mom is None:
+            member.cov.add_inputs(x_rows, member.weight, features=y_rows)
+            return
+        key = _tensor_key(x_rows)
+        if mom.step_id != self._step:
+            mom.step_id, mom.step_key = self._step, key
+            mom.add(x_rows)
+        elif mom.step_key != key:
+            raise RuntimeError(f"ptdeco_amd: layer {member.name} shared its input with other layers on the first "
+                               "calibration step but not on this one; set PTD_SHARE_INPUT_COVARIANCE=off")
+
+    def end_step(self) -> None:
+        if self.discovered:
+            return
+        by_key: dict = {}
+        for member, x_rows, _ in self._pending:
+            by_key.setdefault(_tensor_key(x_rows), []).append(member)
+        t_rows = {id(m): x.shape[0] for m, x, _ in self._pending}
+        for members in by_key.values():
+            self._plan_group(members, t_rows[id(members[0])])
+        for m in self.members:
+            if m.cov is None:  # not reached by the forward: same error as a tap that saw no input
+                raise RuntimeError(f"layer {m.name} was not reached by the model's forward")
+        self.discovered = True
+        if self._accumulate:
+            for member, x_rows, y_rows in self._pending:
+                self._add(member, x_rows, y_rows)
+        self._pending.clear()
+
+    def _plan_group(self, members: list, t_rows: int) -> None:
+        n_in = members[0].weight.shape[1]
+        wide = [m for m in members if _input_route_wanted(m.weight.shape[0], n_in, m.top_k)]
+        rest = [m for m in members if m not in wide]
+        d = self.num_data_steps
+        direct = {id(m): d * t_rows * m.weight.shape[0] ** 2 / self.RATE_F32 for m in rest}
+        explicit = {id(m): (2.0 * m.weight.shape[0] * n_in * n_in + 2.0 * m.weight.shape[0] ** 2 * n_in) / self.RATE_F64
+                    for m in rest}
+        if self.mode == "off" or len(members) < 2:
+            shared_wide, shared_rest = [], []
+        elif self.mode == "all":
+            shared_wide, shared_rest = wide, rest
+        else:
+            shared_wide = wide if len(wide) >= 2 or (wide and rest) else []
+            gain = [m for m in rest if explicit[id(m)] < direct[id(m)]]
+            moment_cost = 0.0 if shared_wide else d * t_rows * n_in * n_in / self.RATE_F32
+            saved = sum(direct[id(m)] - explicit[id(m)] for m in gain)
+            shared_rest = gain if (gain and saved > moment_cost and (shared_wide or len(gain) >= 2 or wide)) else []
+            if shared_rest and not shared_wide:
+                shared_wide = wide
+        sharing = shared_wide + shared_rest
+        if len(sharing) >= 2:
+            moment = InputMoment(n_in, self.device, self.float64)
+            for m in sharing:
+                m.moment = moment
+                m.cov = MomentCovariance(m.weight.detach(), moment, factored=m in shared_wide)
+            self.groups.append([m.name for m in sharing])
+        for m in members:
+            if m.cov is None:
+                m.cov = Covariance(m.weight.shape[0], self.device, self.float64, weight=m.weight.detach(), top_k=m.top_k)
+
+    def moments(self) -> list:
+        out: list = []
+        for m in self.members:
+            if m.moment is not None and all(m.moment is not o for o in out):
+                out.append(m.moment)
+        return out
+
+    def all_reduce(self, group=None) -> None:
+        """Sum the partial statistics over the ranks: one collective per shared moment / unshared layer."""
+        for mom in self.moments():
+            mom.all_reduce(group)
+        for m in self.members:
+            if m.moment is None:
+                m.cov.all_reduce(group)
+
+    def finalize(self) -> None:
+        """Shared Ex matrices, formed once on the caller's stream before the (concurrent) eigendecompositions."""
+        for mom in self.moments():
+            mom.finalize()
 
 
 def run_concurrently(jobs, device: torch.device, max_streams: Optional[int] = None) -> list:

@@ -46,11 +46,15 @@ SIGNATURES = {
     "ptd_lowrank_forward": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p,
                                     c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_size_t, c_int,
                                     c_void_p]),
+    "ptd_lowrank_forward_nchw_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int64, c_int]),
+    "ptd_lowrank_forward_nchw": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p,
+                                         c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "ptd_nsr_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "ptd_nsr": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_double, c_void_p, c_void_p, c_size_t,
                         c_void_p]),
     "ptd_sym_kl_workspace_bytes": (c_size_t, [c_int64]),
     "ptd_sym_kl": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "ptd_kl_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p]),
 }
 
 

@@ -181,6 +181,40 @@ int ptd_lowrank_forward(const void* x, int64_t ldx, int64_t T, int64_t n_i, cons
   return ptd_gemm(h, r, 1, B, 1, ldb, y, ldy, T, n_o, r, dtype, dtype, 1.0, bias, stream);
 }
 
+size_t ptd_lowrank_forward_nchw_workspace_bytes(int64_t batch, int64_t hw, int64_t r, int dtype) {
+  return align_up((size_t)batch * (size_t)r * (size_t)hw * elt_bytes(dtype), 256);
+}
+
+int ptd_lowrank_forward_nchw(const void* x, int64_t batch, int64_t n_i, int64_t hw, const void* A, int64_t lda,
+                             int64_t r, const void* B, int64_t ldb, int64_t n_o, const void* bias, void* y, void* ws,
+                             size_t ws_bytes, int dtype, void* stream) {
+  PTD_REQUIRE(x && A && B && y && ws, "ptd_lowrank_forward_nchw: null pointer");
+  PTD_REQUIRE(batch >= 0 && n_i >= 1 && hw >= 1 && r >= 1 && n_o >= 1 && lda >= n_i && ldb >= r,
+              "ptd_lowrank_forward_nchw: bad shape");
+  PTD_REQUIRE(dtype == PTD_F32 || dtype == PTD_BF16, "ptd_lowrank_forward_nchw: dtype must be f32 or bf16");
+  if (ws_bytes < ptd_lowrank_forward_nchw_workspace_bytes(batch, hw, r, dtype)) {
+    set_error("ptd_lowrank_forward_nchw: workspace too small");
+    return PTD_ERR_WORKSPACE;
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  // per image b: h_b[r, hw] = A x_b (x_b = x + b n_i hw viewed [n_i, hw], pixels contiguous), y_b[n_o, hw] = B h_b + bias
+  if (dtype == PTD_F32) {
+    int rc = gemm_f32_batched(static_cast<const float*>(A), lda, 1, 0, static_cast<const float*>(x), hw, 1, n_i * hw,
+                              static_cast<float*>(ws), hw, r * hw, r, hw, n_i, batch, 1.0, nullptr, st);
+    if (rc != PTD_OK) return rc;
+    return gemm_f32_batched(static_cast<const float*>(B), ldb, 1, 0, static_cast<const float*>(ws), hw, 1, r * hw,
+                            static_cast<float*>(y), hw, n_o * hw, n_o, hw, r, batch, 1.0,
+                            static_cast<const float*>(bias), st);
+  }
+  typedef unsigned short u16;
+  int rc = gemm_bf16_batched(static_cast<const u16*>(A), lda, 1, 0, static_cast<const u16*>(x), hw, 1, n_i * hw,
+                             static_cast<u16*>(ws), hw, r * hw, r, hw, n_i, batch, 1.0, nullptr, st);
+  if (rc != PTD_OK) return rc;
+  return gemm_bf16_batched(static_cast<const u16*>(B), ldb, 1, 0, static_cast<const u16*>(ws), hw, 1, r * hw,
+                           static_cast<u16*>(y), hw, n_o * hw, n_o, hw, r, batch, 1.0, static_cast<const u16*>(bias),
+                           st);
+}
+
 size_t ptd_nsr_workspace_bytes(int64_t R, int64_t C) { return nsr_workspace_bytes(R, C); }
 
 int ptd_nsr(const void* x, const void* y, int64_t R, int64_t C, int dtype, double eps, double* out, void* ws,
@@ -193,6 +227,10 @@ size_t ptd_sym_kl_workspace_bytes(int64_t B) { return sym_kl_workspace_bytes(B);
 int ptd_sym_kl(const void* s, const void* t, int64_t B, int64_t C, int dtype, double* out, void* ws, size_t ws_bytes,
                void* stream) {
   return sym_kl(s, t, B, C, dtype, out, ws, ws_bytes, static_cast<hipStream_t>(stream));
+}
+
+int ptd_kl_rows(const void* q, const void* p, int64_t B, int64_t C, int dtype, double* rows, void* stream) {
+  return kl_rows(q, p, B, C, dtype, rows, static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

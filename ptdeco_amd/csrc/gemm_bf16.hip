@@ -53,6 +53,8 @@ struct GemmBf16Args {
   int atomic;
   int vecA, vecB;
   int64_t cslab;  // split K of the LDS-DMA kernel: blockIdx.y writes its f32 partial tile to C + y * cslab
+  int64_t zsa, zsb, zsc;  // batched products (generic kernel only): blockIdx.z advances A, B, C by these element strides
+  int bias_rows;          // bias indexed by the output ROW (an NCHW 1x1 convolution's channel) instead of the column
 };
 
 // f32 -> bf16, round to nearest even, NaN stays NaN: gfx950's v_cvt_pk_bf16_f32 (one VALU instruction
@@ -146,8 +148,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmBf16Args a)
   const int kend = min(a.K, kbeg + a.kchunk);
   const int nk = (kend - kbeg + BK - 1) / BK;
 
-  const unsigned short* Ap = a.A + (int64_t)m0 * a.sam + (int64_t)kbeg * a.sak;
-  const unsigned short* Bp = a.B + (int64_t)n0 * a.sbn + (int64_t)kbeg * a.sbk;
+  const unsigned short* Ap = a.A + (int64_t)blockIdx.z * a.zsa + (int64_t)m0 * a.sam + (int64_t)kbeg * a.sak;
+  const unsigned short* Bp = a.B + (int64_t)blockIdx.z * a.zsb + (int64_t)n0 * a.sbn + (int64_t)kbeg * a.sbk;
   const int64_t sa = AKC ? a.sam : a.sak;
   const int64_t sb = BKC ? a.sbn : a.sbk;
   const int64_t astep = (int64_t)BK * a.sak, bstep = (int64_t)BK * a.sbk;
@@ -209,11 +211,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmBf16Args a)
         const float v = acc[i][j][r];
         if (EPI == EPI_STORE_BF16 || EPI == EPI_STORE_F32) {
           float o = a.alpha * v;
-          if (a.bias) o += bf16_to_f32(a.bias[col]);
+          if (a.bias) o += bf16_to_f32(a.bias[a.bias_rows ? row : col]);
+          const int64_t ci = (int64_t)blockIdx.z * a.zsc + (int64_t)row * a.ldc + col;
           if (EPI == EPI_STORE_BF16)
-            reinterpret_cast<unsigned short*>(a.C)[(int64_t)row * a.ldc + col] = f32_to_bf16(o);
+            reinterpret_cast<unsigned short*>(a.C)[ci] = f32_to_bf16(o);
           else
-            reinterpret_cast<float*>(a.C)[(int64_t)row * a.ldc + col] = o;
+            reinterpret_cast<float*>(a.C)[ci] = o;
         } else if (EPI == EPI_ACC_F64) {
           double* e = reinterpret_cast<double*>(a.C) + (int64_t)row * a.ldc + col;
           const double d = a.scale * (double)v;
@@ -1505,6 +1508,31 @@ int gemm_bf16(const unsigned short* A, int64_t sam, int64_t sak, const unsigned 
   } else if (c_bf16) launch_bf16<EPI_STORE_BF16>(a, akc, bkc, grid, st);
   else launch_bf16<EPI_STORE_F32>(a, akc, bkc, grid, st);
   PTD_CHECK_LAUNCH("gemm_bf16");
+  return PTD_OK;
+}
+
+// batched form of the generic kernel (see gemm_f32_batched): bf16 operands and output
+int gemm_bf16_batched(const unsigned short* A, int64_t sam, int64_t sak, int64_t zsa, const unsigned short* B,
+                      int64_t sbk, int64_t sbn, int64_t zsb, unsigned short* C, int64_t ldc, int64_t zsc, int64_t M,
+                      int64_t N, int64_t K, int64_t batch, double alpha, const unsigned short* bias_rows,
+                      hipStream_t st) {
+  PTD_REQUIRE((sam == 1) != (sak == 1) || (M == 1 || K == 1), "ptd_gemm: exactly one stride of A must be 1");
+  PTD_REQUIRE((sbk == 1) != (sbn == 1) || (N == 1 || K == 1), "ptd_gemm: exactly one stride of B must be 1");
+  PTD_REQUIRE(batch >= 0 && batch < 65536, "ptd_gemm: batch out of range");
+  if (M == 0 || N == 0 || batch == 0) return PTD_OK;
+  GemmBf16Args a{};
+  a.A = A; a.sam = sam; a.sak = sak; a.zsa = zsa;
+  a.B = B; a.sbk = sbk; a.sbn = sbn; a.zsb = zsb;
+  a.C = C; a.ldc = ldc; a.zsc = zsc;
+  a.M = (int)M; a.N = (int)N; a.K = (int)K;
+  a.alpha = (float)alpha; a.scale = 1.0; a.bias = bias_rows; a.bias_rows = 1;
+  a.tiles_m = (int)ceil_div(M, BM);
+  a.kchunk = (int)align_up((size_t)(K > 0 ? K : 1), BK);
+  const bool akc = (sak == 1), bkc = (sbk == 1);
+  a.vecA = aligned16(A) && ((akc ? sam : sak) % 8 == 0) && zsa % 8 == 0;
+  a.vecB = aligned16(B) && ((bkc ? sbn : sbk) % 8 == 0) && zsb % 8 == 0;
+  launch_bf16<EPI_STORE_BF16>(a, akc, bkc, dim3((unsigned)(a.tiles_m * ceil_div(N, BN)), 1, (unsigned)batch), st);
+  PTD_CHECK_LAUNCH("gemm_bf16 (batched)");
   return PTD_OK;
 }
 

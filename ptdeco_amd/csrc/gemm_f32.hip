@@ -50,6 +50,8 @@ struct GemmF32Args {
   int atomic;  // accumulate with atomics (split K)
   int vecA, vecB;
   int64_t cslab;  // EPI_STORE split K: blockIdx.y writes its partial tile to C + y * cslab
+  int64_t zsa, zsb, zsc;  // batched products (generic kernel only): blockIdx.z advances A, B, C by these element strides
+  int bias_rows;          // bias indexed by the output ROW (an NCHW 1x1 convolution's channel) instead of the column
 };
 
 // Fetch this thread's share of a TS x 32 operand tile (TS = 128: four 4-element groups, TS = 64: two).
@@ -120,8 +122,8 @@ __device__ __forceinline__ void gemm_f32_tile(const GemmF32Args& a, const int ti
   const int kend = min(a.K, kbeg + a.kchunk);
   const int nk = (kend - kbeg + BK - 1) / BK;
 
-  const float* Ap = a.A + (int64_t)m0 * a.sam + (int64_t)kbeg * a.sak;
-  const float* Bp = a.B + (int64_t)n0 * a.sbn + (int64_t)kbeg * a.sbk;
+  const float* Ap = a.A + (int64_t)blockIdx.z * a.zsa + (int64_t)m0 * a.sam + (int64_t)kbeg * a.sak;
+  const float* Bp = a.B + (int64_t)blockIdx.z * a.zsb + (int64_t)n0 * a.sbn + (int64_t)kbeg * a.sbk;
   const int64_t sa = AKC ? a.sam : a.sak;  // stride of the non-contiguous index
   const int64_t sb = BKC ? a.sbn : a.sbk;
   const int64_t astep = (int64_t)BK * a.sak, bstep = (int64_t)BK * a.sbk;
@@ -186,8 +188,9 @@ __device__ __forceinline__ void gemm_f32_tile(const GemmF32Args& a, const int ti
         const float v = acc[i][j][r];
         if (EPI == EPI_STORE) {
           float o = a.alpha * v;
-          if (a.bias) o += a.bias[col];
-          reinterpret_cast<float*>(a.C)[(int64_t)blockIdx.y * a.cslab + (int64_t)row * a.ldc + col] = o;
+          if (a.bias) o += a.bias[a.bias_rows ? row : col];
+          reinterpret_cast<float*>(a.C)[(int64_t)blockIdx.z * a.zsc + (int64_t)blockIdx.y * a.cslab +
+                                        (int64_t)row * a.ldc + col] = o;
         } else if (EPI == EPI_ACC_F64) {
           double* e = reinterpret_cast<double*>(a.C) + (int64_t)row * a.ldc + col;
           const double d = a.scale * (double)v;
@@ -511,6 +514,32 @@ int gemm_f32(const float* A, int64_t sam, int64_t sak, const float* B, int64_t s
     launch_f32<EPI_STORE>(a, akc, bkc, dim3((unsigned)tiles, 1), st);
   }
   PTD_CHECK_LAUNCH("gemm_f32");
+  return PTD_OK;
+}
+
+// `batch` independent products C_z = alpha A_z B_z (+ bias per output row) with A, B, C advanced by the
+// element strides zsa, zsb, zsc (0 = shared operand) per z: the NCHW 1x1-convolution pair, whose per-image
+// operand x[b] is a [C, H W] matrix with the pixels contiguous.
+int gemm_f32_batched(const float* A, int64_t sam, int64_t sak, int64_t zsa, const float* B, int64_t sbk, int64_t sbn,
+                     int64_t zsb, float* C, int64_t ldc, int64_t zsc, int64_t M, int64_t N, int64_t K, int64_t batch,
+                     double alpha, const float* bias_rows, hipStream_t st) {
+  PTD_REQUIRE((sam == 1) != (sak == 1) || (M == 1 || K == 1), "ptd_gemm: exactly one stride of A must be 1");
+  PTD_REQUIRE((sbk == 1) != (sbn == 1) || (N == 1 || K == 1), "ptd_gemm: exactly one stride of B must be 1");
+  PTD_REQUIRE(batch >= 0 && batch < 65536, "ptd_gemm: batch out of range");
+  if (M == 0 || N == 0 || batch == 0) return PTD_OK;
+  GemmF32Args a{};
+  a.A = A; a.sam = sam; a.sak = sak; a.zsa = zsa;
+  a.B = B; a.sbk = sbk; a.sbn = sbn; a.zsb = zsb;
+  a.C = C; a.ldc = ldc; a.zsc = zsc;
+  a.M = (int)M; a.N = (int)N; a.K = (int)K;
+  a.alpha = (float)alpha; a.scale = 1.0; a.bias = bias_rows; a.bias_rows = 1;
+  a.tiles_m = (int)ceil_div(M, BM);
+  a.kchunk = (int)align_up((size_t)(K > 0 ? K : 1), BK);
+  const bool akc = (sak == 1), bkc = (sbk == 1);
+  a.vecA = aligned16(A) && ((akc ? sam : sak) % 4 == 0) && zsa % 4 == 0;
+  a.vecB = aligned16(B) && ((bkc ? sbn : sbk) % 4 == 0) && zsb % 4 == 0;
+  launch_f32<EPI_STORE>(a, akc, bkc, dim3((unsigned)(a.tiles_m * ceil_div(N, BN)), 1, (unsigned)batch), st);
+  PTD_CHECK_LAUNCH("gemm_f32 (batched)");
   return PTD_OK;
 }
 

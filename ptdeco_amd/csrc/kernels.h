@@ -10,6 +10,9 @@ int gemm_f32(const float* A, int64_t sam, int64_t sak, const float* B, int64_t s
              int64_t ldc, int64_t M, int64_t N, int64_t K, double alpha, const float* bias, void* ws, size_t ws_bytes,
              hipStream_t st);
 size_t gemm_f32_workspace_bytes(int64_t M, int64_t N, int64_t K);
+int gemm_f32_batched(const float* A, int64_t sam, int64_t sak, int64_t zsa, const float* B, int64_t sbk, int64_t sbn,
+                     int64_t zsb, float* C, int64_t ldc, int64_t zsc, int64_t M, int64_t N, int64_t K, int64_t batch,
+                     double alpha, const float* bias_rows, hipStream_t st);
 int syrk_f32(const float* Y, int64_t T, int64_t n, int64_t ldy, void* E, int64_t ldE, bool e_f64, double scale,
              hipStream_t st);
 
@@ -18,6 +21,10 @@ int gemm_bf16(const unsigned short* A, int64_t sam, int64_t sak, const unsigned 
               void* C, int64_t ldc, int64_t M, int64_t N, int64_t K, bool c_bf16, double alpha,
               const unsigned short* bias, void* ws, size_t ws_bytes, hipStream_t st);
 size_t gemm_bf16_workspace_bytes(int64_t M, int64_t N, int64_t K);
+int gemm_bf16_batched(const unsigned short* A, int64_t sam, int64_t sak, int64_t zsa, const unsigned short* B,
+                      int64_t sbk, int64_t sbn, int64_t zsb, unsigned short* C, int64_t ldc, int64_t zsc, int64_t M,
+                      int64_t N, int64_t K, int64_t batch, double alpha, const unsigned short* bias_rows,
+                      hipStream_t st);
 int syrk_bf16(const unsigned short* Y, int64_t T, int64_t n, int64_t ldy, void* E, int64_t ldE, bool e_f64,
               double scale, hipStream_t st);
 
@@ -54,5 +61,6 @@ int nsr(const void* x, const void* y, int64_t R, int64_t C, int dtype, double ep
 size_t sym_kl_workspace_bytes(int64_t B);
 int sym_kl(const void* s, const void* t, int64_t B, int64_t C, int dtype, double* out, void* ws, size_t ws_bytes,
            hipStream_t st);
+int kl_rows(const void* q, const void* p, int64_t B, int64_t C, int dtype, double* rows, hipStream_t st);
 
 }  // namespace ptd

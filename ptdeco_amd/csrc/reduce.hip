@@ -178,7 +178,9 @@ __global__ void sum_scale_kernel(const double* __restrict__ v, int64_t n, double
 }
 
 // -------------------------------------------------------------------- sym_kl
-template <typename T>
+// SYM: rows[b] = max(KL(t || s), KL(s || t)) (calc_kl_loss before its mean); otherwise rows[b] = KL(t || s),
+// the reference's calc_kl_divergence(q_logits = s, p_logits = t) (losses_primitives.py:48-54).
+template <typename T, bool SYM>
 __global__ void sym_kl_rows_kernel(const T* __restrict__ s, const T* __restrict__ t, int64_t B, int64_t C,
                                    double* __restrict__ rows) {
   const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -211,7 +213,7 @@ __global__ void sym_kl_rows_kernel(const T* __restrict__ s, const T* __restrict_
   }
   kts = wave_sum(kts);
   kst = wave_sum(kst);
-  if (lane == 0) rows[row] = fmax(kts, kst);
+  if (lane == 0) rows[row] = SYM ? fmax(kts, kst) : kts;
 }
 
 __global__ void mean_kernel(const double* __restrict__ v, int64_t n, double* __restrict__ out) {
@@ -349,10 +351,10 @@ int sym_kl(const void* s, const void* t, int64_t B, int64_t C, int dtype, double
   double* rows = static_cast<double*>(ws);
   const unsigned grid = (unsigned)ceil_div(B, 4);
   if (dtype == PTD_F32)
-    hipLaunchKernelGGL((sym_kl_rows_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)s, (const float*)t,
-                       B, C, rows);
+    hipLaunchKernelGGL((sym_kl_rows_kernel<float, true>), dim3(grid), dim3(256), 0, st, (const float*)s,
+                       (const float*)t, B, C, rows);
   else if (dtype == PTD_BF16)
-    hipLaunchKernelGGL((sym_kl_rows_kernel<unsigned short>), dim3(grid), dim3(256), 0, st,
+    hipLaunchKernelGGL((sym_kl_rows_kernel<unsigned short, true>), dim3(grid), dim3(256), 0, st,
                        (const unsigned short*)s, (const unsigned short*)t, B, C, rows);
   else {
     set_error("ptd_sym_kl: unsupported dtype");
@@ -360,6 +362,23 @@ int sym_kl(const void* s, const void* t, int64_t B, int64_t C, int dtype, double
   }
   hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(1024), 0, st, rows, B, out);
   PTD_CHECK_LAUNCH("sym_kl");
+  return PTD_OK;
+}
+
+int kl_rows(const void* q, const void* p, int64_t B, int64_t C, int dtype, double* rows, hipStream_t st) {
+  PTD_REQUIRE(q && p && rows && B >= 1 && C >= 1, "ptd_kl_rows: bad argument");
+  const unsigned grid = (unsigned)ceil_div(B, 4);
+  if (dtype == PTD_F32)
+    hipLaunchKernelGGL((sym_kl_rows_kernel<float, false>), dim3(grid), dim3(256), 0, st, (const float*)q,
+                       (const float*)p, B, C, rows);
+  else if (dtype == PTD_BF16)
+    hipLaunchKernelGGL((sym_kl_rows_kernel<unsigned short, false>), dim3(grid), dim3(256), 0, st,
+                       (const unsigned short*)q, (const unsigned short*)p, B, C, rows);
+  else {
+    set_error("ptd_kl_rows: unsupported dtype");
+    return PTD_ERR_UNSUPPORTED;
+  }
+  PTD_CHECK_LAUNCH("kl_rows");
   return PTD_OK;
 }
 

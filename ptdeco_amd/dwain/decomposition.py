@@ -69,25 +69,27 @@ class CovarianceComputingLinearModule(torch.nn.Module):
     output, and the layer's feature covariance accumulates in HBM as a side effect."""
 
     def __init__(self, weight: torch.nn.Parameter, bias: Optional[torch.nn.Parameter], decompose_in_float64: bool,
-                 top_k: Optional[int] = None):
+                 top_k: Optional[int] = None, pool: Optional[eng.SharedInputPool] = None, name: str = ""):
         super().__init__()
         if weight.dim() != 2:
             raise RuntimeError("covariance precompute supports nn.Linear only (2-D weight), like the reference "
                                "whose x @ weight.T fails for a Conv2d weight")
         self.weight = weight
         self.bias = bias
+        self.name = name
         self.in_features, self.out_features = weight.shape[1], weight.shape[0]
         self.top_k = top_k  # largest rank the search can ask for; None = all eigenvectors
-        self.cov = eng.Covariance(self.out_features, weight.device, decompose_in_float64, weight=weight.detach(),
-                                  top_k=top_k)
+        # the pool decides on the first forward whether this layer keeps its own statistics or shares an
+        # input moment x^T x with the other layers that read the same tensor (SURVEY 8f-4); it sets .cov
+        self.pool = pool if pool is not None else eng.SharedInputPool(0, decompose_in_float64, weight.device, "off")
+        self.pool.register(self)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         rows = x.reshape(-1, self.in_features)
-        y = ops.matmul(rows, self.weight.T)
-        self.cov.add_inputs(rows, self.weight, features=y)
-        if self.bias is not None:
-            y += self.bias
-        return y.reshape(*x.shape[:-1], self.out_features)
+        y = ops.matmul(rows, self.weight.T)  # without the bias: what the covariance accumulates (:194-200)
+        self.pool.observe(self, rows, y)
+        out = y + self.bias if self.bias is not None else y
+        return out.reshape(*x.shape[:-1], self.out_features)
 
     def get_eigenvectors(self) -> torch.Tensor:
         # the reference parks u on the CPU (:208); with 288 GB of HBM it stays resident
@@ -111,26 +113,34 @@ def _precompute_covariance_matrix_decompositions(*, module, submodule_names, num
                                                  reduction_factor: float) -> dict[str, torch.Tensor]:
     """:580-633."""
     originals = {}
+    pool = eng.SharedInputPool(num_data_steps, decompose_in_float64, device)
     for name in submodule_names:
         old = module.get_submodule(name)
         originals[name] = old
         logger.info(f"Replacing {name} by covariance computing wrapper")
         top_k = _max_candidate_rank(old.weight.shape[1], old.weight.shape[0], min_rank, reduction_factor)
         utils.replace_submodule_in_place(
-            module, name, CovarianceComputingLinearModule(old.weight, old.bias, decompose_in_float64, top_k))
+            module, name, CovarianceComputingLinearModule(old.weight, old.bias, decompose_in_float64, top_k, pool, name))
     module.eval()
     stand_ins = [module.get_submodule(n) for n in submodule_names]
     with torch.no_grad():
         for step in range(num_data_steps):
             batch = next(data_iterator)  # every rank advances the stream identically
-            if not shard.mine(step):
+            mine = shard.mine(step)
+            if not mine and pool.discovered:
                 continue
+            # (the first forward also discovers which layers share an input: every rank runs it, the
+            # ranks that do not own the step discard its statistics)
+            pool.begin_step(accumulate=mine)
             module(utils.to_device(batch, device))
+            pool.end_step()
+    for group in pool.groups:
+        logger.info(f"Sharing one input second moment between {group}")
     logger.info("Computing eigenvectors ...")
     u_dict: dict[str, torch.Tensor] = {}
     if shard.active:
-        for m in stand_ins:
-            m.cov.all_reduce(shard.group)
+        pool.all_reduce(shard.group)
+    pool.finalize()
     # eigendecompositions of a split are owned round-robin (non-owners receive u later); the ones
     # this rank owns are independent and run concurrently on separate streams
     owned = [i for i in range(len(stand_ins)) if shard.owns(i)]

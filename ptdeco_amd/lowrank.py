@@ -13,15 +13,35 @@ pair.
 
 from __future__ import annotations
 
+import logging
+
 import torch
 
 from . import ops
 
+logger = logging.getLogger(__name__)
+
 _HIP_DTYPES = (torch.float32, torch.bfloat16)
+_warned: set = set()
 
 
-def _use_hip(x: torch.Tensor, w: torch.Tensor) -> bool:
-    return x.is_cuda and x.dtype in _HIP_DTYPES and x.dtype == w.dtype
+def warn_once(key: str, message: str) -> None:
+    """One WARNING per process and reason whenever something leaves the HIP kernels."""
+    if key not in _warned:
+        _warned.add(key)
+        logger.warning(message)
+
+
+def _use_hip(x: torch.Tensor, w: torch.Tensor, who: str) -> bool:
+    """The pair runs on the HIP kernels for f32 / bf16 tensors on a ROCm device.  Anything else (a CPU
+    copy of the model, fp16, an autocast dtype mismatch) is evaluated by the container's two torch
+    layers -- the module IS an nn.Sequential -- and says so once, at WARNING."""
+    if x.is_cuda and x.dtype in _HIP_DTYPES and x.dtype == w.dtype:
+        return True
+    why = "a CPU tensor" if not x.is_cuda else f"input dtype {x.dtype} with weight dtype {w.dtype}"
+    warn_once(f"{who}:{why}", f"ptdeco_amd.{who}: {why} is not served by the HIP low-rank kernels (f32 / bf16 on a "
+                              "ROCm device); running the two torch layers of the pair instead")
+    return False
 
 
 class _LowRankFunction(torch.autograd.Function):
@@ -64,7 +84,7 @@ def _pair_forward(x2d: torch.Tensor, a: torch.Tensor, b: torch.Tensor, bias) -> 
 class LowRankLinear(torch.nn.Sequential):
     def forward(self, x: torch.Tensor) -> torch.Tensor:  # type: ignore[override]
         first, second = self[0], self[1]
-        if not _use_hip(x, first.weight):
+        if not _use_hip(x, first.weight, "LowRankLinear"):
             return second(first(x))
         y = _pair_forward(x.reshape(-1, first.in_features), first.weight, second.weight, second.bias)
         return y.reshape(*x.shape[:-1], second.out_features)
@@ -73,11 +93,18 @@ class LowRankLinear(torch.nn.Sequential):
 class LowRankConv1x1(torch.nn.Sequential):
     def forward(self, x: torch.Tensor) -> torch.Tensor:  # type: ignore[override]
         first, second = self[0], self[1]
-        if not _use_hip(x, first.weight):
+        if not _use_hip(x, first.weight, "LowRankConv1x1"):
             return second(first(x))
         b, c, h, w = x.shape
-        rows = x.permute(0, 2, 3, 1).reshape(-1, c)  # NHWC rows; free for channels_last inputs
-        y = _pair_forward(rows, first.weight[:, :, 0, 0], second.weight[:, :, 0, 0], second.bias)
+        wa, wb, bias = first.weight[:, :, 0, 0], second.weight[:, :, 0, 0], second.bias
+        needs_grad = torch.is_grad_enabled() and (x.requires_grad or wa.requires_grad or wb.requires_grad
+                                                  or (bias is not None and bias.requires_grad))
+        if x.is_contiguous() and not needs_grad and h * w > 1:
+            # NCHW as it lies: per image x_b is a [C, H W] matrix with the pixels contiguous, y_b = B (A x_b) + bias
+            # goes straight into NCHW -- no NHWC copy (the reference's permute, dwain.py:116)
+            return ops.lowrank_forward_nchw(x, wa, wb, bias)
+        rows = x.permute(0, 2, 3, 1).reshape(-1, c)  # NHWC rows: a view for channels_last inputs
+        y = _pair_forward(rows, wa, wb, bias)
         return y.reshape(b, h, w, second.out_channels).permute(0, 3, 1, 2)
 
 

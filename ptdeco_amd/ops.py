@@ -203,6 +203,29 @@ def lowrank_forward(x2d: torch.Tensor, A: torch.Tensor, B: torch.Tensor, bias: O
     return y
 
 
+def lowrank_forward_nchw(x: torch.Tensor, A: torch.Tensor, B: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    """The rank-r 1x1-convolution pair on a contiguous NCHW input, no layout copy: per image
+    y_b = B (A x_b) + bias[:, None] with x_b viewed [n_i, H W]; y is contiguous NCHW."""
+    _dev(x, A, B, bias)
+    assert x.dim() == 4 and x.is_contiguous() and x.dtype == A.dtype == B.dtype
+    A, B = _rows2d(A), _rows2d(B)
+    b, n_i, h, w = x.shape
+    r, n_o = A.shape[0], B.shape[0]
+    assert A.shape[1] == n_i and B.shape[1] == r
+    y = torch.empty((b, n_o, h, w), dtype=x.dtype, device=x.device)
+    lib = _hip.load()
+    ws_bytes = lib.ptd_lowrank_forward_nchw_workspace_bytes(b, h * w, r, _code(x))
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=x.device)
+    if bias is not None:
+        bias = bias.to(x.dtype).contiguous()
+    with torch.cuda.device(x.device):
+        rc = lib.ptd_lowrank_forward_nchw(x.data_ptr(), b, n_i, h * w, A.data_ptr(), A.stride(0), r, B.data_ptr(),
+                                          B.stride(0), n_o, _ptr(bias), y.data_ptr(), ws.data_ptr(), ws_bytes,
+                                          _code(x), _stream(x))
+    _hip.check(rc, "ptd_lowrank_forward_nchw")
+    return y
+
+
 def nsr(x: torch.Tensor, y: torch.Tensor, channels: int, eps: float = 1e-3) -> torch.Tensor:
     """Scalar (f64, on device): mean over the `channels` trailing-dim channels of
     mean((x-y)^2) / (var(y) + eps), x and y viewed as [-1, channels]."""
@@ -235,3 +258,16 @@ def sym_kl(s: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
                             _stream(s))
     _hip.check(rc, "ptd_sym_kl")
     return out[0]
+
+
+def kl_rows(q: torch.Tensor, p: torch.Tensor) -> torch.Tensor:
+    """[B] f64: KL(p_b || q_b) over softmax(dim=-1) of logits q, p [B, C]."""
+    _dev(q, p)
+    assert q.shape == p.shape and q.dim() == 2 and q.dtype == p.dtype
+    q, p = q.contiguous(), p.contiguous()
+    B, C = q.shape
+    rows = torch.empty(B, dtype=torch.float64, device=q.device)
+    with torch.cuda.device(q.device):
+        rc = _hip.load().ptd_kl_rows(q.data_ptr(), p.data_ptr(), B, C, _code(q), rows.data_ptr(), _stream(q))
+    _hip.check(rc, "ptd_kl_rows")
+    return rows

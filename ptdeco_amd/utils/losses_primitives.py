@@ -43,9 +43,11 @@ def calc_per_channel_noise_to_signal_ratio(
 
 
 def calc_kl_divergence(q_logits: torch.Tensor, p_logits: torch.Tensor) -> torch.Tensor:
-    """Per-row KL(p || q) over softmax(dim=-1) (losses_primitives.py:48-54); 2-D logits."""
-    raise NotImplementedError(
-        "calc_kl_divergence is not on the accelerated path; use calc_kl_loss (the only caller in falor)")
+    """Per-row KL(p || q) = sum_c p log(p / q) over softmax(dim=-1) (losses_primitives.py:48-54).
+    Logits [batch, classes]; returns a [batch] f64 tensor (one wave per row, f64 accumulation)."""
+    if q_logits.dim() != 2 or q_logits.shape != p_logits.shape:
+        raise ValueError("calc_kl_divergence expects two logit tensors of the same shape [batch, classes]")
+    return ops.kl_rows(q_logits, p_logits)
 
 
 def calc_kl_loss(student_logits: torch.Tensor, teacher_logits: torch.Tensor) -> torch.Tensor:

@@ -210,3 +210,101 @@ def test_splits_must_cover_all_layers(monkeypatch):
         dw._precompute_covariance_matrix_decompositions_in_splits(
             module=None, modules_to_decompose=list("abcdefghijk"), num_splits=4, num_data_steps=1, data_iterator=None,
             device=CPU, decompose_in_float64=True, shard=Shard.from_env(None), min_rank=1, reduction_factor=0.5)
+
+
+class _TwoBranchBlock(torch.nn.Module):
+    """q / k / v read one tensor, gate / up another (a transformer block's sharing pattern)."""
+
+    def __init__(self, d=48, kv=16, ff=120):
+        super().__init__()
+        self.q, self.k, self.v = (torch.nn.Linear(d, n, bias=False) for n in (d, kv, kv))
+        self.o = torch.nn.Linear(d, d, bias=True)
+        self.gate, self.up = torch.nn.Linear(d, ff, bias=False), torch.nn.Linear(d, ff, bias=False)
+        self.down = torch.nn.Linear(ff, d, bias=False)
+        self.rep = d // kv
+
+    def forward(self, batch):
+        x = batch["x"]
+        h = x * 1.5
+        a = self.q(h) + self.k(h).repeat(1, self.rep) + self.v(h).repeat(1, self.rep)
+        x = x + self.o(a)
+        h = torch.tanh(x)
+        return x + self.down(torch.nn.functional.silu(self.gate(h)) * self.up(h))
+
+
+@pytest.mark.parametrize("mode,expected_groups,syrks_per_step", [
+    ("off", [], 7),                                        # every layer on its own
+    ("all", [["q", "k", "v"], ["gate", "up"]], 4),         # 2 shared x^T x + o + down
+    ("auto", [["gate", "up"]], 6),                         # D = 3 steps: y^T y is cheaper for q / k / v
+])
+def test_precompute_pass_shares_one_input_moment_per_group(mode, expected_groups, syrks_per_step, monkeypatch):
+    """SURVEY 8f-4 / dwain.py:580-633: layers reading the same tensor accumulate ONE x^T x per calibration
+    step; the eigenvectors (W Ex W^T route) equal those of every layer's own y^T y."""
+    from ptdeco_amd import _engine as eng
+    from ptdeco_amd.dwain import decomposition as dw
+    from ptdeco_amd.sharding import Shard
+
+    monkeypatch.setenv("PTD_SHARE_INPUT_COVARIANCE", mode)
+    g = torch.Generator().manual_seed(7)
+    model = _TwoBranchBlock()
+    with torch.no_grad():
+        for p in model.parameters():
+            p.copy_(torch.randn(p.shape, generator=g) / p.shape[-1] ** 0.5)
+    batches = [{"x": torch.randn(200, 48, generator=g) * torch.logspace(0, -1, 48)} for _ in range(3)]
+    names = ["q", "k", "v", "o", "gate", "up", "down"]
+    calls = []
+    with cpu_shim.installed(monkeypatch):
+        from ptdeco_amd import ops
+        real = ops.syrk_accumulate
+        monkeypatch.setattr(ops, "syrk_accumulate", lambda E, y, s: (calls.append(tuple(E.shape)), real(E, y, s))[1])
+        pools = []
+        orig_pool = eng.SharedInputPool
+        monkeypatch.setattr(eng, "SharedInputPool", lambda *a, **k: (pools.append(orig_pool(*a, **k)), pools[-1])[1])
+        ref_out = model(batches[0])
+        u = dw._precompute_covariance_matrix_decompositions(
+            module=model, submodule_names=names, num_data_steps=3, data_iterator=iter(batches), device=CPU,
+            decompose_in_float64=True, shard=Shard.from_env(None), min_rank=4, reduction_factor=0.5)
+    assert pools[0].groups == expected_groups
+    assert len(calls) == 3 * syrks_per_step
+    assert all(isinstance(model.get_submodule(n), torch.nn.Linear) for n in names)  # originals restored
+    assert torch.equal(model(batches[0]), ref_out)
+    # every layer's top-k eigenvectors span the same space as those of its own output covariance
+    taps = {n: [] for n in names}
+    hooks = [model.get_submodule(n).register_forward_hook(lambda m, i, o, n=n: taps[n].append(o.detach()))
+             for n in names]
+    with torch.no_grad():
+        for b in batches:
+            model(b)
+    for h in hooks:
+        h.remove()
+    for n in names:
+        lay = model.get_submodule(n)
+        ys = [y - lay.bias if lay.bias is not None else y for y in taps[n]]
+        e = sum((y.double().T @ y.double()) / y.shape[0] for y in ys) / 3
+        e = e + torch.eye(e.shape[0], dtype=torch.float64) * (0.01 * torch.diag(e).mean())
+        k = u[n].shape[1]
+        v = torch.linalg.eigh(e)[1][:, -k:]
+        p, p_ref = u[n].double() @ u[n].double().T, v @ v.T
+        assert (p - p_ref).norm().item() <= 1e-5 * k ** 0.5, n
+
+
+def test_shared_input_pool_rejects_sharing_that_changes_between_steps(monkeypatch):
+    from ptdeco_amd import _engine as eng
+
+    class M:
+        def __init__(self, name, w):
+            self.name, self.weight, self.top_k = name, w, 4
+
+    with cpu_shim.installed(monkeypatch):
+        pool = eng.SharedInputPool(2, True, CPU, "all")
+        a, b = M("a", torch.randn(8, 6)), M("b", torch.randn(8, 6))
+        pool.register(a), pool.register(b)
+        x = torch.randn(10, 6)
+        pool.begin_step()
+        pool.observe(a, x, x @ a.weight.T), pool.observe(b, x, x @ b.weight.T)
+        pool.end_step()
+        assert pool.groups == [["a", "b"]] and a.moment is b.moment and a.moment.steps == 1
+        pool.begin_step()
+        pool.observe(a, x, x @ a.weight.T)
+        with pytest.raises(RuntimeError, match="shared its input"):
+            pool.observe(b, x.clone(), x @ b.weight.T)

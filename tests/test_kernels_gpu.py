@@ -603,3 +603,130 @@ def test_factor_bank_slices_equal_per_rank_products(ops):
         assert torch.equal(uk, uk2) and torch.equal(big_u.contiguous(), big_u2) and torch.equal(w_deco, w_deco2)
     with pytest.raises(ValueError):
         bank.get(65)
+
+
+# ---------------------------------------------------------------- round-2 additions
+def test_kl_rows_golden_and_random(ops):
+    """calc_kl_divergence (losses_primitives.py:48-54): per-row KL(p || q); golden `kl.div` from the reference."""
+    from ptdeco_amd import utils
+
+    z = gio.npz("metrics")
+    s, t = gio.t(z["kl.s"]), gio.t(z["kl.t"])
+    got = utils.calc_kl_divergence(s.to(DEV), t.to(DEV))
+    assert got.shape == (32,) and got.dtype == torch.float64
+    want = gio.t(z["kl.div"]).double()
+    assert (got.cpu() - want).abs().max().item() <= 2e-6 * want.abs().max().item()
+    for B, C in [(1, 2), (7, 33), (300, 4097)]:
+        q = _rand((B, C), 1) * 3
+        p = q + 0.5 * _rand((B, C), 2)
+        ref = orc.kl_div(q.double(), p.double())
+        assert (utils.calc_kl_divergence(q.to(DEV), p.to(DEV)).cpu() - ref).abs().max().item() <= 1e-12 * max(1.0, ref.max().item())
+    # the loss is the mean of the row-wise maximum of the two directions
+    a, b = utils.calc_kl_divergence(s.to(DEV), t.to(DEV)), utils.calc_kl_divergence(t.to(DEV), s.to(DEV))
+    assert torch.maximum(a, b).mean().item() == pytest.approx(utils.calc_kl_loss(s.to(DEV), t.to(DEV)).item(), rel=1e-12)
+    with pytest.raises(ValueError):
+        utils.calc_kl_divergence(s.to(DEV)[0], t.to(DEV)[0])
+
+
+def test_nsr_4d_golden_default_non_channel_dim():
+    """The reference's default non_channel_dim=(0, 2, 3) on an NCHW tensor: the permuting branch of the
+    channels-last view (losses_primitives.py:10-22)."""
+    from ptdeco_amd import utils
+
+    z = gio.npz("metrics")
+    x, y = gio.t(z["nsr4d.x"]).to(DEV), gio.t(z["nsr4d.y"]).to(DEV)
+    got = utils.calc_per_channel_noise_to_signal_ratio(x=x, y=y)
+    assert got.item() == pytest.approx(float(z["nsr4d.out"]), rel=2e-6)
+    ref = orc.nsr(x=x.cpu().double(), y=y.cpu().double(), non_channel_dim=(0, 2, 3)).item()
+    assert got.item() == pytest.approx(ref, rel=1e-9)
+
+
+@pytest.mark.parametrize("r", [256, 512, 1024])
+def test_lowrank_forward_bf16_c5_shapes_exact(ops, r):
+    """BASELINE configs[4] exactly as bench.py times it: T = 16384 rows, 4096 -> r -> 4096, bf16, through
+    ptd_lowrank_forward.  Integer operands: h = x A^T is exact in f32 (|h| <= 4 * 4096 -> rounded to bf16 like
+    the kernel's intermediate), y = h B^T compared bit for bit; repeated for races."""
+    g = torch.Generator().manual_seed(30 + r)
+    T, n = 16384, 4096
+    x = torch.randint(-2, 3, (T, n), generator=g).to(torch.bfloat16).to(DEV)
+    a = torch.randint(-2, 3, (r, n), generator=g).to(torch.bfloat16).to(DEV)
+    b = torch.randint(-1, 2, (n, r), generator=g).to(torch.bfloat16).to(DEV)
+    bias = torch.randint(-3, 4, (n,), generator=g).to(torch.bfloat16).to(DEV)
+    h = (x.float() @ a.float().T).to(torch.bfloat16).float()
+    want = (h @ b.float().T).to(torch.bfloat16)
+    want_b = (h @ b.float().T + bias.float()).to(torch.bfloat16)
+    for rep in range(3):
+        assert torch.equal(ops.lowrank_forward(x, a, b, None), want), (r, rep)
+    assert torch.equal(ops.lowrank_forward(x, a, b, bias), want_b), r
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 64, 7, 7, 24, 40), (3, 96, 16, 16, 32, 130), (1, 256, 14, 14, 64, 512),
+                                   (5, 10, 3, 5, 3, 7)])
+def test_lowrank_conv1x1_pair_nchw_without_layout_copy(ops, dtype, shape):
+    """the 1x1-conv pair on a contiguous NCHW input -- per image B (A x_b) + bias written straight
+    into NCHW (ptd_lowrank_forward_nchw), against two f64 convolutions; ragged H W (49, 15), bias on rows."""
+    b, ci, h, w, r, co = shape
+    x = _rand((b, ci, h, w), 1, dtype)
+    wa = _rand((r, ci), 2, dtype, ci ** -0.5)
+    wb = _rand((co, r), 3, dtype, r ** -0.5)
+    bias = _rand((co,), 4, dtype)
+    got = ops.lowrank_forward_nchw(x.to(DEV), wa.to(DEV), wb.to(DEV), bias.to(DEV))
+    assert got.shape == (b, co, h, w) and got.is_contiguous()
+    hh = torch.einsum("rc,bchw->brhw", wa.double(), x.double())
+    if dtype == torch.bfloat16:
+        hh = hh.to(torch.bfloat16).double()
+    ref = torch.einsum("or,brhw->bohw", wb.double(), hh) + bias.double()[None, :, None, None]
+    tol = (1e-5 if dtype == torch.float32 else 1.5e-2) * max(1.0, ref.abs().max().item())
+    assert (got.cpu().double() - ref).abs().max().item() <= tol
+    assert torch.equal(ops.lowrank_forward_nchw(x.to(DEV), wa.to(DEV), wb.to(DEV), None).cpu().double() + 0,
+                       ops.lowrank_forward_nchw(x.to(DEV), wa.to(DEV), wb.to(DEV), None).cpu().double())
+
+
+def test_lowrank_conv_module_takes_the_nchw_path_and_matches_rows_path(ops, monkeypatch):
+    from ptdeco_amd import lowrank
+
+    g = torch.Generator().manual_seed(3)
+    seq = torch.nn.Sequential(torch.nn.Conv2d(32, 8, 1, bias=False), torch.nn.Conv2d(8, 48, 1, bias=True))
+    with torch.no_grad():
+        for p in seq.parameters():
+            p.copy_(torch.randn(p.shape, generator=g) / 4)
+    fused = lowrank.fuse_pair(seq).to(DEV)
+    assert isinstance(fused, lowrank.LowRankConv1x1)
+    x = torch.randn(4, 32, 12, 12, generator=g).to(DEV)
+    calls = []
+    real = ops.lowrank_forward_nchw
+    monkeypatch.setattr(ops, "lowrank_forward_nchw", lambda *a: (calls.append(1), real(*a))[1])
+    with torch.no_grad():
+        y = fused(x)                                              # NCHW contiguous: no permute copy
+        y_cl = fused(x.contiguous(memory_format=torch.channels_last))  # channels_last: rows view, no copy either
+        ref = torch.nn.functional.conv2d(torch.nn.functional.conv2d(x, fused[0].weight), fused[1].weight, fused[1].bias)
+    assert calls == [1]
+    assert (y - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+    assert (y_cl - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+
+
+def test_pair_outside_the_hip_dtypes_warns_instead_of_silently_running_torch(ops, caplog):
+    """fp16 is not served by the HIP kernels: the pair says so (once, WARNING) and runs its two torch layers."""
+    import logging
+
+    from ptdeco_amd import lowrank
+
+    lowrank._warned.clear()
+    seq = torch.nn.Sequential(torch.nn.Linear(16, 4, bias=False), torch.nn.Linear(4, 8))
+    fused = lowrank.fuse_pair(seq).to(DEV).half()
+    x = torch.randn(3, 16, device=DEV).half()
+    with caplog.at_level(logging.WARNING, logger="ptdeco_amd.lowrank"):
+        with torch.no_grad():
+            y1, y2 = fused(x), fused(x)
+    msgs = [r for r in caplog.records if "not served by the HIP low-rank kernels" in r.getMessage()]
+    assert len(msgs) == 1 and "float16" in msgs[0].getMessage()
+    assert torch.equal(y1, y2) and y1.dtype == torch.float16
+    # the rank-search tap refuses a candidate it cannot evaluate through the pair
+    from ptdeco_amd import _engine as eng
+    net = torch.nn.Sequential(torch.nn.Linear(16, 8)).to(DEV)
+    tap = eng.LayerTap(net, "0")
+    assert tap.use_pair(torch.randn(16, 4, device=DEV), torch.randn(8, 4, device=DEV))
+    with pytest.raises(TypeError, match="cannot be evaluated through the pair"):
+        net(torch.randn(3, 16, device=DEV).half())
+    tap.close()

@@ -121,10 +121,14 @@ def _seq_ce(batch, logits):
 def test_dwain_llama_shaped_mini_matches_oracle(splits):
     """14 decomposable layers of four distinct shapes incl. n_out > n_in (gate/up) and
     n_out < n_in (k, v, down); head blacklisted; f32 model, f64 decomposition; with and without the
-    precompute-in-splits pass.  Same decisions as the CPU oracle, outputs within 1e-4."""
+    precompute-in-splits pass.  Same decisions as the CPU oracle, outputs within 1e-4.
+
+    Seed 52 was picked on the CPU (45 seeds scanned with the oracle) so that in BOTH variants every
+    step of the oracle's run is more than 1e-3 away from every threshold it is compared with: the
+    decision, config and end-state comparisons below are unconditional."""
     import ptdeco_amd
 
-    g = torch.Generator().manual_seed(11)
+    g = torch.Generator().manual_seed(52)
     model = LlamaMini()
     with torch.no_grad():
         for p in model.parameters():
@@ -148,19 +152,23 @@ def test_dwain_llama_shaped_mini_matches_oracle(splits):
 
     margins = [min(abs(t["ppl_diff"] - t["threshold"]), abs(t["ppl_diff"] - 0.05), abs(t["nsr"] - 0.05))
                for t in ref_trace]
-    assert [(t["layer"], t["rank"]) for t in trace] == [(t["layer"], t["rank"]) for t in ref_trace]
-    for t, r, mg in zip(trace, ref_trace, margins):
+    assert min(margins) > 1e-3, f"the oracle run is within {min(margins):.1e} of a threshold: pick another seed"
+    assert [(t["layer"], t["rank"], t["accepted"]) for t in trace] == \
+           [(t["layer"], t["rank"], t["accepted"]) for t in ref_trace]
+    for t, r in zip(trace, ref_trace):
         assert abs(t["nsr"] - r["nsr"]) <= 1e-4 * abs(r["nsr"]) + 2e-6, (t, r)
         assert abs(t["ppl_diff"] - r["ppl_diff"]) <= 1e-4 * abs(r["ppl_diff"]) + 2e-5, (t, r)
-        if mg > 1e-3:  # decisions must agree wherever the reference is not within 1e-3 of a threshold
-            assert t["accepted"] == r["accepted"], (t, r)
-    if all(m > 1e-3 for m in margins):
-        assert list(cfg.keys()) == list(ref_cfg.keys())
-        with torch.no_grad():
-            out = model({"x": xs[0].to(DEV)}).cpu()
-            ref = ref_model({"x": xs[0]})
-        assert (out - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
-    assert len(trace) >= 14
+    assert len(trace) >= 14 and len(ref_cfg) >= 3 and sum(t["accepted"] for t in ref_trace) >= 4
+    assert list(cfg.keys()) == list(ref_cfg.keys())
+    for name in cfg:
+        assert cfg[name]["modules"] == ref_cfg[name]["modules"], name
+        a_g, b_g = (model.get_submodule(name)[i].weight.detach().cpu().double() for i in (0, 1))
+        a_r, b_r = (ref_model.get_submodule(name)[i].weight.detach().double() for i in (0, 1))
+        assert (b_g @ a_g - b_r @ a_r).norm().item() <= 1e-4 * (b_r @ a_r).norm().item(), name
+    with torch.no_grad():
+        out = model({"x": xs[0].to(DEV)}).cpu()
+        ref = ref_model({"x": xs[0]})
+    assert (out - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
 
 
 def test_dwain_bf16_model_runs_and_tracks_f32():
@@ -205,13 +213,18 @@ def test_dwain_bf16_model_runs_and_tracks_f32():
 def test_falor_vit_shaped_mini_matches_oracle():
     """ViT layout (patch convolution, class token, softmax attention, GELU MLP, biases): 9 Linear
     layers of four shapes incl. qkv (n_out = 3 n_in) and fc2 (n_out < n_in).  Same bisection path as
-    the CPU oracle wherever it is not within 1e-3 of a threshold, metrics within 1e-4."""
+    the CPU oracle, metrics within 1e-4, same config, factor products and outputs.
+
+    A bisection homes in on its thresholds, so some step always lands near one; the seeds (model 3,
+    data 6: best of 200 pairs scanned on the CPU with the oracle) leave every step of the oracle's run
+    more than 5e-4 from both thresholds -- 40x the 1e-4-relative tolerance the metrics are compared
+    at, so an agreeing metric implies an agreeing decision and every comparison is unconditional."""
     import ptdeco_amd
 
     model = tm.ViT(img=32, patch=8, d=96, depth=2, heads=4, mlp=256, classes=24)
     tm.init_randn(model, 3)
     model.eval()
-    g = torch.Generator().manual_seed(4)
+    g = torch.Generator().manual_seed(6)
     pool = [torch.randn(24, 3, 32, 32, generator=g) for _ in range(9)]
     kw = dict(proportion_threshold=0.95, nsr_final_threshold=0.08, kl_final_threshold=0.02, num_data_steps=3,
               num_metric_steps=2, use_float64=True, use_mean=True, use_damping=True)
@@ -222,32 +235,24 @@ def test_falor_vit_shaped_mini_matches_oracle():
     cfg = ptdeco_amd.falor.decompose_in_place(module=model, device=DEV,
                                               data_iterator=itertools.cycle([x.to(DEV) for x in pool]), trace=trace, **kw)
     assert len(ref_trace) >= 50
-    # the bisection is a decision chain: compare layer by layer up to the first near-threshold step
-    by_layer = {}
-    for t in ref_trace:
-        by_layer.setdefault(t["layer"], []).append(t)
-    mine = {}
-    for t in trace:
-        mine.setdefault(t["layer"], []).append(t)
-    assert list(mine.keys()) == list(by_layer.keys())
-    clean = True
-    for name, ref_steps in by_layer.items():
-        for t, r in zip(mine[name], ref_steps):
-            assert t["rank"] == r["rank"], (t, r)
-            assert abs(t["nsr"] - r["nsr"]) <= 1e-4 * abs(r["nsr"]) + 2e-6, (t, r)
-            assert abs(t["kl"] - r["kl"]) <= 1e-4 * abs(r["kl"]) + 2e-6, (t, r)
-            if min(abs(r["nsr"] - 0.08), abs(r["kl"] - 0.02)) <= 1e-3:
-                clean = False
-                break  # later ranks of this layer may legitimately differ
-            assert t["accepted"] == r["accepted"], (t, r)
-    if clean:
-        assert list(cfg.keys()) == list(ref_cfg.keys())
-        for name in cfg:
-            assert cfg[name]["modules"] == ref_cfg[name]["modules"]
-        with torch.no_grad():
-            out = model(pool[0].to(DEV)).cpu()
-            ref = ref_model(pool[0])
-        assert (out - ref).abs().max().item() <= 1e-4 * ref.abs().max().item() + 1e-6
+    margin = min(min(abs(r["nsr"] - 0.08), abs(r["kl"] - 0.02)) for r in ref_trace)
+    assert margin > 3e-4, f"the oracle run is within {margin:.1e} of a threshold: pick other seeds"
+    assert [(t["layer"], t["rank"], t["accepted"]) for t in trace] == \
+           [(t["layer"], t["rank"], t["accepted"]) for t in ref_trace]
+    for t, r in zip(trace, ref_trace):
+        assert abs(t["nsr"] - r["nsr"]) <= 1e-4 * abs(r["nsr"]) + 2e-6, (t, r)
+        assert abs(t["kl"] - r["kl"]) <= 1e-4 * abs(r["kl"]) + 2e-6, (t, r)
+    assert len(ref_cfg) >= 4 and list(cfg.keys()) == list(ref_cfg.keys())
+    for name in cfg:
+        assert cfg[name]["modules"] == ref_cfg[name]["modules"]
+        assert cfg[name]["__meta__"]["proportion"] == ref_cfg[name]["__meta__"]["proportion"]
+        a_g, b_g = (model.get_submodule(name)[i].weight.detach().cpu().double() for i in (0, 1))
+        a_r, b_r = (ref_model.get_submodule(name)[i].weight.detach().double() for i in (0, 1))
+        assert (b_g @ a_g - b_r @ a_r).norm().item() <= 1e-4 * (b_r @ a_r).norm().item(), name
+    with torch.no_grad():
+        out = model(pool[0].to(DEV)).cpu()
+        ref = ref_model(pool[0])
+    assert (out - ref).abs().max().item() <= 1e-4 * ref.abs().max().item() + 1e-6
 
 
 def test_falor_resnet18_shaped_matches_oracle():
@@ -284,3 +289,135 @@ def test_falor_resnet18_shaped_matches_oracle():
     w_g = model.fc[1].weight.detach().cpu().double() @ model.fc[0].weight.detach().cpu().double()
     w_r = ref_model.fc[1].weight.detach().double() @ ref_model.fc[0].weight.detach().double()
     assert (w_g - w_r).norm().item() <= 1e-4 * w_r.norm().item()
+
+
+def test_eigh_factored_full_size_matches_the_direct_route():
+    """The default route of C4's gate / up layers at FULL size (4096 -> 14336, top 1024 as dwain asks):
+    ptd_eigh_factored (n_in-sized problem) against ptd_eigh on the explicit 14336^2 matrix W Ex W^T --
+    eigenvalues, residual on the explicit matrix, orthonormality, projector difference."""
+    from ptdeco_amd import ops
+
+    n_i, n_o, k, t = 4096, 14336, 1024, 8192
+    g = torch.Generator(device="cuda").manual_seed(17)
+    w = torch.randn(n_o, n_i, generator=g, device=DEV) / n_i ** 0.5
+    scale = torch.logspace(0, -2, n_i, device=DEV)
+    e = torch.zeros(n_i, n_i, dtype=torch.float64, device=DEV)
+    for _ in range(2):
+        x = torch.randn(t, n_i, generator=g, device=DEV) * scale
+        ops.syrk_accumulate(e, x, 1.0 / t)
+    ex = ops.cov_finalize(e, 2, 0.0)
+    got = ops.eigh_factored(w, ex, k)
+    assert got is not None
+    lam, u = got
+    assert u.shape == (n_o, k)
+    w64 = w.double()
+    c = ops.cov_finalize(ops.matmul(ops.matmul(w64, ex), w64.T), 1, 0.0)   # explicit, exactly symmetric
+    del w64
+    wmax = lam[-1].item()
+    assert bool(torch.all(lam[1:] >= lam[:-1]))
+    gram = u.T @ u
+    assert (gram - torch.eye(k, dtype=torch.float64, device=DEV)).abs().max().item() <= 5e-9
+    assert (c @ u - u * lam).abs().max().item() <= 1e-10 * wmax
+    w_d, v_d = ops.eigh(c, k, all_values=False)
+    assert (w_d[n_o - k:] - lam).abs().max().item() <= 1e-10 * wmax
+    # same invariant subspaces at the ranks dwain would cut: || U_r U_r^T - V_r V_r^T ||_F^2 = 2 r - 2 ||U_r^T V_r||_F^2
+    for r in (1024, 512, 64):
+        ur, vr = u[:, k - r:], v_d[:, k - r:]
+        d2 = 2.0 * r - 2.0 * (ur.T @ vr).pow(2).sum().item()
+        assert d2 <= (1e-6 * r ** 0.5) ** 2 + 1e-9, (r, d2)
+
+
+def test_dwain_c2_headline_workload_end_to_end_matches_oracle():
+    """BASELINE configs[1] / SURVEY C2 exactly as bench.py runs it (bench.make_workload, DWAIN_KW): dwain on one
+    nn.Linear(4096, 4096), f32 model, f64 decomposition, T = 4 x 1024, D = 4, M = 2, against the CPU oracle on the
+    same seeded inputs: identical (rank, accepted) decisions, nsr / ppl within 1e-4, the chosen pair's product
+    B A within 1e-4 (Frobenius), sign-canonical leading columns where the spectrum is separated, outputs 1e-4."""
+    import bench
+    import ptdeco_amd
+
+    model, data, metric = bench.make_workload(1, "cpu", bench.D_STEPS, 7 * bench.M_STEPS)
+    cpu = torch.device("cpu")
+    data_c, metric_c = bench.with_targets(model, data, cpu), bench.with_targets(model, metric, cpu)
+    gpu_model = copy.deepcopy(model).to(DEV)
+    data_g = [{k: v.to(DEV) for k, v in b.items()} for b in data_c]      # same targets on both sides
+    metric_g = [{k: v.to(DEV) for k, v in b.items()} for b in metric_c]
+
+    ref_trace, trace = [], []
+    ref_cfg = orc.dwain_decompose(module=model, data_iterator=itertools.cycle(data_c), loss_fn=bench.ce_loss,
+                                  metric_iterator=itertools.cycle(metric_c), finetune_fn=None, trace=ref_trace,
+                                  **bench.DWAIN_KW)
+    cfg = ptdeco_amd.dwain.decompose_in_place(
+        module=gpu_model, device=DEV, data_iterator=itertools.cycle(data_g), loss_fn=bench.ce_loss,
+        metric_iterator=itertools.cycle(metric_g), finetune_fn=lambda m, d, n: m, trace=trace, **bench.DWAIN_KW)
+
+    assert len(ref_trace) == 6  # 2048 is skipped (no parameter drop); 1024 .. 32 are evaluated
+    assert [(t["rank"], t["accepted"]) for t in trace] == [(t["rank"], t["accepted"]) for t in ref_trace]
+    for t, r in zip(trace, ref_trace):
+        for key in ("nsr", "ppl_deco", "ppl_diff"):
+            assert abs(t[key] - r[key]) <= 1e-4 * abs(r[key]) + 2e-6, (key, t, r)
+    assert list(cfg.keys()) == list(ref_cfg.keys()) == ["layers.0"]
+    assert cfg["layers.0"]["modules"] == ref_cfg["layers.0"]["modules"]
+    meta, ref_meta = cfg["layers.0"]["__meta__"], ref_cfg["layers.0"]["__meta__"]
+    assert meta["proportion"] == ref_meta["proportion"] and meta["drop_in_params"] == ref_meta["drop_in_params"]
+    a_g, b_g = (gpu_model.layers[0][i].weight.detach().cpu().double() for i in (0, 1))
+    a_r, b_r = (model.layers[0][i].weight.detach().double() for i in (0, 1))
+    prod_r = b_r @ a_r
+    assert (b_g @ a_g - prod_r).norm().item() <= 1e-4 * prod_r.norm().item()
+    # leading eigenvectors (last columns of the second factor): the 64 largest eigenvalues of this spectrum are
+    # separated by relative gaps >> 1e-4, so the sign-canonical columns agree individually
+    def canon(bm):
+        idx = bm.abs().argmax(dim=0)
+        return bm * torch.sign(bm[idx, torch.arange(bm.shape[1])])
+    lead_g, lead_r = canon(b_g[:, -64:]), canon(b_r[:, -64:])
+    assert (lead_g - lead_r).norm().item() <= 1e-4 * lead_r.norm().item()
+    with torch.no_grad():
+        out = gpu_model({"x": data_g[0]["x"]}).cpu()
+        ref = model({"x": data_c[0]["x"]})
+    assert (out - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
+
+
+def test_llama_shaped_stack_shares_input_moments_and_matches_oracle(monkeypatch):
+    """SURVEY 8f-4 on the 2-block Llama-shaped mini stack: with PTD_SHARE_INPUT_COVARIANCE=all the precompute pass
+    performs 4 input-side SYRKs per calibration step (one per q/k/v group and one per gate/up group) instead of
+    10, plus the 4 output-side ones of o and down -- and the run still reproduces the oracle."""
+    import ptdeco_amd
+    from ptdeco_amd import ops
+
+    monkeypatch.setenv("PTD_SHARE_INPUT_COVARIANCE", "all")
+    g = torch.Generator().manual_seed(52)
+    model = LlamaMini()
+    with torch.no_grad():
+        for p in model.parameters():
+            p.copy_(torch.randn(p.shape, generator=g) / p.shape[1] ** 0.5)
+    scale = torch.logspace(0, -1, 512)
+    xs = [torch.randn(2, 96, 512, generator=g) * scale for _ in range(10)]
+    with torch.no_grad():
+        batches = [{"x": x, "targets": model({"x": x}).argmax(-1)} for x in xs]
+    kw = dict(num_data_steps=3, num_metric_steps=1, nsr_final_threshold=0.05, min_rank=16, trade_off_factor=2.0,
+              reduction_factor=0.5, max_accepted_ppl_diff=0.05, decompose_in_float64=True,
+              blacklisted_module_names=["head"], precomputing_covariance_num_splits=1)
+    ref_model, ref_trace = copy.deepcopy(model), []
+    orc.dwain_decompose(module=ref_model, data_iterator=itertools.cycle(batches), loss_fn=_seq_ce,
+                        metric_iterator=itertools.cycle(batches[5:]), trace=ref_trace, **kw)
+    margins = [min(abs(t["ppl_diff"] - t["threshold"]), abs(t["ppl_diff"] - 0.05), abs(t["nsr"] - 0.05))
+               for t in ref_trace]
+    shapes = []
+    real = ops.syrk_accumulate
+    monkeypatch.setattr(ops, "syrk_accumulate", lambda E, y, s: (shapes.append(tuple(E.shape)), real(E, y, s))[1])
+    model.to(DEV)
+    trace = []
+    ptdeco_amd.dwain.decompose_in_place(
+        module=model, device=DEV, data_iterator=itertools.cycle(batches), loss_fn=_seq_ce,
+        metric_iterator=itertools.cycle(batches[5:]), finetune_fn=lambda m, d, n: m, trace=trace, **kw)
+    # per step: 2 blocks x (1 shared x^T x for q/k/v + 1 for gate/up [512^2 each] + o [512^2] + down [512^2])
+    assert len(shapes) == 3 * 8 and all(s == (512, 512) for s in shapes)
+    assert min(margins) > 5e-4  # (seed 52, one split: 9.8e-4 on the CPU)
+    assert [(t["layer"], t["rank"], t["accepted"]) for t in trace] == \
+           [(t["layer"], t["rank"], t["accepted"]) for t in ref_trace]
+    for t, r in zip(trace, ref_trace):
+        assert abs(t["nsr"] - r["nsr"]) <= 1e-4 * abs(r["nsr"]) + 2e-6, (t, r)
+        assert abs(t["ppl_diff"] - r["ppl_diff"]) <= 1e-4 * abs(r["ppl_diff"]) + 2e-5, (t, r)
+    with torch.no_grad():
+        out = model({"x": xs[0].to(DEV)}).cpu()
+        ref = ref_model({"x": xs[0]})
+    assert (out - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
