@@ -119,6 +119,11 @@ int ptd_eigh_factored(const void* W, int64_t ldw, int w_dtype, int64_t n_o, int6
  *                            dispatch-attached events on every 8th launch, scaled), 1 the rest of the
  *                            reduction (alpha kernels, rank-2k updates, launch gaps), 2 work only
  *                            (flops of the rank-2k updates), 3 eigenvalues + inverse iteration +
+ *                            back-transformation
+ *   method 2 (two-stage tridiagonal, n a multiple of 32 in [128, 8192]): ms = {stage 1 dense -> band of
+ *                            width 32 on the f64 matrix cores, stage 2 bulge chasing, eigenpairs of T,
+ *                            back-transformation Q1 Q2 Y}; work = {4/3 n^3 flop, 6 n^2 b flop, 0,
+ *                            4 n^2 k flop}; launches[3] = microseconds of the Q2 part of the
  *                            back-transformation */
 typedef struct {
   int method;
@@ -137,6 +142,16 @@ int ptd_eigh_profiled(const double* A, int64_t lda, int64_t n, int64_t k, int al
 size_t ptd_tridiagonalize_workspace_bytes(int64_t n);
 int ptd_tridiagonalize(const double* A, int64_t lda, int64_t n, double* d, double* e, double* evals,
                        void* ws, size_t ws_bytes, void* stream);
+
+/* Diagnostic: the two-stage reduction (dense -> band of width PTD_BAND -> tridiagonal) stopped after
+ * `stages` (1 or 2) stages.  band [n][PTD_BAND_LD]: entry (i, j) of the band matrix, 0 <= i - j <=
+ * 2 PTD_BAND, at band[i * PTD_BAND_LD + (j - i + 2 PTD_BAND)] (lower part; the matrix is symmetric).
+ * Workspace: ptd_tridiagonalize_workspace_bytes(n).  PTD_ERR_UNSUPPORTED if the two-stage route does
+ * not apply to n. */
+#define PTD_BAND 32
+#define PTD_BAND_LD 66
+int ptd_band_reduce(const double* A, int64_t lda, int64_t n, int stages, double* band, void* ws,
+                    size_t ws_bytes, void* stream);
 
 /* ---- dense products (layer output, factor construction) ----------------- */
 

@@ -37,6 +37,7 @@ SIGNATURES = {
     "ptd_tridiagonalize_workspace_bytes": (c_size_t, [c_int64]),
     "ptd_tridiagonalize": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                    c_void_p]),
+    "ptd_band_reduce": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "ptd_eigh_factored_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int64]),
     "ptd_eigh_factored": (c_int, [c_void_p, c_int64, c_int, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p,
                                   c_void_p, c_int64, c_void_p, c_size_t, c_void_p]),

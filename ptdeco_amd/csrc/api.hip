@@ -122,6 +122,11 @@ int ptd_tridiagonalize(const double* A, int64_t lda, int64_t n, double* d, doubl
   return tridiagonalize_f64(A, lda, n, d, e, evals, ws, ws_bytes, static_cast<hipStream_t>(stream));
 }
 
+int ptd_band_reduce(const double* A, int64_t lda, int64_t n, int stages, double* band, void* ws, size_t ws_bytes,
+                    void* stream) {
+  return band_reduce_f64(A, lda, n, stages, band, ws, ws_bytes, static_cast<hipStream_t>(stream));
+}
+
 int ptd_gemm(const void* A, int64_t sam, int64_t sak, const void* B, int64_t sbk, int64_t sbn, void* C, int64_t ldc,
              int64_t M, int64_t N, int64_t K, int ab_dtype, int c_dtype, double alpha, const void* bias,
              void* stream) {

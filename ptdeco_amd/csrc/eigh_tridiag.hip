@@ -17,6 +17,7 @@
 #include <hip/hip_ext.h>
 
 #include "common.h"
+#include "twostage.h"
 
 namespace ptd {
 
@@ -1091,6 +1092,9 @@ struct TridiagPlan {
   size_t off_u1, off_u2, off_u3, off_lm, off_sw, off_G, off_T, off_W1, off_W2, off_wraw, off_wraw2, off_part2, off_cbuf;
   size_t off_qv, off_px2, off_rowpart, off_colpart, off_gpart, off_tall;
   int64_t ldp;     // leading dimension of the symmetric SYMV's partial-result arrays
+  bool two;        // two-stage reduction (eigh_twostage.hip) available for this order
+  TwoStagePlan ts;
+  size_t off_ts;
   size_t total;
 };
 
@@ -1144,6 +1148,11 @@ TridiagPlan tridiag_plan(int64_t n) {
   p.off_colpart = take((size_t)ceil_div(n, TR) * p.ldp * 8);
   p.off_gpart = take((size_t)p.npanels * ceil_div(n, GCH) * NB * NB * 8);
   p.off_tall = take((size_t)p.npanels * NB * NB * 8);
+  p.two = twostage_supported(n);
+  if (p.two) {
+    p.ts = twostage_plan(n, p.ld);
+    p.off_ts = take(p.ts.total);
+  }
   p.total = o;
   return p;
 }
@@ -1302,7 +1311,8 @@ int tridiag_eigenvalues(const TridiagPlan& p, char* base, int first, hipStream_t
 
 // eigenvectors of T for all eigenvalues into Y (= evecs, [n][ldv]), then Y <- Q Y
 int tridiag_vectors_and_backtransform(const TridiagPlan& p, char* base, int nvec, double* Y, int64_t ldy,
-                                      double ortol, int niter, hipStream_t st) {
+                                      double ortol, int niter, bool two, hipEvent_t ev_vec, hipEvent_t ev_q2,
+                                      hipStream_t st) {
   const int n = p.n;
   const int64_t ld = p.ld;
   double* d = reinterpret_cast<double*>(base + p.off_d);
@@ -1329,6 +1339,10 @@ int tridiag_vectors_and_backtransform(const TridiagPlan& p, char* base, int nvec
     hipLaunchKernelGGL(tridiag_chain_mgs_kernel, dim3((unsigned)nvec), dim3(256), 0, st, lamk, n, nvec, bounds, ortol,
                        Y, ldy);
   PTD_CHECK_LAUNCH("tridiag_invit");
+  if (ev_vec) PTD_CHECK_HIP(hipEventRecord(ev_vec, st));
+  if (two)  // Z = Q1 (Q2 Y); the inverse-iteration factors (off_u1) are dead by now and hold T_p V_p
+    return twostage_backtransform(p.ts, base + p.off_ts, reinterpret_cast<const double*>(base + p.off_A), Vall, ld,
+                                  reinterpret_cast<double*>(base + p.off_u1), Y, ldy, nvec, ev_q2, st);
   // Y <- Q_0 Q_1 ... Q_last Y : apply the panels' block reflectors from the last to the first,
   // Q_p Y = Y - V_p^T (TV_p Y) with TV_p = T_p V_p formed for all panels up front
   double* TVall = reinterpret_cast<double*>(base + p.off_A);  // the working copy of A is dead by now
@@ -1394,29 +1408,61 @@ int eigh_tridiag(const double* A, int64_t lda, int64_t n, int64_t k, double* eva
     for (auto& e : timer.ev) (void)hipEventDestroy(e);
     if (e0) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2); }
   };
-  hipLaunchKernelGGL(copy_pad_kernel, dim3(2048), dim3(256), 0, st, A, lda, (int)n, Aw, p.ld);
-  int rc = sytrd_f64(p, base, stats ? &timer : nullptr, st);
-  if (rc != PTD_OK) { cleanup(); return rc; }
-  if (stats) PTD_CHECK_HIP(hipEventRecord(e1, st));
-  // only the gaps that touch one of the k requested (largest) eigenvalues matter, and unless the caller
-  // wants every eigenvalue only those k + 1 are computed (one wave each: 5.4 ms for all 4096)
+  // Two-stage reduction (dense -> band -> tridiagonal, eigh_twostage.hip) where it applies; its failure words
+  // (a Cholesky breakdown in a panel factorisation: a numerically rank-deficient panel; a chase time-out) are
+  // read at the host synchronisation below and send the matrix through the one-stage reduction instead.
+  bool two = p.two;
+  hipEvent_t em = nullptr, ev = nullptr, eq = nullptr;  // stage 1 | stage 2, vectors | Q2, Q2 | Q1
+  if (stats && two) {
+    PTD_CHECK_HIP(hipEventCreate(&em));
+    PTD_CHECK_HIP(hipEventCreate(&ev));
+    PTD_CHECK_HIP(hipEventCreate(&eq));
+  }
+  auto cleanup2 = [&]() {
+    cleanup();
+    if (em) { (void)hipEventDestroy(em); (void)hipEventDestroy(ev); (void)hipEventDestroy(eq); }
+  };
   const int first = (int)std::max<int64_t>(0, n - k - 1);
-  rc = tridiag_eigenvalues(p, base, all_values ? 0 : first, st);
-  if (rc != PTD_OK) { cleanup(); return rc; }
   double* lam = reinterpret_cast<double*>(base + p.off_lam);
   double* bounds = reinterpret_cast<double*>(base + p.off_bounds);
   const double ortol = 1e-7;  // neighbours closer than this (relative to |T|) are re-orthogonalised
-  hipLaunchKernelGGL(min_gap_kernel, dim3(1), dim3(1024), 0, st, lam + first, (int)n - first, bounds, ortol,
-                     bounds + 4);
   double h_gap[2] = {0.0, 0.0};
-  PTD_CHECK_HIP(hipMemcpyAsync(h_gap, bounds + 4, 16, hipMemcpyDeviceToHost, st));
-  PTD_CHECK_HIP(hipStreamSynchronize(st));
+  int rc = PTD_OK;
+  for (;;) {
+    hipLaunchKernelGGL(copy_pad_kernel, dim3(2048), dim3(256), 0, st, A, lda, (int)n, Aw, p.ld);
+    if (two)
+      rc = twostage_reduce(p.ts, base + p.off_ts, Aw, reinterpret_cast<double*>(base + p.off_V), p.ld,
+                           reinterpret_cast<double*>(base + p.off_d), reinterpret_cast<double*>(base + p.off_e), em, st);
+    else
+      rc = sytrd_f64(p, base, stats ? &timer : nullptr, st);
+    if (rc != PTD_OK) { cleanup2(); return rc; }
+    if (stats) PTD_CHECK_HIP(hipEventRecord(e1, st));
+    // only the gaps that touch one of the k requested (largest) eigenvalues matter, and unless the caller
+    // wants every eigenvalue only those k + 1 are computed (one wave each: 5.4 ms for all 4096)
+    rc = tridiag_eigenvalues(p, base, all_values ? 0 : first, st);
+    if (rc != PTD_OK) { cleanup2(); return rc; }
+    hipLaunchKernelGGL(min_gap_kernel, dim3(1), dim3(1024), 0, st, lam + first, (int)n - first, bounds, ortol,
+                       bounds + 4);
+    int h_status[2] = {0, 0};
+    PTD_CHECK_HIP(hipMemcpyAsync(h_gap, bounds + 4, 16, hipMemcpyDeviceToHost, st));
+    if (two)
+      PTD_CHECK_HIP(hipMemcpyAsync(h_status, twostage_status(p.ts, base + p.off_ts), 8, hipMemcpyDeviceToHost, st));
+    PTD_CHECK_HIP(hipStreamSynchronize(st));
+    if (two && (h_status[0] || h_status[1])) {
+      if (getenv("PTD_JACOBI_DEBUG"))
+        fprintf(stderr, "[eigh_tridiag] two-stage reduction refused (cholesky %d, chase %d): one-stage\n", h_status[0],
+                h_status[1]);
+      two = false;
+      continue;
+    }
+    break;
+  }
   if (getenv("PTD_JACOBI_DEBUG"))
-    fprintf(stderr, "[eigh_tridiag] n=%lld min relative gap %.3e, longest chain of gaps below %.0e: %d\n",
-            (long long)n, h_gap[0], ortol, (int)h_gap[1]);
+    fprintf(stderr, "[eigh_tridiag] n=%lld %s min relative gap %.3e, longest chain of gaps below %.0e: %d\n",
+            (long long)n, two ? "two-stage" : "one-stage", h_gap[0], ortol, (int)h_gap[1]);
   if (n > 1 && (!(h_gap[0] > cluster_tol) || h_gap[1] > 48.0)) {
     set_error("eigh_tridiag: clustered eigenvalues (min relative gap %.3e, chain of %d)", h_gap[0], (int)h_gap[1] + 1);
-    cleanup();
+    cleanup2();
     return PTD_ERR_UNSUPPORTED;
   }
   // Inverse iteration from a random start with eigenvalues exact to working precision: an iteration damps the
@@ -1424,8 +1470,9 @@ int eigh_tridiag(const double* A, int64_t lda, int64_t n, int64_t k, double* eva
   // below 1e-21; closer spectra keep the third (and the re-orthogonalisation above 1e-7)
   static const int force_iter = getenv("PTD_INVIT_ITERS") ? atoi(getenv("PTD_INVIT_ITERS")) : 0;
   const int niter = force_iter > 0 ? force_iter : (h_gap[0] > 1e-5 ? 2 : 3);
-  rc = tridiag_vectors_and_backtransform(p, base, (int)k, evecs, ldv, h_gap[1] > 0.0 ? ortol : 0.0, niter, st);
-  if (rc != PTD_OK) { cleanup(); return rc; }
+  rc = tridiag_vectors_and_backtransform(p, base, (int)k, evecs, ldv, h_gap[1] > 0.0 ? ortol : 0.0, niter, two,
+                                         two ? ev : nullptr, two ? eq : nullptr, st);
+  if (rc != PTD_OK) { cleanup2(); return rc; }
   PTD_CHECK_HIP(hipMemcpyAsync(evals, lam, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
   if (stats) {
     PTD_CHECK_HIP(hipEventRecord(e2, st));
@@ -1434,6 +1481,29 @@ int eigh_tridiag(const double* A, int64_t lda, int64_t n, int64_t k, double* eva
     (void)hipEventElapsedTime(&t_red, e0, e1);
     (void)hipEventElapsedTime(&t_tail, e1, e2);
     stats->total_ms = t_red + t_tail;
+    if (two) {
+      // method 2: ms = {stage 1 (dense -> band), stage 2 (bulge chasing), eigenpairs of T, back-transformation};
+      // work = {4/3 n^3 flop of stage 1, 6 n^2 b flop of stage 2, 0, 4 n^2 k flop of Q2 and Q1};
+      // launches[3] holds the microseconds of the Q2 part of the back-transformation
+      float t1 = 0.f, t_vec = 0.f, t_q2 = 0.f;
+      (void)hipEventElapsedTime(&t1, e0, em);
+      (void)hipEventElapsedTime(&t_vec, e1, ev);
+      (void)hipEventElapsedTime(&t_q2, ev, eq);
+      stats->method = 2;
+      stats->ms[0] = t1;
+      stats->ms[1] = t_red - t1;
+      stats->ms[2] = t_vec;
+      stats->ms[3] = t_tail - t_vec;
+      stats->launches[0] = p.ts.npanels * 9;
+      stats->launches[1] = 1;
+      stats->launches[3] = (int)(t_q2 * 1000.f);
+      const double dn = (double)n;
+      stats->work[0] = 4.0 / 3.0 * dn * dn * dn;
+      stats->work[1] = 6.0 * dn * dn * TS_BAND;
+      stats->work[3] = 4.0 * dn * dn * (double)k;
+      cleanup2();
+      return PTD_OK;
+    }
     // SYMV launches: every stride-th column carries events; the columns of one stride block have
     // nearly the same trailing order, so the block's time is stride x its sample
     double timed_ms = 0.0;
@@ -1454,7 +1524,7 @@ int eigh_tridiag(const double* A, int64_t lda, int64_t n, int64_t k, double* eva
     stats->launches[1] = 2 * (int)n;
     stats->ms[3] = t_tail;
     stats->work[2] = 4.0 / 3.0 * (double)n * (double)n * (double)n;  // rank-2k updates of the full trailing square
-    cleanup();
+    cleanup2();
   }
   return PTD_OK;
 }
@@ -1473,13 +1543,44 @@ int tridiagonalize_f64(const double* A, int64_t lda, int64_t n, double* d_out, d
   char* base = static_cast<char*>(ws);
   double* Aw = reinterpret_cast<double*>(base + p.off_A);
   hipLaunchKernelGGL(copy_pad_kernel, dim3(2048), dim3(256), 0, st, A, lda, (int)n, Aw, p.ld);
-  int rc = sytrd_f64(p, base, nullptr, st);
+  int rc;
+  if (p.two)
+    rc = twostage_reduce(p.ts, base + p.off_ts, Aw, reinterpret_cast<double*>(base + p.off_V), p.ld,
+                         reinterpret_cast<double*>(base + p.off_d), reinterpret_cast<double*>(base + p.off_e), nullptr, st);
+  else
+    rc = sytrd_f64(p, base, nullptr, st);
   if (rc != PTD_OK) return rc;
   rc = tridiag_eigenvalues(p, base, 0, st);
   if (rc != PTD_OK) return rc;
   if (d_out) PTD_CHECK_HIP(hipMemcpyAsync(d_out, base + p.off_d, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
   if (e_out) PTD_CHECK_HIP(hipMemcpyAsync(e_out, base + p.off_e, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
   if (evals_out) PTD_CHECK_HIP(hipMemcpyAsync(evals_out, base + p.off_lam, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
+  return PTD_OK;
+}
+
+// Diagnostic entry: the band matrix after stage 1 (stages = 1) or after both stages (stages = 2) of the
+// two-stage reduction, as band rows [n][TS_LDBAND] (entry (i, j), 0 <= i - j <= 2 b, at [i][j - i + 2 b]).
+int band_reduce_f64(const double* A, int64_t lda, int64_t n, int stages, double* band_out, void* ws, size_t ws_bytes,
+                    hipStream_t st) {
+  PTD_REQUIRE(A && ws && band_out && n >= 1 && lda >= n, "ptd_band_reduce: bad argument");
+  const TridiagPlan p = tridiag_plan(n);
+  if (!p.two) {
+    set_error("ptd_band_reduce: the two-stage reduction does not apply to n = %lld", (long long)n);
+    return PTD_ERR_UNSUPPORTED;
+  }
+  if (ws_bytes < p.total) {
+    set_error("ptd_band_reduce: workspace %zu < required %zu bytes", ws_bytes, p.total);
+    return PTD_ERR_WORKSPACE;
+  }
+  char* base = static_cast<char*>(ws);
+  double* Aw = reinterpret_cast<double*>(base + p.off_A);
+  hipLaunchKernelGGL(copy_pad_kernel, dim3(2048), dim3(256), 0, st, A, lda, (int)n, Aw, p.ld);
+  const int rc = twostage_reduce_stages(p.ts, base + p.off_ts, Aw, reinterpret_cast<double*>(base + p.off_V), p.ld,
+                                        reinterpret_cast<double*>(base + p.off_d),
+                                        reinterpret_cast<double*>(base + p.off_e), nullptr, stages, st);
+  if (rc != PTD_OK) return rc;
+  PTD_CHECK_HIP(hipMemcpyAsync(band_out, base + p.off_ts + p.ts.off_band, (size_t)n * TS_LDBAND * 8,
+                               hipMemcpyDeviceToDevice, st));
   return PTD_OK;
 }
 

@@ -44,6 +44,9 @@ int eigh_tridiag(const double* A, int64_t lda, int64_t n, int64_t k, double* eva
 int tridiagonalize_f64(const double* A, int64_t lda, int64_t n, double* d_out, double* e_out, double* evals_out,
                        void* ws, size_t ws_bytes, hipStream_t st);
 
+int band_reduce_f64(const double* A, int64_t lda, int64_t n, int stages, double* band_out, void* ws, size_t ws_bytes,
+                    hipStream_t st);
+
 // eigh_factored.hip
 size_t eigh_factored_workspace_bytes(int64_t n_o, int64_t n_i, int64_t k);
 int eigh_factored(const void* W, int64_t ldw, int w_dtype, int64_t n_o, int64_t n_i, const double* Ex, int64_t ldx,

@@ -161,6 +161,29 @@ def tridiagonalize(A: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor, torch.T
     return d, e, w
 
 
+def band_reduce(A: torch.Tensor, stages: int = 1) -> torch.Tensor:
+    """Diagnostic: dense symmetric [n, n] matrix with the band of the two-stage reduction after `stages` stages
+    (bandwidth 32 after stage 1, tridiagonal after stage 2; orthogonally similar to A)."""
+    _dev(A)
+    assert A.dtype == torch.float64 and A.dim() == 2 and A.shape[0] == A.shape[1] and A.stride(1) == 1
+    n = A.shape[0]
+    lib = _hip.load()
+    band = torch.empty((n, 66), dtype=torch.float64, device=A.device)
+    ws = torch.empty(lib.ptd_tridiagonalize_workspace_bytes(n), dtype=torch.uint8, device=A.device)
+    with torch.cuda.device(A.device):
+        rc = lib.ptd_band_reduce(A.data_ptr(), A.stride(0), n, int(stages), band.data_ptr(), ws.data_ptr(), ws.numel(),
+                                 _stream(A))
+    _hip.check(rc, "ptd_band_reduce")
+    band = band.cpu()
+    dense = torch.zeros((n, n), dtype=torch.float64)
+    for k in range(65):
+        off = 64 - k  # i - j
+        idx = torch.arange(off, n)
+        dense[idx, idx - off] = band[idx, k]
+    dense = torch.tril(dense) + torch.tril(dense, -1).T
+    return dense
+
+
 def matmul(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = None, alpha: float = 1.0,
            out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
     """a [M, K] @ b [K, N] (+ bias[N]); a and b may be transposed views (no copies are made
