@@ -84,47 +84,104 @@ __global__ __launch_bounds__(256) void ts_gram_kernel(const double* __restrict__
   gram_accumulate(Xs, Ys, cw, G, tid);
 }
 
-// In-LDS factorisations of a 32 x 32 matrix held as S[32][SP], 256 threads.
+// value of `v` in lane `src` (wave-uniform, here always a compile-time constant of an unrolled loop)
+__device__ __forceinline__ double readlane_d(double v, int src) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+
+// Factorisations of a 32 x 32 matrix held in LDS as S[32][SP].  The sequential part runs on ONE wave with the
+// matrix in registers (lane i = row i, right-looking, fully unrolled: the pivot row / column entries travel by
+// v_readlane, there is no LDS traffic and no barrier inside); the other waves of the workgroup wait at the
+// barrier that follows.  (The first version -- in LDS, three workgroup barriers per column -- took 51 us for a
+// Cholesky factorisation + inverse and 137 us for the reconstruction kernel: 24 ms per n = 4096 matrix.)
 // Cholesky (lower, in place in the lower triangle); returns false (to all threads) on a non-positive pivot.
 __device__ bool chol32(double* S, int tid, int* flag_s) {
-  if (tid == 0) *flag_s = 0;
-  __syncthreads();
-  for (int k = 0; k < TB; ++k) {
-    if (tid == 0) {
-      const double piv = S[k * SP + k];
-      if (!(piv > 0.0)) { *flag_s = 1; S[k * SP + k] = 1.0; }
-      else S[k * SP + k] = sqrt(piv);
+  if (tid < 64) {
+    const int i = tid & 31;
+    double w[TB];
+#pragma unroll
+    for (int j = 0; j < TB; ++j) w[j] = S[i * SP + j];
+    int bad = 0;
+#pragma unroll
+    for (int k = 0; k < TB; ++k) {
+      double piv = readlane_d(w[k], k);
+      if (!(piv > 0.0)) { bad = 1; piv = 1.0; }
+      const double d = sqrt(piv);
+      w[k] = (i == k) ? d : w[k] / d;                 // column k of L (rows i > k; the rest is never read)
+#pragma unroll
+      for (int j = k + 1; j < TB; ++j) w[j] -= w[k] * readlane_d(w[k], j);   // S[i][j] -= L[i][k] L[j][k]
     }
-    __syncthreads();
-    if (tid > k && tid < TB) S[tid * SP + k] /= S[k * SP + k];
-    __syncthreads();
-    // trailing update of the lower triangle: rows i > k, columns k < j <= i
-    for (int e = tid; e < TB * TB; e += 256) {
-      const int i = e >> 5, j = e & 31;
-      if (j > k && i >= j) S[i * SP + j] -= S[i * SP + k] * S[j * SP + k];
+    if (tid < TB) {
+#pragma unroll
+      for (int j = 0; j < TB; ++j) S[i * SP + j] = w[j];
     }
-    __syncthreads();
+    if (tid == 0) *flag_s = bad;
   }
+  __syncthreads();
   return *flag_s == 0;
 }
 
-// X = L^-1 for a lower triangular L (unit_diag: the diagonal is taken as 1); one thread per column, result in
-// the lower triangle of X[32][SP], zeros above
-__device__ void tri_lower_inverse32(const double* L, double* X, bool unit_diag, int tid) {
-  if (tid < TB) {
-    const int j = tid;
-    double x[TB];
+// LU without pivoting of W - diag(D), D_kk = -sign of the pivot candidate (|pivot| >= 1: stable), in place:
+// strict lower = multipliers L (unit diagonal implied), upper = U.  Same one-wave register scheme.
+__device__ void lu_signed32(double* W, double* Dg, int tid) {
+  if (tid < 64) {
+    const int i = tid & 31;
+    double w[TB];
 #pragma unroll
-    for (int i = 0; i < TB; ++i) {
-      double acc = (i == j) ? 1.0 : 0.0;
+    for (int j = 0; j < TB; ++j) w[j] = W[i * SP + j];
 #pragma unroll
-      for (int k = 0; k < TB; ++k)
-        if (k < i) acc -= (k >= j ? L[i * SP + k] * x[k] : 0.0);
-      x[i] = (i < j) ? 0.0 : (unit_diag ? acc : acc / L[i * SP + i]);
+    for (int k = 0; k < TB; ++k) {
+      const double cand = readlane_d(w[k], k);
+      const double dg = cand >= 0.0 ? -1.0 : 1.0;
+      const double piv = cand - dg;
+      if (tid == 0) Dg[k] = dg;
+      if (i == k) w[k] = piv;
+      else if (i > k) w[k] = w[k] / piv;             // multiplier
+#pragma unroll
+      for (int j = k + 1; j < TB; ++j) {
+        const double ukj = readlane_d(w[j], k);       // U[k][j]
+        if (i > k) w[j] -= w[k] * ukj;
+      }
     }
+    if (tid < TB) {
 #pragma unroll
-    for (int i = 0; i < TB; ++i) X[i * SP + j] = x[i];
+      for (int j = 0; j < TB; ++j) W[i * SP + j] = w[j];
+    }
   }
+  __syncthreads();
+}
+
+// X = L^-1 for a lower triangular L in LDS (unit_diag: the diagonal is taken as 1), zeros above the diagonal of X.
+// One wave, lane i = row i of L and of X in registers: forward elimination of [L | I], row k of X is final at
+// step k and travels to the rows below by v_readlane (no LDS traffic, no barrier inside; ends with a workgroup
+// barrier).  (One thread per column reading L from LDS element by element: 40 us per call, latency bound.)
+__device__ void tri_lower_inverse32(const double* L, double* X, bool unit_diag, int tid) {
+  if (tid < 64) {
+    const int i = tid & 31;
+    double l[TB], x[TB];
+#pragma unroll
+    for (int j = 0; j < TB; ++j) { l[j] = L[i * SP + j]; x[j] = (i == j) ? 1.0 : 0.0; }
+#pragma unroll
+    for (int k = 0; k < TB; ++k) {
+      if (!unit_diag) {
+        const double dinv = 1.0 / l[k];               // (only lane k's value is used)
+#pragma unroll
+        for (int j = 0; j <= k; ++j) x[j] = (i == k) ? x[j] * dinv : x[j];
+      }
+#pragma unroll
+      for (int j = 0; j <= k; ++j) {
+        const double xkj = readlane_d(x[j], k);       // X[k][j]
+        if (i > k) x[j] -= l[k] * xkj;
+      }
+    }
+    if (tid < TB) {
+#pragma unroll
+      for (int j = 0; j < TB; ++j) X[i * SP + j] = x[j];
+    }
+  }
+  __syncthreads();
 }
 
 // C = op(A) op(B) for 32 x 32 LDS matrices; element (i, k) of op(A) is A[i*sai + k*sak] etc.
@@ -172,28 +229,27 @@ __global__ __launch_bounds__(256) void ts_lmul_kernel(const double* __restrict__
   const int c0 = blockIdx.x * CH;
   const int c = c0 + tid;
   const bool act = tid < CH && c >= c_lo && c < m;
-  double x[TB], o[TB];
+  double x[TB];
   if (act) {
 #pragma unroll
     for (int k = 0; k < TB; ++k) x[k] = X[(int64_t)k * ld + c];
-#pragma unroll
-    for (int i = 0; i < TB; ++i) {
+#pragma unroll 1
+    for (int i = 0; i < TB; ++i) {       // (rolled: the unrolled form is 18 KB of straight-line code run once)
       double acc = 0.0;
 #pragma unroll
       for (int k = 0; k < TB; ++k) acc += Ls[i * TB + k] * x[k];
-      o[i] = acc;
+      X[(int64_t)i * ld + c] = acc;
+      if (G) Os[i * (CH + 1) + tid] = acc;
     }
-#pragma unroll
-    for (int i = 0; i < TB; ++i) X[(int64_t)i * ld + c] = o[i];
   }
   if (zero_out && tid < CH && c < m) {
 #pragma unroll
     for (int i = 0; i < TB; ++i) zero_out[(int64_t)i * ld + c] = 0.0;
   }
   if (G) {
-    if (tid < CH) {
-#pragma unroll
-      for (int i = 0; i < TB; ++i) Os[i * (CH + 1) + tid] = act ? o[i] : 0.0;
+    if (tid < CH && !act) {
+#pragma unroll 1
+      for (int i = 0; i < TB; ++i) Os[i * (CH + 1) + tid] = 0.0;
     }
     __syncthreads();
     gram_accumulate(Os, Os, CH, G, tid);
@@ -226,22 +282,7 @@ __global__ __launch_bounds__(256) void ts_hr_kernel(const double* __restrict__ G
   mm32(X, 1, SP, R2i, 1, SP, W, 1.0, tid);   // op(A)(i,k) = X[k][i]; op(B)(k,j) = R2i[j][k]
   __syncthreads();
   // LU without pivoting of Qtop - D, D_ii = -sign(pivot candidate): |pivot| >= 1
-  for (int i = 0; i < TB; ++i) {
-    if (tid == 0) {
-      const double piv = W[i * SP + i];
-      const double dg = piv >= 0.0 ? -1.0 : 1.0;
-      Dg[i] = dg;
-      W[i * SP + i] = piv - dg;
-    }
-    __syncthreads();
-    if (tid > i && tid < TB) W[tid * SP + i] /= W[i * SP + i];
-    __syncthreads();
-    for (int e = tid; e < TB * TB; e += 256) {
-      const int r = e >> 5, c = e & 31;
-      if (r > i && c > i) W[r * SP + c] -= W[r * SP + i] * W[i * SP + c];
-    }
-    __syncthreads();
-  }
+  lu_signed32(W, Dg, tid);
   // W = strict lower L (unit) + upper U.  Uinv^T: invert the lower triangular U^T
   for (int e = tid; e < TB * TB; e += 256) {
     const int i = e >> 5, j = e & 31;
@@ -306,7 +347,7 @@ __global__ __launch_bounds__(256) void ts_x_kernel(const double* __restrict__ T,
   double w[TB], v[TB];
 #pragma unroll
   for (int k = 0; k < TB; ++k) { w[k] = W0t[(int64_t)k * ld + c]; v[k] = Vt[(int64_t)k * ld + c]; }
-#pragma unroll
+#pragma unroll 1
   for (int i = 0; i < TB; ++i) {
     double acc = 0.0;
 #pragma unroll
@@ -327,6 +368,21 @@ __global__ __launch_bounds__(256) void ts_band_diag_kernel(const double* __restr
   }
 }
 
+// sum over the 16 lanes of a DPP row (quad_perm xor 1, xor 2, row_ror 4, row_ror 8): VALU only, no LDS crossbar
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov_d(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row16_sum(double v) {
+  v += dpp_mov_d<0xB1>(v);
+  v += dpp_mov_d<0x4E>(v);
+  v += dpp_mov_d<0x124>(v);
+  v += dpp_mov_d<0x128>(v);
+  return v;
+}
+
 // ------------------------------------------------------------------------------------------------ stage 2
 __device__ __forceinline__ double ld_sc1(const double* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -336,21 +392,6 @@ __device__ __forceinline__ void st_sc1(double* p, double v) {
 }
 
 constexpr int PROG_DONE = 1 << 30;
-
-// Wait until sweep s - 1 has completed `need` tasks (or all of them).  Bounded: on a time-out (a worker that
-// is not resident: the launch is sized to be co-resident) the failure flag is raised and every worker leaves.
-__device__ __forceinline__ bool chase_wait(const int* prog, int s, int need, int* fail) {
-  if (s == 0) return true;
-  const int* f = prog + (s - 1);
-  for (long spin = 0; spin < 40000000L; ++spin) {
-    const int v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (v >= need) return true;
-    if ((spin & 1023) == 1023 && __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
-    __builtin_amdgcn_s_sleep(1);
-  }
-  __hip_atomic_store(fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return false;
-}
 
 // Householder vector of x (one entry per lane of the first half wave, zero beyond the length): returns v_i for the
 // lane's row, tau and beta (uniform).  LAPACK dlarfg convention, v_0 = 1.
@@ -370,117 +411,315 @@ __device__ __forceinline__ void householder32(double x, int i, bool first_half, 
   v = __shfl(v, i);  // both half waves hold row i: the second half takes it from the first
 }
 
-// Bulge chasing, one wave per sweep (tools/twostage_proto.py: band_to_tridiag).  Lane l = (row i = l & 31,
-// half h = l >> 5) holds columns 16 h .. 16 h + 15 of row i of the 32 x 32 blocks.  All band accesses are
-// agent-scope (sc1) 8-byte loads / stores: the band is handed from wave to wave through L2.
-__global__ __launch_bounds__(64) void ts_chase_kernel(double* __restrict__ band, int n, int* __restrict__ prog,
-                                                      int* __restrict__ fail, double* __restrict__ V2, int64_t ldv2,
-                                                      double* __restrict__ tau2, int npos) {
-  __shared__ double Bs[TB * SP];
-  __shared__ double vb[TB], wb[TB], ub[TB];
-  const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
-#define BAND(gi, gj) band[(int64_t)(gi) * LDB + ((gj) - (gi) + 2 * TB)]
-  for (int s = blockIdx.x; s < n - 2; s += gridDim.x) {
-    int r = s + 1;
-    int ln = min(TB, n - r);
-    if (ln < 2) break;
-    // ---- task 0: reflector from column s, two-sided on the diagonal block
-    if (!chase_wait(prog, s, 2, fail)) return;
-    asm volatile("" ::: "memory");
-    double x = (h == 0 && i < ln) ? ld_sc1(&BAND(r + i, s)) : 0.0;
-    double v, tau, beta;
-    householder32(x, i, h == 0, v, tau, beta);
-    if (i >= ln) v = 0.0;
-    if (h == 0 && i < ln) st_sc1(&BAND(r + i, s), i == 0 ? beta : 0.0);
+// Bulge chasing (tools/twostage_proto.py: band_to_tridiag) as a systolic pipeline.
+//
+// Task (s, p) -- sweep s (column s), block position p -- touches band rows r_p .. r_p + 31, r_p = s + 1 + 32 p, and
+// may run once (s, p - 1) and (s - 1, p + 1) are done: consecutive sweeps follow each other two positions apart,
+// so the critical path is 2 n task times whatever the parallelism.  The first version ran one wave per sweep over
+// a band in L2 (sc1 loads / stores, a progress counter per sweep): a task then costs two global round trips and a
+// store drain, 7 us per sweep, 57 ms at n = 4096.  Here a workgroup owns CG consecutive sweeps (one wave each) and
+// keeps the part of the band they are working on in LDS: a circular window of WROWS band rows that a fourth
+// wave fills ahead of the first sweep and drains behind the last one.  Sweep-to-sweep hand-offs inside a group are
+// LDS progress counters; only group-to-group hand-offs go through global memory (rows stored with sc1, a
+// per-group counter published behind `s_waitcnt vmcnt(0)`, polled with sc1 loads, every spin bounded).
+// Rows of different tasks that may run concurrently are disjoint (a band row belongs to exactly one block row).
+constexpr int CG = 3;             // sweeps (waves) per group
+constexpr int WROWS = 256;        // LDS window, band rows (slot = row % WROWS)
+// window pitch in doubles = the pitch of the band in memory: a column of a block is (row, k = j - i + 64), i.e.
+// stride WP - 1 = 65 doubles over the lanes -- odd in 8-byte units, conflict-free (pitch 65 gave stride 64: every
+// lane of a column access on one bank)
+constexpr int WP = LDB;
+constexpr int CHASE_THREADS = 64 * (CG + 2);   // CG sweep waves, a loader wave, a storer wave
+
+struct ChaseShared {
+  double win[WROWS * WP];
+  double vb[CG][TB], wb[CG][TB];
+  volatile int prog[CG];       // completed tasks of each sweep of the current group
+  volatile int loaded;         // band rows < loaded are in the window
+  volatile int stored;         // band rows < stored have left the window
+  volatile int abort_flag;
+};
+
+__device__ __forceinline__ void lds_order() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// x(i, h = 0) + x(i, h = 1) in both half waves: two v_permlane32_swap + one add (a ds_bpermute shuffle costs an LDS
+// round trip on the dependent chain of every task)
+__device__ __forceinline__ double half_sum(double x) {
+  const unsigned lo = __double2loint(x), hi = __double2hiint(x);
+  const auto r0 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto r1 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __hiloint2double(r1[0], r0[0]) + __hiloint2double(r1[1], r0[1]);
+}
+// the value of lane (i, h = 0) in both half waves
+__device__ __forceinline__ double from_first_half(double x) {
+  const unsigned lo = __double2loint(x), hi = __double2hiint(x);
+  const auto r0 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto r1 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __hiloint2double(r1[0], r0[0]);
+}
+// sum over the 32 lanes of the first half wave (wave-uniform result): DPP row sums + two v_readlane
+__device__ __forceinline__ double sum_first_half(double x) {
+  const double r = row16_sum(x);
+  return readlane_d(r, 0) + readlane_d(r, 16);
+}
+
+// Householder vector of x (one entry per lane of the first half wave, zero beyond the length): returns v_i for the
+// lane's row (both half waves), tau and beta (uniform).  LAPACK dlarfg convention, v_0 = 1.
+__device__ __forceinline__ void householder32w(double x, int i, bool first_half, double& v, double& tau, double& beta) {
+  const double alpha = readlane_d(x, 0);
+  const double sigma = sum_first_half((first_half && i >= 1) ? x * x : 0.0);
+  if (sigma == 0.0) {
+    tau = 0.0; beta = alpha; v = (i == 0) ? 1.0 : 0.0;
+  } else {
+    const double nrm = sqrt(alpha * alpha + sigma);
+    beta = alpha >= 0.0 ? -nrm : nrm;
+    tau = (beta - alpha) / beta;
+    const double sc = 1.0 / (alpha - beta);
+    v = (i == 0) ? 1.0 : x * sc;
+  }
+  v = from_first_half(v);
+}
+
+// one sweep of the chase by one wave, band rows in the LDS window
+__device__ void chase_sweep_wave(ChaseShared& sh, const int w, const int s, const int n,
+                                 double* __restrict__ V2, const int64_t ldv2, double* __restrict__ tau2,
+                                 const int npos, const int dbg) {
+  const int lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
+  double* vb = sh.vb[w];
+  double* wb = sh.wb[w];
+#define WIN(gi, gj) sh.win[((gi) % WROWS) * WP + ((gj) - (gi) + 2 * TB)]
+  // wait until the rows of task p are there: wave 0 waits for the loader, the others for the sweep ahead
+  auto wait_rows = [&](int p, int last_row) -> bool {
+    for (long spin = 0; spin < 200000000L; ++spin) {
+      const bool ok = (w == 0) ? (sh.loaded > last_row) : (sh.prog[w - 1] >= p + 2);
+      if (ok) return true;
+      if (sh.abort_flag) return false;
+      __builtin_amdgcn_s_sleep(1);
+    }
+    sh.abort_flag = 1;
+    return false;
+  };
+  int r = s + 1;
+  int ln = min(TB, n - r);
+  if (dbg & 1) {   // timing experiment: the hand-off protocol only, no arithmetic
     int p = 0;
     for (;;) {
-      // two-sided update of the diagonal block D (rows / columns r .. r + ln) with (v, tau)
-      double Dv[16];
-#pragma unroll
-      for (int jj = 0; jj < 16; ++jj) {
-        const int j = 16 * h + jj;
-        double val = 0.0;
-        if (i < ln && j < ln) val = (j <= i) ? ld_sc1(&BAND(r + i, r + j)) : ld_sc1(&BAND(r + j, r + i));
-        Dv[jj] = val;
-      }
-      if (h == 0) vb[i] = v;
-      __syncthreads();
-      double part = 0.0;
-#pragma unroll
-      for (int jj = 0; jj < 16; ++jj) part += Dv[jj] * vb[16 * h + jj];
-      part += __shfl_xor(part, 32);
-      double w = tau * part;
-      const double wv = wave_sum64(h == 0 ? w * v : 0.0);
-      w -= 0.5 * tau * wv * v;
-      if (h == 0) wb[i] = w;
-      __syncthreads();
-#pragma unroll
-      for (int jj = 0; jj < 16; ++jj) {
-        const int j = 16 * h + jj;
-        Dv[jj] -= v * wb[j] + w * vb[j];
-        if (j <= i && i < ln) st_sc1(&BAND(r + i, r + j), Dv[jj]);
-      }
-      if (h == 0 && i < ln) V2[(int64_t)s * ldv2 + r + i] = v;
-      if (lane == 0) tau2[(int64_t)s * npos + p] = tau;
-      // publish: every store of this task has left the wave, then the counter
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (!wait_rows(p, r + ln - 1)) return;
       ++p;
-      if (lane == 0) __hip_atomic_store(prog + s, p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      // ---- next block position
-      const int c0 = r;
-      r = c0 + ln;           // (ln == TB whenever another block follows)
+      if (lane == 0) sh.prog[w] = p;
+      r += ln;
       ln = min(TB, n - r);
       if (ln <= 0) break;
-      if (!chase_wait(prog, s, p + 2, fail)) return;
-      asm volatile("" ::: "memory");
-      // B = A[r : r + ln, c0 : c0 + TB]: right-apply the previous reflector (v over the columns)
-      double Bv[16];
-#pragma unroll
-      for (int jj = 0; jj < 16; ++jj) {
-        const int j = 16 * h + jj;
-        Bv[jj] = (i < ln) ? ld_sc1(&BAND(r + i, c0 + j)) : 0.0;
-      }
-      // (vb still holds v indexed by the previous block's row = this block's column)
-      part = 0.0;
-#pragma unroll
-      for (int jj = 0; jj < 16; ++jj) part += Bv[jj] * vb[16 * h + jj];
-      part += __shfl_xor(part, 32);
-      const double t = tau * part;
-#pragma unroll
-      for (int jj = 0; jj < 16; ++jj) Bv[jj] -= t * vb[16 * h + jj];
-      // new reflector from the first column of B
-      double vn, taun, betan;
-      householder32(h == 0 ? Bv[0] : 0.0, i, h == 0, vn, taun, betan);
-      if (i >= ln) vn = 0.0;
-      if (ln < 2) { taun = 0.0; }
-      // left-apply to the columns 1 .. of B: u_j = sum_i vn_i B_ij through an LDS transpose
-      __syncthreads();   // vb reads above are done before it is overwritten below
-#pragma unroll
-      for (int jj = 0; jj < 16; ++jj) Bs[i * SP + 16 * h + jj] = Bv[jj];
-      if (h == 0) wb[i] = vn;
-      __syncthreads();
-      {
-        const int j = i, g = h;   // lane -> column j, row half g
-        double up = 0.0;
-#pragma unroll
-        for (int ii = 0; ii < 16; ++ii) up += wb[16 * g + ii] * Bs[(16 * g + ii) * SP + j];
-        up += __shfl_xor(up, 32);
-        if (g == 0) ub[j] = up;
-      }
-      __syncthreads();
-#pragma unroll
-      for (int jj = 0; jj < 16; ++jj) {
-        const int j = 16 * h + jj;
-        if (j == 0) Bv[jj] = (i == 0) ? betan : 0.0;   // H x = beta e1
-        else Bv[jj] -= taun * vn * ub[j];
-        if (i < ln) st_sc1(&BAND(r + i, c0 + j), Bv[jj]);
-      }
-      v = vn; tau = taun;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0) __hip_atomic_store(prog + s, PROG_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) sh.prog[w] = PROG_DONE;
+    return;
   }
-#undef BAND
+  if (!wait_rows(0, r + ln - 1)) return;
+  lds_order();
+  double x = (h == 0 && i < ln) ? WIN(r + i, s) : 0.0;
+  double v, tau, beta;
+  householder32w(x, i, h == 0, v, tau, beta);
+  if (i >= ln) v = 0.0;
+  if (h == 0 && i < ln) WIN(r + i, s) = (i == 0) ? beta : 0.0;
+  if (h == 0) vb[i] = v;
+  int p = 0;
+  for (;;) {
+    // ---- two-sided update of the diagonal block D (rows / columns r .. r + ln) with (v, tau); vb holds v
+    double Dv[16];
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) {
+      const int j = 16 * h + jj;
+      double val = 0.0;
+      if (i < ln && j < ln) val = (j <= i) ? WIN(r + i, r + j) : WIN(r + j, r + i);
+      Dv[jj] = val;
+    }
+    lds_order();
+    double part = 0.0;
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) part += Dv[jj] * vb[16 * h + jj];
+    double wv_ = tau * half_sum(part);
+    const double dotwv = sum_first_half(wv_ * v);
+    wv_ -= 0.5 * tau * dotwv * v;
+    if (h == 0) wb[i] = wv_;
+    lds_order();
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) {
+      const int j = 16 * h + jj;
+      Dv[jj] -= v * wb[j] + wv_ * vb[j];
+      if (j <= i && i < ln) WIN(r + i, r + j) = Dv[jj];
+    }
+    if (h == 0 && i < ln) V2[(int64_t)s * ldv2 + r + i] = v;
+    if (lane == 0) tau2[(int64_t)s * npos + p] = tau;
+    lds_order();
+    ++p;
+    if (lane == 0) sh.prog[w] = p;
+    // ---- next block position
+    const int c0 = r;
+    r = c0 + ln;
+    ln = min(TB, n - r);
+    if (ln <= 0) break;
+    if (!wait_rows(p, r + ln - 1)) return;
+    lds_order();
+    // B = A[r : r + ln, c0 : c0 + 32] by rows: right-apply the previous reflector (vb over the columns)
+    double Bv[16];
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) Bv[jj] = (i < ln) ? WIN(r + i, c0 + 16 * h + jj) : 0.0;
+    part = 0.0;
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) part += Bv[jj] * vb[16 * h + jj];
+    const double t = tau * half_sum(part);
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) Bv[jj] -= t * vb[16 * h + jj];
+    // new reflector from the first column of B;  H x = beta e1
+    double vn, taun, betan;
+    householder32w(h == 0 ? Bv[0] : 0.0, i, h == 0, vn, taun, betan);
+    if (i >= ln) vn = 0.0;
+    if (ln < 2) taun = 0.0;
+    lds_order();   // (every read of the old vb is done)
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) {
+      const int j = 16 * h + jj;
+      if (i < ln) WIN(r + i, c0 + j) = (j == 0) ? ((i == 0) ? betan : 0.0) : Bv[jj];
+    }
+    if (h == 0) vb[i] = vn;
+    lds_order();
+    // left-apply to the columns 1 .. 31 by columns, through the window (no private transposition buffer): lane
+    // (j, g) holds rows 16 g .. 16 g + 15 of column j; a column access has stride 65 doubles: conflict-free
+    {
+      const int j = i, g = h;
+      double cv[16];
+#pragma unroll
+      for (int ii = 0; ii < 16; ++ii) cv[ii] = (16 * g + ii < ln) ? WIN(r + 16 * g + ii, c0 + j) : 0.0;
+      double up = 0.0;
+#pragma unroll
+      for (int ii = 0; ii < 16; ++ii) up += vb[16 * g + ii] * cv[ii];
+      const double u = taun * half_sum(up);
+      if (j >= 1) {
+#pragma unroll
+        for (int ii = 0; ii < 16; ++ii)
+          if (16 * g + ii < ln) WIN(r + 16 * g + ii, c0 + j) = cv[ii] - u * vb[16 * g + ii];
+      }
+    }
+    lds_order();
+    v = vn; tau = taun;
+  }
+  lds_order();
+  if (lane == 0) sh.prog[w] = PROG_DONE;
+#undef WIN
+}
+
+// Loader wave of a group: brings 32-row chunks of the band into the window ahead of the first sweep, once the
+// previous group has published them (band rows are contiguous in memory: a chunk is one flat, fully coalesced range).
+__device__ void chase_loader_wave(ChaseShared& sh, const int grp, const int s_base, const int n,
+                                  const double* __restrict__ band, const int* __restrict__ gprog, int* __restrict__ fail,
+                                  const int dbg) {
+  const int lane = threadIdx.x & 63;
+  const int base_row = s_base + 1;
+  int loaded = base_row, chunk = 0;
+  long idle = 0;
+  while (loaded < n) {
+    const int hi = min(n, base_row + TB * (chunk + 1));
+    bool ready = hi - sh.stored <= WROWS - 8;
+    if (ready && grp > 0)
+      ready = __hip_atomic_load(gprog + grp - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= chunk + 2;
+    if (ready) {
+      asm volatile("" ::: "memory");
+      constexpr int UB = 34;   // 32 rows x 66 doubles = 33 wave loads: the whole chunk in flight
+      if (!(dbg & 2)) {
+        const int e0 = loaded * LDB, e1 = hi * LDB;
+        double tmp[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+          const int e = e0 + 64 * u + lane;
+          tmp[u] = (e < e1) ? ld_sc1(&band[e]) : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+          const int e = e0 + 64 * u + lane;
+          const int row = e / LDB, k = e - row * LDB;
+          if (e < e1) sh.win[(row % WROWS) * WP + k] = tmp[u];
+        }
+      }
+      lds_order();
+      loaded = hi;
+      ++chunk;
+      if (lane == 0) sh.loaded = loaded;
+      idle = 0;
+    } else {
+      if (sh.abort_flag) return;
+      if (++idle > 100000000L || ((idle & 1023) == 0 && __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+        sh.abort_flag = 1;
+        __hip_atomic_store(fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+}
+
+// Storer wave of a group: writes the rows the last sweep is done with back to memory and publishes the group's
+// progress (the next group's loader polls it).
+__device__ void chase_storer_wave(ChaseShared& sh, const int grp, const int ga, const int s_base, const int n,
+                                  double* __restrict__ band, int* __restrict__ gprog, const int dbg) {
+  const int lane = threadIdx.x & 63;
+  const int s_last = s_base + ga - 1;
+  int stored = s_base + 1, pub = 0;
+  for (long idle = 0; idle < 400000000L; ++idle) {
+    const int pl = sh.prog[ga - 1];
+    if (pl > pub) {
+      const int fin = (pl >= PROG_DONE) ? n : min(n, s_last + 1 + TB * pl);   // rows < fin are final
+      lds_order();
+      if (!(dbg & 2)) {
+        for (int e = stored * LDB + lane; e < fin * LDB; e += 64) {
+          const int row = e / LDB, k = e - row * LDB;
+          st_sc1(&band[e], sh.win[(row % WROWS) * WP + k]);
+        }
+      }
+      stored = max(stored, fin);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      pub = pl;
+      if (lane == 0) {
+        sh.stored = stored;
+        __hip_atomic_store(gprog + grp, pl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (pl >= PROG_DONE) return;
+      idle = 0;
+    } else {
+      if (sh.abort_flag) return;
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  sh.abort_flag = 1;
+}
+
+__global__ __launch_bounds__(CHASE_THREADS) void ts_chase_kernel(double* __restrict__ band, int n,
+                                                                 int* __restrict__ gprog, int* __restrict__ fail,
+                                                                 double* __restrict__ V2, int64_t ldv2,
+                                                                 double* __restrict__ tau2, int npos, int dbg) {
+  extern __shared__ char chase_smem[];
+  ChaseShared& sh = *reinterpret_cast<ChaseShared*>(chase_smem);
+  const int wave = threadIdx.x >> 6;
+  const int nsweeps = n - 2;
+  const int ngroups = (nsweeps + CG - 1) / CG;
+  for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int s_base = grp * CG;
+    const int ga = min(CG, nsweeps - s_base);     // active sweeps of this group
+    if (threadIdx.x == 0) {
+      for (int q = 0; q < CG; ++q) sh.prog[q] = 0;
+      sh.loaded = 0;
+      sh.stored = s_base + 1;
+      sh.abort_flag = 0;
+    }
+    __syncthreads();
+    if (wave < ga) chase_sweep_wave(sh, wave, s_base + wave, n, V2, ldv2, tau2, npos, dbg);
+    else if (wave == CG) chase_loader_wave(sh, grp, s_base, n, band, gprog, fail, dbg);
+    else if (wave == CG + 1) chase_storer_wave(sh, grp, ga, s_base, n, band, gprog, dbg);
+    __syncthreads();
+    if (sh.abort_flag) {
+      if (threadIdx.x == 0) __hip_atomic_store(fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+  }
 }
 
 // d, e of the tridiagonal band
@@ -495,44 +734,64 @@ __global__ void ts_extract_tridiag_kernel(const double* __restrict__ band, int n
 
 // -------------------------------------------------------------------------------------- back-transformation
 // Y[:, c0 : c0 + CQ] <- Q2 Y (the reflectors of stage 2 in reverse order of their generation), the column chunk
-// resident in LDS as [CQ][n + 1].  Within a sweep the reflectors touch disjoint rows: wave w takes positions
-// w, w + 8, ...; lane (i, cp) holds row i of the reflector and the column pair cp.
-template <int CQ>
-__global__ __launch_bounds__(512) void ts_apply_q2_kernel(const double* __restrict__ V2, int64_t ldv2,
-                                                          const double* __restrict__ tau2, int npos, int n,
-                                                          double* __restrict__ Y, int64_t ldy, int nvec) {
+// resident in LDS as [CQ][n + 1].  Within a sweep the reflectors touch disjoint rows.  A 16-lane DPP row owns one
+// (reflector, column pair): lane i2 of the row holds rows 2 i2, 2 i2 + 1 of the reflector, so the two dot products
+// are reduced by four DPP adds.  A wave (four DPP rows) handles 4 / PAIRS reflectors per step, wave w of 16 the
+// positions (4 / PAIRS) (w + 16 q) + ..; the reflectors of the NEXT sweep are fetched while the current one is
+// applied.  (First version: one reflector per wave step, 32-lane reductions through ds_bpermute, a dependent global
+// load per reflector: 24 ms at n = 4096, k = 1024.)
+template <int CQ, int MAXQ>
+__global__ __launch_bounds__(1024) void ts_apply_q2_kernel(const double* __restrict__ V2, int64_t ldv2,
+                                                           const double* __restrict__ tau2, int npos, int n,
+                                                           double* __restrict__ Y, int64_t ldy, int nvec) {
   extern __shared__ double Ys[];   // [CQ][n + 1]
+  constexpr int PAIRS = CQ / 2;    // column pairs
+  constexpr int PPI = 4 / PAIRS;   // reflectors per wave step
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c0 = blockIdx.x * CQ;
   const int pitch = n + 1;
-  for (int e = tid; e < n * CQ; e += 512) {
+  for (int e = tid; e < n * CQ; e += 1024) {
     const int r = e / CQ, c = e % CQ;
     Ys[c * pitch + r] = (c0 + c < nvec) ? Y[(int64_t)r * ldy + c0 + c] : 0.0;
   }
+  const int g = lane >> 4, i2 = lane & 15;
+  const int cp = g % PAIRS, ps = g / PAIRS;
+  double* ya = Ys + (2 * cp) * pitch;
+  double* yb = ya + pitch;
+  double va_c[MAXQ], vb_c[MAXQ], t_c[MAXQ], va_n[MAXQ], vb_n[MAXQ], t_n[MAXQ];
+  auto fetch = [&](int s, double (&va)[MAXQ], double (&vb)[MAXQ], double (&t)[MAXQ]) {
+#pragma unroll
+    for (int q = 0; q < MAXQ; ++q) {
+      const int p = PPI * (wave + 16 * q) + ps;
+      const int r = s + 1 + p * TB + 2 * i2;
+      const bool on = s + 1 + p * TB < n;
+      t[q] = on ? tau2[(int64_t)s * npos + p] : 0.0;
+      va[q] = (on && r < n) ? V2[(int64_t)s * ldv2 + r] : 0.0;
+      vb[q] = (on && r + 1 < n) ? V2[(int64_t)s * ldv2 + r + 1] : 0.0;
+    }
+  };
+  fetch(n - 3, va_c, vb_c, t_c);
   __syncthreads();
-  constexpr int PAIRS = CQ / 2;           // column pairs; lanes beyond 32 * PAIRS idle (CQ = 2)
-  const int i = lane & 31, cp = lane >> 5;
-  const bool lane_on = cp < PAIRS;
   for (int s = n - 3; s >= 0; --s) {
-    const int first = s + 1;
-    const int np_s = (n - first + TB - 1) / TB;
-    for (int p = wave; p < np_s; p += 8) {
-      const int r = first + p * TB;
-      const int ln = min(TB, n - r);
-      const double tau = tau2[(int64_t)s * npos + p];
-      const double v = (i < ln) ? V2[(int64_t)s * ldv2 + r + i] : 0.0;
-      double y0 = 0.0, y1 = 0.0;
-      if (lane_on && i < ln) { y0 = Ys[(2 * cp) * pitch + r + i]; y1 = Ys[(2 * cp + 1) * pitch + r + i]; }
-      double d0 = v * y0, d1 = v * y1;
-      for (int o = 16; o > 0; o >>= 1) { d0 += __shfl_xor(d0, o); d1 += __shfl_xor(d1, o); }
-      if (lane_on && i < ln) {
-        Ys[(2 * cp) * pitch + r + i] = y0 - tau * v * d0;
-        Ys[(2 * cp + 1) * pitch + r + i] = y1 - tau * v * d1;
-      }
+    if (s > 0) fetch(s - 1, va_n, vb_n, t_n);
+#pragma unroll
+    for (int q = 0; q < MAXQ; ++q) {
+      const int p = PPI * (wave + 16 * q) + ps;
+      const int r = s + 1 + p * TB + 2 * i2;
+      // (rows beyond n: v = 0 there and tau = 0 for absent reflectors, so clamped reads are harmless)
+      const int ra = min(r, n - 1), rb = min(r + 1, n - 1);
+      const double va = va_c[q], vb = vb_c[q], tau = t_c[q];
+      const double y0a = ya[ra], y0b = ya[rb], y1a = yb[ra], y1b = yb[rb];
+      const double d0 = tau * row16_sum(va * y0a + vb * y0b);
+      const double d1 = tau * row16_sum(va * y1a + vb * y1b);
+      if (r < n) { ya[r] = y0a - va * d0; yb[r] = y1a - va * d1; }
+      if (r + 1 < n) { ya[r + 1] = y0b - vb * d0; yb[r + 1] = y1b - vb * d1; }
     }
     __syncthreads();
+#pragma unroll
+    for (int q = 0; q < MAXQ; ++q) { va_c[q] = va_n[q]; vb_c[q] = vb_n[q]; t_c[q] = t_n[q]; }
   }
-  for (int e = tid; e < n * CQ; e += 512) {
+  for (int e = tid; e < n * CQ; e += 1024) {
     const int r = e / CQ, c = e % CQ;
     if (c0 + c < nvec) Y[(int64_t)r * ldy + c0 + c] = Ys[c * pitch + r];
   }
@@ -555,7 +814,7 @@ __global__ __launch_bounds__(256) void ts_tv_kernel(const double* __restrict__ A
   double v[TB];
 #pragma unroll
   for (int k = 0; k < TB; ++k) v[k] = Vt[(int64_t)k * ld + c];
-#pragma unroll
+#pragma unroll 1
   for (int i = 0; i < TB; ++i) {
     double acc = 0.0;
 #pragma unroll
@@ -595,9 +854,12 @@ TwoStagePlan twostage_plan(int64_t n, int64_t ld) {
   return p;
 }
 
+// Opt-in (PTD_EIGH_STAGES=2, read on every call): as measured on MI355X the two-stage route is correct to
+// 3e-15 but not yet faster than the one-stage reduction at n = 4096 (101 ms against 72 ms, DESIGN.md section 3:
+// the bulge chase is bound by the instruction issue rate of the single wave that executes a task).
 bool twostage_supported(int64_t n) {
-  static const int mode = getenv("PTD_EIGH_STAGES") ? atoi(getenv("PTD_EIGH_STAGES")) : 2;
-  return mode == 2 && n % TB == 0 && n >= 4 * TB && n <= 8192;
+  const char* e = getenv("PTD_EIGH_STAGES");
+  return e && atoi(e) == 2 && n % TB == 0 && n >= 4 * TB && n <= 8192;
 }
 
 // A (working copy, n x n, both triangles, leading dimension ld; destroyed: afterwards it holds the reflector
@@ -658,11 +920,14 @@ int twostage_reduce_stages(const TwoStagePlan& p, char* base, double* Aw, double
   PTD_CHECK_LAUNCH("twostage stage 1");
   if (mid) PTD_CHECK_HIP(hipEventRecord(mid, st));
   if (stages < 2) return PTD_OK;
-  // stage 2: one single-wave workgroup per sweep in flight (at most n / 64 sweeps overlap)
+  // stage 2: a group of CG sweeps per workgroup; a group trails its predecessor by ~2 CG + 2 block positions, so at
+  // most ~n / (32 (2 CG + 2)) groups overlap: one workgroup per CU, all co-resident (the spins are bounded anyway)
   static const int workers_env = getenv("PTD_CHASE_WORKERS") ? atoi(getenv("PTD_CHASE_WORKERS")) : 0;
-  const int workers = workers_env > 0 ? workers_env : (int)std::min<int64_t>(192, std::max<int64_t>(8, n / (2 * TB) + 8));
-  hipLaunchKernelGGL(ts_chase_kernel, dim3((unsigned)workers), dim3(64), 0, st, band, n, prog, status + 1, V2, ldv2, tau2,
-                     p.npos);
+  const int workers = workers_env > 0 ? workers_env : (int)std::min<int64_t>(128, std::max<int64_t>(4, n / (TB * 2 * CG) + 4));
+  PTD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ts_chase_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ChaseShared)));
+  hipLaunchKernelGGL(ts_chase_kernel, dim3((unsigned)workers), dim3(CHASE_THREADS), sizeof(ChaseShared), st, band, n,
+                     prog, status + 1, V2, ldv2, tau2, p.npos, getenv("PTD_CHASE_DBG") ? atoi(getenv("PTD_CHASE_DBG")) : 0);
   hipLaunchKernelGGL(ts_extract_tridiag_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, band, n, d, e);
   PTD_CHECK_LAUNCH("twostage stage 2");
   return PTD_OK;
@@ -681,17 +946,17 @@ int twostage_backtransform(const TwoStagePlan& p, char* base, const double* Aw, 
   if (n <= 4096) {
     constexpr int CQ = 4;
     const size_t lds = (size_t)CQ * (n + 1) * 8;
-    PTD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ts_apply_q2_kernel<CQ>),
+    PTD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ts_apply_q2_kernel<CQ, 4>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(ts_apply_q2_kernel<CQ>, dim3((unsigned)ceil_div(nvec, CQ)), dim3(512), lds, st, V2, ldv2, tau2,
-                       p.npos, n, Y, ldy, nvec);
+    hipLaunchKernelGGL((ts_apply_q2_kernel<CQ, 4>), dim3((unsigned)ceil_div(nvec, CQ)), dim3(1024), lds, st, V2, ldv2,
+                       tau2, p.npos, n, Y, ldy, nvec);
   } else {
     constexpr int CQ = 2;
     const size_t lds = (size_t)CQ * (n + 1) * 8;
-    PTD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ts_apply_q2_kernel<CQ>),
+    PTD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ts_apply_q2_kernel<CQ, 4>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(ts_apply_q2_kernel<CQ>, dim3((unsigned)ceil_div(nvec, CQ)), dim3(512), lds, st, V2, ldv2, tau2,
-                       p.npos, n, Y, ldy, nvec);
+    hipLaunchKernelGGL((ts_apply_q2_kernel<CQ, 4>), dim3((unsigned)ceil_div(nvec, CQ)), dim3(1024), lds, st, V2, ldv2,
+                       tau2, p.npos, n, Y, ldy, nvec);
   }
   PTD_CHECK_LAUNCH("twostage Q2");
   if (mid) PTD_CHECK_HIP(hipEventRecord(mid, st));

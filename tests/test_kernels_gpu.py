@@ -730,3 +730,70 @@ def test_pair_outside_the_hip_dtypes_warns_instead_of_silently_running_torch(ops
     with pytest.raises(TypeError, match="cannot be evaluated through the pair"):
         net(torch.randn(3, 16, device=DEV).half())
     tap.close()
+
+
+# ---------------------------------------------------------------- two-stage tridiagonalisation (opt-in route)
+@pytest.fixture
+def two_stage(monkeypatch):
+    monkeypatch.setenv("PTD_EIGH_STAGES", "2")
+    monkeypatch.setenv("PTD_EIGH_METHOD", "tridiag")
+
+
+def _spd(n, seed):
+    y = _rand((2 * n + 3, n), seed).double() * torch.logspace(0, -2, n, dtype=torch.float64)
+    a = y.T @ y / y.shape[0]
+    return a + torch.eye(n, dtype=torch.float64) * (0.01 * torch.diag(a).mean())
+
+
+@pytest.mark.parametrize("n", [128, 160, 512])
+def test_two_stage_band_and_tridiagonal_are_orthogonally_similar(ops, two_stage, n):
+    """eigh_twostage.hip: stage 1 (CholeskyQR2 + Householder-reconstruction panels, two-sided block updates) leaves a
+    band of width 32, stage 2 (bulge chasing through the LDS window pipeline) a tridiagonal matrix, both with the
+    eigenvalues of A (LAPACK on the host) to working precision."""
+    a = _spd(n, 900 + n)
+    w_ref = torch.linalg.eigvalsh(a)
+    b1 = ops.band_reduce(a.to(DEV), 1)
+    assert torch.tril(b1, -33).abs().max().item() == 0.0
+    assert (torch.linalg.eigvalsh(b1) - w_ref).abs().max().item() <= 1e-13 * w_ref.max().item()
+    b2 = ops.band_reduce(a.to(DEV), 2)
+    assert torch.tril(b2, -2).abs().max().item() == 0.0
+    assert (torch.linalg.eigvalsh(b2) - w_ref).abs().max().item() <= 1e-13 * w_ref.max().item()
+    d, e, w = ops.tridiagonalize(a.to(DEV))
+    # (two runs: the Gram matrices of stage 1 are accumulated with f64 atomics, so they agree to rounding only)
+    assert (d.cpu() - torch.diag(b2)).abs().max().item() <= 1e-12 * w_ref.max().item()
+    assert (e.cpu()[: n - 1].abs() - torch.diag(b2, -1).abs()).abs().max().item() <= 1e-12 * w_ref.max().item()
+    assert (w.cpu() - w_ref).abs().max().item() <= 1e-12 * w_ref.max().item()
+
+
+@pytest.mark.parametrize("n,k", [(256, 64), (1024, 256), (1024, 1024)])
+def test_two_stage_eigh_top_k(ops, two_stage, n, k):
+    """The whole route (reduction, eigenpairs of T, back-transformation Z = Q1 Q2 Y) against LAPACK; the reflectors
+    keep Z orthonormal to 1e-13, two orders better than inverse iteration alone leaves the one-stage route."""
+    a = _spd(n, 70 + n)
+    ops.EIGH_PROFILE = []
+    try:
+        w, v = ops.eigh(a.to(DEV), k)
+        prof = ops.EIGH_PROFILE[0]
+    finally:
+        ops.EIGH_PROFILE = None
+    assert prof["method"] == 2
+    w, v = w.cpu(), v.cpu()
+    w_ref, v_ref = torch.linalg.eigh(a)
+    assert (w - w_ref).abs().max().item() <= 1e-12 * w_ref.max().item()
+    assert (v.T @ v - torch.eye(k, dtype=torch.float64)).abs().max().item() <= 5e-9
+    assert (a @ v - v * w[n - k:]).abs().max().item() <= 1e-11 * w_ref.max().item()
+    p, p_ref = v @ v.T, v_ref[:, n - k:] @ v_ref[:, n - k:].T
+    assert (p - p_ref).norm().item() <= 1e-6 * math.sqrt(k)
+
+
+def test_two_stage_falls_back_on_a_rank_deficient_panel(ops, two_stage):
+    """A numerically singular panel breaks the Cholesky factorisation of its Gram matrix: the failure word is read at
+    the solver's host synchronisation and the matrix goes through the one-stage reduction (or Jacobi) instead."""
+    n = 256
+    y = _rand((40, n), 9).double()          # rank 40 << n, no damping
+    a = y.T @ y
+    w, v = ops.eigh(a.to(DEV), 64)
+    w, v = w.cpu(), v.cpu()
+    w_ref = torch.linalg.eigvalsh(a)
+    assert (w - w_ref).abs().max().item() <= 1e-10 * w_ref.max().item()
+    assert (a @ v - v * w[n - 64:]).abs().max().item() <= 1e-9 * w_ref.max().item()
