@@ -7,18 +7,28 @@ N = 1 workload (BASELINE.json configs[1], SURVEY.md 8d "C2"): dwain.decompose_in
 nn.Linear(4096, 4096, bias=False), f32 model, f64 decomposition, B=4 x S=1024 tokens per batch,
 D = 4 calibration steps, M = 2 metric steps, 7 candidate ranks (2048 .. 32), CE loss over the
 4096 outputs, identity finetune_fn.  One "step" = one full decompose_in_place call on a fresh
-copy of the layer, every input already resident in HBM.  N > 1: a chain of N such layers, one
-process per GPU (torchrun), calibration steps / eigendecompositions / candidate ranks dealt
-round-robin to the ranks, covariance sums all-reduced over RCCL (weak scaling: one layer per GPU).
+copy of the layer, every input already resident in HBM.
+
+N > 1 (weak scaling, one layer per GPU; BASELINE configs[3] in small): a stack of N such layers in
+bf16 (the throughput configuration of SURVEY 8d), dwain with precomputing_covariance_num_splits=1,
+D = max(4, N) calibration steps dealt to the ranks, the N covariance sums reduced to their owners
+(packed lower triangles over RCCL), the N eigendecompositions owned one per rank, eigenvectors
+broadcast, (candidate, metric batch) pairs dealt to the ranks.  With a bf16 stack the model
+forwards of the rank search (2 N GEMMs per pair: the method's own cost) stay small
+next to the sharded part (N x SYRK + N eigendecompositions), which is what the curve measures.
 
 Prints ONE JSON line (rank 0) with the driver's contract fields plus
-  roofline       the eigensolver (dominant cost) against the f64 MFMA peak, algorithmic flops
-                 4/3 n^3 + 2 n^2 k per matrix, HIP-event timed in this process
-  kernels        per-kernel device time / executed-flop rates (Jacobi gram / inner / update,
-                 covariance SYRK, layer-output GEMM, NSR) from HIP events
+  roofline       the dominant kernel of the eigensolver against its bound: frac on SURVEY 8d's
+                 algorithmic bytes, hw_frac on the bytes the counters saw, solver_frac for the
+                 whole ptd_eigh call against the reduction's bound
+  phases_ms      device-time split of one step: A accumulate, B eigh, C factors, D metrics, comm
+  kernels        per-kernel device time / rates from HIP events
   cpu_baseline   the CPU oracle (restatement of the reference, torch-CPU/MKL) on the same
-                 workload on this box's host cores, rank 0, N = 1 only
+                 workload on this box's physical host cores, rank 0, N = 1 only
   decomposed_fwd rank-r two-GEMM forward vs dense 4096x4096, bf16 (BASELINE configs[4])
+Counter-derived fields (traffic, MFMA utilisation) are quoted from committed rocprofv3 PMC
+summaries; each carries the hash of the kernel source it was measured on and is marked
+"stale": true when the source has changed since.
 """
 
 from __future__ import annotations
@@ -60,6 +70,23 @@ class LinearChain(torch.nn.Module):
 def ce_loss(batch, logits):
     return torch.nn.functional.cross_entropy(logits.reshape(-1, logits.shape[-1]), batch["targets"].reshape(-1),
                                              reduction="none")
+
+
+def pmc_file(pattern: str, sources: tuple):
+    """Latest committed counter summary matching `pattern`, with provenance: {"data", "source", "stale"}.
+    stale = the kernel sources it names have changed since the pass (or it predates the hash)."""
+    import glob
+
+    from ptdeco_amd import _hip
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+    if not files:
+        return None
+    d = json.load(open(files[-1]))
+    want = d.get("source_sha16")
+    have = _hip.source_sha16(*sources)
+    return {"data": d, "source": "profiles/" + os.path.basename(files[-1]), "stale": want != have,
+            "measured_on_source_sha16": want, "current_source_sha16": have}
 
 
 def make_workload(n_layers: int, device, n_data: int, n_metric: int):
@@ -140,17 +167,16 @@ def kernel_lines(device):
     by = 2 * y.numel() * 4
     lines["nsr_f32"] = {"ms": t * 1e3, "algorithmic_bytes": by, "gbps": by / t / 1e9, "frac_of_hbm_peak": by / t / PEAK_HBM}
     # MFMA utilisation from the committed rocprofv3 PMC pass over the same kernels (tools/pmc_driver mfma)
-    import glob
-    here = os.path.dirname(os.path.abspath(__file__))
-    pmc = sorted(glob.glob(os.path.join(here, "profiles", "pmc_mfma_r*.json")))
+    pmc = pmc_file("pmc_mfma_r*.json", ("gemm_f32.hip", "gemm_bf16.hip"))
     if pmc:
-        kern = json.load(open(pmc[-1]))["kernels"]
+        kern = pmc["data"]["kernels"]
         for line, key in (("syrk_f32_f64acc", "syrk_f32_mixed_kernel"), ("gemm_f32_nt", "gemm_f32_nt_8ph_kernel"),
-                          ("gemm_bf16_nt", "gemm_bf16_nt_8ph_kernel")):
+                          ("syrk_bf16_f64acc", "syrk_bf16"), ("gemm_bf16_nt", "gemm_bf16_nt_8ph_kernel")):
             for name, c in kern.items():
                 if name.startswith(key) and "MfmaUtil" in c and line in lines:
                     lines[line]["mfma_util_pmc_percent"] = c["MfmaUtil"]
-                    lines[line]["mfma_util_source"] = "profiles/" + os.path.basename(pmc[-1])
+                    lines[line]["mfma_util_source"] = pmc["source"]
+                    lines[line]["mfma_util_stale"] = pmc["stale"]
     return lines
 
 
@@ -181,14 +207,14 @@ def decomposed_forward_lines(device):
                         "speedup_vs_dense_torch_hipblaslt": lib_t / t, "torch_hipblaslt_pair_ms": lib_pair * 1e3,
                         "frac_of_bf16_mfma_peak": fl / t / PEAK_BF16_MFMA, "hbm_gbps_algorithmic": by / t / 1e9}
     # MFMA utilisation of the two rank-256 kernels from the committed counter pass (tools/pmc_driver mfma)
-    import glob
-    pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", "pmc_mfma_r*.json")))
+    pmc = pmc_file("pmc_mfma_r*.json", ("gemm_f32.hip", "gemm_bf16.hip"))
     if pmc:
-        kern = json.load(open(pmc[-1]))["kernels"]
+        kern = pmc["data"]["kernels"]
         for label, key in (("x_At", "gemm_bf16_nt_glds_kernel<0, 4>"), ("h_Bt", "gemm_bf16_shortk4_kernel<4>")):
             if key in kern and "MfmaUtil" in kern[key]:
                 out["r256"][f"mfma_util_pmc_percent_{label}"] = kern[key]["MfmaUtil"]
-        out["r256"]["mfma_util_source"] = "profiles/" + os.path.basename(pmc[-1])
+        out["r256"]["mfma_util_source"] = pmc["source"]
+        out["r256"]["mfma_util_stale"] = pmc["stale"]
     return out
 
 
@@ -197,14 +223,13 @@ def pmc_traffic(n):
     (profiles/pmc_symv_rNN.json, made by tools/pmc_summary.py from separate FETCH_SIZE / WRITE_SIZE
     runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  Counters cannot be read
     from inside this process, so the figure is the latest committed pass for the same matrix order."""
-    import glob
-    here = os.path.dirname(os.path.abspath(__file__))
-    for f in sorted(glob.glob(os.path.join(here, "profiles", "pmc_symv_r*.json")), reverse=True):
-        d = json.load(open(f))
-        if d.get("n") == n:
-            return {"traffic": d["traffic_bytes_per_launch"],
-                    "traffic_source": "profiles/" + os.path.basename(f) + ": (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per launch, "
-                                      "%.3f x the algorithmic bytes" % d["traffic_over_algorithmic"]}
+    pmc = pmc_file("pmc_symv_r*.json", ("eigh_tridiag.hip",))
+    if pmc and pmc["data"].get("n") == n:
+        d = pmc["data"]
+        return {"traffic": d["traffic_bytes_per_launch"],
+                "traffic_source": pmc["source"] + ": (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per launch, "
+                                  "%.3f x the algorithmic bytes" % d["traffic_over_algorithmic"],
+                "traffic_stale": pmc["stale"]}
     return {"traffic": None}
 
 
@@ -213,7 +238,15 @@ def cpu_baseline():
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import ptdeco_oracle as orc
 
-    cores = torch.get_num_threads()
+    # physical cores of this box: torch defaults to the logical count, which oversubscribes MKL
+    try:
+        import psutil
+        physical = psutil.cpu_count(logical=False) or os.cpu_count()
+    except Exception:
+        physical = os.cpu_count()
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
+    cores = max(1, min(physical, usable))
+    torch.set_num_threads(cores)
     model, data, metric = make_workload(1, "cpu", D_STEPS, 7 * M_STEPS)
     cpu = torch.device("cpu")
     data, metric = with_targets(model, data, cpu), with_targets(model, metric, cpu)
@@ -223,7 +256,9 @@ def cpu_baseline():
     dt = time.perf_counter() - t0
     prop = cfg["layers.0"]["__meta__"]["proportion"] if cfg else 1.0
     return {"value": 1.0 / dt, "unit": "layers/s", "cores": cores, "kind": "port",
-            "sample": f"1 layer = the full N=1 workload once ({dt:.1f} s); chosen proportion {prop}"}
+            "physical_cores": physical, "logical_cpus": os.cpu_count(), "usable_cpus": usable,
+            "sample": f"1 layer = the full N=1 workload once ({dt:.1f} s, torch threads = {cores}); "
+                      f"chosen proportion {prop}"}
 
 
 def main():
@@ -258,16 +293,25 @@ def main():
     from ptdeco_amd import ops
 
     n_layers = world
-    model0, data, metric = make_workload(n_layers, device, D_STEPS, 7 * M_STEPS)
+    d_steps = D_STEPS if world == 1 else max(D_STEPS, world)
+    model0, data, metric = make_workload(n_layers, device, d_steps, 7 * M_STEPS)
     model0.to(device)
     data, metric = with_targets(model0, data, device), with_targets(model0, metric, device)
+    model_dtype = torch.float32
+    if world > 1:   # the throughput configuration: bf16 stack (see the module docstring)
+        model_dtype = torch.bfloat16
+        model0.to(model_dtype)
+        data = [{"x": b["x"].to(model_dtype), "targets": b["targets"]} for b in data]
+        metric = [{"x": b["x"].to(model_dtype), "targets": b["targets"]} for b in metric]
+    kw = dict(DWAIN_KW, num_data_steps=d_steps)
+    loss = ce_loss if world == 1 else (lambda b, y: ce_loss(b, y.float()))
 
     def one_step():
         model = copy.deepcopy(model0)
         return ptdeco_amd.dwain.decompose_in_place(
-            module=model, device=device, data_iterator=itertools.cycle(data), loss_fn=ce_loss,
+            module=model, device=device, data_iterator=itertools.cycle(data), loss_fn=loss,
             metric_iterator=itertools.cycle(metric), finetune_fn=lambda m, d, names: m,
-            precomputing_covariance_num_splits=(1 if world > 1 else None), **DWAIN_KW)
+            precomputing_covariance_num_splits=(1 if world > 1 else None), **kw)
 
     def barrier():
         if world > 1:
@@ -300,16 +344,33 @@ def main():
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": "dwain decompose_in_place, chain of %d x nn.Linear(4096,4096) f32, T=4x1024 tokens/batch, "
-                               "D=4, M=2, 7 candidate ranks, f64 covariance+eigh" % n_layers,
+        "config": {"workload": ("dwain decompose_in_place of one nn.Linear(4096,4096) f32 (BASELINE configs[1]), T=4x1024 "
+                                "tokens/batch, D=4, M=2, 7 candidate ranks, f64 covariance+eigh" if world == 1 else
+                                "dwain decompose_in_place, stack of %d x nn.Linear(4096,4096) bf16 (one layer per GPU), "
+                                "precompute pass (1 split), T=4x1024 tokens/batch, D=%d, M=2, 7 candidate ranks, f64 "
+                                "covariance+eigh; packed-triangle reduce to the layer owners + eigenvector broadcast"
+                                % (n_layers, d_steps)),
+                   "model_dtype": str(model_dtype).replace("torch.", ""),
                    "layers_per_step": n_layers, "parallelism": f"dp{world}" if world > 1 else "single",
                    "ranks_kept": {k: v["__meta__"]["proportion"] for k, v in cfg.items()}},
     }
 
     prof = []
     if not args.no_extras:
-        # one extra, untimed, profiled step: per-phase HIP-event timings of the eigensolver.
-        # Every rank takes part (the step contains collectives); rank 0 keeps the profile.
+        # two extra, untimed steps.  (1) phase spans of the step on the device timeline (A accumulate, B
+        # eigh, C factors, D metrics, comm); (2) per-phase HIP-event timings inside the eigensolver.  Every rank takes
+        # part (the steps contain collectives); rank 0 keeps the numbers.
+        from ptdeco_amd import _engine as eng
+        eng.PHASES = eng.PhaseTimer()
+        barrier()
+        t0p = time.perf_counter()
+        one_step()
+        barrier()
+        wall_p = (time.perf_counter() - t0p) * 1e3
+        ph, eng.PHASES = eng.PHASES.totals_ms(), None
+        ph["other_host_and_gaps"] = max(0.0, wall_p - sum(ph.values()))
+        ph["step_wall_ms"] = wall_p
+        result["phases_ms"] = {k: round(v, 3) for k, v in ph.items()}
         ops.EIGH_PROFILE = []
         one_step()
         barrier()
@@ -326,9 +387,23 @@ def main():
                 # tridiagonal route: the dominant kernel is the per-column SYMV, bound by the stream
                 # of the trailing matrix (8/3 n^3 bytes per matrix for a one-stage reduction)
                 ms, cnt, byts = p["ms"][0], p["launches"][0], p["work"][0]
+                tr = pmc_traffic(n)
+                hw = {}
+                if tr.get("traffic"):
+                    # what the memory side actually moved per launch (the symmetric kernel reads one triangle) over the
+                    # same launch time: the hardware-side bandwidth fraction, below `frac` by construction
+                    hw = {"hw_achieved": tr["traffic"] * cnt / (ms * 1e-3) / 1e9,
+                          "hw_frac": tr["traffic"] * cnt / (ms * 1e-3) / PEAK_HBM}
+                # the whole reduction against the same bound: 8/3 n^3 bytes at the HBM peak vs the time from the first
+                # launch of the reduction to the tridiagonal matrix (SYMV + per-column kernels + rank-2k updates + gaps)
+                red_ms = p["ms"][0] + p["ms"][1]
                 result["roofline"] = {
                     "bound": "hbm", "achieved": byts / (ms * 1e-3) / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
-                    "frac": byts / (ms * 1e-3) / PEAK_HBM, **pmc_traffic(n),
+                    "frac": byts / (ms * 1e-3) / PEAK_HBM, **tr, **hw,
+                    "solver_frac": byts / (red_ms * 1e-3) / PEAK_HBM,
+                    "solver_note": "solver_frac = the same algorithmic bytes over the WHOLE reduction time (%.1f ms: SYMV "
+                                   "launches + per-column kernels + rank-2k updates + launch gaps); the full ptd_eigh call "
+                                   "takes %.1f ms" % (red_ms, p["total_ms"]),
                     "kernel": "sytrd_symv2_kernel / sytrd_symv_kernel (Householder tridiagonalisation, one SYMV launch "
                               "per column; symmetric lower-triangle tiles for trailing orders >= 1024)",
                     "n": n, "launches": cnt, "avg_launch_us": ms / max(cnt, 1) * 1e3,
@@ -341,7 +416,7 @@ def main():
                 kl["sytrd_other_per_column"] = {"total_ms": p["ms"][1],
                                                 "note": "alpha kernels + rank-2k updates + launch gaps"}
                 kl["eigvals_invit_backtransform"] = {"total_ms": p["ms"][3]}
-            else:
+            elif p["method"] == 0:
                 names = ("jac_gram_kernel", "jac_inner_kernel", "jac_update_kernel")
                 for i, nm in enumerate(names):
                     ms, cnt, fl = p["ms"][i], p["launches"][i], p["work"][i]
@@ -353,7 +428,17 @@ def main():
                                       "unit": "TFLOP/s", "frac": algo_flops / t / PEAK_F64_MFMA, "traffic": None,
                                       "kernel": "ptd_eigh (one-sided block Jacobi: jac_gram + jac_inner + jac_update)",
                                       "n": n, "sweeps": p["sweeps"], "algorithmic_flops": algo_flops}
-            result["eigh"] = {"method": "tridiagonal" if p["method"] == 1 else "jacobi", "n": n, "k": k,
+            if p["method"] == 2:
+                # two-stage route (opt-in): stage 1 is the f64-MFMA-bound kernel family
+                result["roofline"] = {"bound": "mfma", "achieved": p["work"][0] / (p["ms"][0] * 1e-3) / 1e12,
+                                      "peak": PEAK_F64_MFMA / 1e12, "unit": "TFLOP/s",
+                                      "frac": p["work"][0] / (p["ms"][0] * 1e-3) / PEAK_F64_MFMA, "traffic": None,
+                                      "kernel": "two-stage reduction, stage 1 (dense -> band 32): 4/3 n^3 flop on the f64 "
+                                                "matrix cores", "n": n}
+                kl = {"stage1_dense_to_band": {"total_ms": p["ms"][0]}, "stage2_bulge_chase": {"total_ms": p["ms"][1]},
+                      "tridiagonal_eigenpairs": {"total_ms": p["ms"][2]},
+                      "backtransform_q2_q1": {"total_ms": p["ms"][3], "q2_ms": p["launches"][3] / 1e3}}
+            result["eigh"] = {"method": {0: "jacobi", 1: "tridiagonal", 2: "two-stage tridiagonal"}[p["method"]], "n": n, "k": k,
                               "ms_per_matrix": p["total_ms"],
                               "algorithmic_tflops": algo_flops / t / 1e12,
                               "frac_of_f64_mfma_peak_on_algorithmic_flops": algo_flops / t / PEAK_F64_MFMA}

@@ -23,6 +23,45 @@ from .lowrank import fuse_pair, warn_once
 EIGEN_DAMPEN_FACTOR = 0.01  # reference dwain.py:14, falor.py:22
 
 
+class PhaseTimer:
+    """Device-time spans of the phases of a decomposition (A accumulate, B eigh, C factors, D metrics,
+    comm), measured with HIP events on the caller's stream; bench.py installs one as ``PHASES`` for an extra,
+    untimed step.  Spans include the launch gaps inside them, i.e. they add up to the step's device timeline."""
+
+    def __init__(self):
+        self.spans: list = []
+
+    def span(self, name: str):
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            try:
+                yield
+            finally:
+                e1.record()
+                self.spans.append((name, e0, e1))
+        return cm()
+
+    def totals_ms(self) -> dict:
+        torch.cuda.synchronize()
+        out: dict = {}
+        for name, e0, e1 in self.spans:
+            out[name] = out.get(name, 0.0) + e0.elapsed_time(e1)
+        return out
+
+
+PHASES: Optional[PhaseTimer] = None
+
+
+def phase(name: str):
+    import contextlib
+
+    return PHASES.span(name) if PHASES is not None else contextlib.nullcontext()
+
+
 def is_decomposeable_module(module: torch.nn.Module) -> bool:
     """nn.Linear, or nn.Conv2d with a 1x1 kernel and groups == 1 (dwain.py:540-546, falor.py:402-408)."""
     if isinstance(module, torch.nn.Linear):
@@ -208,16 +247,20 @@ class Covariance:
             return
         self.add_features(features if features is not None else ops.matmul(x_rows, weight2d.T))
 
-    def all_reduce(self, group=None) -> None:
-        """Sum the partial statistics of all ranks (the one collective of the path: RCCL over xGMI)."""
-        import torch.distributed as dist
-
-        dist.all_reduce(self.E, op=dist.ReduceOp.SUM, group=group)
+    def reduce_to_owner(self, shard, index: int) -> None:
+        """Sum the partial statistics of all ranks on the owner of `index` (the one bulk exchange of the path:
+        RCCL over xGMI; packed lower triangle, see sharding.py).  Only the owner may call eigenvectors()."""
+        with phase("comm"):
+            shard.reduce_lower_to_owner(self.E, index)
+        small = [torch.tensor([float(self.steps)], dtype=torch.float64, device=self.E.device)]
         if self.ey is not None:
-            dist.all_reduce(self.ey, op=dist.ReduceOp.SUM, group=group)
-        steps = torch.tensor([self.steps], dtype=torch.int64, device=self.E.device)
-        dist.all_reduce(steps, op=dist.ReduceOp.SUM, group=group)
-        self.steps = int(steps.item())
+            small.append(self.ey.double())
+        flat = torch.cat(small)
+        shard.reduce_small_to_owner(flat, index)
+        if shard.owns(index):
+            self.steps = int(round(flat[0].item()))
+            if self.ey is not None:
+                self.ey.copy_(flat[1:].to(self.ey.dtype))
 
     def eigenvectors(self, damp_factor: float, use_mean: bool = False, top_k: Optional[int] = None) -> torch.Tensor:
         """Finalise (divide by steps, optional mean removal, Tikhonov damping) and return the
@@ -266,12 +309,11 @@ class InputMoment:
         ops.syrk_accumulate(self.E, x_rows, 1.0 / x_rows.shape[0])
         self.steps += 1
 
-    def all_reduce(self, group=None) -> None:
-        import torch.distributed as dist
-
-        dist.all_reduce(self.E, op=dist.ReduceOp.SUM, group=group)
+    def all_reduce(self, shard) -> None:
+        """A shared moment feeds layers with different owners: its lower triangle is summed on every rank."""
+        shard.all_reduce_lower(self.E)
         steps = torch.tensor([self.steps], dtype=torch.int64, device=self.E.device)
-        dist.all_reduce(steps, op=dist.ReduceOp.SUM, group=group)
+        shard.all_reduce_small(steps)
         self.steps = int(steps.item())
 
     def finalize(self) -> None:
@@ -411,13 +453,14 @@ class SharedInputPool:
                 out.append(m.moment)
         return out
 
-    def all_reduce(self, group=None) -> None:
-        """Sum the partial statistics over the ranks: one collective per shared moment / unshared layer."""
+    def reduce(self, shard) -> None:
+        """Sum the partial statistics over the ranks: shared moments everywhere (their layers have different
+        owners), an unshared layer's statistics on its owner only (member i of the pass is owned by rank i % G)."""
         for mom in self.moments():
-            mom.all_reduce(group)
-        for m in self.members:
+            mom.all_reduce(shard)
+        for i, m in enumerate(self.members):
             if m.moment is None:
-                m.cov.all_reduce(group)
+                m.cov.reduce_to_owner(shard, i)
 
     def finalize(self) -> None:
         """Shared Ex matrices, formed once on the caller's stream before the (concurrent) eigendecompositions."""

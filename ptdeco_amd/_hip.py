@@ -65,6 +65,18 @@ class EighStats(ctypes.Structure):
                 ("work", c_double * 4), ("total_ms", ctypes.c_float)]
 
 
+def source_sha16(*names: str) -> str:
+    """sha256 (first 16 hex digits) of the named kernel sources under csrc/: ties a committed counter summary
+    (profiles/pmc_*.json) to the code that produced it, without needing a git checkout on the GPU box."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for name in names:
+        with open(os.path.join(_HERE, "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 class HipLibraryError(RuntimeError):
     pass
 

@@ -123,7 +123,7 @@ def _precompute_covariance_matrix_decompositions(*, module, submodule_names, num
             module, name, CovarianceComputingLinearModule(old.weight, old.bias, decompose_in_float64, top_k, pool, name))
     module.eval()
     stand_ins = [module.get_submodule(n) for n in submodule_names]
-    with torch.no_grad():
+    with torch.no_grad(), eng.phase("A_accumulate"):
         for step in range(num_data_steps):
             batch = next(data_iterator)  # every rank advances the stream identically
             mine = shard.mine(step)
@@ -139,21 +139,24 @@ def _precompute_covariance_matrix_decompositions(*, module, submodule_names, num
     logger.info("Computing eigenvectors ...")
     u_dict: dict[str, torch.Tensor] = {}
     if shard.active:
-        pool.all_reduce(shard.group)
+        with eng.phase("comm"):
+            pool.reduce(shard)
     pool.finalize()
     # eigendecompositions of a split are owned round-robin (non-owners receive u later); the ones
     # this rank owns are independent and run concurrently on separate streams
     owned = [i for i in range(len(stand_ins)) if shard.owns(i)]
-    got = eng.run_concurrently([stand_ins[i].get_eigenvectors for i in owned], device)
+    with eng.phase("B_eigh"):
+        got = eng.run_concurrently([stand_ins[i].get_eigenvectors for i in owned], device)
     for name in submodule_names:
         u_dict[name] = None
     for i, u in zip(owned, got):
         u_dict[submodule_names[i]] = u
     for i, name in enumerate(submodule_names):
         if shard.active:
-            u_dict[name] = shard.broadcast_from_owner(
-                u_dict[name], i, (stand_ins[i].out_features, min(stand_ins[i].top_k, stand_ins[i].out_features)),
-                stand_ins[i].weight.dtype, device)
+            with eng.phase("comm"):
+                u_dict[name] = shard.broadcast_from_owner(
+                    u_dict[name], i, (stand_ins[i].out_features, min(stand_ins[i].top_k, stand_ins[i].out_features)),
+                    stand_ins[i].weight.dtype, device)
         logger.info(f"Replacing {name} by original linear")
         utils.replace_submodule_in_place(module, name, originals[name])
     del stand_ins
@@ -183,22 +186,34 @@ def _precompute_covariance_matrix_decompositions_in_splits(*, module, modules_to
 
 def _compute_covariance_matrix_decomposition(*, root_module, tap: eng.LayerTap, data_iterator, weight, num_data_steps,
                                              device, decompose_in_float64, shard: Shard,
-                                             top_k: Optional[int] = None) -> torch.Tensor:
-    """:211-244 -- D model forwards, y = x W^T, Eyyt += y^T y / T, damped eigenvectors."""
+                                             top_k: Optional[int] = None, layer_index: int = 0) -> torch.Tensor:
+    """:211-244 -- D model forwards, y = x W^T, Eyyt += y^T y / T, damped eigenvectors.  With several GPUs
+    the partial sums are reduced to the layer's owner (rank layer_index % G), which runs the eigensolver and
+    sends the top-k eigenvectors back in the weight dtype (the dtype every candidate uses them in, :424-426)."""
     root_module.eval()
     logger.info("Using float64 for decomposition" if decompose_in_float64 else "Using float32 for decomposition")
     cov = eng.Covariance(weight.shape[0], device, decompose_in_float64, weight=weight, top_k=top_k)
     tap.use_dense(weight)
-    for step in range(num_data_steps):
-        batch = next(data_iterator)
-        if not shard.mine(step):
-            continue
-        root_module(utils.to_device(batch, device))
-        # (the layer's own forward may already have formed y = x W^T on the GPU: tap.last_features)
-        cov.add_inputs(tap.last_input_rows(), weight, features=tap.last_features)
-    if shard.active:
-        cov.all_reduce(shard.group)
-    return cov.eigenvectors(EIGEN_DAMPEN_FACTOR, top_k=top_k)
+    with eng.phase("A_accumulate"):
+        for step in range(num_data_steps):
+            batch = next(data_iterator)
+            if not shard.mine(step):
+                continue
+            root_module(utils.to_device(batch, device))
+            # (the layer's own forward may already have formed y = x W^T on the GPU: tap.last_features)
+            cov.add_inputs(tap.last_input_rows(), weight, features=tap.last_features)
+    if not shard.active:
+        with eng.phase("B_eigh"):
+            return cov.eigenvectors(EIGEN_DAMPEN_FACTOR, top_k=top_k)
+    cov.reduce_to_owner(shard, layer_index)
+    u = None
+    if shard.owns(layer_index):
+        with eng.phase("B_eigh"):
+            u = cov.eigenvectors(EIGEN_DAMPEN_FACTOR, top_k=top_k).to(weight.dtype)
+    n = weight.shape[0]
+    with eng.phase("comm"):
+        return shard.broadcast_from_owner(u, layer_index, (n, n if top_k is None else min(top_k, n)), weight.dtype,
+                                          device)
 
 
 def _compute_metrics(*, input_dict, root_module, tap: eng.LayerTap, orig_weight, candidate, loss_fn):
@@ -230,7 +245,7 @@ def _compute_metrics(*, input_dict, root_module, tap: eng.LayerTap, orig_weight,
 def _process_module(*, root_module, decomposed_submodule_name, data_iterator, loss_fn, nsr_final_threshold,
                     num_data_steps, num_metric_steps, device, metric_iterator, num_params, min_rank,
                     trade_off_factor, reduction_factor, max_accepted_ppl_diff, decompose_in_float64, u_matrix,
-                    shard: Shard, trace: Optional[list] = None) -> dict[str, Any]:
+                    shard: Shard, trace: Optional[list] = None, layer_index: int = 0) -> dict[str, Any]:
     """:333-537."""
     indent = "    "
     name = decomposed_submodule_name
@@ -253,7 +268,8 @@ def _process_module(*, root_module, decomposed_submodule_name, data_iterator, lo
             u_matrix = _compute_covariance_matrix_decomposition(
                 root_module=root_module, tap=tap, data_iterator=data_iterator, weight=orig_weight,
                 num_data_steps=num_data_steps, device=device, decompose_in_float64=decompose_in_float64,
-                shard=shard, top_k=_max_candidate_rank(dim_in, dim_out, min_rank, reduction_factor))
+                shard=shard, top_k=_max_candidate_rank(dim_in, dim_out, min_rank, reduction_factor),
+                layer_index=layer_index)
             logger.info(f"Computed u_matrix, {u_matrix.dtype=}")
         else:
             logger.info(f"Using pre-computed u_matrix, {u_matrix.dtype=}")
@@ -274,7 +290,8 @@ def _process_module(*, root_module, decomposed_submodule_name, data_iterator, lo
         # rank (c M + m) % G on exactly the batch the sequential order gives it
         sums = torch.zeros((max(len(candidates), 1), 3), dtype=torch.float64, device=device)
         # U = W^T uk once for the largest candidate; smaller ranks are column slices of it (:424-429)
-        bank = eng.FactorBank(orig_weight, u_matrix, candidates[0][0], orig_dtype) if candidates else None
+        with eng.phase("C_factors"):
+            bank = eng.FactorBank(orig_weight, u_matrix, candidates[0][0], orig_dtype) if candidates else None
         for c, (rank_new, _drop) in enumerate(candidates):
             batches = [next(metric_iterator) for _ in range(num_metric_steps)]
             candidate = None
@@ -284,12 +301,17 @@ def _process_module(*, root_module, decomposed_submodule_name, data_iterator, lo
                 if not shard.mine(c * num_metric_steps + m):
                     continue
                 if candidate is None:
-                    candidate = bank.get(rank_new, dense=not fast)
-                sums[c] += _compute_metrics(input_dict=utils.to_device(batch, device), root_module=root_module,
-                                            tap=tap, orig_weight=orig_weight, candidate=candidate, loss_fn=loss_fn)
+                    with eng.phase("C_factors"):
+                        candidate = bank.get(rank_new, dense=not fast)
+                with eng.phase("D_metrics"):
+                    sums[c] += _compute_metrics(input_dict=utils.to_device(batch, device), root_module=root_module,
+                                                tap=tap, orig_weight=orig_weight, candidate=candidate,
+                                                loss_fn=loss_fn)
         if shard.active:
-            shard.all_reduce_small(sums)
-        table = (sums / num_metric_steps).tolist()  # the one host sync of the rank search
+            with eng.phase("comm"):
+                shard.all_reduce_small(sums)
+        with eng.phase("D_metrics"):
+            table = (sums / num_metric_steps).tolist()  # the one host sync of the rank search
 
         rank_best, nsr_best, ppl_deco_best = full_rank, 0.0, 0.0
         for i, ((rank_new, drop), (nsr_new, ppl_deco_new, ppl_diff_new)) in enumerate(zip(candidates, table), 1):
@@ -320,8 +342,9 @@ def _process_module(*, root_module, decomposed_submodule_name, data_iterator, lo
             logger.info(f"{indent}i=FINAL rank={rank_best}/{full_rank} {proportion=:.4f} nsr={nsr_best:.6f} "
                         f"ppl={ppl_deco_best:.6f}")
         if decomposition_occurred and full_rank != rank_best and decide:
-            uk, big_u, _ = bank.get(rank_best)  # :507-511
-            new_module = eng.build_pair(layer, big_u, uk, orig_dtype).to(orig_device)
+            with eng.phase("C_factors"):
+                uk, big_u, _ = bank.get(rank_best)  # :507-511
+                new_module = eng.build_pair(layer, big_u, uk, orig_dtype).to(orig_device)
             drop_in_params = baseline_params - _get_params_for_proportion(proportion, dim_in, dim_out)
             return {"proportion": proportion, "nsr_final": nsr_best, "ppl_final": ppl_deco_best,
                     "drop_in_params": drop_in_params, "decomposed_module": new_module}
@@ -396,7 +419,7 @@ def decompose_in_place(
                 num_params=num_params, trade_off_factor=trade_off_factor, reduction_factor=reduction_factor,
                 max_accepted_ppl_diff=max_accepted_ppl_diff, min_rank=min_rank,
                 decompose_in_float64=decompose_in_float64,
-                u_matrix=u_dict.pop(name) if len(u_dict) > 0 else None, shard=shard, trace=trace)
+                u_matrix=u_dict.pop(name) if len(u_dict) > 0 else None, shard=shard, trace=trace, layer_index=i)
         current_params -= result.get("drop_in_params", 0)
         logger.info(f"CURRENT PARAMS IN M: {current_params / 1e6}")
         new_module = result["decomposed_module"]

@@ -6,6 +6,11 @@ covariance matrices -- plus a few scalars and the broadcast of finished factors.
 Work is dealt round-robin by a deterministic index (calibration step, candidate rank or
 layer number), every rank advances the data iterators identically, so the union of the
 ranks' work is exactly the sequential reference stream.
+
+Traffic: only the layer's owner runs the eigendecomposition, so the partial
+covariance sums are REDUCED to the owner (half the bytes a ring all-reduce moves per link) and
+only the live lower triangle travels (half again); the owner sends back the top-k eigenvectors in
+the weight dtype (n k elements instead of n^2 f64).
 """
 
 from __future__ import annotations
@@ -13,6 +18,26 @@ from __future__ import annotations
 from typing import Any, Optional
 
 import torch
+
+
+PACK_BLOCK = 512
+
+
+def pack_lower(E: torch.Tensor, block: int = PACK_BLOCK) -> torch.Tensor:
+    """The lower triangle of E (n x n, rows [i0, i1) contribute E[i0:i1, :i1]) as one flat buffer:
+    n^2 / 2 + n block / 2 elements, no index tensors."""
+    n = E.shape[0]
+    return torch.cat([E[i0:min(n, i0 + block), :min(n, i0 + block)].reshape(-1) for i0 in range(0, n, block)])
+
+
+def unpack_lower(packed: torch.Tensor, E: torch.Tensor, block: int = PACK_BLOCK) -> None:
+    """Inverse of pack_lower: writes the slabs back into E (entries above the slabs are untouched)."""
+    n, off = E.shape[0], 0
+    for i0 in range(0, n, block):
+        i1 = min(n, i0 + block)
+        cnt = (i1 - i0) * i1
+        E[i0:i1, :i1] = packed[off:off + cnt].view(i1 - i0, i1)
+        off += cnt
 
 
 class Shard:
@@ -55,6 +80,29 @@ class Shard:
         import torch.distributed as dist
 
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+
+    def reduce_lower_to_owner(self, E: torch.Tensor, index: int) -> None:
+        """Sum the lower triangles of every rank's E on the owner of `index` (in place there; the other
+        ranks' E is left as it was: they do not use it)."""
+        import torch.distributed as dist
+
+        packed = pack_lower(E)
+        dist.reduce(packed, dst=self._global_rank(self.owner(index)), op=dist.ReduceOp.SUM, group=self.group)
+        if self.owns(index):
+            unpack_lower(packed, E)
+
+    def all_reduce_lower(self, E: torch.Tensor) -> None:
+        """Sum of the lower triangles on every rank (a statistic several owners need)."""
+        import torch.distributed as dist
+
+        packed = pack_lower(E)
+        dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=self.group)
+        unpack_lower(packed, E)
+
+    def reduce_small_to_owner(self, t: torch.Tensor, index: int) -> None:
+        import torch.distributed as dist
+
+        dist.reduce(t, dst=self._global_rank(self.owner(index)), op=dist.ReduceOp.SUM, group=self.group)
 
     def broadcast_from_owner(self, t: Optional[torch.Tensor], index: int, shape, dtype, device) -> torch.Tensor:
         """The owner of `index` holds `t`; everyone returns a copy of it."""

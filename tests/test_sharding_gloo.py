@@ -65,10 +65,10 @@ def _worker(rank, world, port, name, outdir):
     dist.destroy_process_group()
 
 
-def _run(name):
+def _run(name, world=2):
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_worker, args=(2, _free_port(), name, d), nprocs=2, join=True)
-        return [torch.load(os.path.join(d, f"rank{r}.pt"), weights_only=False) for r in range(2)]
+        mp.spawn(_worker, args=(world, _free_port(), name, d), nprocs=world, join=True)
+        return [torch.load(os.path.join(d, f"rank{r}.pt"), weights_only=False) for r in range(world)]
 
 
 @pytest.mark.parametrize("name", ["dwain_mlp_nosplit", "dwain_mlp_split2", "dwain_conv"])
@@ -117,3 +117,51 @@ def test_falor_two_ranks_match_sequential_golden(name):
         assert torch.equal(r0["state"][k], r1["state"][k]), k
     ref = gio.t(gio.npz("e2e")[f"{name}.final_out"])
     assert (r1["out"] - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+
+
+def test_pack_lower_round_trip_and_traffic():
+    """The covariance exchange ships the lower triangle only: slabs E[i0:i1, :i1] (no index tensors)."""
+    from ptdeco_amd.sharding import pack_lower, unpack_lower
+
+    for n, block in [(5, 2), (64, 16), (100, 32), (1000, 512)]:
+        g = torch.Generator().manual_seed(n)
+        e = torch.randn(n, n, generator=g, dtype=torch.float64)
+        packed = pack_lower(e, block)
+        assert packed.numel() <= n * n // 2 + n * block
+        out = torch.full((n, n), 7.0, dtype=torch.float64)
+        unpack_lower(packed, out, block)
+        assert torch.equal(torch.tril(out), torch.tril(e))
+    assert pack_lower(torch.zeros(4096, 4096)).numel() / 4096**2 < 0.57
+
+
+@pytest.mark.parametrize("name", ["dwain_mlp_f32acc", "dwain_mlp_split2", "falor_mlp_mean32"])
+def test_three_ranks_with_a_layer_count_they_do_not_divide(name):
+    """World size 3: two decomposable layers (one rank owns none; 4 calibration steps dealt 2 / 1 / 1), and three
+    layers precomputed in three one-layer splits (rank 0 owns every eigendecomposition, ranks 1 and 2 only
+    contribute partial sums through the packed-triangle reduce and receive the eigenvectors).  Every rank must
+    reproduce the sequential golden run and end with identical weights."""
+    sys.path.insert(0, HERE)
+    import golden_io as gio
+
+    scn = gio.e2e_meta()[name]
+    runs = _run(name, world=3)
+    if name.startswith("dwain"):
+        want = [(s["layer"], s["rank"], s["accepted"]) for s in scn["steps"]]
+        for r in runs:
+            assert [(s["layer"], s["rank"], s["accepted"]) for s in r["trace"]] == want
+    else:
+        merged = [s for r in runs for s in r["trace"]]
+        order = list(dict.fromkeys(t["layer"] for t in scn["steps"]))
+        merged.sort(key=lambda s: (order.index(s["layer"]), s["i"]))
+        assert [(s["layer"], s["rank"]) for s in merged] == [(s["layer"], s["rank"]) for s in scn["steps"]]
+        assert sum(1 for r in runs if not r["trace"]) == 1   # two layers, three ranks
+    for r in runs:
+        assert list(r["cfg"].keys()) == list(scn["config"].keys())
+        for layer, c in scn["config"].items():
+            assert r["cfg"][layer]["modules"] == c["modules"]
+            for k, v in c["__meta__"].items():
+                assert r["cfg"][layer]["__meta__"][k] == pytest.approx(v, rel=1e-5, abs=1e-6)
+    for k in runs[0]["state"]:
+        assert torch.equal(runs[0]["state"][k], runs[1]["state"][k]) and torch.equal(runs[0]["state"][k], runs[2]["state"][k]), k
+    ref = gio.t(gio.npz("e2e")[f"{name}.final_out"])
+    assert (runs[2]["out"] - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
