@@ -37,7 +37,6 @@ namespace {
 
 constexpr int TB = TS_BAND;       // bandwidth, panel width, reflector length of stage 2
 constexpr int LDB = TS_LDBAND;    // band row [i][k], k = j - i + 2 TB (k = 2 TB is the diagonal)
-constexpr int CH = 128;           // columns of a wide panel per workgroup
 constexpr int SP = 33;            // LDS pitch of a 32 x 32 matrix
 
 __device__ __forceinline__ double wave_sum64(double v) {
@@ -46,44 +45,6 @@ __device__ __forceinline__ double wave_sum64(double v) {
 }
 
 // ------------------------------------------------------------------------------------------------ stage 1
-// G += X[:, c0 : c0 + cw] Y[:, ...]^T for 32-row wide panels staged in LDS as [32][CH + 1]
-__device__ __forceinline__ void gram_accumulate(const double* __restrict__ Xs, const double* __restrict__ Ys, int cw,
-                                                double* __restrict__ G, int tid) {
-  const int ti = tid >> 4, tj = tid & 15;  // 2 x 2 entries per thread: rows 2 ti.., columns 2 tj..
-  double a00 = 0.0, a01 = 0.0, a10 = 0.0, a11 = 0.0;
-  const double* x0 = Xs + (2 * ti) * (CH + 1);
-  const double* x1 = x0 + (CH + 1);
-  const double* y0 = Ys + (2 * tj) * (CH + 1);
-  const double* y1 = y0 + (CH + 1);
-#pragma unroll 4
-  for (int c = 0; c < cw; ++c) {
-    const double xa = x0[c], xb = x1[c], ya = y0[c], yb = y1[c];
-    a00 += xa * ya; a01 += xa * yb; a10 += xb * ya; a11 += xb * yb;
-  }
-  atomicAdd(&G[(2 * ti) * TB + 2 * tj], a00);
-  atomicAdd(&G[(2 * ti) * TB + 2 * tj + 1], a01);
-  atomicAdd(&G[(2 * ti + 1) * TB + 2 * tj], a10);
-  atomicAdd(&G[(2 * ti + 1) * TB + 2 * tj + 1], a11);
-}
-
-// G (32 x 32, zeroed by the caller) += X Y^T over the m columns of two wide panels (X == Y allowed)
-__global__ __launch_bounds__(256) void ts_gram_kernel(const double* __restrict__ X, const double* __restrict__ Y,
-                                                      int64_t ld, int m, double* __restrict__ G) {
-  extern __shared__ double sm[];
-  double* Xs = sm;
-  double* Ys = (X == Y) ? sm : sm + TB * (CH + 1);
-  const int tid = threadIdx.x;
-  const int c0 = blockIdx.x * CH, cw = min(CH, m - c0);
-  for (int e = tid; e < TB * CH; e += 256) {
-    const int r = e / CH, c = e % CH;
-    const bool ok = c < cw;
-    Xs[r * (CH + 1) + c] = ok ? X[(int64_t)r * ld + c0 + c] : 0.0;
-    if (X != Y) Ys[r * (CH + 1) + c] = ok ? Y[(int64_t)r * ld + c0 + c] : 0.0;
-  }
-  __syncthreads();
-  gram_accumulate(Xs, Ys, cw, G, tid);
-}
-
 // value of `v` in lane `src` (wave-uniform, here always a compile-time constant of an unrolled loop)
 __device__ __forceinline__ double readlane_d(double v, int src) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
@@ -125,20 +86,28 @@ __device__ bool chol32(double* S, int tid, int* flag_s) {
 
 // LU without pivoting of W - diag(D), D_kk = -sign of the pivot candidate (|pivot| >= 1: stable), in place:
 // strict lower = multipliers L (unit diagonal implied), upper = U.  Same one-wave register scheme.
-__device__ void lu_signed32(double* W, double* Dg, int tid) {
+// With R2t (the lower Cholesky factor L2 = R2^T of the second pass, may be null = identity) the matrix factored is
+// W - diag(D) R2: row k of D R2 is inserted when D_k becomes known (it has no entries left of the diagonal).  Its
+// factors are L and U R2 of the unscaled problem W R2^-1 - diag(D), with the same signs D.
+__device__ void lu_signed32(double* W, double* Dg, const double* R2t, int tid) {
   if (tid < 64) {
     const int i = tid & 31;
-    double w[TB];
+    double w[TB], r2[TB];
 #pragma unroll
-    for (int j = 0; j < TB; ++j) w[j] = W[i * SP + j];
+    for (int j = 0; j < TB; ++j) {
+      w[j] = W[i * SP + j];
+      r2[j] = R2t ? ((j >= i) ? R2t[j * SP + i] : 0.0) : ((i == j) ? 1.0 : 0.0);   // row i of R2 (upper)
+    }
 #pragma unroll
     for (int k = 0; k < TB; ++k) {
       const double cand = readlane_d(w[k], k);
       const double dg = cand >= 0.0 ? -1.0 : 1.0;
-      const double piv = cand - dg;
+      const double piv = cand - dg * readlane_d(r2[k], k);
       if (tid == 0) Dg[k] = dg;
-      if (i == k) w[k] = piv;
-      else if (i > k) w[k] = w[k] / piv;             // multiplier
+      if (i == k) {
+#pragma unroll
+        for (int j = k; j < TB; ++j) w[j] -= dg * r2[j];   // row k of -D R2
+      } else if (i > k) w[k] = w[k] / piv;             // multiplier
 #pragma unroll
       for (int j = k + 1; j < TB; ++j) {
         const double ukj = readlane_d(w[j], k);       // U[k][j]
@@ -157,8 +126,16 @@ __device__ void lu_signed32(double* W, double* Dg, int tid) {
 // One wave, lane i = row i of L and of X in registers: forward elimination of [L | I], row k of X is final at
 // step k and travels to the rows below by v_readlane (no LDS traffic, no barrier inside; ends with a workgroup
 // barrier).  (One thread per column reading L from LDS element by element: 40 us per call, latency bound.)
+__device__ void tri_lower_inverse32_wave(const double* L, double* X, bool unit_diag, int lane);
+
 __device__ void tri_lower_inverse32(const double* L, double* X, bool unit_diag, int tid) {
-  if (tid < 64) {
+  if (tid < 64) tri_lower_inverse32_wave(L, X, unit_diag, tid);
+  __syncthreads();
+}
+
+// (one wave; no barrier: the caller synchronises)
+__device__ void tri_lower_inverse32_wave(const double* L, double* X, bool unit_diag, int tid) {
+  {
     const int i = tid & 31;
     double l[TB], x[TB];
 #pragma unroll
@@ -181,7 +158,6 @@ __device__ void tri_lower_inverse32(const double* L, double* X, bool unit_diag, 
       for (int j = 0; j < TB; ++j) X[i * SP + j] = x[j];
     }
   }
-  __syncthreads();
 }
 
 // C = op(A) op(B) for 32 x 32 LDS matrices; element (i, k) of op(A) is A[i*sai + k*sak] etc.
@@ -214,125 +190,189 @@ __global__ __launch_bounds__(256) void ts_chol_kernel(const double* __restrict__
   }
 }
 
-// Left multiplication of the columns [c_lo, m) of a wide panel by a 32 x 32 matrix Lm (row-major, read from
-// memory into LDS):  X[:, c] <- Lm X[:, c].  One thread per column.  Optionally accumulates the Gram matrix of
-// the result into G and zeroes the same columns of a second wide panel.
-__global__ __launch_bounds__(256) void ts_lmul_kernel(const double* __restrict__ Lm, double* __restrict__ X,
-                                                      int64_t ld, int c_lo, int m, double* __restrict__ G,
-                                                      double* __restrict__ zero_out) {
-  extern __shared__ double sm[];
-  double* Ls = sm;                  // [32][32]
-  double* Os = sm + TB * TB;        // [32][CH + 1] when G
-  const int tid = threadIdx.x;
-  for (int e = tid; e < TB * TB; e += 256) Ls[e] = Lm[e];
-  __syncthreads();
-  const int c0 = blockIdx.x * CH;
-  const int c = c0 + tid;
-  const bool act = tid < CH && c >= c_lo && c < m;
-  double x[TB];
-  if (act) {
-#pragma unroll
-    for (int k = 0; k < TB; ++k) x[k] = X[(int64_t)k * ld + c];
-#pragma unroll 1
-    for (int i = 0; i < TB; ++i) {       // (rolled: the unrolled form is 18 KB of straight-line code run once)
-      double acc = 0.0;
-#pragma unroll
-      for (int k = 0; k < TB; ++k) acc += Ls[i * TB + k] * x[k];
-      X[(int64_t)i * ld + c] = acc;
-      if (G) Os[i * (CH + 1) + tid] = acc;
-    }
-  }
-  if (zero_out && tid < CH && c < m) {
-#pragma unroll
-    for (int i = 0; i < TB; ++i) zero_out[(int64_t)i * ld + c] = 0.0;
-  }
-  if (G) {
-    if (tid < CH && !act) {
-#pragma unroll 1
-      for (int i = 0; i < TB; ++i) Os[i * (CH + 1) + tid] = 0.0;
-    }
-    __syncthreads();
-    gram_accumulate(Os, Os, CH, G, tid);
-  }
-}
-
 // K4: second Cholesky pass + Householder reconstruction of the panel (single workgroup).
 //   in : G2 = Q1t Q1t^T, L1 (first pass), Q1t_top = At[0:32, 0:32] (At = the wide panel, leading dimension ld)
 //   out: Vt_top written over Q1t_top, MT (Vt_rest = MT Q1t_rest), T (32 x 32 upper, row-major), the band entries of
 //        R~ = D R2 R1 (the sub-diagonal block of the band), status on breakdown
+// With Q = Q1 R2^-1:  LU(Q_top - D) = L U  <=>  LU(Q1_top - D R2) = L (U R2), so ONE factorisation of the scaled
+// matrix gives L and U~ = U R2, and V_rest = Q_rest U^-1 = Q1_rest U~^-1: no R2^-1 on the way to V.  The three
+// triangular inverses that remain (U~^T for MT, L and L2 for T = -U~ R2^-1 D L^-T) are independent and run on
+// three waves at once.  Chain: Cholesky, LU, inverses, two 32^3 products.
 __global__ __launch_bounds__(256) void ts_hr_kernel(const double* __restrict__ G2, const double* __restrict__ L1,
                                                     double* __restrict__ At, int64_t ld, double* __restrict__ MT,
                                                     double* __restrict__ T, double* __restrict__ band_row0,
                                                     int* __restrict__ status) {
-  __shared__ double S[TB * SP], R2i[TB * SP], W[TB * SP], X[TB * SP], Y[TB * SP], L1s[TB * SP];
+  __shared__ double S[TB * SP], W[TB * SP], Ut[TB * SP], Lu[TB * SP], Xu[TB * SP], Xl[TB * SP], X2[TB * SP];
   __shared__ double Dg[TB];
   __shared__ int flag;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, wave = tid >> 6;
   for (int e = tid; e < TB * TB; e += 256) {
     S[(e >> 5) * SP + (e & 31)] = G2[e];
-    L1s[(e >> 5) * SP + (e & 31)] = L1[e];
+    W[(e & 31) * SP + (e >> 5)] = At[(int64_t)(e >> 5) * ld + (e & 31)];   // W[i][k] = Q1top[i][k] = Q1t[k][i]
   }
   __syncthreads();
   if (!chol32(S, tid, &flag) && tid == 0) atomicExch(status, 1);   // S lower = L2, R2 = L2^T
-  tri_lower_inverse32(S, R2i, false, tid);                          // R2i = L2^-1 ; R2^-1 = R2i^T
-  __syncthreads();
-  // Qtop[i][j] = sum_k Q1top[i][k] R2inv[k][j] = sum_k Q1t[k][i] L2inv[j][k]
-  for (int e = tid; e < TB * TB; e += 256) X[(e >> 5) * SP + (e & 31)] = At[(int64_t)(e >> 5) * ld + (e & 31)];  // X[k][i] = Q1t[k][i]
-  __syncthreads();
-  mm32(X, 1, SP, R2i, 1, SP, W, 1.0, tid);   // op(A)(i,k) = X[k][i]; op(B)(k,j) = R2i[j][k]
-  __syncthreads();
-  // LU without pivoting of Qtop - D, D_ii = -sign(pivot candidate): |pivot| >= 1
-  lu_signed32(W, Dg, tid);
-  // W = strict lower L (unit) + upper U.  Uinv^T: invert the lower triangular U^T
+  lu_signed32(W, Dg, S, tid);                                       // W = strict lower L (unit) + upper U~
   for (int e = tid; e < TB * TB; e += 256) {
     const int i = e >> 5, j = e & 31;
-    Y[i * SP + j] = (j <= i) ? W[j * SP + i] : 0.0;   // Y = U^T (lower)
+    Ut[i * SP + j] = (j <= i) ? W[j * SP + i] : 0.0;                // U~^T (lower)
+    Lu[i * SP + j] = (j < i) ? W[i * SP + j] : (i == j ? 1.0 : 0.0);
+    // Vt_top[c][i] = L[i][c]
+    At[(int64_t)i * ld + j] = (j > i) ? W[j * SP + i] : (i == j ? 1.0 : 0.0);
   }
   __syncthreads();
-  tri_lower_inverse32(Y, X, false, tid);               // X = (U^T)^-1 = (U^-1)^T
+  if (wave == 0) tri_lower_inverse32_wave(Ut, Xu, false, tid & 63);       // Xu = (U~^T)^-1 = (U~^-1)^T = MT
+  else if (wave == 1) tri_lower_inverse32_wave(Lu, Xl, true, tid & 63);   // Xl = L^-1
+  else if (wave == 2) tri_lower_inverse32_wave(S, X2, false, tid & 63);   // X2 = L2^-1 ; R2^-1 = X2^T
   __syncthreads();
-  // M = R2inv Uinv ;  MT[j][i] = M[i][j] = sum_k R2inv[i][k] Uinv[k][j] = sum_k R2i[k][i] X[j][k]
-  mm32(X, SP, 1, R2i, SP, 1, Y, 1.0, tid);             // Y[j][i] = sum_k X[j][k] R2i[k][i]  = MT
-  __syncthreads();
-  for (int e = tid; e < TB * TB; e += 256) MT[e] = Y[(e >> 5) * SP + (e & 31)];
-  // Vt_top[c][i] = L[i][c]
+  for (int e = tid; e < TB * TB; e += 256) MT[e] = Xu[(e >> 5) * SP + (e & 31)];
+  // Z[a][j] = sum_b R2inv[a][b] D_b Linv[j][b] = sum_b X2[b][a] D_b Xl[j][b]   (into Ut, dead by now)
   for (int e = tid; e < TB * TB; e += 256) {
-    const int c = e >> 5, i = e & 31;
-    At[(int64_t)c * ld + i] = (i > c) ? W[i * SP + c] : (i == c ? 1.0 : 0.0);
-  }
-  __syncthreads();
-  // Linv of the unit lower L
-  for (int e = tid; e < TB * TB; e += 256) {
-    const int i = e >> 5, j = e & 31;
-    Y[i * SP + j] = (j < i) ? W[i * SP + j] : (i == j ? 1.0 : 0.0);
-  }
-  __syncthreads();
-  tri_lower_inverse32(Y, X, true, tid);                // X = L^-1
-  __syncthreads();
-  // T[i][j] = - sum_k U[i][k] D[k] Linv[j][k]
-  for (int e = tid; e < TB * TB; e += 256) {
-    const int i = e >> 5, j = e & 31;
+    const int a = e >> 5, j = e & 31;
     double acc = 0.0;
-    for (int k = i; k <= j; ++k) acc += W[i * SP + k] * Dg[k] * X[j * SP + k];
+#pragma unroll 8
+    for (int b = 0; b < TB; ++b) acc += X2[b * SP + a] * Dg[b] * Xl[j * SP + b];
+    Ut[a * SP + j] = acc;
+  }
+  __syncthreads();
+  // T = -U~ Z (upper triangular);  R~[i][j] = D[i] sum_{k=i..j} L2[k][i] L1[j][k]  (j >= i): band entry
+  // (r0 + i, j0 + j) at k = j - i + TB of band row r0 + i
+  for (int e = tid; e < TB * TB; e += 256) {
+    const int i = e >> 5, j = e & 31;
+    double acc = 0.0, accr = 0.0;
+#pragma unroll 8
+    for (int k = 0; k < TB; ++k) {
+      acc += (k >= i ? W[i * SP + k] : 0.0) * Ut[k * SP + j];
+      accr += (k >= i && k <= j) ? S[k * SP + i] * L1[j * TB + k] : 0.0;
+    }
     T[e] = (j >= i) ? -acc : 0.0;
-  }
-  // R~[i][j] = D[i] sum_k R2[i][k] R1[k][j] = D[i] sum_{k=i..j} L2[k][i] L1[j][k]   (j >= i), band entry
-  // (r0 + i, j0 + j): k = j - i + TB of band row r0 + i
-  for (int e = tid; e < TB * TB; e += 256) {
-    const int i = e >> 5, j = e & 31;
-    if (j < i) continue;
-    double acc = 0.0;
-    for (int k = i; k <= j; ++k) acc += S[k * SP + i] * L1s[j * SP + k];
-    band_row0[(int64_t)i * LDB + (j - i + TB)] = Dg[i] * acc;
+    if (j >= i) band_row0[(int64_t)i * LDB + (j - i + TB)] = Dg[i] * accr;
   }
 }
 
-// K7b: Xt[:, c] = T^T W0t[:, c] - 1/2 C Vt[:, c],  C = T^T Z0 T  (symmetric); one thread per column
-__global__ __launch_bounds__(256) void ts_x_kernel(const double* __restrict__ T, const double* __restrict__ Z0,
-                                                   const double* __restrict__ Vt, const double* __restrict__ W0t,
-                                                   double* __restrict__ Xt, int64_t ld, int m) {
+// ---- panel operations on the f64 matrix cores (v_mfma_f64_16x16x4_f64: lane l holds A[m = l & 15][k = l >> 4],
+// B[k = l >> 4][n = l & 15], D[row = (l >> 4) + 4 reg][col = l & 15]).  The 32 x 32 operand sits in registers as MFMA
+// fragments, a wave owns a 16-column tile (left multiplication) or a 32-column slice (Gram product) and reads the
+// panel straight from memory.  (First version: VALU, one thread per column, the 32 x 32 operand broadcast from LDS
+// element by element -- two LDS reads per fma, 32 workgroups: 13 - 35 us per call at m <= 4096 against 5 - 8 us.)
+
+// G (32 x 32, zeroed by the caller) += X Y^T over the m columns (m % 32 == 0) of two wide panels; 4 waves x 32 columns
+__global__ __launch_bounds__(256) void ts_gram_mfma_kernel(const double* __restrict__ X, const double* __restrict__ Y,
+                                                           int64_t ld, int m, double* __restrict__ G) {
+  __shared__ double red[4][TB * TB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int c0 = (blockIdx.x * 4 + wave) * 32;
+  f64x4 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
+  if (c0 < m) {
+    double xa[2][8], ya[2][8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const int c = c0 + 4 * ks + l4;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        xa[t][ks] = X[(int64_t)(16 * t + l15) * ld + c];
+        ya[t][ks] = (X == Y) ? xa[t][ks] : Y[(int64_t)(16 * t + l15) * ld + c];
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[a][ks], ya[b][ks], acc[a][b], 0, 0, 0);
+  }
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[wave][(16 * a + l4 + 4 * r) * TB + 16 * b + l15] = acc[a][b][r];
+  __syncthreads();
+  for (int e = tid; e < TB * TB; e += 256) {
+    const double v = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+    atomicAdd(&G[e], v);
+  }
+}
+
+// X[:, c] <- Lm X[:, c] for the columns [c_lo, m) of a wide panel (c_lo, m multiples of 16); a wave owns 16 columns.
+// Optionally accumulates the Gram matrix of the result into G and zeroes the same columns of a second panel.
+__global__ __launch_bounds__(256) void ts_lmul_mfma_kernel(const double* __restrict__ Lm, double* __restrict__ X,
+                                                           int64_t ld, int c_lo, int m, double* __restrict__ G,
+                                                           double* __restrict__ zero_out) {
+  __shared__ double tile[4][TB * 17];
+  __shared__ double red[4][TB * TB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int c0 = (blockIdx.x * 4 + wave) * 16;
+  const bool act = c0 >= c_lo && c0 < m;
+  f64x4 acc[2] = {f64x4{0.0, 0.0, 0.0, 0.0}, f64x4{0.0, 0.0, 0.0, 0.0}};
+  if (act) {
+    double la[2][8], xb[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      la[0][ks] = Lm[l15 * TB + 4 * ks + l4];
+      la[1][ks] = Lm[(16 + l15) * TB + 4 * ks + l4];
+      xb[ks] = X[(int64_t)(4 * ks + l4) * ld + c0 + l15];
+    }
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(la[0][ks], xb[ks], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(la[1][ks], xb[ks], acc[1], 0, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) X[(int64_t)(16 * t + l4 + 4 * r) * ld + c0 + l15] = acc[t][r];
+  }
+  if (zero_out && c0 < m) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) zero_out[(int64_t)(l4 + 4 * r) * ld + c0 + l15] = 0.0;
+  }
+  if (G) {
+    // Gram matrix of the wave's 32 x 16 result tile: through LDS into the operand layout (k = column of the tile)
+    double* tl = tile[wave];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tl[(16 * t + l4 + 4 * r) * 17 + l15] = act ? acc[t][r] : 0.0;
+    __syncthreads();
+    f64x4 g[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) g[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const double f0 = tl[l15 * 17 + 4 * ks + l4], f1 = tl[(16 + l15) * 17 + 4 * ks + l4];
+      g[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(f0, f0, g[0][0], 0, 0, 0);
+      g[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(f0, f1, g[0][1], 0, 0, 0);
+      g[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(f1, f0, g[1][0], 0, 0, 0);
+      g[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(f1, f1, g[1][1], 0, 0, 0);
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][(16 * a + l4 + 4 * r) * TB + 16 * b + l15] = g[a][b][r];
+    __syncthreads();
+    for (int e = tid; e < TB * TB; e += 256) atomicAdd(&G[e], (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]));
+  }
+}
+
+// Xt[:, c] = T^T W0t[:, c] - 1/2 C Vt[:, c],  C = T^T Z0 T (symmetric); a wave owns 16 columns
+__global__ __launch_bounds__(256) void ts_x_mfma_kernel(const double* __restrict__ T, const double* __restrict__ Z0,
+                                                        const double* __restrict__ Vt, const double* __restrict__ W0t,
+                                                        double* __restrict__ Xt, int64_t ld, int m) {
   __shared__ double Ts[TB * SP], Zs[TB * SP], Es[TB * SP], Cs[TB * SP];
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4;
   for (int e = tid; e < TB * TB; e += 256) {
     Ts[(e >> 5) * SP + (e & 31)] = T[e];
     Zs[(e >> 5) * SP + (e & 31)] = Z0[e];
@@ -340,20 +380,34 @@ __global__ __launch_bounds__(256) void ts_x_kernel(const double* __restrict__ T,
   __syncthreads();
   mm32(Zs, SP, 1, Ts, SP, 1, Es, 1.0, tid);    // E = Z0 T
   __syncthreads();
-  mm32(Ts, 1, SP, Es, SP, 1, Cs, 1.0, tid);    // C = T^T E
+  mm32(Ts, 1, SP, Es, SP, 1, Cs, -0.5, tid);   // -1/2 C = -1/2 T^T E
   __syncthreads();
-  const int c = blockIdx.x * CH + tid;
-  if (tid >= CH || c >= m) return;
-  double w[TB], v[TB];
+  const int c0 = (blockIdx.x * 4 + wave) * 16;
+  if (c0 >= m) return;
+  f64x4 acc[2] = {f64x4{0.0, 0.0, 0.0, 0.0}, f64x4{0.0, 0.0, 0.0, 0.0}};
+  double ta[2][8], ca[2][8], wb[8], vb[8];
 #pragma unroll
-  for (int k = 0; k < TB; ++k) { w[k] = W0t[(int64_t)k * ld + c]; v[k] = Vt[(int64_t)k * ld + c]; }
-#pragma unroll 1
-  for (int i = 0; i < TB; ++i) {
-    double acc = 0.0;
+  for (int ks = 0; ks < 8; ++ks) {
+    const int k = 4 * ks + l4;
 #pragma unroll
-    for (int k = 0; k < TB; ++k) acc += Ts[k * SP + i] * w[k] - 0.5 * Cs[i * SP + k] * v[k];
-    Xt[(int64_t)i * ld + c] = acc;
+    for (int t = 0; t < 2; ++t) {
+      ta[t][ks] = Ts[k * SP + 16 * t + l15];       // (T^T)[i][k] = T[k][i]
+      ca[t][ks] = Cs[(16 * t + l15) * SP + k];
+    }
+    wb[ks] = W0t[(int64_t)k * ld + c0 + l15];
+    vb[ks] = Vt[(int64_t)k * ld + c0 + l15];
   }
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[t][ks], wb[ks], acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ca[t][ks], vb[ks], acc[t], 0, 0, 0);
+    }
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Xt[(int64_t)(16 * t + l4 + 4 * r) * ld + c0 + l15] = acc[t][r];
 }
 
 // band[i][k] for the entries of the diagonal blocks (lower triangles); the sub-diagonal blocks were written by
@@ -392,24 +446,6 @@ __device__ __forceinline__ void st_sc1(double* p, double v) {
 }
 
 constexpr int PROG_DONE = 1 << 30;
-
-// Householder vector of x (one entry per lane of the first half wave, zero beyond the length): returns v_i for the
-// lane's row, tau and beta (uniform).  LAPACK dlarfg convention, v_0 = 1.
-__device__ __forceinline__ void householder32(double x, int i, bool first_half, double& v, double& tau, double& beta) {
-  const double alpha = __shfl(x, 0);
-  const double sq = (first_half && i >= 1) ? x * x : 0.0;
-  const double sigma = wave_sum64(sq);
-  if (sigma == 0.0) {
-    tau = 0.0; beta = alpha; v = (i == 0) ? 1.0 : 0.0;
-  } else {
-    const double nrm = sqrt(alpha * alpha + sigma);
-    beta = alpha >= 0.0 ? -nrm : nrm;
-    tau = (beta - alpha) / beta;
-    const double sc = 1.0 / (alpha - beta);
-    v = (i == 0) ? 1.0 : x * sc;
-  }
-  v = __shfl(v, i);  // both half waves hold row i: the second half takes it from the first
-}
 
 // Bulge chasing (tools/twostage_proto.py: band_to_tridiag) as a systolic pipeline.
 //
@@ -733,64 +769,109 @@ __global__ void ts_extract_tridiag_kernel(const double* __restrict__ band, int n
 }
 
 // -------------------------------------------------------------------------------------- back-transformation
-// Y[:, c0 : c0 + CQ] <- Q2 Y (the reflectors of stage 2 in reverse order of their generation), the column chunk
-// resident in LDS as [CQ][n + 1].  Within a sweep the reflectors touch disjoint rows.  A 16-lane DPP row owns one
-// (reflector, column pair): lane i2 of the row holds rows 2 i2, 2 i2 + 1 of the reflector, so the two dot products
-// are reduced by four DPP adds.  A wave (four DPP rows) handles 4 / PAIRS reflectors per step, wave w of 16 the
-// positions (4 / PAIRS) (w + 16 q) + ..; the reflectors of the NEXT sweep are fetched while the current one is
-// applied.  (First version: one reflector per wave step, 32-lane reductions through ds_bpermute, a dependent global
-// load per reflector: 24 ms at n = 4096, k = 1024.)
-template <int CQ, int MAXQ>
+// Y[:, c0 : c0 + 4] <- Q2 Y (the reflectors of stage 2 in reverse order of their generation), the column chunk
+// resident in LDS as [4][n + 41].  Within a sweep the reflectors touch disjoint rows.  A quad of lanes owns one
+// (reflector, column): lane sub of the quad holds rows sub, sub + 4, .., sub + 28, so a dot product is eight fmas
+// and two quad_perm DPP adds; a wave (16 quads) handles 4 reflectors x 4 columns per step, wave w of 16 the positions
+// 4 (w + 16 q) + ...  The four lanes that need the same reflector entries (one per column) each load a quarter
+// of them and pass the rest around with row_ror DPP moves -- loaded four times over, the reflectors saturate the CU's
+// vector-memory path (147 KB per sweep: 2.3 us per sweep whatever else changed) -- and the entries of the next THREE
+// sweeps are in flight while one is applied (12 registers per sweep).
+// History at n = 4096, k = 1024: one reflector per wave step, 32-lane ds_bpermute reductions, dependent loads 24 ms;
+// DPP reductions + one-sweep prefetch 11.4 ms; 8 rows per lane 9.5 ms.
+template <int MAXQ>
 __global__ __launch_bounds__(1024) void ts_apply_q2_kernel(const double* __restrict__ V2, int64_t ldv2,
                                                            const double* __restrict__ tau2, int npos, int n,
                                                            double* __restrict__ Y, int64_t ldy, int nvec) {
-  extern __shared__ double Ys[];   // [CQ][n + 1]
-  constexpr int PAIRS = CQ / 2;    // column pairs
-  constexpr int PPI = 4 / PAIRS;   // reflectors per wave step
+  // rows n .. n + 39 are zero padding, the landing zone of reflector rows beyond the matrix (V2 is zero there too:
+  // twostage_reduce clears it), so the inner loops carry no per-element predicate
+  extern __shared__ double Ys[];
+  constexpr int CQ = 4, PPI = 4;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c0 = blockIdx.x * CQ;
-  const int pitch = n + 1;
-  for (int e = tid; e < n * CQ; e += 1024) {
+  const int pitch = n + 41;
+  for (int e = tid; e < pitch * CQ; e += 1024) {
     const int r = e / CQ, c = e % CQ;
-    Ys[c * pitch + r] = (c0 + c < nvec) ? Y[(int64_t)r * ldy + c0 + c] : 0.0;
+    Ys[c * pitch + r] = (r < n && c0 + c < nvec) ? Y[(int64_t)r * ldy + c0 + c] : 0.0;
   }
-  const int g = lane >> 4, i2 = lane & 15;
-  const int cp = g % PAIRS, ps = g / PAIRS;
-  double* ya = Ys + (2 * cp) * pitch;
-  double* yb = ya + pitch;
-  double va_c[MAXQ], vb_c[MAXQ], t_c[MAXQ], va_n[MAXQ], vb_n[MAXQ], t_n[MAXQ];
-  auto fetch = [&](int s, double (&va)[MAXQ], double (&vb)[MAXQ], double (&t)[MAXQ]) {
+  const int sub = lane & 3, col = (lane >> 2) & 3, ps = lane >> 4;
+  // logical element j = 2 k + e of this lane is reflector row sub + 4 ((2 (col - k) + e) & 7): k = 0 are the two
+  // entries the lane loads itself, k = 1, 2, 3 the own entries of the lane k columns down (row_ror k * 4 brings the
+  // value of lane l - 4 k of the 16-lane row)
+  int yoff[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) yoff[j] = col * pitch + sub + 4 * ((2 * (col - (j >> 1)) + (j & 1)) & 7);
+  const double* vbase = V2 + sub + 4 * (2 * col);
+  int poff[MAXQ];
+#pragma unroll
+  for (int q = 0; q < MAXQ; ++q) poff[q] = 1 + (PPI * (wave + 16 * q) + ps) * TB;
+  struct Set { double v0[MAXQ], v1[MAXQ], t[MAXQ]; int row[MAXQ]; };
+  auto fetch = [&](int s, Set& f) {
 #pragma unroll
     for (int q = 0; q < MAXQ; ++q) {
-      const int p = PPI * (wave + 16 * q) + ps;
-      const int r = s + 1 + p * TB + 2 * i2;
-      const bool on = s + 1 + p * TB < n;
-      t[q] = on ? tau2[(int64_t)s * npos + p] : 0.0;
-      va[q] = (on && r < n) ? V2[(int64_t)s * ldv2 + r] : 0.0;
-      vb[q] = (on && r + 1 < n) ? V2[(int64_t)s * ldv2 + r + 1] : 0.0;
+      const int r0 = s + poff[q];
+      const bool on = r0 < n;
+      f.row[q] = on ? r0 : n;                    // absent reflector: zero rows of V2 / Ys, tau = 0
+      f.t[q] = on ? tau2[(int64_t)s * npos + PPI * (wave + 16 * q) + ps] : 0.0;
+      const double* vp = vbase + (int64_t)s * ldv2 + f.row[q];
+      f.v0[q] = vp[0];
+      f.v1[q] = vp[4];
     }
   };
-  fetch(n - 3, va_c, vb_c, t_c);
-  __syncthreads();
-  for (int s = n - 3; s >= 0; --s) {
-    if (s > 0) fetch(s - 1, va_n, vb_n, t_n);
+  auto apply = [&](const Set& f) {
 #pragma unroll
     for (int q = 0; q < MAXQ; ++q) {
-      const int p = PPI * (wave + 16 * q) + ps;
-      const int r = s + 1 + p * TB + 2 * i2;
-      // (rows beyond n: v = 0 there and tau = 0 for absent reflectors, so clamped reads are harmless)
-      const int ra = min(r, n - 1), rb = min(r + 1, n - 1);
-      const double va = va_c[q], vb = vb_c[q], tau = t_c[q];
-      const double y0a = ya[ra], y0b = ya[rb], y1a = yb[ra], y1b = yb[rb];
-      const double d0 = tau * row16_sum(va * y0a + vb * y0b);
-      const double d1 = tau * row16_sum(va * y1a + vb * y1b);
-      if (r < n) { ya[r] = y0a - va * d0; yb[r] = y1a - va * d1; }
-      if (r + 1 < n) { ya[r + 1] = y0b - vb * d0; yb[r + 1] = y1b - vb * d1; }
-    }
-    __syncthreads();
+      double v[8];
+      v[0] = f.v0[q]; v[1] = f.v1[q];
+      v[2] = dpp_mov_d<0x124>(v[0]); v[3] = dpp_mov_d<0x124>(v[1]);   // row_ror 4: from the lane one column down
+      v[4] = dpp_mov_d<0x128>(v[0]); v[5] = dpp_mov_d<0x128>(v[1]);
+      v[6] = dpp_mov_d<0x12C>(v[0]); v[7] = dpp_mov_d<0x12C>(v[1]);
+      int yo[8];   // (indices into the shared array, one per element and opaque: single 8-byte DS accesses)
 #pragma unroll
-    for (int q = 0; q < MAXQ; ++q) { va_c[q] = va_n[q]; vb_c[q] = vb_n[q]; t_c[q] = t_n[q]; }
+      for (int j = 0; j < 8; ++j) {
+        yo[j] = yoff[j] + f.row[q];
+        asm volatile("" : "+v"(yo[j]));
+      }
+      double y[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) y[j] = Ys[yo[j]];
+      double d = 0.0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) d += v[j] * y[j];
+      d += dpp_mov_d<0xB1>(d);
+      d += dpp_mov_d<0x4E>(d);
+      d *= f.t[q];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) Ys[yo[j]] = y[j] - v[j] * d;
+    }
+  };
+  // (__syncthreads() waits for vmcnt(0) too, i.e. for the prefetched reflectors: every earlier version of this
+  // kernel paid a full global-load latency per sweep because of it, whatever else was changed)
+  auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+  Set f0, f1, f2, f3;
+  fetch(n - 3, f0);
+  if (n - 4 >= 0) fetch(n - 4, f1);
+  if (n - 5 >= 0) fetch(n - 5, f2);
+  __syncthreads();
+  // four sweeps per iteration: the set fetched three sweeps ago is used in place (no register copies)
+  for (int s = n - 3; s >= 0; s -= 4) {
+    if (s - 3 >= 0) fetch(s - 3, f3);
+    apply(f0);
+    lds_barrier();
+    if (s - 1 < 0) break;
+    if (s - 4 >= 0) fetch(s - 4, f0);
+    apply(f1);
+    lds_barrier();
+    if (s - 2 < 0) break;
+    if (s - 5 >= 0) fetch(s - 5, f1);
+    apply(f2);
+    lds_barrier();
+    if (s - 3 < 0) break;
+    if (s - 6 >= 0) fetch(s - 6, f2);
+    apply(f3);
+    lds_barrier();
   }
+  __syncthreads();
   for (int e = tid; e < n * CQ; e += 1024) {
     const int r = e / CQ, c = e % CQ;
     if (c0 + c < nvec) Y[(int64_t)r * ldy + c0 + c] = Ys[c * pitch + r];
@@ -859,7 +940,7 @@ TwoStagePlan twostage_plan(int64_t n, int64_t ld) {
 // the bulge chase is bound by the instruction issue rate of the single wave that executes a task).
 bool twostage_supported(int64_t n) {
   const char* e = getenv("PTD_EIGH_STAGES");
-  return e && atoi(e) == 2 && n % TB == 0 && n >= 4 * TB && n <= 8192;
+  return e && atoi(e) == 2 && n % TB == 0 && n >= 4 * TB && n <= 4096;   // (Q2 keeps 4 columns of Y in LDS)
 }
 
 // A (working copy, n x n, both triangles, leading dimension ld; destroyed: afterwards it holds the reflector
@@ -887,9 +968,8 @@ int twostage_reduce_stages(const TwoStagePlan& p, char* base, double* Aw, double
   double* Xt = reinterpret_cast<double*>(base + p.off_Xt);
   double* tau2 = reinterpret_cast<double*>(base + p.off_tau2);
   PTD_CHECK_HIP(hipMemsetAsync(base + p.off_zero, 0, p.zero_bytes, st));
-  PTD_CHECK_HIP(hipMemsetAsync(tau2, 0, (size_t)n * p.npos * 8, st));  // (every entry of V2 that is read is written)
-  const size_t lds_gram1 = (size_t)TB * (CH + 1) * 8, lds_gram2 = 2 * lds_gram1;
-  const size_t lds_lmul = (size_t)TB * TB * 8, lds_lmul_g = lds_lmul + lds_gram1;
+  PTD_CHECK_HIP(hipMemsetAsync(tau2, 0, (size_t)n * p.npos * 8, st));
+  PTD_CHECK_HIP(hipMemsetAsync(V2, 0, (size_t)n * ldv2 * 8, st));   // (the Q2 kernel reads rows past n as zeros)
   for (int pn = 0; pn < p.npanels; ++pn) {
     const int j0 = pn * TB, r0 = j0 + TB, m = n - r0;
     double* Pt = Aw + (int64_t)j0 * ld + r0;          // wide panel [32][m]
@@ -898,20 +978,20 @@ int twostage_reduce_stages(const TwoStagePlan& p, char* base, double* Aw, double
     double* g2 = G2 + (size_t)pn * TB * TB;
     double* z0 = Z0 + (size_t)pn * TB * TB;
     double* Tp = Tall + (size_t)pn * TB * TB;
-    const unsigned nch = (unsigned)ceil_div(m, CH);
-    hipLaunchKernelGGL(ts_gram_kernel, dim3(nch), dim3(256), lds_gram1, st, Pt, Pt, ld, m, g1);
+    const unsigned ng = (unsigned)ceil_div(m, 128), nl = (unsigned)ceil_div(m, 64);
+    hipLaunchKernelGGL(ts_gram_mfma_kernel, dim3(ng), dim3(256), 0, st, Pt, Pt, ld, m, g1);
     hipLaunchKernelGGL(ts_chol_kernel, dim3(1), dim3(256), 0, st, g1, L1, L1inv, status);
-    hipLaunchKernelGGL(ts_lmul_kernel, dim3(nch), dim3(256), lds_lmul_g, st, L1inv, Pt, ld, 0, m, g2, (double*)nullptr);
+    hipLaunchKernelGGL(ts_lmul_mfma_kernel, dim3(nl), dim3(256), 0, st, L1inv, Pt, ld, 0, m, g2, (double*)nullptr);
     hipLaunchKernelGGL(ts_hr_kernel, dim3(1), dim3(256), 0, st, g2, L1, Pt, ld, MT, Tp, band + (int64_t)r0 * LDB, status);
-    hipLaunchKernelGGL(ts_lmul_kernel, dim3(nch), dim3(256), lds_lmul, st, MT, Pt, ld, TB, m, (double*)nullptr, W0t);
+    hipLaunchKernelGGL(ts_lmul_mfma_kernel, dim3(nl), dim3(256), 0, st, MT, Pt, ld, TB, m, (double*)nullptr, W0t);
     // W0t (32 x m) = Vt A22  (split K, atomics into the zeroed W0t)
     const int tiles = (int)ceil_div(m, 64);
     int ks = (int)std::min<int64_t>(32, std::max<int64_t>(1, 768 / tiles));
     ks = (int)std::min<int64_t>(ks, std::max<int64_t>(1, m / 64));
     int rc = gemm_f64(Pt, ld, 1, A22, ld, 1, W0t, ld, TB, m, m, 1.0, true, ks, st);
     if (rc != PTD_OK) return rc;
-    hipLaunchKernelGGL(ts_gram_kernel, dim3(nch), dim3(256), lds_gram2, st, Pt, W0t, ld, m, z0);
-    hipLaunchKernelGGL(ts_x_kernel, dim3(nch), dim3(256), 0, st, Tp, z0, Pt, W0t, Xt, ld, m);
+    hipLaunchKernelGGL(ts_gram_mfma_kernel, dim3(ng), dim3(256), 0, st, Pt, W0t, ld, m, z0);
+    hipLaunchKernelGGL(ts_x_mfma_kernel, dim3(nl), dim3(256), 0, st, Tp, z0, Pt, W0t, Xt, ld, m);
     // A22 -= V X^T + X V^T
     rc = gemm_f64_pair(Pt, Xt, Xt, Pt, 1, ld, ld, 1, A22, ld, m, m, TB, -1.0, nullptr, st);
     if (rc != PTD_OK) return rc;
@@ -943,20 +1023,12 @@ int twostage_backtransform(const TwoStagePlan& p, char* base, const double* Aw, 
   const double* tau2 = reinterpret_cast<const double*>(base + p.off_tau2);
   const double* Tall = reinterpret_cast<const double*>(base + p.off_T);
   double* W2 = reinterpret_cast<double*>(base + p.off_W2);
-  if (n <= 4096) {
-    constexpr int CQ = 4;
-    const size_t lds = (size_t)CQ * (n + 1) * 8;
-    PTD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ts_apply_q2_kernel<CQ, 4>),
+  {
+    const size_t lds = (size_t)4 * (n + 41) * 8;
+    PTD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ts_apply_q2_kernel<2>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((ts_apply_q2_kernel<CQ, 4>), dim3((unsigned)ceil_div(nvec, CQ)), dim3(1024), lds, st, V2, ldv2,
-                       tau2, p.npos, n, Y, ldy, nvec);
-  } else {
-    constexpr int CQ = 2;
-    const size_t lds = (size_t)CQ * (n + 1) * 8;
-    PTD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ts_apply_q2_kernel<CQ, 4>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((ts_apply_q2_kernel<CQ, 4>), dim3((unsigned)ceil_div(nvec, CQ)), dim3(1024), lds, st, V2, ldv2,
-                       tau2, p.npos, n, Y, ldy, nvec);
+    hipLaunchKernelGGL((ts_apply_q2_kernel<2>), dim3((unsigned)ceil_div(nvec, 4)), dim3(1024), lds, st, V2, ldv2, tau2,
+                       p.npos, n, Y, ldy, nvec);
   }
   PTD_CHECK_LAUNCH("twostage Q2");
   if (mid) PTD_CHECK_HIP(hipEventRecord(mid, st));
