@@ -21,5 +21,9 @@ for d in ("pmc_mfma", "pmc_mfma2"):
 for nm, c in out["kernels"].items():
     if "SQ_VALU_MFMA_BUSY_CYCLES" in c and c.get("GRBM_GUI_ACTIVE"):
         c["busy_fraction"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] / 8.0 * 256 * 4)
+sys.path.insert(0, root)
+from ptdeco_amd import _hip  # noqa: E402  (provenance: bench.py marks the figures stale when the kernel sources change)
+out["source_sha16"] = _hip.source_sha16("gemm_f32.hip", "gemm_bf16.hip")
+out["source_files"] = ["ptdeco_amd/csrc/gemm_f32.hip", "ptdeco_amd/csrc/gemm_bf16.hip"]
 json.dump(out, open(os.path.join(root, "profiles", f"pmc_mfma_r{rnd}.json"), "w"), indent=1)
 print(json.dumps(out["kernels"], indent=1))

@@ -58,5 +58,9 @@ summary = {
     "first_launch": {"algorithmic": rows[0][2], "read": rows[0][3], "write": rows[0][4]},
     "l2_hit_rate": sum(r[5] for r in rows) / (sum(r[5] for r in rows) + sum(r[6] for r in rows)),
 }
+sys.path.insert(0, root)
+from ptdeco_amd import _hip  # noqa: E402  (provenance: bench.py marks the figures stale when the kernel source changes)
+summary["source_sha16"] = _hip.source_sha16("eigh_tridiag.hip")
+summary["source_files"] = ["ptdeco_amd/csrc/eigh_tridiag.hip"]
 json.dump(summary, open(os.path.join(root, "profiles", f"pmc_symv_r{rnd}.json"), "w"), indent=1)
 print(json.dumps(summary, indent=1))

@@ -1,9 +1,33 @@
+#!/bin/bash
+# Regenerates the measurements under profiles/ on a GPU box:  bash tools/refresh_profiles.sh <round, e.g. 02> [part]
+# part: all (default) | main (tests + bench + kernel stats) | c4 | pmc.  Outputs land in gpurun_out/ and are
+# condensed / copied into profiles/ afterwards in the build container (tools/pmc_summary.py, pmc_mfma_summary.py,
+# make_profiles_readme.py).
 set -o pipefail
+R=${1:-02}; PART=${2:-all}
 cd $GRAFT_REPO_ROOT
-timeout -k 10 900 python -m pytest tests -q -m gpu > gpurun_out/gpu_tests_r01.log 2>&1; echo "tests rc=$?"; tail -2 gpurun_out/gpu_tests_r01.log
-timeout -k 10 400 python bench.py --steps 5 --warmup 1 > gpurun_out/bench_r01.json 2> gpurun_out/bench_r01.err; echo "bench rc=$?"
-cut -c1-200 gpurun_out/bench_r01.json
-(cd /tmp && export TMPDIR=/tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_r01b -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-extras > $GRAFT_REPO_ROOT/gpurun_out/prof_r01b.log 2>&1); echo "rocprof rc=$?"
-timeout -k 10 300 python tools/c4_shapes.py > gpurun_out/c4_f32.json 2> gpurun_out/c4_f32.err; echo "c4 f32 rc=$?"
-timeout -k 10 300 python tools/c4_shapes.py bf16 > gpurun_out/c4_bf16.json 2> gpurun_out/c4_bf16.err; echo "c4 bf16 rc=$?"
-ls gpurun_out/prof_r01b/*/
+if [ "$PART" = all ] || [ "$PART" = main ]; then
+  timeout -k 10 900 python -m pytest tests -q -m gpu > gpurun_out/gpu_tests_r$R.log 2>&1; echo "tests rc=$?"; tail -2 gpurun_out/gpu_tests_r$R.log
+  timeout -k 10 500 python bench.py --steps 5 --warmup 1 > gpurun_out/bench_r$R.json 2> gpurun_out/bench_r$R.err; echo "bench rc=$?"
+  cut -c1-200 gpurun_out/bench_r$R.json
+  (cd /tmp && export TMPDIR=/tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_r$R -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-extras > $GRAFT_REPO_ROOT/gpurun_out/prof_r$R.log 2>&1); echo "rocprof rc=$?"
+fi
+if [ "$PART" = all ] || [ "$PART" = c4 ]; then
+  timeout -k 10 300 python tools/c4_shapes.py > gpurun_out/c4_f32_r$R.json 2> gpurun_out/c4_f32.err; echo "c4 f32 rc=$?"
+  timeout -k 10 300 python tools/c4_shapes.py bf16 > gpurun_out/c4_bf16_r$R.json 2> gpurun_out/c4_bf16.err; echo "c4 bf16 rc=$?"
+  timeout -k 10 300 python tools/c4_stack.py 2 > gpurun_out/c4_stack_f32_r$R.json 2> gpurun_out/c4_stack_f32.err; echo "c4 stack f32 rc=$?"
+  timeout -k 10 300 python tools/c4_stack.py 2 bf16 > gpurun_out/c4_stack_bf16_r$R.json 2> gpurun_out/c4_stack_bf16.err; echo "c4 stack bf16 rc=$?"
+  timeout -k 10 300 python tools/c3_vit.py > gpurun_out/c3_vit_r$R.json 2> gpurun_out/c3_vit.err; echo "c3 rc=$?"
+  timeout -k 10 900 python tools/c4_shapes_cpu.py > gpurun_out/c4_cpu_r$R.json 2> gpurun_out/c4_cpu.err; echo "c4 cpu rc=$?"; tail -5 gpurun_out/c4_cpu.err
+fi
+if [ "$PART" = all ] || [ "$PART" = pmc ]; then
+  hipcc -O2 -o tools/pmc_driver tools/pmc_driver.cpp -Iinclude -Lptdeco_amd -lptdeco_hip -Wl,-rpath,'$ORIGIN/../ptdeco_amd' || exit 1
+  cd /tmp && export TMPDIR=/tmp
+  G=$GRAFT_REPO_ROOT
+  for c in FETCH_SIZE:pmc_fetch WRITE_SIZE:pmc_write "TCC_HIT_sum TCC_MISS_sum":pmc_tcc; do
+    ctr=${c%%:*}; dir=${c##*:}
+    timeout -k 10 300 rocprofv3 --pmc $ctr --kernel-include-regex sytrd_symv --kernel-trace --output-format csv -d $G/gpurun_out/$dir -- $G/tools/pmc_driver 4096 > $G/gpurun_out/$dir.log 2>&1; echo "$dir rc=$?"
+  done
+  timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-include-regex "syrk|gemm" --kernel-trace --output-format csv -d $G/gpurun_out/pmc_mfma -- $G/tools/pmc_driver mfma > $G/gpurun_out/pmc_mfma.log 2>&1; echo "pmc_mfma rc=$?"
+  timeout -k 10 300 rocprofv3 --pmc MfmaUtil --kernel-include-regex "syrk|gemm" --kernel-trace --output-format csv -d $G/gpurun_out/pmc_mfma2 -- $G/tools/pmc_driver mfma > $G/gpurun_out/pmc_mfma2.log 2>&1; echo "pmc_mfma2 rc=$?"
+fi
