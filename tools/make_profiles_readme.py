@@ -34,6 +34,16 @@ r, e = b["roofline"], b.get("eigh", {})
 o.append(f"* dominant kernel `{r['kernel'].split(' ')[0]}`: bound {r['bound']}, {r['achieved']:.0f} {r['unit']} = "
          f"**{100 * r['frac']:.0f} %** of the {r['peak']:.0f} {r['unit']} peak over {r.get('launches', '?')} launches "
          f"(avg {r.get('avg_launch_us', 0):.1f} us, dispatch-attached HIP events; rocprofv3's average for the same kernel is in the table below).\n")
+if "hw_frac" in r:
+    o.append(f"* the same launches on the bytes the memory-side counters saw (`roofline.traffic`, {r['traffic'] / 1e6:.1f} MB per launch"
+             f"{', STALE: kernel source changed since the counter pass' if r.get('traffic_stale') else ''}): `hw_frac` = "
+             f"**{100 * r['hw_frac']:.0f} %** of peak -- the launches are latency-bound, not bandwidth-bound; `solver_frac` = "
+             f"**{100 * r['solver_frac']:.0f} %**: {r['solver_note'].split('= ', 1)[1]}.\n")
+ph = b.get("phases_ms")
+if ph:
+    o.append("* device-time split of one step (`phases_ms`, HIP-event spans incl. the launch gaps inside them): "
+             + ", ".join(f"{k.replace('_', ' ')} {v:.1f} ms" for k, v in ph.items() if k != "step_wall_ms")
+             + f" (step {ph.get('step_wall_ms', 0):.1f} ms).\n")
 sv = [x for x in rows if "sytrd_symv" in x["Name"]]
 if sv:
     calls = sum(int(x["Calls"]) for x in sv)
@@ -67,6 +77,18 @@ if os.path.exists(mf):
     o.append("* MFMA utilisation from the counters (`pmc_mfma_r%s.json`, `tools/pmc_driver mfma`): " % rnd
              + "; ".join(f"`{k}` MfmaUtil {v.get('MfmaUtil', float('nan')):.0f} % (busy cycles {100 * v.get('busy_fraction', float('nan')):.0f} %)" for k, v in mk.items())
              + " -- in line with the event-timed rates below.\n\n")
+ts = os.path.join(root, f"twostage_r{rnd}.json")
+if os.path.exists(ts):
+    t2 = json.load(open(ts))
+    o.append("## Two-stage tridiagonalisation (opt-in, `PTD_EIGH_STAGES=2`)\n\n"
+             f"`PTD_EIGH_STAGES=2 python tools/twostage_check.py 1024 4096` (HIP events inside `ptd_eigh_profiled`; `{os.path.basename(ts)}`):\n\n"
+             "| n, k | stage 1 dense -> band 32 | stage 2 bulge chase | eigenpairs of T | back-transformation (of which Q2) | total | residual / orthogonality |\n|---|---|---|---|---|---|---|\n")
+    for row in t2["runs"]:
+        o.append(f"| {row['n']}, {row['k']} | {row['ms'][0]:.1f} ms | {row['ms'][1]:.1f} ms | {row['ms'][2]:.1f} ms | {row['ms'][3]:.1f} ms ({row['q2_us'] / 1e3:.1f}) | "
+                 f"**{row['total_ms']:.1f} ms** | {row['residual']:.1e} / {row['orth']:.1e} |\n")
+    o.append(f"\nThe one-stage route takes {e['ms_per_matrix']:.0f} ms at n = 4096, k = 1024: the two-stage route is correct but does not win yet and stays "
+             "opt-in.  Timing experiments on the chase kernel (`PTD_CHASE_DBG`): " + t2.get("experiments", "") + "  DESIGN.md section 3 has the analysis "
+             "(the chase is bound by the instruction issue rate of the one wave that executes a task) and what was tried and rejected.\n\n")
 o.append("## Top kernels (rocprofv3 --stats)\n\n| kernel | calls | avg us | % of GPU time |\n|---|---|---|---|\n")
 for x in rows[:14]:
     o.append(f"| `{short(x['Name'])}` | {x['Calls']} | {float(x['AverageNs']) / 1e3:.1f} | {float(x['Percentage']):.2f} |\n")
@@ -105,6 +127,17 @@ if os.path.exists(c4p):
         o.append(f"| {k} | {v['n_in']} -> {v['n_out']} | {v['ms_per_layer']:.0f} | {desc} |\n")
     o.append(f"\nExtrapolated to the 224 layers of the 32-block stack: {c4['extrapolated_224_layers_s']:.0f} s on one GPU "
              f"({c4['extrapolated_layers_per_s_1gpu']:.1f} layers/s).\n")
+c4c = os.path.join(root, f"c4_shapes_cpu_r{rnd}.json")
+if os.path.exists(c4c) and os.path.exists(c4p):
+    cc = json.load(open(c4c))
+    o.append(f"\nCPU baseline per shape (`c4_shapes_cpu_r{rnd}.json`, `python tools/c4_shapes_cpu.py`: the CPU oracle on the same inputs, "
+             f"torch threads = {cc['cores']} = the physical cores of the box):\n\n| layer | CPU s per layer | GPU ms per layer |\n|---|---|---|\n")
+    for k in ("q_o", "k_v", "gate_up", "down"):
+        if k in cc:
+            o.append(f"| {k} | {cc[k]['s_per_layer']:.1f} | {c4[k]['ms_per_layer']:.0f} |\n")
+    if "extrapolated_224_layers_s" in cc:
+        o.append(f"\n224 layers extrapolated on the CPU: {cc['extrapolated_224_layers_s'] / 60:.0f} min ({cc['extrapolated_layers_per_s']:.3f} layers/s). "
+                 "(A reported baseline, not a target: the roofline fractions above say how good the kernels are.)\n")
 c4b = os.path.join(root, f"c4_shapes_bf16_r{rnd}.json")
 if os.path.exists(c4b):
     cb16 = json.load(open(c4b))
@@ -124,5 +157,23 @@ if os.path.exists(c3):
              f"**{v['seconds']:.1f} s = {v['layers_per_s']:.2f} layers/s** on one GPU ({v['decomposed']} layers replaced). The run is dominated by the "
              "user model's own forwards (two per bisection step and metric batch); the widening layers (qkv, fc1, head: rank-deficient feature "
              "covariance) only ask for the eigenvectors the bisection can use, which keeps them on the tridiagonal route (23.6 s before).\n")
+o.append("""
+## The abort under `rocprofv3 --pmc` recorded in round 1 (`gpurun_out/pmc1.log`)
+
+Evidence: the SIGSEGV is below a kernel launch in `ptd::sytrd_f64`, called from `ptd_eigh_topk` -- that entry passes no statistics
+object, so the faulting launch is a plain `hipLaunchKernelGGL`, NOT one of the `hipExtLaunchKernelGGL` calls that carry
+dispatch-attached start / stop events (those only exist under `ptd_eigh_profiled`, which the probe did not call); the fault
+address is page aligned and the frames above the launch are inside the HIP runtime / profiler interception; it happened in
+the THIRD heavy call of the process (after ~16,000 instrumented dispatches, 1.4 s per tridiagonalisation with every dispatch
+serialised for counter collection), the first two completed with correct results.  The same python process and command line
+with counter collection restricted to the kernels of interest (`--kernel-include-regex sytrd_symv`, one verification pass
+this round: `gpurun_out/pmc_verify.log`, rc 0, all three calls correct) completes.  Conclusion: a profiler-side failure
+under tens of thousands of instrumented dispatches in one process, not a fault of a kernel or of the event-carrying launches;
+the counter passes therefore (i) restrict collection with `--kernel-include-regex` and (ii) use the torch-free
+`tools/pmc_driver` (one matrix per process).  The six-rank rehearsal log of round 1 (`gpurun_out/rehearse6.log`) ends after
+rendezvous with no result line; its cause was not recorded then and cannot be reconstructed from the log.  This round's
+rehearsal (`PTD_BENCH_REHEARSE=1`, two ranks sharing the one GPU over gloo, `gpurun_out/bench_r02_n2.json`) completes: 156 ms
+per 2-layer step (a functional check of the N > 1 path, not a measurement).
+""")
 open(os.path.join(root, "README.md"), "w").write("".join(o))
 print("".join(o))

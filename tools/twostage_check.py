@@ -19,7 +19,10 @@ def spd(n, seed):
 
 
 def main():
-    sizes = [int(x) for x in sys.argv[1:]] or [128, 256, 1024]
+    args = [a for a in sys.argv[1:] if not a.startswith("--json")]
+    out_json = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--json=")]
+    runs = []
+    sizes = [int(x) for x in args] or [128, 256, 1024]
     for n in sizes:
         a = spd(n, n)
         w_ref = torch.linalg.eigvalsh(a)
@@ -39,12 +42,22 @@ def main():
         orth = (vc.T @ vc - torch.eye(k, dtype=torch.float64)).abs().max().item()
         print(f"n={n} eigh top-{k}: method {prof['method']} residual {res:.2e} orth {orth:.2e} ms {prof['ms']} "
               f"total {prof['total_ms']:.2f} q2_us {prof['launches'][3]}", flush=True)
+        runs.append({"n": n, "k": k, "method": prof["method"], "ms": prof["ms"], "total_ms": prof["total_ms"],
+                     "q2_us": prof["launches"][3], "residual": res, "orth": orth})
         if n >= 2048:
             for _ in range(2):
                 t0 = time.perf_counter()
                 ops.eigh(ad, k, all_values=False)
                 torch.cuda.synchronize()
                 print(f"   wall {1e3 * (time.perf_counter() - t0):.2f} ms", flush=True)
+
+
+    if out_json:
+        import json
+        json.dump({"command": "PTD_EIGH_STAGES=2 python tools/twostage_check.py " + " ".join(map(str, sizes)),
+                   "note": "ms = [stage 1 dense -> band 32, stage 2 bulge chase, eigenpairs of T, back-transformation Q1 Q2 Y]; "
+                           "q2_us = the Q2 part of the back-transformation; residual = max |A z - lambda z| / |A|, "
+                           "orth = max |Z^T Z - I|", "runs": runs}, open(out_json[0], "w"), indent=1)
 
 
 if __name__ == "__main__":
