@@ -51,4 +51,32 @@ __device__ __forceinline__ float bf16_to_f32(unsigned short v) {
   return __uint_as_float(static_cast<unsigned int>(v) << 16);
 }
 
+// E[row][col] += scale * acc for one 32 x 32 MFMA block (lane l: column col, rows row0 + (r & 3) + 8 (r >> 2) of
+// register r), lower triangle only when `tri`.  The 16 old values of a lane are requested together: written as
+// `*e += d` per register they are 16 dependent round trips (the compiler may not move a load above the store before
+// it), which made the epilogue of a covariance tile as long as its K loop.
+template <typename ET>
+__device__ __forceinline__ void accumulate_block(ET* __restrict__ E, const int64_t ld, const int row0, const int col,
+                                                 const int M, const int N, const bool tri, const bool atomic,
+                                                 const double scale, const f32x16& acc) {
+  ET old[16];
+  if (!atomic) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = row0 + (r & 3) + 8 * (r >> 2);
+      const bool ok = row < M && col < N && !(tri && col > row);
+      old[r] = ok ? E[(int64_t)row * ld + col] : (ET)0;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = row0 + (r & 3) + 8 * (r >> 2);
+    const bool ok = row < M && col < N && !(tri && col > row);
+    if (!ok) continue;
+    const ET d = (ET)(scale * (double)acc[r]);
+    ET* e = E + (int64_t)row * ld + col;
+    if (atomic) atomicAdd(e, d); else *e = old[r] + d;
+  }
+}
+
 }  // namespace ptd

@@ -203,6 +203,14 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmBf16Args a)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+      if (EPI == EPI_ACC_F64 || EPI == EPI_ACC_F32) {
+        const int row0 = m0 + wm * 64 + i * 32 + 4 * (lane >> 5);
+        if (EPI == EPI_ACC_F64)
+          accumulate_block(reinterpret_cast<double*>(a.C), a.ldc, row0, col, a.M, a.N, a.tri != 0, a.atomic != 0, a.scale, acc[i][j]);
+        else
+          accumulate_block(reinterpret_cast<float*>(a.C), a.ldc, row0, col, a.M, a.N, a.tri != 0, a.atomic != 0, a.scale, acc[i][j]);
+        continue;
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -378,6 +386,160 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 1) void gemm_bf16_nt_glds_kern
     const f32x4 v = *reinterpret_cast<const f32x4*>(lds + lr * CP + ch * 16);
     char* dst = reinterpret_cast<char*>(a.C) + ((int64_t)blockIdx.y * a.cslab + (int64_t)(m0 + lr) * a.ldc + n0) * ES + ch * 16;
     *reinterpret_cast<f32x4*>(dst) = v;
+  }
+}
+
+// ---- covariance product E += scale * Y^T Y on the LDS-DMA schedule ----
+// Both operands are r-contiguous (a tile's 64 k-rows are 64 rows of Y): the image is [64 k][TS r], unpadded
+// because the DMA writes lane-linearly (one wave instruction = 1 KiB = 4 k-rows of a 128-wide tile, 8 of a 64-wide
+// one), and the MFMA fragment (8 consecutive k of one r) comes out of two ds_read_b64_tr_b16 as in frag<false>.
+// A half wave of such a read touches 4 k-rows x 64 B; with a 256-B (128-B) pitch those would share a bank quarter,
+// so the 64-B granule g of row k lives at g ^ (k & 3) (TS = 128) or g ^ ((k >> 1) & 1) (TS = 64) -- applied on the
+// per-lane SOURCE address of the DMA and again on the read.
+// Schedule: double buffered, one barrier per K step, two workgroups per CU covering each other's barrier
+// (gemm_bf16_nt_glds_kernel<EPI, 2>).  A diagonal tile stages its operand once and skips the MFMAs of the wave whose
+// quadrant lies above the diagonal.
+template <int EPI, int TS>
+__device__ __forceinline__ void syrk_bf16_glds_tile(const GemmBf16Args& a, const int ti, const int tj, char* lds,
+                                                    const int kbeg, const int kchunk, const bool atomic) {
+  constexpr int ROWB = TS * 2;             // bytes per k-row of an operand image
+  constexpr int OPB = BK * ROWB;           // one operand, one K step
+  constexpr int KPI = 1024 / ROWB;         // k-rows per DMA wave instruction
+  constexpr int NI = BK / (4 * KPI);       // DMA instructions per wave, operand and K step
+  constexpr int CPR = ROWB / 16;           // 16-byte chunks per k-row
+  constexpr int F = TS / 64;               // 32-wide fragments per wave and operand
+  constexpr int WS = TS / 2;               // a wave's square of the tile
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 1, wn = wid & 1;
+  const int m0 = ti * TS, n0 = tj * TS;
+  const bool same = ti == tj;
+  const bool dead = same && wm == 0 && wn == 1;
+  const int nk = max(0, min(a.K, kbeg + kchunk) - kbeg) / BK;
+  const int64_t ld = a.sak;
+  const unsigned short* Ag = a.A + (int64_t)kbeg * ld + m0;
+  const unsigned short* Bg = a.B + (int64_t)kbeg * ld + n0;
+
+  const int skr = lane / CPR, sc = lane % CPR;
+  auto stage = [&](int buf, int kt) {
+    char* As = lds + buf * 2 * OPB;
+    char* Bs = As + OPB;
+#pragma unroll
+    for (int q = 0; q < NI; ++q) {
+      const int kb = (wid * NI + q) * KPI;           // wave-uniform first k-row of this 1-KiB piece
+      const int k = kb + skr;
+      const int cs = sc ^ ((TS == 128 ? (k & 3) : ((k >> 1) & 1)) << 2);   // source chunk that belongs at position sc
+      const int64_t off = (int64_t)(kt * BK + k) * ld + cs * 8;
+      __builtin_amdgcn_global_load_lds((glb_void*)(Ag + off), (lds_void*)(As + kb * ROWB), 16, 0, 0);
+      if (!same) __builtin_amdgcn_global_load_lds((glb_void*)(Bg + off), (lds_void*)(Bs + kb * ROWB), 16, 0, 0);
+    }
+  };
+  // fragment read: lane 4q+p of a 16-lane group supplies the address of k-row q, columns 4p..4p+3 (frag<false>)
+  const int fg = lane >> 4, fq = (lane >> 2) & 3, fp = lane & 3;
+  const int fk = 8 * (fg >> 1) + fq;                      // k within a 16-slice (the second read: + 4)
+  const int fsw = TS == 128 ? fq : (fq >> 1);             // granule swizzle of that k-row (same for k + 4)
+  const int fro = (16 * (fg & 1) + 4 * fp) * 2;           // byte offset within the 64-B granule
+  auto fragment = [&](const char* L, int r0, int kk) -> s16x8 {
+    const char* p = L + (kk + fk) * ROWB + (((r0 >> 5) ^ fsw) << 6) + fro;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * ROWB));
+    return s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  };
+
+  f32x16 acc[F][F];
+#pragma unroll
+  for (int i = 0; i < F; ++i)
+#pragma unroll
+    for (int j = 0; j < F; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (nk > 0) stage(0, 0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+    const char* As = lds + cur * 2 * OPB;
+    const char* Bs = same ? As : As + OPB;
+    if (!dead) {
+#pragma unroll
+      for (int kk = 0; kk < BK; kk += 16) {
+        s16x8 af[F], bf[F];
+#pragma unroll
+        for (int i = 0; i < F; ++i) {
+          af[i] = fragment(As, wm * WS + i * 32, kk);
+          bf[i] = fragment(Bs, wn * WS + i * 32, kk);
+        }
+#pragma unroll
+        for (int i = 0; i < F; ++i)
+#pragma unroll
+          for (int j = 0; j < F; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    __syncthreads();   // retires this step's LDS-DMA (vmcnt(0)) and the reads of buffer `cur`
+  }
+  if (dead || nk == 0) return;
+
+  // lane l holds column (l & 31) and rows (r & 3) + 8 (r >> 2) + 4 (l >> 5) of each 32 x 32 block: a register is
+  // two 256-byte row segments of E
+#pragma unroll
+  for (int i = 0; i < F; ++i)
+#pragma unroll
+    for (int j = 0; j < F; ++j) {
+      const int col = n0 + wn * WS + j * 32 + (lane & 31);
+      const int row0 = m0 + wm * WS + i * 32 + 4 * (lane >> 5);
+      if (EPI == EPI_ACC_F64)
+        accumulate_block(reinterpret_cast<double*>(a.C), a.ldc, row0, col, a.M, a.N, true, atomic, a.scale, acc[i][j]);
+      else
+        accumulate_block(reinterpret_cast<float*>(a.C), a.ldc, row0, col, a.M, a.N, true, atomic, a.scale, acc[i][j]);
+    }
+}
+
+// Block order (one launch): the nbig strictly-lower tiles, then ndiag whole diagonal tiles, then the remaining
+// diagonal tiles cut into PEEL_K ranges of K each, added with atomics.  n = 4096 is 528 tiles for 512 resident
+// workgroups (256 CUs x 2): with equal tiles the last 16 run alone after everyone else.  The f32 kernel quarters the
+// AREA of those tiles (syrk_f32_mixed_kernel); here a K step is bound by the latency of its DMA, not by its MFMAs
+// (a 64 x 64 piece took as long as a whole tile), so the K RANGE is what has to shrink.  (Only these diagonal tiles
+// see atomics: their last bits depend on the order in which the ranges arrive.)
+// The strictly-lower tiles are walked in groups of 8 tile rows, column by column, and every XCD (blocks b, b + 8, ..
+// share one and its L2) gets a contiguous run of that walk, so the ~64 tiles an XCD runs at a time form an 8 x 8
+// patch that needs 16 panels of Y instead of 65.
+constexpr int PEEL_K = 4;
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void syrk_bf16_glds_kernel(const GemmBf16Args a, const int nbig, const int ndiag) {
+  __shared__ __attribute__((aligned(16))) char lds[4 * 16384];
+  const int b = blockIdx.x;
+  const int kbeg = blockIdx.y * a.kchunk;
+  if (b < nbig) {
+    const int q8 = nbig >> 3, r8 = nbig & 7, xcd = b & 7;
+    int rem = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (b >> 3);
+    const int nt = a.tiles_m;
+    int G = 0, gr = min(8, nt);
+    for (;;) {
+      const int cnt = gr * 8 * G + gr * (gr - 1) / 2;
+      if (rem < cnt) break;
+      rem -= cnt;
+      ++G;
+      gr = min(8, nt - 8 * G);
+    }
+    int ti, tj;
+    if (rem < gr * 8 * G) {
+      tj = rem / gr;
+      ti = 8 * G + rem % gr;
+    } else {
+      rem -= gr * 8 * G;
+      int c = 0;
+      while (rem >= gr - 1 - c) { rem -= gr - 1 - c; ++c; }
+      tj = 8 * G + c;
+      ti = 8 * G + c + 1 + rem;
+    }
+    syrk_bf16_glds_tile<EPI, 128>(a, ti, tj, lds, kbeg, a.kchunk, a.atomic != 0);
+  } else if (b < nbig + ndiag) {
+    syrk_bf16_glds_tile<EPI, 128>(a, b - nbig, b - nbig, lds, kbeg, a.kchunk, a.atomic != 0);
+  } else {
+    const int s = b - nbig - ndiag, d = ndiag + s / PEEL_K, q = s % PEEL_K;
+    const int kc = (a.K / BK + PEEL_K - 1) / PEEL_K * BK;
+    syrk_bf16_glds_tile<EPI, 128>(a, d, d, lds, q * kc, kc, true);
   }
 }
 
@@ -1549,15 +1711,38 @@ int syrk_bf16(const unsigned short* Y, int64_t T, int64_t n, int64_t ldy, void* 
   a.tiles_m = nt;
   a.tri = 1;
   const int tiles = nt * (nt + 1) / 2;
+  static const bool no_glds = getenv("PTD_GEMM_NO_GLDS") != nullptr;
+  // The LDS-DMA kernel where it was measured faster than the register-staged one (T = 4096: n = 4096 0.121 vs 0.144 ms,
+  // T = 16384 0.387 vs 0.469 ms); with few tiles (split K, n = 2048: 0.080 vs 0.074 ms) or many rounds (n = 14336:
+  // 1.32 vs 1.28 ms) the generic kernel is as fast or faster.
+  const bool glds = !no_glds && n % BM == 0 && T >= BK && aligned16(Y) && ldy % 8 == 0 && tiles >= 192 && tiles <= 2080;
+  // rows of Y handled by this launch: the LDS-DMA kernel takes whole K steps, the generic kernel the rest
+  const int64_t T_main = glds ? T - T % BK : T;
   int ksplit = 1;
   if (tiles < 192) {
-    ksplit = (int)std::min<int64_t>(ceil_div(512, tiles), ceil_div(T, 4 * BK));
+    ksplit = (int)std::min<int64_t>(ceil_div(512, tiles), ceil_div(T_main, 4 * BK));
     if (ksplit < 1) ksplit = 1;
   }
-  a.kchunk = (int)align_up((size_t)ceil_div(T, ksplit), BK);
-  ksplit = (int)ceil_div(T, a.kchunk);
+  a.K = (int)T_main;
+  a.kchunk = (int)align_up((size_t)ceil_div(T_main, ksplit), BK);
+  ksplit = (int)ceil_div(T_main, a.kchunk);
   a.atomic = ksplit > 1;
   a.vecA = a.vecB = aligned16(Y) && (ldy % 8 == 0);
+  if (glds) {
+    const int nbig = nt * (nt - 1) / 2;
+    const int npeel = (ksplit == 1 && tiles % 512 <= nt) ? tiles % 512 : 0;   // 512 = two workgroups on each of 256 CUs
+    const int ndiag = nt - npeel;
+    dim3 grid((unsigned)(nbig + ndiag + PEEL_K * npeel), (unsigned)ksplit);
+    if (e_f64) hipLaunchKernelGGL((syrk_bf16_glds_kernel<EPI_ACC_F64>), grid, dim3(256), 0, st, a, nbig, ndiag);
+    else hipLaunchKernelGGL((syrk_bf16_glds_kernel<EPI_ACC_F32>), grid, dim3(256), 0, st, a, nbig, ndiag);
+    PTD_CHECK_LAUNCH("syrk_bf16 (LDS-DMA)");
+    if (T_main == T) return PTD_OK;
+    a.A = a.B = Y + T_main * ldy;
+    a.K = (int)(T - T_main);
+    a.kchunk = BK;
+    a.atomic = 0;
+    ksplit = 1;
+  }
   dim3 grid((unsigned)tiles, (unsigned)ksplit);
   if (e_f64) hipLaunchKernelGGL((gemm_bf16_kernel<false, false, EPI_ACC_F64>), grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL((gemm_bf16_kernel<false, false, EPI_ACC_F32>), grid, dim3(256), 0, st, a);

@@ -180,6 +180,14 @@ __device__ __forceinline__ void gemm_f32_tile(const GemmF32Args& a, const int ti
 #pragma unroll
     for (int j = 0; j < MI; ++j) {
       const int col = n0 + wn * (TS / 2) + j * 32 + (lane & 31);
+      if (EPI != EPI_STORE) {
+        const int row0 = m0 + wm * (TS / 2) + i * 32 + 4 * (lane >> 5);
+        if (EPI == EPI_ACC_F64)
+          accumulate_block(reinterpret_cast<double*>(a.C), a.ldc, row0, col, a.M, a.N, a.tri != 0, a.atomic != 0, a.scale, acc[i][j]);
+        else
+          accumulate_block(reinterpret_cast<float*>(a.C), a.ldc, row0, col, a.M, a.N, a.tri != 0, a.atomic != 0, a.scale, acc[i][j]);
+        continue;
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * (TS / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);

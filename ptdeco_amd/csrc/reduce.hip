@@ -132,48 +132,60 @@ __global__ void nsr_partial_kernel(const T* __restrict__ x, const T* __restrict_
       s2 += sm[1][k * Ct + cl];
       s3 += sm[2][k * Ct + cl];
     }
-    double* o = part + ((int64_t)blockIdx.y * C + c) * 3;
-    o[0] = s1; o[1] = s2; o[2] = s3;
+    // partials as [chunk][3][C]: the final pass reads them coalesced
+    double* o = part + (int64_t)blockIdx.y * 3 * C + c;
+    o[0] = s1; o[C] = s2; o[2 * C] = s3;
   }
 }
 
-// one thread per channel; every block leaves the sum of its channels' ratios in blocksum[blockIdx.x]
-__global__ void nsr_final_kernel(const double* __restrict__ part, int64_t R, int64_t C, int nchunk, double eps,
-                                 double* __restrict__ blocksum) {
-  __shared__ double red[16];
-  double acc = 0.0;
-  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (c < C) {
-    double s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    for (int k = 0; k < nchunk; ++k) {
-      const double* p = part + ((int64_t)k * C + c) * 3;
-      s1 += p[0]; s2 += p[1]; s3 += p[2];
+// 64 channels x 4 chunk lanes per block: the chunk partials of a channel are added in a fixed order (lane q takes
+// chunks q, q + 4, ..., then lanes 0 .. 3), the block leaves the sum of its channels' ratios in blocksum[blockIdx.x],
+// and the LAST block to finish (ticket counter) adds the block sums in index order and writes the result:
+// deterministic, and one launch instead of three (the old per-channel loop over strided partials took 21 us).
+__global__ __launch_bounds__(256) void nsr_final_kernel(const double* __restrict__ part, int64_t R, int64_t C,
+                                                        int nchunk, double eps, double* __restrict__ blocksum,
+                                                        unsigned int* __restrict__ ticket, double* __restrict__ out) {
+  __shared__ double sm[3][4][64];
+  __shared__ double red[4];
+  __shared__ bool last;
+  const int cl = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int64_t c = (int64_t)blockIdx.x * 64 + cl;
+  double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  if (c < C)
+    for (int k = q; k < nchunk; k += 4) {
+      const double* p = part + (int64_t)k * 3 * C + c;
+      s1 += p[0]; s2 += p[C]; s3 += p[2 * C];
     }
+  sm[0][q][cl] = s1; sm[1][q][cl] = s2; sm[2][q][cl] = s3;
+  __syncthreads();
+  double acc = 0.0;
+  if (q == 0 && c < C) {
+    s1 = (sm[0][0][cl] + sm[0][1][cl]) + (sm[0][2][cl] + sm[0][3][cl]);
+    s2 = (sm[1][0][cl] + sm[1][1][cl]) + (sm[1][2][cl] + sm[1][3][cl]);
+    s3 = (sm[2][0][cl] + sm[2][1][cl]) + (sm[2][2][cl] + sm[2][3][cl]);
     const double n = (double)R;
     const double var = (s2 - s1 * s1 / n) / (n - 1.0);  // unbiased, like torch.std
     acc = (s3 / n) / (var + eps);
   }
-  acc = wave_sum(acc);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double t = 0.0;
-    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
-    blocksum[blockIdx.x] = t;
+  if (q == 0) {
+    acc = wave_sum(acc);
+    if (cl == 0) {
+      blocksum[blockIdx.x] = acc;
+      __threadfence();
+      last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    }
   }
-}
-
-__global__ void sum_scale_kernel(const double* __restrict__ v, int64_t n, double scale, double* __restrict__ out) {
-  __shared__ double red[16];
-  double s = 0.0;
-  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) s += v[i];
-  s = wave_sum(s);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  double t = 0.0;
+  for (unsigned i = threadIdx.x; i < gridDim.x; i += 256) t += __hip_atomic_load(&blocksum[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  t = wave_sum(t);
+  if (cl == 0) red[q] = t;
   __syncthreads();
   if (threadIdx.x == 0) {
-    double t = 0.0;
-    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
-    out[0] = t * scale;
+    out[0] = ((red[0] + red[1]) + (red[2] + red[3])) / (double)C;
+    *ticket = 0u;   // ready for the next call on this workspace
   }
 }
 
@@ -305,7 +317,7 @@ int colsum_accumulate(const void* y, int64_t T, int64_t n, int64_t ldy, int y_dt
 
 size_t nsr_workspace_bytes(int64_t R, int64_t C) {
   const NsrPlan p = nsr_plan(R, C);
-  return align_up((size_t)p.nchunk * C * 3 * 8, 256) + align_up((size_t)ceil_div(C, 256) * 8, 256);
+  return align_up((size_t)p.nchunk * C * 3 * 8, 256) + align_up((size_t)ceil_div(C, 64) * 8, 256) + 256;
 }
 
 int nsr(const void* x, const void* y, int64_t R, int64_t C, int dtype, double eps, double* out, void* ws,
@@ -332,9 +344,11 @@ int nsr(const void* x, const void* y, int64_t R, int64_t C, int dtype, double ep
     return PTD_ERR_UNSUPPORTED;
   }
   double* blocksum = part + align_up((size_t)p.nchunk * C * 3 * 8, 256) / 8;
-  const unsigned fblocks = (unsigned)ceil_div(C, 256);
-  hipLaunchKernelGGL(nsr_final_kernel, dim3(fblocks), dim3(256), 0, st, part, R, C, p.nchunk, eps, blocksum);
-  hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(256), 0, st, blocksum, (int64_t)fblocks, 1.0 / (double)C, out);
+  const unsigned fblocks = (unsigned)ceil_div(C, 64);
+  unsigned int* ticket = reinterpret_cast<unsigned int*>(blocksum + align_up((size_t)fblocks * 8, 256) / 8);
+  // (the ticket is zeroed here: the workspace is the caller's and arrives uninitialised; the kernel resets it too)
+  PTD_CHECK_HIP(hipMemsetAsync(ticket, 0, 4, st));
+  hipLaunchKernelGGL(nsr_final_kernel, dim3(fblocks), dim3(256), 0, st, part, R, C, p.nchunk, eps, blocksum, ticket, out);
   PTD_CHECK_LAUNCH("nsr");
   return PTD_OK;
 }

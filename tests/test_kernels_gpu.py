@@ -50,6 +50,26 @@ def test_syrk_accumulate(ops, T, n, ydt, edt):
     assert err <= tol * max(1.0, ref.abs().max().item()), err
 
 
+@pytest.mark.parametrize("T,n,ld", [(64, 128, 128), (200, 384, 392), (1000, 1152, 1152), (333, 2560, 2568),
+                                    (128, 4096, 4096), (640, 4096, 4096), (72, 4224, 4224)])
+@pytest.mark.parametrize("edt", [torch.float64, torch.float32])
+def test_syrk_bf16_lds_dma_kernel_is_exact_on_small_integers(ops, T, n, ld, edt):
+    """The bf16 covariance kernels: the generic one (few tiles: split K with atomics) and, from 192 tiles on, the one
+    on the LDS-DMA schedule -- tile walk per XCD with a partial last group of tile rows (n = 2560), n = 4096
+    (528 tiles, 16 diagonal ones cut into K ranges added with atomics, here with fewer K steps than ranges), the ragged
+    last rows of T through the generic kernel, a padded row pitch.  Entries in -3 .. 3 keep every sum an integer
+    below 2^24: the result must equal the integer product, whatever the order of accumulation."""
+    g = torch.Generator().manual_seed(T * 7 + n)
+    big = torch.randint(-3, 4, (T, ld), generator=g).to(torch.bfloat16).to(DEV)
+    y = big[:, :n]
+    e = torch.full((n, n), 5.0, dtype=edt, device=DEV)
+    ops.syrk_accumulate(e, y, 2.0)
+    yi = y.to(torch.float64)
+    ref = 5.0 + 2.0 * (yi.T @ yi)
+    assert torch.equal(torch.tril(e.double()), torch.tril(ref))
+    assert torch.equal(torch.triu(e, 1), torch.full_like(e, 5.0).triu(1))
+
+
 def test_syrk_matches_oracle_product_in_activation_dtype(ops):
     """dwain.py:152: the oracle forms y^T y / T in y's dtype (f32) then adds into f64."""
     z = gio.npz("prim")

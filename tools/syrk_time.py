@@ -1,14 +1,21 @@
-import sys, torch
-sys.path.insert(0, "/root/repo")
+"""Event-timed bf16 / f32 covariance accumulate at the bench shapes (n = 4096 and the Llama down_proj input width)."""
+import json
+import sys
+
+import torch
+
+sys.path.insert(0, ".")
+import bench
 from ptdeco_amd import ops
+
 dev = torch.device("cuda")
-for n, T in [(4096, 4096), (14336, 2048), (3072, 3152)]:
+out = {}
+for n, T in ((4096, 4096), (4096, 16384), (14336, 4096), (2048, 4096)):
     y = torch.randn(T, n, device=dev)
     e = torch.zeros(n, n, dtype=torch.float64, device=dev)
-    for _ in range(3): ops.syrk_accumulate(e, y, 1.0 / T)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(10): ops.syrk_accumulate(e, y, 1.0 / T)
-    e1.record(); torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / 10
-    print(f"n={n} T={T}: {ms:.3f} ms  {T*n*n/ms/1e9:.1f} TFLOP/s algorithmic")
+    for name, yy in (("bf16", y.bfloat16()), ("f32", y)):
+        t = bench.time_events(lambda: ops.syrk_accumulate(e, yy, 1.0 / T), iters=10)
+        fl = T * n * (n + 1)
+        out[f"{name}_n{n}_T{T}"] = {"ms": round(t * 1e3, 4), "tflops": round(fl / t / 1e12, 1)}
+    del y, e
+print(json.dumps(out, indent=1))
