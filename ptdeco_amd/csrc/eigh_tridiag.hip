@@ -599,6 +599,276 @@ __global__ void sytrd_wfix_kernel(int n, int r0, int ilast, int jlast, const dou
   if (r < n) Wp[(int64_t)ilast * ldv + r] = wraw[r] + a2s * Vp[(int64_t)ilast * ldv + r];
 }
 
+// ------------------------------------------------------------------------------------- resident tail
+// The last RES_MAX columns of the reduction in ONE launch.  From a trailing order of 768 the matrix (4.7 MB, both
+// triangles) fits the LDS of the 32 CUs of one XCD, and what a column costs is no longer its bytes but its two global
+// dependencies (the reflector's norm; w = p - tau/2 (p^T v) v) -- two dependent launches of ~5 us each on the
+// blocked path, whatever their size.  Workgroups of one XCD share an L2, and a counter in THAT L2 (workgroup-scope
+// atomics, which execute in the L2; polled with returning atomics, which cannot hit a stale L1 line) makes a barrier
+// of 1.2 us against 5.8 us at agent scope (tools/probes/xcd_barrier_probe.hip).  So: 256 workgroups of 160 KB LDS
+// (one per CU), the 32 with blockIdx.x % 8 == 0 -- XCC 0, checked against the hardware id -- keep row slot + 32 q of
+// the trailing block in LDS and run the unblocked reduction (dsytd2) with two such barriers per column:
+//   x = A[j+1:, j] and partial norms -> barrier -> every workgroup forms v, tau, beta (identical arithmetic);
+//   p = tau A v for its rows, partial p^T v -> barrier -> every workgroup forms w; rank-2 update of its rows.
+// Vectors cross through small buffers: plain stores (the L1 is write-through) drained before the barrier, read back
+// with sc1 loads.  Every spin is bounded; a time-out or an XCC mismatch sets the status word and
+// the host repeats the reduction on the blocked path.
+constexpr int RES_MAX = 768;
+constexpr int RES_WG = 32;
+constexpr int RES_T = 512;
+constexpr int RES_RW = RES_MAX / RES_WG;                 // rows per workgroup
+constexpr int RES_XS = RES_MAX + 64;                     // exchange vector: m entries + 32 partials
+constexpr size_t RES_LDS = 150 * 1024;   // two vectors and scalars; sized so that a CU takes exactly one workgroup
+constexpr long RES_SPIN = 2000000L;
+
+struct ResCtl {
+  unsigned arrive; unsigned pad0[31];   // barrier counter, lives in XCC 0's L2
+  unsigned reg;    unsigned pad1[31];   // registration (agent scope)
+  int fail;        int pad2[31];        // 1 time-out, 2 XCC mismatch
+  int xcc[32];
+};
+
+__device__ __forceinline__ unsigned res_ld_u32(unsigned* p) {
+  unsigned v;
+  const unsigned z = 0;
+  asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p), "v"(z) : "memory");
+  return v;
+}
+// Exchanged vectors are read with device-scope (sc1) loads: they bypass this CU's L1 and are served by the XCD's
+// L2, where the other workgroups' plain stores are (probe: 8 KB per workgroup and barrier for +0.5 us; read with
+// returning atomics instead, the 32 workgroups' requests for one line serialise in the L2: +1.9 us, and 500 us when
+// the idle lanes shared a dummy address).
+__device__ __forceinline__ double res_ld_f64(const double* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void res_fetch(const double* V, int c0, bool ok0, int c1, bool ok1, double& a, double& b) {
+  a = ok0 ? res_ld_f64(V + c0) : 0.0;
+  b = ok1 ? res_ld_f64(V + c1) : 0.0;
+}
+
+__device__ __forceinline__ bool res_barrier(ResCtl* c, unsigned target, int* flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave's hand-off stores are in the L2 before it arrives
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(&c->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    int ok = 1;
+    for (long spin = 0;; ++spin) {
+      if (res_ld_u32(&c->arrive) >= target) break;
+      if (spin > RES_SPIN) { ok = 0; __hip_atomic_store(&c->fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+    }
+    *flag = ok;
+  }
+  __syncthreads();
+  return *flag != 0;
+}
+
+// sum over the 64 lanes of a wave without the LDS crossbar: DPP adds inside each row of 16 lanes, then the four row
+// sums by v_readlane in a fixed order (wave-uniform result)
+template <int CTRL>
+__device__ __forceinline__ double res_dpp(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double res_readlane(double v, int src) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double res_wave_sum(double v) {
+  v += res_dpp<0xB1>(v);    // quad_perm [1, 0, 3, 2]
+  v += res_dpp<0x4E>(v);    // quad_perm [2, 3, 0, 1]
+  v += res_dpp<0x124>(v);   // row_ror 4
+  v += res_dpp<0x128>(v);   // row_ror 8
+  return (res_readlane(v, 0) + res_readlane(v, 16)) + (res_readlane(v, 32) + res_readlane(v, 48));
+}
+
+// The workgroup's rows live in REGISTERS: wave w holds rows q = w, w + 8, w + 16 (global row slot + 32 q), lane l
+// their columns l + 64 k -- 36 doubles a thread, the layout of the product and of the rank-2 update, which therefore
+// touch no memory at all (kept in LDS, streaming the 147 KB slice through the LDS pipe twice a column took 2.9 us of
+// a 7.3 us column).  LDS holds the two vectors of the column and the scalars.
+constexpr int RES_RI = RES_RW / (RES_T / 64);     // rows per wave
+constexpr int RES_CK = RES_MAX / 64;              // columns per lane and row
+
+__global__ __launch_bounds__(RES_T) void sytrd_resident_kernel(const double* __restrict__ Aw, int64_t ld, int n, int t0,
+                                                               double* __restrict__ Vall, double* __restrict__ taus,
+                                                               double* __restrict__ d, double* __restrict__ e,
+                                                               ResCtl* __restrict__ ctl, double* __restrict__ Xbuf,
+                                                               double* __restrict__ Pv) {
+  extern __shared__ __attribute__((aligned(16))) char res_smem[];
+  if ((blockIdx.x & 7) != 0) return;
+  double* vs = reinterpret_cast<double*>(res_smem);
+  double* wv = vs + RES_MAX;
+  double* scr = wv + RES_MAX;                 // [0, 32) partials, [32] alpha, [40, 48) per-wave sums
+  __shared__ int flag;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int slot = blockIdx.x >> 3;
+  const int m = n - t0;
+  // ---- the 32 workgroups must sit on one XCC
+  const int my_xcc = (int)__builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11));   // HW_REG_XCC_ID[3:0]
+  if (tid == 0) {
+    if (slot == 0) __hip_atomic_exchange(&ctl->arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_store(&ctl->xcc[slot], my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(&ctl->reg, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    int ok = 1;
+    for (long spin = 0;; ++spin) {
+      if (__hip_atomic_load(&ctl->reg, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)RES_WG) break;
+      if (spin > RES_SPIN) { ok = 0; __hip_atomic_store(&ctl->fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+    }
+    if (ok)
+      for (int q = 0; q < RES_WG; ++q)
+        if (__hip_atomic_load(&ctl->xcc[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != my_xcc) {
+          ok = 0;
+          __hip_atomic_store(&ctl->fail, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    flag = ok;
+  }
+  __syncthreads();
+  if (!flag) return;
+  // ---- this thread's entries (zero beyond m: they meet zeros of v but must be finite)
+  double a[RES_RI][RES_CK];
+  int lr[RES_RI];
+#pragma unroll
+  for (int i = 0; i < RES_RI; ++i) {
+    lr[i] = slot + RES_WG * (wid + (RES_T / 64) * i);
+    const double* src = Aw + (int64_t)(t0 + min(lr[i], m - 1)) * ld + t0;
+#pragma unroll
+    for (int k = 0; k < RES_CK; ++k) {
+      const int c = lane + 64 * k;
+      a[i][k] = (lr[i] < m && c < m) ? src[c] : 0.0;
+    }
+  }
+  const int c0 = tid, c1 = tid + RES_T;       // the columns whose vector entries this thread forms (c1 < 768: tid < 256)
+  unsigned target = 0;
+  for (int jl = 0; jl + 1 < m; ++jl) {
+    // (x alternates between two buffers: a column with tau = 0 passes one barrier only, and the next column's
+    // entries must not land on values a slower workgroup is still reading)
+    double* X = Xbuf + (jl & 1) * RES_XS;
+    const int kj = jl >> 6;                   // the register column of jl, held by lane jl & 63
+    const int kmin = (jl + 1) >> 6;           // register columns below hold only retired columns
+    // ---- A: this workgroup's entries of column jl and their share of the norm
+    if (lane == (jl & 63)) {
+      double sq = 0.0;
+#pragma unroll
+      for (int i = 0; i < RES_RI; ++i) {
+        double val = 0.0;
+#pragma unroll
+        for (int k = 0; k < RES_CK; ++k) val = (k == kj) ? a[i][k] : val;
+        if (lr[i] < m) {
+          if (lr[i] > jl) X[lr[i]] = val;
+          if (lr[i] >= jl + 2) sq += val * val;
+          if (lr[i] == jl) d[t0 + jl] = val;
+        }
+      }
+      scr[40 + wid] = sq;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      double sq = 0.0;
+#pragma unroll
+      for (int w = 0; w < RES_T / 64; ++w) sq += scr[40 + w];
+      X[RES_MAX + slot] = sq;
+    }
+    target += RES_WG;
+    if (!res_barrier(ctl, target, &flag)) return;
+    double x0, x1;
+    res_fetch(X, c0, c0 > jl && c0 < m, c1, c1 > jl && c1 < m, x0, x1);
+    if (wid == RES_T / 64 - 1 && lane < RES_WG) scr[lane] = res_ld_f64(X + RES_MAX + lane);
+    if (c0 == jl + 1) scr[32] = x0;
+    if (c1 == jl + 1) scr[32] = x1;
+    __syncthreads();
+    double xn2 = 0.0;
+#pragma unroll
+    for (int q = 0; q < RES_WG; ++q) xn2 += scr[q];       // fixed order: the same value in every workgroup
+    const double alpha = scr[32];
+    double tau, beta, scale;
+    if (xn2 == 0.0) {
+      tau = 0.0; beta = alpha; scale = 0.0;
+    } else {
+      const double nrm = sqrt(alpha * alpha + xn2);
+      beta = alpha >= 0.0 ? -nrm : nrm;
+      tau = (beta - alpha) / beta;
+      scale = 1.0 / (alpha - beta);
+    }
+    const double v0 = (c0 == jl + 1) ? 1.0 : x0 * scale;   // x is zero outside (jl, m)
+    const double v1 = (c1 == jl + 1) ? 1.0 : x1 * scale;
+    vs[c0] = v0;
+    if (c1 < RES_MAX) vs[c1] = v1;
+    if (slot == (jl & (RES_WG - 1))) {
+      double* vrow = Vall + (int64_t)(t0 + jl) * ld + t0;
+      if (c0 > jl && c0 < m) vrow[c0] = v0;
+      if (c1 > jl && c1 < m) vrow[c1] = v1;
+      if (tid == 0) { taus[t0 + jl] = tau; e[t0 + jl] = beta; }
+    }
+    __syncthreads();
+    if (tau == 0.0) continue;                               // H = I: nothing to apply (uniform over the grid)
+    // ---- B: p = tau A v for this workgroup's rows
+    double vreg[RES_CK], vrow_[RES_RI];
+#pragma unroll
+    for (int k = 0; k < RES_CK; ++k) vreg[k] = vs[lane + 64 * k];
+#pragma unroll
+    for (int i = 0; i < RES_RI; ++i) vrow_[i] = vs[min(lr[i], RES_MAX - 1)];
+    {
+      double acc[RES_RI];
+#pragma unroll
+      for (int i = 0; i < RES_RI; ++i) {
+        acc[i] = 0.0;
+#pragma unroll
+        for (int k = 0; k < RES_CK; ++k)
+          if (k >= kmin) acc[i] += a[i][k] * vreg[k];
+      }
+      double dotpart = 0.0;
+#pragma unroll
+      for (int i = 0; i < RES_RI; ++i) {
+        const double pi = tau * res_wave_sum(acc[i]);
+        if (lr[i] > jl && lr[i] < m) {
+          if (lane == 0) Pv[lr[i]] = pi;
+          dotpart += pi * vrow_[i];
+        }
+      }
+      if (lane == 0) scr[40 + wid] = dotpart;
+      __syncthreads();
+      if (tid == 0) {
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < RES_T / 64; ++w) s += scr[40 + w];
+        Pv[RES_MAX + slot] = s;
+      }
+    }
+    target += RES_WG;
+    if (!res_barrier(ctl, target, &flag)) return;
+    double p0, p1;
+    res_fetch(Pv, c0, c0 > jl && c0 < m, c1, c1 > jl && c1 < m, p0, p1);
+    if (wid == RES_T / 64 - 1 && lane < RES_WG) scr[lane] = res_ld_f64(Pv + RES_MAX + lane);
+    __syncthreads();
+    double dot = 0.0;
+#pragma unroll
+    for (int q = 0; q < RES_WG; ++q) dot += scr[q];
+    const double hk = 0.5 * tau * dot;
+    wv[c0] = p0 - hk * v0;                                  // zero outside (jl, m): p and v are
+    if (c1 < RES_MAX) wv[c1] = p1 - hk * v1;
+    __syncthreads();
+    // ---- C: A -= v w^T + w v^T on this workgroup's rows
+#pragma unroll
+    for (int i = 0; i < RES_RI; ++i) {
+      const double wr_ = wv[min(lr[i], RES_MAX - 1)];
+      const bool live = lr[i] > jl && lr[i] < m;
+#pragma unroll
+      for (int k = 0; k < RES_CK; ++k) {
+        const double wk = wv[lane + 64 * k];
+        if (live && k >= kmin) a[i][k] -= vrow_[i] * wk + wr_ * vreg[k];
+      }
+    }
+    // (vs / wv / scr are rewritten only behind the next column's first barrier)
+  }
+  // ---- the last diagonal entry
+#pragma unroll
+  for (int i = 0; i < RES_RI; ++i)
+#pragma unroll
+    for (int k = 0; k < RES_CK; ++k)
+      if (lr[i] == m - 1 && lane + 64 * k == m - 1) d[t0 + m - 1] = a[i][k];
+}
+
 // very last diagonal entry: d[n-1] = base[n-1] - delta (delta = 0 if the column opens a panel)
 __global__ void sytrd_last_kernel(int n, int i, const double* __restrict__ colbuf,
                                   const double* __restrict__ partial2, int nparts2,
@@ -1090,7 +1360,7 @@ struct TridiagPlan {
   int npanels;
   size_t off_A, off_V, off_W, off_col, off_p, off_part, off_refl, off_d, off_e, off_e2, off_ds, off_tau, off_bounds, off_lam;
   size_t off_u1, off_u2, off_u3, off_lm, off_sw, off_G, off_T, off_W1, off_W2, off_wraw, off_wraw2, off_part2, off_cbuf;
-  size_t off_qv, off_px2, off_rowpart, off_colpart, off_gpart, off_tall;
+  size_t off_qv, off_px2, off_rowpart, off_colpart, off_gpart, off_tall, off_res;
   int64_t ldp;     // leading dimension of the symmetric SYMV's partial-result arrays
   bool two;        // two-stage reduction (eigh_twostage.hip) available for this order
   TwoStagePlan ts;
@@ -1148,6 +1418,7 @@ TridiagPlan tridiag_plan(int64_t n) {
   p.off_colpart = take((size_t)ceil_div(n, TR) * p.ldp * 8);
   p.off_gpart = take((size_t)p.npanels * ceil_div(n, GCH) * NB * NB * 8);
   p.off_tall = take((size_t)p.npanels * NB * NB * 8);
+  p.off_res = take(4096 + 3 * (size_t)RES_XS * 8);   // resident tail: control block, three exchange vectors
   p.two = twostage_supported(n);
   if (p.two) {
     p.ts = twostage_plan(n, p.ld);
@@ -1162,12 +1433,23 @@ TridiagPlan tridiag_plan(int64_t n) {
 struct SymvTimer {
   std::vector<hipEvent_t> ev;  // two per SAMPLED column: index 2 * (j / stride)
   int stride = 1;              // every stride-th column is timed (timing every launch slows the chain)
-  bool sampled(int j) const { return j % stride == stride / 2; }
+  int limit = INT32_MAX;       // columns from here on have no SYMV launch (resident tail)
+  bool sampled(int j) const { return j < limit && j % stride == stride / 2; }
   hipEvent_t start(int j) const { return ev[2 * (size_t)(j / stride)]; }
   hipEvent_t stop(int j) const { return ev[2 * (size_t)(j / stride) + 1]; }
 };
 
-int sytrd_f64(const TridiagPlan& p, char* base, SymvTimer* timer, hipStream_t st) {
+// first column of the resident tail: the first panel boundary with a trailing order of at most RES_MAX
+// (n itself for orders the tail kernel does not take; PTD_SYTRD_RESIDENT=0 switches it off)
+int resident_start(int n) {
+  static const bool off = getenv("PTD_SYTRD_RESIDENT") && atoi(getenv("PTD_SYTRD_RESIDENT")) == 0;
+  if (off || n < 128) return n;
+  return n <= RES_MAX ? 0 : (int)align_up((size_t)(n - RES_MAX), NB);
+}
+
+int* resident_status(const TridiagPlan& p, char* base) { return &reinterpret_cast<ResCtl*>(base + p.off_res)->fail; }
+
+int sytrd_f64(const TridiagPlan& p, char* base, SymvTimer* timer, bool resident, hipStream_t st) {
   const int n = p.n;
   const int64_t ld = p.ld;
   double* Aw = reinterpret_cast<double*>(base + p.off_A);
@@ -1204,8 +1486,24 @@ int sytrd_f64(const TridiagPlan& p, char* base, SymvTimer* timer, hipStream_t st
   PTD_CHECK_HIP(hipMemsetAsync(wr[0], 0, (size_t)(n + 8) * 8, st));
   PTD_CHECK_HIP(hipMemsetAsync(wr[1], 0, (size_t)(n + 8) * 8, st));
   bool colbuf_ready = false;
+  const int t_res = resident ? resident_start(n) : n;
+  if (timer) timer->limit = t_res;
+  ResCtl* rctl = reinterpret_cast<ResCtl*>(base + p.off_res);
+  PTD_CHECK_HIP(hipMemsetAsync(rctl, 0, sizeof(ResCtl), st));
   for (int pn = 0; pn < p.npanels; ++pn) {
     const int j0 = pn * NB;
+    if (j0 == t_res && n - j0 >= 2) {
+      // the rest of the reduction in one launch, the trailing block resident in the LDS of one XCD
+      double* X = reinterpret_cast<double*>(base + p.off_res + 4096);
+      static const bool attr = [] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(sytrd_resident_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)RES_LDS) == hipSuccess;
+      }();
+      PTD_REQUIRE(attr, "sytrd_f64: cannot reserve the LDS of the resident tail");
+      hipLaunchKernelGGL(sytrd_resident_kernel, dim3(8 * RES_WG), dim3(RES_T), RES_LDS, st, Aw, ld, n, j0, Vall, taus, d,
+                         e, rctl, X, X + 2 * RES_XS);
+      break;
+    }
     const int cols = std::min(NB, n - j0);
     double* Vp = Vall + (size_t)pn * NB * ld;
     int nparts2 = 0, npx2 = 0;
@@ -1412,6 +1710,7 @@ int eigh_tridiag(const double* A, int64_t lda, int64_t n, int64_t k, double* eva
   // (a Cholesky breakdown in a panel factorisation: a numerically rank-deficient panel; a chase time-out) are
   // read at the host synchronisation below and send the matrix through the one-stage reduction instead.
   bool two = p.two;
+  bool resident = true;   // the resident tail of the one-stage reduction; its status word is read below as well
   hipEvent_t em = nullptr, ev = nullptr, eq = nullptr;  // stage 1 | stage 2, vectors | Q2, Q2 | Q1
   if (stats && two) {
     PTD_CHECK_HIP(hipEventCreate(&em));
@@ -1434,7 +1733,7 @@ int eigh_tridiag(const double* A, int64_t lda, int64_t n, int64_t k, double* eva
       rc = twostage_reduce(p.ts, base + p.off_ts, Aw, reinterpret_cast<double*>(base + p.off_V), p.ld,
                            reinterpret_cast<double*>(base + p.off_d), reinterpret_cast<double*>(base + p.off_e), em, st);
     else
-      rc = sytrd_f64(p, base, stats ? &timer : nullptr, st);
+      rc = sytrd_f64(p, base, stats ? &timer : nullptr, resident, st);
     if (rc != PTD_OK) { cleanup2(); return rc; }
     if (stats) PTD_CHECK_HIP(hipEventRecord(e1, st));
     // only the gaps that touch one of the k requested (largest) eigenvalues matter, and unless the caller
@@ -1443,8 +1742,9 @@ int eigh_tridiag(const double* A, int64_t lda, int64_t n, int64_t k, double* eva
     if (rc != PTD_OK) { cleanup2(); return rc; }
     hipLaunchKernelGGL(min_gap_kernel, dim3(1), dim3(1024), 0, st, lam + first, (int)n - first, bounds, ortol,
                        bounds + 4);
-    int h_status[2] = {0, 0};
+    int h_status[2] = {0, 0}, h_res = 0;
     PTD_CHECK_HIP(hipMemcpyAsync(h_gap, bounds + 4, 16, hipMemcpyDeviceToHost, st));
+    if (!two) PTD_CHECK_HIP(hipMemcpyAsync(&h_res, resident_status(p, base), 4, hipMemcpyDeviceToHost, st));
     if (two)
       PTD_CHECK_HIP(hipMemcpyAsync(h_status, twostage_status(p.ts, base + p.off_ts), 8, hipMemcpyDeviceToHost, st));
     PTD_CHECK_HIP(hipStreamSynchronize(st));
@@ -1453,6 +1753,12 @@ int eigh_tridiag(const double* A, int64_t lda, int64_t n, int64_t k, double* eva
         fprintf(stderr, "[eigh_tridiag] two-stage reduction refused (cholesky %d, chase %d): one-stage\n", h_status[0],
                 h_status[1]);
       two = false;
+      continue;
+    }
+    if (h_res) {
+      if (getenv("PTD_JACOBI_DEBUG"))
+        fprintf(stderr, "[eigh_tridiag] resident tail gave up (status %d): blocked path to the end\n", h_res);
+      resident = false;
       continue;
     }
     break;
@@ -1507,7 +1813,7 @@ int eigh_tridiag(const double* A, int64_t lda, int64_t n, int64_t k, double* eva
     // SYMV launches: every stride-th column carries events; the columns of one stride block have
     // nearly the same trailing order, so the block's time is stride x its sample
     double timed_ms = 0.0;
-    for (int64_t j = 0; j + 1 < n; ++j) {
+    for (int64_t j = 0; j + 1 < std::min<int64_t>(n, timer.limit); ++j) {
       if (timer.sampled((int)j)) {
         float ms = 0.f;
         (void)hipEventElapsedTime(&ms, timer.start((int)j), timer.stop((int)j));
@@ -1547,8 +1853,17 @@ int tridiagonalize_f64(const double* A, int64_t lda, int64_t n, double* d_out, d
   if (p.two)
     rc = twostage_reduce(p.ts, base + p.off_ts, Aw, reinterpret_cast<double*>(base + p.off_V), p.ld,
                          reinterpret_cast<double*>(base + p.off_d), reinterpret_cast<double*>(base + p.off_e), nullptr, st);
-  else
-    rc = sytrd_f64(p, base, nullptr, st);
+  else {
+    rc = sytrd_f64(p, base, nullptr, true, st);
+    if (rc != PTD_OK) return rc;
+    int h_res = 0;
+    PTD_CHECK_HIP(hipMemcpyAsync(&h_res, resident_status(p, base), 4, hipMemcpyDeviceToHost, st));
+    PTD_CHECK_HIP(hipStreamSynchronize(st));
+    if (h_res) {   // the resident tail gave up: once more on the blocked path
+      hipLaunchKernelGGL(copy_pad_kernel, dim3(2048), dim3(256), 0, st, A, lda, (int)n, Aw, p.ld);
+      rc = sytrd_f64(p, base, nullptr, false, st);
+    }
+  }
   if (rc != PTD_OK) return rc;
   rc = tridiag_eigenvalues(p, base, 0, st);
   if (rc != PTD_OK) return rc;

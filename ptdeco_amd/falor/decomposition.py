@@ -62,13 +62,15 @@ def _compute_decompositon_of_covariance_matrix(*, root_module, tap: eng.LayerTap
     """:165-208.  Quirk kept: damping is applied to Eyyt after cov was formed, so with
     use_mean=True it never reaches the matrix that is decomposed (:196-205)."""
     root_module.eval()
-    cov = eng.Covariance(weight.shape[0], device, use_float64, with_mean=True, weight=weight, top_k=top_k)
-    for _ in range(num_data_steps):
-        root_module(next(data_iterator).to(device))
-        cov.add_inputs(tap.last_input_rows(), weight)
+    with eng.phase("A_accumulate"):
+        cov = eng.Covariance(weight.shape[0], device, use_float64, with_mean=True, weight=weight, top_k=top_k)
+        for _ in range(num_data_steps):
+            root_module(next(data_iterator).to(device))
+            cov.add_inputs(tap.last_input_rows(), weight)
     logger.info("Using mean for covariance" if use_mean else "Not using mean for covariance")
     damp = EIGEN_DAMPEN_FACTOR if (use_damping and not use_mean) else 0.0
-    return cov.eigenvectors(damp, use_mean=use_mean, top_k=top_k)
+    with eng.phase("B_eigh"):
+        return cov.eigenvectors(damp, use_mean=use_mean, top_k=top_k)
 
 
 def _compute_metrics(*, x, root_module, tap: eng.LayerTap, orig_weight, candidate) -> torch.Tensor:
@@ -126,16 +128,19 @@ def _process_module(*, root_module, decomposed_submodule_name, data_iterator, ns
         rank_best = full_rank
         nsr_best = kl_best = nsr_new = kl_new = 0.0
         uk = big_u = None
-        bank = eng.FactorBank(orig_weight, u, full_rank, torch.float32)  # U = W^T u once (:346-348)
+        with eng.phase("C_factors"):
+            bank = eng.FactorBank(orig_weight, u, full_rank, torch.float32)  # U = W^T u once (:346-348)
         for i, rank_width in enumerate(_bisection_widths(full_rank), start=1):
             rank_new = rank_best - rank_width
-            candidate = bank.get(rank_new, dense=not fast)
+            with eng.phase("C_factors"):
+                candidate = bank.get(rank_new, dense=not fast)
             uk, big_u, _ = candidate
-            acc = torch.zeros(2, dtype=torch.float64, device=device)
-            for _ in range(num_metric_steps):
-                acc += _compute_metrics(x=next(data_iterator).to(device), root_module=root_module, tap=tap,
-                                        orig_weight=orig_weight, candidate=candidate)
-            nsr_new, kl_new = (acc / num_metric_steps).tolist()
+            with eng.phase("D_metrics"):
+                acc = torch.zeros(2, dtype=torch.float64, device=device)
+                for _ in range(num_metric_steps):
+                    acc += _compute_metrics(x=next(data_iterator).to(device), root_module=root_module, tap=tap,
+                                            orig_weight=orig_weight, candidate=candidate)
+                nsr_new, kl_new = (acc / num_metric_steps).tolist()
             accepted = nsr_new < nsr_final_threshold and kl_new < kl_final_threshold
             if accepted:
                 rank_best, nsr_best, kl_best = rank_new, nsr_new, kl_new

@@ -19,11 +19,15 @@ pool = [torch.randn(batch, 3, 224, 224, generator=g).to(dev) for _ in range(24)]
 kw = dict(proportion_threshold=0.9, nsr_final_threshold=0.05, kl_final_threshold=0.01, num_data_steps=4,
           num_metric_steps=2, use_float64=True, use_mean=True, use_damping=True)
 trace = []
+from ptdeco_amd import _engine as eng
+if os.environ.get("PTD_PHASES"):
+    eng.PHASES = eng.PhaseTimer()   # device-time split (adds two event records per span)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 cfg = ptdeco_amd.falor.decompose_in_place(module=model, device=dev, data_iterator=itertools.cycle(pool), trace=trace, **kw)
 torch.cuda.synchronize(); dt = time.perf_counter() - t0
 layers = sum(1 for n, m in ViT(depth=depth).named_modules() if isinstance(m, torch.nn.Linear))
-print(json.dumps({"workload": f"falor.decompose_in_place, ViT-B/16-shaped, depth {depth}, f32 model, f64 covariance + eigh, "
+phases = {k: round(v, 1) for k, v in eng.PHASES.totals_ms().items()} if eng.PHASES is not None else None
+print(json.dumps({"phases_ms": phases, "workload": f"falor.decompose_in_place, ViT-B/16-shaped, depth {depth}, f32 model, f64 covariance + eigh, "
                               f"[{batch},3,224,224] images, D=4, M=2", "layers": layers, "seconds": dt,
                   "layers_per_s": layers / dt, "candidates_evaluated": len(trace), "decomposed": len(cfg),
                   "kept": {k: v["__meta__"]["proportion"] for k, v in list(cfg.items())[:6]}}))
