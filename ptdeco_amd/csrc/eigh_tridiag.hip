@@ -9,6 +9,7 @@
 //   4. back-transformation Z = Q Y with compact-WY block reflectors (f64 MFMA GEMMs).
 // The full matrix (both triangles) is kept current, so the column a panel step needs is a contiguous row.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -601,39 +602,34 @@ __global__ void sytrd_wfix_kernel(int n, int r0, int ilast, int jlast, const dou
 
 // ------------------------------------------------------------------------------------- resident tail
 // The last RES_MAX columns of the reduction in ONE launch.  From a trailing order of 768 the matrix (4.7 MB, both
-// triangles) fits the LDS of the 32 CUs of one XCD, and what a column costs is no longer its bytes but its two global
-// dependencies (the reflector's norm; w = p - tau/2 (p^T v) v) -- two dependent launches of ~5 us each on the
-// blocked path, whatever their size.  Workgroups of one XCD share an L2, and a counter in THAT L2 (workgroup-scope
-// atomics, which execute in the L2; polled with returning atomics, which cannot hit a stale L1 line) makes a barrier
-// of 1.2 us against 5.8 us at agent scope (tools/probes/xcd_barrier_probe.hip).  So: 256 workgroups of 160 KB LDS
-// (one per CU), the 32 with blockIdx.x % 8 == 0 -- XCC 0, checked against the hardware id -- keep row slot + 32 q of
-// the trailing block in LDS and run the unblocked reduction (dsytd2) with two such barriers per column:
-//   x = A[j+1:, j] and partial norms -> barrier -> every workgroup forms v, tau, beta (identical arithmetic);
-//   p = tau A v for its rows, partial p^T v -> barrier -> every workgroup forms w; rank-2 update of its rows.
-// Vectors cross through small buffers: plain stores (the L1 is write-through) drained before the barrier, read back
-// with sc1 loads.  Every spin is bounded; a time-out or an XCC mismatch sets the status word and
-// the host repeats the reduction on the blocked path.
-constexpr int RES_MAX = 768;
+// triangles) fits the registers of the 32 CUs of one XCD, and what a column costs is no longer its bytes but its two
+// global dependencies (v needs the whole column; w = p - tau/2 (p^T v) v needs the whole product) -- two dependent
+// launches of ~5 us each on the blocked path, whatever their size.  Workgroups of one XCD share an L2: a plain store
+// of one CU (the L1 is write-through) is seen by a device-scope (sc1) load of another as soon as it is acknowledged,
+// without the write-back / invalidate of an agent-scope release / acquire pair (tools/probes/xcd_barrier_probe.hip: a
+// barrier through that L2 1.2 us, with fences 5.8 us).  So: 256 workgroups of 150 KB LDS (one per CU), the 32 with
+// blockIdx.x % 8 == 0 -- XCC 0, checked against the hardware id -- keep rows slot + 32 q of the trailing block and run
+// the unblocked reduction (dsytd2) with two all-to-all hand-offs per column:
+//   x = A[j+1:, j]  -> every workgroup forms the norm, v, tau, beta (identical arithmetic);
+//   p = tau A v     -> every workgroup forms p^T v and w; rank-2 update of its rows.
+// Every spin is bounded; a time-out or an XCC mismatch sets the status word and the host repeats the reduction on the
+// blocked path.  Measured (n = 4096, k = 1024): 68.2 -> 64.1 ms; n = 768: 9.0 -> 5.3 ms, 4.8 us per column against
+// 11.5.  A tail of 1024 columns (64 doubles a thread, 244 VGPRs) was no faster: 64.5 ms.
+constexpr int RES_MAX = 768;                             // one XCD: 32 workgroups
 constexpr int RES_WG = 32;
 constexpr int RES_T = 512;
-constexpr int RES_RW = RES_MAX / RES_WG;                 // rows per workgroup
-constexpr int RES_XS = RES_MAX + 64;                     // exchange vector: m entries + 32 partials
+constexpr int RES_XS = RES_MAX + 64;                     // one exchange vector
 constexpr size_t RES_LDS = 150 * 1024;   // two vectors and scalars; sized so that a CU takes exactly one workgroup
 constexpr long RES_SPIN = 2000000L;
 
 struct ResCtl {
-  unsigned arrive; unsigned pad0[31];   // barrier counter, lives in XCC 0's L2
+  unsigned long long fx[RES_WG];        // [0]: sequence number of the last published row (column of x)
+  unsigned long long fp[RES_WG];        // per workgroup: sequence number of its last published p entries
   unsigned reg;    unsigned pad1[31];   // registration (agent scope)
   int fail;        int pad2[31];        // 1 time-out, 2 XCC mismatch
   int xcc[32];
 };
 
-__device__ __forceinline__ unsigned res_ld_u32(unsigned* p) {
-  unsigned v;
-  const unsigned z = 0;
-  asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p), "v"(z) : "memory");
-  return v;
-}
 // Exchanged vectors are read with device-scope (sc1) loads: they bypass this CU's L1 and are served by the XCD's
 // L2, where the other workgroups' plain stores are (probe: 8 KB per workgroup and barrier for +0.5 us; read with
 // returning atomics instead, the 32 workgroups' requests for one line serialise in the L2: +1.9 us, and 500 us when
@@ -641,25 +637,25 @@ __device__ __forceinline__ unsigned res_ld_u32(unsigned* p) {
 __device__ __forceinline__ double res_ld_f64(const double* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void res_fetch(const double* V, int c0, bool ok0, int c1, bool ok1, double& a, double& b) {
-  a = ok0 ? res_ld_f64(V + c0) : 0.0;
-  b = ok1 ? res_ld_f64(V + c1) : 0.0;
-}
 
-__device__ __forceinline__ bool res_barrier(ResCtl* c, unsigned target, int* flag) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave's hand-off stores are in the L2 before it arrives
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __hip_atomic_fetch_add(&c->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    int ok = 1;
-    for (long spin = 0;; ++spin) {
-      if (res_ld_u32(&c->arrive) >= target) break;
-      if (spin > RES_SPIN) { ok = 0; __hip_atomic_store(&c->fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+// Hand-off: a workgroup stores its entries, drains the stores (they are in the L2 then), and publishes a sequence
+// number; a consumer wave watches the 32 numbers (lane s: workgroup s) and then reads the vector.  Against a counter
+// barrier followed by the read this saves one L2 round trip per exchange, and nothing serialises on one address.
+// false after a time-out.
+__device__ __forceinline__ bool res_wait(const unsigned long long* F, unsigned long long seq, int lane, ResCtl* c) {
+  for (long spin = 0;; ++spin) {
+    const unsigned long long f = __hip_atomic_load(F + (lane & (RES_WG - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (__all(f >= seq)) return true;
+    if (spin > RES_SPIN) {
+      __hip_atomic_store(&c->fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return false;
     }
-    *flag = ok;
   }
+}
+__device__ __forceinline__ void res_publish(unsigned long long* F, int slot, unsigned long long seq) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave's entries are in the L2 ...
   __syncthreads();
-  return *flag != 0;
+  if (threadIdx.x == 0) __hip_atomic_store(F + slot, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // ... before the number
 }
 
 // sum over the 64 lanes of a wave without the LDS crossbar: DPP adds inside each row of 16 lanes, then the four row
@@ -683,104 +679,123 @@ __device__ __forceinline__ double res_wave_sum(double v) {
   return (res_readlane(v, 0) + res_readlane(v, 16)) + (res_readlane(v, 32) + res_readlane(v, 48));
 }
 
-// The workgroup's rows live in REGISTERS: wave w holds rows q = w, w + 8, w + 16 (global row slot + 32 q), lane l
-// their columns l + 64 k -- 36 doubles a thread, the layout of the product and of the rank-2 update, which therefore
-// touch no memory at all (kept in LDS, streaming the 147 KB slice through the LDS pipe twice a column took 2.9 us of
-// a 7.3 us column).  LDS holds the two vectors of the column and the scalars.
-constexpr int RES_RI = RES_RW / (RES_T / 64);     // rows per wave
-constexpr int RES_CK = RES_MAX / 64;              // columns per lane and row
-
+// The workgroup's rows live in REGISTERS: wave w holds rows q = w, w + 8, .. (global row slot + NWG q), lane l their
+// columns l + 64 k -- the layout of the product and of the rank-2 update, which therefore touch no memory at all
+// (kept in LDS, streaming the 147 KB slice through the LDS pipe twice a column took 2.9 us of a 7.3 us column).
+// LDS holds the two vectors of the column and the scalars.
+// (The same kernel on all 256 CUs -- 2048 resident columns, hand-offs written through to memory with sc1 stores -- is
+// correct and slower than the blocked path: ~14 us per column, n = 2048 31.3 vs 22.2 ms; a hand-off that leaves the
+// XCD costs 5-6 us.)
 __global__ __launch_bounds__(RES_T) void sytrd_resident_kernel(const double* __restrict__ Aw, int64_t ld, int n, int t0,
                                                                double* __restrict__ Vall, double* __restrict__ taus,
                                                                double* __restrict__ d, double* __restrict__ e,
                                                                ResCtl* __restrict__ ctl, double* __restrict__ Xbuf,
-                                                               double* __restrict__ Pv) {
+                                                               double* __restrict__ Pv, unsigned long long epoch) {
+  constexpr int NWG = RES_WG, MAXM = RES_MAX;
+  constexpr int NW = RES_T / 64;                    // waves
+  constexpr int RI = MAXM / NWG / NW;               // rows per wave
+  constexpr int CK = MAXM / 64;                     // columns per lane and row
+  constexpr int CT = MAXM / RES_T + (MAXM % RES_T != 0);   // vector entries formed per thread
+  static_assert(RI >= 1 && RI * NW * NWG == MAXM, "rows must divide evenly");
   extern __shared__ __attribute__((aligned(16))) char res_smem[];
   if ((blockIdx.x & 7) != 0) return;
   double* vs = reinterpret_cast<double*>(res_smem);
-  double* wv = vs + RES_MAX;
-  double* scr = wv + RES_MAX;                 // [0, 32) partials, [32] alpha, [40, 48) per-wave sums
+  double* wv = vs + MAXM;
+  double* scr = wv + MAXM;                    // [0, 8) per-wave sums of x^2, [8] alpha, [16, 24) per-wave sums of p v
   __shared__ int flag;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int slot = blockIdx.x >> 3;
   const int m = n - t0;
-  // ---- the 32 workgroups must sit on one XCC
-  const int my_xcc = (int)__builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11));   // HW_REG_XCC_ID[3:0]
-  if (tid == 0) {
-    if (slot == 0) __hip_atomic_exchange(&ctl->arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    __hip_atomic_store(&ctl->xcc[slot], my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_fetch_add(&ctl->reg, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    int ok = 1;
-    for (long spin = 0;; ++spin) {
-      if (__hip_atomic_load(&ctl->reg, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)RES_WG) break;
-      if (spin > RES_SPIN) { ok = 0; __hip_atomic_store(&ctl->fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+  {
+    // ---- the 32 workgroups must sit on one XCC
+    const int my_xcc = (int)__builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11));   // HW_REG_XCC_ID[3:0]
+    if (tid == 0) {
+      __hip_atomic_store(&ctl->xcc[slot], my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(&ctl->reg, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      int ok = 1;
+      for (long spin = 0;; ++spin) {
+        if (__hip_atomic_load(&ctl->reg, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)NWG) break;
+        if (spin > RES_SPIN) { ok = 0; __hip_atomic_store(&ctl->fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      }
+      if (ok)
+        for (int q = 0; q < NWG; ++q)
+          if (__hip_atomic_load(&ctl->xcc[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != my_xcc) {
+            ok = 0;
+            __hip_atomic_store(&ctl->fail, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+      flag = ok;
     }
-    if (ok)
-      for (int q = 0; q < RES_WG; ++q)
-        if (__hip_atomic_load(&ctl->xcc[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != my_xcc) {
-          ok = 0;
-          __hip_atomic_store(&ctl->fail, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    flag = ok;
+    __syncthreads();
+    if (!flag) return;
   }
-  __syncthreads();
-  if (!flag) return;
   // ---- this thread's entries (zero beyond m: they meet zeros of v but must be finite)
-  double a[RES_RI][RES_CK];
-  int lr[RES_RI];
+  double a[RI][CK];
+  int lr[RI];
 #pragma unroll
-  for (int i = 0; i < RES_RI; ++i) {
-    lr[i] = slot + RES_WG * (wid + (RES_T / 64) * i);
+  for (int i = 0; i < RI; ++i) {
+    lr[i] = slot + NWG * (wid + NW * i);
     const double* src = Aw + (int64_t)(t0 + min(lr[i], m - 1)) * ld + t0;
 #pragma unroll
-    for (int k = 0; k < RES_CK; ++k) {
+    for (int k = 0; k < CK; ++k) {
       const int c = lane + 64 * k;
       a[i][k] = (lr[i] < m && c < m) ? src[c] : 0.0;
     }
   }
-  const int c0 = tid, c1 = tid + RES_T;       // the columns whose vector entries this thread forms (c1 < 768: tid < 256)
-  unsigned target = 0;
+  // sequence numbers are unique over calls (epoch), so a number left in a cache by an earlier call can never pass
   for (int jl = 0; jl + 1 < m; ++jl) {
-    // (x alternates between two buffers: a column with tau = 0 passes one barrier only, and the next column's
-    // entries must not land on values a slower workgroup is still reading)
+    const unsigned long long seq = epoch + (unsigned long long)jl + 1;
+    // (x alternates between two buffers: the next row may be published while a slower workgroup still reads this one)
     double* X = Xbuf + (jl & 1) * RES_XS;
-    const int kj = jl >> 6;                   // the register column of jl, held by lane jl & 63
     const int kmin = (jl + 1) >> 6;           // register columns below hold only retired columns
-    // ---- A: this workgroup's entries of column jl and their share of the norm
-    if (lane == (jl & 63)) {
-      double sq = 0.0;
+    // ---- A: column jl below the diagonal is row jl to the right of it, and that row sits in ONE wave: the wave
+    // publishes it as soon as its own update is done -- nobody waits for the slowest of 32 workgroups here, and the
+    // hand-off overlaps the other workgroups' updates.  (The two triangles can differ in the last bit -- the update
+    // contracts one of its two products into an fma -- which is a perturbation of eps |A|, like choosing a triangle.)
+    if (slot == (jl & (NWG - 1)) && wid == ((jl / NWG) & (NW - 1))) {
+      const int io = jl / (NWG * NW);
 #pragma unroll
-      for (int i = 0; i < RES_RI; ++i) {
-        double val = 0.0;
+      for (int k = 0; k < CK; ++k) {
+        double val = a[0][k];
 #pragma unroll
-        for (int k = 0; k < RES_CK; ++k) val = (k == kj) ? a[i][k] : val;
-        if (lr[i] < m) {
-          if (lr[i] > jl) X[lr[i]] = val;
-          if (lr[i] >= jl + 2) sq += val * val;
-          if (lr[i] == jl) d[t0 + jl] = val;
-        }
+        for (int i = 1; i < RI; ++i) val = (i == io) ? a[i][k] : val;
+        const int c = lane + 64 * k;
+        if (c > jl && c < m) X[c] = val;
+        if (c == jl) d[t0 + jl] = val;
       }
-      scr[40 + wid] = sq;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the row is in the L2 before its number
+      if (lane == 0) __hip_atomic_store(&ctl->fx[0], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
-    __syncthreads();
-    if (tid == 0) {
+    for (long spin = 0;; ++spin) {
+      if (__hip_atomic_load(&ctl->fx[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= seq) break;
+      if (spin > RES_SPIN) {
+        __hip_atomic_store(&ctl->fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+      }
+    }
+    // the vector entries this thread forms: columns tid, tid + 512, ..
+    double xv[CT], vv[CT];
+#pragma unroll
+    for (int t = 0; t < CT; ++t) {
+      const int c = tid + RES_T * t;
+      xv[t] = (c > jl && c < m) ? res_ld_f64(X + c) : 0.0;
+    }
+    {
+      // the norm from the whole column, the same arithmetic in every workgroup
       double sq = 0.0;
 #pragma unroll
-      for (int w = 0; w < RES_T / 64; ++w) sq += scr[40 + w];
-      X[RES_MAX + slot] = sq;
+      for (int t = 0; t < CT; ++t) {
+        const int c = tid + RES_T * t;
+        if (c >= jl + 2) sq += xv[t] * xv[t];
+        if (c == jl + 1) scr[8] = xv[t];
+      }
+      sq = res_wave_sum(sq);
+      if (lane == 0) scr[wid] = sq;
     }
-    target += RES_WG;
-    if (!res_barrier(ctl, target, &flag)) return;
-    double x0, x1;
-    res_fetch(X, c0, c0 > jl && c0 < m, c1, c1 > jl && c1 < m, x0, x1);
-    if (wid == RES_T / 64 - 1 && lane < RES_WG) scr[lane] = res_ld_f64(X + RES_MAX + lane);
-    if (c0 == jl + 1) scr[32] = x0;
-    if (c1 == jl + 1) scr[32] = x1;
     __syncthreads();
     double xn2 = 0.0;
 #pragma unroll
-    for (int q = 0; q < RES_WG; ++q) xn2 += scr[q];       // fixed order: the same value in every workgroup
-    const double alpha = scr[32];
+    for (int w = 0; w < NW; ++w) xn2 += scr[w];
+    const double alpha = scr[8];
     double tau, beta, scale;
     if (xn2 == 0.0) {
       tau = 0.0; beta = alpha; scale = 0.0;
@@ -790,82 +805,88 @@ __global__ __launch_bounds__(RES_T) void sytrd_resident_kernel(const double* __r
       tau = (beta - alpha) / beta;
       scale = 1.0 / (alpha - beta);
     }
-    const double v0 = (c0 == jl + 1) ? 1.0 : x0 * scale;   // x is zero outside (jl, m)
-    const double v1 = (c1 == jl + 1) ? 1.0 : x1 * scale;
-    vs[c0] = v0;
-    if (c1 < RES_MAX) vs[c1] = v1;
-    if (slot == (jl & (RES_WG - 1))) {
+    {
       double* vrow = Vall + (int64_t)(t0 + jl) * ld + t0;
-      if (c0 > jl && c0 < m) vrow[c0] = v0;
-      if (c1 > jl && c1 < m) vrow[c1] = v1;
-      if (tid == 0) { taus[t0 + jl] = tau; e[t0 + jl] = beta; }
+      const bool writer = slot == (jl & (NWG - 1));
+#pragma unroll
+      for (int t = 0; t < CT; ++t) {
+        const int c = tid + RES_T * t;
+        vv[t] = (c == jl + 1) ? 1.0 : xv[t] * scale;        // x is zero outside (jl, m)
+        if (c < MAXM) vs[c] = vv[t];
+        if (writer && c > jl && c < m) vrow[c] = vv[t];
+      }
+      if (writer && tid == 0) { taus[t0 + jl] = tau; e[t0 + jl] = beta; }
     }
     __syncthreads();
-    if (tau == 0.0) continue;                               // H = I: nothing to apply (uniform over the grid)
+    if (tau == 0.0) {                                       // H = I: nothing to apply (uniform over the grid),
+      res_publish(ctl->fp, slot, seq);                      // but every column keeps its all-to-all hand-off: the
+      if (!res_wait(ctl->fp, seq, lane, ctl)) return;       // x buffers are reused two columns later
+      continue;
+    }
     // ---- B: p = tau A v for this workgroup's rows
-    double vreg[RES_CK], vrow_[RES_RI];
+    double vreg[CK], vrow_[RI];
 #pragma unroll
-    for (int k = 0; k < RES_CK; ++k) vreg[k] = vs[lane + 64 * k];
+    for (int k = 0; k < CK; ++k) vreg[k] = vs[lane + 64 * k];
 #pragma unroll
-    for (int i = 0; i < RES_RI; ++i) vrow_[i] = vs[min(lr[i], RES_MAX - 1)];
+    for (int i = 0; i < RI; ++i) vrow_[i] = vs[min(lr[i], MAXM - 1)];
     {
-      double acc[RES_RI];
+      double acc[RI];
 #pragma unroll
-      for (int i = 0; i < RES_RI; ++i) {
+      for (int i = 0; i < RI; ++i) {
         acc[i] = 0.0;
 #pragma unroll
-        for (int k = 0; k < RES_CK; ++k)
+        for (int k = 0; k < CK; ++k)
           if (k >= kmin) acc[i] += a[i][k] * vreg[k];
       }
-      double dotpart = 0.0;
 #pragma unroll
-      for (int i = 0; i < RES_RI; ++i) {
+      for (int i = 0; i < RI; ++i) {
         const double pi = tau * res_wave_sum(acc[i]);
-        if (lr[i] > jl && lr[i] < m) {
-          if (lane == 0) Pv[lr[i]] = pi;
-          dotpart += pi * vrow_[i];
-        }
-      }
-      if (lane == 0) scr[40 + wid] = dotpart;
-      __syncthreads();
-      if (tid == 0) {
-        double s = 0.0;
-#pragma unroll
-        for (int w = 0; w < RES_T / 64; ++w) s += scr[40 + w];
-        Pv[RES_MAX + slot] = s;
+        if (lane == 0 && lr[i] > jl && lr[i] < m) Pv[lr[i]] = pi;
       }
     }
-    target += RES_WG;
-    if (!res_barrier(ctl, target, &flag)) return;
-    double p0, p1;
-    res_fetch(Pv, c0, c0 > jl && c0 < m, c1, c1 > jl && c1 < m, p0, p1);
-    if (wid == RES_T / 64 - 1 && lane < RES_WG) scr[lane] = res_ld_f64(Pv + RES_MAX + lane);
+    res_publish(ctl->fp, slot, seq);
+    if (!res_wait(ctl->fp, seq, lane, ctl)) return;
+    double pv_[CT];
+    {
+      double dp = 0.0;
+#pragma unroll
+      for (int t = 0; t < CT; ++t) {
+        const int c = tid + RES_T * t;
+        pv_[t] = (c > jl && c < m) ? res_ld_f64(Pv + c) : 0.0;
+        dp += pv_[t] * vv[t];
+      }
+      dp = res_wave_sum(dp);                                // p^T v from the whole vectors
+      if (lane == 0) scr[16 + wid] = dp;
+    }
     __syncthreads();
     double dot = 0.0;
 #pragma unroll
-    for (int q = 0; q < RES_WG; ++q) dot += scr[q];
+    for (int w = 0; w < NW; ++w) dot += scr[16 + w];
     const double hk = 0.5 * tau * dot;
-    wv[c0] = p0 - hk * v0;                                  // zero outside (jl, m): p and v are
-    if (c1 < RES_MAX) wv[c1] = p1 - hk * v1;
+#pragma unroll
+    for (int t = 0; t < CT; ++t) {
+      const int c = tid + RES_T * t;
+      if (c < MAXM) wv[c] = pv_[t] - hk * vv[t];            // zero outside (jl, m): p and v are
+    }
     __syncthreads();
     // ---- C: A -= v w^T + w v^T on this workgroup's rows
 #pragma unroll
-    for (int i = 0; i < RES_RI; ++i) {
-      const double wr_ = wv[min(lr[i], RES_MAX - 1)];
+    for (int i = 0; i < RI; ++i) {
+      const double wr_ = wv[min(lr[i], MAXM - 1)];
       const bool live = lr[i] > jl && lr[i] < m;
 #pragma unroll
-      for (int k = 0; k < RES_CK; ++k) {
+      for (int k = 0; k < CK; ++k) {
         const double wk = wv[lane + 64 * k];
         if (live && k >= kmin) a[i][k] -= vrow_[i] * wk + wr_ * vreg[k];
       }
     }
-    // (vs / wv / scr are rewritten only behind the next column's first barrier)
+    // (vs / wv / scr are rewritten only behind the barrier inside the next publication)
   }
   // ---- the last diagonal entry
 #pragma unroll
-  for (int i = 0; i < RES_RI; ++i)
+  for (int i = 0; i < RI; ++i)
 #pragma unroll
-    for (int k = 0; k < RES_CK; ++k)
+    for (int k = 0; k < CK; ++k)
       if (lr[i] == m - 1 && lane + 64 * k == m - 1) d[t0 + m - 1] = a[i][k];
 }
 
@@ -1418,7 +1439,7 @@ TridiagPlan tridiag_plan(int64_t n) {
   p.off_colpart = take((size_t)ceil_div(n, TR) * p.ldp * 8);
   p.off_gpart = take((size_t)p.npanels * ceil_div(n, GCH) * NB * NB * 8);
   p.off_tall = take((size_t)p.npanels * NB * NB * 8);
-  p.off_res = take(4096 + 3 * (size_t)RES_XS * 8);   // resident tail: control block, three exchange vectors
+  p.off_res = take(8192 + 3 * (size_t)RES_XS * 8);   // resident tail: control block, three exchange vectors
   p.two = twostage_supported(n);
   if (p.two) {
     p.ts = twostage_plan(n, p.ld);
@@ -1442,8 +1463,8 @@ struct SymvTimer {
 // first column of the resident tail: the first panel boundary with a trailing order of at most RES_MAX
 // (n itself for orders the tail kernel does not take; PTD_SYTRD_RESIDENT=0 switches it off)
 int resident_start(int n) {
-  static const bool off = getenv("PTD_SYTRD_RESIDENT") && atoi(getenv("PTD_SYTRD_RESIDENT")) == 0;
-  if (off || n < 128) return n;
+  const char* env = getenv("PTD_SYTRD_RESIDENT");   // 0: off; 2: test hook, see sytrd_f64
+  if ((env && atoi(env) == 0) || n < 128) return n;
   return n <= RES_MAX ? 0 : (int)align_up((size_t)(n - RES_MAX), NB);
 }
 
@@ -1494,14 +1515,19 @@ int sytrd_f64(const TridiagPlan& p, char* base, SymvTimer* timer, bool resident,
     const int j0 = pn * NB;
     if (j0 == t_res && n - j0 >= 2) {
       // the rest of the reduction in one launch, the trailing block resident in the LDS of one XCD
-      double* X = reinterpret_cast<double*>(base + p.off_res + 4096);
+      double* X = reinterpret_cast<double*>(base + p.off_res + 8192);
       static const bool attr = [] {
         return hipFuncSetAttribute(reinterpret_cast<const void*>(sytrd_resident_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)RES_LDS) == hipSuccess;
       }();
       PTD_REQUIRE(attr, "sytrd_f64: cannot reserve the LDS of the resident tail");
+      static std::atomic<unsigned long long> calls{0};
+      const unsigned long long epoch = (calls.fetch_add(1) + 1) << 16;   // > any sequence number of an earlier call
       hipLaunchKernelGGL(sytrd_resident_kernel, dim3(8 * RES_WG), dim3(RES_T), RES_LDS, st, Aw, ld, n, j0, Vall, taus, d,
-                         e, rctl, X, X + 2 * RES_XS);
+                         e, rctl, X, X + 2 * RES_XS, epoch);
+      // test hook: PTD_SYTRD_RESIDENT=2 reports the tail as failed, so that the caller's repeat on the blocked path runs
+      if (getenv("PTD_SYTRD_RESIDENT") && atoi(getenv("PTD_SYTRD_RESIDENT")) == 2)
+        PTD_CHECK_HIP(hipMemsetAsync(&rctl->fail, 1, 1, st));
       break;
     }
     const int cols = std::min(NB, n - j0);

@@ -284,6 +284,31 @@ def test_eigh_mid_size_against_lapack(ops, method):
         assert (p - p_ref).norm().item() <= 1e-6 * math.sqrt(r)
 
 
+@pytest.mark.parametrize("n", [130, 500, 768, 1000, 1500])
+def test_resident_tail_of_the_reduction_matches_the_blocked_path(ops, monkeypatch, n):
+    """The last <= 768 columns of the tridiagonalisation run in one launch on one XCD (eigh_tridiag.hip,
+    sytrd_resident_kernel): the same spectrum as the blocked path and as LAPACK, for orders it takes whole (n <= 768),
+    with a ragged row distribution (n = 130, 500, 1000: not multiples of 32 / 64) and behind blocked panels (n > 768).
+    PTD_SYTRD_RESIDENT=2 reports the tail as failed after the launch: the caller must repeat the reduction on the
+    blocked path and return exactly what that path returns."""
+    monkeypatch.setenv("PTD_EIGH_METHOD", "tridiag")
+    y = _rand((2 * n + 3, n), 900 + n).double() * torch.logspace(0, -2, n, dtype=torch.float64)
+    a = y.T @ y / y.shape[0]
+    a = a + torch.eye(n, dtype=torch.float64) * (0.01 * torch.diag(a).mean())
+    w_ref = torch.linalg.eigvalsh(a)
+    scale = w_ref.abs().max().item()
+    got = {}
+    for mode in ("0", "1", "2"):
+        monkeypatch.setenv("PTD_SYTRD_RESIDENT", mode)
+        _, _, w = ops.tridiagonalize(a.to(DEV))
+        got[mode] = w.cpu()
+        assert (got[mode] - w_ref).abs().max().item() <= 1e-12 * scale, mode
+    assert torch.equal(got["2"], got["0"])
+    for mode in ("1", "2"):
+        monkeypatch.setenv("PTD_SYTRD_RESIDENT", mode)
+        _check_eigh(ops, a)
+
+
 # ---------------------------------------------------------------- dense products
 LAYOUTS = ["nn", "nt", "tn", "tt"]
 
