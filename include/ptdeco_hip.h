@@ -44,6 +44,12 @@ typedef enum {
 int ptd_version(void);
 const char* ptd_last_error(void);
 
+/* Hint: the caller is about to run `chains` independent eigendecompositions at once, each on its own stream
+ * (the reference has no counterpart: torch.linalg.eigh calls are serial, dwain.py:155-163).  With chains > 1 the
+ * solver avoids kernels that claim a whole XCD for milliseconds (the resident tail of the tridiagonalisation), which
+ * shorten one chain and stall the others.  Process-wide, default 1; returns the previous value. */
+int ptd_set_concurrent_chains(int chains);
+
 /* ---- covariance accumulation ------------------------------------------- */
 
 /* E[i][j] += scale * sum_t Y[t][i] * Y[t][j]  for i >= j  (LOWER triangle only;

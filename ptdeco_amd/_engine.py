@@ -512,11 +512,18 @@ def run_concurrently(jobs, device: torch.device, max_streams: Optional[int] = No
         except BaseException as exc:  # re-raised on the calling thread
             errors.append(exc)
 
+    from . import _hip
+
     threads = [threading.Thread(target=worker, args=(w,), name=f"ptdeco-eigh-{w}") for w in range(workers)]
-    for th in threads:
-        th.start()
-    for th in threads:
-        th.join()
+    # interleaved chains: no kernel may claim a whole XCD for itself (ptd_set_concurrent_chains)
+    before = _hip.load().ptd_set_concurrent_chains(workers)
+    try:
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+    finally:
+        _hip.load().ptd_set_concurrent_chains(before)
     for st in streams:
         main.wait_stream(st)
     for res in out:  # the results were allocated on a side stream and live on under the caller's

@@ -20,6 +20,7 @@ ABI_VERSION = 1
 SIGNATURES = {
     "ptd_version": (c_int, []),
     "ptd_last_error": (c_char_p, []),
+    "ptd_set_concurrent_chains": (c_int, [c_int]),
     "ptd_syrk_accumulate": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_int64, c_int,
                                     c_double, c_void_p]),
     "ptd_colsum_accumulate": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_int, c_double,

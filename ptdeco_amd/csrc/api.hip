@@ -28,6 +28,8 @@ int ptd_version(void) { return PTD_ABI_VERSION; }
 
 const char* ptd_last_error(void) { return g_err; }
 
+int ptd_set_concurrent_chains(int chains) { return concurrent_chains_exchange(chains < 1 ? 1 : chains); }
+
 int ptd_syrk_accumulate(const void* y, int64_t T, int64_t n, int64_t ldy, int y_dtype, void* E, int64_t ldE,
                         int E_dtype, double scale, void* stream) {
   PTD_REQUIRE(y && E, "ptd_syrk_accumulate: null pointer");

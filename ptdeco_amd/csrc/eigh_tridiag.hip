@@ -1462,9 +1462,14 @@ struct SymvTimer {
 
 // first column of the resident tail: the first panel boundary with a trailing order of at most RES_MAX
 // (n itself for orders the tail kernel does not take; PTD_SYTRD_RESIDENT=0 switches it off)
+std::atomic<int> g_concurrent_chains{1};
+
 int resident_start(int n) {
   const char* env = getenv("PTD_SYTRD_RESIDENT");   // 0: off; 2: test hook, see sytrd_f64
   if ((env && atoi(env) == 0) || n < 128) return n;
+  // several chains at once (ptd_set_concurrent_chains): the tail would hold XCC 0 for milliseconds while the other
+  // chains' launches queue behind it (2-block Llama stack, three chains: 1.50 s with it, 1.38 s without)
+  if (g_concurrent_chains.load(std::memory_order_relaxed) > 1) return n;
   return n <= RES_MAX ? 0 : (int)align_up((size_t)(n - RES_MAX), NB);
 }
 
@@ -1839,7 +1844,7 @@ int eigh_tridiag(const double* A, int64_t lda, int64_t n, int64_t k, double* eva
     // SYMV launches: every stride-th column carries events; the columns of one stride block have
     // nearly the same trailing order, so the block's time is stride x its sample
     double timed_ms = 0.0;
-    for (int64_t j = 0; j + 1 < std::min<int64_t>(n, timer.limit); ++j) {
+    for (int64_t j = 0; j < std::min<int64_t>(n - 1, timer.limit); ++j) {
       if (timer.sampled((int)j)) {
         float ms = 0.f;
         (void)hipEventElapsedTime(&ms, timer.start((int)j), timer.stop((int)j));
@@ -1862,6 +1867,8 @@ int eigh_tridiag(const double* A, int64_t lda, int64_t n, int64_t k, double* eva
 }
 
 size_t tridiag_workspace_bytes(int64_t n) { return tridiag_plan(n).total; }
+
+int concurrent_chains_exchange(int chains) { return g_concurrent_chains.exchange(chains); }
 
 // Diagnostic entry: tridiagonalise A and return (d, e, tau) and the eigenvalues of T.
 int tridiagonalize_f64(const double* A, int64_t lda, int64_t n, double* d_out, double* e_out, double* evals_out,

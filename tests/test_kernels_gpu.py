@@ -304,6 +304,16 @@ def test_resident_tail_of_the_reduction_matches_the_blocked_path(ops, monkeypatc
         got[mode] = w.cpu()
         assert (got[mode] - w_ref).abs().max().item() <= 1e-12 * scale, mode
     assert torch.equal(got["2"], got["0"])
+    # several chains at once (ptd_set_concurrent_chains, what _engine.run_concurrently announces): no kernel may hold
+    # an XCD for itself, so the blocked path runs to the end
+    from ptdeco_amd import _hip
+    monkeypatch.setenv("PTD_SYTRD_RESIDENT", "1")
+    before = _hip.load().ptd_set_concurrent_chains(3)
+    try:
+        assert before == 1
+        assert torch.equal(ops.tridiagonalize(a.to(DEV))[2].cpu(), got["0"])
+    finally:
+        assert _hip.load().ptd_set_concurrent_chains(before) == 3
     for mode in ("1", "2"):
         monkeypatch.setenv("PTD_SYTRD_RESIDENT", mode)
         _check_eigh(ops, a)

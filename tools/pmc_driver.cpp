@@ -12,7 +12,7 @@
 
 #include "ptdeco_hip.h"
 
-// mode "mfma": the f32 covariance SYRK, the f32 layer-output GEMM and the bf16 GEMM at 4096^3, for
+// mode "mfma": the f32 and bf16 covariance SYRK, the f32 layer-output GEMM and the bf16 GEMM at 4096^3, for
 //   rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-include-regex "syrk|gemm" -- tools/pmc_driver mfma
 static int run_mfma() {
   const int64_t n = 4096;
@@ -33,6 +33,7 @@ static int run_mfma() {
     int rc = ptd_syrk_accumulate(X, n, n, n, 0, E, n, 1, 1.0 / n, nullptr);
     rc |= ptd_gemm(X, n, 1, W, 1, n, Y, n, n, n, n, 0, 0, 1.0, nullptr, nullptr);      // y = x W^T, f32
     rc |= ptd_gemm(Xb, n, 1, Wb, 1, n, Yb, n, n, n, n, 2, 2, 1.0, nullptr, nullptr);    // bf16
+    rc |= ptd_syrk_accumulate(Xb, n, n, n, 2, E, n, 1, 1.0 / n, nullptr);                // bf16 covariance product
     if (rc) { fprintf(stderr, "mfma mode rc=%d: %s\n", rc, ptd_last_error()); return 1; }
   }
   // the bf16 decomposed forward at rank 256 (BASELINE configs[4]): h = x A^T (16384 x 256 x 4096), y = h B^T (16384 x 4096 x 256)

@@ -28,7 +28,8 @@ write = load("pmc_write")["WRITE_SIZE"]
 tcc = load("pmc_tcc")
 hit, miss = tcc["TCC_HIT_sum"], tcc["TCC_MISS_sum"]
 L = len(fetch)
-assert L == n - 1 == len(write) == len(hit) == len(miss), (L, len(write), len(hit))
+# one SYMV launch per column j = 0 .. L - 1; the last columns (trailing order <= 768) run in the resident tail kernel
+assert L == len(write) == len(hit) == len(miss) and L <= n - 1, (L, len(write), len(hit))
 rows = []
 for j in range(L):
     m = n - j - 1
@@ -46,7 +47,7 @@ tot_wr = sum(r[4] for r in rows)
 big = [r for r in rows if r[1] >= 2048]
 summary = {
     "kernel": "sytrd_symv2_kernel (trailing order >= 1024: lower triangle only) + sytrd_symv_kernel (smaller trailing orders)",
-    "n": n, "launches": L,
+    "n": n, "launches": L, "columns_without_a_launch": n - 1 - L,
     "command": "rocprofv3 --pmc <COUNTER> --kernel-include-regex sytrd_symv --kernel-trace --output-format csv -- tools/pmc_driver %d (separate passes: FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum)" % n,
     "correction": "read bytes = 2 x FETCH_SIZE KiB x 1024 (gfx950 tallies 128-B requests at 64 B); WRITE_SIZE exact",
     "algorithmic_bytes_per_launch": tot_alg / L,
