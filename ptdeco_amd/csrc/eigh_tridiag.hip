@@ -623,8 +623,7 @@ constexpr size_t RES_LDS = 150 * 1024;   // two vectors and scalars; sized so th
 constexpr long RES_SPIN = 2000000L;
 
 struct ResCtl {
-  unsigned long long fx[RES_WG];        // [0]: sequence number of the last published row (column of x)
-  unsigned long long fp[RES_WG];        // per workgroup: sequence number of its last published p entries
+  unsigned long long fp[RES_WG];        // per workgroup: sequence number of its last published entries
   unsigned reg;    unsigned pad1[31];   // registration (agent scope)
   int fail;        int pad2[31];        // 1 time-out, 2 XCC mismatch
   int xcc[32];
@@ -690,7 +689,7 @@ __global__ __launch_bounds__(RES_T) void sytrd_resident_kernel(const double* __r
                                                                double* __restrict__ Vall, double* __restrict__ taus,
                                                                double* __restrict__ d, double* __restrict__ e,
                                                                ResCtl* __restrict__ ctl, double* __restrict__ Xbuf,
-                                                               double* __restrict__ Pv, unsigned long long epoch) {
+                                                               unsigned long long epoch) {
   constexpr int NWG = RES_WG, MAXM = RES_MAX;
   constexpr int NW = RES_T / 64;                    // waves
   constexpr int RI = MAXM / NWG / NW;               // rows per wave
@@ -741,46 +740,39 @@ __global__ __launch_bounds__(RES_T) void sytrd_resident_kernel(const double* __r
       a[i][k] = (lr[i] < m && c < m) ? src[c] : 0.0;
     }
   }
-  // sequence numbers are unique over calls (epoch), so a number left in a cache by an earlier call can never pass
-  for (int jl = 0; jl + 1 < m; ++jl) {
-    const unsigned long long seq = epoch + (unsigned long long)jl + 1;
-    // (x alternates between two buffers: the next row may be published while a slower workgroup still reads this one)
-    double* X = Xbuf + (jl & 1) * RES_XS;
-    const int kmin = (jl + 1) >> 6;           // register columns below hold only retired columns
-    // ---- A: column jl below the diagonal is row jl to the right of it, and that row sits in ONE wave: the wave
-    // publishes it as soon as its own update is done -- nobody waits for the slowest of 32 workgroups here, and the
-    // hand-off overlaps the other workgroups' updates.  (The two triangles can differ in the last bit -- the update
-    // contracts one of its two products into an fma -- which is a perturbation of eps |A|, like choosing a triangle.)
-    if (slot == (jl & (NWG - 1)) && wid == ((jl / NWG) & (NW - 1))) {
-      const int io = jl / (NWG * NW);
+  // One all-to-all hand-off per column.  With v_j[j+1] = 1 the updated column j+1 is
+  //   A'[r][j+1] = A[r][j+1] - v[r] w[j+1] - w[r] = (A[r][j+1] - p[r]) - v[r] (p[j+1] - 2 hk),   hk = tau/2 p^T v,
+  // so a workgroup publishes, next to its entries of p = tau A v, the entries b[r] = A[r][j+1] - p[r] of its own rows,
+  // and whoever holds all of p, b and v forms p^T v, w AND the next column (its entry r = j+1 is the next diagonal
+  // element) without a second exchange.  Sequence numbers are unique over calls (epoch), so a number left in a cache
+  // by an earlier call can never pass; the vectors alternate between two buffers (a fast workgroup publishes column
+  // j + 1 while a slow one still reads column j).
+  double xv[CT];                                            // column jl below its diagonal (entries tid + 512 t), and
+  double dnext = 0.0;                                       // the diagonal entry in front of it
+  {
+    // column 0 is gathered as it lies: b = A[:, 0], p = 0
+    if (lane == 0)
 #pragma unroll
-      for (int k = 0; k < CK; ++k) {
-        double val = a[0][k];
-#pragma unroll
-        for (int i = 1; i < RI; ++i) val = (i == io) ? a[i][k] : val;
-        const int c = lane + 64 * k;
-        if (c > jl && c < m) X[c] = val;
-        if (c == jl) d[t0 + jl] = val;
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the row is in the L2 before its number
-      if (lane == 0) __hip_atomic_store(&ctl->fx[0], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-    for (long spin = 0;; ++spin) {
-      if (__hip_atomic_load(&ctl->fx[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= seq) break;
-      if (spin > RES_SPIN) {
-        __hip_atomic_store(&ctl->fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return;
-      }
-    }
-    // the vector entries this thread forms: columns tid, tid + 512, ..
-    double xv[CT], vv[CT];
+      for (int i = 0; i < RI; ++i)
+        if (lr[i] < m) Xbuf[RES_XS + lr[i]] = a[i][0];
+    res_publish(ctl->fp, slot, epoch);
+    if (!res_wait(ctl->fp, epoch, lane, ctl)) return;
 #pragma unroll
     for (int t = 0; t < CT; ++t) {
       const int c = tid + RES_T * t;
-      xv[t] = (c > jl && c < m) ? res_ld_f64(X + c) : 0.0;
+      xv[t] = (c >= 1 && c < m) ? res_ld_f64(Xbuf + RES_XS + c) : 0.0;
     }
+    dnext = res_ld_f64(Xbuf + RES_XS);
+  }
+  for (int jl = 0; jl + 1 < m; ++jl) {
+    const unsigned long long seq = epoch + (unsigned long long)jl + 1;
+    double* Pb = Xbuf + ((jl + 1) & 1) * 2 * RES_XS;        // this column's p entries, then its b entries
+    double* Bb = Pb + RES_XS;
+    const int kmin = (jl + 1) >> 6;                         // register columns below hold only retired columns
+    const int k1 = (jl + 1) >> 6, l1 = (jl + 1) & 63;       // where column jl + 1 sits in the registers
+    // ---- the reflector of column jl: the same arithmetic in every workgroup
+    double vv[CT];
     {
-      // the norm from the whole column, the same arithmetic in every workgroup
       double sq = 0.0;
 #pragma unroll
       for (int t = 0; t < CT; ++t) {
@@ -811,19 +803,14 @@ __global__ __launch_bounds__(RES_T) void sytrd_resident_kernel(const double* __r
 #pragma unroll
       for (int t = 0; t < CT; ++t) {
         const int c = tid + RES_T * t;
-        vv[t] = (c == jl + 1) ? 1.0 : xv[t] * scale;        // x is zero outside (jl, m)
+        vv[t] = (c == jl + 1) ? 1.0 : ((c > jl + 1) ? xv[t] * scale : 0.0);
         if (c < MAXM) vs[c] = vv[t];
         if (writer && c > jl && c < m) vrow[c] = vv[t];
       }
-      if (writer && tid == 0) { taus[t0 + jl] = tau; e[t0 + jl] = beta; }
+      if (writer && tid == 0) { taus[t0 + jl] = tau; e[t0 + jl] = beta; d[t0 + jl] = dnext; }
     }
     __syncthreads();
-    if (tau == 0.0) {                                       // H = I: nothing to apply (uniform over the grid),
-      res_publish(ctl->fp, slot, seq);                      // but every column keeps its all-to-all hand-off: the
-      if (!res_wait(ctl->fp, seq, lane, ctl)) return;       // x buffers are reused two columns later
-      continue;
-    }
-    // ---- B: p = tau A v for this workgroup's rows
+    // ---- p = tau A v and b = A[:, jl + 1] - p for this workgroup's rows
     double vreg[CK], vrow_[RI];
 #pragma unroll
     for (int k = 0; k < CK; ++k) vreg[k] = vs[lane + 64 * k];
@@ -841,19 +828,28 @@ __global__ __launch_bounds__(RES_T) void sytrd_resident_kernel(const double* __r
 #pragma unroll
       for (int i = 0; i < RI; ++i) {
         const double pi = tau * res_wave_sum(acc[i]);
-        if (lane == 0 && lr[i] > jl && lr[i] < m) Pv[lr[i]] = pi;
+        double aj1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < CK; ++k) aj1 = (k == k1) ? a[i][k] : aj1;
+        if (lane == l1 && lr[i] > jl && lr[i] < m) {
+          Pb[lr[i]] = pi;
+          Bb[lr[i]] = aj1 - pi;
+        }
       }
     }
     res_publish(ctl->fp, slot, seq);
     if (!res_wait(ctl->fp, seq, lane, ctl)) return;
-    double pv_[CT];
+    double pv_[CT], bv_[CT];
     {
       double dp = 0.0;
 #pragma unroll
       for (int t = 0; t < CT; ++t) {
         const int c = tid + RES_T * t;
-        pv_[t] = (c > jl && c < m) ? res_ld_f64(Pv + c) : 0.0;
+        const bool ok = c > jl && c < m;
+        pv_[t] = ok ? res_ld_f64(Pb + c) : 0.0;
+        bv_[t] = ok ? res_ld_f64(Bb + c) : 0.0;
         dp += pv_[t] * vv[t];
+        if (c == jl + 1) scr[9] = pv_[t];
       }
       dp = res_wave_sum(dp);                                // p^T v from the whole vectors
       if (lane == 0) scr[16 + wid] = dp;
@@ -863,31 +859,33 @@ __global__ __launch_bounds__(RES_T) void sytrd_resident_kernel(const double* __r
 #pragma unroll
     for (int w = 0; w < NW; ++w) dot += scr[16 + w];
     const double hk = 0.5 * tau * dot;
+    const double g = scr[9] - 2.0 * hk;                     // p[jl + 1] - 2 hk
 #pragma unroll
     for (int t = 0; t < CT; ++t) {
       const int c = tid + RES_T * t;
       if (c < MAXM) wv[c] = pv_[t] - hk * vv[t];            // zero outside (jl, m): p and v are
+      const double xn = bv_[t] - vv[t] * g;                 // the updated column jl + 1, rows jl + 1 ..
+      if (c == jl + 1) scr[10] = xn;                        // .. whose first entry is the next diagonal element
+      xv[t] = (c >= jl + 2) ? xn : 0.0;
     }
     __syncthreads();
-    // ---- C: A -= v w^T + w v^T on this workgroup's rows
+    dnext = scr[10];
+    // ---- A -= v w^T + w v^T on this workgroup's rows
+    if (tau != 0.0) {
 #pragma unroll
-    for (int i = 0; i < RI; ++i) {
-      const double wr_ = wv[min(lr[i], MAXM - 1)];
-      const bool live = lr[i] > jl && lr[i] < m;
+      for (int i = 0; i < RI; ++i) {
+        const double wr_ = wv[min(lr[i], MAXM - 1)];
+        const bool live = lr[i] > jl && lr[i] < m;
 #pragma unroll
-      for (int k = 0; k < CK; ++k) {
-        const double wk = wv[lane + 64 * k];
-        if (live && k >= kmin) a[i][k] -= vrow_[i] * wk + wr_ * vreg[k];
+        for (int k = 0; k < CK; ++k) {
+          const double wk = wv[lane + 64 * k];
+          if (live && k >= kmin) a[i][k] -= vrow_[i] * wk + wr_ * vreg[k];
+        }
       }
     }
-    // (vs / wv / scr are rewritten only behind the barrier inside the next publication)
+    // (vs / wv / scr are rewritten only behind the barriers of the next column)
   }
-  // ---- the last diagonal entry
-#pragma unroll
-  for (int i = 0; i < RI; ++i)
-#pragma unroll
-    for (int k = 0; k < CK; ++k)
-      if (lr[i] == m - 1 && lane + 64 * k == m - 1) d[t0 + m - 1] = a[i][k];
+  if (slot == 0 && tid == 0) d[t0 + m - 1] = dnext;
 }
 
 // very last diagonal entry: d[n-1] = base[n-1] - delta (delta = 0 if the column opens a panel)
@@ -1439,7 +1437,7 @@ TridiagPlan tridiag_plan(int64_t n) {
   p.off_colpart = take((size_t)ceil_div(n, TR) * p.ldp * 8);
   p.off_gpart = take((size_t)p.npanels * ceil_div(n, GCH) * NB * NB * 8);
   p.off_tall = take((size_t)p.npanels * NB * NB * 8);
-  p.off_res = take(8192 + 3 * (size_t)RES_XS * 8);   // resident tail: control block, three exchange vectors
+  p.off_res = take(8192 + 4 * (size_t)RES_XS * 8);   // resident tail: control block, two pairs of exchange vectors
   p.two = twostage_supported(n);
   if (p.two) {
     p.ts = twostage_plan(n, p.ld);
@@ -1528,8 +1526,9 @@ int sytrd_f64(const TridiagPlan& p, char* base, SymvTimer* timer, bool resident,
       PTD_REQUIRE(attr, "sytrd_f64: cannot reserve the LDS of the resident tail");
       static std::atomic<unsigned long long> calls{0};
       const unsigned long long epoch = (calls.fetch_add(1) + 1) << 16;   // > any sequence number of an earlier call
+      static_assert(RES_MAX < (1 << 16), "sequence numbers of one call: epoch .. epoch + m");
       hipLaunchKernelGGL(sytrd_resident_kernel, dim3(8 * RES_WG), dim3(RES_T), RES_LDS, st, Aw, ld, n, j0, Vall, taus, d,
-                         e, rctl, X, X + 2 * RES_XS, epoch);
+                         e, rctl, X, epoch);
       // test hook: PTD_SYTRD_RESIDENT=2 reports the tail as failed, so that the caller's repeat on the blocked path runs
       if (getenv("PTD_SYTRD_RESIDENT") && atoi(getenv("PTD_SYTRD_RESIDENT")) == 2)
         PTD_CHECK_HIP(hipMemsetAsync(&rctl->fail, 1, 1, st));
