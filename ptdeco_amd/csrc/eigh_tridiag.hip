@@ -617,13 +617,15 @@ __global__ void sytrd_wfix_kernel(int n, int r0, int ilast, int jlast, const dou
 // 11.5.  A tail of 1024 columns (64 doubles a thread, 244 VGPRs) was no faster: 64.5 ms.
 constexpr int RES_MAX = 768;                             // one XCD: 32 workgroups
 constexpr int RES_WG = 32;
+constexpr int RESG_MAX = 2048;                           // the whole chip: 256 workgroups, hand-offs through memory
+constexpr int RESG_WG = 256;
 constexpr int RES_T = 512;
-constexpr int RES_XS = RES_MAX + 64;                     // one exchange vector
+constexpr int RES_XS = RESG_MAX + 64;                    // one exchange vector
 constexpr size_t RES_LDS = 150 * 1024;   // two vectors and scalars; sized so that a CU takes exactly one workgroup
 constexpr long RES_SPIN = 2000000L;
 
 struct ResCtl {
-  unsigned long long fp[RES_WG];        // per workgroup: sequence number of its last published entries
+  unsigned long long fp[RESG_WG];       // per workgroup: sequence number of its last published entries
   unsigned reg;    unsigned pad1[31];   // registration (agent scope)
   int fail;        int pad2[31];        // 1 time-out, 2 XCC mismatch
   int xcc[32];
@@ -641,20 +643,34 @@ __device__ __forceinline__ double res_ld_f64(const double* p) {
 // number; a consumer wave watches the 32 numbers (lane s: workgroup s) and then reads the vector.  Against a counter
 // barrier followed by the read this saves one L2 round trip per exchange, and nothing serialises on one address.
 // false after a time-out.
+template <int NWG>
 __device__ __forceinline__ bool res_wait(const unsigned long long* F, unsigned long long seq, int lane, ResCtl* c) {
   for (long spin = 0;; ++spin) {
-    const unsigned long long f = __hip_atomic_load(F + (lane & (RES_WG - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (__all(f >= seq)) return true;
+    bool ok = true;
+#pragma unroll
+    for (int q = 0; q < (NWG + 63) / 64; ++q)
+      ok = ok && __hip_atomic_load(F + ((lane + 64 * q) & (NWG - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= seq;
+    if (__all(ok)) return true;
     if (spin > RES_SPIN) {
       __hip_atomic_store(&c->fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       return false;
     }
   }
 }
+// GLOBAL: the consumers sit on other XCDs -- entries and number are written through to memory (sc1)
+template <bool GLOBAL>
+__device__ __forceinline__ void res_st_f64(double* p, double v) {
+  if (GLOBAL) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+template <bool GLOBAL>
 __device__ __forceinline__ void res_publish(unsigned long long* F, int slot, unsigned long long seq) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave's entries are in the L2 ...
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave's entries have arrived ...
   __syncthreads();
-  if (threadIdx.x == 0) __hip_atomic_store(F + slot, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // ... before the number
+  if (threadIdx.x == 0) {                            // ... before the number
+    if (GLOBAL) __hip_atomic_store(F + slot, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else __hip_atomic_store(F + slot, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
 }
 
 // sum over the 64 lanes of a wave without the LDS crossbar: DPP adds inside each row of 16 lanes, then the four row
@@ -685,27 +701,30 @@ __device__ __forceinline__ double res_wave_sum(double v) {
 // (The same kernel on all 256 CUs -- 2048 resident columns, hand-offs written through to memory with sc1 stores -- is
 // correct and slower than the blocked path: ~14 us per column, n = 2048 31.3 vs 22.2 ms; a hand-off that leaves the
 // XCD costs 5-6 us.)
-__global__ __launch_bounds__(RES_T) void sytrd_resident_kernel(const double* __restrict__ Aw, int64_t ld, int n, int t0,
+//   <32, 768, false>    the workgroups of XCC 0 (blockIdx.x % 8 == 0 of a grid of 256), hand-offs through its L2
+//   <256, 2048, true>   every CU of the chip, hand-offs written through to memory; stops after `ncols` columns and
+//                       leaves the trailing block in Aw for the kernel above
+template <int NWG, int MAXM, bool GLOBAL>
+__global__ __launch_bounds__(RES_T) void sytrd_resident_kernel(double* __restrict__ Aw, int64_t ld, int n, int t0, int ncols,
                                                                double* __restrict__ Vall, double* __restrict__ taus,
                                                                double* __restrict__ d, double* __restrict__ e,
                                                                ResCtl* __restrict__ ctl, double* __restrict__ Xbuf,
                                                                unsigned long long epoch) {
-  constexpr int NWG = RES_WG, MAXM = RES_MAX;
   constexpr int NW = RES_T / 64;                    // waves
   constexpr int RI = MAXM / NWG / NW;               // rows per wave
   constexpr int CK = MAXM / 64;                     // columns per lane and row
   constexpr int CT = MAXM / RES_T + (MAXM % RES_T != 0);   // vector entries formed per thread
   static_assert(RI >= 1 && RI * NW * NWG == MAXM, "rows must divide evenly");
   extern __shared__ __attribute__((aligned(16))) char res_smem[];
-  if ((blockIdx.x & 7) != 0) return;
+  if (!GLOBAL && (blockIdx.x & 7) != 0) return;
   double* vs = reinterpret_cast<double*>(res_smem);
   double* wv = vs + MAXM;
   double* scr = wv + MAXM;                    // [0, 8) per-wave sums of x^2, [8] alpha, [16, 24) per-wave sums of p v
   __shared__ int flag;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int slot = blockIdx.x >> 3;
+  const int slot = GLOBAL ? blockIdx.x : blockIdx.x >> 3;
   const int m = n - t0;
-  {
+  if (!GLOBAL) {
     // ---- the 32 workgroups must sit on one XCC
     const int my_xcc = (int)__builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11));   // HW_REG_XCC_ID[3:0]
     if (tid == 0) {
@@ -754,9 +773,9 @@ __global__ __launch_bounds__(RES_T) void sytrd_resident_kernel(const double* __r
     if (lane == 0)
 #pragma unroll
       for (int i = 0; i < RI; ++i)
-        if (lr[i] < m) Xbuf[RES_XS + lr[i]] = a[i][0];
-    res_publish(ctl->fp, slot, epoch);
-    if (!res_wait(ctl->fp, epoch, lane, ctl)) return;
+        if (lr[i] < m) res_st_f64<GLOBAL>(Xbuf + RES_XS + lr[i], a[i][0]);
+    res_publish<GLOBAL>(ctl->fp, slot, epoch);
+    if (!res_wait<NWG>(ctl->fp, epoch, lane, ctl)) return;
 #pragma unroll
     for (int t = 0; t < CT; ++t) {
       const int c = tid + RES_T * t;
@@ -764,7 +783,7 @@ __global__ __launch_bounds__(RES_T) void sytrd_resident_kernel(const double* __r
     }
     dnext = res_ld_f64(Xbuf + RES_XS);
   }
-  for (int jl = 0; jl + 1 < m; ++jl) {
+  for (int jl = 0; jl < ncols; ++jl) {
     const unsigned long long seq = epoch + (unsigned long long)jl + 1;
     double* Pb = Xbuf + ((jl + 1) & 1) * 2 * RES_XS;        // this column's p entries, then its b entries
     double* Bb = Pb + RES_XS;
@@ -832,13 +851,18 @@ __global__ __launch_bounds__(RES_T) void sytrd_resident_kernel(const double* __r
 #pragma unroll
         for (int k = 0; k < CK; ++k) aj1 = (k == k1) ? a[i][k] : aj1;
         if (lane == l1 && lr[i] > jl && lr[i] < m) {
-          Pb[lr[i]] = pi;
-          Bb[lr[i]] = aj1 - pi;
+          res_st_f64<GLOBAL>(Pb + lr[i], pi);
+          res_st_f64<GLOBAL>(Bb + lr[i], aj1 - pi);
         }
       }
     }
-    res_publish(ctl->fp, slot, seq);
-    if (!res_wait(ctl->fp, seq, lane, ctl)) return;
+    res_publish<GLOBAL>(ctl->fp, slot, seq);
+    if (GLOBAL) {
+      // one wave watches the 256 numbers (eight waves of 256 workgroups polling four lines were a storm of their own)
+      if (wid == 0) { const bool ok = res_wait<NWG>(ctl->fp, seq, lane, ctl); if (lane == 0) flag = ok; }
+      __syncthreads();
+      if (!flag) return;
+    } else if (!res_wait<NWG>(ctl->fp, seq, lane, ctl)) return;
     double pv_[CT], bv_[CT];
     {
       double dp = 0.0;
@@ -885,7 +909,18 @@ __global__ __launch_bounds__(RES_T) void sytrd_resident_kernel(const double* __r
     }
     // (vs / wv / scr are rewritten only behind the barriers of the next column)
   }
-  if (slot == 0 && tid == 0) d[t0 + m - 1] = dnext;
+  if (ncols == m - 1) {
+    if (slot == 0 && tid == 0) d[t0 + m - 1] = dnext;
+  } else {
+    // the trailing block goes back to memory for the next kernel (both triangles, as it lies in the registers)
+#pragma unroll
+    for (int i = 0; i < RI; ++i)
+#pragma unroll
+      for (int k = 0; k < CK; ++k) {
+        const int c = lane + 64 * k;
+        if (lr[i] >= ncols && lr[i] < m && c >= ncols && c < m) Aw[(int64_t)(t0 + lr[i]) * ld + t0 + c] = a[i][k];
+      }
+  }
 }
 
 // very last diagonal entry: d[n-1] = base[n-1] - delta (delta = 0 if the column opens a panel)
@@ -1462,13 +1497,20 @@ struct SymvTimer {
 // (n itself for orders the tail kernel does not take; PTD_SYTRD_RESIDENT=0 switches it off)
 std::atomic<int> g_concurrent_chains{1};
 
+// PTD_SYTRD_RESIDENT: 0 off; 1 the one-XCD tail only; 2 test hook, see sytrd_f64; 3 (default) whole-chip kernel from a
+// trailing order of 2048, then the one-XCD tail
+int resident_mode() {
+  const char* env = getenv("PTD_SYTRD_RESIDENT");
+  return env ? atoi(env) : 3;
+}
 int resident_start(int n) {
-  const char* env = getenv("PTD_SYTRD_RESIDENT");   // 0: off; 2: test hook, see sytrd_f64
-  if ((env && atoi(env) == 0) || n < 128) return n;
+  const int mode = resident_mode();
+  if (mode == 0 || n < 128) return n;
   // several chains at once (ptd_set_concurrent_chains): the tail would hold XCC 0 for milliseconds while the other
   // chains' launches queue behind it (2-block Llama stack, three chains: 1.50 s with it, 1.38 s without)
   if (g_concurrent_chains.load(std::memory_order_relaxed) > 1) return n;
-  return n <= RES_MAX ? 0 : (int)align_up((size_t)(n - RES_MAX), NB);
+  const int cap = (mode == 3 && n > RES_MAX) ? RESG_MAX : RES_MAX;
+  return n <= cap ? 0 : (int)align_up((size_t)(n - cap), NB);
 }
 
 int* resident_status(const TridiagPlan& p, char* base) { return &reinterpret_cast<ResCtl*>(base + p.off_res)->fail; }
@@ -1520,17 +1562,27 @@ int sytrd_f64(const TridiagPlan& p, char* base, SymvTimer* timer, bool resident,
       // the rest of the reduction in one launch, the trailing block resident in the LDS of one XCD
       double* X = reinterpret_cast<double*>(base + p.off_res + 8192);
       static const bool attr = [] {
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(sytrd_resident_kernel),
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(sytrd_resident_kernel<RES_WG, RES_MAX, false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)RES_LDS) == hipSuccess &&
+               hipFuncSetAttribute(reinterpret_cast<const void*>(sytrd_resident_kernel<RESG_WG, RESG_MAX, true>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)RES_LDS) == hipSuccess;
       }();
       PTD_REQUIRE(attr, "sytrd_f64: cannot reserve the LDS of the resident tail");
       static std::atomic<unsigned long long> calls{0};
-      const unsigned long long epoch = (calls.fetch_add(1) + 1) << 16;   // > any sequence number of an earlier call
-      static_assert(RES_MAX < (1 << 16), "sequence numbers of one call: epoch .. epoch + m");
-      hipLaunchKernelGGL(sytrd_resident_kernel, dim3(8 * RES_WG), dim3(RES_T), RES_LDS, st, Aw, ld, n, j0, Vall, taus, d,
-                         e, rctl, X, epoch);
+      static_assert(RESG_MAX < (1 << 16), "sequence numbers of one launch: epoch .. epoch + m");
+      int t1 = j0;
+      if (n - j0 > RES_MAX) {
+        // every CU first: down to a trailing order of 768
+        const unsigned long long epoch = (calls.fetch_add(1) + 1) << 16;   // > any sequence number of an earlier launch
+        t1 = n - RES_MAX;
+        hipLaunchKernelGGL((sytrd_resident_kernel<RESG_WG, RESG_MAX, true>), dim3(RESG_WG), dim3(RES_T), RES_LDS, st, Aw, ld,
+                           n, j0, t1 - j0, Vall, taus, d, e, rctl, X, epoch);
+      }
+      const unsigned long long epoch = (calls.fetch_add(1) + 1) << 16;
+      hipLaunchKernelGGL((sytrd_resident_kernel<RES_WG, RES_MAX, false>), dim3(8 * RES_WG), dim3(RES_T), RES_LDS, st, Aw, ld,
+                         n, t1, n - t1 - 1, Vall, taus, d, e, rctl, X, epoch);
       // test hook: PTD_SYTRD_RESIDENT=2 reports the tail as failed, so that the caller's repeat on the blocked path runs
-      if (getenv("PTD_SYTRD_RESIDENT") && atoi(getenv("PTD_SYTRD_RESIDENT")) == 2)
+      if (resident_mode() == 2)
         PTD_CHECK_HIP(hipMemsetAsync(&rctl->fail, 1, 1, st));
       break;
     }
