@@ -404,11 +404,11 @@ def main():
                     "solver_frac": all_bytes / (red_ms * 1e-3) / PEAK_HBM,
                     "solver_note": "solver_frac = the algorithmic bytes of ALL columns (8/3 n^3) over the WHOLE reduction "
                                    "time (%.1f ms: SYMV launches + per-column kernels + rank-2k updates + the resident "
-                                   "tail + launch gaps); the full ptd_eigh call takes %.1f ms" % (red_ms, p["total_ms"]),
+                                   "kernels + launch gaps); the full ptd_eigh call takes %.1f ms" % (red_ms, p["total_ms"]),
                     "kernel": "sytrd_symv2_kernel / sytrd_symv_kernel (Householder tridiagonalisation, one SYMV launch "
-                              "per column down to a trailing order of 768; symmetric lower-triangle tiles for trailing "
-                              "orders >= 1024; the last 768 columns run in one launch, resident in the registers of one "
-                              "XCD, and read nothing from HBM)",
+                              "per column down to a trailing order of 2048, symmetric lower-triangle tiles; the last "
+                              "2048 columns run in two launches, resident in registers -- every CU down to 768 columns, "
+                              "one XCD for the rest -- and read nothing from HBM)",
                     "n": n, "launches": cnt, "avg_launch_us": ms / max(cnt, 1) * 1e3,
                     "algorithmic_bytes_per_launch": byts / max(cnt, 1),
                     "note": "algorithmic bytes = 8 (n-j-1)(n-j-2) per column j (rows j+1.., columns j+2.. of the "
@@ -418,7 +418,7 @@ def main():
                 kl["sytrd_symv_kernels"] = {"launches": cnt, "avg_us": ms / max(cnt, 1) * 1e3, "total_ms": ms,
                                            "gbps": byts / (ms * 1e-3) / 1e9}
                 kl["sytrd_other_per_column"] = {"total_ms": p["ms"][1],
-                                                "note": "alpha kernels + rank-2k updates + resident tail + launch gaps"}
+                                                "note": "alpha kernels + rank-2k updates + resident kernels + launch gaps"}
                 kl["eigvals_invit_backtransform"] = {"total_ms": p["ms"][3]}
             elif p["method"] == 0:
                 names = ("jac_gram_kernel", "jac_inner_kernel", "jac_update_kernel")

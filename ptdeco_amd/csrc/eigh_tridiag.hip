@@ -600,21 +600,21 @@ __global__ void sytrd_wfix_kernel(int n, int r0, int ilast, int jlast, const dou
   if (r < n) Wp[(int64_t)ilast * ldv + r] = wraw[r] + a2s * Vp[(int64_t)ilast * ldv + r];
 }
 
-// ------------------------------------------------------------------------------------- resident tail
-// The last RES_MAX columns of the reduction in ONE launch.  From a trailing order of 768 the matrix (4.7 MB, both
-// triangles) fits the registers of the 32 CUs of one XCD, and what a column costs is no longer its bytes but its two
-// global dependencies (v needs the whole column; w = p - tau/2 (p^T v) v needs the whole product) -- two dependent
-// launches of ~5 us each on the blocked path, whatever their size.  Workgroups of one XCD share an L2: a plain store
-// of one CU (the L1 is write-through) is seen by a device-scope (sc1) load of another as soon as it is acknowledged,
-// without the write-back / invalidate of an agent-scope release / acquire pair (tools/probes/xcd_barrier_probe.hip: a
-// barrier through that L2 1.2 us, with fences 5.8 us).  So: 256 workgroups of 150 KB LDS (one per CU), the 32 with
-// blockIdx.x % 8 == 0 -- XCC 0, checked against the hardware id -- keep rows slot + 32 q of the trailing block and run
-// the unblocked reduction (dsytd2) with two all-to-all hand-offs per column:
-//   x = A[j+1:, j]  -> every workgroup forms the norm, v, tau, beta (identical arithmetic);
-//   p = tau A v     -> every workgroup forms p^T v and w; rank-2 update of its rows.
+// ------------------------------------------------------------------------------------- resident kernels
+// The last columns of the reduction with the trailing block resident in registers: what a column costs there is no
+// longer its bytes but its global dependencies -- two dependent launches of ~5 us each on the blocked path, whatever
+// their size.  The unblocked reduction (dsytd2) needs ONE all-to-all hand-off per column (see the loop), and what a
+// hand-off costs depends on where it happens:
+//   * workgroups of one XCD share an L2, the vector L1 is write-through: a plain store of one CU is seen by a
+//     device-scope (sc1) load of another as soon as it is acknowledged, without the write-back / invalidate of an
+//     agent-scope release / acquire pair (tools/probes/xcd_barrier_probe.hip: a barrier through that L2 1.2 us, with
+//     fences 5.8 us).  <32, 768, false>: 256 workgroups of 150 KB LDS (one per CU), the 32 with blockIdx.x % 8 == 0 --
+//     XCC 0, checked against the hardware id -- take the last 768 columns: 4.6 us per column against 11.5.
+//   * across XCDs entries and sequence numbers are written through to memory (sc1 stores): a hand-off costs 5.3 us.
+//     <256, 2048, true>: every CU, from a trailing order of 2048 down to 768 (then the block goes back to memory for
+//     the kernel above): 9.0 us per column against ~16.4 blocked.
 // Every spin is bounded; a time-out or an XCC mismatch sets the status word and the host repeats the reduction on the
-// blocked path.  Measured (n = 4096, k = 1024): 68.2 -> 64.1 ms; n = 768: 9.0 -> 5.3 ms, 4.8 us per column against
-// 11.5.  A tail of 1024 columns (64 doubles a thread, 244 VGPRs) was no faster: 64.5 ms.
+// blocked path.  ptd_eigh_topk n = 4096, k = 1024: 68.2 -> 59.5 ms; n = 768: 9.0 -> 4.7 ms.
 constexpr int RES_MAX = 768;                             // one XCD: 32 workgroups
 constexpr int RES_WG = 32;
 constexpr int RESG_MAX = 2048;                           // the whole chip: 256 workgroups, hand-offs through memory
@@ -782,6 +782,17 @@ __global__ __launch_bounds__(RES_T) void sytrd_resident_kernel(double* __restric
       xv[t] = (c >= 1 && c < m) ? res_ld_f64(Xbuf + RES_XS + c) : 0.0;
     }
     dnext = res_ld_f64(Xbuf + RES_XS);
+    // per-wave sums of x^2 (rows 2 ..) and alpha = x[1] of column 0; later columns get theirs where x is formed
+    double sq = 0.0;
+#pragma unroll
+    for (int t = 0; t < CT; ++t) {
+      const int c = tid + RES_T * t;
+      if (c >= 2) sq += xv[t] * xv[t];
+      if (c == 1) scr[8] = xv[t];
+    }
+    sq = res_wave_sum(sq);
+    if (lane == 0) scr[wid] = sq;
+    __syncthreads();
   }
   for (int jl = 0; jl < ncols; ++jl) {
     const unsigned long long seq = epoch + (unsigned long long)jl + 1;
@@ -791,19 +802,7 @@ __global__ __launch_bounds__(RES_T) void sytrd_resident_kernel(double* __restric
     const int k1 = (jl + 1) >> 6, l1 = (jl + 1) & 63;       // where column jl + 1 sits in the registers
     // ---- the reflector of column jl: the same arithmetic in every workgroup
     double vv[CT];
-    {
-      double sq = 0.0;
-#pragma unroll
-      for (int t = 0; t < CT; ++t) {
-        const int c = tid + RES_T * t;
-        if (c >= jl + 2) sq += xv[t] * xv[t];
-        if (c == jl + 1) scr[8] = xv[t];
-      }
-      sq = res_wave_sum(sq);
-      if (lane == 0) scr[wid] = sq;
-    }
-    __syncthreads();
-    double xn2 = 0.0;
+    double xn2 = 0.0;                                       // (scr[0 .. 8] were written behind the last barrier)
 #pragma unroll
     for (int w = 0; w < NW; ++w) xn2 += scr[w];
     const double alpha = scr[8];
@@ -891,6 +890,18 @@ __global__ __launch_bounds__(RES_T) void sytrd_resident_kernel(double* __restric
       const double xn = bv_[t] - vv[t] * g;                 // the updated column jl + 1, rows jl + 1 ..
       if (c == jl + 1) scr[10] = xn;                        // .. whose first entry is the next diagonal element
       xv[t] = (c >= jl + 2) ? xn : 0.0;
+    }
+    {
+      // the next reflector's sums travel through the same barrier: alpha = x[jl + 2], x^2 over the rows below
+      double sq = 0.0;
+#pragma unroll
+      for (int t = 0; t < CT; ++t) {
+        const int c = tid + RES_T * t;
+        if (c >= jl + 3) sq += xv[t] * xv[t];
+        if (c == jl + 2) scr[8] = xv[t];
+      }
+      sq = res_wave_sum(sq);
+      if (lane == 0) scr[wid] = sq;
     }
     __syncthreads();
     dnext = scr[10];
