@@ -55,9 +55,10 @@ for name, n_in, n_out, count in (("q_o", 4096, 4096, 64), ("k_v", 4096, 1024, 64
         p = prof[0]
         line["eigh"] = {"n": p["n"], "k": p["k"], "method": "tridiagonal" if p["method"] == 1 else "jacobi",
                         "ms_in_profiled_pass": p["total_ms"]}
-        if p["method"] == 1:
+        if p["method"] == 1 and p["ms"][0] > 0.0:   # (orders up to 2048 run in the resident kernels: no SYMV launch)
             line["eigh"]["symv_gbps"] = p["work"][0] / (p["ms"][0] * 1e-3) / 1e9
             line["eigh"]["symv_ms"] = p["ms"][0]
+            line["eigh"]["symv_launches"] = p["launches"][0]
     else:
         line["eigh"] = {"route": "factored: W Ex W^T through an n_in-sized problem (ptd_eigh_factored)"}
     out[name] = line

@@ -18,6 +18,23 @@ torch.set_num_threads(cores)
 shapes = [s for s in sys.argv[1:] if not s.startswith("-")] or ["q_o", "k_v", "gate_up", "down"]
 
 
+def _heartbeat():
+    # one layer takes up to ~7 minutes: a line a minute on stderr shows the run is alive (a GPU box kills a command
+    # that writes nothing for 7 minutes)
+    import threading
+    t0 = time.time()
+
+    def beat():
+        while True:
+            time.sleep(60)
+            print(f"[c4_shapes_cpu] running, {time.time() - t0:.0f} s", file=sys.stderr, flush=True)
+
+    threading.Thread(target=beat, daemon=True).start()
+
+
+_heartbeat()
+
+
 class One(torch.nn.Module):
     def __init__(self, n_in, n_out):
         super().__init__()

@@ -19,6 +19,7 @@ o = [f"# profiles -- round {int(rnd)} (one MI355X, ROCm 7.2, gpurun box)\n\n", "
      f"* `c4_shapes_f32_r{rnd}.json` -- `python tools/c4_shapes.py`: dwain on one layer of each Llama-3-8B shape (BASELINE configs[3]), 224-layer figure extrapolated\n",
      f"* `c4_shapes_bf16_r{rnd}.json`, `c4_stack_2blocks_r{rnd}.json` -- the same in bf16; `python tools/c4_stack.py 2 [bf16]` end to end on a 2-block full-width stack\n",
      f"* `c3_vit_falor_r{rnd}.json` -- `python tools/c3_vit.py`: falor on a ViT-B/16-shaped model (BASELINE configs[2])\n",
+     f"* `c3_vit_falor_phases_r{rnd}.json` (if present) -- the same run with `PTD_PHASES=1`: device-time split A accumulate / B eigh / C factors / D metrics. The run is the user model's own forward passes (D: 2 x 2 x 9 whole-model forwards per layer, A: 4): the eigendecompositions are about a second of its sixteen\n",
      f"* `pmc_symv_r{rnd}.json` / `.csv` -- `tools/pmc_summary.py` over separate `rocprofv3 --pmc` passes of `tools/pmc_driver 4096` (per-launch HBM traffic of the SYMV kernels)\n",
      f"* `gpu_tests_r{rnd}.log` -- `python -m pytest tests -q -m gpu` on the same box\n",
      "* `tools/refresh_profiles.sh` reruns the first four on a GPU box\n\n", "## Headline\n\n"]

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Regenerates the measurements under profiles/ on a GPU box:  bash tools/refresh_profiles.sh <round, e.g. 02> [part]
-# part: all (default) | main (tests + bench + kernel stats) | c4 | pmc.  Outputs land in gpurun_out/ and are
+# part: all (default) | main (tests + bench + kernel stats) | c4 (= c4gpu + c4cpu) | pmc.  Outputs land in gpurun_out/ and are
 # condensed / copied into profiles/ afterwards in the build container (tools/pmc_summary.py, pmc_mfma_summary.py,
 # make_profiles_readme.py).
 set -o pipefail
@@ -12,12 +12,15 @@ if [ "$PART" = all ] || [ "$PART" = main ]; then
   cut -c1-200 gpurun_out/bench_r$R.json
   (cd /tmp && export TMPDIR=/tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_r$R -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-extras > $GRAFT_REPO_ROOT/gpurun_out/prof_r$R.log 2>&1); echo "rocprof rc=$?"
 fi
-if [ "$PART" = all ] || [ "$PART" = c4 ]; then
+if [ "$PART" = all ] || [ "$PART" = c4 ] || [ "$PART" = c4gpu ]; then
   timeout -k 10 300 python tools/c4_shapes.py > gpurun_out/c4_f32_r$R.json 2> gpurun_out/c4_f32.err; echo "c4 f32 rc=$?"
   timeout -k 10 300 python tools/c4_shapes.py bf16 > gpurun_out/c4_bf16_r$R.json 2> gpurun_out/c4_bf16.err; echo "c4 bf16 rc=$?"
   timeout -k 10 300 python tools/c4_stack.py 2 > gpurun_out/c4_stack_f32_r$R.json 2> gpurun_out/c4_stack_f32.err; echo "c4 stack f32 rc=$?"
   timeout -k 10 300 python tools/c4_stack.py 2 bf16 > gpurun_out/c4_stack_bf16_r$R.json 2> gpurun_out/c4_stack_bf16.err; echo "c4 stack bf16 rc=$?"
   timeout -k 10 300 python tools/c3_vit.py > gpurun_out/c3_vit_r$R.json 2> gpurun_out/c3_vit.err; echo "c3 rc=$?"
+fi
+if [ "$PART" = all ] || [ "$PART" = c4 ] || [ "$PART" = c4cpu ]; then
+  # (the torch-CPU oracle on the box's host cores: ~8 minutes; the tool writes a line a minute to gpurun_out/c4_cpu.err)
   timeout -k 10 900 python tools/c4_shapes_cpu.py > gpurun_out/c4_cpu_r$R.json 2> gpurun_out/c4_cpu.err; echo "c4 cpu rc=$?"; tail -5 gpurun_out/c4_cpu.err
 fi
 if [ "$PART" = all ] || [ "$PART" = pmc ]; then
