@@ -1083,9 +1083,16 @@ __device__ __forceinline__ double hash_uniform(unsigned int i, unsigned int k) {
 __global__ __launch_bounds__(64) void tridiag_invit_kernel(const double* __restrict__ d, const double* __restrict__ e,
                                                           int n, const double* __restrict__ lam,
                                                           const double* __restrict__ bounds, int nvec, InvitWs ws,
-                                                          double* __restrict__ Y, int64_t ldy, const int niter) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= nvec) return;
+                                                          double* __restrict__ Y, int64_t ldy, const int niter,
+                                                          const int* __restrict__ list, const int* __restrict__ count) {
+  // with a work list (the vectors the twisted-factorisation kernel gave up on): entry blockIdx.x * 64 + lane of it
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (list) {
+    if (k >= *count) return;
+    k = list[k];
+  } else if (k >= nvec) {
+    return;
+  }
   const double tnorm = bounds[3];
   const double tiny = fmax(2.220446049250313e-16 * tnorm, 2.2250738585072014e-308 * 4.0);
   const double lk = lam[k];
@@ -1190,6 +1197,289 @@ __global__ __launch_bounds__(64) void tridiag_invit_kernel(const double* __restr
   // the final scaling is left to invit_scale_kernel (fully parallel over the matrix; done here it is one more
   // latency-bound pass of n / UB round trips per lane): the factor goes to row 0 of this vector's Lm column
   Lm[0] = carry;
+}
+
+// ---- eigenvectors of T by twisted factorisations, one WAVE per eigenvector, the recurrences as scans ----
+// The inverse iteration above runs one eigenvector per LANE: 4 n sequential steps each, a memory round trip per 12
+// rows, 16 waves on a chip of 1024 SIMDs (3.3 ms at n = 4096, k = 1024).  Here lane c owns rows 64 c .. 64 c + 63.
+//   forward pivots   s_0 = a_0, s_i = a_i - b_{i-1} / s_{i-1}           (a = (d - lambda) / |T|, b = (e / |T|)^2)
+//   backward pivots  t_{n-1} = a_{n-1}, t_i = a_i - b_i / t_{i+1}
+//   gamma_i = s_i + t_i - a_i;  twist r = argmin |gamma|;  z_r = 1,
+//   z_i = -(e_i / s_i) z_{i+1} above r,  z_i = -(e_{i-1} / t_i) z_{i-1} below      (Parlett & Dhillon; LAPACK dlar1v)
+// A pivot recurrence is a Moebius map, i.e. the three-term recurrence of the leading (trailing) minors
+// p_{i+1} = a_i p_i - b_{i-1} p_{i-1}: a lane multiplies the 2 x 2 matrices of its 64 rows, a wave scan of those
+// products (rescaled by powers of two) gives every lane the minors just before its first row, hence its first
+// pivot, and the lane then runs the ordinary recurrence over its own rows.  z is a running product of links: the
+// same pattern with (mantissa, exponent) pairs, since entries far from the twist underflow legitimately.
+// The result is checked row by row against (T - lambda) z = gamma_r e_r.  A residual rho leaves a component
+// ~rho / gap along the neighbouring eigenvector, so a vector is accepted when rho <= TW_ORTH x its gap (and
+// rho <= TW_TOL); the others -- the members of tight clusters, mostly -- go on a list that the inverse-iteration kernel
+// works off afterwards (empty for spectra with relative gaps above ~1e-5, e.g. the top of a covariance spectrum).
+constexpr int TW_MAXN = 4096;
+constexpr double TW_TOL = 2e-13;
+constexpr double TW_ORTH = 1e-9;
+constexpr double TW_PIVMIN = 1e-290;
+
+// dsT[il * 64 + c] = d[64 c + il] / |T|, esT likewise for e: lane c's rows as coalesced loads
+__global__ void tw_prepare_kernel(const double* __restrict__ d, const double* __restrict__ e, int n,
+                                  const double* __restrict__ bounds, double* __restrict__ dsT,
+                                  double* __restrict__ esT, int* __restrict__ count) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int R = (n + 63) / 64;
+  if (t == 0) *count = 0;
+  if (t >= R * 64) return;
+  const int il = t >> 6, c = t & 63, i = c * R + il;
+  const double sc = bounds[3] > 0.0 ? 1.0 / bounds[3] : 1.0;
+  dsT[t] = i < n ? d[i] * sc : 0.0;
+  esT[t] = i + 1 < n ? e[i] * sc : 0.0;
+}
+
+struct M22 { double a, b, c, d; };   // [[a, b], [c, d]], defined up to a positive factor
+__device__ __forceinline__ void m22_renorm(M22& m) {
+  const double mx = fmax(fmax(fabs(m.a), fabs(m.b)), fmax(fabs(m.c), fabs(m.d)));
+  if (mx > 0.0 && mx < INFINITY) {
+    int ex;
+    (void)frexp(mx, &ex);
+    m.a = ldexp(m.a, -ex); m.b = ldexp(m.b, -ex); m.c = ldexp(m.c, -ex); m.d = ldexp(m.d, -ex);
+  }
+}
+__device__ __forceinline__ M22 m22_mul(const M22& x, const M22& y) {   // x y
+  return M22{x.a * y.a + x.b * y.c, x.a * y.b + x.b * y.d, x.c * y.a + x.d * y.c, x.c * y.b + x.d * y.d};
+}
+__device__ __forceinline__ M22 m22_shfl(const M22& m, int src) {
+  return M22{__shfl(m.a, src), __shfl(m.b, src), __shfl(m.c, src), __shfl(m.d, src)};
+}
+// (mantissa, exponent) products
+__device__ __forceinline__ void me_mul(double& m, int& e, double f) {
+  m *= f;
+  if (m != 0.0 && fabs(m) < INFINITY) { int ex; m = frexp(m, &ex); e += ex; }
+}
+
+__global__ __launch_bounds__(64) void tridiag_twist_kernel(const double* __restrict__ dsT, const double* __restrict__ esT,
+                                                           int n, const double* __restrict__ lam,
+                                                           const double* __restrict__ bounds, int nvec,
+                                                           double* __restrict__ Y, int64_t ldy,
+                                                           double* __restrict__ scale_out, int* __restrict__ fail_list,
+                                                           int* __restrict__ fail_count, int has_below) {
+  extern __shared__ __attribute__((aligned(16))) char tw_smem[];
+  double* S = reinterpret_cast<double*>(tw_smem);        // [R][64]: forward pivots, then z mantissas, then z
+  double* Tt = S + 64 * 64;                               // [R][64]: backward pivots, then z exponents
+  const int k = blockIdx.x, lane = threadIdx.x;
+  const int R = (n + 63) / 64;
+  const int i0 = lane * R;                                // this lane's rows i0 .. i0 + R - 1
+  const double tnorm = bounds[3];
+  double ls = tnorm > 0.0 ? lam[k] / tnorm : lam[k];
+#define TW_A(il) (dsT[(il) * 64 + lane] - ls)
+#define TW_E(il) (esT[(il) * 64 + lane])
+  // e of the row above this lane's first row (links the chunks)
+  const double e_above = __shfl_up(esT[(R - 1) * 64 + lane], 1);   // lane - 1's last row; lane 0: unused
+  // Two passes: the first one's twisted factorisation yields the Rayleigh-quotient correction of the shift,
+  // lambda + gamma_r / z^T z (dlarrv's RQI step) -- the multisection leaves ~1e-14 |T| of error in lambda, and a vector
+  // computed at a shift that far off carries that much residual; at the corrected shift it is at rounding level.
+  double ss = 0.0, nrm = 0.0;
+  int r = 0;
+  for (int pass = 0; pass < 2; ++pass) {
+  // ---- forward: product of this lane's row matrices, scan, first pivot, pivots
+  M22 m{1.0, 0.0, 0.0, 1.0};
+  for (int il = 0; il < R; ++il) {
+    const int i = i0 + il;
+    if (i >= n) break;
+    const double a = TW_A(il);
+    const double ep = il == 0 ? (lane == 0 ? 0.0 : e_above) : TW_E(il - 1);
+    const double b = ep * ep;
+    m = M22{a * m.a - b * m.c, a * m.b - b * m.d, m.a, m.b};
+    if ((il & 7) == 7) m22_renorm(m);
+  }
+  m22_renorm(m);
+  for (int off = 1; off < 64; off <<= 1) {
+    const M22 o = m22_shfl(m, max(lane - off, 0));
+    if (lane >= off) { m = m22_mul(m, o); m22_renorm(m); }
+  }
+  {
+    // state before this lane's first row = first column of the product up to lane - 1: (p_{i0}, p_{i0-1})
+    const double pn = __shfl_up(m.a, 1), pd = __shfl_up(m.c, 1);
+    double sprev_inv = (lane == 0 || pn == 0.0) ? 0.0 : pd / pn;   // 1 / s_{i0-1}; p_{i0} = 0: pivot 0 -> handled as pivmin
+    if (lane > 0 && pn == 0.0) sprev_inv = -1.0 / TW_PIVMIN;
+    double s = 0.0;
+    for (int il = 0; il < R; ++il) {
+      const int i = i0 + il;
+      if (i >= n) break;
+      const double a = TW_A(il);
+      const double ep = il == 0 ? (lane == 0 ? 0.0 : e_above) : TW_E(il - 1);
+      const double b = ep * ep;
+      s = (il == 0) ? a - b * sprev_inv : a - b / s;
+      if (!(fabs(s) >= TW_PIVMIN)) s = -TW_PIVMIN;
+      S[il * 64 + lane] = s;
+    }
+  }
+  // ---- backward: the same from the bottom; gamma and its smallest magnitude on the way
+  M22 w{1.0, 0.0, 0.0, 1.0};
+  for (int il = R - 1; il >= 0; --il) {
+    const int i = i0 + il;
+    if (i >= n) continue;
+    const double a = TW_A(il);
+    const double e_ = TW_E(il);                            // zero for i = n - 1
+    const double b = e_ * e_;
+    w = M22{a * w.a - b * w.c, a * w.b - b * w.d, w.a, w.b};
+    if ((il & 7) == 0) m22_renorm(w);
+  }
+  m22_renorm(w);
+  for (int off = 1; off < 64; off <<= 1) {
+    const M22 o = m22_shfl(w, min(lane + off, 63));
+    if (lane + off < 64) { w = m22_mul(w, o); m22_renorm(w); }
+  }
+  double gbest = INFINITY, gsign = 0.0;
+  int rbest = 0;
+  {
+    const double qn = __shfl_down(w.a, 1), qd = __shfl_down(w.c, 1);   // (q_{i1}, q_{i1+1}) of the rows below
+    double tnext_inv = (lane == 63 || qn == 0.0) ? 0.0 : qd / qn;
+    if (lane < 63 && qn == 0.0) tnext_inv = -1.0 / TW_PIVMIN;
+    double t = 0.0;
+    bool first = true;
+    for (int il = R - 1; il >= 0; --il) {
+      const int i = i0 + il;
+      if (i >= n) continue;
+      const double a = TW_A(il);
+      const double e_ = TW_E(il);
+      const double b = e_ * e_;
+      t = first ? a - b * tnext_inv : a - b / t;
+      first = false;
+      if (!(fabs(t) >= TW_PIVMIN)) t = -TW_PIVMIN;
+      Tt[il * 64 + lane] = t;
+      const double gs = S[il * 64 + lane] + t - a;
+      const double g = fabs(gs);
+      if (g < gbest) { gbest = g; rbest = i; gsign = gs; }  // (NaN never wins)
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    const double og = __shfl_xor(gbest, off), os = __shfl_xor(gsign, off);
+    const int orr = __shfl_xor(rbest, off);
+    if (og < gbest || (og == gbest && orr < rbest)) { gbest = og; rbest = orr; gsign = os; }
+  }
+  r = rbest;
+  const int cr = r / R;
+  // ---- z as running products of links, (mantissa, exponent) per row; S <- mantissa, Tt <- exponent
+  int* Ex = reinterpret_cast<int*>(Tt);                    // one int per slot (the doubles of Tt are consumed first)
+  double vm = 1.0; int ve = 0;                              // this lane's total link product towards the twist
+  if (lane <= cr) {                                         // rows above the twist: z_i = f_i z_{i+1}, f_i = -e_i / s_i
+    double pm = 1.0; int pe = 0;
+    for (int il = R - 1; il >= 0; --il) {
+      const int i = i0 + il;
+      if (i >= n || i > r) continue;
+      if (i == r) { S[il * 64 + lane] = 1.0; Ex[2 * (il * 64 + lane)] = 0; continue; }
+      const double f = -TW_E(il) / S[il * 64 + lane];
+      me_mul(pm, pe, f);
+      S[il * 64 + lane] = pm; Ex[2 * (il * 64 + lane)] = pe;
+    }
+    vm = pm; ve = pe;
+  }
+  if (lane >= cr) {                                         // rows below: z_i = g_i z_{i-1}, g_i = -e_{i-1} / t_i
+    double pm = 1.0; int pe = 0;
+    for (int il = 0; il < R; ++il) {
+      const int i = i0 + il;
+      if (i >= n) break;
+      if (i <= r) continue;
+      const double ep = il == 0 ? e_above : TW_E(il - 1);
+      const double g = -ep / Tt[il * 64 + lane];
+      me_mul(pm, pe, g);
+      S[il * 64 + lane] = pm; Ex[2 * (il * 64 + lane)] = pe;
+    }
+    if (lane > cr) { vm = pm; ve = pe; }
+  }
+  // base factor of a lane: the product of the totals of the lanes between it and the twist lane (the twist lane's
+  // partial products above / below r count as its totals in the two directions)
+  double upm = vm; int upe = ve;                            // totals used by the lanes ABOVE (smaller index)
+  double dnm = vm; int dne = ve;                            // totals used by the lanes BELOW
+  if (lane == cr) {
+    // vm / ve currently hold the ABOVE partial if rows above r exist in this lane, recompute both explicitly
+    double am = 1.0; int ae = 0, be = 0; double bm = 1.0;
+    const int ilr = r - i0;
+    if (ilr > 0) { am = S[0 * 64 + lane]; ae = Ex[2 * (0 * 64 + lane)]; }
+    const int last = min(R - 1, n - 1 - i0);
+    if (last > ilr) { bm = S[last * 64 + lane]; be = Ex[2 * (last * 64 + lane)]; }
+    upm = am; upe = ae; dnm = bm; dne = be;
+  }
+  if (lane > cr) { upm = 1.0; upe = 0; }
+  if (lane < cr) { dnm = 1.0; dne = 0; }
+  // exclusive suffix product of upm over lanes (what the lanes above multiply by), exclusive prefix product of dnm
+  double bum = 1.0; int bue = 0, bde = 0; double bdm = 1.0;
+  {
+    double sm = upm; int se = upe;                          // inclusive suffix
+    for (int off = 1; off < 64; off <<= 1) {
+      const double om = __shfl_down(sm, off); const int oe = __shfl_down(se, off);
+      if (lane + off < 64) { sm *= om; se += oe; if (sm != 0.0 && fabs(sm) < INFINITY) { int ex; sm = frexp(sm, &ex); se += ex; } }
+    }
+    bum = __shfl_down(sm, 1); bue = __shfl_down(se, 1);
+    if (lane == 63) { bum = 1.0; bue = 0; }
+    double qm = dnm; int qe = dne;                          // inclusive prefix
+    for (int off = 1; off < 64; off <<= 1) {
+      const double om = __shfl_up(qm, off); const int oe = __shfl_up(qe, off);
+      if (lane >= off) { qm *= om; qe += oe; if (qm != 0.0 && fabs(qm) < INFINITY) { int ex; qm = frexp(qm, &ex); qe += ex; } }
+    }
+    bdm = __shfl_up(qm, 1); bde = __shfl_up(qe, 1);
+    if (lane == 0) { bdm = 1.0; bde = 0; }
+  }
+  // ---- assemble: exponent range, scaling, 2-norm
+  int emax = -(1 << 30);
+  for (int il = 0; il < R; ++il) {
+    const int i = i0 + il;
+    if (i >= n) break;
+    double fm = 1.0; int fe = 0;
+    if (i < r && lane < cr) { fm = bum; fe = bue; }
+    if (i > r && lane > cr) { fm = bdm; fe = bde; }
+    double zm = S[il * 64 + lane] * fm;
+    int ze = Ex[2 * (il * 64 + lane)] + fe;
+    if (zm != 0.0 && fabs(zm) < INFINITY) { int ex; zm = frexp(zm, &ex); ze += ex; } else if (!(fabs(zm) < INFINITY)) { zm = 0.0; ze = -(1 << 29); }
+    S[il * 64 + lane] = zm; Ex[2 * (il * 64 + lane)] = ze;
+    if (zm != 0.0) emax = max(emax, ze);
+  }
+  for (int off = 32; off > 0; off >>= 1) emax = max(emax, __shfl_xor(emax, off));
+  ss = 0.0;
+  for (int il = 0; il < R; ++il) {
+    const int i = i0 + il;
+    if (i >= n) break;
+    const int de = Ex[2 * (il * 64 + lane)] - emax;
+    const double z = de < -1100 ? 0.0 : ldexp(S[il * 64 + lane], de);
+    S[il * 64 + lane] = z;
+    ss += z * z;
+  }
+  for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+  nrm = ss > 0.0 ? 1.0 / sqrt(ss) : 0.0;
+  if (pass == 0) {
+    // z^T z in the scale where z_r = 1 is ss 4^emax; the correction is taken only while it is a refinement
+    const double corr = (ss > 0.0 && emax < 400) ? ldexp(gsign / ss, -2 * emax) : 0.0;
+    if (fabs(corr) <= 1e-11) ls += corr;
+    __syncthreads();   // (the pivots of the second pass overwrite S / Tt)
+  }
+  }
+  __syncthreads();   // (one wave; the barrier keeps the compiler from moving the neighbour reads above the writes)
+  // ---- residual of (T - lambda) z, in units of |T| with |z|_2 = 1, and the output
+  double res = 0.0;
+  for (int il = 0; il < R; ++il) {
+    const int i = i0 + il;
+    if (i >= n) break;
+    const double z = S[il * 64 + lane];
+    const double zu = il > 0 ? S[(il - 1) * 64 + lane] : (lane > 0 ? S[(R - 1) * 64 + lane - 1] : 0.0);
+    const bool has_dn = i + 1 < n;
+    const double zd = !has_dn ? 0.0 : (il + 1 < R ? S[(il + 1) * 64 + lane] : S[0 * 64 + lane + 1]);
+    const double eu = il == 0 ? (lane == 0 ? 0.0 : e_above) : TW_E(il - 1);
+    const double rr = i == r ? 0.0 : fabs(eu * zu + TW_A(il) * z + TW_E(il) * zd) * nrm;
+    res = fmax(res, rr);
+    Y[(int64_t)i * ldy + k] = z * nrm;
+  }
+  for (int off = 32; off > 0; off >>= 1) res = fmax(res, __shfl_xor(res, off));
+  if (lane == 0) {
+    scale_out[k] = 1.0;                                     // invit_scale_kernel multiplies by this
+    // gap to the neighbours in units of |T| (lam[-1] exists when an eigenvalue below the requested ones was computed)
+    double gap = INFINITY;
+    if (k + 1 < nvec) gap = fmin(gap, lam[k + 1] - lam[k]);
+    if (k > 0 || has_below) gap = fmin(gap, lam[k] - lam[k - 1]);
+    gap = tnorm > 0.0 ? gap / tnorm : gap;
+    const double tol = fmin(TW_TOL, TW_ORTH * gap);
+    if (!(res <= tol) || !(ss > 0.0)) fail_list[atomicAdd(fail_count, 1)] = k;
+  }
+#undef TW_A
+#undef TW_E
 }
 
 // Y[:, k] *= scale[k]: the normalisation of the inverse-iteration vectors
@@ -1425,7 +1715,7 @@ struct TridiagPlan {
   int npanels;
   size_t off_A, off_V, off_W, off_col, off_p, off_part, off_refl, off_d, off_e, off_e2, off_ds, off_tau, off_bounds, off_lam;
   size_t off_u1, off_u2, off_u3, off_lm, off_sw, off_G, off_T, off_W1, off_W2, off_wraw, off_wraw2, off_part2, off_cbuf;
-  size_t off_qv, off_px2, off_rowpart, off_colpart, off_gpart, off_tall, off_res;
+  size_t off_qv, off_px2, off_rowpart, off_colpart, off_gpart, off_tall, off_res, off_twd, off_twe, off_twl;
   int64_t ldp;     // leading dimension of the symmetric SYMV's partial-result arrays
   bool two;        // two-stage reduction (eigh_twostage.hip) available for this order
   TwoStagePlan ts;
@@ -1484,6 +1774,9 @@ TridiagPlan tridiag_plan(int64_t n) {
   p.off_gpart = take((size_t)p.npanels * ceil_div(n, GCH) * NB * NB * 8);
   p.off_tall = take((size_t)p.npanels * NB * NB * 8);
   p.off_res = take(8192 + 4 * (size_t)RES_XS * 8);   // resident tail: control block, two pairs of exchange vectors
+  p.off_twd = take((size_t)TW_MAXN * 8);             // twisted factorisations: d / |T|, e / |T| by lane chunks,
+  p.off_twe = take((size_t)TW_MAXN * 8);
+  p.off_twl = take((size_t)(n + 16) * 4);            // ... [0] count, [16 ..] list of the vectors left to inverse iteration
   p.two = twostage_supported(n);
   if (p.two) {
     p.ts = twostage_plan(n, p.ld);
@@ -1722,8 +2015,31 @@ int tridiag_vectors_and_backtransform(const TridiagPlan& p, char* base, int nvec
   const double* lamk = lam + (n - nvec);  // the nvec largest eigenvalues, ascending
   // (the recurrences are sequential in the row index and latency bound -- one round trip per 12 rows --, every wave
   // runs the same chain, so fewer lanes per wave / more waves do not shorten the launch: measured 64 = 32 = 16 = 8)
-  hipLaunchKernelGGL(tridiag_invit_kernel, dim3((unsigned)ceil_div(nvec, 64)), dim3(64), 0, st, d, e, n, lamk, bounds,
-                     nvec, ws, Y, ldy, niter);
+  static const bool no_twist = getenv("PTD_EIGH_TWIST") && atoi(getenv("PTD_EIGH_TWIST")) == 0;
+  if (n <= TW_MAXN && n >= 64 && !no_twist) {
+    double* dsT = reinterpret_cast<double*>(base + p.off_twd);
+    double* esT = reinterpret_cast<double*>(base + p.off_twe);
+    int* cnt = reinterpret_cast<int*>(base + p.off_twl);
+    int* list = cnt + 16;
+    static const bool attr = hipFuncSetAttribute(reinterpret_cast<const void*>(tridiag_twist_kernel),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 65536) == hipSuccess;
+    PTD_REQUIRE(attr, "tridiag_twist: cannot reserve LDS");
+    hipLaunchKernelGGL(tw_prepare_kernel, dim3(TW_MAXN / 256), dim3(256), 0, st, d, e, n, bounds, dsT, esT, cnt);
+    hipLaunchKernelGGL(tridiag_twist_kernel, dim3((unsigned)nvec), dim3(64), 65536, st, dsT, esT, n, lamk, bounds, nvec,
+                       Y, ldy, ws.Lm, list, cnt, nvec < n ? 1 : 0);
+    // the vectors whose residual was refused (normally none): inverse iteration
+    hipLaunchKernelGGL(tridiag_invit_kernel, dim3((unsigned)ceil_div(nvec, 64)), dim3(64), 0, st, d, e, n, lamk, bounds,
+                       nvec, ws, Y, ldy, niter, list, cnt);
+    if (getenv("PTD_JACOBI_DEBUG")) {
+      int h = 0;
+      PTD_CHECK_HIP(hipMemcpyAsync(&h, cnt, 4, hipMemcpyDeviceToHost, st));
+      PTD_CHECK_HIP(hipStreamSynchronize(st));
+      fprintf(stderr, "[eigh_tridiag] twisted factorisations: %d of %d vectors left to inverse iteration\n", h, nvec);
+    }
+  } else {
+    hipLaunchKernelGGL(tridiag_invit_kernel, dim3((unsigned)ceil_div(nvec, 64)), dim3(64), 0, st, d, e, n, lamk, bounds,
+                       nvec, ws, Y, ldy, niter, (const int*)nullptr, (const int*)nullptr);
+  }
   hipLaunchKernelGGL(invit_scale_kernel, dim3((unsigned)ceil_div(nvec, 256), 256), dim3(256), 0, st, Y, ldy, n, nvec,
                      ws.Lm);
   if (ortol > 0.0)

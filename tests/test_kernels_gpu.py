@@ -321,6 +321,42 @@ def test_resident_tail_of_the_reduction_matches_the_blocked_path(ops, monkeypatc
         _check_eigh(ops, a)
 
 
+@pytest.mark.parametrize("n,k", [(64, 64), (200, 200), (1000, 300), (2048, 700), (4096, 1024)])
+def test_twisted_factorisation_eigenvectors_match_inverse_iteration(ops, monkeypatch, n, k):
+    """Eigenvectors of T from twisted factorisations, one wave per vector with the recurrences as scans
+    (tridiag_twist_kernel; vectors it refuses go to the inverse-iteration kernel), against the inverse-iteration kernel
+    alone (PTD_EIGH_TWIST=0): the same eigenvalues bit for bit, the same vectors up to sign and the rounding a gap
+    allows, residual and orthogonality at the tolerances of the other eigensolver tests -- on a covariance spectrum
+    (dense at the low end: tight gaps when k = n) and on the closed-form geometric spectrum below."""
+    monkeypatch.setenv("PTD_EIGH_METHOD", "tridiag")
+    y = _rand((2 * n + 3, n), 700 + n).double() * torch.logspace(0, -2, n, dtype=torch.float64)
+    a = y.T @ y / y.shape[0]
+    a = a + torch.eye(n, dtype=torch.float64) * (0.01 * torch.diag(a).mean())
+    ad = a.to(DEV)
+    # (the library reads the switch once per process: the reference run is a child process)
+    import subprocess, sys, tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        torch.save(a, os.path.join(tmp, "a.pt"))
+        code = ("import sys, torch; sys.path.insert(0, %r); from ptdeco_amd import ops; a = torch.load(%r).cuda(); "
+                "w, v = ops.eigh(a, %d); torch.save((w.cpu(), v.cpu()), %r)"
+                % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.join(tmp, "a.pt"), k,
+                   os.path.join(tmp, "ref.pt")))
+        env = dict(os.environ, PTD_EIGH_TWIST="0", PTD_EIGH_METHOD="tridiag")
+        subprocess.run([sys.executable, "-c", code], check=True, env=env, timeout=600)
+        w0, v0 = torch.load(os.path.join(tmp, "ref.pt"))
+    w1, v1 = ops.eigh(ad, k)
+    w1, v1 = w1.cpu(), v1.cpu()
+    assert torch.equal(w0, w1)
+    scale = w1.abs().max().item()
+    assert (a @ v1 - v1 * w1[n - k:]).abs().max().item() <= 1e-11 * scale
+    assert (v1.T @ v1 - torch.eye(k, dtype=torch.float64)).abs().max().item() <= 5e-9
+    # same invariant subspaces at a few cuts (a projector does not see signs or rotations inside a cluster)
+    for r in sorted({k, max(1, k // 2), max(1, k // 7)}):
+        p0 = v0[:, k - r:] @ v0[:, k - r:].T
+        p1 = v1[:, k - r:] @ v1[:, k - r:].T
+        assert (p0 - p1).norm().item() <= 1e-6 * math.sqrt(r)
+
+
 # ---------------------------------------------------------------- dense products
 LAYOUTS = ["nn", "nt", "tn", "tt"]
 
