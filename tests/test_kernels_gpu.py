@@ -326,8 +326,8 @@ def test_twisted_factorisation_eigenvectors_match_inverse_iteration(ops, monkeyp
     """Eigenvectors of T from twisted factorisations, one wave per vector with the recurrences as scans
     (tridiag_twist_kernel; vectors it refuses go to the inverse-iteration kernel), against the inverse-iteration kernel
     alone (PTD_EIGH_TWIST=0): the same eigenvalues bit for bit, the same vectors up to sign and the rounding a gap
-    allows, residual and orthogonality at the tolerances of the other eigensolver tests -- on a covariance spectrum
-    (dense at the low end: tight gaps when k = n) and on the closed-form geometric spectrum below."""
+    allows, residual and orthogonality at the tolerances of the other eigensolver tests -- on covariance spectra
+    (dense at the low end: tight gaps, many refusals, when k = n; none for the top quarter)."""
     monkeypatch.setenv("PTD_EIGH_METHOD", "tridiag")
     y = _rand((2 * n + 3, n), 700 + n).double() * torch.logspace(0, -2, n, dtype=torch.float64)
     a = y.T @ y / y.shape[0]
