@@ -1865,12 +1865,12 @@ int sytrd_f64(const TridiagPlan& p, char* base, SymvTimer* timer, bool resident,
     if (j0 == t_res && n - j0 >= 2) {
       // the rest of the reduction in one launch, the trailing block resident in the LDS of one XCD
       double* X = reinterpret_cast<double*>(base + p.off_res + 8192);
-      static const bool attr = [] {
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(sytrd_resident_kernel<RES_WG, RES_MAX, false>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)RES_LDS) == hipSuccess &&
-               hipFuncSetAttribute(reinterpret_cast<const void*>(sytrd_resident_kernel<RESG_WG, RESG_MAX, true>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)RES_LDS) == hipSuccess;
-      }();
+      // (set at every call: the attribute belongs to the current device's copy of the function)
+      const bool attr =
+          hipFuncSetAttribute(reinterpret_cast<const void*>(sytrd_resident_kernel<RES_WG, RES_MAX, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)RES_LDS) == hipSuccess &&
+          hipFuncSetAttribute(reinterpret_cast<const void*>(sytrd_resident_kernel<RESG_WG, RESG_MAX, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)RES_LDS) == hipSuccess;
       PTD_REQUIRE(attr, "sytrd_f64: cannot reserve the LDS of the resident tail");
       static std::atomic<unsigned long long> calls{0};
       static_assert(RESG_MAX < (1 << 16), "sequence numbers of one launch: epoch .. epoch + m");
@@ -2021,8 +2021,8 @@ int tridiag_vectors_and_backtransform(const TridiagPlan& p, char* base, int nvec
     double* esT = reinterpret_cast<double*>(base + p.off_twe);
     int* cnt = reinterpret_cast<int*>(base + p.off_twl);
     int* list = cnt + 16;
-    static const bool attr = hipFuncSetAttribute(reinterpret_cast<const void*>(tridiag_twist_kernel),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 65536) == hipSuccess;
+    const bool attr = hipFuncSetAttribute(reinterpret_cast<const void*>(tridiag_twist_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 65536) == hipSuccess;
     PTD_REQUIRE(attr, "tridiag_twist: cannot reserve LDS");
     hipLaunchKernelGGL(tw_prepare_kernel, dim3(TW_MAXN / 256), dim3(256), 0, st, d, e, n, bounds, dsT, esT, cnt);
     hipLaunchKernelGGL(tridiag_twist_kernel, dim3((unsigned)nvec), dim3(64), 65536, st, dsT, esT, n, lamk, bounds, nvec,
