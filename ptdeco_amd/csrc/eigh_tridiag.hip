@@ -794,6 +794,15 @@ __global__ __launch_bounds__(RES_T) void sytrd_resident_kernel(double* __restric
     if (lane == 0) scr[wid] = sq;
     __syncthreads();
   }
+  // The rank-2 update of column jl - 1 is applied in the same pass over the registers as the product of column jl
+  // (v_{jl} is known before the update: it comes from the hand-off), so the matrix is walked once per column:
+  // a <- a - v_r w_c - w_r v_c, then acc += a v'_c.  vreg / vrow_ / wrow_ hold the pending reflector.
+  double vreg[CK], vrow_[RI], wrow_[RI];
+#pragma unroll
+  for (int k = 0; k < CK; ++k) vreg[k] = 0.0;
+#pragma unroll
+  for (int i = 0; i < RI; ++i) { vrow_[i] = 0.0; wrow_[i] = 0.0; }
+  bool pending = false;
   for (int jl = 0; jl < ncols; ++jl) {
     const unsigned long long seq = epoch + (unsigned long long)jl + 1;
     double* Pb = Xbuf + ((jl + 1) & 1) * 2 * RES_XS;        // this column's p entries, then its b entries
@@ -828,21 +837,29 @@ __global__ __launch_bounds__(RES_T) void sytrd_resident_kernel(double* __restric
       if (writer && tid == 0) { taus[t0 + jl] = tau; e[t0 + jl] = beta; d[t0 + jl] = dnext; }
     }
     __syncthreads();
-    // ---- p = tau A v and b = A[:, jl + 1] - p for this workgroup's rows
-    double vreg[CK], vrow_[RI];
-#pragma unroll
-    for (int k = 0; k < CK; ++k) vreg[k] = vs[lane + 64 * k];
-#pragma unroll
-    for (int i = 0; i < RI; ++i) vrow_[i] = vs[min(lr[i], MAXM - 1)];
+    // ---- the pending update, then p = tau A v and b = A[:, jl + 1] - p for this workgroup's rows
     {
       double acc[RI];
 #pragma unroll
-      for (int i = 0; i < RI; ++i) {
-        acc[i] = 0.0;
+      for (int i = 0; i < RI; ++i) acc[i] = 0.0;
+      const int kold = jl >> 6;                             // first live register column of the pending update
 #pragma unroll
-        for (int k = 0; k < CK; ++k)
-          if (k >= kmin) acc[i] += a[i][k] * vreg[k];
+      for (int k = 0; k < CK; ++k) {
+        if (k < kold) continue;                             // (wave-uniform)
+        const double vnew = vs[lane + 64 * k];
+        if (pending) {
+          const double wk = wv[lane + 64 * k];
+#pragma unroll
+          for (int i = 0; i < RI; ++i)
+            if (lr[i] >= jl && lr[i] < m) a[i][k] -= vrow_[i] * wk + wrow_[i] * vreg[k];
+        }
+        vreg[k] = vnew;
+        if (k >= kmin)
+#pragma unroll
+          for (int i = 0; i < RI; ++i) acc[i] += a[i][k] * vnew;
       }
+#pragma unroll
+      for (int i = 0; i < RI; ++i) vrow_[i] = vs[min(lr[i], MAXM - 1)];
 #pragma unroll
       for (int i = 0; i < RI; ++i) {
         const double pi = tau * res_wave_sum(acc[i]);
@@ -905,30 +922,23 @@ __global__ __launch_bounds__(RES_T) void sytrd_resident_kernel(double* __restric
     }
     __syncthreads();
     dnext = scr[10];
-    // ---- A -= v w^T + w v^T on this workgroup's rows
-    if (tau != 0.0) {
+    // ---- the update A -= v w^T + w v^T waits for the next column's pass (or the one behind the loop)
 #pragma unroll
-      for (int i = 0; i < RI; ++i) {
-        const double wr_ = wv[min(lr[i], MAXM - 1)];
-        const bool live = lr[i] > jl && lr[i] < m;
-#pragma unroll
-        for (int k = 0; k < CK; ++k) {
-          const double wk = wv[lane + 64 * k];
-          if (live && k >= kmin) a[i][k] -= vrow_[i] * wk + wr_ * vreg[k];
-        }
-      }
-    }
+    for (int i = 0; i < RI; ++i) wrow_[i] = wv[min(lr[i], MAXM - 1)];
+    pending = tau != 0.0;
     // (vs / wv / scr are rewritten only behind the barriers of the next column)
   }
   if (ncols == m - 1) {
     if (slot == 0 && tid == 0) d[t0 + m - 1] = dnext;
   } else {
-    // the trailing block goes back to memory for the next kernel (both triangles, as it lies in the registers)
+    // the trailing block goes back to memory for the next kernel (both triangles, as it lies in the registers),
+    // with the last column's update applied on the way
 #pragma unroll
     for (int i = 0; i < RI; ++i)
 #pragma unroll
       for (int k = 0; k < CK; ++k) {
         const int c = lane + 64 * k;
+        if (pending) a[i][k] -= vrow_[i] * wv[c] + wrow_[i] * vreg[k];
         if (lr[i] >= ncols && lr[i] < m && c >= ncols && c < m) Aw[(int64_t)(t0 + lr[i]) * ld + t0 + c] = a[i][k];
       }
   }
