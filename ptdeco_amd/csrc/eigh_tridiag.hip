@@ -613,14 +613,17 @@ __global__ void sytrd_wfix_kernel(int n, int r0, int ilast, int jlast, const dou
 //   * across XCDs entries and sequence numbers are written through to memory (sc1 stores): a hand-off costs 5.3 us.
 //     <256, 2048, true>: every CU, from a trailing order of 2048 down to 768 (then the block goes back to memory for
 //     the kernel above): 9.0 us per column against ~16.4 blocked.
+//   * sytrd_resident3_kernel (further down): the same on every CU for trailing orders 3072 .. 2049, three half rows
+//     per wave: ~14.7 us per column.
 // Every spin is bounded; a time-out or an XCC mismatch sets the status word and the host repeats the reduction on the
-// blocked path.  ptd_eigh_topk n = 4096, k = 1024: 68.2 -> 59.5 ms; n = 768: 9.0 -> 4.7 ms.
+// blocked path.  ptd_eigh_topk n = 4096, k = 1024: 68.2 -> 54.3 ms (with the twisted-factorisation eigenvectors);
+// n = 768: 9.0 -> 4.3 ms.
 constexpr int RES_MAX = 768;                             // one XCD: 32 workgroups
 constexpr int RES_WG = 32;
 constexpr int RESG_MAX = 2048;                           // the whole chip: 256 workgroups, hand-offs through memory
 constexpr int RESG_WG = 256;
 constexpr int RES_T = 512;
-constexpr int RES_XS = RESG_MAX + 64;                    // one exchange vector
+constexpr int RES_XS = 3072 + 64;                        // one exchange vector (the widest kernel: R3_MAX)
 constexpr size_t RES_LDS = 150 * 1024;   // two vectors and scalars; sized so that a CU takes exactly one workgroup
 constexpr long RES_SPIN = 2000000L;
 
@@ -939,6 +942,228 @@ __global__ __launch_bounds__(RES_T) void sytrd_resident_kernel(double* __restric
       for (int k = 0; k < CK; ++k) {
         const int c = lane + 64 * k;
         if (pending) a[i][k] -= vrow_[i] * wv[c] + wrow_[i] * vreg[k];
+        if (lr[i] >= ncols && lr[i] < m && c >= ncols && c < m) Aw[(int64_t)(t0 + lr[i]) * ld + t0 + c] = a[i][k];
+      }
+  }
+}
+
+// The whole-chip kernel for trailing orders up to 3072 (12 rows a workgroup).  A row does not fit one wave's
+// registers next to everything else, so a wave holds three HALF rows -- half-row h = wave + 8 i is row h / 2 of the
+// workgroup (global row slot + 256 (h / 2)), columns (h & 1) 1536 + lane + 64 k: 72 doubles a thread -- and the
+// product of a row is the sum of two waves' partial sums (LDS).  v, w and the next column live in LDS (3 x 24 KB);
+// nothing of the matrix does.  As the columns retire left to right the waves of the left halves fall idle after
+// 1536 columns; the hand-offs, not the arithmetic, set the pace.  Run from a trailing order of at most 3072 down to
+// 2048, where sytrd_resident_kernel<256, 2048, true> takes over (one row per wave, operands in registers).
+constexpr int R3_MAX = 3072;
+constexpr int R3_HALF = R3_MAX / 2;
+constexpr int R3_CK = R3_HALF / 64;       // columns per lane and half row
+constexpr int R3_HR = 3;                  // half rows per wave (24 half rows over 8 waves)
+constexpr int R3_CT = R3_MAX / RES_T;     // vector entries formed per thread
+
+__global__ __launch_bounds__(RES_T) void sytrd_resident3_kernel(double* __restrict__ Aw, int64_t ld, int n, int t0,
+                                                                int ncols, double* __restrict__ Vall,
+                                                                double* __restrict__ taus, double* __restrict__ d,
+                                                                double* __restrict__ e, ResCtl* __restrict__ ctl,
+                                                                double* __restrict__ Xbuf, unsigned long long epoch) {
+  constexpr int NWG = RESG_WG, NW = RES_T / 64;
+  extern __shared__ __attribute__((aligned(16))) char res_smem[];
+  double* vs = reinterpret_cast<double*>(res_smem);
+  double* wv = vs + R3_MAX;
+  double* xs = wv + R3_MAX;                   // the current column below its diagonal
+  double* part = xs + R3_MAX;                 // [24] partial row products
+  double* scr = part + 32;                    // [0, 8) per-wave sums of x^2, [8] alpha, [9] p[jl+1], [10] next diagonal, [16, 24) p^T v
+  __shared__ int flag;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int slot = blockIdx.x;
+  const int m = n - t0;
+  const int half = wid & 1, cbase = half * R3_HALF + lane;
+  double a[R3_HR][R3_CK];
+  int lr[R3_HR];
+#pragma unroll
+  for (int i = 0; i < R3_HR; ++i) {
+    lr[i] = slot + NWG * ((wid + NW * i) >> 1);
+    const double* src = Aw + (int64_t)(t0 + min(lr[i], m - 1)) * ld + t0;
+#pragma unroll
+    for (int k = 0; k < R3_CK; ++k) {
+      const int c = cbase + 64 * k;
+      a[i][k] = (lr[i] < m && c < m) ? src[c] : 0.0;
+    }
+  }
+  auto wait_all = [&](unsigned long long seq) -> bool {
+    if (wid == 0) { const bool ok = res_wait<NWG>(ctl->fp, seq, lane, ctl); if (lane == 0) flag = ok; }
+    __syncthreads();
+    return flag != 0;
+  };
+  double dnext;
+  {
+    // column 0 is gathered as it lies: b = A[:, 0], p = 0
+    if (half == 0 && lane == 0)
+#pragma unroll
+      for (int i = 0; i < R3_HR; ++i)
+        if (lr[i] < m) res_st_f64<true>(Xbuf + RES_XS + lr[i], a[i][0]);
+    res_publish<true>(ctl->fp, slot, epoch);
+    if (!wait_all(epoch)) return;
+#pragma unroll
+    for (int t = 0; t < R3_CT; ++t) {
+      const int c = tid + RES_T * t;
+      xs[c] = (c >= 1 && c < m) ? res_ld_f64(Xbuf + RES_XS + c) : 0.0;
+    }
+    dnext = res_ld_f64(Xbuf + RES_XS);
+  }
+  // the rank-2 update of column jl - 1 rides in the product pass of column jl (see sytrd_resident_kernel); the old v
+  // of the lane's columns cannot stay in registers here, so it is kept in a third LDS vector
+  double* vo = scr + 32;                      // [3072] v of the pending update
+  double vrow_[R3_HR], wrow_[R3_HR];
+#pragma unroll
+  for (int i = 0; i < R3_HR; ++i) { vrow_[i] = 0.0; wrow_[i] = 0.0; }
+  bool pending = false;
+  for (int jl = 0; jl < ncols; ++jl) {
+    const unsigned long long seq = epoch + (unsigned long long)jl + 1;
+    double* Pb = Xbuf + ((jl + 1) & 1) * 2 * RES_XS;
+    double* Bb = Pb + RES_XS;
+    const int kmin = max(0, (jl + 1 - half * R3_HALF) >> 6);     // this half's register columns below are retired
+    // ---- the reflector of column jl: the same arithmetic in every workgroup
+    {
+      double sq = 0.0;
+#pragma unroll
+      for (int t = 0; t < R3_CT; ++t) {
+        const int c = tid + RES_T * t;
+        const double x = xs[c];
+        if (c >= jl + 2) sq += x * x;
+        if (c == jl + 1) scr[8] = x;
+      }
+      sq = res_wave_sum(sq);
+      if (lane == 0) scr[wid] = sq;
+    }
+    __syncthreads();
+    double xn2 = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) xn2 += scr[w];
+    const double alpha = scr[8];
+    double tau, beta, scale;
+    if (xn2 == 0.0) {
+      tau = 0.0; beta = alpha; scale = 0.0;
+    } else {
+      const double nrm = sqrt(alpha * alpha + xn2);
+      beta = alpha >= 0.0 ? -nrm : nrm;
+      tau = (beta - alpha) / beta;
+      scale = 1.0 / (alpha - beta);
+    }
+    {
+      double* vrow = Vall + (int64_t)(t0 + jl) * ld + t0;
+      const bool writer = slot == (jl & (NWG - 1));
+#pragma unroll
+      for (int t = 0; t < R3_CT; ++t) {
+        const int c = tid + RES_T * t;
+        const double v = (c == jl + 1) ? 1.0 : ((c > jl + 1) ? xs[c] * scale : 0.0);
+        vs[c] = v;
+        if (writer && c > jl && c < m) vrow[c] = v;
+      }
+      if (writer && tid == 0) { taus[t0 + jl] = tau; e[t0 + jl] = beta; d[t0 + jl] = dnext; }
+    }
+    __syncthreads();
+    // ---- the pending update, then the partial products of the half rows
+    {
+      double acc[R3_HR];
+#pragma unroll
+      for (int i = 0; i < R3_HR; ++i) acc[i] = 0.0;
+      const int kold = max(0, (jl - half * R3_HALF) >> 6);
+#pragma unroll
+      for (int k = 0; k < R3_CK; ++k) {
+        if (k < kold) continue;
+        const int c = cbase + 64 * k;
+        const double vnew = vs[c];
+        if (pending) {
+          const double wk = wv[c], vold = vo[c];
+#pragma unroll
+          for (int i = 0; i < R3_HR; ++i)
+            if (lr[i] >= jl && lr[i] < m) a[i][k] -= vrow_[i] * wk + wrow_[i] * vold;
+        }
+        if (k >= kmin)
+#pragma unroll
+          for (int i = 0; i < R3_HR; ++i) acc[i] += a[i][k] * vnew;
+      }
+#pragma unroll
+      for (int i = 0; i < R3_HR; ++i) {
+        const double sacc = res_wave_sum(acc[i]);
+        if (lane == 0) part[wid + NW * i] = sacc;
+        vrow_[i] = vs[min(lr[i], R3_MAX - 1)];
+      }
+    }
+    __syncthreads();
+    // ---- p = tau A v and b = A[:, jl + 1] - p, stored by the lane that holds column jl + 1 of the row
+    {
+      const int half1 = (jl + 1) >= R3_HALF ? 1 : 0;
+      const int l1 = (jl + 1 - half1 * R3_HALF) & 63, k1 = (jl + 1 - half1 * R3_HALF) >> 6;
+      if (half == half1 && lane == l1) {
+#pragma unroll
+        for (int i = 0; i < R3_HR; ++i) {
+          const int h0 = (wid + NW * i) & ~1;
+          const double pi = tau * (part[h0] + part[h0 + 1]);
+          double aj1 = 0.0;
+#pragma unroll
+          for (int k = 0; k < R3_CK; ++k) aj1 = (k == k1) ? a[i][k] : aj1;
+          if (lr[i] > jl && lr[i] < m) {
+            res_st_f64<true>(Pb + lr[i], pi);
+            res_st_f64<true>(Bb + lr[i], aj1 - pi);
+          }
+        }
+      }
+    }
+    res_publish<true>(ctl->fp, slot, seq);
+    if (!wait_all(seq)) return;
+    double pv_[R3_CT], bv_[R3_CT];
+    {
+      double dp = 0.0;
+#pragma unroll
+      for (int t = 0; t < R3_CT; ++t) {
+        const int c = tid + RES_T * t;
+        const bool ok = c > jl && c < m;
+        pv_[t] = ok ? res_ld_f64(Pb + c) : 0.0;
+        bv_[t] = ok ? res_ld_f64(Bb + c) : 0.0;
+        dp += pv_[t] * vs[c];
+        if (c == jl + 1) scr[9] = pv_[t];
+      }
+      dp = res_wave_sum(dp);
+      if (lane == 0) scr[16 + wid] = dp;
+    }
+    __syncthreads();
+    double dot = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) dot += scr[16 + w];
+    const double hk = 0.5 * tau * dot;
+    const double g = scr[9] - 2.0 * hk;
+#pragma unroll
+    for (int t = 0; t < R3_CT; ++t) {
+      const int c = tid + RES_T * t;
+      const double v = vs[c];
+      wv[c] = pv_[t] - hk * v;
+      const double xn = bv_[t] - v * g;
+      if (c == jl + 1) scr[10] = xn;
+      xs[c] = (c >= jl + 2) ? xn : 0.0;
+    }
+    __syncthreads();
+    dnext = scr[10];
+    // ---- the update waits for the next column's pass; its v moves to vo (vs is rewritten at the top of the loop)
+#pragma unroll
+    for (int t = 0; t < R3_CT; ++t) {
+      const int c = tid + RES_T * t;
+      vo[c] = vs[c];
+    }
+#pragma unroll
+    for (int i = 0; i < R3_HR; ++i) wrow_[i] = wv[min(lr[i], R3_MAX - 1)];
+    pending = tau != 0.0;
+    // (vo is read in the next pass behind the barrier after the vs writes)
+  }
+  if (ncols == m - 1) {
+    if (slot == 0 && tid == 0) d[t0 + m - 1] = dnext;
+  } else {
+#pragma unroll
+    for (int i = 0; i < R3_HR; ++i)
+#pragma unroll
+      for (int k = 0; k < R3_CK; ++k) {
+        const int c = cbase + 64 * k;
+        if (pending) a[i][k] -= vrow_[i] * wv[c] + wrow_[i] * vo[c];
         if (lr[i] >= ncols && lr[i] < m && c >= ncols && c < m) Aw[(int64_t)(t0 + lr[i]) * ld + t0 + c] = a[i][k];
       }
   }
@@ -1811,11 +2036,11 @@ struct SymvTimer {
 // (n itself for orders the tail kernel does not take; PTD_SYTRD_RESIDENT=0 switches it off)
 std::atomic<int> g_concurrent_chains{1};
 
-// PTD_SYTRD_RESIDENT: 0 off; 1 the one-XCD tail only; 2 test hook, see sytrd_f64; 3 (default) whole-chip kernel from a
-// trailing order of 2048, then the one-XCD tail
+// PTD_SYTRD_RESIDENT: 0 off; 1 the one-XCD tail only; 2 test hook, see sytrd_f64; 3 whole-chip kernel from a trailing
+// order of 2048, then the one-XCD tail; 4 (default) the half-row whole-chip kernel from 3072 in front of those
 int resident_mode() {
   const char* env = getenv("PTD_SYTRD_RESIDENT");
-  return env ? atoi(env) : 3;
+  return env ? atoi(env) : 4;
 }
 int resident_start(int n) {
   const int mode = resident_mode();
@@ -1823,7 +2048,7 @@ int resident_start(int n) {
   // several chains at once (ptd_set_concurrent_chains): the tail would hold XCC 0 for milliseconds while the other
   // chains' launches queue behind it (2-block Llama stack, three chains: 1.50 s with it, 1.38 s without)
   if (g_concurrent_chains.load(std::memory_order_relaxed) > 1) return n;
-  const int cap = (mode == 3 && n > RES_MAX) ? RESG_MAX : RES_MAX;
+  const int cap = n <= RES_MAX ? RES_MAX : (mode == 4 ? R3_MAX : (mode == 3 ? RESG_MAX : RES_MAX));
   return n <= cap ? 0 : (int)align_up((size_t)(n - cap), NB);
 }
 
@@ -1880,17 +2105,26 @@ int sytrd_f64(const TridiagPlan& p, char* base, SymvTimer* timer, bool resident,
           hipFuncSetAttribute(reinterpret_cast<const void*>(sytrd_resident_kernel<RES_WG, RES_MAX, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)RES_LDS) == hipSuccess &&
           hipFuncSetAttribute(reinterpret_cast<const void*>(sytrd_resident_kernel<RESG_WG, RESG_MAX, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)RES_LDS) == hipSuccess &&
+          hipFuncSetAttribute(reinterpret_cast<const void*>(sytrd_resident3_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)RES_LDS) == hipSuccess;
       PTD_REQUIRE(attr, "sytrd_f64: cannot reserve the LDS of the resident tail");
       static std::atomic<unsigned long long> calls{0};
       static_assert(RESG_MAX < (1 << 16), "sequence numbers of one launch: epoch .. epoch + m");
-      int t1 = j0;
-      if (n - j0 > RES_MAX) {
+      int t1 = j0, t2 = j0;
+      if (n - j0 > RESG_MAX) {
+        // half rows first: down to a trailing order of 2048
+        const unsigned long long epoch = (calls.fetch_add(1) + 1) << 16;
+        t2 = n - RESG_MAX;
+        hipLaunchKernelGGL(sytrd_resident3_kernel, dim3(RESG_WG), dim3(RES_T), RES_LDS, st, Aw, ld, n, j0, t2 - j0, Vall,
+                           taus, d, e, rctl, X, epoch);
+      }
+      if (n - t2 > RES_MAX) {
         // every CU first: down to a trailing order of 768
         const unsigned long long epoch = (calls.fetch_add(1) + 1) << 16;   // > any sequence number of an earlier launch
         t1 = n - RES_MAX;
         hipLaunchKernelGGL((sytrd_resident_kernel<RESG_WG, RESG_MAX, true>), dim3(RESG_WG), dim3(RES_T), RES_LDS, st, Aw, ld,
-                           n, j0, t1 - j0, Vall, taus, d, e, rctl, X, epoch);
+                           n, t2, t1 - t2, Vall, taus, d, e, rctl, X, epoch);
       }
       const unsigned long long epoch = (calls.fetch_add(1) + 1) << 16;
       hipLaunchKernelGGL((sytrd_resident_kernel<RES_WG, RES_MAX, false>), dim3(8 * RES_WG), dim3(RES_T), RES_LDS, st, Aw, ld,
