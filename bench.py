@@ -406,9 +406,9 @@ def main():
                                    "time (%.1f ms: SYMV launches + per-column kernels + rank-2k updates + the resident "
                                    "kernels + launch gaps); the full ptd_eigh call takes %.1f ms" % (red_ms, p["total_ms"]),
                     "kernel": "sytrd_symv2_kernel / sytrd_symv_kernel (Householder tridiagonalisation, one SYMV launch "
-                              "per column down to a trailing order of 2048, symmetric lower-triangle tiles; the last "
-                              "2048 columns run in two launches, resident in registers -- every CU down to 768 columns, "
-                              "one XCD for the rest -- and read nothing from HBM)",
+                              "per column down to a trailing order of 3072, symmetric lower-triangle tiles; the last "
+                              "3072 columns run in three launches, resident in registers -- every CU down to 768 "
+                              "columns, one XCD for the rest -- and read nothing from HBM)",
                     "n": n, "launches": cnt, "avg_launch_us": ms / max(cnt, 1) * 1e3,
                     "algorithmic_bytes_per_launch": byts / max(cnt, 1),
                     "note": "algorithmic bytes = 8 (n-j-1)(n-j-2) per column j (rows j+1.., columns j+2.. of the "

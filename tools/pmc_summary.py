@@ -28,7 +28,7 @@ write = load("pmc_write")["WRITE_SIZE"]
 tcc = load("pmc_tcc")
 hit, miss = tcc["TCC_HIT_sum"], tcc["TCC_MISS_sum"]
 L = len(fetch)
-# one SYMV launch per column j = 0 .. L - 1; the last columns (trailing order <= 2048) run in the resident kernels
+# one SYMV launch per column j = 0 .. L - 1; the last columns (trailing order <= 3072) run in the resident kernels
 assert L == len(write) == len(hit) == len(miss) and L <= n - 1, (L, len(write), len(hit))
 rows = []
 for j in range(L):
