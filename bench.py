@@ -203,8 +203,20 @@ def decomposed_forward_lines(device):
         # the same pair as two torch.nn.functional.linear calls (hipBLASLt): what apply_decompose_config_in_place's
         # Sequential(Linear, Linear) costs without the fused module
         lib_pair = time_events(lambda: torch.nn.functional.linear(torch.nn.functional.linear(x, a), b), iters=10)
+        # what the installed module (LowRankLinear, inference) runs: it times both forms once per shape and keeps the
+        # faster; "ms" above stays the package's own kernels (ptd_lowrank_forward)
+        from ptdeco_amd import lowrank
+        from ptdeco_amd.lowrank import fuse_pair
+        pair = torch.nn.Sequential(torch.nn.Linear(N_FEAT, r, bias=False), torch.nn.Linear(r, N_FEAT, bias=False))
+        pair = fuse_pair(pair).to(device).bfloat16()
+        with torch.no_grad():
+            pair[0].weight.copy_(a); pair[1].weight.copy_(b)
+            mod_t = time_events(lambda: pair(x), iters=10)
         out[f"r{r}"] = {"ms": t * 1e3, "gflops": fl / t / 1e9, "speedup_vs_dense": dense_t / t,
                         "speedup_vs_dense_torch_hipblaslt": lib_t / t, "torch_hipblaslt_pair_ms": lib_pair * 1e3,
+                        "module_ms": mod_t * 1e3,
+                        "module_runs": "library pair" if lowrank._library_choice.get(
+                            (torch.bfloat16, int(t_rows).bit_length(), N_FEAT, r, N_FEAT)) else "package kernels",
                         "frac_of_bf16_mfma_peak": fl / t / PEAK_BF16_MFMA, "hbm_gbps_algorithmic": by / t / 1e9}
     # MFMA utilisation of the two rank-256 kernels from the committed counter pass (tools/pmc_driver mfma)
     pmc = pmc_file("pmc_mfma_r*.json", ("gemm_f32.hip", "gemm_bf16.hip"))

@@ -637,6 +637,45 @@ def test_eigendecompositions_on_concurrent_streams_match_sequential(ops):
         eng.run_concurrently([lambda: ops.eigh(mats[0], 5), lambda: (_ for _ in ()).throw(ValueError("x"))], DEV)
 
 
+def test_lowrank_linear_times_both_forms_once_per_shape_and_keeps_the_faster(ops, monkeypatch, caplog):
+    """LowRankLinear in inference: the first call of a (large) shape times the package's kernels and the two library
+    GEMMs once and keeps the winner (logged at INFO); either way the output is the pair's output; autograd and
+    PTD_LOWRANK_AUTOTUNE=0 stay on the package's kernels; small problems are never timed."""
+    import logging
+    from ptdeco_amd import lowrank
+    from ptdeco_amd.lowrank import fuse_pair
+
+    monkeypatch.setattr(lowrank, "_library_choice", {})
+    g = torch.Generator().manual_seed(5)
+    n, r, T = 4096, 1024, 4096
+    seq = torch.nn.Sequential(torch.nn.Linear(n, r, bias=False), torch.nn.Linear(r, n, bias=True))
+    with torch.no_grad():
+        seq[0].weight.copy_(torch.randn(r, n, generator=g) / n**0.5)
+        seq[1].weight.copy_(torch.randn(n, r, generator=g) / r**0.5)
+    seq = fuse_pair(seq).to(DEV).bfloat16()
+    x = torch.randn(T, n, generator=g).to(DEV).bfloat16()
+    ref = torch.nn.functional.linear(torch.nn.functional.linear(x, seq[0].weight), seq[1].weight, seq[1].bias).float()
+    with caplog.at_level(logging.INFO, logger="ptdeco_amd.lowrank"), torch.no_grad():
+        y1 = seq(x)
+        y2 = seq(x)
+    assert sum("package kernels" in r_.getMessage() and "library pair" in r_.getMessage() for r_ in caplog.records) == 1
+    assert len(lowrank._library_choice) == 1
+    tol = 0.02 * ref.abs().max().item()
+    assert (y1.float() - ref).abs().max().item() <= tol and torch.equal(y1, y2)
+    monkeypatch.setenv("PTD_LOWRANK_AUTOTUNE", "0")
+    with torch.no_grad():
+        y3 = seq(x)
+    assert torch.equal(y3, ops.lowrank_forward(x, seq[0].weight, seq[1].weight, seq[1].bias))
+    monkeypatch.delenv("PTD_LOWRANK_AUTOTUNE")
+    # a small problem: package kernels, nothing cached
+    small = fuse_pair(torch.nn.Sequential(torch.nn.Linear(64, 8, bias=False), torch.nn.Linear(8, 32))).to(DEV)
+    xs = torch.randn(10, 64, generator=g).to(DEV)
+    with torch.no_grad():
+        ys = small(xs)
+    assert len(lowrank._library_choice) == 1
+    assert torch.allclose(ys, small[1](small[0](xs)), atol=1e-5)
+
+
 @pytest.mark.parametrize("kind", ["linear", "conv"])
 def test_lowrank_pair_backward_matches_autograd_of_the_two_layers(ops, kind):
     """A user finetune_fn trains the fused pair: dx, dA, dB, dbias from the strided GEMM

@@ -107,12 +107,13 @@ for k, v in b["kernels"].items():
 d = b.get("decomposed_fwd")
 if d:
     o.append(f"\n## Decomposed forward (bf16, {d['rows']} rows, 4096 -> r -> 4096; BASELINE configs[4])\n\n"
-             "| r | ms | GFLOP/s (2 T r (n_i + n_o)) | speed-up vs dense 4096^2 (own kernel) | vs dense through torch / hipBLASLt | the pair as two torch linears (hipBLASLt), ms |\n|---|---|---|---|---|---|\n")
+             "| r | ms (`ptd_lowrank_forward`) | GFLOP/s (2 T r (n_i + n_o)) | speed-up vs dense 4096^2 (own kernel) | vs dense through torch / hipBLASLt | the pair as two torch linears (hipBLASLt), ms | the installed module `LowRankLinear`, ms (what it runs) |\n|---|---|---|---|---|---|---|\n")
     for rr in (256, 512, 1024):
         v = d[f"r{rr}"]
         lib = f"{v['speedup_vs_dense_torch_hipblaslt']:.2f}x" if "speedup_vs_dense_torch_hipblaslt" in v else ""
         lp = f"{v['torch_hipblaslt_pair_ms']:.3f}" if "torch_hipblaslt_pair_ms" in v else ""
-        o.append(f"| {rr} | {v['ms']:.3f} | {v['gflops']:.0f} | {v['speedup_vs_dense']:.2f}x | {lib} | {lp} |\n")
+        mod = f"{v['module_ms']:.3f} ({v['module_runs']})" if "module_ms" in v else ""
+        o.append(f"| {rr} | {v['ms']:.3f} | {v['gflops']:.0f} | {v['speedup_vs_dense']:.2f}x | {lib} | {lp} | {mod} |\n")
     o.append(f"\nDense 4096x4096 bf16 on `gemm_bf16_nt_8ph_kernel`: {d['dense_ms']:.3f} ms = {d['dense_tflops']:.0f} TFLOP/s"
              + (f"; the same layer through `torch.nn.functional.linear` (hipBLASLt): {d['dense_torch_hipblaslt_ms']:.3f} ms = "
                 f"{d['dense_torch_hipblaslt_tflops']:.0f} TFLOP/s" if "dense_torch_hipblaslt_ms" in d else "") + ".\n")
