@@ -3,19 +3,19 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-N = 1 workload (BASELINE.json configs[1], SURVEY.md 8d "C2"): dwain.decompose_in_place of one
+ONE workload family at every N (weak scaling, one layer per GPU): dwain.decompose_in_place of a stack of N
 nn.Linear(4096, 4096, bias=False), f32 model, f64 decomposition, B=4 x S=1024 tokens per batch,
-D = 4 calibration steps, M = 2 metric steps, 7 candidate ranks (2048 .. 32), CE loss over the
-4096 outputs, identity finetune_fn.  One "step" = one full decompose_in_place call on a fresh
-copy of the layer, every input already resident in HBM.
+precomputing_covariance_num_splits=1, D = max(4, N) calibration steps, M = 2 metric steps, 7 candidate
+ranks (2048 .. 32), CE loss over the 4096 outputs, identity finetune_fn.  N = 1 is BASELINE.json
+configs[1] (SURVEY.md 8d "C2"); N > 1 is configs[3] in small: calibration steps dealt to the ranks, the N
+covariance sums reduced to their owners (packed lower triangles over RCCL), the N eigendecompositions owned
+one per rank, eigenvectors broadcast, (candidate, metric batch) pairs dealt to the ranks.  One "step" =
+one full decompose_in_place call on a fresh copy of the stack, every input already resident in HBM.
+`python bench.py --gpus N` starts its own N ranks when no launcher did (children, before any GPU call).
 
-N > 1 (weak scaling, one layer per GPU; BASELINE configs[3] in small): a stack of N such layers in
-bf16 (the throughput configuration of SURVEY 8d), dwain with precomputing_covariance_num_splits=1,
-D = max(4, N) calibration steps dealt to the ranks, the N covariance sums reduced to their owners
-(packed lower triangles over RCCL), the N eigendecompositions owned one per rank, eigenvectors
-broadcast, (candidate, metric batch) pairs dealt to the ranks.  With a bf16 stack the model
-forwards of the rank search (2 N GEMMs per pair: the method's own cost) stay small
-next to the sharded part (N x SYRK + N eigendecompositions), which is what the curve measures.
+The same line carries `bf16_stack`: the same family timed once more with a bf16 model (SURVEY 8d's
+throughput configuration).  The method's own whole-model forwards (2 N GEMMs per (candidate, batch) pair,
+SURVEY 3.5) grow with N; in bf16 they stay small next to the sharded part, so that curve shows the sharding.
 
 Prints ONE JSON line (rank 0) with the driver's contract fields plus
   roofline       the dominant kernel of the eigensolver against its bound: frac on SURVEY 8d's
@@ -203,9 +203,7 @@ def decomposed_forward_lines(device):
         # the same pair as two torch.nn.functional.linear calls (hipBLASLt): what apply_decompose_config_in_place's
         # Sequential(Linear, Linear) costs without the fused module
         lib_pair = time_events(lambda: torch.nn.functional.linear(torch.nn.functional.linear(x, a), b), iters=10)
-        # what the installed module (LowRankLinear, inference) runs: it times both forms once per shape and keeps the
-        # faster; "ms" above stays the package's own kernels (ptd_lowrank_forward)
-        from ptdeco_amd import lowrank
+        # the module apply_decompose_config_in_place installs (LowRankLinear): always ptd_lowrank_forward
         from ptdeco_amd.lowrank import fuse_pair
         pair = torch.nn.Sequential(torch.nn.Linear(N_FEAT, r, bias=False), torch.nn.Linear(r, N_FEAT, bias=False))
         pair = fuse_pair(pair).to(device).bfloat16()
@@ -215,8 +213,7 @@ def decomposed_forward_lines(device):
         out[f"r{r}"] = {"ms": t * 1e3, "gflops": fl / t / 1e9, "speedup_vs_dense": dense_t / t,
                         "speedup_vs_dense_torch_hipblaslt": lib_t / t, "torch_hipblaslt_pair_ms": lib_pair * 1e3,
                         "module_ms": mod_t * 1e3,
-                        "module_runs": "library pair" if lowrank._library_choice.get(
-                            (torch.bfloat16, int(t_rows).bit_length(), N_FEAT, r, N_FEAT)) else "package kernels",
+                        "module_runs": "package kernels",
                         "frac_of_bf16_mfma_peak": fl / t / PEAK_BF16_MFMA, "hbm_gbps_algorithmic": by / t / 1e9}
     # MFMA utilisation of the two rank-256 kernels from the committed counter pass (tools/pmc_driver mfma)
     pmc = pmc_file("pmc_mfma_r*.json", ("gemm_f32.hip", "gemm_bf16.hip"))
@@ -273,6 +270,21 @@ def cpu_baseline():
                       f"chosen proportion {prop}"}
 
 
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes of this one
+    (python -m torch.distributed.run, rendezvous on 127.0.0.1) before anything here has touched the GPU, pass
+    their output through (rank 0 prints the JSON line) and return their exit code."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -280,15 +292,19 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip kernel / forward / cpu side measurements")
+    ap.add_argument("--no-bf16-stack", action="store_true", help="skip the second (bf16 model) timed run")
     args = ap.parse_args()
-
-    import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world == 1 and args.gpus > 1:
+        raise SystemExit(launch_ranks(args))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch.distributed as dist
+
     # PTD_BENCH_REHEARSE=1: rehearsal of the N > 1 code path on a one-GPU box -- every rank on cuda:0,
     # gloo transport (RCCL refuses two ranks on one device).  Not a measurement.
     rehearse = os.environ.get("PTD_BENCH_REHEARSE") == "1"
@@ -304,44 +320,61 @@ def main():
     import ptdeco_amd
     from ptdeco_amd import ops
 
+    # ONE workload family at every N (weak scaling, one layer per GPU): a stack of N nn.Linear(4096, 4096), dwain
+    # with the precompute pass (1 split), D = max(4, N) calibration steps.  N = 1 is BASELINE configs[1] (C2).
     n_layers = world
-    d_steps = D_STEPS if world == 1 else max(D_STEPS, world)
-    model0, data, metric = make_workload(n_layers, device, d_steps, 7 * M_STEPS)
-    model0.to(device)
-    data, metric = with_targets(model0, data, device), with_targets(model0, metric, device)
-    model_dtype = torch.float32
-    if world > 1:   # the throughput configuration: bf16 stack (see the module docstring)
-        model_dtype = torch.bfloat16
-        model0.to(model_dtype)
-        data = [{"x": b["x"].to(model_dtype), "targets": b["targets"]} for b in data]
-        metric = [{"x": b["x"].to(model_dtype), "targets": b["targets"]} for b in metric]
+    d_steps = max(D_STEPS, world)
+    model32, data32, metric32 = make_workload(n_layers, device, d_steps, 7 * M_STEPS)
+    model32.to(device)
+    data32, metric32 = with_targets(model32, data32, device), with_targets(model32, metric32, device)
     kw = dict(DWAIN_KW, num_data_steps=d_steps)
-    loss = ce_loss if world == 1 else (lambda b, y: ce_loss(b, y.float()))
-
-    def one_step():
-        model = copy.deepcopy(model0)
-        return ptdeco_amd.dwain.decompose_in_place(
-            module=model, device=device, data_iterator=itertools.cycle(data), loss_fn=loss,
-            metric_iterator=itertools.cycle(metric), finetune_fn=lambda m, d, names: m,
-            precomputing_covariance_num_splits=(1 if world > 1 else None), **kw)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        cfg = one_step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        cfg = one_step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    def family(model_dtype):
+        """(one_step, loss) of the workload with the model and its activations in `model_dtype`."""
+        if model_dtype == torch.float32:
+            model0, data, metric, loss = model32, data32, metric32, ce_loss
+        else:
+            model0 = copy.deepcopy(model32).to(model_dtype)
+            data = [{"x": b["x"].to(model_dtype), "targets": b["targets"]} for b in data32]
+            metric = [{"x": b["x"].to(model_dtype), "targets": b["targets"]} for b in metric32]
+            loss = lambda b, y: ce_loss(b, y.float())  # noqa: E731
+
+        def one_step():
+            model = copy.deepcopy(model0)
+            return ptdeco_amd.dwain.decompose_in_place(
+                module=model, device=device, data_iterator=itertools.cycle(data), loss_fn=loss,
+                metric_iterator=itertools.cycle(metric), finetune_fn=lambda m, d, names: m,
+                precomputing_covariance_num_splits=1, **kw)
+        return one_step
+
+    def timed(one_step):
+        """W untimed steps, then exactly K steps between barrier + synchronize; max over ranks."""
+        cfg = None
+        for _ in range(args.warmup):
+            cfg = one_step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            cfg = one_step()
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        return dt, cfg
+
+    one_step = family(torch.float32)
+    dt, cfg = timed(one_step)
+    what = ("dwain decompose_in_place, stack of %d x nn.Linear(4096,4096) %s (one layer per GPU; N = 1 is BASELINE "
+            "configs[1]), precompute pass (1 split), T=4x1024 tokens/batch, D=%d, M=2, 7 candidate ranks, f64 "
+            "covariance+eigh%s")
+    comm = "; packed-triangle reduce to the layer owners + eigenvector broadcast over RCCL" if world > 1 else ""
 
     result = {
         "metric": "layers decomposed/sec (incl. covariance+SVD)",
@@ -356,16 +389,20 @@ def main():
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": ("dwain decompose_in_place of one nn.Linear(4096,4096) f32 (BASELINE configs[1]), T=4x1024 "
-                                "tokens/batch, D=4, M=2, 7 candidate ranks, f64 covariance+eigh" if world == 1 else
-                                "dwain decompose_in_place, stack of %d x nn.Linear(4096,4096) bf16 (one layer per GPU), "
-                                "precompute pass (1 split), T=4x1024 tokens/batch, D=%d, M=2, 7 candidate ranks, f64 "
-                                "covariance+eigh; packed-triangle reduce to the layer owners + eigenvector broadcast"
-                                % (n_layers, d_steps)),
-                   "model_dtype": str(model_dtype).replace("torch.", ""),
+        "config": {"workload": what % (n_layers, "f32", d_steps, comm),
+                   "model_dtype": "float32",
                    "layers_per_step": n_layers, "parallelism": f"dp{world}" if world > 1 else "single",
                    "ranks_kept": {k: v["__meta__"]["proportion"] for k, v in cfg.items()}},
     }
+    if not args.no_bf16_stack:
+        # the same family with a bf16 model ("model fp32 for parity, bf16 for throughput"), same K / W and
+        # the same barrier protocol: at N > 1 the method's own whole-model forwards (2 N GEMMs per (candidate, batch)
+        # pair) stay small next to the sharded part, so this curve shows the sharding; `value` above stays the f32 one
+        dt16, cfg16 = timed(family(torch.bfloat16))
+        result["bf16_stack"] = {"value": n_layers * args.steps / dt16, "unit": "layers/s",
+                                "ms_per_step": dt16 / args.steps * 1e3, "model_dtype": "bfloat16",
+                                "workload": what % (n_layers, "bf16", d_steps, comm),
+                                "ranks_kept": {k: v["__meta__"]["proportion"] for k, v in cfg16.items()}}
 
     prof = []
     if not args.no_extras:
@@ -459,6 +496,25 @@ def main():
                               "algorithmic_tflops": algo_flops / t / 1e12,
                               "frac_of_f64_mfma_peak_on_algorithmic_flops": algo_flops / t / PEAK_F64_MFMA}
             result["kernels"] = kl
+            # context, not credit: the reference's own device path is torch.linalg.eigh (dwain.py:162) -- the library
+            # eigensolver on the same box and a covariance of the same workload (all n eigenpairs: it has no top-k)
+            try:
+                e = torch.zeros(n, n, dtype=torch.float64, device=device)
+                for b in data32[:D_STEPS]:
+                    ops.syrk_accumulate(e, ops.matmul(b["x"].reshape(-1, N_FEAT), model32.layers[0].weight.T), 1.0 / (BATCH * SEQ))
+                c = ops.cov_finalize(e, D_STEPS, 0.01)
+                torch.linalg.eigh(c)
+                torch.cuda.synchronize()
+                t0l = time.perf_counter()
+                torch.linalg.eigh(c)
+                torch.cuda.synchronize()
+                result["eigh"]["gpu_library_eigh_ms"] = (time.perf_counter() - t0l) * 1e3
+                result["eigh"]["gpu_library_eigh_note"] = ("torch.linalg.eigh on the device, same n and a covariance of the "
+                                                           "same workload, all eigenpairs (context only)")
+                del e, c
+            except Exception as exc:  # the library call is context: never fail the bench for it
+                result["eigh"]["gpu_library_eigh_ms"] = None
+                result["eigh"]["gpu_library_eigh_note"] = f"torch.linalg.eigh failed: {exc}"
         result["kernels"] = {**result.get("kernels", {}), **kernel_lines(device)}
         result["decomposed_fwd"] = decomposed_forward_lines(device)
         if world == 1 and not args.no_cpu_baseline:

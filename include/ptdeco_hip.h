@@ -15,8 +15,11 @@
  *    caller passes workspaces sized by the matching *_workspace_bytes query
  *  - return value: 0 = ok, negative = ptd_status; ptd_last_error() gives the
  *    message of the last failing call on the calling thread
- *  - no global mutable state besides lazily loaded code objects: re-entrant
- *    across streams and devices
+ *  - re-entrant across streams, devices and host threads.  Mutable state is kept per DEVICE and is
+ *    advisory only (it selects between equivalent kernels, never results): lazily loaded code objects,
+ *    the device facts queried once (CU count, architecture, occupancy of the whole-chip kernels), the
+ *    ptd_set_concurrent_chains hint, the count of eigendecompositions this library has in flight on the
+ *    device, and a back-off counter after a whole-chip kernel timed out
  */
 #ifndef PTDECO_HIP_H
 #define PTDECO_HIP_H
@@ -46,8 +49,12 @@ const char* ptd_last_error(void);
 
 /* Hint: the caller is about to run `chains` independent eigendecompositions at once, each on its own stream
  * (the reference has no counterpart: torch.linalg.eigh calls are serial, dwain.py:155-163).  With chains > 1 the
- * solver avoids kernels that claim a whole XCD for milliseconds (the resident tail of the tridiagonalisation), which
- * shorten one chain and stall the others.  Process-wide, default 1; returns the previous value. */
+ * solver avoids kernels that claim a whole XCD or the whole chip for milliseconds (the resident kernels of the
+ * tridiagonalisation), which shorten one chain and stall the others.  Applies to the CURRENT device (hipGetDevice of the
+ * calling thread), default 1; returns the previous value.  Without the hint the library still notices its own
+ * overlapping calls on a device (they take the blocked path), and the whole-chip kernels only run at all on an
+ * unpartitioned 256-CU gfx950 whose occupancy query admits them; every inter-workgroup wait in them is bounded by a
+ * 10 ms wall-clock time-out after which the reduction is repeated on the blocked path. */
 int ptd_set_concurrent_chains(int chains);
 
 /* ---- covariance accumulation ------------------------------------------- */

@@ -30,18 +30,28 @@ class PhaseTimer:
 
     def __init__(self):
         self.spans: list = []
+        self._open: dict = {}   # name -> nesting depth: a span inside a span of the same name is not counted twice
 
     def span(self, name: str):
         import contextlib
 
         @contextlib.contextmanager
         def cm():
+            depth = self._open.get(name, 0)
+            self._open[name] = depth + 1
+            if depth:
+                try:
+                    yield
+                finally:
+                    self._open[name] -= 1
+                return
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             try:
                 yield
             finally:
                 e1.record()
+                self._open[name] -= 1
                 self.spans.append((name, e0, e1))
         return cm()
 
@@ -332,7 +342,13 @@ class MomentCovariance:
 
 
 def _tensor_key(t: torch.Tensor):
-    return (t.data_ptr(), tuple(t.shape), tuple(t.stride()), t.dtype, t._version)
+    """Identity of an input tensor within one forward; None when it cannot be told (inference tensors carry no
+    version counter: such a layer then keeps its own statistics, like mode "off")."""
+    try:
+        version = t._version
+    except RuntimeError:
+        return None
+    return (t.data_ptr(), tuple(t.shape), tuple(t.stride()), t.dtype, version)
 
 
 class SharedInputPool:
@@ -350,8 +366,11 @@ class SharedInputPool:
     the others only when the f64 products W Ex W^T cost less than their D output-side SYRKs (they do for the
     D >= ~32 calibration steps of real runs; with a handful of steps y^T y is cheaper)."""
 
-    RATE_F32 = 100e12  # measured covariance SYRK rate (f32 in, f64 accumulate) on MI355X
-    RATE_F64 = 45e12   # measured f64 MFMA GEMM rate
+    # Tunables of the "auto" decision only (which of two equivalent routes is cheaper; results agree to f64
+    # rounding either way): rates of the covariance SYRK (f32 in, f64 accumulate) and of the f64 MFMA GEMM as
+    # bench.py / profiles/ report them on MI355X.  PTD_SHARE_RATE_SYRK_TFLOPS / PTD_SHARE_RATE_F64_TFLOPS override.
+    RATE_F32 = 100e12
+    RATE_F64 = 45e12
 
     def __init__(self, num_data_steps: int, float64: bool, device: torch.device, mode: Optional[str] = None):
         import os
@@ -360,6 +379,8 @@ class SharedInputPool:
         if self.mode not in ("off", "all", "auto"):
             raise ValueError(f"PTD_SHARE_INPUT_COVARIANCE={self.mode!r}: expected off, all or auto")
         self.num_data_steps, self.float64, self.device = num_data_steps, float64, device
+        self.rate_syrk = float(os.environ.get("PTD_SHARE_RATE_SYRK_TFLOPS", self.RATE_F32 / 1e12)) * 1e12
+        self.rate_f64 = float(os.environ.get("PTD_SHARE_RATE_F64_TFLOPS", self.RATE_F64 / 1e12)) * 1e12
         self.members: list = []
         self.discovered = False
         self.groups: list[list] = []    # for introspection / tests: lists of member names
@@ -393,19 +414,33 @@ class SharedInputPool:
         if mom.step_id != self._step:
             mom.step_id, mom.step_key = self._step, key
             mom.add(x_rows)
-        elif mom.step_key != key:
+        elif mom.step_key != key or key is None:
             raise RuntimeError(f"ptdeco_amd: layer {member.name} shared its input with other layers on the first "
                                "calibration step but not on this one; set PTD_SHARE_INPUT_COVARIANCE=off")
 
     def end_step(self) -> None:
         if self.discovered:
             return
+        # a stand-in called more than once per forward (tied layers, a layer reused across time steps) keeps its own
+        # statistics and accumulates at every call, as the reference does (dwain.py:166-208); so does a layer whose
+        # input tensor has no identity (inference tensors)
+        calls: dict = {}
+        for member, _, _ in self._pending:
+            calls[id(member)] = calls.get(id(member), 0) + 1
         by_key: dict = {}
+        alone: list = []
         for member, x_rows, _ in self._pending:
-            by_key.setdefault(_tensor_key(x_rows), []).append(member)
+            key = _tensor_key(x_rows)
+            if calls[id(member)] > 1 or key is None:
+                if all(member is not a for a, _ in alone):
+                    alone.append((member, x_rows.shape[0]))
+                continue
+            by_key.setdefault(key, []).append(member)
         t_rows = {id(m): x.shape[0] for m, x, _ in self._pending}
         for members in by_key.values():
             self._plan_group(members, t_rows[id(members[0])])
+        for member, rows in alone:
+            self._plan_group([member], rows)
         for m in self.members:
             if m.cov is None:  # not reached by the forward: same error as a tap that saw no input
                 raise RuntimeError(f"layer {m.name} was not reached by the model's forward")
@@ -420,8 +455,8 @@ class SharedInputPool:
         wide = [m for m in members if _input_route_wanted(m.weight.shape[0], n_in, m.top_k)]
         rest = [m for m in members if m not in wide]
         d = self.num_data_steps
-        direct = {id(m): d * t_rows * m.weight.shape[0] ** 2 / self.RATE_F32 for m in rest}
-        explicit = {id(m): (2.0 * m.weight.shape[0] * n_in * n_in + 2.0 * m.weight.shape[0] ** 2 * n_in) / self.RATE_F64
+        direct = {id(m): d * t_rows * m.weight.shape[0] ** 2 / self.rate_syrk for m in rest}
+        explicit = {id(m): (2.0 * m.weight.shape[0] * n_in * n_in + 2.0 * m.weight.shape[0] ** 2 * n_in) / self.rate_f64
                     for m in rest}
         if self.mode == "off" or len(members) < 2:
             shared_wide, shared_rest = [], []
@@ -430,7 +465,7 @@ class SharedInputPool:
         else:
             shared_wide = wide if len(wide) >= 2 or (wide and rest) else []
             gain = [m for m in rest if explicit[id(m)] < direct[id(m)]]
-            moment_cost = 0.0 if shared_wide else d * t_rows * n_in * n_in / self.RATE_F32
+            moment_cost = 0.0 if shared_wide else d * t_rows * n_in * n_in / self.rate_syrk
             saved = sum(direct[id(m)] - explicit[id(m)] for m in gain)
             shared_rest = gain if (gain and saved > moment_cost and (shared_wide or len(gain) >= 2 or wide)) else []
             if shared_rest and not shared_wide:

@@ -13,6 +13,8 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <vector>
 
 #include <hip/hip_ext.h>
@@ -625,12 +627,17 @@ constexpr int RESG_WG = 256;
 constexpr int RES_T = 512;
 constexpr int RES_XS = 3072 + 64;                        // one exchange vector (the widest kernel: R3_MAX)
 constexpr size_t RES_LDS = 150 * 1024;   // two vectors and scalars; sized so that a CU takes exactly one workgroup
-constexpr long RES_SPIN = 2000000L;
+// Waits are bounded in TIME (wall_clock64: the 100 MHz constant clock), not in polls: 10 ms is three orders above
+// the longest legitimate wait (a hand-off: microseconds) and short against the blocked repeat it triggers.  The clock
+// and the shared failure word are looked at every RES_CHECK polls; one workgroup's time-out therefore releases every
+// other workgroup within RES_CHECK polls instead of each of them running into a time-out of its own.
+constexpr unsigned long long RES_TIMEOUT_TICKS = 1000000ULL;
+constexpr int RES_CHECK = 256;
 
 struct ResCtl {
   unsigned long long fp[RESG_WG];       // per workgroup: sequence number of its last published entries
   unsigned reg;    unsigned pad1[31];   // registration (agent scope)
-  int fail;        int pad2[31];        // 1 time-out, 2 XCC mismatch
+  int fail;        int pad2[31];        // 1 time-out, 2 XCC mismatch, 3 the test hook PTD_SYTRD_RESIDENT=2
   int xcc[32];
 };
 
@@ -646,18 +653,27 @@ __device__ __forceinline__ double res_ld_f64(const double* p) {
 // number; a consumer wave watches the 32 numbers (lane s: workgroup s) and then reads the vector.  Against a counter
 // barrier followed by the read this saves one L2 round trip per exchange, and nothing serialises on one address.
 // false after a time-out.
+// one look at the clock and at the failure word; false = give up (after marking the time-out)
+__device__ __forceinline__ bool res_alive(ResCtl* c, unsigned long long& t_start) {
+  if (__hip_atomic_load(&c->fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+  const unsigned long long now = wall_clock64();
+  if (t_start == 0) t_start = now;
+  if (now - t_start > RES_TIMEOUT_TICKS) {
+    __hip_atomic_store(&c->fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return false;
+  }
+  return true;
+}
 template <int NWG>
 __device__ __forceinline__ bool res_wait(const unsigned long long* F, unsigned long long seq, int lane, ResCtl* c) {
-  for (long spin = 0;; ++spin) {
+  unsigned long long t_start = 0;
+  for (int spin = 1;; ++spin) {
     bool ok = true;
 #pragma unroll
     for (int q = 0; q < (NWG + 63) / 64; ++q)
       ok = ok && __hip_atomic_load(F + ((lane + 64 * q) & (NWG - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= seq;
     if (__all(ok)) return true;
-    if (spin > RES_SPIN) {
-      __hip_atomic_store(&c->fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      return false;
-    }
+    if (spin % RES_CHECK == 0 && !res_alive(c, t_start)) return false;
   }
 }
 // GLOBAL: the consumers sit on other XCDs -- entries and number are written through to memory (sc1)
@@ -734,9 +750,10 @@ __global__ __launch_bounds__(RES_T) void sytrd_resident_kernel(double* __restric
       __hip_atomic_store(&ctl->xcc[slot], my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_fetch_add(&ctl->reg, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
       int ok = 1;
-      for (long spin = 0;; ++spin) {
+      unsigned long long t_start = 0;
+      for (int spin = 1;; ++spin) {
         if (__hip_atomic_load(&ctl->reg, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)NWG) break;
-        if (spin > RES_SPIN) { ok = 0; __hip_atomic_store(&ctl->fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        if (spin % RES_CHECK == 0 && !res_alive(ctl, t_start)) { ok = 0; break; }
       }
       if (ok)
         for (int q = 0; q < NWG; ++q)
@@ -2032,9 +2049,51 @@ struct SymvTimer {
   hipEvent_t stop(int j) const { return ev[2 * (size_t)(j / stride) + 1]; }
 };
 
-// first column of the resident tail: the first panel boundary with a trailing order of at most RES_MAX
-// (n itself for orders the tail kernel does not take; PTD_SYTRD_RESIDENT=0 switches it off)
-std::atomic<int> g_concurrent_chains{1};
+// ---- when the resident kernels may run: per-device facts and state
+// They assume the whole chip: 256 workgroups of 150 KB LDS that must ALL be resident at once (one per CU) and, for the
+// tail, 32 of them on one XCC.  That is a fact about the device (an unpartitioned MI355X: 256 CUs = 8 XCCs x 32; a CPX /
+// CU-masked partition has fewer), about the kernel (the occupancy query must admit one such workgroup per CU) and
+// about what else runs (another chain of this process on the device would share the CUs).  Queried once per device;
+// the moving parts are per device as well: the caller's hint (ptd_set_concurrent_chains), the number of
+// eigendecompositions this library has in flight there, and a back-off after a time-out.
+constexpr int MAX_DEVICES = 64;
+struct DeviceState {
+  std::once_flag probed;
+  int cus = 0;
+  bool gfx950 = false;
+  bool occupancy_ok = false;
+  std::atomic<int> chains{1};     // ptd_set_concurrent_chains
+  std::atomic<int> inflight{0};   // eigendecompositions of this process between entry and exit on this device
+  std::atomic<int> skip{0};       // calls that stay on the blocked path after a time-out
+  std::atomic<int> failures{0};
+};
+DeviceState g_dev[MAX_DEVICES];
+
+DeviceState& device_state() {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  return g_dev[(dev < 0 || dev >= MAX_DEVICES) ? 0 : dev];
+}
+
+void probe_device(DeviceState& ds) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return;
+  ds.cus = prop.multiProcessorCount;
+  ds.gfx950 = strncmp(prop.gcnArchName, "gfx950", 6) == 0;
+  // (the attribute belongs to this device's copy of the function; it is set again before every launch)
+  const void* kernels[3] = {reinterpret_cast<const void*>(sytrd_resident_kernel<RES_WG, RES_MAX, false>),
+                            reinterpret_cast<const void*>(sytrd_resident_kernel<RESG_WG, RESG_MAX, true>),
+                            reinterpret_cast<const void*>(sytrd_resident3_kernel)};
+  bool ok = true;
+  for (const void* f : kernels) {
+    int blocks = 0;
+    ok = ok && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RES_LDS) == hipSuccess &&
+         hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, f, RES_T, RES_LDS) == hipSuccess && blocks >= 1;
+  }
+  ds.occupancy_ok = ok;
+}
 
 // PTD_SYTRD_RESIDENT: 0 off; 1 the one-XCD tail only; 2 test hook, see sytrd_f64; 3 whole-chip kernel from a trailing
 // order of 2048, then the one-XCD tail; 4 (default) the half-row whole-chip kernel from 3072 in front of those
@@ -2042,15 +2101,40 @@ int resident_mode() {
   const char* env = getenv("PTD_SYTRD_RESIDENT");
   return env ? atoi(env) : 4;
 }
+// first column of the resident part: the first panel boundary with a trailing order the kernels take; n itself
+// (= nothing resident) when they may not run here and now
 int resident_start(int n) {
   const int mode = resident_mode();
   if (mode == 0 || n < 128) return n;
-  // several chains at once (ptd_set_concurrent_chains): the tail would hold XCC 0 for milliseconds while the other
-  // chains' launches queue behind it (2-block Llama stack, three chains: 1.50 s with it, 1.38 s without)
-  if (g_concurrent_chains.load(std::memory_order_relaxed) > 1) return n;
+  DeviceState& ds = device_state();
+  std::call_once(ds.probed, probe_device, std::ref(ds));
+  // test hook, read at every call: PTD_SYTRD_FAKE_CUS=<count> stands for a device with that many CUs
+  const char* fake = getenv("PTD_SYTRD_FAKE_CUS");
+  const int cus = fake ? atoi(fake) : ds.cus;
+  if (cus != RESG_WG || !ds.gfx950 || !ds.occupancy_ok) return n;
+  // several chains at once -- announced (ptd_set_concurrent_chains) or seen (another call of this process is between
+  // entry and exit on this device): the kernels would hold XCC 0, or the chip, for milliseconds while the other
+  // chains' launches queue behind them (2-block Llama stack, three chains: 1.50 s with, 1.38 s without), and two of
+  // them at once could never all be resident
+  if (ds.chains.load(std::memory_order_relaxed) > 1 || ds.inflight.load(std::memory_order_relaxed) > 1) return n;
+  // after a time-out (someone else's work held CUs): blocked path for a while, doubling per failure
+  int left = ds.skip.load(std::memory_order_relaxed);
+  while (left > 0)
+    if (ds.skip.compare_exchange_weak(left, left - 1, std::memory_order_relaxed)) return n;
   const int cap = n <= RES_MAX ? RES_MAX : (mode == 4 ? R3_MAX : (mode == 3 ? RESG_MAX : RES_MAX));
   return n <= cap ? 0 : (int)align_up((size_t)(n - cap), NB);
 }
+void resident_failed(int status) {
+  if (status == 3) return;   // the test hook is not evidence about the device
+  DeviceState& ds = device_state();
+  const int f = std::min(ds.failures.fetch_add(1) + 1, 14);
+  ds.skip.store(32 << f, std::memory_order_relaxed);
+}
+struct InflightGuard {
+  DeviceState& ds;
+  InflightGuard() : ds(device_state()) { ds.inflight.fetch_add(1); }
+  ~InflightGuard() { ds.inflight.fetch_sub(1); }
+};
 
 int* resident_status(const TridiagPlan& p, char* base) { return &reinterpret_cast<ResCtl*>(base + p.off_res)->fail; }
 
@@ -2131,7 +2215,7 @@ int sytrd_f64(const TridiagPlan& p, char* base, SymvTimer* timer, bool resident,
                          n, t1, n - t1 - 1, Vall, taus, d, e, rctl, X, epoch);
       // test hook: PTD_SYTRD_RESIDENT=2 reports the tail as failed, so that the caller's repeat on the blocked path runs
       if (resident_mode() == 2)
-        PTD_CHECK_HIP(hipMemsetAsync(&rctl->fail, 1, 1, st));
+        PTD_CHECK_HIP(hipMemsetAsync(&rctl->fail, 3, 1, st));
       break;
     }
     const int cols = std::min(NB, n - j0);
@@ -2340,6 +2424,7 @@ int eigh_tridiag(const double* A, int64_t lda, int64_t n, int64_t k, double* eva
     set_error("eigh_tridiag: workspace %zu < required %zu bytes", ws_bytes, p.total);
     return PTD_ERR_WORKSPACE;
   }
+  InflightGuard in_flight;
   char* base = static_cast<char*>(ws);
   double* Aw = reinterpret_cast<double*>(base + p.off_A);
   SymvTimer timer;
@@ -2411,6 +2496,7 @@ int eigh_tridiag(const double* A, int64_t lda, int64_t n, int64_t k, double* eva
     if (h_res) {
       if (getenv("PTD_JACOBI_DEBUG"))
         fprintf(stderr, "[eigh_tridiag] resident tail gave up (status %d): blocked path to the end\n", h_res);
+      resident_failed(h_res);
       resident = false;
       continue;
     }
@@ -2490,7 +2576,7 @@ int eigh_tridiag(const double* A, int64_t lda, int64_t n, int64_t k, double* eva
 
 size_t tridiag_workspace_bytes(int64_t n) { return tridiag_plan(n).total; }
 
-int concurrent_chains_exchange(int chains) { return g_concurrent_chains.exchange(chains); }
+int concurrent_chains_exchange(int chains) { return device_state().chains.exchange(chains); }
 
 // Diagnostic entry: tridiagonalise A and return (d, e, tau) and the eigenvalues of T.
 int tridiagonalize_f64(const double* A, int64_t lda, int64_t n, double* d_out, double* e_out, double* evals_out,
@@ -2501,20 +2587,34 @@ int tridiagonalize_f64(const double* A, int64_t lda, int64_t n, double* d_out, d
     set_error("ptd_tridiagonalize: workspace %zu < required %zu bytes", ws_bytes, p.total);
     return PTD_ERR_WORKSPACE;
   }
+  InflightGuard in_flight;
   char* base = static_cast<char*>(ws);
   double* Aw = reinterpret_cast<double*>(base + p.off_A);
   hipLaunchKernelGGL(copy_pad_kernel, dim3(2048), dim3(256), 0, st, A, lda, (int)n, Aw, p.ld);
   int rc;
-  if (p.two)
+  bool two = p.two;
+  if (two) {
     rc = twostage_reduce(p.ts, base + p.off_ts, Aw, reinterpret_cast<double*>(base + p.off_V), p.ld,
                          reinterpret_cast<double*>(base + p.off_d), reinterpret_cast<double*>(base + p.off_e), nullptr, st);
-  else {
+    if (rc != PTD_OK) return rc;
+    // the failure words of the two-stage reduction (Cholesky breakdown in a panel, chase time-out): as in
+    // eigh_tridiag, such a matrix goes through the one-stage reduction
+    int h_status[2] = {0, 0};
+    PTD_CHECK_HIP(hipMemcpyAsync(h_status, twostage_status(p.ts, base + p.off_ts), 8, hipMemcpyDeviceToHost, st));
+    PTD_CHECK_HIP(hipStreamSynchronize(st));
+    if (h_status[0] || h_status[1]) {
+      two = false;
+      hipLaunchKernelGGL(copy_pad_kernel, dim3(2048), dim3(256), 0, st, A, lda, (int)n, Aw, p.ld);
+    }
+  }
+  if (!two) {
     rc = sytrd_f64(p, base, nullptr, true, st);
     if (rc != PTD_OK) return rc;
     int h_res = 0;
     PTD_CHECK_HIP(hipMemcpyAsync(&h_res, resident_status(p, base), 4, hipMemcpyDeviceToHost, st));
     PTD_CHECK_HIP(hipStreamSynchronize(st));
     if (h_res) {   // the resident tail gave up: once more on the blocked path
+      resident_failed(h_res);
       hipLaunchKernelGGL(copy_pad_kernel, dim3(2048), dim3(256), 0, st, A, lda, (int)n, Aw, p.ld);
       rc = sytrd_f64(p, base, nullptr, false, st);
     }
@@ -2549,6 +2649,14 @@ int band_reduce_f64(const double* A, int64_t lda, int64_t n, int stages, double*
                                         reinterpret_cast<double*>(base + p.off_d),
                                         reinterpret_cast<double*>(base + p.off_e), nullptr, stages, st);
   if (rc != PTD_OK) return rc;
+  int h_status[2] = {0, 0};
+  PTD_CHECK_HIP(hipMemcpyAsync(h_status, twostage_status(p.ts, base + p.off_ts), 8, hipMemcpyDeviceToHost, st));
+  PTD_CHECK_HIP(hipStreamSynchronize(st));
+  if (h_status[0] || h_status[1]) {
+    set_error("ptd_band_reduce: the two-stage reduction refused this matrix (cholesky %d, chase %d)", h_status[0],
+              h_status[1]);
+    return PTD_ERR_UNSUPPORTED;
+  }
   PTD_CHECK_HIP(hipMemcpyAsync(band_out, base + p.off_ts + p.ts.off_band, (size_t)n * TS_LDBAND * 8,
                                hipMemcpyDeviceToDevice, st));
   return PTD_OK;

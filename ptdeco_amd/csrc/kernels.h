@@ -39,7 +39,8 @@ int gemm_f64(const double* A, int64_t sam, int64_t sak, const double* B, int64_t
 
 // eigh_tridiag.hip
 size_t tridiag_workspace_bytes(int64_t n);
-// ptd_set_concurrent_chains: how many eigendecompositions the caller runs at once (returns the previous value)
+// ptd_set_concurrent_chains: how many eigendecompositions the caller runs at once on the current device (returns the
+// previous value)
 int concurrent_chains_exchange(int chains);
 int eigh_tridiag(const double* A, int64_t lda, int64_t n, int64_t k, double* evals, double* evecs, int64_t ldv,
                  void* ws, size_t ws_bytes, double cluster_tol, bool all_values, ptd_eigh_stats* stats, hipStream_t st);

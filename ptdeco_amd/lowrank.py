@@ -14,7 +14,6 @@ pair.
 from __future__ import annotations
 
 import logging
-import os
 
 import torch
 
@@ -82,67 +81,12 @@ def _pair_forward(x2d: torch.Tensor, a: torch.Tensor, b: torch.Tensor, bias) -> 
     return ops.lowrank_forward(x2d, a, b, bias)
 
 
-# (dtype, log2 rows, n_in, r, n_out) -> True when the two library GEMMs beat the package's kernels
-_library_choice: dict = {}
-
-
-def library_pair_is_faster(x2d: torch.Tensor, a: torch.Tensor, b: torch.Tensor, bias) -> bool:
-    """Inference only.  At rank >= 512 the pair is two plain large GEMMs, and torch's nn.Linear path (hipBLASLt's
-    hand-scheduled kernels) runs those 8-28 % faster than ``gemm_bf16_nt_8ph_kernel`` on this chip (DESIGN.md section 7,
-    ``tools/gemm_bf16_vs_lib.py``); below, the package's short-K kernels win (r = 256: 0.089 vs 0.111 ms).  Rather
-    than a fixed threshold the first call of a shape times both once (three blocks of ten launches each, HIP events,
-    best block) and keeps the winner; the decision is logged at INFO.  ``PTD_LOWRANK_AUTOTUNE=0`` keeps every shape on
-    the package's kernels; small problems, autograd and stream capture are never timed (package kernels)."""
-    if os.environ.get("PTD_LOWRANK_AUTOTUNE", "1") == "0":
-        return False
-    rows, n_in, r, n_out = x2d.shape[0], a.shape[1], a.shape[0], b.shape[0]
-    key = (x2d.dtype, int(rows).bit_length(), n_in, r, n_out)
-    hit = _library_choice.get(key)
-    if hit is None:
-        if rows * r * (n_in + n_out) < (1 << 31) or torch.cuda.is_current_stream_capturing():
-            return False  # (not cached: a later, larger or uncaptured call may still be timed)
-
-        def timed(fn) -> float:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(10):
-                fn()
-            e1.record()
-            e1.synchronize()
-            return e0.elapsed_time(e1) / 10.0
-
-        def own_fn():
-            return ops.lowrank_forward(x2d, a, b, bias)
-
-        def lib_fn():
-            return torch.nn.functional.linear(torch.nn.functional.linear(x2d, a), b, bias)
-
-        with torch.no_grad():
-            for _ in range(3):      # (the library picks its kernel on the first calls of a shape; clocks settle)
-                own_fn(); lib_fn()
-            # alternating blocks, the best block of each form: a clock ramp or a neighbour's burst does not decide
-            own, lib = timed(own_fn), timed(lib_fn)
-            for _ in range(2):
-                own, lib = min(own, timed(own_fn)), min(lib, timed(lib_fn))
-        hit = lib < 0.97 * own
-        _library_choice[key] = hit
-        logger.info("ptdeco_amd.LowRankLinear [%d x %d -> %d -> %d, %s]: package kernels %.3f ms, library pair %.3f ms: "
-                    "using the %s", rows, n_in, r, n_out, str(x2d.dtype).replace("torch.", ""), own, lib,
-                    "library pair" if hit else "package kernels")
-    return hit
-
-
 class LowRankLinear(torch.nn.Sequential):
     def forward(self, x: torch.Tensor) -> torch.Tensor:  # type: ignore[override]
         first, second = self[0], self[1]
         if not _use_hip(x, first.weight, "LowRankLinear"):
             return second(first(x))
         x2d = x.reshape(-1, first.in_features)
-        needs_grad = torch.is_grad_enabled() and (x.requires_grad or first.weight.requires_grad
-                                                  or second.weight.requires_grad
-                                                  or (second.bias is not None and second.bias.requires_grad))
-        if not needs_grad and library_pair_is_faster(x2d, first.weight, second.weight, second.bias):
-            return second(first(x))     # two plain GEMMs on the library, chosen by measurement (see above)
         y = _pair_forward(x2d, first.weight, second.weight, second.bias)
         return y.reshape(*x.shape[:-1], second.out_features)
 

@@ -308,3 +308,91 @@ def test_shared_input_pool_rejects_sharing_that_changes_between_steps(monkeypatc
         pool.observe(a, x, x @ a.weight.T)
         with pytest.raises(RuntimeError, match="shared its input"):
             pool.observe(b, x.clone(), x @ b.weight.T)
+
+
+class _TiedNet(torch.nn.Module):
+    """`rec` is applied at two time steps of one forward (a layer reused across time steps); a / b share an input."""
+
+    def __init__(self, d=24):
+        super().__init__()
+        self.rec = torch.nn.Linear(d, d, bias=False)
+        self.a, self.b = torch.nn.Linear(d, 2 * d, bias=False), torch.nn.Linear(d, 2 * d, bias=False)
+        self.out = torch.nn.Linear(2 * d, d, bias=False)
+
+    def forward(self, batch):
+        h = torch.tanh(self.rec(batch["x"]))
+        h = torch.tanh(self.rec(h))
+        return self.out(self.a(h) * torch.sigmoid(self.b(h)))
+
+
+@pytest.mark.parametrize("inference", [False, True])
+def test_precompute_pass_with_a_layer_called_twice_and_with_inference_tensors(inference, monkeypatch):
+    """dwain.py:166-208: a stand-in accumulates at EVERY call and divides by its call count.  A layer called twice
+    per forward keeps its own statistics (it is not put into a sharing group, and it is not an error); under
+    torch.inference_mode() tensors have no version counter, so nothing is shared and nothing raises."""
+    from ptdeco_amd import _engine as eng
+    from ptdeco_amd.dwain import decomposition as dw
+    from ptdeco_amd.sharding import Shard
+
+    monkeypatch.setenv("PTD_SHARE_INPUT_COVARIANCE", "all")
+    g = torch.Generator().manual_seed(11)
+    model = _TiedNet()
+    with torch.no_grad():
+        for p in model.parameters():
+            p.copy_(torch.randn(p.shape, generator=g) / p.shape[-1] ** 0.5)
+    batches = [{"x": torch.randn(64, 24, generator=g) * torch.logspace(0, -1, 24)} for _ in range(2)]
+    names = ["rec", "a", "b", "out"]
+    feats = {n: [] for n in names}
+    hooks = [model.get_submodule(n).register_forward_hook(lambda m, i, o, n=n: feats[n].append(o.detach().clone()))
+             for n in names]
+    with torch.no_grad():
+        for b in batches:
+            model(b)
+    for h in hooks:
+        h.remove()
+    pools = []
+    with cpu_shim.installed(monkeypatch):
+        orig_pool = eng.SharedInputPool
+        monkeypatch.setattr(eng, "SharedInputPool", lambda *a, **k: (pools.append(orig_pool(*a, **k)), pools[-1])[1])
+        ctx = torch.inference_mode() if inference else torch.no_grad()
+        with ctx:
+            u = dw._precompute_covariance_matrix_decompositions(
+                module=model, submodule_names=names, num_data_steps=2, data_iterator=iter(batches), device=CPU,
+                decompose_in_float64=True, shard=Shard.from_env(None), min_rank=2, reduction_factor=0.5)
+    assert pools[0].groups == ([] if inference else [["a", "b"]])
+    for n in names:
+        ys = feats[n]
+        assert len(ys) == (4 if n == "rec" else 2)
+        e = sum((y.double().T @ y.double()) / y.shape[0] for y in ys) / len(ys)   # Eyyt / num calls
+        e = e + torch.eye(e.shape[0], dtype=torch.float64) * (0.01 * torch.diag(e).mean())
+        k = u[n].shape[1]
+        v = torch.linalg.eigh(e)[1][:, -k:]
+        p, p_ref = u[n].double() @ u[n].double().T, v @ v.T
+        assert (p - p_ref).norm().item() <= 1e-5 * k ** 0.5, n
+
+
+def test_phase_timer_counts_a_nested_span_of_the_same_name_once(monkeypatch):
+    from ptdeco_amd import _engine as eng
+
+    class Ev:
+        count = 0
+
+        def __init__(self, enable_timing=True):
+            pass
+
+        def record(self):
+            Ev.count += 1
+
+        def elapsed_time(self, other):
+            return 1.0
+
+    monkeypatch.setattr(torch.cuda, "Event", Ev)
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda: None)
+    t = eng.PhaseTimer()
+    with t.span("comm"):
+        with t.span("comm"):
+            with t.span("B_eigh"):
+                pass
+    with t.span("comm"):
+        pass
+    assert t.totals_ms() == {"B_eigh": 1.0, "comm": 2.0} and Ev.count == 6
