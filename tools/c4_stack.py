@@ -47,25 +47,44 @@ def ce(b, y):
     return torch.nn.functional.cross_entropy(y.float().reshape(-1, y.shape[-1]), b["targets"].reshape(-1), reduction="none")
 
 
-g = torch.Generator().manual_seed(0)
-model = Stack(blocks)
+# (weights and inputs are generated on the device: 7e9 parameters take minutes through the CPU generator)
+g = torch.Generator(device=dev).manual_seed(0)
+with torch.device(dev):
+    model = Stack(blocks).to(dtype)
 with torch.no_grad():
     for p in model.parameters():
-        p.copy_(torch.randn(p.shape, generator=g) / p.shape[1] ** 0.5)
-model.to(dev).to(dtype)
-xs = [torch.randn(1, 2048, D, generator=g).to(dev).to(dtype) for _ in range(12)]
+        p.copy_((torch.randn(p.shape, generator=g, device=dev) / p.shape[1] ** 0.5).to(dtype))
+xs = [torch.randn(1, 2048, D, generator=g, device=dev).to(dtype) for _ in range(12)]
 with torch.no_grad():
     bt = [{"x": x, "targets": model({"x": x}).argmax(-1)} for x in xs]
 torch.cuda.synchronize()
 trace = []
+from ptdeco_amd import _engine as eng
+if os.environ.get("PTD_PHASES"):
+    eng.PHASES = eng.PhaseTimer()   # device-time split (two event records per span)
+import logging, threading
+def heartbeat():
+    # (a line a minute on stderr: a 32-block run takes minutes and gpurun takes silence for a hang)
+    while not done.wait(45.0):
+        print(f"[c4_stack] {time.perf_counter() - t0:.0f} s, {len(trace)} candidates evaluated", file=sys.stderr, flush=True)
+done = threading.Event()
 t0 = time.perf_counter()
+threading.Thread(target=heartbeat, daemon=True).start()
 cfg = ptdeco_amd.dwain.decompose_in_place(
     module=model, device=dev, data_iterator=itertools.cycle(bt), loss_fn=ce, metric_iterator=itertools.cycle(bt[8:]),
     num_data_steps=8, num_metric_steps=2, nsr_final_threshold=1.0, finetune_fn=lambda m, d, n: m,
     blacklisted_module_names=["head"], precomputing_covariance_num_splits=4, trace=trace)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
+done.set()
+phases = None
+if eng.PHASES is not None:
+    phases = {k: round(v, 1) for k, v in eng.PHASES.totals_ms().items()}
+    phases["other_host_and_gaps"] = round(dt * 1e3 - sum(phases.values()), 1)
 layers = 7 * blocks
-print(json.dumps({"blocks": blocks, "dtype": str(dtype), "layers": layers, "seconds": dt, "layers_per_s": layers / dt,
+print(json.dumps({"workload": f"dwain.decompose_in_place, Llama-3-8B-shaped stack, {blocks} blocks x (q, k, v, o, gate, up, down) at "
+                              "4096 / 1024 / 14336 + blacklisted head, [1, 2048, 4096] calibration batches, D = 8, M = 2, "
+                              "precomputing_covariance_num_splits = 4, f64 covariance + eigh, one MI355X",
+                  "phases_ms": phases, "blocks": blocks, "dtype": str(dtype), "layers": layers, "seconds": dt, "layers_per_s": layers / dt,
                   "candidates_evaluated": len(trace), "decomposed": {k: v["__meta__"]["proportion"] for k, v in cfg.items()},
                   "max_mem_gb": torch.cuda.max_memory_allocated() / 2**30}))

@@ -1,0 +1,28 @@
+#!/bin/bash
+# Round-3 GPU pass: the -m gpu suite, the bench line, a two-rank rehearsal of `bench.py --gpus 2` started WITHOUT a
+# launcher, and the 32-block C4 stack.  A step that hits its time limit ends the call (no further GPU step).
+set -o pipefail
+cd $GRAFT_REPO_ROOT
+step() {  # step <seconds> <label> <command...>
+  local limit=$1 label=$2; shift 2
+  timeout -k 10 $limit "$@"; local rc=$?
+  echo "$label rc=$rc"
+  if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "$label hit its limit: stopping"; exit $rc; fi
+  return 0
+}
+PARTS=${1:-tests,bench,rehearse,c4,probe}
+if [[ $PARTS == *tests* ]]; then
+  step 1000 tests bash -c "python -m pytest tests -q -m gpu -x --durations=15 > gpurun_out/gpu_tests_r03.log 2>&1"; tail -25 gpurun_out/gpu_tests_r03.log
+fi
+if [[ $PARTS == *bench* ]]; then
+  step 500 bench bash -c "python bench.py --steps 5 --warmup 1 > gpurun_out/bench_r03.json 2> gpurun_out/bench_r03.err"; cut -c1-400 gpurun_out/bench_r03.json; tail -3 gpurun_out/bench_r03.err
+fi
+if [[ $PARTS == *rehearse* ]]; then
+  step 300 rehearse bash -c "PTD_BENCH_REHEARSE=1 python bench.py --gpus 2 --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/bench_r03_n2.json 2> gpurun_out/bench_r03_n2.err"; cut -c1-400 gpurun_out/bench_r03_n2.json; tail -3 gpurun_out/bench_r03_n2.err
+fi
+if [[ $PARTS == *c4* ]]; then
+  step 900 c4stack bash -c "PTD_PHASES=1 python tools/c4_stack.py 32 bf16 > gpurun_out/c4_stack_32blocks_bf16_r03.json 2> gpurun_out/c4_stack_32.err"; cat gpurun_out/c4_stack_32blocks_bf16_r03.json | cut -c1-1500; tail -3 gpurun_out/c4_stack_32.err
+fi
+if [[ $PARTS == *probe* ]]; then
+  step 300 probe bash -c "python tools/chefsi_probe.py > gpurun_out/chefsi_probe.json 2> gpurun_out/chefsi_probe.err"; cat gpurun_out/chefsi_probe.json; tail -3 gpurun_out/chefsi_probe.err
+fi
