@@ -15,8 +15,13 @@ import torch
 import toy_models as tm
 
 # ---------------------------------------------------------------- C3: falor on a ViT-B/16-width model
+# "head" (768 -> 1000) reads the class token only: 8 rows per step, 40 in all, so 960 of its 1000 covariance
+# eigenvalues are one degenerate (damping) value and the eigenvectors a rank-384 candidate takes from that null
+# space are whatever basis the eigensolver happens to return -- LAPACK's in the reference, another one here.  The
+# reference's own result is arbitrary there; the layer is blacklisted on BOTH sides (falor.py:439-447).
 C3_KW = dict(proportion_threshold=0.9, nsr_final_threshold=0.05, kl_final_threshold=0.01, num_data_steps=5,
-             num_metric_steps=2, use_float64=True, use_mean=False, use_damping=True)
+             num_metric_steps=2, use_float64=True, use_mean=False, use_damping=True,
+             blacklisted_module_names=["head"])
 C3_SEEDS = (0, 1)       # (model, data): see tools/scan_fullwidth_seeds.py
 
 
