@@ -68,13 +68,23 @@ static int eigh_method() {
 }
 
 size_t ptd_eigh_workspace_bytes(int64_t n) {
-  return std::max(eigh_workspace_bytes(n), tridiag_workspace_bytes(n));
+  return std::max(std::max(eigh_workspace_bytes(n), tridiag_workspace_bytes(n)), eigh_filtered_workspace_bytes(n));
 }
 
 static int eigh_dispatch(const double* A, int64_t lda, int64_t n, int64_t k, double* evals, double* evecs,
                          int64_t ldv, void* ws, size_t ws_bytes, int* sweeps_out, bool all_values,
                          ptd_eigh_stats* stats, hipStream_t st) {
   const int method = eigh_method();
+  // a quarter of the spectrum of a large matrix: filtered subspace iteration on the f64 matrix cores; it declines
+  // (flat spectrum, breakdown, residual above tolerance) with PTD_ERR_UNSUPPORTED and the direct route below runs
+  if (method == 2 && A && evals && evecs && ws && lda >= n && k >= 1 && k <= n && ldv >= k && (lda % 2) == 0 &&
+      eigh_filtered_applies(n, k, all_values) && ws_bytes >= eigh_filtered_workspace_bytes(n)) {
+    const int rc = eigh_filtered(A, lda, n, k, evals, evecs, ldv, ws, ws_bytes, stats, st);
+    if (rc != PTD_ERR_UNSUPPORTED) {
+      if (sweeps_out) *sweeps_out = 0;
+      return rc;
+    }
+  }
   if (method != 0 && (method == 1 || n >= 256) && A && evals && evecs && ws && n >= 2 && lda >= n && k >= 1 &&
       k <= n && ldv >= k) {
     const char* ct = getenv("PTD_EIGH_CLUSTER_TOL");

@@ -1,0 +1,724 @@
+// Top-k eigenpairs of a symmetric positive semi-definite f64 matrix by Chebyshev-filtered subspace iteration:
+// the eigensolver of the rank search when it asks for a quarter of the spectrum (dwain on a square layer: the 1024
+// largest of 4096, dwain.py:155-163 + 407-421), built from dense f64 products on the matrix cores instead of a
+// Householder reduction of the whole matrix.
+//
+//   1. Lanczos (4 chains x 32 steps, one SYMV-with-4-vectors launch per step): spectral bounds [lo, hi] and the
+//      density of states; from it the cut `a` with about m = k + k / 4 eigenvalues above it and an estimate of
+//      lambda_k.  If lambda_k is too close to `a` for the filter to separate them in a sensible number of products
+//      (a flat spectrum), the route declines and the caller reduces the matrix directly (eigh_tridiag).
+//   2. X [n, m] random; rounds of X <- T_d((2 C - (a + lo)) / (a - lo)) X by the three-term recurrence (one product
+//      C Y per degree, scaled so that the top eigenvalue stays O(1)), each followed by Cholesky-QR passes
+//      (G = X^T X, shifted on the first pass of a round since cond(X) grows like 150^d; G = L L^T; X <- X L^-T).
+//      Eigendirections above `a` grow like (x + sqrt(x^2 - 1))^d, x > 1 their position relative to the damped
+//      interval; those inside stay bounded by 1.
+//   3. Rayleigh-Ritz: Z = C X, H = X^T Z (m x m), H y = theta y by the dense solver at order m (eigh_tridiag: at
+//      m = 1280 the whole reduction is resident on chip), V = X Y_k.
+//   4. Residual check ||C v - theta v|| = ||Z y - V theta|| for every returned pair (no further product with C);
+//      above the tolerance the route declines as well.
+// Every step is a product on v_mfma_f64_16x16x4_f64 (gemm_f64.hip) except the small factorisations; n = 4096,
+// k = 1024: 15 products with C (0.19 TFLOP each) instead of 4/3 n^3 flop of latency-bound Householder columns.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <utility>
+#include <vector>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace ptd {
+
+int cholesky_f64(double* L, int np, double* linv_ws, int linv_stride, int* fail, hipStream_t st);  // chol.hip
+
+namespace {
+
+constexpr int LZ_NV = 4;        // Lanczos chains (independent start vectors)
+constexpr int LZ_STEPS = 32;
+constexpr int FB = 64;          // block size of the Cholesky factorisation / triangular inverse
+constexpr int FP = 66;          // LDS pitch of a 64 x 64 tile
+
+// ------------------------------------------------------------------------------------------------ small kernels
+__device__ __forceinline__ double hash_uniform(unsigned long long i, unsigned long long seed) {
+  unsigned long long z = (i + 1) * 0x9E3779B97F4A7C15ULL + seed;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  z ^= z >> 31;
+  return (double)(z >> 11) * (2.0 / 9007199254740992.0) - 1.0;   // [-1, 1)
+}
+
+__global__ void fs_random_kernel(double* __restrict__ X, int64_t total, unsigned long long seed) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+    X[i] = hash_uniform((unsigned long long)i, seed);
+}
+
+// Lanczos start: NV interleaved unit vectors [n][NV], previous vectors and W zero
+__global__ __launch_bounds__(1024) void fs_lanczos_init_kernel(double* __restrict__ Qc, double* __restrict__ Qp,
+                                                               double* __restrict__ W, int n) {
+  __shared__ double red[1024];
+  const int v = blockIdx.x, tid = threadIdx.x;
+  double s = 0.0;
+  for (int i = tid; i < n; i += 1024) {
+    const double x = hash_uniform((unsigned long long)i * LZ_NV + v, 0x51ED27ULL);
+    Qc[(int64_t)i * LZ_NV + v] = x;
+    s += x * x;
+  }
+  red[tid] = s;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if (tid < o) red[tid] += red[tid + o];
+    __syncthreads();
+  }
+  const double inv = 1.0 / sqrt(red[0]);
+  for (int i = tid; i < n; i += 1024) {
+    Qc[(int64_t)i * LZ_NV + v] *= inv;
+    Qp[(int64_t)i * LZ_NV + v] = 0.0;
+    W[(int64_t)i * LZ_NV + v] = 0.0;
+  }
+}
+
+// W[r][0..3] = sum_k A[r][k] Q[k][0..3]: a wave owns 4 rows, lanes stride over k; Q (n x 4, 32 n bytes) sits in LDS
+// when it fits (n <= 4096), else it is read through the caches.  HBM-bound: A is streamed once per launch.
+template <bool QLDS>
+__global__ __launch_bounds__(256) void fs_symv4_kernel(const double* __restrict__ A, int64_t lda, int n,
+                                                       const double* __restrict__ Q, double* __restrict__ W) {
+  extern __shared__ __attribute__((aligned(16))) char fs_smem[];
+  double* qs = reinterpret_cast<double*>(fs_smem);
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  if (QLDS) {
+    for (int i = tid; i < n * (LZ_NV / 2); i += 256)
+      reinterpret_cast<double2*>(qs)[i] = reinterpret_cast<const double2*>(Q)[i];
+    __syncthreads();
+  }
+  const double* q = QLDS ? qs : Q;
+  for (int r0 = (blockIdx.x * 4 + wid) * 4; r0 < n; r0 += gridDim.x * 16) {
+    double acc[4][LZ_NV];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int v = 0; v < LZ_NV; ++v) acc[i][v] = 0.0;
+    for (int k = lane; k < n; k += 64) {
+      const double2 q01 = *reinterpret_cast<const double2*>(q + (int64_t)k * LZ_NV);
+      const double2 q23 = *reinterpret_cast<const double2*>(q + (int64_t)k * LZ_NV + 2);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const double av = (r0 + i < n) ? A[(int64_t)(r0 + i) * lda + k] : 0.0;
+        acc[i][0] += av * q01.x;
+        acc[i][1] += av * q01.y;
+        acc[i][2] += av * q23.x;
+        acc[i][3] += av * q23.y;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int v = 0; v < LZ_NV; ++v) {
+        double s = acc[i][v];
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0 && r0 + i < n) W[(int64_t)(r0 + i) * LZ_NV + v] = s;
+      }
+  }
+}
+
+// One Lanczos step of chain v = blockIdx.x: alpha = q.w, w -= alpha q + beta_prev q_prev, beta = |w|, (q_prev, q) <-
+// (q, w / beta).  ab: [NV][2][STEPS] (alphas, betas).
+__global__ __launch_bounds__(1024) void fs_lanczos_step_kernel(double* __restrict__ Qc, double* __restrict__ Qp,
+                                                               const double* __restrict__ W, int n,
+                                                               double* __restrict__ ab, int step) {
+  __shared__ double red[1024];
+  __shared__ double bc;
+  const int v = blockIdx.x, tid = threadIdx.x;
+  double* alpha = ab + (size_t)v * 2 * LZ_STEPS;
+  double* beta = alpha + LZ_STEPS;
+  const double bprev = step > 0 ? beta[step - 1] : 0.0;
+  double s = 0.0;
+  for (int i = tid; i < n; i += 1024) s += Qc[(int64_t)i * LZ_NV + v] * W[(int64_t)i * LZ_NV + v];
+  red[tid] = s;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if (tid < o) red[tid] += red[tid + o];
+    __syncthreads();
+  }
+  const double al = red[0];
+  __syncthreads();
+  double s2 = 0.0;
+  // (n <= 8 * 1024 elements per thread kept in registers would be nicer; the vectors are L2 resident)
+  for (int i = tid; i < n; i += 1024) {
+    const int64_t at = (int64_t)i * LZ_NV + v;
+    const double w = W[at] - al * Qc[at] - bprev * Qp[at];
+    s2 += w * w;
+  }
+  red[tid] = s2;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if (tid < o) red[tid] += red[tid + o];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const double b = sqrt(red[0]);
+    alpha[step] = al;
+    beta[step] = b;
+    bc = b;
+  }
+  __syncthreads();
+  const double inv = bc > 0.0 ? 1.0 / bc : 0.0;
+  for (int i = tid; i < n; i += 1024) {
+    const int64_t at = (int64_t)i * LZ_NV + v;
+    const double qc = Qc[at];
+    const double w = W[at] - al * qc - bprev * Qp[at];
+    Qp[at] = qc;
+    Qc[at] = w * inv;
+  }
+}
+
+// Out = b * Y + c * X (the part of a Chebyshev step that is not the product; the product is added by the GEMM)
+__global__ void fs_axpby_kernel(double* __restrict__ Out, const double* __restrict__ Y, const double* __restrict__ X,
+                                double b, double c, int64_t total2) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total2; i += (int64_t)gridDim.x * blockDim.x) {
+    const double2 y = reinterpret_cast<const double2*>(Y)[i];
+    double2 o;
+    if (X) {
+      const double2 x = reinterpret_cast<const double2*>(X)[i];
+      o.x = b * y.x + c * x.x;
+      o.y = b * y.y + c * x.y;
+    } else {
+      o.x = b * y.x;
+      o.y = b * y.y;
+    }
+    reinterpret_cast<double2*>(Out)[i] = o;
+  }
+}
+
+// G[i][i] += shift_rel * trace(G)  (one workgroup)
+__global__ __launch_bounds__(1024) void fs_shift_kernel(double* __restrict__ G, int m, double shift_rel) {
+  __shared__ double red[1024];
+  const int tid = threadIdx.x;
+  double s = 0.0;
+  for (int i = tid; i < m; i += 1024) s += G[(int64_t)i * m + i];
+  red[tid] = s;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if (tid < o) red[tid] += red[tid + o];
+    __syncthreads();
+  }
+  const double sh = shift_rel * red[0];
+  for (int i = tid; i < m; i += 1024) G[(int64_t)i * m + i] += sh;
+}
+
+// H <- (H + H^T) / 2 in place (tiles above the diagonal own the pair)
+__global__ __launch_bounds__(256) void fs_symmetrize_kernel(double* __restrict__ H, int m) {
+  __shared__ double t[32][33];
+  const int bi = blockIdx.y, bj = blockIdx.x;
+  if (bj < bi) return;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) {
+    const int i = bj * 32 + r, j = bi * 32 + tx;   // element (i, j) of the mirror tile
+    t[r][tx] = (i < m && j < m) ? H[(int64_t)i * m + j] : 0.0;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int i = bi * 32 + r, j = bj * 32 + tx;
+    if (i < m && j < m) {
+      const double v = 0.5 * (H[(int64_t)i * m + j] + t[tx][r]);
+      H[(int64_t)i * m + j] = v;
+      H[(int64_t)j * m + i] = v;
+    }
+  }
+}
+
+// max over the k columns of | T[:, c] - V[:, c] lam[c] |_2 and max |lam|, into out[0], out[1] (bit patterns of
+// non-negative doubles order like integers).  One workgroup per column.
+__global__ __launch_bounds__(256) void fs_residual_kernel(const double* __restrict__ T, int64_t ldt,
+                                                          const double* __restrict__ V, int64_t ldv,
+                                                          const double* __restrict__ lam, int n, int k,
+                                                          unsigned long long* __restrict__ out) {
+  __shared__ double red[256];
+  const int c = blockIdx.x, tid = threadIdx.x;
+  const double l = lam[c];
+  double s = 0.0;
+  for (int i = tid; i < n; i += 256) {
+    const double r = T[(int64_t)i * ldt + c] - V[(int64_t)i * ldv + c] * l;
+    s += r * r;
+  }
+  red[tid] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) red[tid] += red[tid + o];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    atomicMax(out, (unsigned long long)__double_as_longlong(sqrt(red[0])));
+    atomicMax(out + 1, (unsigned long long)__double_as_longlong(fabs(l)));
+  }
+}
+
+// ------------------------------------------------------------------------------------ triangular inverse
+// acc (+)= P Q^T for 64 x 64 row-major LDS tiles of pitch FP; the four waves own 32 x 32 quadrants (2 x 2 MFMA tiles)
+__device__ __forceinline__ void fs_tile_abt(const double* __restrict__ Ps, const double* __restrict__ Qs, int wr, int wc,
+                                            int lane, f64x4 (&acc)[2][2]) {
+  const int l15 = lane & 15, l4 = lane >> 4;
+#pragma unroll
+  for (int kk = 0; kk < FB; kk += 4) {
+    const double a0 = Ps[(wr * 32 + l15) * FP + kk + l4];
+    const double a1 = Ps[(wr * 32 + 16 + l15) * FP + kk + l4];
+    const double b0 = Qs[(wc * 32 + l15) * FP + kk + l4];
+    const double b1 = Qs[(wc * 32 + 16 + l15) * FP + kk + l4];
+    acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+  }
+}
+
+// W = L^-T (upper triangular, row-major [m][m]) from the Cholesky factor L (lower, in G) and the inverses of its
+// diagonal blocks (linv: 64 x 64 per block).  Block column j of L^-1 is one workgroup:
+//   X_jj = L_jj^-1,   X_ij = - L_ii^-1 sum_{j <= k < i} L_ik X_kj   (i > j),
+// written transposed: W[64 j + c][64 i + r] = X_ij[r][c].  Tiles of the column already formed are re-read through
+// L2 (device-scope loads: the vector L1 is not kept coherent with this workgroup's own earlier stores).
+__global__ __launch_bounds__(256) void fs_trtri_kernel(const double* __restrict__ L, int m, const double* __restrict__ linv,
+                                                       double* __restrict__ Wt) {
+  __shared__ __attribute__((aligned(16))) double Ps[FB * FP];
+  __shared__ __attribute__((aligned(16))) double Qs[FB * FP];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wr = wid >> 1, wc = wid & 1;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int nb = m / FB;
+  const int j = blockIdx.x;
+  // zero the part of W below the diagonal block row-wise: rows 64 j.., columns < 64 j
+  for (int e = tid; e < FB * (j * FB); e += 256) {
+    const int r = e / (j * FB), c = e % (j * FB);
+    Wt[(int64_t)(j * FB + r) * m + c] = 0.0;
+  }
+  // diagonal tile: W[64 j + c][64 j + r] = Linv_jj[r][c]
+  for (int e = tid; e < FB * FB; e += 256) {
+    const int c = e >> 6, r = e & 63;
+    Wt[(int64_t)(j * FB + c) * m + j * FB + r] = linv[(size_t)j * FB * FB + (size_t)r * FB + c];
+  }
+  __threadfence();
+  __syncthreads();
+  for (int i = j + 1; i < nb; ++i) {
+    f64x4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
+    for (int k = j; k < i; ++k) {
+      // Ps = L_ik (row-major), Qs[c][kk] = X_kj[kk][c] = W[64 j + c][64 k + kk]: rows of W as they lie
+      for (int e = tid; e < FB * FB / 2; e += 256) {
+        const int r = e >> 5, c2 = (e & 31) * 2;
+        *reinterpret_cast<double2*>(&Ps[r * FP + c2]) =
+            *reinterpret_cast<const double2*>(L + (int64_t)(i * FB + r) * m + k * FB + c2);
+        const double* src = Wt + (int64_t)(j * FB + r) * m + k * FB + c2;
+        Qs[r * FP + c2] = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        Qs[r * FP + c2 + 1] = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __syncthreads();
+      fs_tile_abt(Ps, Qs, wr, wc, lane, acc);      // acc[r][c] += sum_kk L_ik[r][kk] X_kj[kk][c]
+      __syncthreads();
+    }
+    // S -> Qs transposed (Qs[c][r] = S[r][c]), Ps = Linv_ii; X_ij = - Linv_ii S
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = wr * 32 + a * 16 + l4 + 4 * r, col = wc * 32 + b * 16 + l15;
+          Qs[col * FP + row] = acc[a][b][r];
+        }
+    for (int e = tid; e < FB * FB / 2; e += 256) {
+      const int r = e >> 5, c2 = (e & 31) * 2;
+      *reinterpret_cast<double2*>(&Ps[r * FP + c2]) =
+          *reinterpret_cast<const double2*>(linv + (size_t)i * FB * FB + (size_t)r * FB + c2);
+    }
+    __syncthreads();
+    f64x4 out[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) out[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
+    fs_tile_abt(Ps, Qs, wr, wc, lane, out);        // out[r][c] = sum_q Linv_ii[r][q] S[q][c]
+    __syncthreads();
+    // W[64 j + c][64 i + r] = - out[r][c]: stage through LDS so that the stores run along rows of W
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = wr * 32 + a * 16 + l4 + 4 * r, col = wc * 32 + b * 16 + l15;
+          Ps[col * FP + row] = -out[a][b][r];
+        }
+    __syncthreads();
+    for (int e = tid; e < FB * FB / 2; e += 256) {
+      const int c = e >> 5, r2 = (e & 31) * 2;
+      double* dst = Wt + (int64_t)(j * FB + c) * m + i * FB + r2;
+      __hip_atomic_store(dst, Ps[c * FP + r2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(dst + 1, Ps[c * FP + r2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+// eigenvalues of the symmetric tridiagonal (d, e) by implicit QL, with the first components of the normalised
+// eigenvectors in z (on entry z = e_1).  d, e, z of length n; e[i] couples i and i + 1.  false: no convergence.
+bool tridiag_ql_first_row(int n, double* d, double* e, double* z) {
+  if (n <= 0) return true;
+  e[n - 1] = 0.0;
+  for (int l = 0; l < n; ++l) {
+    int iter = 0, m;
+    do {
+      for (m = l; m < n - 1; ++m) {
+        const double dd = fabs(d[m]) + fabs(d[m + 1]);
+        if (fabs(e[m]) <= 2.3e-16 * dd) break;
+      }
+      if (m != l) {
+        if (iter++ == 80) return false;
+        double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
+        double r = hypot(g, 1.0);
+        g = d[m] - d[l] + e[l] / (g + copysign(r, g));
+        double s = 1.0, c = 1.0, p = 0.0;
+        int i;
+        for (i = m - 1; i >= l; --i) {
+          double f = s * e[i];
+          const double b = c * e[i];
+          e[i + 1] = r = hypot(f, g);
+          if (r == 0.0) {
+            d[i + 1] -= p;
+            e[m] = 0.0;
+            break;
+          }
+          s = f / r;
+          c = g / r;
+          g = d[i + 1] - p;
+          r = (d[i] - g) * s + 2.0 * c * b;
+          p = s * r;
+          d[i + 1] = g + p;
+          g = c * r - b;
+          f = z[i + 1];
+          z[i + 1] = s * z[i] + c * f;
+          z[i] = c * z[i] - s * f;
+        }
+        if (r == 0.0 && i >= l) continue;
+        d[l] -= p;
+        e[l] = g;
+        e[m] = 0.0;
+      }
+    } while (m != l);
+  }
+  return true;
+}
+
+struct FilterPlan {
+  int m;
+  size_t off_X, off_Y, off_Z, off_H, off_G, off_W, off_linv, off_Yk, off_lam, off_lz, off_ab, off_flags, off_eigh;
+  size_t eigh_bytes, total;
+};
+
+int filter_block(int64_t n, int64_t k) {
+  // k + 25 % (at least 128 more), a multiple of 320 = lcm(64: Cholesky blocks, 80: column tile of the products)
+  const int64_t want = k + std::max<int64_t>(k / 4, 128);
+  return (int)std::min<int64_t>(align_up((size_t)want, 320), n / 128 * 128);
+}
+
+FilterPlan filter_plan(int64_t n, int64_t k) {
+  FilterPlan p{};
+  p.m = filter_block(n, k);
+  const size_t m = (size_t)p.m;
+  size_t o = 0;
+  auto take = [&](size_t bytes) { size_t at = o; o += align_up(bytes, 256); return at; };
+  p.off_X = take((size_t)n * m * 8);
+  p.off_Y = take((size_t)n * m * 8);
+  p.off_Z = take((size_t)n * m * 8);
+  p.off_H = take(m * m * 8);
+  p.off_G = take(m * m * 8);
+  p.off_W = take(m * m * 8);
+  p.off_linv = take((m / FB) * FB * FB * 8);
+  p.off_Yk = take(m * (size_t)k * 8);
+  p.off_lam = take(m * 8);
+  p.off_lz = take((size_t)3 * n * LZ_NV * 8);
+  p.off_ab = take((size_t)LZ_NV * 2 * LZ_STEPS * 8);
+  p.off_flags = take(256);
+  p.eigh_bytes = tridiag_workspace_bytes((int64_t)m);
+  p.off_eigh = take(p.eigh_bytes);
+  p.total = o;
+  return p;
+}
+
+double env_double(const char* name, double dflt) {
+  const char* e = getenv(name);
+  return e ? atof(e) : dflt;
+}
+
+}  // namespace
+
+bool eigh_filtered_applies(int64_t n, int64_t k, bool all_values) {
+  const char* e = getenv("PTD_EIGH_FILTERED");
+  const int mode = e ? atoi(e) : 1;       // 0 off, 1 auto, 2 whenever the shapes allow (tests)
+  if (mode == 0 || all_values) return false;
+  if (n % 128 != 0 || k < 32) return false;
+  if (filter_block(n, k) > n / 2) return false;           // the subspace must stay well below the matrix order
+  if (mode >= 2) return n >= 512;
+  return n >= 2048 && 3 * k <= n;
+}
+
+size_t eigh_filtered_workspace_bytes(int64_t n) {
+  // the largest request the route accepts at this order
+  if (n % 128 != 0 || n < 512) return 0;
+  int64_t k = n / 3;
+  while (k >= 32 && filter_block(n, k) > n / 2) k -= 32;
+  return k >= 32 ? filter_plan(n, k).total : 0;
+}
+
+// PTD_OK, or PTD_ERR_UNSUPPORTED when the route declines (flat spectrum, a breakdown, residual above tolerance): the
+// outputs are then unspecified and the caller takes the direct route.
+int eigh_filtered(const double* A, int64_t lda, int64_t n, int64_t k, double* evals, double* evecs, int64_t ldv,
+                  void* ws, size_t ws_bytes, ptd_eigh_stats* stats, hipStream_t st) {
+  const FilterPlan p = filter_plan(n, k);
+  if (ws_bytes < p.total) {
+    set_error("eigh_filtered: workspace %zu < required %zu bytes", ws_bytes, p.total);
+    return PTD_ERR_WORKSPACE;
+  }
+  const bool debug = getenv("PTD_JACOBI_DEBUG") != nullptr;
+  const int m = p.m;
+  char* base = static_cast<char*>(ws);
+  double* X = reinterpret_cast<double*>(base + p.off_X);
+  double* Y = reinterpret_cast<double*>(base + p.off_Y);
+  double* Z = reinterpret_cast<double*>(base + p.off_Z);
+  double* H = reinterpret_cast<double*>(base + p.off_H);
+  double* G = reinterpret_cast<double*>(base + p.off_G);
+  double* Wt = reinterpret_cast<double*>(base + p.off_W);
+  double* linv = reinterpret_cast<double*>(base + p.off_linv);
+  double* Yk = reinterpret_cast<double*>(base + p.off_Yk);
+  double* lam = reinterpret_cast<double*>(base + p.off_lam);
+  double* Qc = reinterpret_cast<double*>(base + p.off_lz);
+  double* Qp = Qc + (size_t)n * LZ_NV;
+  double* Wl = Qp + (size_t)n * LZ_NV;
+  double* ab = reinterpret_cast<double*>(base + p.off_ab);
+  int* fail = reinterpret_cast<int*>(base + p.off_flags);
+  unsigned long long* resid = reinterpret_cast<unsigned long long*>(base + p.off_flags + 64);
+
+  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  if (stats) {
+    memset(stats, 0, sizeof(*stats));
+    stats->method = 3;
+    for (auto& e : ev) PTD_CHECK_HIP(hipEventCreate(&e));
+    PTD_CHECK_HIP(hipEventRecord(ev[0], st));
+  }
+  auto cleanup = [&]() {
+    for (auto& e : ev)
+      if (e) (void)hipEventDestroy(e);
+  };
+  auto decline = [&](const char* why) {
+    if (debug) fprintf(stderr, "[eigh_filtered] n=%lld k=%lld declines: %s\n", (long long)n, (long long)k, why);
+    set_error("eigh_filtered: %s", why);
+    cleanup();
+    return PTD_ERR_UNSUPPORTED;
+  };
+
+  // ---- 1. Lanczos: bounds and density of states
+  PTD_CHECK_HIP(hipMemsetAsync(base + p.off_flags, 0, 256, st));
+  hipLaunchKernelGGL(fs_lanczos_init_kernel, dim3(LZ_NV), dim3(1024), 0, st, Qc, Qp, Wl, (int)n);
+  const bool qlds = (size_t)n * LZ_NV * 8 <= 128 * 1024;
+  if (qlds)
+    PTD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fs_symv4_kernel<true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+  const int symv_grid = (int)std::min<int64_t>(256, ceil_div(n, 16));
+  for (int s = 0; s < LZ_STEPS; ++s) {
+    if (qlds)
+      hipLaunchKernelGGL((fs_symv4_kernel<true>), dim3(symv_grid), dim3(256), (size_t)n * LZ_NV * 8, st, A, lda, (int)n,
+                         Qc, Wl);
+    else
+      hipLaunchKernelGGL((fs_symv4_kernel<false>), dim3(symv_grid), dim3(256), 0, st, A, lda, (int)n, Qc, Wl);
+    hipLaunchKernelGGL(fs_lanczos_step_kernel, dim3(LZ_NV), dim3(1024), 0, st, Qc, Qp, Wl, (int)n, ab, s);
+  }
+  PTD_CHECK_LAUNCH("eigh_filtered lanczos");
+  double h_ab[LZ_NV * 2 * LZ_STEPS];
+  PTD_CHECK_HIP(hipMemcpyAsync(h_ab, ab, sizeof(h_ab), hipMemcpyDeviceToHost, st));
+  // (the random start of the filter does not depend on the bounds: queue it behind the copy)
+  hipLaunchKernelGGL(fs_random_kernel, dim3(2048), dim3(256), 0, st, X, (int64_t)n * m, 0xC0FFEEULL);
+  PTD_CHECK_HIP(hipStreamSynchronize(st));
+  if (stats) PTD_CHECK_HIP(hipEventRecord(ev[1], st));
+
+  std::vector<std::pair<double, double>> nodes;   // (theta, weight), weights of one chain sum to 1 / NV
+  double lo = INFINITY, hi = -INFINITY;
+  for (int v = 0; v < LZ_NV; ++v) {
+    double d[LZ_STEPS], e[LZ_STEPS], z[LZ_STEPS];
+    int len = LZ_STEPS;
+    for (int i = 0; i < LZ_STEPS; ++i) {
+      d[i] = h_ab[v * 2 * LZ_STEPS + i];
+      e[i] = h_ab[v * 2 * LZ_STEPS + LZ_STEPS + i];
+      z[i] = i == 0 ? 1.0 : 0.0;
+      if (!std::isfinite(d[i]) || !std::isfinite(e[i])) return decline("non-finite Lanczos coefficients");
+      if (i < len - 1 && !(e[i] > 0.0)) len = i + 1;   // an invariant subspace: the chain ends here
+    }
+    const double blast = e[len - 1];
+    if (!tridiag_ql_first_row(len, d, e, z)) return decline("Lanczos tridiagonal did not converge");
+    for (int i = 0; i < len; ++i) nodes.emplace_back(d[i], z[i] * z[i] / LZ_NV);
+    // |beta_last| bounds how far a Ritz value can sit inside the spectrum's edge
+    for (int i = 0; i < len; ++i) {
+      lo = std::min(lo, d[i] - fabs(blast));
+      hi = std::max(hi, d[i] + fabs(blast));
+    }
+  }
+  std::sort(nodes.begin(), nodes.end(), [](const auto& x, const auto& y) { return x.first > y.first; });
+  // theta with an estimated `count` eigenvalues above it (piecewise linear in the cumulative weight)
+  auto quantile = [&](double count) {
+    double cum = 0.0, prev_cum = 0.0, prev_theta = nodes.front().first;
+    for (const auto& nd : nodes) {
+      prev_cum = cum;
+      cum += nd.second * (double)n;
+      if (cum >= count) {
+        const double t = cum > prev_cum ? (count - prev_cum) / (cum - prev_cum) : 1.0;
+        return prev_theta + t * (nd.first - prev_theta);
+      }
+      prev_theta = nd.first;
+    }
+    return nodes.back().first;
+  };
+  const double theta_max = nodes.front().first;
+  const double a_cut = quantile((double)k + 0.9 * (double)(m - k));
+  const double lam_k = quantile(1.05 * (double)k);
+  lo = std::min(lo, a_cut);
+  if (!(hi > 0.0) || !(a_cut > lo) || !(lam_k > a_cut) || (a_cut - lo) < 1e-10 * fabs(hi))
+    return decline("degenerate spectral bounds");
+  const double ee = 0.5 * (a_cut - lo), cc = 0.5 * (a_cut + lo);
+  const double xk = (lam_k - cc) / ee;
+  const double growth = xk + sqrt(xk * xk - 1.0);
+  const double tol = env_double("PTD_EIGH_FILTER_TOL", 1e-10);     // residual / |lambda_max| accepted
+  const int max_products = (int)env_double("PTD_EIGH_FILTER_MAX_PRODUCTS", 24);
+  // measured on covariance spectra: the residual falls like 0.05 g^-d with g about three quarters of the way from 1
+  // to the asymptotic factor (rounds restart the polynomial; the neighbours of the cut grow a little as well)
+  const double g_eff = 1.0 + 0.75 * (growth - 1.0);
+  int degree = (int)ceil(log(0.05 / tol) / log(g_eff)) + 1;
+  degree = std::max(degree, 4);
+  if (debug)
+    fprintf(stderr, "[eigh_filtered] n=%lld k=%lld m=%d: lo %.3e a %.3e lambda_k~%.3e hi %.3e growth %.2f/product -> "
+                    "%d products\n", (long long)n, (long long)k, m, lo, a_cut, lam_k, hi, growth, degree);
+  if (!(growth > 1.0) || degree > max_products) return decline("spectrum too flat for the filter");
+  // rounds of at most 6 products (cond(X) grows ~150^d), the last one at most 4 (it sets the final accuracy)
+  std::vector<int> rounds;
+  {
+    const int last = std::min(4, degree);
+    int rest = degree - last;
+    const int nr = (int)ceil_div(rest, 6);
+    for (int r = 0; r < nr; ++r) {
+      const int d = (int)ceil_div(rest, nr - r);
+      rounds.push_back(d);
+      rest -= d;
+    }
+    rounds.push_back(last);
+  }
+
+  // ---- 2. filter rounds
+  const int64_t tot2 = (int64_t)n * m / 2;
+  const double shift_rel = env_double("PTD_EIGH_FILTER_SHIFT", 6e-13);
+  int products = 0, rc = PTD_OK;
+  auto chol_pass = [&](bool shifted) -> int {
+    // G = X^T X (K split: the tiles of an m x m product do not fill the chip), G = L L^T, W = L^-T, X <- X W
+    PTD_CHECK_HIP(hipMemsetAsync(G, 0, (size_t)m * m * 8, st));
+    int r2 = gemm_f64(X, 1, m, X, m, 1, G, m, m, m, n, 1.0, true, 3, st);
+    if (r2 != PTD_OK) return r2;
+    if (shifted) hipLaunchKernelGGL(fs_shift_kernel, dim3(1), dim3(1024), 0, st, G, m, shift_rel);
+    r2 = cholesky_f64(G, m, linv, FB * FB, fail, st);
+    if (r2 != PTD_OK) return r2;
+    hipLaunchKernelGGL(fs_trtri_kernel, dim3(m / FB), dim3(256), 0, st, G, m, linv, Wt);
+    r2 = gemm_f64(X, m, 1, Wt, m, 1, Y, m, n, m, m, 1.0, false, 1, st);
+    std::swap(X, Y);
+    return r2;
+  };
+  for (size_t ri = 0; ri < rounds.size(); ++ri) {
+    const int d = rounds[ri];
+    // Y_1 = s1 / e (C - c) X;  Y_{j+1} = 2 s_{j+1} / e (C - c) Y_j - s_j s_{j+1} Y_{j-1},  s_{j+1} = 1 / (2 / s1 - s_j)
+    const double s1 = ee / (hi - cc);
+    double sg = s1;
+    hipLaunchKernelGGL(fs_axpby_kernel, dim3(2048), dim3(256), 0, st, Y, X, (const double*)nullptr, -cc * s1 / ee, 0.0,
+                       tot2);
+    rc = gemm_f64(A, lda, 1, X, m, 1, Y, m, n, m, n, s1 / ee, true, 1, st);
+    if (rc != PTD_OK) { cleanup(); return rc; }
+    ++products;
+    // (X, Y) = (Y_{j-1}, Y_j); Z receives Y_{j+1}
+    for (int j = 2; j <= d; ++j) {
+      const double sn = 1.0 / (2.0 / s1 - sg);
+      hipLaunchKernelGGL(fs_axpby_kernel, dim3(2048), dim3(256), 0, st, Z, Y, X, -2.0 * sn * cc / ee, -sg * sn, tot2);
+      rc = gemm_f64(A, lda, 1, Y, m, 1, Z, m, n, m, n, 2.0 * sn / ee, true, 1, st);
+      if (rc != PTD_OK) { cleanup(); return rc; }
+      ++products;
+      double* t = X; X = Y; Y = Z; Z = t;
+      sg = sn;
+    }
+    std::swap(X, Y);   // X = the filtered block
+    const bool last = ri + 1 == rounds.size();
+    rc = chol_pass(true);
+    if (rc == PTD_OK) rc = chol_pass(false);
+    if (rc == PTD_OK && last) rc = chol_pass(false);
+    if (rc != PTD_OK) { cleanup(); return rc; }
+  }
+  PTD_CHECK_LAUNCH("eigh_filtered filter");
+  if (stats) PTD_CHECK_HIP(hipEventRecord(ev[2], st));
+
+  // ---- 3. Rayleigh-Ritz
+  rc = gemm_f64(A, lda, 1, X, m, 1, Z, m, n, m, n, 1.0, false, 1, st);           // Z = C X
+  if (rc != PTD_OK) { cleanup(); return rc; }
+  ++products;
+  PTD_CHECK_HIP(hipMemsetAsync(H, 0, (size_t)m * m * 8, st));
+  rc = gemm_f64(X, 1, m, Z, m, 1, H, m, m, m, n, 1.0, true, 3, st);              // H = X^T Z
+  if (rc != PTD_OK) { cleanup(); return rc; }
+  hipLaunchKernelGGL(fs_symmetrize_kernel, dim3((unsigned)ceil_div(m, 32), (unsigned)ceil_div(m, 32)), dim3(256), 0, st,
+                     H, m);
+  if (stats) PTD_CHECK_HIP(hipEventRecord(ev[3], st));
+  rc = eigh_tridiag(H, m, m, k, lam, Yk, k, base + p.off_eigh, p.eigh_bytes, 1e-10, false, nullptr, st);
+  if (rc == PTD_ERR_UNSUPPORTED) return decline("clustered Ritz values");
+  if (rc != PTD_OK) { cleanup(); return rc; }
+  if (stats) PTD_CHECK_HIP(hipEventRecord(ev[4], st));
+  rc = gemm_f64(X, m, 1, Yk, k, 1, evecs, ldv, n, k, m, 1.0, false, 1, st);      // V = X Y_k
+  if (rc != PTD_OK) { cleanup(); return rc; }
+
+  // ---- 4. residuals: C V - V theta = Z Y_k - V theta
+  double* T = Y;
+  rc = gemm_f64(Z, m, 1, Yk, k, 1, T, k, n, k, m, 1.0, false, 1, st);
+  if (rc != PTD_OK) { cleanup(); return rc; }
+  hipLaunchKernelGGL(fs_residual_kernel, dim3((unsigned)k), dim3(256), 0, st, T, (int64_t)k, evecs, ldv, lam + (m - k),
+                     (int)n, (int)k, resid);
+  // eigenvalues: the k largest at the end of evals[n], NaN below (the convention of ptd_eigh_topk with all_values = 0)
+  PTD_CHECK_HIP(hipMemsetAsync(evals, 0xFF, (size_t)(n - k) * 8, st));
+  PTD_CHECK_HIP(hipMemcpyAsync(evals + (n - k), lam + (m - k), (size_t)k * 8, hipMemcpyDeviceToDevice, st));
+  struct { int fail; int pad[15]; unsigned long long res, lmax; } h{};
+  PTD_CHECK_HIP(hipMemcpyAsync(&h, base + p.off_flags, sizeof(h), hipMemcpyDeviceToHost, st));
+  if (stats) PTD_CHECK_HIP(hipEventRecord(ev[5], st));
+  PTD_CHECK_HIP(hipStreamSynchronize(st));
+  double res, lmax;
+  memcpy(&res, &h.res, 8);
+  memcpy(&lmax, &h.lmax, 8);
+  if (debug)
+    fprintf(stderr, "[eigh_filtered] %d products, chol fail %d, max residual %.3e = %.2e |lambda_max| (theta_max %.3e)\n",
+            products, h.fail, res, res / std::max(lmax, 1e-300), theta_max);
+  if (h.fail) return decline("Cholesky breakdown in an orthonormalisation pass");
+  if (!(res <= tol * lmax)) return decline("residual above the tolerance");
+  if (stats) {
+    float t01 = 0, t12 = 0, t23 = 0, t34 = 0, t45 = 0;
+    (void)hipEventElapsedTime(&t01, ev[0], ev[1]);
+    (void)hipEventElapsedTime(&t12, ev[1], ev[2]);
+    (void)hipEventElapsedTime(&t23, ev[2], ev[3]);
+    (void)hipEventElapsedTime(&t34, ev[3], ev[4]);
+    (void)hipEventElapsedTime(&t45, ev[4], ev[5]);
+    // ms: 0 Lanczos bounds, 1 filter rounds (products with C + orthonormalisation), 2 the m x m eigenproblem,
+    // 3 Rayleigh-Ritz products + back-multiplication + residuals; work[1] = flop of the products with C
+    stats->ms[0] = t01;
+    stats->ms[1] = t12;
+    stats->ms[2] = t34;
+    stats->ms[3] = t23 + t45;
+    stats->launches[0] = LZ_STEPS;
+    stats->launches[1] = products;
+    stats->launches[2] = m;
+    stats->work[1] = 2.0 * (double)n * (double)n * (double)m * (double)products;
+    stats->total_ms = t01 + t12 + t23 + t34 + t45;
+  }
+  cleanup();
+  return PTD_OK;
+}
+
+}  // namespace ptd

@@ -10,6 +10,7 @@
 // image [k][m] with pitch 80 doubles: the one-f64-per-lane operand read (16 consecutive m of
 // row k, k = lane >> 4) then touches all 64 banks exactly once per half wave.
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -156,6 +157,204 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(const GemmF64Args a) {
       }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// LDS-DMA kernel for the large products of the eigensolver (C X, X^T X, X R of the filtered subspace iteration; the
+// operands of eigh_factored): B is [K][N] with N contiguous, A is either [M][K] with K contiguous (AM = false) or
+// [K][M] with M contiguous (AM = true: A^T B of a row-major A).  v_mfma_f64_16x16x4_f64 takes 64 cycles for 2048
+// flop, so a wave needs only one 8-byte LDS read per operand fragment and 16 passes of matrix work: what bounds the
+// 64 x 64 kernel above (38 TFLOP/s on 4096 x 4096 x 1280) is not LDS or issue but the bytes it pulls through L2 (a
+// 64 x 64 tile re-reads 16 KiB per 16-deep K step for 16 MFMAs a wave) and two full barriers with a register-staged
+// write pass per step.  Here: 128 x (16 NT) tile, 4 waves stacked in M (32 rows x 16 NT columns = 2 x NT
+// accumulators each), K step 16, both operands staged by global_load_lds (16 B per lane, 1 KiB per instruction) into
+// two buffers, the next step's DMA in flight across the barriers (counted vmcnt, raw s_barrier); two workgroups per
+// CU cover each other's barrier stalls.
+//   A image (AM = false): [128 rows][16 k] = 128-byte rows; the 16-byte chunks of row r are XOR-swizzled with
+//     (r >> 1) & 7 on the SOURCE address, so the 16 rows x 16 B a half wave reads for one fragment (lane: row l & 15,
+//     k = kk + (l >> 4)) cover all 64 banks once.
+//   B image, and A when AM: [16 k][W] rows of W = 16 NT (or 128) doubles as they lie in memory; a half wave reads 16
+//     consecutive doubles of two neighbouring k rows: conflict-free when the row stride is an odd multiple of 128 B,
+//     otherwise chunk index ^= 8 (k & 1) on the source address moves odd rows by half a bank row.
+constexpr int GM = 128, GK = 16;
+
+template <int NT, bool AM>
+struct GldsCfg {
+  static constexpr int BN = 16 * NT;
+  static constexpr int A_BYTES = GM * GK * 8;                    // 16 KiB either layout
+  static constexpr int B_BYTES = GK * BN * 8;
+  static constexpr int A_PIECES = A_BYTES / 1024;                // 16: 4 per wave
+  static constexpr int B_PIECES = B_BYTES / 1024;                // 2 NT
+  static constexpr int B_PER_WAVE = (B_PIECES + 3) / 4;
+  static constexpr int STAGE = A_BYTES + B_BYTES;
+  static constexpr int PER_WAVE = 4 + B_PER_WAVE;                // DMA instructions a wave issues per stage
+};
+
+template <int NT, bool AM>
+__global__ __launch_bounds__(256, 2) void gemm_f64_glds_kernel(const GemmF64Args a) {
+  using Cfg = GldsCfg<NT, AM>;
+  constexpr int BN = Cfg::BN;
+  __shared__ __attribute__((aligned(16))) char lds[2 * Cfg::STAGE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // a contiguous run of tiles per XCD (blocks b and b + 8 share one), row-major over (M tile, N tile) inside it
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int tiles_n = a.N / BN;
+  const int ti = wg / tiles_n, tj = wg % tiles_n;
+  const int m0 = ti * GM, n0 = tj * BN;
+  const int kbeg = blockIdx.y * a.kchunk;
+  const int kend = min(a.K, kbeg + a.kchunk);
+  const int nk = (kend - kbeg) / GK;
+
+  // ---- DMA sources of this lane (advance by one K step per stage)
+  const double* srcA[4];
+  const double* srcB[Cfg::B_PER_WAVE];
+  int64_t stepA, stepB = (int64_t)GK * a.sbk;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int p = wid + 4 * j;                       // piece: bytes [1024 p, 1024 p + 1024) of the A image
+    if (!AM) {
+      const int r = 8 * p + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
+      srcA[j] = a.A + (int64_t)(m0 + r) * a.sam + kbeg + 2 * c;
+    } else {
+      const int k = p, c = lane ^ (8 * (k & 1));     // row k of 128 doubles = one piece; 64 chunks
+      srcA[j] = a.A + (int64_t)(kbeg + k) * a.sak + m0 + 2 * c;
+    }
+  }
+  stepA = AM ? (int64_t)GK * a.sak : (int64_t)GK;
+#pragma unroll
+  for (int j = 0; j < Cfg::B_PER_WAVE; ++j) {
+    int p = wid + 4 * j;
+    if (p >= Cfg::B_PIECES) p -= 4;                  // surplus slot: the wave repeats its previous piece (same bytes)
+    const int o = p * 1024 + lane * 16;              // byte offset in the B image
+    const int k = o / (BN * 8);
+    int c = (o % (BN * 8)) >> 4;
+    if ((NT & 1) == 0) c ^= 8 * (k & 1);
+    srcB[j] = a.B + (int64_t)(kbeg + k) * a.sbk + n0 + 2 * c;
+  }
+  auto stage = [&](int buf, int kt) {
+    char* base = lds + buf * Cfg::STAGE;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[j] + kt * stepA),
+                                       (__attribute__((address_space(3))) void*)(base + (wid + 4 * j) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int j = 0; j < Cfg::B_PER_WAVE; ++j) {
+      int p = wid + 4 * j;
+      if (p >= Cfg::B_PIECES) p -= 4;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcB[j] + kt * stepB),
+                                       (__attribute__((address_space(3))) void*)(base + Cfg::A_BYTES + p * 1024), 16, 0, 0);
+    }
+  };
+
+  // ---- fragment addresses
+  const int l15 = lane & 15, l4 = lane >> 4;
+  int offA[2][4];   // [M sub-tile][k sub-step]
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int k = 4 * ks + l4;
+      if (!AM) {
+        const int r = wid * 32 + t * 16 + l15;
+        offA[t][ks] = r * 128 + (((k >> 1) ^ ((r >> 1) & 7)) << 4) + (k & 1) * 8;
+      } else {
+        const int m = wid * 32 + t * 16 + l15;       // image [k][128]: chunk = m >> 1, swizzled with 8 (k & 1)
+        offA[t][ks] = k * 1024 + ((((m >> 1) ^ (8 * (k & 1)))) << 4) + (m & 1) * 8;
+      }
+    }
+  int offB[4];      // column tile 0; tile j adds 128 bytes (16 doubles), before the swizzle
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) offB[ks] = Cfg::A_BYTES + (4 * ks + l4) * (BN * 8);
+  const int bsw = ((NT & 1) == 0) ? 8 * (l4 & 1) : 0;   // (k & 1) = l4 & 1 since 4 ks is even
+
+  f64x4 acc[2][NT];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[t][j] = f64x4{0.0, 0.0, 0.0, 0.0};
+
+  if (nk > 0) stage(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) {
+      stage(cur ^ 1, kt + 1);                         // (its last readers passed the barrier that ended step kt - 1)
+      if (Cfg::PER_WAVE == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else if (Cfg::PER_WAVE == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();                     // every wave's pieces of stage `cur` have landed
+    const char* base = lds + cur * Cfg::STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      double af[2], bf[NT];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) af[t] = *reinterpret_cast<const double*>(base + offA[t][ks]);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int chunk = (8 * j + (l15 >> 1)) ^ bsw;
+        bf[j] = *reinterpret_cast<const double*>(base + offB[ks] + (chunk << 4) + (l15 & 1) * 8);
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc[t][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[t], bf[j], acc[t][j], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                     // everyone is done reading `cur` before it is staged again
+  }
+
+  // C/D map: col = lane & 15, row = (lane >> 4) + 4 reg.  With beta1 the old values of a row block are requested
+  // together (written as `*c += v` per element they are 8 NT dependent round trips)
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    double old[NT][4];
+    const bool add = a.beta1 && !a.atomic;
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wid * 32 + t * 16 + l4 + 4 * r;
+        old[j][r] = add ? a.C[(int64_t)row * a.ldc + n0 + j * 16 + l15] : 0.0;
+      }
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wid * 32 + t * 16 + l4 + 4 * r;
+        double* c = a.C + (int64_t)row * a.ldc + n0 + j * 16 + l15;
+        const double v = a.alpha * acc[t][j][r];
+        if (a.atomic) atomicAdd(c, v);
+        else *c = old[j][r] + v;
+      }
+  }
+}
+
+template <int NT, bool AM>
+static void launch_glds(const GemmF64Args& a, int ksplit, hipStream_t st) {
+  const dim3 grid((unsigned)((a.M / GM) * (a.N / (16 * NT))), (unsigned)ksplit);
+  hipLaunchKernelGGL((gemm_f64_glds_kernel<NT, AM>), grid, dim3(256), 0, st, a);
+}
+
+// picks the column-tile width (and reports whether the LDS-DMA kernel applies at all)
+static int glds_nt(int64_t M, int64_t N, int64_t K, int ksplit) {
+  if (M % GM || K % GK || N % 16 || M < GM || N < 64) return 0;
+  int best = 0;
+  double best_cost = 0.0;
+  for (int nt : {8, 6, 5, 4}) {
+    if (N % (16 * nt)) continue;
+    const int64_t tiles = (M / GM) * (N / (16 * nt)) * ksplit;
+    const int64_t rounds = ceil_div(tiles, 512);     // two workgroups per CU
+    // time ~ rounds x tile width; narrower tiles re-read A more often (a 10 % handicap per step below 8)
+    const double cost = (double)rounds * nt * (1.0 + 0.04 * (8 - nt));
+    if (!best || cost < best_cost) { best = nt; best_cost = cost; }
+  }
+  return best;
+}
+
 }  // namespace
 
 // C = alpha * op(A) op(B) + (beta1 ? C : 0).  ksplit > 1 needs beta1 (C must hold the addend).
@@ -193,6 +392,28 @@ static int gemm_f64_impl(const double* A, int64_t sam, int64_t sak, const double
   ksplit = (int)ceil_div(std::max<int64_t>(K, 1), a.kchunk);
   a.atomic = ksplit > 1;
   const bool akc = (sak == 1), bkc = (sbk == 1);
+  // the LDS-DMA kernel: B rows N-contiguous, A rows K- or M-contiguous, 16-byte aligned everything
+  static const bool no_glds = getenv("PTD_GEMM_F64_NO_GLDS") != nullptr;
+  if (!no_glds && !A2 && !row0_out && sbn == 1 && (sak == 1 || sam == 1) && M >= 256 && N >= 64 && K >= 64 &&
+      a.kchunk % GK == 0 && (sak == 1 ? sam : sak) % 2 == 0 && sbk % 2 == 0 && ldc % 2 == 0 &&
+      ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B) | reinterpret_cast<uintptr_t>(C)) & 15) == 0) {
+    const int nt = glds_nt(M, N, K, ksplit);
+    const bool am = sak != 1;
+    if (nt) {
+      switch (nt * 2 + (am ? 1 : 0)) {
+        case 16: launch_glds<8, false>(a, ksplit, st); break;
+        case 17: launch_glds<8, true>(a, ksplit, st); break;
+        case 12: launch_glds<6, false>(a, ksplit, st); break;
+        case 13: launch_glds<6, true>(a, ksplit, st); break;
+        case 10: launch_glds<5, false>(a, ksplit, st); break;
+        case 11: launch_glds<5, true>(a, ksplit, st); break;
+        case 8: launch_glds<4, false>(a, ksplit, st); break;
+        default: launch_glds<4, true>(a, ksplit, st); break;
+      }
+      PTD_CHECK_LAUNCH("gemm_f64 (lds-dma)");
+      return PTD_OK;
+    }
+  }
   dim3 grid((unsigned)(a.tiles_m * ceil_div(N, DN)), (unsigned)ksplit);
   if (akc && bkc) hipLaunchKernelGGL((gemm_f64_kernel<true, true>), grid, dim3(256), 0, st, a);
   else if (akc && !bkc) hipLaunchKernelGGL((gemm_f64_kernel<true, false>), grid, dim3(256), 0, st, a);

@@ -50,6 +50,13 @@ int tridiagonalize_f64(const double* A, int64_t lda, int64_t n, double* d_out, d
 int band_reduce_f64(const double* A, int64_t lda, int64_t n, int stages, double* band_out, void* ws, size_t ws_bytes,
                     hipStream_t st);
 
+// eigh_filtered.hip: top-k eigenpairs by Chebyshev-filtered subspace iteration (f64 MFMA products); declines with
+// PTD_ERR_UNSUPPORTED when the spectrum does not suit it
+bool eigh_filtered_applies(int64_t n, int64_t k, bool all_values);
+size_t eigh_filtered_workspace_bytes(int64_t n);
+int eigh_filtered(const double* A, int64_t lda, int64_t n, int64_t k, double* evals, double* evecs, int64_t ldv,
+                  void* ws, size_t ws_bytes, ptd_eigh_stats* stats, hipStream_t st);
+
 // eigh_factored.hip
 size_t eigh_factored_workspace_bytes(int64_t n_o, int64_t n_i, int64_t k);
 int eigh_factored(const void* W, int64_t ldw, int w_dtype, int64_t n_o, int64_t n_i, const double* Ex, int64_t ldx,

@@ -39,7 +39,7 @@ def c3_case(model_seed: int = C3_SEEDS[0], data_seed: int = C3_SEEDS[1], depth: 
 
 
 # ---------------------------------------------------------------- C4: dwain on one full-width Llama block
-C4_KW = dict(num_data_steps=3, num_metric_steps=1, nsr_final_threshold=1.0, min_rank=32, trade_off_factor=20.0,
+C4_KW = dict(num_data_steps=5, num_metric_steps=1, nsr_final_threshold=1.0, min_rank=32, trade_off_factor=20.0,
              reduction_factor=0.5, max_accepted_ppl_diff=0.4, decompose_in_float64=True,
              blacklisted_module_names=["head", "blocks.0.gate", "blocks.0.up"],
              precomputing_covariance_num_splits=None)
@@ -87,10 +87,10 @@ def seq_ce(batch, logits):
                                              batch["targets"].reshape(-1), reduction="none")
 
 
-def c4_case(seed: int = C4_SEED, tokens: int = 2048, n_batches: int = 10):
+def c4_case(seed: int = C4_SEED, tokens: int = 1024, n_batches: int = 10):
     """One block at full width (4096 / 1024 / 14336) + the blacklisted head, f32, W ~ N(0, 1/n_in), inputs
-    N(0, 1) x a decaying feature scale [1, tokens, 4096] (2048 tokens per step; D = 3 steps give
-    more calibration rows than features), targets = argmax of the original logits.  gate / up
+    N(0, 1) x a decaying feature scale [1, tokens, 4096] (1024 tokens per step so that the CPU oracle fits the
+    test budget; D = 5 steps give more calibration rows than features), targets = argmax of the original logits.  gate / up
     are blacklisted ON BOTH SIDES: their 14336^2 eigendecomposition takes the CPU oracle minutes (the factored
     route they would take is checked at full size by test_eigh_factored_full_size_matches_the_direct_route)."""
     g = torch.Generator().manual_seed(seed)

@@ -64,7 +64,7 @@ def test_falor_vit_b16_width_matches_oracle():
 def test_dwain_llama3_8b_width_block_matches_oracle():
     """C4 (dwain.py:333-537, 677-800): ONE block at the Llama-3-8B widths (q / o 4096 -> 4096, k / v 4096 -> 1024,
     down 14336 -> 4096; gate / up 4096 -> 14336 present in the forward and blacklisted on both sides, see
-    fullwidth_cases.c4_case), [1, 2048, 4096] calibration batches, D = 3, f32 model, f64 decomposition.  Identical
+    fullwidth_cases.c4_case), [1, 1024, 4096] calibration batches, D = 5, f32 model, f64 decomposition.  Identical
     (layer, rank, accepted) decisions, nsr / ppl_diff within 1e-4, same config, factor products and outputs."""
     import ptdeco_amd
 

@@ -26,3 +26,11 @@ fi
 if [[ $PARTS == *probe* ]]; then
   step 300 probe bash -c "python tools/chefsi_probe.py > gpurun_out/chefsi_probe.json 2> gpurun_out/chefsi_probe.err"; cat gpurun_out/chefsi_probe.json; tail -3 gpurun_out/chefsi_probe.err
 fi
+if [[ $PARTS == *filt* ]]; then
+  step 300 filt bash -c "PTD_JACOBI_DEBUG=1 python tools/filtered_probe.py > gpurun_out/filtered_probe.json 2> gpurun_out/filtered_probe.err"; cat gpurun_out/filtered_probe.json; grep -v amdgpu.ids gpurun_out/filtered_probe.err | tail -12
+  (cd /tmp && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_filt -- python3 $GRAFT_REPO_ROOT/tools/filtered_probe.py > $GRAFT_REPO_ROOT/gpurun_out/prof_filt.log 2>&1); echo "rocprof rc=$?"
+  f=$(ls gpurun_out/prof_filt/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && head -40 "$f" | cut -c1-160
+fi
+if [[ $PARTS == *gemmtest* ]]; then
+  step 300 gemmtest bash -c "python -m pytest tests/test_kernels_gpu.py -q -x -k 'gemm_f64 or resident_kernels or two_eigendecompositions' > gpurun_out/gemmtest.log 2>&1"; tail -15 gpurun_out/gemmtest.log
+fi
