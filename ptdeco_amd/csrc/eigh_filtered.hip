@@ -30,8 +30,6 @@
 
 namespace ptd {
 
-int cholesky_f64(double* L, int np, double* linv_ws, int linv_stride, int* fail, hipStream_t st);  // chol.hip
-
 namespace {
 
 constexpr int LZ_NV = 4;        // Lanczos chains (independent start vectors)
@@ -271,101 +269,199 @@ __device__ __forceinline__ void fs_tile_abt(const double* __restrict__ Ps, const
   }
 }
 
-// W = L^-T (upper triangular, row-major [m][m]) from the Cholesky factor L (lower, in G) and the inverses of its
-// diagonal blocks (linv: 64 x 64 per block).  Block column j of L^-1 is one workgroup:
-//   X_jj = L_jj^-1,   X_ij = - L_ii^-1 sum_{j <= k < i} L_ik X_kj   (i > j),
-// written transposed: W[64 j + c][64 i + r] = X_ij[r][c].  Tiles of the column already formed are re-read through
-// L2 (device-scope loads: the vector L1 is not kept coherent with this workgroup's own earlier stores).
-__global__ __launch_bounds__(256) void fs_trtri_kernel(const double* __restrict__ L, int m, const double* __restrict__ linv,
-                                                       double* __restrict__ Wt) {
+// ---- Cholesky factor and its inverse of a 64 x 64 SPD tile, one workgroup of 256 threads, everything in LDS
+// A (pitch FQ = 65: a column access by 32 lanes touches 32 different bank pairs) holds the tile, X the inverse being
+// built.  Right-looking, ONE barrier per column j: with p = 1 / A[j][j] (A[j][j] is final when its turn comes),
+//   A[r][c] -= A[r][j] A[c][j] p               j < c <= r       (the column itself stays unscaled: L[r][j] = A[r][j] sqrt(p))
+//   X[r][c] -= (A[r][j] p) X[j][c]             c <= j < r       (X = Lhat^-1, Lhat = L D^-1 unit lower; row j of X is final)
+// and at the end L^-1 = D^-1 X, D[r] = sqrt(A[r][r]).  Thread (r = tid & 63, g = tid >> 6) owns row r, columns c = g mod 4:
+// the column index is wave-uniform, so A[c][j] and X[j][c] are broadcast reads.  A non-positive pivot raises *fail.
+constexpr int FQ = 65;
+__device__ __forceinline__ void fs_chol_inv_tile(double* __restrict__ A, double* __restrict__ X, double* __restrict__ out,
+                                                 int* __restrict__ fail, int tid) {
+  const int r = tid & 63, g = tid >> 6;
+  for (int c = g; c < FB; c += 4) X[r * FQ + c] = (c == r) ? 1.0 : 0.0;
+  __syncthreads();
+  bool bad = false;
+  for (int j = 0; j < FB - 1; ++j) {
+    const double d = A[j * FQ + j];
+    const bool ok = d > 0.0 && d < INFINITY;
+    bad = bad || !ok;
+    const double p = ok ? 1.0 / d : 1.0;
+    if (r > j) {
+      const double arj = A[r * FQ + j] * p;
+      for (int c = j + 1 + ((g - (j + 1)) & 3); c <= r; c += 4) A[r * FQ + c] -= arj * A[c * FQ + j];
+      for (int c = g; c <= j; c += 4) X[r * FQ + c] -= arj * X[j * FQ + c];
+    }
+    __syncthreads();
+  }
+  {
+    const double d = A[(FB - 1) * FQ + FB - 1];
+    bad = bad || !(d > 0.0 && d < INFINITY);
+  }
+  const double dr = A[r * FQ + r];
+  const double rs = (dr > 0.0 && dr < INFINITY) ? 1.0 / sqrt(dr) : 1.0;
+  for (int c = g; c < FB; c += 4) X[r * FQ + c] = (c <= r) ? X[r * FQ + c] * rs : 0.0;
+  __syncthreads();
+  for (int e = tid; e < FB * FB; e += 256) out[e] = X[(e >> 6) * FQ + (e & 63)];
+  if (bad && tid == 0) atomicExch(fail, 1);
+}
+
+__device__ __forceinline__ void fs_load_tile(double* __restrict__ dst, const double* __restrict__ src, int64_t ld, int tid) {
+#pragma unroll
+  for (int p2 = 0; p2 < 8; ++p2) {
+    const int idx = tid + 256 * p2;
+    const int r = idx >> 5, c2 = (idx & 31) * 2;
+    *reinterpret_cast<double2*>(&dst[r * FP + c2]) = *reinterpret_cast<const double2*>(src + (int64_t)r * ld + c2);
+  }
+}
+// accumulators -> LDS tile (row-major)
+__device__ __forceinline__ void fs_store_acc(double* __restrict__ dst, const f64x4 (&acc)[2][2], int wr, int wc, int lane,
+                                             double sign) {
+  const int l15 = lane & 15, l4 = lane >> 4;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        dst[(wr * 32 + a * 16 + l4 + 4 * r) * FP + wc * 32 + b * 16 + l15] = sign * acc[a][b][r];
+}
+__device__ __forceinline__ void fs_zero_acc(f64x4 (&acc)[2][2]) {
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
+}
+
+// Linv_0 of the first diagonal tile of G
+__global__ __launch_bounds__(256) void fs_diag0_kernel(const double* __restrict__ G, int m, double* __restrict__ linv,
+                                                       int* __restrict__ fail) {
+  __shared__ __attribute__((aligned(16))) double T[FB * FQ];
+  __shared__ __attribute__((aligned(16))) double Xs[FB * FQ];
+  for (int e = threadIdx.x; e < FB * FB; e += 256) T[(e >> 6) * FQ + (e & 63)] = G[(int64_t)(e >> 6) * m + (e & 63)];
+  __syncthreads();
+  fs_chol_inv_tile(T, Xs, linv, fail, threadIdx.x);
+}
+
+// W work = identity
+__global__ void fs_identity_kernel(double* __restrict__ W, int m) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < (int64_t)m * m; i += (int64_t)gridDim.x * blockDim.x)
+    W[i] = (i / m == i % m) ? 1.0 : 0.0;
+}
+
+// Step k of the Cholesky sweep G = L L^T that also forms W = L^-T (upper triangular) without ever storing L:
+// with P = Linv_kk (inverse of the factor of the current diagonal tile, from the previous step),
+//   G tile (i, j), k < j <= i:   G_ij -= (G_ik P^T) (G_jk P^T)^T;   the workgroup of (k+1, k+1) then factors its tile:
+//                                Linv_{k+1}
+//   W tile (r, j), r <= k < j:   Ww_rj -= (Ww_rk P^T) (G_jk P^T)^T        (Ww starts as the identity: the same right-
+//   W tile (r, k), r <= k:       Wout_rk = Ww_rk P^T                        looking substitution applied to I gives L^-T)
+// Every tile a step writes is read by no other workgroup of that step (column k of G and of Ww is read-only, the final
+// column goes to Wout), so the steps need no synchronisation beyond their launch order.
+__global__ __launch_bounds__(256) void fs_sweep_kernel(double* __restrict__ G, int m, double* __restrict__ Ww,
+                                                       double* __restrict__ Wout, double* __restrict__ linv,
+                                                       int* __restrict__ fail, int k) {
   __shared__ __attribute__((aligned(16))) double Ps[FB * FP];
   __shared__ __attribute__((aligned(16))) double Qs[FB * FP];
+  __shared__ __attribute__((aligned(16))) double Ss[FB * FP];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wr = wid >> 1, wc = wid & 1;
   const int l15 = lane & 15, l4 = lane >> 4;
-  const int nb = m / FB;
-  const int j = blockIdx.x;
-  // zero the part of W below the diagonal block row-wise: rows 64 j.., columns < 64 j
-  for (int e = tid; e < FB * (j * FB); e += 256) {
-    const int r = e / (j * FB), c = e % (j * FB);
-    Wt[(int64_t)(j * FB + r) * m + c] = 0.0;
+  const int nb = m / FB, nt = nb - k - 1;
+  const double* P = linv + (size_t)k * FB * FB;
+  int idx = blockIdx.x;
+  f64x4 acc[2][2];
+  fs_load_tile(Qs, P, FB, tid);                              // Qs = Linv_kk (row-major): X Qs^T = X Linv^T
+  if (idx < k + 1) {
+    // ---- final column block k of W, row tile r
+    const int r = idx;
+    fs_load_tile(Ps, Ww + (int64_t)r * FB * m + (int64_t)k * FB, m, tid);
+    __syncthreads();
+    fs_zero_acc(acc);
+    fs_tile_abt(Ps, Qs, wr, wc, lane, acc);
+    double* dst = Wout + (int64_t)r * FB * m + (int64_t)k * FB;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          dst[(int64_t)(wr * 32 + a * 16 + l4 + 4 * q) * m + wc * 32 + b * 16 + l15] = acc[a][b][q];
+    return;
   }
-  // diagonal tile: W[64 j + c][64 j + r] = Linv_jj[r][c]
-  for (int e = tid; e < FB * FB; e += 256) {
-    const int c = e >> 6, r = e & 63;
-    Wt[(int64_t)(j * FB + c) * m + j * FB + r] = linv[(size_t)j * FB * FB + (size_t)r * FB + c];
+  idx -= k + 1;
+  const bool wrole = idx < (k + 1) * nt;
+  int ti, tj;   // G role: tile (ti, tj); W role: row tile ti of Ww, column tj
+  if (wrole) {
+    ti = idx / nt;
+    tj = k + 1 + idx % nt;
+  } else {
+    idx -= (k + 1) * nt;
+    int t = (int)((sqrtf(8.f * (float)idx + 1.f) - 1.f) * 0.5f);
+    while (t * (t + 1) / 2 > idx) --t;
+    while ((t + 1) * (t + 2) / 2 <= idx) ++t;
+    ti = k + 1 + t;
+    tj = k + 1 + (idx - t * (t + 1) / 2);
   }
-  __threadfence();
+  // Ss = G_jk P^T  (= L_jk)
+  fs_load_tile(Ps, G + (int64_t)tj * FB * m + (int64_t)k * FB, m, tid);
   __syncthreads();
-  for (int i = j + 1; i < nb; ++i) {
-    f64x4 acc[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < 2; ++b) acc[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
-    for (int k = j; k < i; ++k) {
-      // Ps = L_ik (row-major), Qs[c][kk] = X_kj[kk][c] = W[64 j + c][64 k + kk]: rows of W as they lie
-      for (int e = tid; e < FB * FB / 2; e += 256) {
-        const int r = e >> 5, c2 = (e & 31) * 2;
-        *reinterpret_cast<double2*>(&Ps[r * FP + c2]) =
-            *reinterpret_cast<const double2*>(L + (int64_t)(i * FB + r) * m + k * FB + c2);
-        const double* src = Wt + (int64_t)(j * FB + r) * m + k * FB + c2;
-        Qs[r * FP + c2] = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        Qs[r * FP + c2 + 1] = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      __syncthreads();
-      fs_tile_abt(Ps, Qs, wr, wc, lane, acc);      // acc[r][c] += sum_kk L_ik[r][kk] X_kj[kk][c]
-      __syncthreads();
-    }
-    // S -> Qs transposed (Qs[c][r] = S[r][c]), Ps = Linv_ii; X_ij = - Linv_ii S
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = wr * 32 + a * 16 + l4 + 4 * r, col = wc * 32 + b * 16 + l15;
-          Qs[col * FP + row] = acc[a][b][r];
-        }
-    for (int e = tid; e < FB * FB / 2; e += 256) {
-      const int r = e >> 5, c2 = (e & 31) * 2;
-      *reinterpret_cast<double2*>(&Ps[r * FP + c2]) =
-          *reinterpret_cast<const double2*>(linv + (size_t)i * FB * FB + (size_t)r * FB + c2);
-    }
+  fs_zero_acc(acc);
+  fs_tile_abt(Ps, Qs, wr, wc, lane, acc);
+  __syncthreads();
+  fs_store_acc(Ss, acc, wr, wc, lane, 1.0);
+  // Ps = (row operand) P^T: G_ik P^T or Ww_rk P^T
+  const bool same = !wrole && ti == tj;
+  if (!same) {
+    const double* src = wrole ? Ww + (int64_t)ti * FB * m + (int64_t)k * FB : G + (int64_t)ti * FB * m + (int64_t)k * FB;
+    fs_load_tile(Ps, src, m, tid);
     __syncthreads();
-    f64x4 out[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < 2; ++b) out[a][b] = f64x4{0.0, 0.0, 0.0, 0.0};
-    fs_tile_abt(Ps, Qs, wr, wc, lane, out);        // out[r][c] = sum_q Linv_ii[r][q] S[q][c]
+    fs_zero_acc(acc);
+    fs_tile_abt(Ps, Qs, wr, wc, lane, acc);
     __syncthreads();
-    // W[64 j + c][64 i + r] = - out[r][c]: stage through LDS so that the stores run along rows of W
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = wr * 32 + a * 16 + l4 + 4 * r, col = wc * 32 + b * 16 + l15;
-          Ps[col * FP + row] = -out[a][b][r];
-        }
-    __syncthreads();
-    for (int e = tid; e < FB * FB / 2; e += 256) {
-      const int c = e >> 5, r2 = (e & 31) * 2;
-      double* dst = Wt + (int64_t)(j * FB + c) * m + i * FB + r2;
-      __hip_atomic_store(dst, Ps[c * FP + r2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(dst + 1, Ps[c * FP + r2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    fs_store_acc(Ps, acc, wr, wc, lane, 1.0);
   }
+  __syncthreads();
+  fs_zero_acc(acc);
+  fs_tile_abt(same ? Ss : Ps, Ss, wr, wc, lane, acc);        // acc[r][c] = sum_q Row[r][q] L_jk[c][q]
+  double* dst = (wrole ? Ww : G) + (int64_t)ti * FB * m + (int64_t)tj * FB;
+  const bool diag = same && ti == k + 1;
+  double upd[2][2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        upd[a][b][q] = dst[(int64_t)(wr * 32 + a * 16 + l4 + 4 * q) * m + wc * 32 + b * 16 + l15];
+  if (!diag) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          dst[(int64_t)(wr * 32 + a * 16 + l4 + 4 * q) * m + wc * 32 + b * 16 + l15] = upd[a][b][q] - acc[a][b][q];
+    return;
+  }
+  // ---- the next diagonal tile: updated value into LDS (pitch FQ), factor + inverse by the whole workgroup
+  __syncthreads();
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        Ps[(wr * 32 + a * 16 + l4 + 4 * q) * FQ + wc * 32 + b * 16 + l15] = upd[a][b][q] - acc[a][b][q];
+  __syncthreads();
+  fs_chol_inv_tile(Ps, Ss, linv + (size_t)(k + 1) * FB * FB, fail, tid);
 }
 
 // ------------------------------------------------------------------------------------------------ host side
-// eigenvalues of the symmetric tridiagonal (d, e) by implicit QL, with the first components of the normalised
-// eigenvectors in z (on entry z = e_1).  d, e, z of length n; e[i] couples i and i + 1.  false: no convergence.
-bool tridiag_ql_first_row(int n, double* d, double* e, double* z) {
+// eigenvalues of the symmetric tridiagonal (d, e) by implicit QL, with the first and the last components of the
+// normalised eigenvectors in z and y (on entry z = e_1, y = e_n).  d, e, z, y of length n; e[i] couples i and i + 1.
+// false: no convergence.
+bool tridiag_ql_first_row(int n, double* d, double* e, double* z, double* y) {
   if (n <= 0) return true;
   e[n - 1] = 0.0;
   for (int l = 0; l < n; ++l) {
@@ -401,6 +497,9 @@ bool tridiag_ql_first_row(int n, double* d, double* e, double* z) {
           f = z[i + 1];
           z[i + 1] = s * z[i] + c * f;
           z[i] = c * z[i] - s * f;
+          f = y[i + 1];
+          y[i + 1] = s * y[i] + c * f;
+          y[i] = c * y[i] - s * f;
         }
         if (r == 0.0 && i >= l) continue;
         d[l] -= p;
@@ -546,22 +645,24 @@ int eigh_filtered(const double* A, int64_t lda, int64_t n, int64_t k, double* ev
   std::vector<std::pair<double, double>> nodes;   // (theta, weight), weights of one chain sum to 1 / NV
   double lo = INFINITY, hi = -INFINITY;
   for (int v = 0; v < LZ_NV; ++v) {
-    double d[LZ_STEPS], e[LZ_STEPS], z[LZ_STEPS];
+    double d[LZ_STEPS], e[LZ_STEPS], z[LZ_STEPS], y[LZ_STEPS];
     int len = LZ_STEPS;
     for (int i = 0; i < LZ_STEPS; ++i) {
       d[i] = h_ab[v * 2 * LZ_STEPS + i];
       e[i] = h_ab[v * 2 * LZ_STEPS + LZ_STEPS + i];
       z[i] = i == 0 ? 1.0 : 0.0;
+      y[i] = 0.0;
       if (!std::isfinite(d[i]) || !std::isfinite(e[i])) return decline("non-finite Lanczos coefficients");
       if (i < len - 1 && !(e[i] > 0.0)) len = i + 1;   // an invariant subspace: the chain ends here
     }
     const double blast = e[len - 1];
-    if (!tridiag_ql_first_row(len, d, e, z)) return decline("Lanczos tridiagonal did not converge");
+    y[len - 1] = 1.0;
+    if (!tridiag_ql_first_row(len, d, e, z, y)) return decline("Lanczos tridiagonal did not converge");
     for (int i = 0; i < len; ++i) nodes.emplace_back(d[i], z[i] * z[i] / LZ_NV);
-    // |beta_last| bounds how far a Ritz value can sit inside the spectrum's edge
+    // a Ritz pair's residual is |beta_last| |last component|: an eigenvalue lies within that distance of theta_i
     for (int i = 0; i < len; ++i) {
-      lo = std::min(lo, d[i] - fabs(blast));
-      hi = std::max(hi, d[i] + fabs(blast));
+      lo = std::min(lo, d[i] - fabs(blast * y[i]));
+      hi = std::max(hi, d[i] + fabs(blast * y[i]));
     }
   }
   std::sort(nodes.begin(), nodes.end(), [](const auto& x, const auto& y) { return x.first > y.first; });
@@ -581,8 +682,8 @@ int eigh_filtered(const double* A, int64_t lda, int64_t n, int64_t k, double* ev
   };
   const double theta_max = nodes.front().first;
   const double a_cut = quantile((double)k + 0.9 * (double)(m - k));
-  const double lam_k = quantile(1.05 * (double)k);
-  lo = std::min(lo, a_cut);
+  const double lam_k = quantile((double)k);
+  lo -= 0.01 * std::max(a_cut - lo, 0.0);   // (an eigenvalue just below `lo` would grow like one just above `a`)
   if (!(hi > 0.0) || !(a_cut > lo) || !(lam_k > a_cut) || (a_cut - lo) < 1e-10 * fabs(hi))
     return decline("degenerate spectral bounds");
   const double ee = 0.5 * (a_cut - lo), cc = 0.5 * (a_cut + lo);
@@ -592,8 +693,8 @@ int eigh_filtered(const double* A, int64_t lda, int64_t n, int64_t k, double* ev
   const int max_products = (int)env_double("PTD_EIGH_FILTER_MAX_PRODUCTS", 24);
   // measured on covariance spectra: the residual falls like 0.05 g^-d with g about three quarters of the way from 1
   // to the asymptotic factor (rounds restart the polynomial; the neighbours of the cut grow a little as well)
-  const double g_eff = 1.0 + 0.75 * (growth - 1.0);
-  int degree = (int)ceil(log(0.05 / tol) / log(g_eff)) + 1;
+  const double g_eff = 1.0 + 0.8 * (growth - 1.0);
+  int degree = (int)ceil(log(0.05 / tol) / log(g_eff));
   degree = std::max(degree, 4);
   if (debug)
     fprintf(stderr, "[eigh_filtered] n=%lld k=%lld m=%d: lo %.3e a %.3e lambda_k~%.3e hi %.3e growth %.2f/product -> "
@@ -618,14 +719,21 @@ int eigh_filtered(const double* A, int64_t lda, int64_t n, int64_t k, double* ev
   const double shift_rel = env_double("PTD_EIGH_FILTER_SHIFT", 6e-13);
   int products = 0, rc = PTD_OK;
   auto chol_pass = [&](bool shifted) -> int {
-    // G = X^T X (K split: the tiles of an m x m product do not fill the chip), G = L L^T, W = L^-T, X <- X W
+    // G = X^T X (K split: the tiles of an m x m product do not fill the chip); sweep: G = L L^T and W = L^-T together
+    // (one launch per 64-column panel, L itself is never stored); X <- X W
     PTD_CHECK_HIP(hipMemsetAsync(G, 0, (size_t)m * m * 8, st));
     int r2 = gemm_f64(X, 1, m, X, m, 1, G, m, m, m, n, 1.0, true, 3, st);
     if (r2 != PTD_OK) return r2;
     if (shifted) hipLaunchKernelGGL(fs_shift_kernel, dim3(1), dim3(1024), 0, st, G, m, shift_rel);
-    r2 = cholesky_f64(G, m, linv, FB * FB, fail, st);
-    if (r2 != PTD_OK) return r2;
-    hipLaunchKernelGGL(fs_trtri_kernel, dim3(m / FB), dim3(256), 0, st, G, m, linv, Wt);
+    PTD_CHECK_HIP(hipMemsetAsync(Wt, 0, (size_t)m * m * 8, st));
+    hipLaunchKernelGGL(fs_identity_kernel, dim3(1024), dim3(256), 0, st, H, m);   // (H is free until Rayleigh-Ritz)
+    hipLaunchKernelGGL(fs_diag0_kernel, dim3(1), dim3(256), 0, st, G, m, linv, fail);
+    const int nb = m / FB;
+    for (int kk = 0; kk < nb; ++kk) {
+      const int nt = nb - kk - 1;
+      const int wgs = (kk + 1) + (kk + 1) * nt + nt * (nt + 1) / 2;
+      hipLaunchKernelGGL(fs_sweep_kernel, dim3(wgs), dim3(256), 0, st, G, m, H, Wt, linv, fail, kk);
+    }
     r2 = gemm_f64(X, m, 1, Wt, m, 1, Y, m, n, m, m, 1.0, false, 1, st);
     std::swap(X, Y);
     return r2;
@@ -651,10 +759,9 @@ int eigh_filtered(const double* A, int64_t lda, int64_t n, int64_t k, double* ev
       sg = sn;
     }
     std::swap(X, Y);   // X = the filtered block
-    const bool last = ri + 1 == rounds.size();
+    // a shifted pass (cond(X) ~ 150^d down to ~1e3), then a clean one (orthonormal to ~1e-11)
     rc = chol_pass(true);
     if (rc == PTD_OK) rc = chol_pass(false);
-    if (rc == PTD_OK && last) rc = chol_pass(false);
     if (rc != PTD_OK) { cleanup(); return rc; }
   }
   PTD_CHECK_LAUNCH("eigh_filtered filter");

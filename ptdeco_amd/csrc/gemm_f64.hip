@@ -167,8 +167,10 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(const GemmF64Args a) {
 // 64 x 64 tile re-reads 16 KiB per 16-deep K step for 16 MFMAs a wave) and two full barriers with a register-staged
 // write pass per step.  Here: 128 x (16 NT) tile, 4 waves stacked in M (32 rows x 16 NT columns = 2 x NT
 // accumulators each), K step 16, both operands staged by global_load_lds (16 B per lane, 1 KiB per instruction) into
-// two buffers, the next step's DMA in flight across the barriers (counted vmcnt, raw s_barrier); two workgroups per
-// CU cover each other's barrier stalls.
+// a ring of three buffers: ONE barrier per K step -- wait for the own pieces of step t (those of step t + 1 stay in
+// flight: counted vmcnt), raw s_barrier (everyone's pieces of t have landed and everyone has finished reading step
+// t - 1), issue the DMA of step t + 2 into the buffer step t - 1 used, multiply step t.  Two workgroups per CU (NT <=
+// 5: 78 KiB each) cover each other's barrier stalls.
 //   A image (AM = false): [128 rows][16 k] = 128-byte rows; the 16-byte chunks of row r are XOR-swizzled with
 //     (r >> 1) & 7 on the SOURCE address, so the 16 rows x 16 B a half wave reads for one fragment (lane: row l & 15,
 //     k = kk + (l >> 4)) cover all 64 banks once.
@@ -187,13 +189,16 @@ struct GldsCfg {
   static constexpr int B_PER_WAVE = (B_PIECES + 3) / 4;
   static constexpr int STAGE = A_BYTES + B_BYTES;
   static constexpr int PER_WAVE = 4 + B_PER_WAVE;                // DMA instructions a wave issues per stage
+  // ring depth: three buffers (the DMA two K steps ahead) where two workgroups still fit a CU, else two
+  static constexpr int ST = (3 * STAGE <= 80 * 1024) ? 3 : 2;
 };
 
 template <int NT, bool AM>
 __global__ __launch_bounds__(256, 2) void gemm_f64_glds_kernel(const GemmF64Args a) {
   using Cfg = GldsCfg<NT, AM>;
   constexpr int BN = Cfg::BN;
-  __shared__ __attribute__((aligned(16))) char lds[2 * Cfg::STAGE];
+  constexpr int ST = Cfg::ST;
+  __shared__ __attribute__((aligned(16))) char lds[ST * Cfg::STAGE];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   // a contiguous run of tiles per XCD (blocks b and b + 8 share one), row-major over (M tile, N tile) inside it
@@ -276,18 +281,20 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_glds_kernel(const GemmF64Args
     for (int j = 0; j < NT; ++j) acc[t][j] = f64x4{0.0, 0.0, 0.0, 0.0};
 
   if (nk > 0) stage(0, 0);
+  if (ST == 3 && nk > 1) stage(1, 1);
+  int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) {
-      stage(cur ^ 1, kt + 1);                         // (its last readers passed the barrier that ended step kt - 1)
+    if (ST == 3 && kt + 1 < nk) {
       if (Cfg::PER_WAVE == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
       else if (Cfg::PER_WAVE == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    __builtin_amdgcn_s_barrier();                     // every wave's pieces of stage `cur` have landed
+    __builtin_amdgcn_s_barrier();
+    if (kt + ST - 1 < nk) stage(cur == 0 ? ST - 1 : cur - 1, kt + ST - 1);
     const char* base = lds + cur * Cfg::STAGE;
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       double af[2], bf[NT];
@@ -303,8 +310,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_glds_kernel(const GemmF64Args
 #pragma unroll
         for (int t = 0; t < 2; ++t) acc[t][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[t], bf[j], acc[t][j], 0, 0, 0);
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                     // everyone is done reading `cur` before it is staged again
+    __builtin_amdgcn_s_setprio(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (this step's reads are done before the next barrier)
+    cur = cur == ST - 1 ? 0 : cur + 1;
   }
 
   // C/D map: col = lane & 15, row = (lane >> 4) + 4 reg.  With beta1 the old values of a row block are requested
