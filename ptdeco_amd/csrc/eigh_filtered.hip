@@ -188,6 +188,20 @@ __global__ void fs_axpby_kernel(double* __restrict__ Out, const double* __restri
   }
 }
 
+// G = sum of `ns` slabs in index order (a deterministic K split)
+__global__ void fs_sum_slabs_kernel(double* __restrict__ G, const double* __restrict__ S, int64_t slab, int ns,
+                                    int64_t total2) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total2; i += (int64_t)gridDim.x * blockDim.x) {
+    double2 acc = reinterpret_cast<const double2*>(S)[i];
+    for (int q = 1; q < ns; ++q) {
+      const double2 v = reinterpret_cast<const double2*>(S + q * slab)[i];
+      acc.x += v.x;
+      acc.y += v.y;
+    }
+    reinterpret_cast<double2*>(G)[i] = acc;
+  }
+}
+
 // G[i][i] += shift_rel * trace(G)  (one workgroup)
 __global__ __launch_bounds__(1024) void fs_shift_kernel(double* __restrict__ G, int m, double shift_rel) {
   __shared__ double red[1024];
@@ -269,41 +283,65 @@ __device__ __forceinline__ void fs_tile_abt(const double* __restrict__ Ps, const
   }
 }
 
-// ---- Cholesky factor and its inverse of a 64 x 64 SPD tile, one workgroup of 256 threads, everything in LDS
-// A (pitch FQ = 65: a column access by 32 lanes touches 32 different bank pairs) holds the tile, X the inverse being
-// built.  Right-looking, ONE barrier per column j: with p = 1 / A[j][j] (A[j][j] is final when its turn comes),
-//   A[r][c] -= A[r][j] A[c][j] p               j < c <= r       (the column itself stays unscaled: L[r][j] = A[r][j] sqrt(p))
+// ---- Cholesky factor and its inverse of a 64 x 64 SPD tile, one workgroup of 256 threads
+// Thread (r = tid & 63, g = tid >> 6) keeps row r of the tile and of the inverse being built in REGISTERS, columns
+// c = g mod 4 (16 + 16 doubles, statically indexed: the 64 column steps are unrolled).  Right-looking, ONE barrier per
+// column j: the owners publish the (unscaled) column A[.][j] and row j of X into a double-buffered LDS line; with
+// p = 1 / A[j][j]
+//   A[r][c] -= (A[r][j] p) A[c][j]             j < c <= r       (L[r][j] = A[r][j] sqrt(p); the column stays unscaled)
 //   X[r][c] -= (A[r][j] p) X[j][c]             c <= j < r       (X = Lhat^-1, Lhat = L D^-1 unit lower; row j of X is final)
-// and at the end L^-1 = D^-1 X, D[r] = sqrt(A[r][r]).  Thread (r = tid & 63, g = tid >> 6) owns row r, columns c = g mod 4:
-// the column index is wave-uniform, so A[c][j] and X[j][c] are broadcast reads.  A non-positive pivot raises *fail.
+// the column index of a thread's slot is wave-uniform, so A[c][j] and X[j][c] are broadcast LDS reads and the only
+// per-lane read is A[r][j].  At the end L^-1 = D^-1 X.  (Kept in LDS with read-modify-write updates the same sweep
+// took ~60 us: two dependent LDS round trips per element.)  A: LDS tile (pitch FQ, lower triangle read); buf: 256
+// doubles of LDS.  A non-positive pivot raises *fail.
 constexpr int FQ = 65;
-__device__ __forceinline__ void fs_chol_inv_tile(double* __restrict__ A, double* __restrict__ X, double* __restrict__ out,
-                                                 int* __restrict__ fail, int tid) {
-  const int r = tid & 63, g = tid >> 6;
-  for (int c = g; c < FB; c += 4) X[r * FQ + c] = (c == r) ? 1.0 : 0.0;
-  __syncthreads();
+__device__ __forceinline__ void fs_chol_inv_tile(const double* __restrict__ A, double* __restrict__ buf,
+                                                 double* __restrict__ out, int* __restrict__ fail, int tid) {
+  const int r = tid & 63;
+  const int g = __builtin_amdgcn_readfirstlane(tid >> 6);
+  double a[16], x[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = g + 4 * i;
+    a[i] = (c <= r) ? A[r * FQ + c] : 0.0;
+    x[i] = (c == r) ? 1.0 : 0.0;
+  }
+  __syncthreads();   // (buf may alias the tile's neighbours; everyone has its row)
   bool bad = false;
-  for (int j = 0; j < FB - 1; ++j) {
-    const double d = A[j * FQ + j];
+  double rs = 1.0;
+#pragma unroll
+  for (int j = 0; j < FB; ++j) {
+    const int i = j >> 2, gj = j & 3;
+    double* cb = buf + (j & 1) * 128;
+    double* xb = cb + 64;
+    if (g == gj) cb[r] = a[i];
+    if (r == j) {
+#pragma unroll
+      for (int ii = 0; ii <= i; ++ii) xb[g + 4 * ii] = x[ii];
+    }
+    __syncthreads();
+    const double d = cb[j];
     const bool ok = d > 0.0 && d < INFINITY;
     bad = bad || !ok;
     const double p = ok ? 1.0 / d : 1.0;
-    if (r > j) {
-      const double arj = A[r * FQ + j] * p;
-      for (int c = j + 1 + ((g - (j + 1)) & 3); c <= r; c += 4) A[r * FQ + c] -= arj * A[c * FQ + j];
-      for (int c = g; c <= j; c += 4) X[r * FQ + c] -= arj * X[j * FQ + c];
+    if (r == j) rs = ok ? 1.0 / sqrt(d) : 1.0;
+    const double arj = (r > j) ? cb[r] * p : 0.0;
+#pragma unroll
+    for (int ii = i; ii < 16; ++ii) {
+      const int c = g + 4 * ii;
+      if (ii > i || g > gj) a[ii] -= arj * cb[c];       // columns c > j (the test is wave-uniform)
     }
-    __syncthreads();
+#pragma unroll
+    for (int ii = 0; ii <= i; ++ii) {
+      const int c = g + 4 * ii;
+      if (ii < i || g <= gj) x[ii] -= arj * xb[c];      // columns c <= j
+    }
   }
-  {
-    const double d = A[(FB - 1) * FQ + FB - 1];
-    bad = bad || !(d > 0.0 && d < INFINITY);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = g + 4 * i;
+    out[r * FB + c] = (c <= r) ? x[i] * rs : 0.0;
   }
-  const double dr = A[r * FQ + r];
-  const double rs = (dr > 0.0 && dr < INFINITY) ? 1.0 / sqrt(dr) : 1.0;
-  for (int c = g; c < FB; c += 4) X[r * FQ + c] = (c <= r) ? X[r * FQ + c] * rs : 0.0;
-  __syncthreads();
-  for (int e = tid; e < FB * FB; e += 256) out[e] = X[(e >> 6) * FQ + (e & 63)];
   if (bad && tid == 0) atomicExch(fail, 1);
 }
 
@@ -338,7 +376,7 @@ __device__ __forceinline__ void fs_zero_acc(f64x4 (&acc)[2][2]) {
 __global__ __launch_bounds__(256) void fs_diag0_kernel(const double* __restrict__ G, int m, double* __restrict__ linv,
                                                        int* __restrict__ fail) {
   __shared__ __attribute__((aligned(16))) double T[FB * FQ];
-  __shared__ __attribute__((aligned(16))) double Xs[FB * FQ];
+  __shared__ __attribute__((aligned(16))) double Xs[256];
   for (int e = threadIdx.x; e < FB * FB; e += 256) T[(e >> 6) * FQ + (e & 63)] = G[(int64_t)(e >> 6) * m + (e & 63)];
   __syncthreads();
   fs_chol_inv_tile(T, Xs, linv, fail, threadIdx.x);
@@ -682,7 +720,7 @@ int eigh_filtered(const double* A, int64_t lda, int64_t n, int64_t k, double* ev
   };
   const double theta_max = nodes.front().first;
   const double a_cut = quantile((double)k + 0.9 * (double)(m - k));
-  const double lam_k = quantile((double)k);
+  const double lam_k = quantile(1.05 * (double)k);   // (a little inside: the density estimate is good to ~10 %)
   lo -= 0.01 * std::max(a_cut - lo, 0.0);   // (an eigenvalue just below `lo` would grow like one just above `a`)
   if (!(hi > 0.0) || !(a_cut > lo) || !(lam_k > a_cut) || (a_cut - lo) < 1e-10 * fabs(hi))
     return decline("degenerate spectral bounds");
@@ -693,7 +731,7 @@ int eigh_filtered(const double* A, int64_t lda, int64_t n, int64_t k, double* ev
   const int max_products = (int)env_double("PTD_EIGH_FILTER_MAX_PRODUCTS", 24);
   // measured on covariance spectra: the residual falls like 0.05 g^-d with g about three quarters of the way from 1
   // to the asymptotic factor (rounds restart the polynomial; the neighbours of the cut grow a little as well)
-  const double g_eff = 1.0 + 0.8 * (growth - 1.0);
+  const double g_eff = 1.0 + 0.9 * (growth - 1.0);
   int degree = (int)ceil(log(0.05 / tol) / log(g_eff));
   degree = std::max(degree, 4);
   if (debug)
@@ -718,11 +756,21 @@ int eigh_filtered(const double* A, int64_t lda, int64_t n, int64_t k, double* ev
   const int64_t tot2 = (int64_t)n * m / 2;
   const double shift_rel = env_double("PTD_EIGH_FILTER_SHIFT", 6e-13);
   int products = 0, rc = PTD_OK;
+  // Out = P^T Q (m x m) with the K range split into slabs that are added in index order: the m x m tiles alone do not
+  // fill the chip, and atomics would make the run-to-run rounding -- and with it eigenvector signs -- differ
+  const int ksplit_mm = (int)std::max<int64_t>(1, std::min<int64_t>(3, (int64_t)n / m));
+  auto gram = [&](const double* P, const double* Q, double* Out, double* scratch) -> int {
+    int ns = 1;
+    const int64_t slab = (int64_t)m * m;
+    int r2 = gemm_f64_slabs(P, 1, m, Q, m, 1, scratch, m, slab, m, m, n, 1.0, ksplit_mm, &ns, st);
+    if (r2 != PTD_OK) return r2;
+    hipLaunchKernelGGL(fs_sum_slabs_kernel, dim3(1024), dim3(256), 0, st, Out, scratch, slab, ns, slab / 2);
+    return PTD_OK;
+  };
   auto chol_pass = [&](bool shifted) -> int {
     // G = X^T X (K split: the tiles of an m x m product do not fill the chip); sweep: G = L L^T and W = L^-T together
     // (one launch per 64-column panel, L itself is never stored); X <- X W
-    PTD_CHECK_HIP(hipMemsetAsync(G, 0, (size_t)m * m * 8, st));
-    int r2 = gemm_f64(X, 1, m, X, m, 1, G, m, m, m, n, 1.0, true, 3, st);
+    int r2 = gram(X, X, G, Z);
     if (r2 != PTD_OK) return r2;
     if (shifted) hipLaunchKernelGGL(fs_shift_kernel, dim3(1), dim3(1024), 0, st, G, m, shift_rel);
     PTD_CHECK_HIP(hipMemsetAsync(Wt, 0, (size_t)m * m * 8, st));
@@ -738,73 +786,90 @@ int eigh_filtered(const double* A, int64_t lda, int64_t n, int64_t k, double* ev
     std::swap(X, Y);
     return r2;
   };
-  for (size_t ri = 0; ri < rounds.size(); ++ri) {
-    const int d = rounds[ri];
+  // X <- T_d(..) X, then a shifted Cholesky-QR pass (cond(X) ~ 150^d down to ~1e3) and a clean one (orthonormal to ~1e-11)
+  auto filter_round = [&](int d) -> int {
     // Y_1 = s1 / e (C - c) X;  Y_{j+1} = 2 s_{j+1} / e (C - c) Y_j - s_j s_{j+1} Y_{j-1},  s_{j+1} = 1 / (2 / s1 - s_j)
     const double s1 = ee / (hi - cc);
     double sg = s1;
     hipLaunchKernelGGL(fs_axpby_kernel, dim3(2048), dim3(256), 0, st, Y, X, (const double*)nullptr, -cc * s1 / ee, 0.0,
                        tot2);
-    rc = gemm_f64(A, lda, 1, X, m, 1, Y, m, n, m, n, s1 / ee, true, 1, st);
-    if (rc != PTD_OK) { cleanup(); return rc; }
+    int r2 = gemm_f64(A, lda, 1, X, m, 1, Y, m, n, m, n, s1 / ee, true, 1, st);
+    if (r2 != PTD_OK) return r2;
     ++products;
     // (X, Y) = (Y_{j-1}, Y_j); Z receives Y_{j+1}
     for (int j = 2; j <= d; ++j) {
       const double sn = 1.0 / (2.0 / s1 - sg);
       hipLaunchKernelGGL(fs_axpby_kernel, dim3(2048), dim3(256), 0, st, Z, Y, X, -2.0 * sn * cc / ee, -sg * sn, tot2);
-      rc = gemm_f64(A, lda, 1, Y, m, 1, Z, m, n, m, n, 2.0 * sn / ee, true, 1, st);
-      if (rc != PTD_OK) { cleanup(); return rc; }
+      r2 = gemm_f64(A, lda, 1, Y, m, 1, Z, m, n, m, n, 2.0 * sn / ee, true, 1, st);
+      if (r2 != PTD_OK) return r2;
       ++products;
       double* t = X; X = Y; Y = Z; Z = t;
       sg = sn;
     }
     std::swap(X, Y);   // X = the filtered block
-    // a shifted pass (cond(X) ~ 150^d down to ~1e3), then a clean one (orthonormal to ~1e-11)
-    rc = chol_pass(true);
-    if (rc == PTD_OK) rc = chol_pass(false);
+    r2 = chol_pass(true);
+    if (r2 == PTD_OK) r2 = chol_pass(false);
+    return r2;
+  };
+  for (size_t ri = 0; ri < rounds.size(); ++ri) {
+    rc = filter_round(rounds[ri]);
     if (rc != PTD_OK) { cleanup(); return rc; }
   }
   PTD_CHECK_LAUNCH("eigh_filtered filter");
   if (stats) PTD_CHECK_HIP(hipEventRecord(ev[2], st));
 
-  // ---- 3. Rayleigh-Ritz
-  rc = gemm_f64(A, lda, 1, X, m, 1, Z, m, n, m, n, 1.0, false, 1, st);           // Z = C X
-  if (rc != PTD_OK) { cleanup(); return rc; }
-  ++products;
-  PTD_CHECK_HIP(hipMemsetAsync(H, 0, (size_t)m * m * 8, st));
-  rc = gemm_f64(X, 1, m, Z, m, 1, H, m, m, m, n, 1.0, true, 3, st);              // H = X^T Z
-  if (rc != PTD_OK) { cleanup(); return rc; }
-  hipLaunchKernelGGL(fs_symmetrize_kernel, dim3((unsigned)ceil_div(m, 32), (unsigned)ceil_div(m, 32)), dim3(256), 0, st,
-                     H, m);
-  if (stats) PTD_CHECK_HIP(hipEventRecord(ev[3], st));
-  rc = eigh_tridiag(H, m, m, k, lam, Yk, k, base + p.off_eigh, p.eigh_bytes, 1e-10, false, nullptr, st);
-  if (rc == PTD_ERR_UNSUPPORTED) return decline("clustered Ritz values");
-  if (rc != PTD_OK) { cleanup(); return rc; }
-  if (stats) PTD_CHECK_HIP(hipEventRecord(ev[4], st));
-  rc = gemm_f64(X, m, 1, Yk, k, 1, evecs, ldv, n, k, m, 1.0, false, 1, st);      // V = X Y_k
-  if (rc != PTD_OK) { cleanup(); return rc; }
+  double res = 0.0, lmax = 1.0;
+  const int filter_products = products;
+  for (int attempt = 0;; ++attempt) {
+    // ---- 3. Rayleigh-Ritz
+    rc = gemm_f64(A, lda, 1, X, m, 1, Z, m, n, m, n, 1.0, false, 1, st);           // Z = C X
+    if (rc != PTD_OK) { cleanup(); return rc; }
+    ++products;
+    rc = gram(X, Z, H, Y);                                                         // H = X^T Z
+    if (rc != PTD_OK) { cleanup(); return rc; }
+    hipLaunchKernelGGL(fs_symmetrize_kernel, dim3((unsigned)ceil_div(m, 32), (unsigned)ceil_div(m, 32)), dim3(256), 0,
+                       st, H, m);
+    if (stats && attempt == 0) PTD_CHECK_HIP(hipEventRecord(ev[3], st));
+    rc = eigh_tridiag(H, m, m, k, lam, Yk, k, base + p.off_eigh, p.eigh_bytes, 1e-10, false, nullptr, st);
+    if (rc == PTD_ERR_UNSUPPORTED) return decline("clustered Ritz values");
+    if (rc != PTD_OK) { cleanup(); return rc; }
+    if (stats && attempt == 0) PTD_CHECK_HIP(hipEventRecord(ev[4], st));
+    rc = gemm_f64(X, m, 1, Yk, k, 1, evecs, ldv, n, k, m, 1.0, false, 1, st);      // V = X Y_k
+    if (rc != PTD_OK) { cleanup(); return rc; }
 
-  // ---- 4. residuals: C V - V theta = Z Y_k - V theta
-  double* T = Y;
-  rc = gemm_f64(Z, m, 1, Yk, k, 1, T, k, n, k, m, 1.0, false, 1, st);
-  if (rc != PTD_OK) { cleanup(); return rc; }
-  hipLaunchKernelGGL(fs_residual_kernel, dim3((unsigned)k), dim3(256), 0, st, T, (int64_t)k, evecs, ldv, lam + (m - k),
-                     (int)n, (int)k, resid);
+    // ---- 4. residuals: C V - V theta = Z Y_k - V theta
+    double* T = Y;
+    rc = gemm_f64(Z, m, 1, Yk, k, 1, T, k, n, k, m, 1.0, false, 1, st);
+    if (rc != PTD_OK) { cleanup(); return rc; }
+    PTD_CHECK_HIP(hipMemsetAsync(resid, 0, 16, st));
+    hipLaunchKernelGGL(fs_residual_kernel, dim3((unsigned)k), dim3(256), 0, st, T, (int64_t)k, evecs, ldv,
+                       lam + (m - k), (int)n, (int)k, resid);
+    struct { int fail; int pad[15]; unsigned long long res, lmax; } h{};
+    PTD_CHECK_HIP(hipMemcpyAsync(&h, base + p.off_flags, sizeof(h), hipMemcpyDeviceToHost, st));
+    PTD_CHECK_HIP(hipStreamSynchronize(st));
+    memcpy(&res, &h.res, 8);
+    memcpy(&lmax, &h.lmax, 8);
+    if (debug)
+      fprintf(stderr, "[eigh_filtered] %d products, chol fail %d, max residual %.3e = %.2e |lambda_max| (theta_max %.3e)\n",
+              products, h.fail, res, res / std::max(lmax, 1e-300), theta_max);
+    if (h.fail) return decline("Cholesky breakdown in an orthonormalisation pass");
+    if (res <= tol * lmax) break;
+    // not there yet (the density estimate put lambda_k too high): one more round, sized by the rate measured so far
+    const double rel = res / std::max(lmax, 1e-300);
+    if (attempt >= 2 || !(rel < 1e-3)) return decline("residual above the tolerance");
+    const double rate = pow(0.05 / rel, 1.0 / (double)filter_products);
+    const int extra = std::min(6, std::max(2, (int)ceil(log(rel / (0.2 * tol)) / log(std::max(rate, 1.5)))));
+    if (debug) fprintf(stderr, "[eigh_filtered] measured %.2f per product: %d more\n", rate, extra);
+    rc = filter_round(extra);
+    if (rc != PTD_OK) { cleanup(); return rc; }
+  }
   // eigenvalues: the k largest at the end of evals[n], NaN below (the convention of ptd_eigh_topk with all_values = 0)
   PTD_CHECK_HIP(hipMemsetAsync(evals, 0xFF, (size_t)(n - k) * 8, st));
   PTD_CHECK_HIP(hipMemcpyAsync(evals + (n - k), lam + (m - k), (size_t)k * 8, hipMemcpyDeviceToDevice, st));
-  struct { int fail; int pad[15]; unsigned long long res, lmax; } h{};
-  PTD_CHECK_HIP(hipMemcpyAsync(&h, base + p.off_flags, sizeof(h), hipMemcpyDeviceToHost, st));
-  if (stats) PTD_CHECK_HIP(hipEventRecord(ev[5], st));
-  PTD_CHECK_HIP(hipStreamSynchronize(st));
-  double res, lmax;
-  memcpy(&res, &h.res, 8);
-  memcpy(&lmax, &h.lmax, 8);
-  if (debug)
-    fprintf(stderr, "[eigh_filtered] %d products, chol fail %d, max residual %.3e = %.2e |lambda_max| (theta_max %.3e)\n",
-            products, h.fail, res, res / std::max(lmax, 1e-300), theta_max);
-  if (h.fail) return decline("Cholesky breakdown in an orthonormalisation pass");
-  if (!(res <= tol * lmax)) return decline("residual above the tolerance");
+  if (stats) {
+    PTD_CHECK_HIP(hipEventRecord(ev[5], st));
+    PTD_CHECK_HIP(hipEventSynchronize(ev[5]));
+  }
   if (stats) {
     float t01 = 0, t12 = 0, t23 = 0, t34 = 0, t45 = 0;
     (void)hipEventElapsedTime(&t01, ev[0], ev[1]);

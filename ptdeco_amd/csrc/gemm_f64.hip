@@ -31,6 +31,7 @@ struct GemmF64Args {
   double alpha;
   int beta1;   // 1: accumulate into C
   int atomic;  // 1: split K, accumulate with atomics (requires beta1)
+  int64_t slab;  // > 0: split K without atomics -- K range y writes its partial product to C + y * slab (elements)
   int kchunk;
   int tiles_m;
   const double* A2;  // optional second operand pair with the same strides: C gets A B + A2 B2 in one pass
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(const GemmF64Args a) {
         const int row = m0 + wr * 32 + i * 16 + l4 + 4 * r;
         const int col = n0 + wc * 32 + j * 16 + l15;
         if (row >= a.M || col >= a.N) continue;
-        double* c = a.C + (int64_t)row * a.ldc + col;
+        double* c = a.C + (int64_t)blockIdx.y * a.slab + (int64_t)row * a.ldc + col;
         const double v = a.alpha * acc[i][j][r];
         if (a.atomic) {
           atomicAdd(c, v);
@@ -326,14 +327,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_glds_kernel(const GemmF64Args
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = m0 + wid * 32 + t * 16 + l4 + 4 * r;
-        old[j][r] = add ? a.C[(int64_t)row * a.ldc + n0 + j * 16 + l15] : 0.0;
+        old[j][r] = add ? a.C[(int64_t)blockIdx.y * a.slab + (int64_t)row * a.ldc + n0 + j * 16 + l15] : 0.0;
       }
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = m0 + wid * 32 + t * 16 + l4 + 4 * r;
-        double* c = a.C + (int64_t)row * a.ldc + n0 + j * 16 + l15;
+        double* c = a.C + (int64_t)blockIdx.y * a.slab + (int64_t)row * a.ldc + n0 + j * 16 + l15;
         const double v = a.alpha * acc[t][j][r];
         if (a.atomic) atomicAdd(c, v);
         else *c = old[j][r] + v;
@@ -368,11 +369,22 @@ static int glds_nt(int64_t M, int64_t N, int64_t K, int ksplit) {
 // C = alpha * op(A) op(B) + (beta1 ? C : 0).  ksplit > 1 needs beta1 (C must hold the addend).
 static int gemm_f64_impl(const double* A, int64_t sam, int64_t sak, const double* B, int64_t sbk, int64_t sbn,
                          const double* A2, const double* B2, double* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
-                         double alpha, bool beta1, int ksplit, double* row0_out, hipStream_t st);
+                         double alpha, bool beta1, int ksplit, double* row0_out, hipStream_t st, int64_t slab = 0);
 
 int gemm_f64(const double* A, int64_t sam, int64_t sak, const double* B, int64_t sbk, int64_t sbn, double* C,
              int64_t ldc, int64_t M, int64_t N, int64_t K, double alpha, bool beta1, int ksplit, hipStream_t st) {
   return gemm_f64_impl(A, sam, sak, B, sbk, sbn, nullptr, nullptr, C, ldc, M, N, K, alpha, beta1, ksplit, nullptr, st);
+}
+
+// Split K without atomics: K range y of `ksplit` writes alpha * A(:, range) B(range, :) to C + y * slab; the caller adds
+// the slabs in index order (a deterministic sum).  Returns the number of slabs written in *nslabs.
+int gemm_f64_slabs(const double* A, int64_t sam, int64_t sak, const double* B, int64_t sbk, int64_t sbn, double* C,
+                   int64_t ldc, int64_t slab, int64_t M, int64_t N, int64_t K, double alpha, int ksplit, int* nslabs,
+                   hipStream_t st) {
+  const int kchunk = (int)align_up((size_t)ceil_div(std::max<int64_t>(K, 1), std::max(ksplit, 1)), DK);
+  *nslabs = (int)ceil_div(std::max<int64_t>(K, 1), kchunk);
+  return gemm_f64_impl(A, sam, sak, B, sbk, sbn, nullptr, nullptr, C, ldc, M, N, K, alpha, false, -ksplit, nullptr, st,
+                       slab);
 }
 
 // C += alpha * (A B + A2 B2), both pairs with the same strides, in ONE pass over C
@@ -384,7 +396,7 @@ int gemm_f64_pair(const double* A, const double* B, const double* A2, const doub
 
 static int gemm_f64_impl(const double* A, int64_t sam, int64_t sak, const double* B, int64_t sbk, int64_t sbn,
                          const double* A2, const double* B2, double* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
-                         double alpha, bool beta1, int ksplit, double* row0_out, hipStream_t st) {
+                         double alpha, bool beta1, int ksplit, double* row0_out, hipStream_t st, int64_t slab) {
   if (M <= 0 || N <= 0) return PTD_OK;
   GemmF64Args a{};
   a.A = A; a.sam = sam; a.sak = sak;
@@ -395,10 +407,12 @@ static int gemm_f64_impl(const double* A, int64_t sam, int64_t sak, const double
   a.M = (int)M; a.N = (int)N; a.K = (int)K;
   a.alpha = alpha; a.beta1 = beta1 ? 1 : 0;
   a.tiles_m = (int)ceil_div(M, DM);
-  if (ksplit < 1 || !beta1) ksplit = 1;
+  if (slab > 0) ksplit = -ksplit;          // (slabs: the K split needs no addend in C)
+  else if (ksplit < 1 || !beta1) ksplit = 1;
   a.kchunk = (int)align_up((size_t)ceil_div(std::max<int64_t>(K, 1), ksplit), DK);
   ksplit = (int)ceil_div(std::max<int64_t>(K, 1), a.kchunk);
-  a.atomic = ksplit > 1;
+  a.atomic = ksplit > 1 && slab == 0;
+  a.slab = slab;
   const bool akc = (sak == 1), bkc = (sbk == 1);
   // the LDS-DMA kernel: B rows N-contiguous, A rows K- or M-contiguous, 16-byte aligned everything
   static const bool no_glds = getenv("PTD_GEMM_F64_NO_GLDS") != nullptr;

@@ -37,6 +37,10 @@ int eigh_jacobi(const double* A, int64_t lda, int64_t n, int64_t k, double* eval
 int gemm_f64(const double* A, int64_t sam, int64_t sak, const double* B, int64_t sbk, int64_t sbn, double* C,
              int64_t ldc, int64_t M, int64_t N, int64_t K, double alpha, bool beta1, int ksplit, hipStream_t st);
 
+int gemm_f64_slabs(const double* A, int64_t sam, int64_t sak, const double* B, int64_t sbk, int64_t sbn, double* C,
+                   int64_t ldc, int64_t slab, int64_t M, int64_t N, int64_t K, double alpha, int ksplit, int* nslabs,
+                   hipStream_t st);
+
 // eigh_tridiag.hip
 size_t tridiag_workspace_bytes(int64_t n);
 // ptd_set_concurrent_chains: how many eigendecompositions the caller runs at once on the current device (returns the

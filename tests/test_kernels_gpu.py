@@ -330,6 +330,82 @@ def _twist_case_matrix(n):
     return a + torch.eye(n, dtype=torch.float64) * (0.01 * torch.diag(a).mean())
 
 
+def _profiled_eigh(ops, monkeypatch, a, k):
+    from ptdeco_amd import ops as real_ops
+    monkeypatch.setattr(real_ops, "EIGH_PROFILE", [])
+    w, v = ops.eigh(a, k, all_values=False)
+    prof = real_ops.EIGH_PROFILE[0]
+    monkeypatch.setattr(real_ops, "EIGH_PROFILE", None)
+    return w.cpu(), v.cpu(), prof
+
+
+@pytest.mark.parametrize("n,k", [(2048, 512), (4096, 1024), (2560, 320)])
+def test_eigh_filtered_subspace_route_matches_lapack(ops, monkeypatch, n, k):
+    """ptd_eigh_topk with k <= n / 3, n >= 2048 and all_values = 0 (what the dwain search asks for on a square layer,
+    dwain.py:155-163 + 407-421) takes the Chebyshev-filtered subspace iteration (eigh_filtered.hip: products on the f64
+    matrix cores + Cholesky-QR passes + a Rayleigh-Ritz problem of order ~1.25 k).  Checked against LAPACK on a
+    covariance with a decaying spectrum: eigenvalues to 1e-12 |A|, residual |A v - lambda v| <= 2e-10 |A| per vector
+    (the route's own acceptance bound is 1e-10), orthonormality 1e-10, the invariant subspaces at the ranks dwain cuts,
+    and the eigenvectors themselves where the gaps are wide; the profile says which route ran.  Two runs agree bit for
+    bit in sign and to rounding in value (the K-split products add their slabs in a fixed order)."""
+    a = _twist_case_matrix(n).to(DEV)
+    w, v, prof = _profiled_eigh(ops, monkeypatch, a, k)
+    assert prof["method"] == 3, prof
+    w_ref, v_ref = torch.linalg.eigh(a.cpu())
+    scale = w_ref.abs().max().item()
+    assert torch.isnan(w[: n - k]).all()
+    assert (w[n - k:] - w_ref[n - k:]).abs().max().item() <= 1e-12 * scale
+    ac = a.cpu()
+    assert (ac @ v - v * w[n - k:]).norm(dim=0).max().item() <= 2e-10 * scale
+    assert (v.T @ v - torch.eye(k, dtype=torch.float64)).abs().max().item() <= 1e-10
+    for r in sorted({k, max(1, k // 2), max(1, k // 8)}):
+        d2 = 2.0 * r - 2.0 * (v[:, k - r:].T @ v_ref[:, n - r:]).pow(2).sum().item()
+        assert d2 <= (1e-6 * math.sqrt(r)) ** 2 + 1e-9, (r, d2)
+    lead = 16   # the largest eigenvalues of this spectrum are well separated
+    sgn = torch.sign((v[:, k - lead:] * v_ref[:, n - lead:]).sum(0))
+    assert (v[:, k - lead:] * sgn - v_ref[:, n - lead:]).abs().max().item() <= 1e-8
+    w2, v2 = ops.eigh(a, k, all_values=False)
+    assert (v2.cpu() - v).abs().max().item() <= 1e-9 and (w2.cpu()[n - k:] - w[n - k:]).abs().max().item() <= 1e-13 * scale
+    # the switch: PTD_EIGH_FILTERED=0 reduces the matrix directly and lands on the same eigenpairs
+    monkeypatch.setenv("PTD_EIGH_FILTERED", "0")
+    w0, v0, prof0 = _profiled_eigh(ops, monkeypatch, a, k)
+    assert prof0["method"] == 1
+    assert (w0[n - k:] - w[n - k:]).abs().max().item() <= 1e-12 * scale
+    d2 = 2.0 * k - 2.0 * (v.T @ v0).pow(2).sum().item()
+    assert d2 <= (1e-6 * math.sqrt(k)) ** 2 + 1e-9
+
+
+def test_eigh_filtered_route_declines_where_it_does_not_apply(ops, monkeypatch):
+    """A flat spectrum (identity plus noise: nothing for a polynomial filter to separate), a matrix whose requested
+    eigenvalues sit in a degenerate cluster (rank-deficient covariance: fewer rows than k), and a request for all
+    eigenvalues: the route declines and the direct reduction answers -- same contract, method 1 (or the Jacobi
+    fallback for the cluster) in the profile."""
+    n, k = 2048, 512
+    g = torch.Generator().manual_seed(123)
+    noise = torch.randn(n, n, generator=g, dtype=torch.float64) * 1e-3
+    flat = (torch.eye(n, dtype=torch.float64) + noise + noise.T).to(DEV)
+    w, v, prof = _profiled_eigh(ops, monkeypatch, flat, k)
+    assert prof["method"] != 3
+    w_ref = torch.linalg.eigvalsh(flat.cpu())
+    assert (w[n - k:] - w_ref[n - k:]).abs().max().item() <= 1e-12 * w_ref.abs().max().item()
+    assert (flat.cpu() @ v - v * w[n - k:]).abs().max().item() <= 1e-11 * w_ref.abs().max().item()
+    y = torch.randn(300, n, generator=g, dtype=torch.float64)
+    low = (y.T @ y / 300 + 1e-3 * torch.eye(n, dtype=torch.float64)).to(DEV)     # rank 300 + a flat floor, k = 512
+    w, v, prof = _profiled_eigh(ops, monkeypatch, low, k)
+    assert prof["method"] != 3
+    w_ref = torch.linalg.eigvalsh(low.cpu())
+    assert (w[n - k:] - w_ref[n - k:]).abs().max().item() <= 1e-11 * w_ref.abs().max().item()
+    # k above the rank but the filter still applies when the top of the spectrum is what is asked for
+    w, v, prof = _profiled_eigh(ops, monkeypatch, low, 128)
+    assert (low.cpu() @ v - v * w[n - 128:]).norm(dim=0).max().item() <= 2e-10 * w_ref.abs().max().item()
+    # all eigenvalues requested: never the filtered route
+    from ptdeco_amd import ops as real_ops
+    monkeypatch.setattr(real_ops, "EIGH_PROFILE", [])
+    ops.eigh(_twist_case_matrix(n).to(DEV), k, all_values=True)
+    assert real_ops.EIGH_PROFILE[0]["method"] == 1
+    monkeypatch.setattr(real_ops, "EIGH_PROFILE", None)
+
+
 def test_resident_kernels_are_chosen_on_device_facts(ops, monkeypatch):
     """The whole-chip kernels of the tridiagonalisation only run on an unpartitioned 256-CU gfx950 (CU count,
     architecture and the occupancy query are read once per device).  PTD_SYTRD_FAKE_CUS stands for a device with

@@ -53,7 +53,7 @@ for name, n_in, n_out, count in (("q_o", 4096, 4096, 64), ("k_v", 4096, 1024, 64
     line = {"n_in": n_in, "n_out": n_out, "ms_per_layer": dt * 1e3, "layers_per_s": 1.0 / dt}
     if prof:
         p = prof[0]
-        line["eigh"] = {"n": p["n"], "k": p["k"], "method": "tridiagonal" if p["method"] == 1 else "jacobi",
+        line["eigh"] = {"n": p["n"], "k": p["k"], "method": {0: "jacobi", 1: "tridiagonal", 2: "two-stage", 3: "filtered subspace iteration"}[p["method"]],
                         "ms_in_profiled_pass": p["total_ms"]}
         if p["method"] == 1 and p["ms"][0] > 0.0:   # (orders up to 2048 run in the resident kernels: no SYMV launch)
             line["eigh"]["symv_gbps"] = p["work"][0] / (p["ms"][0] * 1e-3) / 1e9

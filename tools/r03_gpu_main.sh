@@ -32,5 +32,5 @@ if [[ $PARTS == *filt* ]]; then
   f=$(ls gpurun_out/prof_filt/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && head -40 "$f" | cut -c1-160
 fi
 if [[ $PARTS == *gemmtest* ]]; then
-  step 300 gemmtest bash -c "python -m pytest tests/test_kernels_gpu.py -q -x -k 'gemm_f64 or resident_kernels or two_eigendecompositions' > gpurun_out/gemmtest.log 2>&1"; tail -15 gpurun_out/gemmtest.log
+  step 300 gemmtest bash -c "python -m pytest tests/test_kernels_gpu.py -q -x -k 'gemm_f64 or resident_kernels or two_eigendecompositions or filtered or eigh_topk or eigh_mid' > gpurun_out/gemmtest.log 2>&1"; tail -15 gpurun_out/gemmtest.log
 fi
