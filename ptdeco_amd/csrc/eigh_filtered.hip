@@ -218,21 +218,27 @@ __global__ __launch_bounds__(1024) void fs_shift_kernel(double* __restrict__ G, 
   for (int i = tid; i < m; i += 1024) G[(int64_t)i * m + i] += sh;
 }
 
-// H <- (H + H^T) / 2 in place (tiles above the diagonal own the pair)
+// H <- (H + H^T) / 2 in place (tiles on and above the diagonal own the pair; every operand is read before the
+// barrier, every result written after it: a diagonal tile is its own mirror)
 __global__ __launch_bounds__(256) void fs_symmetrize_kernel(double* __restrict__ H, int m) {
   __shared__ double t[32][33];
   const int bi = blockIdx.y, bj = blockIdx.x;
   if (bj < bi) return;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  for (int r = ty; r < 32; r += 8) {
-    const int i = bj * 32 + r, j = bi * 32 + tx;   // element (i, j) of the mirror tile
-    t[r][tx] = (i < m && j < m) ? H[(int64_t)i * m + j] : 0.0;
+  double own[4];
+  for (int q = 0; q < 4; ++q) {
+    const int r = ty + 8 * q;
+    const int im = bj * 32 + r, jm = bi * 32 + tx;   // element (im, jm) of the mirror tile
+    t[r][tx] = (im < m && jm < m) ? H[(int64_t)im * m + jm] : 0.0;
+    const int i = bi * 32 + r, j = bj * 32 + tx;
+    own[q] = (i < m && j < m) ? H[(int64_t)i * m + j] : 0.0;
   }
   __syncthreads();
-  for (int r = ty; r < 32; r += 8) {
+  for (int q = 0; q < 4; ++q) {
+    const int r = ty + 8 * q;
     const int i = bi * 32 + r, j = bj * 32 + tx;
     if (i < m && j < m) {
-      const double v = 0.5 * (H[(int64_t)i * m + j] + t[tx][r]);
+      const double v = 0.5 * (own[q] + t[tx][r]);
       H[(int64_t)i * m + j] = v;
       H[(int64_t)j * m + i] = v;
     }
@@ -263,6 +269,34 @@ __global__ __launch_bounds__(256) void fs_residual_kernel(const double* __restri
     atomicMax(out, (unsigned long long)__double_as_longlong(sqrt(red[0])));
     atomicMax(out + 1, (unsigned long long)__double_as_longlong(fabs(l)));
   }
+}
+
+// Eigenvector signs: the entry of largest modulus of every column becomes positive (lowest row wins a tie), so the
+// sign does not hang on the last bits of the Ritz problem.  One workgroup per column.
+__global__ __launch_bounds__(256) void fs_sign_kernel(double* __restrict__ V, int64_t ldv, int n) {
+  __shared__ double bv[256];
+  __shared__ int bi[256];
+  const int c = blockIdx.x, tid = threadIdx.x;
+  double best = -1.0;
+  int at = 0;
+  for (int i = tid; i < n; i += 256) {
+    const double a = fabs(V[(int64_t)i * ldv + c]);
+    if (a > best) { best = a; at = i; }
+  }
+  bv[tid] = best;
+  bi[tid] = at;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o && (bv[tid + o] > bv[tid] || (bv[tid + o] == bv[tid] && bi[tid + o] < bi[tid]))) {
+      bv[tid] = bv[tid + o];
+      bi[tid] = bi[tid + o];
+    }
+    __syncthreads();
+  }
+  const double sg = V[(int64_t)bi[0] * ldv + c] < 0.0 ? -1.0 : 1.0;
+  __syncthreads();
+  if (sg < 0.0)
+    for (int i = tid; i < n; i += 256) V[(int64_t)i * ldv + c] = -V[(int64_t)i * ldv + c];
 }
 
 // ------------------------------------------------------------------------------------ triangular inverse
@@ -767,11 +801,26 @@ int eigh_filtered(const double* A, int64_t lda, int64_t n, int64_t k, double* ev
     hipLaunchKernelGGL(fs_sum_slabs_kernel, dim3(1024), dim3(256), 0, st, Out, scratch, slab, ns, slab / 2);
     return PTD_OK;
   };
+  const bool checksum = getenv("PTD_FILTER_CHECKSUM") != nullptr;
+  auto dump = [&](const char* what, const double* buf, size_t count) {
+    if (!checksum) return;
+    std::vector<double> hbuf(count);
+    (void)hipMemcpyAsync(hbuf.data(), buf, count * 8, hipMemcpyDeviceToHost, st);
+    (void)hipStreamSynchronize(st);
+    unsigned long long x = 0;
+    for (size_t i = 0; i < count; ++i) {
+      unsigned long long b;
+      memcpy(&b, &hbuf[i], 8);
+      x = (x ^ b) * 0x100000001B3ULL;
+    }
+    fprintf(stderr, "[eigh_filtered] checksum %-28s %016llx\n", what, x);
+  };
   auto chol_pass = [&](bool shifted) -> int {
     // G = X^T X (K split: the tiles of an m x m product do not fill the chip); sweep: G = L L^T and W = L^-T together
     // (one launch per 64-column panel, L itself is never stored); X <- X W
     int r2 = gram(X, X, G, Z);
     if (r2 != PTD_OK) return r2;
+    dump("gram", G, (size_t)m * m);
     if (shifted) hipLaunchKernelGGL(fs_shift_kernel, dim3(1), dim3(1024), 0, st, G, m, shift_rel);
     PTD_CHECK_HIP(hipMemsetAsync(Wt, 0, (size_t)m * m * 8, st));
     hipLaunchKernelGGL(fs_identity_kernel, dim3(1024), dim3(256), 0, st, H, m);   // (H is free until Rayleigh-Ritz)
@@ -782,8 +831,10 @@ int eigh_filtered(const double* A, int64_t lda, int64_t n, int64_t k, double* ev
       const int wgs = (kk + 1) + (kk + 1) * nt + nt * (nt + 1) / 2;
       hipLaunchKernelGGL(fs_sweep_kernel, dim3(wgs), dim3(256), 0, st, G, m, H, Wt, linv, fail, kk);
     }
+    dump("W = L^-T", Wt, (size_t)m * m);
     r2 = gemm_f64(X, m, 1, Wt, m, 1, Y, m, n, m, m, 1.0, false, 1, st);
     std::swap(X, Y);
+    dump("X W", X, (size_t)n * m);
     return r2;
   };
   // X <- T_d(..) X, then a shifted Cholesky-QR pass (cond(X) ~ 150^d down to ~1e3) and a clean one (orthonormal to ~1e-11)
@@ -807,6 +858,7 @@ int eigh_filtered(const double* A, int64_t lda, int64_t n, int64_t k, double* ev
       sg = sn;
     }
     std::swap(X, Y);   // X = the filtered block
+    dump("filtered block", X, (size_t)n * m);
     r2 = chol_pass(true);
     if (r2 == PTD_OK) r2 = chol_pass(false);
     return r2;
@@ -830,10 +882,12 @@ int eigh_filtered(const double* A, int64_t lda, int64_t n, int64_t k, double* ev
     hipLaunchKernelGGL(fs_symmetrize_kernel, dim3((unsigned)ceil_div(m, 32), (unsigned)ceil_div(m, 32)), dim3(256), 0,
                        st, H, m);
     if (stats && attempt == 0) PTD_CHECK_HIP(hipEventRecord(ev[3], st));
+    dump("H", H, (size_t)m * m);
     rc = eigh_tridiag(H, m, m, k, lam, Yk, k, base + p.off_eigh, p.eigh_bytes, 1e-10, false, nullptr, st);
     if (rc == PTD_ERR_UNSUPPORTED) return decline("clustered Ritz values");
     if (rc != PTD_OK) { cleanup(); return rc; }
     if (stats && attempt == 0) PTD_CHECK_HIP(hipEventRecord(ev[4], st));
+    dump("Y_k", Yk, (size_t)m * k);
     rc = gemm_f64(X, m, 1, Yk, k, 1, evecs, ldv, n, k, m, 1.0, false, 1, st);      // V = X Y_k
     if (rc != PTD_OK) { cleanup(); return rc; }
 
@@ -863,6 +917,7 @@ int eigh_filtered(const double* A, int64_t lda, int64_t n, int64_t k, double* ev
     rc = filter_round(extra);
     if (rc != PTD_OK) { cleanup(); return rc; }
   }
+  hipLaunchKernelGGL(fs_sign_kernel, dim3((unsigned)k), dim3(256), 0, st, evecs, ldv, (int)n);
   // eigenvalues: the k largest at the end of evals[n], NaN below (the convention of ptd_eigh_topk with all_values = 0)
   PTD_CHECK_HIP(hipMemsetAsync(evals, 0xFF, (size_t)(n - k) * 8, st));
   PTD_CHECK_HIP(hipMemcpyAsync(evals + (n - k), lam + (m - k), (size_t)k * 8, hipMemcpyDeviceToDevice, st));

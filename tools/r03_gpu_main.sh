@@ -34,3 +34,6 @@ fi
 if [[ $PARTS == *gemmtest* ]]; then
   step 300 gemmtest bash -c "python -m pytest tests/test_kernels_gpu.py -q -x -k 'gemm_f64 or resident_kernels or two_eigendecompositions or filtered or eigh_topk or eigh_mid' > gpurun_out/gemmtest.log 2>&1"; tail -15 gpurun_out/gemmtest.log
 fi
+if [[ $PARTS == *determ* ]]; then
+  step 200 determ bash -c "python tools/filtered_determinism.py 2> gpurun_out/determinism.err"; grep -v amdgpu.ids gpurun_out/determinism.err | awk '/--- run/{r=$3} /checksum/{print r, $0}' | sort -k4,4 -s | awk '{key=$4" "$5" "$6" "$7; if (key==prev && $NF!=pv) print "DIFF:", $0; prev=key; pv=$NF}' | head; grep -c checksum gpurun_out/determinism.err
+fi
