@@ -318,63 +318,80 @@ __device__ __forceinline__ void fs_tile_abt(const double* __restrict__ Ps, const
 }
 
 // ---- Cholesky factor and its inverse of a 64 x 64 SPD tile, one workgroup of 256 threads
-// Thread (r = tid & 63, g = tid >> 6) keeps row r of the tile and of the inverse being built in REGISTERS, columns
-// c = g mod 4 (16 + 16 doubles, statically indexed: the 64 column steps are unrolled).  Right-looking, ONE barrier per
-// column j: the owners publish the (unscaled) column A[.][j] and row j of X into a double-buffered LDS line; with
-// p = 1 / A[j][j]
-//   A[r][c] -= (A[r][j] p) A[c][j]             j < c <= r       (L[r][j] = A[r][j] sqrt(p); the column stays unscaled)
-//   X[r][c] -= (A[r][j] p) X[j][c]             c <= j < r       (X = Lhat^-1, Lhat = L D^-1 unit lower; row j of X is final)
-// the column index of a thread's slot is wave-uniform, so A[c][j] and X[j][c] are broadcast LDS reads and the only
-// per-lane read is A[r][j].  At the end L^-1 = D^-1 X.  (Kept in LDS with read-modify-write updates the same sweep
-// took ~60 us: two dependent LDS round trips per element.)  A: LDS tile (pitch FQ, lower triangle read); buf: 256
-// doubles of LDS.  A non-positive pivot raises *fail.
+// Thread (r = tid & 63, g = tid >> 6) keeps row r in REGISTERS, columns c = g mod 4: ONE array y[16] that holds A[r][c]
+// while column c is still to be eliminated and X[r][c] (X = Lhat^-1, Lhat = L D^-1 unit lower) from then on -- a
+// column's entries are dead once it has been published.  Right-looking, ONE barrier per column j: the owners publish
+// one 64-entry LDS line P (double buffered) with P[c] = A[c][j] for c > j (the unscaled column) and P[c] = X[j][c] for
+// c < j (row j of the inverse, final by then), and p = 1 / A[j][j]; then with m = A[r][j] p (zero for r <= j)
+//   y[c] -= m P[c]            every column c != j   (c > j: A[r][c] -= L[r][j] L[c][j];   c < j: X[r][c] -= Lhat[r][j] X[j][c])
+//   y[j]  = r == j ? 1 : -m   the slot changes hands: X[r][j] = -Lhat[r][j]
+// The column of a slot is wave-uniform, so P[c] are broadcast reads issued together and the register array is
+// indexed statically although the loop over j is rolled.  At the end L^-1 = D^-1 X.  (History: the tile kept in LDS
+// with read-modify-write updates ~60 us per tile; separate A and X arrays with masked multipliers ~65 us -- issue
+// bound, 32 updates a step; fully unrolled over j the compiler spilled.)
+// A: LDS tile (pitch FQ, lower triangle read); buf: 512 doubles of LDS.  A non-positive pivot raises *fail.
 constexpr int FQ = 65;
+__device__ __forceinline__ double fs_rcp(double d) {
+  double p = __builtin_amdgcn_rcp(d);
+  p = fma(fma(-d, p, 1.0), p, p);
+  p = fma(fma(-d, p, 1.0), p, p);
+  return p;
+}
 __device__ __forceinline__ void fs_chol_inv_tile(const double* __restrict__ A, double* __restrict__ buf,
                                                  double* __restrict__ out, int* __restrict__ fail, int tid) {
   const int r = tid & 63;
   const int g = __builtin_amdgcn_readfirstlane(tid >> 6);
-  double a[16], x[16];
+  double y[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int c = g + 4 * i;
-    a[i] = (c <= r) ? A[r * FQ + c] : 0.0;
-    x[i] = (c == r) ? 1.0 : 0.0;
+    y[i] = (c <= r) ? A[r * FQ + c] : 0.0;
   }
   __syncthreads();   // (buf may alias the tile's neighbours; everyone has its row)
+  buf[tid] = 0.0;    // two lines of 128: [0, 64) P, [64] p, [65] bad;  [256, 320): 1 / sqrt(pivot) per row
+  buf[tid + 256] = 0.0;
+  double* rsv = buf + 256;
   bool bad = false;
-  double rs = 1.0;
-#pragma unroll
+#pragma unroll 1
   for (int j = 0; j < FB; ++j) {
     const int i = j >> 2, gj = j & 3;
-    double* cb = buf + (j & 1) * 128;
-    double* xb = cb + 64;
-    if (g == gj) cb[r] = a[i];
+    double* P = buf + (j & 1) * 128;
+    if (g == gj) {
+      double sel = y[0];
+#pragma unroll
+      for (int ii = 1; ii < 16; ++ii) sel = (ii == i) ? y[ii] : sel;
+      if (r > j) P[r] = sel;
+      if (r == j) {
+        const bool ok = sel > 0.0 && sel < INFINITY;
+        P[64] = ok ? fs_rcp(sel) : 1.0;
+        P[65] = ok ? 0.0 : 1.0;
+        rsv[j] = ok ? 1.0 / sqrt(sel) : 1.0;
+      }
+    }
     if (r == j) {
 #pragma unroll
-      for (int ii = 0; ii <= i; ++ii) xb[g + 4 * ii] = x[ii];
+      for (int ii = 0; ii < 16; ++ii)
+        if (g + 4 * ii < j) P[g + 4 * ii] = y[ii];
     }
     __syncthreads();
-    const double d = cb[j];
-    const bool ok = d > 0.0 && d < INFINITY;
-    bad = bad || !ok;
-    const double p = ok ? 1.0 / d : 1.0;
-    if (r == j) rs = ok ? 1.0 / sqrt(d) : 1.0;
-    const double arj = (r > j) ? cb[r] * p : 0.0;
+    const double pv = P[64];
+    bad = bad || P[65] != 0.0;
+    const double m = (r > j) ? P[r] * pv : 0.0;
+    double v[16];
 #pragma unroll
-    for (int ii = i; ii < 16; ++ii) {
-      const int c = g + 4 * ii;
-      if (ii > i || g > gj) a[ii] -= arj * cb[c];       // columns c > j (the test is wave-uniform)
-    }
+    for (int ii = 0; ii < 16; ++ii) v[ii] = P[g + 4 * ii];
 #pragma unroll
-    for (int ii = 0; ii <= i; ++ii) {
-      const int c = g + 4 * ii;
-      if (ii < i || g <= gj) x[ii] -= arj * xb[c];      // columns c <= j
+    for (int ii = 0; ii < 16; ++ii) {
+      const double t = fma(-m, v[ii], y[ii]);
+      y[ii] = (ii == i && g == gj) ? ((r == j) ? 1.0 : -m) : t;
     }
   }
+  __syncthreads();
+  const double rs = rsv[r];
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int c = g + 4 * i;
-    out[r * FB + c] = (c <= r) ? x[i] * rs : 0.0;
+    out[r * FB + c] = (c <= r) ? y[i] * rs : 0.0;
   }
   if (bad && tid == 0) atomicExch(fail, 1);
 }
@@ -410,7 +427,7 @@ __device__ __forceinline__ void fs_zero_acc(f64x4 (&acc)[2][2]) {
 __global__ __launch_bounds__(256) void fs_diag0_kernel(const double* __restrict__ G, int m, double* __restrict__ linv,
                                                        int* __restrict__ fail) {
   __shared__ __attribute__((aligned(16))) double T[FB * FQ];
-  __shared__ __attribute__((aligned(16))) double Xs[256];
+  __shared__ __attribute__((aligned(16))) double Xs[512];
   for (int e = threadIdx.x; e < FB * FB; e += 256) T[(e >> 6) * FQ + (e & 63)] = G[(int64_t)(e >> 6) * m + (e & 63)];
   __syncthreads();
   fs_chol_inv_tile(T, Xs, linv, fail, threadIdx.x);
