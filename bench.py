@@ -493,9 +493,21 @@ def main():
                 t_prod = time_events(lambda: ops.matmul(cm, xm), iters=20)
                 fl = 2.0 * n * n * m_blk
                 del cm, xm
+                # HBM-side bytes per launch and the matrix-pipe busy share from the committed counter passes over the
+                # same kernel (tools/pmc_driver eigh, tools/pmc_filtered_summary.py); counters cannot be read in-process
+                trf = {"traffic": None}
+                pmc = pmc_file("pmc_gemm_f64_r*.json", ("gemm_f64.hip", "eigh_filtered.hip"))
+                if pmc and pmc["data"].get("traffic_bytes_per_launch"):
+                    dd = pmc["data"]
+                    trf = {"traffic": dd["traffic_bytes_per_launch"],
+                           "traffic_source": pmc["source"] + ": (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per launch, %.2f x the "
+                                             "algorithmic bytes 8 (n^2 + 2 n m)" % dd["traffic_over_algorithmic"],
+                           "traffic_stale": pmc["stale"]}
+                    if dd.get("mfma_busy_over_cu_busy_x4_percent") is not None:
+                        trf["mfma_util_pmc_percent"] = dd["mfma_busy_over_cu_busy_x4_percent"]
                 result["roofline"] = {
                     "bound": "mfma", "achieved": fl / t_prod / 1e12, "peak": PEAK_F64_MFMA / 1e12, "unit": "TFLOP/s",
-                    "frac": fl / t_prod / PEAK_F64_MFMA, "traffic": None,
+                    "frac": fl / t_prod / PEAK_F64_MFMA, **trf,
                     "kernel": "gemm_f64_glds_kernel<5, false> (C X of the Chebyshev filter: %d x %d x %d f64, "
                               "v_mfma_f64_16x16x4_f64, LDS-DMA staged 128 x 80 tiles)" % (n, n, m_blk),
                     "n": n, "m": m_blk, "launches": nprod, "avg_launch_us": t_prod * 1e6,

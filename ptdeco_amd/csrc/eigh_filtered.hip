@@ -365,7 +365,7 @@ __device__ __forceinline__ void fs_chol_inv_tile(const double* __restrict__ A, d
         const bool ok = sel > 0.0 && sel < INFINITY;
         P[64] = ok ? fs_rcp(sel) : 1.0;
         P[65] = ok ? 0.0 : 1.0;
-        rsv[j] = ok ? 1.0 / sqrt(sel) : 1.0;
+        rsv[j] = ok ? sel : 1.0;            // the pivot; its inverse square root is taken once, after the sweep
       }
     }
     if (r == j) {
@@ -381,13 +381,15 @@ __device__ __forceinline__ void fs_chol_inv_tile(const double* __restrict__ A, d
 #pragma unroll
     for (int ii = 0; ii < 16; ++ii) v[ii] = P[g + 4 * ii];
 #pragma unroll
-    for (int ii = 0; ii < 16; ++ii) {
-      const double t = fma(-m, v[ii], y[ii]);
-      y[ii] = (ii == i && g == gj) ? ((r == j) ? 1.0 : -m) : t;
+    for (int ii = 0; ii < 16; ++ii) y[ii] = fma(-m, v[ii], y[ii]);
+    if (g == gj) {                         // (wave-uniform) the slot of column j changes hands: X[r][j] = -Lhat[r][j]
+      const double xj = (r == j) ? 1.0 : -m;
+#pragma unroll
+      for (int ii = 0; ii < 16; ++ii) y[ii] = (ii == i) ? xj : y[ii];
     }
   }
   __syncthreads();
-  const double rs = rsv[r];
+  const double rs = 1.0 / sqrt(rsv[r]);
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int c = g + 4 * i;

@@ -5,6 +5,7 @@
 //   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d out -- tools/pmc_driver 4096
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -54,8 +55,42 @@ static int run_mfma() {
   return 0;
 }
 
+// mode "eigh": ptd_eigh_topk(n = 4096, k = 1024, top-k only) on a covariance with a decaying spectrum -- the filtered
+// subspace-iteration route -- for counter passes over its dominant kernel:
+//   rocprofv3 --pmc FETCH_SIZE --kernel-include-regex gemm_f64_glds --kernel-trace --output-format csv -d out -- tools/pmc_driver eigh
+static int run_eigh() {
+  const int64_t n = 4096, T = 8192, k = 1024;
+  std::vector<float> h((size_t)T * n);
+  unsigned long long s = 0x9E3779B97F4A7C15ull;
+  for (int64_t t = 0; t < T; ++t)
+    for (int64_t c = 0; c < n; ++c) {
+      s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+      const double u = (double)(s >> 11) * (2.0 / 9007199254740992.0) - 1.0;
+      h[t * n + c] = (float)(u * pow(10.0, -2.0 * (double)c / (double)(n - 1)));
+    }
+  float* Y; double *E, *C, *evals, *evecs; void *ws, *ws2;
+  const size_t wsb = ptd_eigh_workspace_bytes(n), ws2b = ptd_cov_finalize_workspace_bytes(n);
+  if (hipMalloc(&Y, h.size() * 4) || hipMalloc(&E, n * n * 8) || hipMalloc(&C, n * n * 8) || hipMalloc(&evals, n * 8) ||
+      hipMalloc(&evecs, n * k * 8) || hipMalloc(&ws, wsb) || hipMalloc(&ws2, ws2b ? ws2b : 256)) return 2;
+  (void)hipMemcpy(Y, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+  (void)hipMemset(E, 0, n * n * 8);
+  int rc = ptd_syrk_accumulate(Y, T, n, n, PTD_F32, E, n, PTD_F64, 1.0 / (double)T, nullptr);
+  rc |= ptd_cov_finalize(E, n, PTD_F64, nullptr, PTD_F64, n, 1.0, 0.01, C, n, ws2, ws2b, nullptr);
+  if (rc) { fprintf(stderr, "eigh mode (covariance) rc=%d: %s\n", rc, ptd_last_error()); return 1; }
+  for (int rep = 0; rep < 2; ++rep) {
+    rc = ptd_eigh_topk(C, n, n, k, 0, evals, evecs, k, ws, wsb, nullptr, nullptr);
+    if (rc) { fprintf(stderr, "eigh mode rc=%d: %s\n", rc, ptd_last_error()); return 1; }
+  }
+  (void)hipDeviceSynchronize();
+  std::vector<double> he(n);
+  (void)hipMemcpy(he.data(), evals, n * 8, hipMemcpyDeviceToHost);
+  printf("eigh mode done: lambda_max %.6e lambda_k %.6e\n", he[n - 1], he[n - k]);
+  return 0;
+}
+
 int main(int argc, char** argv) {
   if (argc > 1 && !strcmp(argv[1], "mfma")) return run_mfma();
+  if (argc > 1 && !strcmp(argv[1], "eigh")) return run_eigh();
   const int64_t n = argc > 1 ? atoll(argv[1]) : 4096;
   const int reps = argc > 2 ? atoi(argv[2]) : 1;
   std::vector<double> h((size_t)n * n);

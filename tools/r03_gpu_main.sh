@@ -37,3 +37,6 @@ fi
 if [[ $PARTS == *determ* ]]; then
   step 200 determ bash -c "python tools/filtered_determinism.py 2> gpurun_out/determinism.err"; grep -v amdgpu.ids gpurun_out/determinism.err | awk '/--- run/{r=$3} /checksum/{print r, $0}' | sort -k4,4 -s | awk '{key=$4" "$5" "$6" "$7; if (key==prev && $NF!=pv) print "DIFF:", $0; prev=key; pv=$NF}' | head; grep -c checksum gpurun_out/determinism.err
 fi
+if [[ $PARTS == *mfab* ]]; then
+  step 300 mfab bash -c "python tools/mfma_shape_ab.py > gpurun_out/mfma_shape_ab.txt 2> gpurun_out/mfma_shape_ab.err"; cat gpurun_out/mfma_shape_ab.txt; grep -v amdgpu.ids gpurun_out/mfma_shape_ab.err | tail -5
+fi

@@ -33,4 +33,9 @@ if [ "$PART" = all ] || [ "$PART" = pmc ]; then
   done
   timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-include-regex "syrk|gemm" --kernel-trace --output-format csv -d $G/gpurun_out/pmc_mfma -- $G/tools/pmc_driver mfma > $G/gpurun_out/pmc_mfma.log 2>&1; echo "pmc_mfma rc=$?"
   timeout -k 10 300 rocprofv3 --pmc MfmaUtil --kernel-include-regex "syrk|gemm" --kernel-trace --output-format csv -d $G/gpurun_out/pmc_mfma2 -- $G/tools/pmc_driver mfma > $G/gpurun_out/pmc_mfma2.log 2>&1; echo "pmc_mfma2 rc=$?"
+  # the dominant kernel of the default eigensolver route (filtered subspace iteration): the product C X
+  for c in FETCH_SIZE:pmcf_fetch WRITE_SIZE:pmcf_write "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE":pmcf_mfma; do
+    ctr=${c%%:*}; dir=${c##*:}
+    timeout -k 10 300 rocprofv3 --pmc $ctr --kernel-include-regex gemm_f64_glds --kernel-trace --output-format csv -d $G/gpurun_out/$dir -- $G/tools/pmc_driver eigh > $G/gpurun_out/$dir.log 2>&1; echo "$dir rc=$?"
+  done
 fi
