@@ -7,7 +7,9 @@ set -o pipefail
 R=${1:-02}; PART=${2:-all}
 cd $GRAFT_REPO_ROOT
 if [ "$PART" = all ] || [ "$PART" = main ]; then
-  timeout -k 10 900 python -m pytest tests -q -m gpu > gpurun_out/gpu_tests_r$R.log 2>&1; echo "tests rc=$?"; tail -2 gpurun_out/gpu_tests_r$R.log
+  timeout -k 10 1100 python -m pytest tests -q -m gpu > gpurun_out/gpu_tests_r$R.log 2>&1; echo "tests rc=$?"; tail -2 gpurun_out/gpu_tests_r$R.log
+fi
+if [ "$PART" = all ] || [ "$PART" = main ] || [ "$PART" = bench ]; then
   timeout -k 10 500 python bench.py --steps 5 --warmup 1 > gpurun_out/bench_r$R.json 2> gpurun_out/bench_r$R.err; echo "bench rc=$?"
   cut -c1-200 gpurun_out/bench_r$R.json
   (cd /tmp && export TMPDIR=/tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_r$R -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-extras > $GRAFT_REPO_ROOT/gpurun_out/prof_r$R.log 2>&1); echo "rocprof rc=$?"
