@@ -78,6 +78,7 @@ static int eigh_dispatch(const double* A, int64_t lda, int64_t n, int64_t k, dou
   // a quarter of the spectrum of a large matrix: filtered subspace iteration on the f64 matrix cores; it declines
   // (flat spectrum, breakdown, residual above tolerance) with PTD_ERR_UNSUPPORTED and the direct route below runs
   if (method == 2 && A && evals && evecs && ws && lda >= n && k >= 1 && k <= n && ldv >= k && (lda % 2) == 0 &&
+      (reinterpret_cast<uintptr_t>(A) & 15) == 0 &&
       eigh_filtered_applies(n, k, all_values) && ws_bytes >= eigh_filtered_workspace_bytes(n)) {
     const int rc = eigh_filtered(A, lda, n, k, evals, evecs, ldv, ws, ws_bytes, stats, st);
     if (rc != PTD_ERR_UNSUPPORTED) {

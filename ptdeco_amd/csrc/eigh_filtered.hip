@@ -96,16 +96,42 @@ __global__ __launch_bounds__(256) void fs_symv4_kernel(const double* __restrict_
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int v = 0; v < LZ_NV; ++v) acc[i][v] = 0.0;
-    for (int k = lane; k < n; k += 64) {
+    // a lane takes two consecutive k per trip (16-byte loads of A), two trips unrolled: 8 row loads in flight
+    const int n2 = n & ~255;
+    for (int k0 = 2 * lane; k0 < n2; k0 += 256) {
+      double2 av[2][4];
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          av[u][i] = (r0 + i < n) ? *reinterpret_cast<const double2*>(A + (int64_t)(r0 + i) * lda + k0 + 128 * u)
+                                  : double2{0.0, 0.0};
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int k = k0 + 128 * u;
+        const double2 qa01 = *reinterpret_cast<const double2*>(q + (int64_t)k * LZ_NV);
+        const double2 qa23 = *reinterpret_cast<const double2*>(q + (int64_t)k * LZ_NV + 2);
+        const double2 qb01 = *reinterpret_cast<const double2*>(q + (int64_t)(k + 1) * LZ_NV);
+        const double2 qb23 = *reinterpret_cast<const double2*>(q + (int64_t)(k + 1) * LZ_NV + 2);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          acc[i][0] += av[u][i].x * qa01.x + av[u][i].y * qb01.x;
+          acc[i][1] += av[u][i].x * qa01.y + av[u][i].y * qb01.y;
+          acc[i][2] += av[u][i].x * qa23.x + av[u][i].y * qb23.x;
+          acc[i][3] += av[u][i].x * qa23.y + av[u][i].y * qb23.y;
+        }
+      }
+    }
+    for (int k = n2 + lane; k < n; k += 64) {
       const double2 q01 = *reinterpret_cast<const double2*>(q + (int64_t)k * LZ_NV);
       const double2 q23 = *reinterpret_cast<const double2*>(q + (int64_t)k * LZ_NV + 2);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const double av = (r0 + i < n) ? A[(int64_t)(r0 + i) * lda + k] : 0.0;
-        acc[i][0] += av * q01.x;
-        acc[i][1] += av * q01.y;
-        acc[i][2] += av * q23.x;
-        acc[i][3] += av * q23.y;
+        const double a1 = (r0 + i < n) ? A[(int64_t)(r0 + i) * lda + k] : 0.0;
+        acc[i][0] += a1 * q01.x;
+        acc[i][1] += a1 * q01.y;
+        acc[i][2] += a1 * q23.x;
+        acc[i][3] += a1 * q23.y;
       }
     }
 #pragma unroll

@@ -40,3 +40,6 @@ fi
 if [[ $PARTS == *mfab* ]]; then
   step 300 mfab bash -c "python tools/mfma_shape_ab.py > gpurun_out/mfma_shape_ab.txt 2> gpurun_out/mfma_shape_ab.err"; cat gpurun_out/mfma_shape_ab.txt; grep -v amdgpu.ids gpurun_out/mfma_shape_ab.err | tail -5
 fi
+if [[ $PARTS == *c4cpu* ]]; then
+  step 1000 c4cpu bash -c "python tools/c4_shapes_cpu.py > gpurun_out/c4_cpu_r03.json 2> gpurun_out/c4_cpu.err"; tail -3 gpurun_out/c4_cpu.err; cut -c1-400 gpurun_out/c4_cpu_r03.json
+fi
