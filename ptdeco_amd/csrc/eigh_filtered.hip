@@ -374,14 +374,14 @@ __device__ __forceinline__ void fs_chol_inv_tile(const double* __restrict__ A, d
     y[i] = (c <= r) ? A[r * FQ + c] : 0.0;
   }
   __syncthreads();   // (buf may alias the tile's neighbours; everyone has its row)
-  buf[tid] = 0.0;    // two lines of 128: [0, 64) P, [64] p, [65] bad;  [256, 320): 1 / sqrt(pivot) per row
+  buf[tid] = 0.0;    // two lines of 160: [0, 64) column, [64] p, [65] bad, [66, 130) row of X;  [320, 384): pivots
   buf[tid + 256] = 0.0;
-  double* rsv = buf + 256;
+  double* rsv = buf + 320;
   bool bad = false;
 #pragma unroll 1
   for (int j = 0; j < FB; ++j) {
     const int i = j >> 2, gj = j & 3;
-    double* P = buf + (j & 1) * 128;
+    double* P = buf + (j & 1) * 160;
     if (g == gj) {
       double sel = y[0];
 #pragma unroll
@@ -394,10 +394,9 @@ __device__ __forceinline__ void fs_chol_inv_tile(const double* __restrict__ A, d
         rsv[j] = ok ? sel : 1.0;            // the pivot; its inverse square root is taken once, after the sweep
       }
     }
-    if (r == j) {
+    if (r == j) {                          // row j of X (columns < j; the entries beyond are never read)
 #pragma unroll
-      for (int ii = 0; ii < 16; ++ii)
-        if (g + 4 * ii < j) P[g + 4 * ii] = y[ii];
+      for (int ii = 0; ii < 16; ++ii) P[66 + g + 4 * ii] = y[ii];
     }
     __syncthreads();
     const double pv = P[64];
@@ -405,7 +404,10 @@ __device__ __forceinline__ void fs_chol_inv_tile(const double* __restrict__ A, d
     const double m = (r > j) ? P[r] * pv : 0.0;
     double v[16];
 #pragma unroll
-    for (int ii = 0; ii < 16; ++ii) v[ii] = P[g + 4 * ii];
+    for (int ii = 0; ii < 16; ++ii) {
+      const int c = g + 4 * ii;
+      v[ii] = P[c > j ? c : 66 + c];       // (wave-uniform choice: the column above, the row of X below)
+    }
 #pragma unroll
     for (int ii = 0; ii < 16; ++ii) y[ii] = fma(-m, v[ii], y[ii]);
     if (g == gj) {                         // (wave-uniform) the slot of column j changes hands: X[r][j] = -Lhat[r][j]

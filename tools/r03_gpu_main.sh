@@ -10,7 +10,7 @@ step() {  # step <seconds> <label> <command...>
   if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "$label hit its limit: stopping"; exit $rc; fi
   return 0
 }
-PARTS=${1:-tests,bench,rehearse,c4,probe}
+PARTS=${1:-tests,bench,rehearse,stack32,probe}
 if [[ $PARTS == *tests* ]]; then
   step 1000 tests bash -c "python -m pytest tests -q -m gpu -x --durations=15 > gpurun_out/gpu_tests_r03.log 2>&1"; tail -25 gpurun_out/gpu_tests_r03.log
 fi
@@ -20,7 +20,7 @@ fi
 if [[ $PARTS == *rehearse* ]]; then
   step 300 rehearse bash -c "PTD_BENCH_REHEARSE=1 python bench.py --gpus 2 --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/bench_r03_n2.json 2> gpurun_out/bench_r03_n2.err"; cut -c1-400 gpurun_out/bench_r03_n2.json; tail -3 gpurun_out/bench_r03_n2.err
 fi
-if [[ $PARTS == *c4* ]]; then
+if [[ $PARTS == *stack32* ]]; then
   step 900 c4stack bash -c "PTD_PHASES=1 python tools/c4_stack.py 32 bf16 > gpurun_out/c4_stack_32blocks_bf16_r03.json 2> gpurun_out/c4_stack_32.err"; cat gpurun_out/c4_stack_32blocks_bf16_r03.json | cut -c1-1500; tail -3 gpurun_out/c4_stack_32.err
 fi
 if [[ $PARTS == *probe* ]]; then
