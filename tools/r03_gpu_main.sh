@@ -43,3 +43,8 @@ fi
 if [[ $PARTS == *c4cpu* ]]; then
   step 1000 c4cpu bash -c "python tools/c4_shapes_cpu.py > gpurun_out/c4_cpu_r03.json 2> gpurun_out/c4_cpu.err"; tail -3 gpurun_out/c4_cpu.err; cut -c1-400 gpurun_out/c4_cpu_r03.json
 fi
+if [[ $PARTS == *c3ab* ]]; then
+  step 200 c3a bash -c "PTD_PHASES=1 python tools/c3_vit.py > gpurun_out/c3_phases_r03.json 2> gpurun_out/c3_phases.err"; cut -c1-260 gpurun_out/c3_phases_r03.json
+  step 200 c3b bash -c "PTD_PHASES=1 PTD_GEMM_F64_NO_GLDS=1 python tools/c3_vit.py > gpurun_out/c3_phases_noglds.json 2> gpurun_out/c3_phases2.err"; cut -c1-260 gpurun_out/c3_phases_noglds.json
+  step 200 c3c bash -c "python tools/c3_vit.py > gpurun_out/c3_plain.json 2> gpurun_out/c3_plain.err"; cut -c1-260 gpurun_out/c3_plain.json
+fi

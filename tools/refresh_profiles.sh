@@ -20,6 +20,7 @@ if [ "$PART" = all ] || [ "$PART" = c4 ] || [ "$PART" = c4gpu ]; then
   timeout -k 10 300 python tools/c4_stack.py 2 > gpurun_out/c4_stack_f32_r$R.json 2> gpurun_out/c4_stack_f32.err; echo "c4 stack f32 rc=$?"
   timeout -k 10 300 python tools/c4_stack.py 2 bf16 > gpurun_out/c4_stack_bf16_r$R.json 2> gpurun_out/c4_stack_bf16.err; echo "c4 stack bf16 rc=$?"
   timeout -k 10 300 python tools/c3_vit.py > gpurun_out/c3_vit_r$R.json 2> gpurun_out/c3_vit.err; echo "c3 rc=$?"
+  PTD_PHASES=1 timeout -k 10 300 python tools/c3_vit.py > gpurun_out/c3_phases_r$R.json 2> gpurun_out/c3_phases.err; echo "c3 phases rc=$?"
 fi
 if [ "$PART" = all ] || [ "$PART" = c4 ] || [ "$PART" = c4cpu ]; then
   # (the torch-CPU oracle on the box's host cores: ~8 minutes; the tool writes a line a minute to gpurun_out/c4_cpu.err)
