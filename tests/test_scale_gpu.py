@@ -49,6 +49,32 @@ def test_eigh_full_size_properties(n, k):
     assert ((c @ v) @ v.T - rec).abs().max().item() <= 1e-10 * wmax
 
 
+def test_eigh_filtered_route_at_8192_properties(monkeypatch):
+    """The filtered subspace iteration on a matrix four times the headline's size (n = 8192, k = 2048: subspace 2560,
+    24 MB of Lanczos vectors read through the caches instead of LDS): eigenpairs by their properties -- ascending, NaN
+    below the requested range, residual per vector, orthonormality -- and against the direct reduction of the same
+    matrix (eigenvalues, invariant subspaces at three ranks)."""
+    from ptdeco_amd import ops
+
+    n, k = 8192, 2048
+    c = _cov_on_gpu(n, 16384, 5)
+    monkeypatch.setattr(ops, "EIGH_PROFILE", [])
+    w, v = ops.eigh(c, k, all_values=False)
+    assert ops.EIGH_PROFILE[0]["method"] == 3
+    monkeypatch.setattr(ops, "EIGH_PROFILE", None)
+    wk = w[n - k:]
+    assert bool(torch.isnan(w[: n - k]).all()) and bool(torch.all(wk[1:] >= wk[:-1]))
+    wmax = wk[-1].item()
+    assert (c @ v - v * wk).norm(dim=0).max().item() <= 2e-10 * wmax
+    assert (v.T @ v - torch.eye(k, dtype=torch.float64, device=DEV)).abs().max().item() <= 1e-10
+    monkeypatch.setenv("PTD_EIGH_FILTERED", "0")
+    w0, v0 = ops.eigh(c, k, all_values=False)
+    assert (w0[n - k:] - wk).abs().max().item() <= 1e-12 * wmax
+    for r in (2048, 512, 64):
+        d2 = 2.0 * r - 2.0 * (v[:, k - r:].T @ v0[:, k - r:]).pow(2).sum().item()
+        assert d2 <= (1e-6 * r ** 0.5) ** 2 + 1e-9, (r, d2)
+
+
 def test_syrk_full_size_linearity():
     """E(Y1;Y2) = E(Y1) + E(Y2) and scaling, at n = 4096, T = 4096 (f32 -> f64)."""
     from ptdeco_amd import ops
