@@ -637,9 +637,14 @@ struct FilterPlan {
 };
 
 int filter_block(int64_t n, int64_t k) {
-  // k + 25 % (at least 128 more), a multiple of 320 = lcm(64: Cholesky blocks, 80: column tile of the products)
-  const int64_t want = k + std::max<int64_t>(k / 4, 128);
-  return (int)std::min<int64_t>(align_up((size_t)want, 320), n / 128 * 128);
+  // k + a fraction of k more (at least 128), a multiple of 64 (the panels of the Cholesky sweep; the products pick
+  // their column tile from 64 / 80 / 96 / 128).  The fraction trades products for the Rayleigh-Ritz problem: 1/4
+  // (m = 1280 at k = 1024) takes 16 products and an order-1280 eigenproblem, 1/2 (m = 1536) 9 wider products, four
+  // Cholesky-QR passes instead of six and an order-1536 eigenproblem.  PTD_EIGH_FILTER_OVERSAMPLE overrides.
+  const char* e = getenv("PTD_EIGH_FILTER_OVERSAMPLE");
+  const double f = e ? std::min(1.0, std::max(0.05, atof(e))) : 0.25;
+  const int64_t want = k + std::max<int64_t>((int64_t)ceil((double)k * f), 128);
+  return (int)std::min<int64_t>(align_up((size_t)want, 64), n / 128 * 128);
 }
 
 FilterPlan filter_plan(int64_t n, int64_t k) {

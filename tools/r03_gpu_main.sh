@@ -48,3 +48,14 @@ if [[ $PARTS == *c3ab* ]]; then
   step 200 c3b bash -c "PTD_PHASES=1 PTD_GEMM_F64_NO_GLDS=1 python tools/c3_vit.py > gpurun_out/c3_phases_noglds.json 2> gpurun_out/c3_phases2.err"; cut -c1-260 gpurun_out/c3_phases_noglds.json
   step 200 c3c bash -c "python tools/c3_vit.py > gpurun_out/c3_plain.json 2> gpurun_out/c3_plain.err"; cut -c1-260 gpurun_out/c3_plain.json
 fi
+if [[ $PARTS == *oversample* ]]; then
+  for f in 0.25 0.375 0.5; do
+    step 200 over$f bash -c "PTD_EIGH_FILTER_OVERSAMPLE=$f PTD_JACOBI_DEBUG=1 python tools/filtered_probe.py > gpurun_out/filtered_probe_os$f.json 2> gpurun_out/filtered_probe_os$f.err"
+    python - <<PY
+import json
+d=json.load(open("gpurun_out/filtered_probe_os$f.json"))
+print("oversample $f:", round(d["filtered_ms"],2), "ms", [round(x,2) for x in d["filtered_profile"]["ms"]], d["filtered_profile"]["launches"], "resid %.1e orth %.1e dv %.1e" % (d["filtered"]["resid"], d["filtered"]["orth"], d["filtered"]["max_dv"]))
+PY
+    grep "eigh_filtered\] n=" gpurun_out/filtered_probe_os$f.err | head -1
+  done
+fi
