@@ -244,30 +244,23 @@ __global__ __launch_bounds__(1024) void fs_shift_kernel(double* __restrict__ G, 
   for (int i = tid; i < m; i += 1024) G[(int64_t)i * m + i] += sh;
 }
 
-// H <- (H + H^T) / 2 in place (tiles on and above the diagonal own the pair; every operand is read before the
-// barrier, every result written after it: a diagonal tile is its own mirror)
+// H[j][i] = H[i][j] for j > i: the upper triangle is the mirror of the lower one (the product computed only the
+// tiles that touch the lower triangle)
 __global__ __launch_bounds__(256) void fs_symmetrize_kernel(double* __restrict__ H, int m) {
   __shared__ double t[32][33];
-  const int bi = blockIdx.y, bj = blockIdx.x;
-  if (bj < bi) return;
+  const int bi = blockIdx.y, bj = blockIdx.x;      // lower tile (bi, bj), bj <= bi, is copied to (bj, bi)
+  if (bj > bi) return;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  double own[4];
   for (int q = 0; q < 4; ++q) {
     const int r = ty + 8 * q;
-    const int im = bj * 32 + r, jm = bi * 32 + tx;   // element (im, jm) of the mirror tile
-    t[r][tx] = (im < m && jm < m) ? H[(int64_t)im * m + jm] : 0.0;
     const int i = bi * 32 + r, j = bj * 32 + tx;
-    own[q] = (i < m && j < m) ? H[(int64_t)i * m + j] : 0.0;
+    t[r][tx] = (i < m && j < m) ? H[(int64_t)i * m + j] : 0.0;
   }
   __syncthreads();
   for (int q = 0; q < 4; ++q) {
     const int r = ty + 8 * q;
-    const int i = bi * 32 + r, j = bj * 32 + tx;
-    if (i < m && j < m) {
-      const double v = 0.5 * (own[q] + t[tx][r]);
-      H[(int64_t)i * m + j] = v;
-      H[(int64_t)j * m + i] = v;
-    }
+    const int i = bj * 32 + r, j = bi * 32 + tx;   // element (i, j) of the mirror tile = lower element (j, i) = t[tx][r]
+    if (i < m && j < m && j > i) H[(int64_t)i * m + j] = t[tx][r];
   }
 }
 
@@ -848,7 +841,9 @@ int eigh_filtered(const double* A, int64_t lda, int64_t n, int64_t k, double* ev
   auto gram = [&](const double* P, const double* Q, double* Out, double* scratch) -> int {
     int ns = 1;
     const int64_t slab = (int64_t)m * m;
-    int r2 = gemm_f64_slabs(P, 1, m, Q, m, 1, scratch, m, slab, m, m, n, 1.0, ksplit_mm, &ns, st);
+    // (P^T Q is symmetric for both uses: tiles entirely above the diagonal are not computed; their entries of Out are
+    // unspecified and never read: the sweep walks the lower 64 x 64 tiles, H is mirrored from its lower triangle)
+    int r2 = gemm_f64_slabs(P, 1, m, Q, m, 1, scratch, m, slab, m, m, n, 1.0, ksplit_mm, &ns, true, st);
     if (r2 != PTD_OK) return r2;
     hipLaunchKernelGGL(fs_sum_slabs_kernel, dim3(1024), dim3(256), 0, st, Out, scratch, slab, ns, slab / 2);
     return PTD_OK;

@@ -32,6 +32,7 @@ struct GemmF64Args {
   int beta1;   // 1: accumulate into C
   int atomic;  // 1: split K, accumulate with atomics (requires beta1)
   int64_t slab;  // > 0: split K without atomics -- K range y writes its partial product to C + y * slab (elements)
+  int lower;     // 1: tiles that lie entirely above the diagonal are skipped (symmetric results: X^T X)
   int kchunk;
   int tiles_m;
   const double* A2;  // optional second operand pair with the same strides: C gets A B + A2 B2 in one pass
@@ -209,6 +210,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_glds_kernel(const GemmF64Args
   const int tiles_n = a.N / BN;
   const int ti = wg / tiles_n, tj = wg % tiles_n;
   const int m0 = ti * GM, n0 = tj * BN;
+  if (a.lower && n0 >= m0 + GM) return;   // (wave-uniform: the whole workgroup leaves)
   const int kbeg = blockIdx.y * a.kchunk;
   const int kend = min(a.K, kbeg + a.kchunk);
   const int nk = (kend - kbeg) / GK;
@@ -369,7 +371,8 @@ static int glds_nt(int64_t M, int64_t N, int64_t K, int ksplit) {
 // C = alpha * op(A) op(B) + (beta1 ? C : 0).  ksplit > 1 needs beta1 (C must hold the addend).
 static int gemm_f64_impl(const double* A, int64_t sam, int64_t sak, const double* B, int64_t sbk, int64_t sbn,
                          const double* A2, const double* B2, double* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
-                         double alpha, bool beta1, int ksplit, double* row0_out, hipStream_t st, int64_t slab = 0);
+                         double alpha, bool beta1, int ksplit, double* row0_out, hipStream_t st, int64_t slab = 0,
+                         bool lower_only = false);
 
 int gemm_f64(const double* A, int64_t sam, int64_t sak, const double* B, int64_t sbk, int64_t sbn, double* C,
              int64_t ldc, int64_t M, int64_t N, int64_t K, double alpha, bool beta1, int ksplit, hipStream_t st) {
@@ -380,11 +383,11 @@ int gemm_f64(const double* A, int64_t sam, int64_t sak, const double* B, int64_t
 // the slabs in index order (a deterministic sum).  Returns the number of slabs written in *nslabs.
 int gemm_f64_slabs(const double* A, int64_t sam, int64_t sak, const double* B, int64_t sbk, int64_t sbn, double* C,
                    int64_t ldc, int64_t slab, int64_t M, int64_t N, int64_t K, double alpha, int ksplit, int* nslabs,
-                   hipStream_t st) {
+                   bool lower_only, hipStream_t st) {
   const int kchunk = (int)align_up((size_t)ceil_div(std::max<int64_t>(K, 1), std::max(ksplit, 1)), DK);
   *nslabs = (int)ceil_div(std::max<int64_t>(K, 1), kchunk);
   return gemm_f64_impl(A, sam, sak, B, sbk, sbn, nullptr, nullptr, C, ldc, M, N, K, alpha, false, -ksplit, nullptr, st,
-                       slab);
+                       slab, lower_only);
 }
 
 // C += alpha * (A B + A2 B2), both pairs with the same strides, in ONE pass over C
@@ -396,7 +399,8 @@ int gemm_f64_pair(const double* A, const double* B, const double* A2, const doub
 
 static int gemm_f64_impl(const double* A, int64_t sam, int64_t sak, const double* B, int64_t sbk, int64_t sbn,
                          const double* A2, const double* B2, double* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
-                         double alpha, bool beta1, int ksplit, double* row0_out, hipStream_t st, int64_t slab) {
+                         double alpha, bool beta1, int ksplit, double* row0_out, hipStream_t st, int64_t slab,
+                         bool lower_only) {
   if (M <= 0 || N <= 0) return PTD_OK;
   GemmF64Args a{};
   a.A = A; a.sam = sam; a.sak = sak;
@@ -413,6 +417,7 @@ static int gemm_f64_impl(const double* A, int64_t sam, int64_t sak, const double
   ksplit = (int)ceil_div(std::max<int64_t>(K, 1), a.kchunk);
   a.atomic = ksplit > 1 && slab == 0;
   a.slab = slab;
+  a.lower = 0;
   const bool akc = (sak == 1), bkc = (sbk == 1);
   // the LDS-DMA kernel: B rows N-contiguous, A rows K- or M-contiguous, 16-byte aligned everything
   static const bool no_glds = getenv("PTD_GEMM_F64_NO_GLDS") != nullptr;
@@ -422,6 +427,7 @@ static int gemm_f64_impl(const double* A, int64_t sam, int64_t sak, const double
     const int nt = glds_nt(M, N, K, ksplit);
     const bool am = sak != 1;
     if (nt) {
+      a.lower = lower_only ? 1 : 0;     // (only this kernel skips; the 64 x 64 kernel computes every tile)
       switch (nt * 2 + (am ? 1 : 0)) {
         case 16: launch_glds<8, false>(a, ksplit, st); break;
         case 17: launch_glds<8, true>(a, ksplit, st); break;

@@ -39,7 +39,7 @@ int gemm_f64(const double* A, int64_t sam, int64_t sak, const double* B, int64_t
 
 int gemm_f64_slabs(const double* A, int64_t sam, int64_t sak, const double* B, int64_t sbk, int64_t sbn, double* C,
                    int64_t ldc, int64_t slab, int64_t M, int64_t N, int64_t K, double alpha, int ksplit, int* nslabs,
-                   hipStream_t st);
+                   bool lower_only, hipStream_t st);
 
 // eigh_tridiag.hip
 size_t tridiag_workspace_bytes(int64_t n);
