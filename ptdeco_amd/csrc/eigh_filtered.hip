@@ -813,6 +813,9 @@ int eigh_filtered(const double* A, int64_t lda, int64_t n, int64_t k, double* ev
   const double g_eff = 1.0 + 0.9 * (growth - 1.0);
   int degree = (int)ceil(log(0.05 / tol) / log(g_eff));
   degree = std::max(degree, 4);
+  // test hook: PTD_EIGH_FILTER_FORCE_DEGREE=<d> spends d products before the first Rayleigh-Ritz step whatever the
+  // estimate says (an under-provisioned first attempt exercises the retry rounds)
+  if (const char* fd = getenv("PTD_EIGH_FILTER_FORCE_DEGREE")) degree = std::max(2, atoi(fd));
   if (debug)
     fprintf(stderr, "[eigh_filtered] n=%lld k=%lld m=%d: lo %.3e a %.3e lambda_k~%.3e hi %.3e growth %.2f/product -> "
                     "%d products\n", (long long)n, (long long)k, m, lo, a_cut, lam_k, hi, growth, degree);

@@ -375,6 +375,23 @@ def test_eigh_filtered_subspace_route_matches_lapack(ops, monkeypatch, n, k):
     assert d2 <= (1e-6 * math.sqrt(k)) ** 2 + 1e-9
 
 
+def test_eigh_filtered_route_retries_when_the_first_attempt_falls_short(ops, monkeypatch):
+    """The degree of the filter comes from a density ESTIMATE; when it was too optimistic the residual check after the
+    Rayleigh-Ritz step says so and the route spends one more round sized by the rate it measured (at most twice) instead
+    of returning loose eigenpairs.  PTD_EIGH_FILTER_FORCE_DEGREE under-provisions the first attempt: the profile shows
+    more products than were forced, the result meets the same bounds as an ordinary call."""
+    n, k = 2048, 512
+    a = _twist_case_matrix(n).to(DEV)
+    w_ref = torch.linalg.eigvalsh(a.cpu())
+    scale = w_ref.abs().max().item()
+    monkeypatch.setenv("PTD_EIGH_FILTER_FORCE_DEGREE", "7")
+    w, v, prof = _profiled_eigh(ops, monkeypatch, a, k)
+    assert prof["method"] == 3 and prof["launches"][1] > 7 + 1, prof     # forced products + Rayleigh-Ritz + a retry
+    assert (w[n - k:] - w_ref[n - k:]).abs().max().item() <= 1e-12 * scale
+    assert (a.cpu() @ v - v * w[n - k:]).norm(dim=0).max().item() <= 2e-10 * scale
+    assert (v.T @ v - torch.eye(k, dtype=torch.float64)).abs().max().item() <= 1e-10
+
+
 def test_eigh_filtered_route_declines_where_it_does_not_apply(ops, monkeypatch):
     """A flat spectrum (identity plus noise: nothing for a polynomial filter to separate), a matrix whose requested
     eigenvalues sit in a degenerate cluster (rank-deficient covariance: fewer rows than k), and a request for all
