@@ -337,17 +337,19 @@ __device__ __forceinline__ void fs_tile_abt(const double* __restrict__ Ps, const
 }
 
 // ---- Cholesky factor and its inverse of a 64 x 64 SPD tile, one workgroup of 256 threads
-// Thread (r = tid & 63, g = tid >> 6) keeps row r in REGISTERS, columns c = g mod 4: ONE array y[16] that holds A[r][c]
-// while column c is still to be eliminated and X[r][c] (X = Lhat^-1, Lhat = L D^-1 unit lower) from then on -- a
-// column's entries are dead once it has been published.  Right-looking, ONE barrier per column j: the owners publish
-// one 64-entry LDS line P (double buffered) with P[c] = A[c][j] for c > j (the unscaled column) and P[c] = X[j][c] for
-// c < j (row j of the inverse, final by then), and p = 1 / A[j][j]; then with m = A[r][j] p (zero for r <= j)
+// Thread (r = tid & 63, g = tid >> 6) keeps row r in REGISTERS, columns c = g mod 4: ONE array y[16] that holds the FULL
+// symmetric row A[r][c] while column c is still to be eliminated and X[r][c] (X = Lhat^-1, Lhat = L D^-1 unit lower) from
+// then on.  Right-looking, ONE barrier per column j.  Because both triangles are kept current, row j of the registers IS
+// everything step j needs from elsewhere: its entries c > j are the column A[c][j] = A[j][c], its entries c < j the row
+// X[j][c] of the inverse (final by then), entry j the pivot.  So the four threads that hold row j publish one 64-entry LDS
+// line P (double buffered) and every thread does, with m = P[r] / P[j] for r > j (zero for r <= j),
 //   y[c] -= m P[c]            every column c != j   (c > j: A[r][c] -= L[r][j] L[c][j];   c < j: X[r][c] -= Lhat[r][j] X[j][c])
 //   y[j]  = r == j ? 1 : -m   the slot changes hands: X[r][j] = -Lhat[r][j]
-// The column of a slot is wave-uniform, so P[c] are broadcast reads issued together and the register array is
-// indexed statically although the loop over j is rolled.  At the end L^-1 = D^-1 X.  (History: the tile kept in LDS
-// with read-modify-write updates ~60 us per tile; separate A and X arrays with masked multipliers ~65 us -- issue
-// bound, 32 updates a step; fully unrolled over j the compiler spilled.)
+// 16 broadcast reads at fixed offsets, 16 FMAs, one reciprocal; the slot indices are static although the loop over j is
+// rolled.  At the end L^-1 = D^-1 X.  (History of this step, per 64 x 64 tile: the tile in LDS with read-modify-write
+// updates 60 us; two register arrays with masked multipliers 65 us; one array, column published by its owners and the
+// row of X by row j, addresses selected per slot 50 us -- 270 instructions a column, half of them scalar address
+// arithmetic --; one wave with `v_readlane` broadcasts, fully unrolled: the compiler spilled 35 k instructions.)
 // A: LDS tile (pitch FQ, lower triangle read); buf: 512 doubles of LDS.  A non-positive pivot raises *fail.
 constexpr int FQ = 65;
 __device__ __forceinline__ double fs_rcp(double d) {
@@ -362,59 +364,41 @@ __device__ __forceinline__ void fs_chol_inv_tile(const double* __restrict__ A, d
   const int g = __builtin_amdgcn_readfirstlane(tid >> 6);
   double y[16];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int c = g + 4 * i;
-    y[i] = (c <= r) ? A[r * FQ + c] : 0.0;
+  for (int s = 0; s < 16; ++s) {
+    const int c = g + 4 * s;
+    y[s] = (c <= r) ? A[r * FQ + c] : A[c * FQ + r];      // the full row, mirrored from the lower triangle
   }
   __syncthreads();   // (buf may alias the tile's neighbours; everyone has its row)
-  buf[tid] = 0.0;    // two lines of 160: [0, 64) column, [64] p, [65] bad, [66, 130) row of X;  [320, 384): pivots
-  buf[tid + 256] = 0.0;
-  double* rsv = buf + 320;
   bool bad = false;
+  double myd = 1.0;
 #pragma unroll 1
   for (int j = 0; j < FB; ++j) {
     const int i = j >> 2, gj = j & 3;
-    double* P = buf + (j & 1) * 160;
-    if (g == gj) {
-      double sel = y[0];
+    double* P = buf + (j & 1) * 64;
+    if (r == j) {
 #pragma unroll
-      for (int ii = 1; ii < 16; ++ii) sel = (ii == i) ? y[ii] : sel;
-      if (r > j) P[r] = sel;
-      if (r == j) {
-        const bool ok = sel > 0.0 && sel < INFINITY;
-        P[64] = ok ? fs_rcp(sel) : 1.0;
-        P[65] = ok ? 0.0 : 1.0;
-        rsv[j] = ok ? sel : 1.0;            // the pivot; its inverse square root is taken once, after the sweep
-      }
-    }
-    if (r == j) {                          // row j of X (columns < j; the entries beyond are never read)
-#pragma unroll
-      for (int ii = 0; ii < 16; ++ii) P[66 + g + 4 * ii] = y[ii];
+      for (int s = 0; s < 16; ++s) P[g + 4 * s] = y[s];
     }
     __syncthreads();
-    const double pv = P[64];
-    bad = bad || P[65] != 0.0;
-    const double m = (r > j) ? P[r] * pv : 0.0;
-    double v[16];
+    const double d = P[j];
+    const bool ok = d > 0.0 && d < INFINITY;
+    bad = bad || !ok;
+    const double p = ok ? fs_rcp(d) : 1.0;
+    myd = (r == j && ok) ? d : myd;
+    const double m = (r > j) ? P[r] * p : 0.0;
 #pragma unroll
-    for (int ii = 0; ii < 16; ++ii) {
-      const int c = g + 4 * ii;
-      v[ii] = P[c > j ? c : 66 + c];       // (wave-uniform choice: the column above, the row of X below)
-    }
-#pragma unroll
-    for (int ii = 0; ii < 16; ++ii) y[ii] = fma(-m, v[ii], y[ii]);
+    for (int s = 0; s < 16; ++s) y[s] = fma(-m, P[g + 4 * s], y[s]);
     if (g == gj) {                         // (wave-uniform) the slot of column j changes hands: X[r][j] = -Lhat[r][j]
       const double xj = (r == j) ? 1.0 : -m;
 #pragma unroll
-      for (int ii = 0; ii < 16; ++ii) y[ii] = (ii == i) ? xj : y[ii];
+      for (int s = 0; s < 16; ++s) y[s] = (s == i) ? xj : y[s];
     }
   }
-  __syncthreads();
-  const double rs = 1.0 / sqrt(rsv[r]);
+  const double rs = 1.0 / sqrt(myd);
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int c = g + 4 * i;
-    out[r * FB + c] = (c <= r) ? y[i] * rs : 0.0;
+  for (int s = 0; s < 16; ++s) {
+    const int c = g + 4 * s;
+    out[r * FB + c] = (c <= r) ? y[s] * rs : 0.0;
   }
   if (bad && tid == 0) atomicExch(fail, 1);
 }
@@ -811,7 +795,7 @@ int eigh_filtered(const double* A, int64_t lda, int64_t n, int64_t k, double* ev
   // measured on covariance spectra: the residual falls like 0.05 g^-d with g about three quarters of the way from 1
   // to the asymptotic factor (rounds restart the polynomial; the neighbours of the cut grow a little as well)
   const double g_eff = 1.0 + 0.9 * (growth - 1.0);
-  int degree = (int)ceil(log(0.05 / tol) / log(g_eff));
+  int degree = (int)ceil(log(0.1 / tol) / log(g_eff));    // (aims a factor two below the tolerance)
   degree = std::max(degree, 4);
   // test hook: PTD_EIGH_FILTER_FORCE_DEGREE=<d> spends d products before the first Rayleigh-Ritz step whatever the
   // estimate says (an under-provisioned first attempt exercises the retry rounds)
@@ -921,7 +905,7 @@ int eigh_filtered(const double* A, int64_t lda, int64_t n, int64_t k, double* ev
   if (stats) PTD_CHECK_HIP(hipEventRecord(ev[2], st));
 
   double res = 0.0, lmax = 1.0;
-  const int filter_products = products;
+  int filter_products = products;
   for (int attempt = 0;; ++attempt) {
     // ---- 3. Rayleigh-Ritz
     rc = gemm_f64(A, lda, 1, X, m, 1, Z, m, n, m, n, 1.0, false, 1, st);           // Z = C X
@@ -960,12 +944,14 @@ int eigh_filtered(const double* A, int64_t lda, int64_t n, int64_t k, double* ev
     if (res <= tol * lmax) break;
     // not there yet (the density estimate put lambda_k too high): one more round, sized by the rate measured so far
     const double rel = res / std::max(lmax, 1e-300);
-    if (attempt >= 2 || !(rel < 1e-3)) return decline("residual above the tolerance");
-    const double rate = pow(0.05 / rel, 1.0 / (double)filter_products);
-    const int extra = std::min(6, std::max(2, (int)ceil(log(rel / (0.2 * tol)) / log(std::max(rate, 1.5)))));
+    if (attempt >= 3 || !(rel < 1e-2)) return decline("residual above the tolerance");
+    const double rate = pow(0.05 / rel, 1.0 / (double)filter_products);     // over ALL filter products so far
+    const int extra = std::min(6, std::max(2, (int)ceil(log(rel / (0.1 * tol)) / log(std::max(rate, 1.5)))));
     if (debug) fprintf(stderr, "[eigh_filtered] measured %.2f per product: %d more\n", rate, extra);
+    const int before = products;
     rc = filter_round(extra);
     if (rc != PTD_OK) { cleanup(); return rc; }
+    filter_products += products - before;
   }
   hipLaunchKernelGGL(fs_sign_kernel, dim3((unsigned)k), dim3(256), 0, st, evecs, ldv, (int)n);
   // eigenvalues: the k largest at the end of evals[n], NaN below (the convention of ptd_eigh_topk with all_values = 0)

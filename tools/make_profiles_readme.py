@@ -21,6 +21,11 @@ o = [f"# profiles -- round {int(rnd)} (one MI355X, ROCm 7.2, gpurun box)\n\n", "
      f"* `c3_vit_falor_r{rnd}.json` -- `python tools/c3_vit.py`: falor on a ViT-B/16-shaped model (BASELINE configs[2])\n",
      f"* `c3_vit_falor_phases_r{rnd}.json` (if present) -- the same run with `PTD_PHASES=1`: device-time split A accumulate / B eigh / C factors / D metrics. The run is the user model's own forward passes (D: 2 x 2 x 9 whole-model forwards per layer, A: 4): the eigendecompositions are about a second of its sixteen\n",
      f"* `pmc_symv_r{rnd}.json` / `.csv` -- `tools/pmc_summary.py` over separate `rocprofv3 --pmc` passes of `tools/pmc_driver 4096` (per-launch HBM traffic of the SYMV kernels)\n",
+     f"* `pmc_gemm_f64_r{rnd}.json` -- `tools/pmc_filtered_summary.py` over `rocprofv3 --pmc` passes of `tools/pmc_driver eigh` (fabric-side bytes and matrix-pipe busy share of the f64 product kernel of the filtered eigensolver)\n",
+     f"* `filtered_probe_r{rnd}.json`, `f64_gemm_probe_r{rnd}.json` -- `tools/filtered_probe.py` (filtered vs direct route vs LAPACK), `tools/chefsi_probe.py` (f64 product rates at the route's shapes, beside torch / rocBLAS)\n",
+     f"* `c4_stack_32blocks_bf16_r{rnd}.json` -- `PTD_PHASES=1 python tools/c4_stack.py 32 bf16`: BASELINE configs[3] at full depth on one GPU\n",
+     f"* `c4_shapes_cpu_r{rnd}.json` -- `python tools/c4_shapes_cpu.py`: the CPU oracle on one layer of each Llama-3-8B shape, host cores of the GPU box\n",
+     f"* `bench_r{rnd}_rehearsal_2ranks_1gpu.json` -- `PTD_BENCH_REHEARSE=1 python bench.py --gpus 2` (self-launched; two ranks sharing the one GPU over gloo: a functional check of the N > 1 path, not a measurement)\n",
      f"* `gpu_tests_r{rnd}.log` -- `python -m pytest tests -q -m gpu` on the same box\n",
      "* `tools/refresh_profiles.sh` reruns the first four on a GPU box\n\n", "## Headline\n\n"]
 cb = b.get("cpu_baseline")

@@ -59,3 +59,6 @@ PY
     grep "eigh_filtered\] n=" gpurun_out/filtered_probe_os$f.err | head -1
   done
 fi
+if [[ $PARTS == *retrydbg* ]]; then
+  step 200 retrydbg bash -c "python tools/retry_debug.py 2> gpurun_out/retry_debug.err"; grep -v amdgpu.ids gpurun_out/retry_debug.err | grep -v "eigh_tridiag" | head -40
+fi
