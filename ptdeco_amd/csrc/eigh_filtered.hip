@@ -759,7 +759,10 @@ int eigh_filtered(const double* A, int64_t lda, int64_t n, int64_t k, double* ev
     const double blast = e[len - 1];
     y[len - 1] = 1.0;
     if (!tridiag_ql_first_row(len, d, e, z, y)) return decline("Lanczos tridiagonal did not converge");
-    for (int i = 0; i < len; ++i) nodes.emplace_back(d[i], z[i] * z[i] / LZ_NV);
+    for (int i = 0; i < len; ++i) {
+      if (!std::isfinite(d[i]) || !std::isfinite(z[i]) || !std::isfinite(y[i])) return decline("non-finite Ritz values");
+      nodes.emplace_back(d[i], z[i] * z[i] / LZ_NV);
+    }
     // a Ritz pair's residual is |beta_last| |last component|: an eigenvalue lies within that distance of theta_i
     for (int i = 0; i < len; ++i) {
       lo = std::min(lo, d[i] - fabs(blast * y[i]));

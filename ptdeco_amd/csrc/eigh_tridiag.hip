@@ -633,6 +633,7 @@ constexpr size_t RES_LDS = 150 * 1024;   // two vectors and scalars; sized so th
 // other workgroup within RES_CHECK polls instead of each of them running into a time-out of its own.
 constexpr unsigned long long RES_TIMEOUT_TICKS = 1000000ULL;
 constexpr int RES_CHECK = 256;
+constexpr int RES_MAX_POLLS = 20000000;   // second guard, in polls (seconds): the wait ends even if the clock did not advance
 
 struct ResCtl {
   unsigned long long fp[RESG_WG];       // per workgroup: sequence number of its last published entries
@@ -674,6 +675,10 @@ __device__ __forceinline__ bool res_wait(const unsigned long long* F, unsigned l
       ok = ok && __hip_atomic_load(F + ((lane + 64 * q) & (NWG - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= seq;
     if (__all(ok)) return true;
     if (spin % RES_CHECK == 0 && !res_alive(c, t_start)) return false;
+    if (spin >= RES_MAX_POLLS) {
+      __hip_atomic_store(&c->fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return false;
+    }
   }
 }
 // GLOBAL: the consumers sit on other XCDs -- entries and number are written through to memory (sc1)
@@ -753,7 +758,11 @@ __global__ __launch_bounds__(RES_T) void sytrd_resident_kernel(double* __restric
       unsigned long long t_start = 0;
       for (int spin = 1;; ++spin) {
         if (__hip_atomic_load(&ctl->reg, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)NWG) break;
-        if (spin % RES_CHECK == 0 && !res_alive(ctl, t_start)) { ok = 0; break; }
+        if ((spin % RES_CHECK == 0 && !res_alive(ctl, t_start)) || spin >= RES_MAX_POLLS) {
+          __hip_atomic_store(&ctl->fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok = 0;
+          break;
+        }
       }
       if (ok)
         for (int q = 0; q < NWG; ++q)

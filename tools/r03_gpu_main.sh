@@ -62,3 +62,6 @@ fi
 if [[ $PARTS == *retrydbg* ]]; then
   step 200 retrydbg bash -c "python tools/retry_debug.py 2> gpurun_out/retry_debug.err"; grep -v amdgpu.ids gpurun_out/retry_debug.err | grep -v "eigh_tridiag" | head -40
 fi
+if [[ $PARTS == *hangdbg* ]]; then
+  step 90 hangdbg bash -c "PTD_JACOBI_DEBUG=1 python -m pytest tests/test_kernels_gpu.py -x -q -s -k 'declines_where' > gpurun_out/hangdbg.log 2>&1"; grep -v "amdgpu.ids" gpurun_out/hangdbg.log | tail -40 | cut -c1-220
+fi
