@@ -13,6 +13,31 @@ def short(name):
     return name.split("(")[0][:72]
 
 
+def split_note(kernel):
+    """The stats table averages a template over every shape it ran on.  When the kernel trace of the same rocprofv3 run
+    is at hand (gpurun_out/prof_rNN/*/*_kernel_trace.csv), split that kernel's launches at 0.75 x the longest one and
+    keep the two averages in profiles/roofline_kernel_split_rNN.json, which this README quotes."""
+    import glob
+    keep = os.path.join(root, f"roofline_kernel_split_r{rnd}.json")
+    traces = glob.glob(os.path.join(os.path.dirname(root), "gpurun_out", f"prof_r{rnd}", "*", "*_kernel_trace.csv"))
+    if traces:
+        d = [int(t["End_Timestamp"]) - int(t["Start_Timestamp"]) for t in csv.DictReader(open(sorted(traces)[-1]))
+             if kernel in t["Kernel_Name"] and "true>" not in t["Kernel_Name"]]
+        if d:
+            cut = 0.75 * max(d)
+            lo, hi = [x for x in d if x < cut], [x for x in d if x >= cut]
+            json.dump({"kernel": kernel + " false>", "source": "rocprofv3 --kernel-trace of bench.py --steps 3 --warmup 1 --no-extras",
+                       "launches": len(d), "long_launches": len(hi), "long_avg_us": sum(hi) / len(hi) / 1e3,
+                       "short_launches": len(lo), "short_avg_us": (sum(lo) / len(lo) / 1e3) if lo else None,
+                       "note": "long = the C X products of the filter (K = n = 4096), short = the same output shape at K = m (X W, Ritz vectors)"},
+                      open(keep, "w"), indent=1)
+    if not os.path.exists(keep):
+        return ""
+    k = json.load(open(keep))
+    return (f": in that trace its {k['long_launches']} K = 4096 launches average **{k['long_avg_us']:.0f} us**, the {k['short_launches']} "
+            f"shorter ones {k['short_avg_us']:.0f} us, `roofline_kernel_split_r{rnd}.json`")
+
+
 o = [f"# profiles -- round {int(rnd)} (one MI355X, ROCm 7.2, gpurun box)\n\n", "Files:\n\n",
      f"* `bench_r{rnd}.json` -- `python bench.py --steps 5 --warmup 1` (the driver's contract line plus roofline / eigh / kernels / cpu_baseline / decomposed_fwd)\n",
      f"* `rocprofv3_kernel_stats_r{rnd}.csv` -- `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-extras` (4 decompositions)\n",
@@ -41,7 +66,7 @@ if r["bound"] == "mfma":
     o.append(f"* dominant kernel `{r['kernel'].split(' ')[0]}` ({r['kernel'].split('(', 1)[1].rstrip(')') if '(' in r['kernel'] else ''}): bound mfma, "
              f"{r['achieved']:.1f} {r['unit']} = **{100 * r['frac']:.0f} %** of the {r['peak']:.1f} {r['unit']} f64 matrix peak; {r.get('launches', '?')} "
              f"launches per eigendecomposition, {r.get('avg_launch_us', 0):.0f} us each (HIP events on the launch stream inside `bench.py`; the kernel-trace "
-             "table below averages the same template over its shorter X W launches as well).\n")
+             "table below averages the same template over its shorter X W launches as well" + split_note(r['kernel'].split(' ')[0]) + ").\n")
     if r.get("traffic"):
         o.append(f"* `roofline.traffic`: {r['traffic'] / 1e6:.0f} MB per launch from separate `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` passes over "
                  f"`tools/pmc_driver eigh` ({r.get('traffic_source', '')}{', STALE' if r.get('traffic_stale') else ''}); matrix-pipe busy share from the "
