@@ -941,6 +941,257 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_8ph16_kernel(const GemmBf
     }
 }
 
+// ---- persistent form of the 16 x 16 x 32 schedule (bf16 output): one workgroup per CU walks the tiles b, b + grid, ...
+// The one-tile kernel pays its prologue (first operands from HBM: 1-2 us), its epilogue and the dispatch of the next
+// workgroup once per tile -- about 5 us, a quarter of a K = 512 tile (the second product of the decomposed forward).
+// Here the K steps of a workgroup's consecutive tiles form ONE staged sequence: the last K-step pair of a tile stages
+// K steps 0 and 1 of the NEXT tile in the phases where the steady state stages (kt + 2), (kt + 3), so those loads are
+// in flight while the finished tile leaves through a 32-KiB output image BEHIND the eight staging slots (64 rows x 256
+// columns per pass, four passes, raw barriers: no vmcnt(0) anywhere).  The image is unpadded: the 16-byte chunk c of
+// image row r sits at c ^ (r & 7), its two 8-byte halves swapped when r & 8, so that the 16 rows one ds_write_b64 lane
+// group covers land on 16 different bank pairs and the row-contiguous ds_read_b128 of the store pass stays conflict
+// free.  A thread issues 16 stores per tile; they are younger than the staged loads of the next tile's first K steps,
+// so the first four waits of the pair that follows an epilogue allow 8 + 16 operations in flight.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"   // (m0 is named as clobbered on purpose: the loads below set it)
+template <bool STAGGER>
+__global__ __launch_bounds__(512, 1) void gemm_bf16_nt_8ph16p_kernel(const GemmBf16Args a, const int ntiles) {
+  __shared__ __attribute__((aligned(16))) char lds[10 * 16384];  // 8 staging slots (see above) + the output image
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wid >> 2, wc = wid & 3;
+  const int tiles_m = a.tiles_m, tiles_n = ntiles / tiles_m;
+  const int nk = a.K / 64;
+  // tile t of the walk: the one-tile kernel's XCD-aware order with t in the place of the block index (the grid is a
+  // multiple of 8, so t & 7 is this workgroup's XCD for every tile it takes)
+  auto origin = [&](int t, int& m0, int& n0) {
+    const int q8 = ntiles >> 3, r8 = ntiles & 7, xcd = t & 7;
+    const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (t >> 3);
+    const int width = 8 * tiles_n, first = (wg / width) * 8;
+    const int gsz = min(tiles_m - first, 8);
+    m0 = (first + (wg % width) % gsz) * 256;
+    n0 = ((wg % width) / gsz) * 256;
+  };
+
+  // staging (as in the one-tile kernel): a wave instruction moves 8 rows x 128 B; wave w owns pieces 2w, 2w + 1.
+  // Addresses are a wave-uniform tile base plus 32-bit per-lane byte offsets (the scalar-base form of the load).
+  const int srow = lane >> 3, spos = lane & 7;
+  const int sr0 = wid * 16 + srow, sr1 = sr0 + 8;
+  const unsigned voa0 = (unsigned)((sr0 * a.sam + (spos ^ ((sr0 >> 1) & 7)) * 8) * 2);
+  const unsigned voa1 = (unsigned)((sr1 * a.sam + (spos ^ ((sr1 >> 1) & 7)) * 8) * 2);
+  const unsigned vob0 = (unsigned)((sr0 * a.sbn + (spos ^ ((sr0 >> 1) & 7)) * 8) * 2);
+  const unsigned vob1 = (unsigned)((sr1 * a.sbn + (spos ^ ((sr1 >> 1) & 7)) * 8) * 2);
+  const char *baseA, *baseB;    // wave-uniform: the staged tile's first row of A / of B
+  auto point = [&](int m0, int n0) {
+    baseA = reinterpret_cast<const char*>(a.A + (int64_t)m0 * a.sam);
+    baseB = reinterpret_cast<const char*>(a.B + (int64_t)n0 * a.sbn);
+  };
+  const int64_t halfA = 256 * a.sam, halfB = 256 * a.sbn;   // bytes
+  const unsigned mypiece = (unsigned)(size_t)(lds_void*)lds + wid * 2048;   // LDS byte address of this wave's first piece
+  // (the load is written out: the scalar-base form keeps ONE 32-bit register per lane and piece where the builtin's
+  // 64-bit address arithmetic cost eight and VALU work in every phase)
+#define PTD_DMA(LDSADDR, VOFF, SBASE)                                                                    \
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"                          \
+               : : "s"(LDSADDR), "v"(VOFF), "s"(SBASE) : "memory", "m0")
+#define PTD_STAGE(D, OP, H, KT)                                                                          \
+  do {                                                                                                   \
+    const unsigned slot_ = mypiece + ((((OP) * 2 + (D)) * 2 + (H)) << 14);                               \
+    const char* base_ = ((OP) ? baseB + (H) * halfB : baseA + (H) * halfA) + (int64_t)(KT) * 128;        \
+    PTD_DMA(slot_, ((OP) ? vob0 : voa0), base_);                                                         \
+    PTD_DMA(slot_ + 1024, ((OP) ? vob1 : voa1), base_);                                                  \
+  } while (0)
+
+  // fragment reads: row fr of a 16-row block, chunk (4 ks + fq) ^ ((row >> 1) & 7); the swizzle term does not depend on
+  // the 16-row block (16 mt, 16 nt are multiples of 16), so blocks are 2-KiB immediates on two offsets per operand
+  const int fr = lane & 15, fq = lane >> 4;
+  int offA[2], offB[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const int ch = ((4 * ks + fq) ^ ((fr >> 1) & 7)) << 4;
+    offA[ks] = (wr * 64 + fr) * 128 + ch;
+    offB[ks] = 65536 + (wc * 32 + fr) * 128 + ch;
+  }
+  s16x8 af[4][2], b0[2][2], b1[2][2];
+  f32x4 acc[2][2][4][2];
+#define PTD_ZERO_ACC()                                                                                   \
+  _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)       \
+      _Pragma("unroll") for (int mt_ = 0; mt_ < 4; ++mt_) _Pragma("unroll") for (int nt_ = 0; nt_ < 2; ++nt_) \
+          acc[i_][j_][mt_][nt_] = f32x4{0.f, 0.f, 0.f, 0.f}
+  PTD_ZERO_ACC();
+
+#define PTD_READ_A(D, H)                                                                                 \
+  _Pragma("unroll") for (int mt_ = 0; mt_ < 4; ++mt_) _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_) \
+      af[mt_][ks_] = *reinterpret_cast<const s16x8*>(lds + (((D) * 2 + (H)) << 14) + mt_ * 2048 + offA[ks_])
+#define PTD_READ_B(D, H, DST)                                                                            \
+  _Pragma("unroll") for (int nt_ = 0; nt_ < 2; ++nt_) _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_) \
+      DST[nt_][ks_] = *reinterpret_cast<const s16x8*>(lds + (((D) * 2 + (H)) << 14) + nt_ * 2048 + offB[ks_])
+#define PTD_QUAD(I, J, BREG)                                                                             \
+  do {                                                                                                   \
+    __builtin_amdgcn_s_setprio(1);                                                                       \
+    _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_) _Pragma("unroll") for (int mt_ = 0; mt_ < 4; ++mt_) \
+        _Pragma("unroll") for (int nt_ = 0; nt_ < 2; ++nt_)                                              \
+            acc[I][J][mt_][nt_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BREG[nt_][ks_], af[mt_][ks_],  \
+                                                                          acc[I][J][mt_][nt_], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                                       \
+  } while (0)
+#define PTD_SYNC_IN_(WAIT)                                                                               \
+  do {                                                                                                   \
+    asm volatile("s_waitcnt vmcnt(" #WAIT ")" ::: "memory");                                             \
+    __builtin_amdgcn_s_barrier();                                                                        \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                   \
+  } while (0)
+#define PTD_SYNC_IN(WAIT) PTD_SYNC_IN_(WAIT)
+#define PTD_SYNC_OUT()                                                                                   \
+  do {                                                                                                   \
+    asm volatile("" ::: "memory");                                                                       \
+    __builtin_amdgcn_s_barrier();                                                                        \
+  } while (0)
+  // the first four waits of a pair: 8 operations may stay in flight, or 8 + 16 when the pair follows an epilogue (a
+  // wave-uniform branch around one instruction keeps ONE copy of the pair's code)
+#define PTD_SYNC_IN_F()                                                                                  \
+  do {                                                                                                   \
+    if (fresh) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");                                         \
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                                \
+    __builtin_amdgcn_s_barrier();                                                                        \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                   \
+  } while (0)
+  // one K-step pair (kt, kt + 1) of the tile being computed; it stages (kt + 1) of that tile, then K steps kn, kn + 1
+  // through the staging base -- the same tile's (kt + 2), (kt + 3), or, in a tile's last pair, steps 0, 1 of the next
+  // tile (the base is moved between phase 1 and phase 2)
+#define PTD_PAIR()                                                                                                           \
+  do {                                                                                                                       \
+    PTD_READ_B(0, 0, b0); PTD_READ_A(0, 0); PTD_STAGE(1, 1, 1, kt + 1); PTD_SYNC_IN_F(); PTD_QUAD(0, 0, b0); PTD_SYNC_OUT(); \
+    PTD_READ_B(0, 1, b1);                   PTD_STAGE(1, 0, 1, kt + 1); PTD_SYNC_IN_F(); PTD_QUAD(0, 1, b1); PTD_SYNC_OUT(); \
+    if (last) { origin(tn, nm0, nn0); point(nm0, nn0); }                                                                     \
+    PTD_READ_A(0, 1);                       PTD_STAGE(0, 1, 0, kn);     PTD_SYNC_IN_F(); PTD_QUAD(1, 1, b1); PTD_SYNC_OUT(); \
+                                            PTD_STAGE(0, 0, 0, kn);     PTD_SYNC_IN_F(); PTD_QUAD(1, 0, b0); PTD_SYNC_OUT(); \
+    PTD_READ_B(1, 0, b0); PTD_READ_A(1, 0); PTD_STAGE(0, 1, 1, kn);     PTD_SYNC_IN(8); PTD_QUAD(0, 0, b0); PTD_SYNC_OUT(); \
+    PTD_READ_B(1, 1, b1);                   PTD_STAGE(0, 0, 1, kn);     PTD_SYNC_IN(8); PTD_QUAD(0, 1, b1); PTD_SYNC_OUT(); \
+    PTD_READ_A(1, 1);                       PTD_STAGE(1, 1, 0, kn + 1); PTD_SYNC_IN(8); PTD_QUAD(1, 1, b1); PTD_SYNC_OUT(); \
+                                            PTD_STAGE(1, 0, 0, kn + 1); PTD_SYNC_IN(8); PTD_QUAD(1, 0, b0); PTD_SYNC_OUT(); \
+  } while (0)
+
+  // the finished tile leaves: four passes (A half i, 16-row blocks 2 mtp, 2 mtp + 1 of both wave rows) of 64 rows
+  char* const img = lds + 8 * 16384;
+  auto epilogue = [&](const int m0, const int n0) {
+    // (the thread index goes through an opaque move so that the image and store addresses are formed HERE: hoisted out
+    // of the tile loop they would stay live across the main loop, which has no registers to spare)
+    int etid;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(etid) : "v"(tid));
+    const int elane = etid & 63;
+    const int wlr = wr * 32 + (elane & 15);               // image row of this lane's mtl = 0 fragment (+ 16 for mtl = 1)
+    const int wq = elane >> 4;
+    // bias of this lane's 16 output columns, fetched before the passes (a load inside a pass would wait for the
+    // previous pass's stores: everything a wave has in flight retires in order)
+    float bv[2][2][4];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          bv[jj][g][e] = a.bias ? bf16_to_f32(a.bias[n0 + jj * 128 + wc * 32 + 16 * g + 4 * wq + e]) : 0.f;
+    if (STAGGER && wr == 0) __builtin_amdgcn_s_barrier();   // the waves of row 1 catch up
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int mtp = 0; mtp < 2; ++mtp) {
+        if (i + mtp) {   // the previous pass's image has been read (every wave's reads are retired before it arrives)
+          asm volatile("" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+        }
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+          for (int mtl = 0; mtl < 2; ++mtl)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+              const int lr = wlr + mtl * 16;
+              const int col = jj * 128 + wc * 32 + 16 * g + 4 * wq;   // first of 4 consecutive columns
+              float o[4];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                o[e] = a.alpha * acc[i][jj][2 * mtp + mtl][g][e] + bv[jj][g][e];
+              }
+              const int chunk = col >> 3, half = (col >> 2) & 1;
+              char* dst = img + lr * 512 + ((chunk ^ (lr & 7)) << 4) + ((half ^ ((lr >> 3) & 1)) << 3);
+              typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+              const u32x2 pk = {pack2_bf16(o[0], o[1]), pack2_bf16(o[2], o[3])};
+              *reinterpret_cast<s16x4*>(dst) = __builtin_bit_cast(s16x4, pk);
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const int q = etid + 512 * p;
+          const int lr = q >> 5, ch = q & 31;
+          f32x4 v = *reinterpret_cast<const f32x4*>(img + lr * 512 + ((ch ^ (lr & 7)) << 4));
+          if ((lr >> 3) & 1) v = f32x4{v[2], v[3], v[0], v[1]};
+          const int grow = m0 + i * 128 + (lr >> 5) * 64 + (2 * mtp + ((lr >> 4) & 1)) * 16 + (lr & 15);
+          char* dst = reinterpret_cast<char*>(a.C) + ((int64_t)grow * a.ldc + n0) * 2 + ch * 16;
+          *reinterpret_cast<f32x4*>(dst) = v;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+    PTD_ZERO_ACC();
+    if (STAGGER && wr == 1) __builtin_amdgcn_s_barrier();
+  };
+
+  int t = blockIdx.x;
+  int m0, n0, nm0 = 0, nn0 = 0;
+  origin(t, m0, n0);
+  point(m0, n0);
+  // prologue: K step 0 complete, (1).B0 and (1).A0 in flight
+  PTD_STAGE(0, 1, 0, 0); PTD_STAGE(0, 0, 0, 0); PTD_STAGE(0, 1, 1, 0); PTD_STAGE(0, 0, 1, 0);
+  PTD_STAGE(1, 1, 0, 1); PTD_STAGE(1, 0, 0, 1);
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (STAGGER && wr == 1) __builtin_amdgcn_s_barrier();
+
+  int kt = 0;
+  bool fresh = false;   // the pair follows an epilogue: 16 stores sit between the staged loads and this pair's own
+  for (;;) {
+    const bool last = kt + 2 >= nk;
+    const int tn = t + (int)gridDim.x;
+    if (last && tn >= ntiles) break;
+    const int kn = last ? 0 : kt + 2;
+    PTD_PAIR();
+    if (last) {
+      epilogue(m0, n0);
+      m0 = nm0; n0 = nn0; t = tn; kt = 0;
+      fresh = true;
+    } else {
+      kt += 2;
+      fresh = false;
+    }
+  }
+  {  // the workgroup's last pair: nothing new to stage after (kt + 1).A1; waits count the queue down (stricter than
+     // needed when stores of an epilogue are still counted: never laxer)
+    PTD_READ_B(0, 0, b0); PTD_READ_A(0, 0); PTD_STAGE(1, 1, 1, kt + 1); PTD_SYNC_IN(8); PTD_QUAD(0, 0, b0); PTD_SYNC_OUT();
+    PTD_READ_B(0, 1, b1);                   PTD_STAGE(1, 0, 1, kt + 1); PTD_SYNC_IN(8); PTD_QUAD(0, 1, b1); PTD_SYNC_OUT();
+    PTD_READ_A(0, 1);                                                   PTD_SYNC_IN(6); PTD_QUAD(1, 1, b1); PTD_SYNC_OUT();
+                                                                        PTD_SYNC_IN(4); PTD_QUAD(1, 0, b0); PTD_SYNC_OUT();
+    PTD_READ_B(1, 0, b0); PTD_READ_A(1, 0);                             PTD_SYNC_IN(2); PTD_QUAD(0, 0, b0); PTD_SYNC_OUT();
+    PTD_READ_B(1, 1, b1);                                               PTD_SYNC_IN(0); PTD_QUAD(0, 1, b1); PTD_SYNC_OUT();
+    PTD_READ_A(1, 1);                                                   PTD_SYNC_IN(0); PTD_QUAD(1, 1, b1); PTD_SYNC_OUT();
+                                                                        PTD_SYNC_IN(0); PTD_QUAD(1, 0, b0); PTD_SYNC_OUT();
+  }
+  epilogue(m0, n0);
+#undef PTD_DMA
+#undef PTD_STAGE
+#undef PTD_ZERO_ACC
+#undef PTD_READ_A
+#undef PTD_READ_B
+#undef PTD_QUAD
+#undef PTD_SYNC_IN_
+#undef PTD_SYNC_IN_F
+#undef PTD_SYNC_IN
+#undef PTD_SYNC_OUT
+#undef PTD_PAIR
+}
+#pragma clang diagnostic pop
+
 // ---- short-K product C[M,N] = A[M,K] B[N,K]^T, K <= 512 (the second product of the decomposed
 // forward, K = rank).  With 128 x 128 tiles such a product re-stages both operands for every output
 // tile and never fills its pipeline (4 K-steps): it runs at the global->LDS staging rate (82 us for
@@ -1824,6 +2075,14 @@ int gemm_bf16(const unsigned short* A, int64_t sam, int64_t sak, const unsigned 
       K >= 256 && (M / 256) * (N / 256) >= 192) {
     a.tiles_m = (int)(M / 256);
     dim3 g8((unsigned)((M / 256) * (N / 256)), 1);
+    // more tiles than CUs and a bf16 output: the persistent form (next tile's first operands in flight behind the epilogue)
+    const char* pe_env = getenv("PTD_GEMM_8PH_PERSIST");   // read per call: 0 keeps one workgroup per tile
+    if (mf16 && c_bf16 && g8.x > 256 && !(pe_env && atoi(pe_env) == 0) && a.sam < (1 << 22) && a.sbn < (1 << 22)) {  // (32-bit per-lane byte offsets of up to 255 rows)
+      if (mode_8ph == 1) hipLaunchKernelGGL((gemm_bf16_nt_8ph16p_kernel<false>), dim3(256), dim3(512), 0, st, a, (int)g8.x);
+      else hipLaunchKernelGGL((gemm_bf16_nt_8ph16p_kernel<true>), dim3(256), dim3(512), 0, st, a, (int)g8.x);
+      PTD_CHECK_LAUNCH("gemm_bf16 (256x256, persistent)");
+      return PTD_OK;
+    }
     if (mode_8ph == 1) {
       if (mf16 && c_bf16) hipLaunchKernelGGL((gemm_bf16_nt_8ph16_kernel<EPI_STORE_BF16, false>), g8, dim3(512), 0, st, a);
       else if (mf16) hipLaunchKernelGGL((gemm_bf16_nt_8ph16_kernel<EPI_STORE_F32, false>), g8, dim3(512), 0, st, a);

@@ -658,6 +658,36 @@ def test_gemm_bf16_256_tile_deep_pipeline_exact_and_repeatable(ops):
     assert torch.equal(got.float(), (x_v.float() @ w_v.float().T).to(torch.bfloat16).float())
 
 
+def test_gemm_bf16_256_tile_persistent_form_exact_and_repeatable(ops, monkeypatch):
+    """More 256 x 256 tiles than CUs with a bf16 output: the persistent form of the 8-wave kernel (one workgroup per
+    CU walks tiles b, b + 256, ...; a tile's last K-step pair stages the first two K steps of the NEXT tile, the
+    finished tile leaves through the 32-KiB swizzled image behind the staging slots).  Exact integer products: a
+    half tile of the wrong tile, a slot restaged before its last read or an image row written to the wrong place
+    shows.  Shapes: one K-step pair per tile (every pair both follows and precedes an epilogue), two, four, many;
+    272 tiles (16 workgroups take a second tile, the others stop), 512 (two each), 1024 (four each), a ragged 17 x 19;
+    bias and alpha; the one-tile kernel (PTD_GEMM_8PH_PERSIST=0) must give the same bits."""
+    g = torch.Generator().manual_seed(19)
+    for (M, N, K) in [(4352, 4096, 128), (8192, 4096, 256), (16384, 4096, 512), (4352, 4864, 1024), (8192, 4096, 4096),
+                      (16384, 4096, 128)]:
+        a = torch.randint(-2, 3, (M, K), generator=g).to(torch.bfloat16).to(DEV)
+        b = torch.randint(-2, 3, (N, K), generator=g).to(torch.bfloat16).to(DEV)
+        bias = torch.randint(-3, 4, (N,), generator=g).to(torch.bfloat16).to(DEV)
+        ref = a.float() @ b.float().T                      # exact: |sum| <= 4 K < 2^24
+        want = ref.to(torch.bfloat16)
+        want_b = (0.5 * ref + bias.float()).to(torch.bfloat16)
+        for rep in range(3):
+            assert torch.equal(ops.matmul(a, b.T), want), (M, N, K, rep)
+        assert torch.equal(ops.matmul(a, b.T, bias=bias, alpha=0.5), want_b), (M, N, K)
+        monkeypatch.setenv("PTD_GEMM_8PH_PERSIST", "0")
+        assert torch.equal(ops.matmul(a, b.T), want), (M, N, K, "one tile per workgroup")
+        monkeypatch.delenv("PTD_GEMM_8PH_PERSIST")
+    # row pitches larger than K / N (operands and output are column slices of wider matrices)
+    xa = torch.randint(-2, 3, (8192, 512 + 128), generator=g).to(torch.bfloat16).to(DEV)
+    wa = torch.randint(-2, 3, (4096, 512 + 64), generator=g).to(torch.bfloat16).to(DEV)
+    x_v, w_v = xa[:, 128:], wa[:, :512]
+    assert torch.equal(ops.matmul(x_v, w_v.T), (x_v.float() @ w_v.float().T).to(torch.bfloat16))
+
+
 def test_lowrank_forward_bf16_split_k_first_product_exact(ops):
     """Few rows (T = 4096 and below): x A^T has at most 128 output tiles, so its K range is split over
     blockIdx.y into f32 slabs of the workspace and a second launch adds them in index order.  Integer
