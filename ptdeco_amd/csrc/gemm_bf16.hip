@@ -1192,6 +1192,178 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_8ph16p_kernel(const GemmB
 }
 #pragma clang diagnostic pop
 
+// ---- 128 x 256 tile on the same 8-wave schedule (bf16 output): products whose N is 256 or 512 columns wide (x A^T of the
+// decomposed forward at r = 512: 16384 x 512 has 128 tiles of 256 x 256 for 256 CUs, but 256 of 128 x 256).  One A half
+// tile and two B half tiles per K step, two phases per K step (quadrants A0 x B0, A0 x B1: 16 MFMAs each), and a ring
+// of THREE K steps (3 x 48 KiB) so that a half tile still has four phases between its load and its first read:
+//   phase 0 of step t: read B0, A0 (t);  stage B0 (t + 2), first piece of A0 (t + 2);  wait vmcnt(9);  A0 x B0
+//   phase 1 of step t: read B1 (t);      stage second piece of A0 (t + 2), B1 (t + 2); wait vmcnt(8);  A0 x B1
+// RAW: the wait of phase 0 retires B1 (t) (issued last in step t - 2: nine younger loads), the wait of phase 1 retires
+// A0, B0 (t + 1) (A0's second piece was issued first in phase 1 of step t - 1: eight younger).  WAR: step t + 2 lands in
+// the buffer of step t - 1, whose B0 / A0 were last read two phases and whose B1 was last read two phases before the
+// phase that restages them (the lagging wave row has retired its reads before the barrier in between).  The last
+// two steps stage nothing and count the queue down (6, 2, 0, 0).
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"   // (m0 is named as clobbered on purpose: the loads below set it)
+template <bool STAGGER>
+__global__ __launch_bounds__(512, 1) void gemm_bf16_nt_6ph16_kernel(const GemmBf16Args a) {
+  __shared__ __attribute__((aligned(16))) char lds[9 * 16384];  // buffer b at 48 KiB b: A0, B0, B1 (16 KiB each)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wid >> 2, wc = wid & 3;
+  // XCD-aware order as in the 256 x 256 kernel (8-tile-tall column groups, a contiguous run per XCD)
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int tiles_m = a.tiles_m, tiles_n = nwg / tiles_m;
+  const int width = 8 * tiles_n, first = (wg / width) * 8;
+  const int gsz = min(tiles_m - first, 8);
+  const int m0 = (first + (wg % width) % gsz) * 128, n0 = ((wg % width) / gsz) * 256;
+  const int nk = a.K / 64;
+
+  // staging: a wave instruction moves 8 rows x 128 B; wave w owns pieces 2w, 2w + 1 of every half tile; the 16-byte
+  // chunk c of row r is stored at position c ^ ((r >> 1) & 7) (swizzle on the source address)
+  const int srow = lane >> 3, spos = lane & 7;
+  const int sr0 = wid * 16 + srow, sr1 = sr0 + 8;
+  const unsigned voa0 = (unsigned)((sr0 * a.sam + (spos ^ ((sr0 >> 1) & 7)) * 8) * 2);
+  const unsigned voa1 = (unsigned)((sr1 * a.sam + (spos ^ ((sr1 >> 1) & 7)) * 8) * 2);
+  const unsigned vob0 = (unsigned)((sr0 * a.sbn + (spos ^ ((sr0 >> 1) & 7)) * 8) * 2);
+  const unsigned vob1 = (unsigned)((sr1 * a.sbn + (spos ^ ((sr1 >> 1) & 7)) * 8) * 2);
+  const char* const baseA = reinterpret_cast<const char*>(a.A + (int64_t)m0 * a.sam);
+  const char* const baseB = reinterpret_cast<const char*>(a.B + (int64_t)n0 * a.sbn);
+  const int64_t halfB = 256 * a.sbn;   // bytes
+  const unsigned mypiece = (unsigned)(size_t)(lds_void*)lds + wid * 2048;
+#define PTD_DMA(LDSADDR, VOFF, SBASE)                                                                    \
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"                          \
+               : : "s"(LDSADDR), "v"(VOFF), "s"(SBASE) : "memory", "m0")
+#define PTD_STAGE_B(BUF, H, KT)                                                                          \
+  do {                                                                                                   \
+    const unsigned slot_ = mypiece + (BUF) + 16384 * (1 + (H));                                          \
+    const char* base_ = baseB + (H) * halfB + (int64_t)(KT) * 128;                                       \
+    PTD_DMA(slot_, vob0, base_);                                                                         \
+    PTD_DMA(slot_ + 1024, vob1, base_);                                                                  \
+  } while (0)
+#define PTD_STAGE_A(BUF, KT, P)                                                                          \
+  do {                                                                                                   \
+    const unsigned slot_ = mypiece + (BUF) + 1024 * (P);                                                 \
+    const char* base_ = baseA + (int64_t)(KT) * 128;                                                     \
+    PTD_DMA(slot_, ((P) ? voa1 : voa0), base_);                                                          \
+  } while (0)
+
+  // fragment reads (v_mfma_f32_16x16x32_bf16): row fr of a 16-row block, chunk (4 ks + fq) ^ ((row >> 1) & 7)
+  const int fr = lane & 15, fq = lane >> 4;
+  int offA[2], offB[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const int ch = ((4 * ks + fq) ^ ((fr >> 1) & 7)) << 4;
+    offA[ks] = (wr * 64 + fr) * 128 + ch;
+    offB[ks] = 16384 + (wc * 32 + fr) * 128 + ch;
+  }
+  s16x8 af[4][2], b0[2][2], b1[2][2];
+  f32x4 acc[2][4][2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) acc[j][mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#define PTD_READ_A()                                                                                     \
+  _Pragma("unroll") for (int mt_ = 0; mt_ < 4; ++mt_) _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_) \
+      af[mt_][ks_] = *reinterpret_cast<const s16x8*>(lds + ra[ks_] + mt_ * 2048)
+#define PTD_READ_B(H, DST)                                                                               \
+  _Pragma("unroll") for (int nt_ = 0; nt_ < 2; ++nt_) _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_) \
+      DST[nt_][ks_] = *reinterpret_cast<const s16x8*>(lds + rb[ks_] + (H) * 16384 + nt_ * 2048)
+#define PTD_QUAD(J, BREG)                                                                                \
+  do {                                                                                                   \
+    __builtin_amdgcn_s_setprio(1);                                                                       \
+    _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_) _Pragma("unroll") for (int mt_ = 0; mt_ < 4; ++mt_) \
+        _Pragma("unroll") for (int nt_ = 0; nt_ < 2; ++nt_)                                              \
+            acc[J][mt_][nt_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BREG[nt_][ks_], af[mt_][ks_],     \
+                                                                       acc[J][mt_][nt_], 0, 0, 0);       \
+    __builtin_amdgcn_s_setprio(0);                                                                       \
+  } while (0)
+  // (a wave-uniform branch around the one wait instruction: full / next-to-last / last K step)
+#define PTD_SYNC_IN3(W2, W1, W0)                                                                         \
+  do {                                                                                                   \
+    if (st2) asm volatile("s_waitcnt vmcnt(" #W2 ")" ::: "memory");                                      \
+    else if (st1) asm volatile("s_waitcnt vmcnt(" #W1 ")" ::: "memory");                                 \
+    else asm volatile("s_waitcnt vmcnt(" #W0 ")" ::: "memory");                                          \
+    __builtin_amdgcn_s_barrier();                                                                        \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                   \
+  } while (0)
+#define PTD_SYNC_OUT()                                                                                   \
+  do {                                                                                                   \
+    asm volatile("" ::: "memory");                                                                       \
+    __builtin_amdgcn_s_barrier();                                                                        \
+  } while (0)
+
+  // prologue: K steps 0 and 1 requested (B0, A0 of a step first), B0 and A0 of step 0 complete
+  PTD_STAGE_B(0, 0, 0); PTD_STAGE_A(0, 0, 0); PTD_STAGE_A(0, 0, 1); PTD_STAGE_B(0, 1, 0);
+  PTD_STAGE_B(49152, 0, 1); PTD_STAGE_A(49152, 1, 0); PTD_STAGE_A(49152, 1, 1); PTD_STAGE_B(49152, 1, 1);
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (STAGGER && wr == 1) __builtin_amdgcn_s_barrier();
+
+  int bo = 0, bs = 98304;   // buffer of K step t, of K step t + 2
+  for (int t = 0; t < nk; ++t) {
+    const bool st2 = t + 2 < nk, st1 = t + 1 < nk;
+    const int ra[2] = {offA[0] + bo, offA[1] + bo}, rb[2] = {offB[0] + bo, offB[1] + bo};
+    PTD_READ_B(0, b0); PTD_READ_A();
+    if (st2) { PTD_STAGE_B(bs, 0, t + 2); PTD_STAGE_A(bs, t + 2, 0); }
+    PTD_SYNC_IN3(9, 6, 0); PTD_QUAD(0, b0); PTD_SYNC_OUT();
+    PTD_READ_B(1, b1);
+    if (st2) { PTD_STAGE_A(bs, t + 2, 1); PTD_STAGE_B(bs, 1, t + 2); }
+    PTD_SYNC_IN3(8, 2, 0); PTD_QUAD(1, b1); PTD_SYNC_OUT();
+    bo = bo == 98304 ? 0 : bo + 49152;
+    bs = bs == 98304 ? 0 : bs + 49152;
+  }
+  if (STAGGER && wr == 0) __builtin_amdgcn_s_barrier();
+#undef PTD_DMA
+#undef PTD_STAGE_A
+#undef PTD_STAGE_B
+#undef PTD_READ_A
+#undef PTD_READ_B
+#undef PTD_QUAD
+#undef PTD_SYNC_IN3
+#undef PTD_SYNC_OUT
+
+  // epilogue: the accumulators are transposed output blocks (lane l: output row l & 15, four consecutive columns);
+  // the tile leaves through a padded LDS image (128 rows x 256 bf16) as 16-byte row-contiguous stores
+  constexpr int CP = 256 * 2 + 16;
+  static_assert(128 * CP <= 9 * 16384, "the C image must fit the staging buffers");
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const int lr = wr * 64 + mt * 16 + (lane & 15);
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const int lc = j * 128 + wc * 32 + 16 * g + 4 * (lane >> 4);
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float bv = a.bias ? bf16_to_f32(a.bias[n0 + lc + e]) : 0.f;
+          o[e] = a.alpha * acc[j][mt][g][e] + bv;
+        }
+        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+        const u32x2 pk = {pack2_bf16(o[0], o[1]), pack2_bf16(o[2], o[3])};
+        *reinterpret_cast<s16x4*>(lds + lr * CP + lc * 2) = __builtin_bit_cast(s16x4, pk);
+      }
+    }
+  __syncthreads();
+#pragma unroll
+  for (int p = 0; p < 128 * 32 / 512; ++p) {
+    const int q = tid + 512 * p;
+    const int lr = q >> 5, ch = q & 31;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(lds + lr * CP + ch * 16);
+    char* dst = reinterpret_cast<char*>(a.C) + ((int64_t)(m0 + lr) * a.ldc + n0) * 2 + ch * 16;
+    *reinterpret_cast<f32x4*>(dst) = v;
+  }
+}
+#pragma clang diagnostic pop
+
 // ---- short-K product C[M,N] = A[M,K] B[N,K]^T, K <= 512 (the second product of the decomposed
 // forward, K = rank).  With 128 x 128 tiles such a product re-stages both operands for every output
 // tile and never fills its pipeline (4 K-steps): it runs at the global->LDS staging rate (82 us for
@@ -2095,6 +2267,18 @@ int gemm_bf16(const unsigned short* A, int64_t sam, int64_t sak, const unsigned 
       else hipLaunchKernelGGL((gemm_bf16_nt_8ph_kernel<EPI_STORE_F32, true>), g8, dim3(512), 0, st, a);
     }
     PTD_CHECK_LAUNCH("gemm_bf16 (256x256)");
+    return PTD_OK;
+  }
+  // too few 256 x 256 tiles, enough of 128 x 256 (N = 256 .. 512 with many rows: x A^T of the decomposed forward)
+  const char* t6_env = getenv("PTD_GEMM_6PH");   // read per call: 0 keeps the 128 x 128 kernel
+  if (!no_glds && mode_8ph && mf16 && c_bf16 && akc && bkc && a.vecA && a.vecB && c_vec && M % 128 == 0 && N % 256 == 0 &&
+      K % 64 == 0 && K > 512 && (M / 128) * (N / 256) >= 192 && (M / 128) * (N / 256) <= 256 &&   // (one round of tiles: more would idle half the chip in the second)
+      !(t6_env && atoi(t6_env) == 0) && a.sam < (1 << 22) && a.sbn < (1 << 22)) {
+    a.tiles_m = (int)(M / 128);
+    dim3 g6((unsigned)((M / 128) * (N / 256)), 1);
+    if (mode_8ph == 1) hipLaunchKernelGGL((gemm_bf16_nt_6ph16_kernel<false>), g6, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((gemm_bf16_nt_6ph16_kernel<true>), g6, dim3(512), 0, st, a);
+    PTD_CHECK_LAUNCH("gemm_bf16 (128x256)");
     return PTD_OK;
   }
   if (!no_glds && !no_shortk && akc && bkc && a.vecA && a.vecB && M % 128 == 0 && N % 64 == 0 && N >= 256 &&

@@ -688,6 +688,30 @@ def test_gemm_bf16_256_tile_persistent_form_exact_and_repeatable(ops, monkeypatc
     assert torch.equal(ops.matmul(x_v, w_v.T), (x_v.float() @ w_v.float().T).to(torch.bfloat16))
 
 
+def test_gemm_bf16_128x256_tile_three_buffer_ring_exact_and_repeatable(ops, monkeypatch):
+    """N of 512 / 768 columns with many rows (x A^T of the decomposed forward at r = 512): fewer than 192 tiles of
+    256 x 256 but 192 .. 256 of 128 x 256 -- the 8-wave kernel with one A half tile, two B half tiles and a ring of
+    three K steps.  Exact integer products; K / 64 = 9, 11, 16, 64 covers every phase of the ring at the tail (the last
+    two steps stage nothing); bias and alpha; PTD_GEMM_6PH=0 (the 128 x 128 kernel) must give the same bits."""
+    g = torch.Generator().manual_seed(23)
+    for (M, N, K) in [(16384, 512, 4096), (12288, 512, 1024), (8192, 768, 576), (10240, 768, 704)]:
+        a = torch.randint(-2, 3, (M, K), generator=g).to(torch.bfloat16).to(DEV)
+        b = torch.randint(-2, 3, (N, K), generator=g).to(torch.bfloat16).to(DEV)
+        bias = torch.randint(-3, 4, (N,), generator=g).to(torch.bfloat16).to(DEV)
+        ref = a.float() @ b.float().T                      # exact: |sum| <= 4 K < 2^24
+        want = ref.to(torch.bfloat16)
+        for rep in range(3):
+            assert torch.equal(ops.matmul(a, b.T), want), (M, N, K, rep)
+        assert torch.equal(ops.matmul(a, b.T, bias=bias, alpha=0.5), (0.5 * ref + bias.float()).to(torch.bfloat16)), (M, N, K)
+        monkeypatch.setenv("PTD_GEMM_6PH", "0")
+        assert torch.equal(ops.matmul(a, b.T), want), (M, N, K, "128 x 128 kernel")
+        monkeypatch.delenv("PTD_GEMM_6PH")
+    xa = torch.randint(-2, 3, (16384, 1024 + 128), generator=g).to(torch.bfloat16).to(DEV)   # row pitch != K
+    wa = torch.randint(-2, 3, (512, 1024 + 64), generator=g).to(torch.bfloat16).to(DEV)
+    x_v, w_v = xa[:, 128:], wa[:, :1024]
+    assert torch.equal(ops.matmul(x_v, w_v.T), (x_v.float() @ w_v.float().T).to(torch.bfloat16))
+
+
 def test_lowrank_forward_bf16_split_k_first_product_exact(ops):
     """Few rows (T = 4096 and below): x A^T has at most 128 output tiles, so its K range is split over
     blockIdx.y into f32 slabs of the workspace and a second launch adds them in index order.  Integer
