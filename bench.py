@@ -171,7 +171,7 @@ def kernel_lines(device):
     if pmc:
         kern = pmc["data"]["kernels"]
         for line, key in (("syrk_f32_f64acc", "syrk_f32_mixed_kernel"), ("gemm_f32_nt", "gemm_f32_nt_8ph_kernel"),
-                          ("syrk_bf16_f64acc", "syrk_bf16"), ("gemm_bf16_nt", "gemm_bf16_nt_8ph_kernel")):
+                          ("syrk_bf16_f64acc", "syrk_bf16"), ("gemm_bf16_nt", "gemm_bf16_nt_8ph")):
             for name, c in kern.items():
                 if name.startswith(key) and "MfmaUtil" in c and line in lines:
                     lines[line]["mfma_util_pmc_percent"] = c["MfmaUtil"]
@@ -194,10 +194,16 @@ def decomposed_forward_lines(device):
     out = {"rows": t_rows, "dense_ms": dense_t * 1e3, "dense_tflops": 2 * t_rows * N_FEAT * N_FEAT / dense_t / 1e12,
            "dense_torch_hipblaslt_ms": lib_t * 1e3,
            "dense_torch_hipblaslt_tflops": 2 * t_rows * N_FEAT * N_FEAT / lib_t / 1e12}
+    import itertools
+    rot = itertools.cycle([x] + [torch.randn(t_rows, N_FEAT, device=device).bfloat16() for _ in range(5)])
     for r in (256, 512, 1024):
         a = (torch.randn(r, N_FEAT, generator=g) / 64).bfloat16().to(device)
         b = (torch.randn(N_FEAT, r, generator=g) / r**0.5).bfloat16().to(device)
         t = time_events(lambda: ops.lowrank_forward(x, a, b, None), iters=10)
+        # the same with the input rotating over buffers larger than the 256-MB Infinity Cache: x comes from HBM at
+        # every launch, as in a forward pass of a model (the single-buffer loop above re-reads a cached x)
+        t_cold = time_events(lambda: ops.lowrank_forward(next(rot), a, b, None), iters=12)
+        lib_cold = time_events(lambda: torch.nn.functional.linear(torch.nn.functional.linear(next(rot), a), b), iters=12)
         fl = 2 * t_rows * r * 2 * N_FEAT
         by = 2 * (2 * t_rows * N_FEAT + 2 * r * N_FEAT)
         # the same pair as two torch.nn.functional.linear calls (hipBLASLt): what apply_decompose_config_in_place's
@@ -212,6 +218,7 @@ def decomposed_forward_lines(device):
             mod_t = time_events(lambda: pair(x), iters=10)
         out[f"r{r}"] = {"ms": t * 1e3, "gflops": fl / t / 1e9, "speedup_vs_dense": dense_t / t,
                         "speedup_vs_dense_torch_hipblaslt": lib_t / t, "torch_hipblaslt_pair_ms": lib_pair * 1e3,
+                        "ms_rotating_inputs": t_cold * 1e3, "torch_hipblaslt_pair_ms_rotating_inputs": lib_cold * 1e3,
                         "module_ms": mod_t * 1e3,
                         "module_runs": "package kernels",
                         "frac_of_bf16_mfma_peak": fl / t / PEAK_BF16_MFMA, "hbm_gbps_algorithmic": by / t / 1e9}

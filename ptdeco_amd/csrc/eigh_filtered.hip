@@ -371,25 +371,47 @@ __device__ __forceinline__ void fs_chol_inv_tile(const double* __restrict__ A, d
   __syncthreads();   // (buf may alias the tile's neighbours; everyone has its row)
   bool bad = false;
   double myd = 1.0;
+  // Two columns per barrier: rows j and j + 1 publish their lines P and R as they stand BEFORE column j is eliminated;
+  // every thread forms the multipliers of column j, row j + 1 as column j leaves it (Q = R - l P, slot j = -l: the
+  // very operations the row's own lane performs), the pivot and multipliers of column j + 1 from Q, and applies both
+  // updates -- the same fma sequence, bit for bit, as two one-column steps, for one barrier and one LDS round trip.
 #pragma unroll 1
-  for (int j = 0; j < FB; ++j) {
+  for (int j = 0; j < FB; j += 2) {
     const int i = j >> 2, gj = j & 3;
-    double* P = buf + (j & 1) * 64;
-    if (r == j) {
+    double* P = buf + ((j >> 1) & 1) * 128;
+    double* R = P + 64;
+    if (r == j || r == j + 1) {
+      double* dst = (r == j) ? P : R;
 #pragma unroll
-      for (int s = 0; s < 16; ++s) P[g + 4 * s] = y[s];
+      for (int s = 0; s < 16; ++s) dst[g + 4 * s] = y[s];
     }
     __syncthreads();
-    const double d = P[j];
-    const bool ok = d > 0.0 && d < INFINITY;
-    bad = bad || !ok;
-    const double p = ok ? fs_rcp(d) : 1.0;
-    myd = (r == j && ok) ? d : myd;
-    const double m = (r > j) ? P[r] * p : 0.0;
+    const double d0 = P[j];
+    const bool ok0 = d0 > 0.0 && d0 < INFINITY;
+    const double p0 = ok0 ? fs_rcp(d0) : 1.0;
+    const double pj1 = P[j + 1];
+    const double l = pj1 * p0;                               // multiplier of row j + 1 in column j
+    const double m0 = (r > j) ? P[r] * p0 : 0.0;
+    const double d1 = fma(-l, pj1, R[j + 1]);                // pivot of column j + 1
+    const bool ok1 = d1 > 0.0 && d1 < INFINITY;
+    const double p1 = ok1 ? fs_rcp(d1) : 1.0;
+    const double m1 = (r > j + 1) ? fma(-l, P[r], R[r]) * p1 : 0.0;
+    bad = bad || !ok0 || !ok1;
+    myd = (r == j && ok0) ? d0 : myd;
+    myd = (r == j + 1 && ok1) ? d1 : myd;
 #pragma unroll
-    for (int s = 0; s < 16; ++s) y[s] = fma(-m, P[g + 4 * s], y[s]);
-    if (g == gj) {                         // (wave-uniform) the slot of column j changes hands: X[r][j] = -Lhat[r][j]
-      const double xj = (r == j) ? 1.0 : -m;
+    for (int s = 0; s < 16; ++s) {
+      const double pc = P[g + 4 * s];
+      const double t = fma(-m0, pc, y[s]);
+      y[s] = fma(-m1, fma(-l, pc, R[g + 4 * s]), t);
+    }
+    if (g == gj) {        // (wave-uniform) slot j: X[r][j] = -Lhat[r][j] after column j, then column j + 1 acts on it (Q[j] = -l)
+      const double xj = fma(-m1, -l, (r == j) ? 1.0 : -m0);
+#pragma unroll
+      for (int s = 0; s < 16; ++s) y[s] = (s == i) ? xj : y[s];
+    }
+    if (g == gj + 1) {    // slot j + 1
+      const double xj = (r == j + 1) ? 1.0 : -m1;
 #pragma unroll
       for (int s = 0; s < 16; ++s) y[s] = (s == i) ? xj : y[s];
     }
