@@ -260,7 +260,9 @@ def cpu_baseline():
         physical = psutil.cpu_count(logical=False) or os.cpu_count()
     except Exception:
         physical = os.cpu_count()
-    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
+    # ... and a cgroup CPU quota below the visible count throttles a pool sized by it (oracle/cpu_quota.py)
+    from cpu_quota import usable_cpus
+    usable = usable_cpus()
     cores = max(1, min(physical, usable))
     torch.set_num_threads(cores)
     model, data, metric = make_workload(1, "cpu", D_STEPS, 7 * M_STEPS)
@@ -272,7 +274,7 @@ def cpu_baseline():
     dt = time.perf_counter() - t0
     prop = cfg["layers.0"]["__meta__"]["proportion"] if cfg else 1.0
     return {"value": 1.0 / dt, "unit": "layers/s", "cores": cores, "kind": "port",
-            "physical_cores": physical, "logical_cpus": os.cpu_count(), "usable_cpus": usable,
+            "physical_cores": physical, "logical_cpus": os.cpu_count(), "usable_cpus": usable,   # usable = affinity and cgroup quota
             "sample": f"1 layer = the full N=1 workload once ({dt:.1f} s, torch threads = {cores}); "
                       f"chosen proportion {prop}"}
 

@@ -11,6 +11,17 @@ for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
 
 torch.set_float32_matmul_precision("highest")
 
+# CPU thread pools (LAPACK references, the oracle) sized by what the cgroup grants, not by what the host shows
+from cpu_quota import usable_cpus  # noqa: E402  (oracle/ is on the path above)
+
+torch.set_num_threads(max(1, min(torch.get_num_threads(), usable_cpus())))
+try:
+    import threadpoolctl
+
+    _BLAS_LIMIT = threadpoolctl.threadpool_limits(limits=usable_cpus())   # numpy / scipy BLAS and OpenMP pools
+except Exception:  # pragma: no cover
+    _BLAS_LIMIT = None
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
