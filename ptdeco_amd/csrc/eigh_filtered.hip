@@ -264,58 +264,73 @@ __global__ __launch_bounds__(256) void fs_symmetrize_kernel(double* __restrict__
   }
 }
 
-// max over the k columns of | T[:, c] - V[:, c] lam[c] |_2 and max |lam|, into out[0], out[1] (bit patterns of
-// non-negative doubles order like integers).  One workgroup per column.
-__global__ __launch_bounds__(256) void fs_residual_kernel(const double* __restrict__ T, int64_t ldt,
-                                                          const double* __restrict__ V, int64_t ldv,
-                                                          const double* __restrict__ lam, int n, int k,
-                                                          unsigned long long* __restrict__ out) {
-  __shared__ double red[256];
-  const int c = blockIdx.x, tid = threadIdx.x;
-  const double l = lam[c];
-  double s = 0.0;
-  for (int i = tid; i < n; i += 256) {
-    const double r = T[(int64_t)i * ldt + c] - V[(int64_t)i * ldv + c] * l;
-    s += r * r;
+// Column statistics of the Ritz vectors in ONE row-contiguous pass over T = C V and V (a workgroup owns 64 columns of a
+// slab of rows: 512-byte row segments instead of one 8-byte element per 8-KiB stride): per (slab, column) the sum of
+// squares of T[:, c] - V[:, c] lam[c] and the entry of largest modulus with its row (lowest row wins a tie).
+constexpr int FS_SLABS = 16;
+__global__ __launch_bounds__(256) void fs_colstat_kernel(const double* __restrict__ T, int64_t ldt,
+                                                         const double* __restrict__ V, int64_t ldv,
+                                                         const double* __restrict__ lam, int n, int k,
+                                                         double* __restrict__ stat) {
+  __shared__ double ss[4][64], sb[4][64];
+  __shared__ int si[4][64];
+  const int tid = threadIdx.x, cl = tid & 63, rq = tid >> 6;
+  const int c = blockIdx.x * 64 + cl, slab = blockIdx.y;
+  const int rows = (n + FS_SLABS - 1) / FS_SLABS;
+  const int r0 = slab * rows, r1 = min(n, r0 + rows);
+  double s = 0.0, best = -1.0;
+  int at = r0;
+  if (c < k) {
+    const double l = lam[c];
+    for (int i = r0 + rq; i < r1; i += 4) {
+      const double v = V[(int64_t)i * ldv + c];
+      const double r = T[(int64_t)i * ldt + c] - v * l;
+      s += r * r;
+      const double a = fabs(v);
+      if (a > best) { best = a; at = i; }
+    }
   }
-  red[tid] = s;
+  ss[rq][cl] = s; sb[rq][cl] = best; si[rq][cl] = at;
   __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (tid < o) red[tid] += red[tid + o];
-    __syncthreads();
-  }
-  if (tid == 0) {
-    atomicMax(out, (unsigned long long)__double_as_longlong(sqrt(red[0])));
-    atomicMax(out + 1, (unsigned long long)__double_as_longlong(fabs(l)));
+  if (rq == 0 && c < k) {
+#pragma unroll
+    for (int q = 1; q < 4; ++q) {
+      s += ss[q][cl];
+      if (sb[q][cl] > best || (sb[q][cl] == best && si[q][cl] < at)) { best = sb[q][cl]; at = si[q][cl]; }
+    }
+    double* o = stat + ((int64_t)slab * k + c) * 3;
+    o[0] = s; o[1] = best; o[2] = (double)at;
   }
 }
 
-// Eigenvector signs: the entry of largest modulus of every column becomes positive (lowest row wins a tie), so the
-// sign does not hang on the last bits of the Ritz problem.  One workgroup per column.
-__global__ __launch_bounds__(256) void fs_sign_kernel(double* __restrict__ V, int64_t ldv, int n) {
-  __shared__ double bv[256];
-  __shared__ int bi[256];
-  const int c = blockIdx.x, tid = threadIdx.x;
-  double best = -1.0;
+// per column, slabs in index order (a fixed summation order): the residual norm and |lam| into out[0], out[1] (bit
+// patterns of non-negative doubles order like integers), and the sign that makes the column's entry of largest
+// modulus positive -- so the sign does not hang on the last bits of the Ritz problem
+__global__ __launch_bounds__(256) void fs_colfinal_kernel(const double* __restrict__ stat, const double* __restrict__ V,
+                                                          int64_t ldv, const double* __restrict__ lam, int k,
+                                                          unsigned long long* __restrict__ out, double* __restrict__ sgn) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= k) return;
+  double s = 0.0, best = -1.0;
   int at = 0;
-  for (int i = tid; i < n; i += 256) {
-    const double a = fabs(V[(int64_t)i * ldv + c]);
-    if (a > best) { best = a; at = i; }
+  for (int slab = 0; slab < FS_SLABS; ++slab) {
+    const double* o = stat + ((int64_t)slab * k + c) * 3;
+    s += o[0];
+    if (o[1] > best) { best = o[1]; at = (int)o[2]; }
   }
-  bv[tid] = best;
-  bi[tid] = at;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (tid < o && (bv[tid + o] > bv[tid] || (bv[tid + o] == bv[tid] && bi[tid + o] < bi[tid]))) {
-      bv[tid] = bv[tid + o];
-      bi[tid] = bi[tid + o];
-    }
-    __syncthreads();
+  atomicMax(out, (unsigned long long)__double_as_longlong(sqrt(s)));
+  atomicMax(out + 1, (unsigned long long)__double_as_longlong(fabs(lam[c])));
+  sgn[c] = V[(int64_t)at * ldv + c] < 0.0 ? -1.0 : 1.0;
+}
+
+__global__ __launch_bounds__(256) void fs_flip_kernel(double* __restrict__ V, int64_t ldv, int n, int k,
+                                                      const double* __restrict__ sgn) {
+  const int64_t total = (int64_t)n * k;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % k);
+    const int64_t r = i / k;
+    if (sgn[c] < 0.0) V[r * ldv + c] = -V[r * ldv + c];
   }
-  const double sg = V[(int64_t)bi[0] * ldv + c] < 0.0 ? -1.0 : 1.0;
-  __syncthreads();
-  if (sg < 0.0)
-    for (int i = tid; i < n; i += 256) V[(int64_t)i * ldv + c] = -V[(int64_t)i * ldv + c];
 }
 
 // ------------------------------------------------------------------------------------ triangular inverse
@@ -955,8 +970,11 @@ int eigh_filtered(const double* A, int64_t lda, int64_t n, int64_t k, double* ev
     rc = gemm_f64(Z, m, 1, Yk, k, 1, T, k, n, k, m, 1.0, false, 1, st);
     if (rc != PTD_OK) { cleanup(); return rc; }
     PTD_CHECK_HIP(hipMemsetAsync(resid, 0, 16, st));
-    hipLaunchKernelGGL(fs_residual_kernel, dim3((unsigned)k), dim3(256), 0, st, T, (int64_t)k, evecs, ldv,
-                       lam + (m - k), (int)n, (int)k, resid);
+    // (G and W are free outside the orthonormalisation passes: column statistics and signs live there)
+    hipLaunchKernelGGL(fs_colstat_kernel, dim3((unsigned)ceil_div(k, 64), FS_SLABS), dim3(256), 0, st, T, (int64_t)k, evecs,
+                       ldv, lam + (m - k), (int)n, (int)k, G);
+    hipLaunchKernelGGL(fs_colfinal_kernel, dim3((unsigned)ceil_div(k, 256)), dim3(256), 0, st, G, evecs, ldv, lam + (m - k),
+                       (int)k, resid, Wt);
     struct { int fail; int pad[15]; unsigned long long res, lmax; } h{};
     PTD_CHECK_HIP(hipMemcpyAsync(&h, base + p.off_flags, sizeof(h), hipMemcpyDeviceToHost, st));
     PTD_CHECK_HIP(hipStreamSynchronize(st));
@@ -978,7 +996,7 @@ int eigh_filtered(const double* A, int64_t lda, int64_t n, int64_t k, double* ev
     if (rc != PTD_OK) { cleanup(); return rc; }
     filter_products += products - before;
   }
-  hipLaunchKernelGGL(fs_sign_kernel, dim3((unsigned)k), dim3(256), 0, st, evecs, ldv, (int)n);
+  hipLaunchKernelGGL(fs_flip_kernel, dim3(1024), dim3(256), 0, st, evecs, ldv, (int)n, (int)k, Wt);   // signs of the accepted attempt
   // eigenvalues: the k largest at the end of evals[n], NaN below (the convention of ptd_eigh_topk with all_values = 0)
   PTD_CHECK_HIP(hipMemsetAsync(evals, 0xFF, (size_t)(n - k) * 8, st));
   PTD_CHECK_HIP(hipMemcpyAsync(evals + (n - k), lam + (m - k), (size_t)k * 8, hipMemcpyDeviceToDevice, st));

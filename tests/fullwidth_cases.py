@@ -25,7 +25,7 @@ C3_KW = dict(proportion_threshold=0.9, nsr_final_threshold=0.05, kl_final_thresh
 C3_SEEDS = (0, 1)       # (model, data): see tools/scan_fullwidth_seeds.py
 
 
-def c3_case(model_seed: int = C3_SEEDS[0], data_seed: int = C3_SEEDS[1], depth: int = 1, batch: int = 8):
+def c3_case(model_seed: int = C3_SEEDS[0], data_seed: int = C3_SEEDS[1], depth: int = 3, batch: int = 8):
     """timm vit_base_patch16_224 shapes (d = 768, qkv 2304, mlp 3072, head 1000, 197 tokens per image),
     `depth` blocks; the reference's trainer settings (decompose_falor.yaml:18-22: batch 8, D = 5;
     run_decompose_falor.py:92-93: use_mean=False, use_damping=True) with M = 2 and thresholds at which

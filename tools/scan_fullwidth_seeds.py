@@ -14,7 +14,7 @@ for seed in seeds:
     t0 = time.perf_counter()
     trace = []
     if which == "c3":
-        model, pool = fc.c3_case(seed, seed + 1, depth=int(os.environ.get("C3_DEPTH", "2")))
+        model, pool = fc.c3_case(seed, seed + 1, depth=int(os.environ.get("C3_DEPTH", "3")))
         cfg = orc.falor_decompose(module=model, data_iterator=fc.cycle(pool), trace=trace, **fc.C3_KW)
         rel = min(min(abs(r["nsr"] / fc.C3_KW["nsr_final_threshold"] - 1), abs(r["kl"] / fc.C3_KW["kl_final_threshold"] - 1))
                   for r in trace)
