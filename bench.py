@@ -202,8 +202,11 @@ def decomposed_forward_lines(device):
         t = time_events(lambda: ops.lowrank_forward(x, a, b, None), iters=10)
         # the same with the input rotating over buffers larger than the 256-MB Infinity Cache: x comes from HBM at
         # every launch, as in a forward pass of a model (the single-buffer loop above re-reads a cached x)
-        t_cold = time_events(lambda: ops.lowrank_forward(next(rot), a, b, None), iters=12)
-        lib_cold = time_events(lambda: torch.nn.functional.linear(torch.nn.functional.linear(next(rot), a), b), iters=12)
+        # (two rounds each, the faster kept: the first launches of a shape can hit the caching allocator's first
+        # allocation of the 134-MB output blocks)
+        t_cold = min(time_events(lambda: ops.lowrank_forward(next(rot), a, b, None), iters=12) for _ in range(2))
+        lib_cold = min(time_events(lambda: torch.nn.functional.linear(torch.nn.functional.linear(next(rot), a), b), iters=12)
+                       for _ in range(2))
         fl = 2 * t_rows * r * 2 * N_FEAT
         by = 2 * (2 * t_rows * N_FEAT + 2 * r * N_FEAT)
         # the same pair as two torch.nn.functional.linear calls (hipBLASLt): what apply_decompose_config_in_place's
