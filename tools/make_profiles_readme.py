@@ -21,7 +21,7 @@ def split_note(kernel):
     keep = os.path.join(root, f"roofline_kernel_split_r{rnd}.json")
     traces = glob.glob(os.path.join(os.path.dirname(root), "gpurun_out", f"prof_r{rnd}", "*", "*_kernel_trace.csv"))
     if traces:
-        d = [int(t["End_Timestamp"]) - int(t["Start_Timestamp"]) for t in csv.DictReader(open(sorted(traces)[-1]))
+        d = [int(t["End_Timestamp"]) - int(t["Start_Timestamp"]) for t in csv.DictReader(open(max(traces, key=os.path.getmtime)))
              if kernel in t["Kernel_Name"] and "true>" not in t["Kernel_Name"]]
         if d:
             cut = 0.75 * max(d)

@@ -12,6 +12,7 @@ fi
 if [ "$PART" = all ] || [ "$PART" = main ] || [ "$PART" = bench ]; then
   timeout -k 10 500 python bench.py --steps 5 --warmup 1 > gpurun_out/bench_r$R.json 2> gpurun_out/bench_r$R.err; echo "bench rc=$?"
   cut -c1-200 gpurun_out/bench_r$R.json
+  rm -rf $GRAFT_REPO_ROOT/gpurun_out/prof_r$R   # (earlier runs leave PID-named files beside the new ones)
   (cd /tmp && export TMPDIR=/tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_r$R -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-extras > $GRAFT_REPO_ROOT/gpurun_out/prof_r$R.log 2>&1); echo "rocprof rc=$?"
 fi
 if [ "$PART" = all ] || [ "$PART" = c4 ] || [ "$PART" = c4gpu ]; then
