@@ -1,6 +1,6 @@
 """C4 (BASELINE configs[3]) per-shape CPU baseline: the CPU oracle (restatement of the reference,
 torch-CPU / MKL, f32 model, f64 decomposition) on ONE layer of each Llama-3-8B linear shape with the same synthetic
-inputs as tools/c4_shapes.py ([1, 2048, n_in] tokens, D = 8, M = 2), torch threads = physical cores of the box.
+inputs as tools/c4_shapes.py ([1, 2048, n_in] tokens, D = 8, M = 2), torch threads = min(physical cores, CPUs the cgroup grants).
 Prints a JSON object; the 224-layer figure is an extrapolation like the GPU one.  A few minutes of CPU time."""
 import itertools, json, os, sys, time, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -12,7 +12,9 @@ try:
     physical = psutil.cpu_count(logical=False) or os.cpu_count()
 except Exception:
     physical = os.cpu_count()
-usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+from cpu_quota import usable_cpus   # affinity AND cgroup quota: the GPU boxes show 256 CPUs and grant 16
+usable = usable_cpus()
 cores = max(1, min(physical, usable))
 torch.set_num_threads(cores)
 shapes = [s for s in sys.argv[1:] if not s.startswith("-")] or ["q_o", "k_v", "gate_up", "down"]
