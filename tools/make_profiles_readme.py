@@ -213,7 +213,7 @@ c4c = os.path.join(root, f"c4_shapes_cpu_r{rnd}.json")
 if os.path.exists(c4c) and os.path.exists(c4p):
     cc = json.load(open(c4c))
     o.append(f"\nCPU baseline per shape (`c4_shapes_cpu_r{rnd}.json`, `python tools/c4_shapes_cpu.py`: the CPU oracle on the same inputs, "
-             f"torch threads = {cc['cores']} = the physical cores of the box):\n\n| layer | CPU s per layer | GPU ms per layer |\n|---|---|---|\n")
+             f"torch threads = {cc['cores']} = min(physical cores, CPUs the box's cgroup grants)):\n\n| layer | CPU s per layer | GPU ms per layer |\n|---|---|---|\n")
     for k in ("q_o", "k_v", "gate_up", "down"):
         if k in cc:
             o.append(f"| {k} | {cc[k]['s_per_layer']:.1f} | {c4[k]['ms_per_layer']:.0f} |\n")
