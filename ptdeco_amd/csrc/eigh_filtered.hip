@@ -844,12 +844,19 @@ int eigh_filtered(const double* A, int64_t lda, int64_t n, int64_t k, double* ev
     fprintf(stderr, "[eigh_filtered] n=%lld k=%lld m=%d: lo %.3e a %.3e lambda_k~%.3e hi %.3e growth %.2f/product -> "
                     "%d products\n", (long long)n, (long long)k, m, lo, a_cut, lam_k, hi, growth, degree);
   if (!(growth > 1.0) || degree > max_products) return decline("spectrum too flat for the filter");
-  // rounds of at most 6 products (cond(X) grows ~150^d), the last one at most 4 (it sets the final accuracy)
+  // A round multiplies cond(X) by about g_top^d, g_top the growth per product at the top of the spectrum (~150 on
+  // covariance spectra: six products reach 1e13, which the shifted Cholesky-QR pass still takes; a spectrum with a wide
+  // gap right below lambda_k grows by 1e4 and more per product and broke the pass down at four).  Rounds of at most
+  // dmax = floor(log 3e14 / log g_top) <= 6 products, the last one at most 4 (it sets the final accuracy).
+  const double x_top = (hi - cc) / ee;
+  const double g_top = x_top + sqrt(std::max(x_top * x_top - 1.0, 0.0));
+  const int dmax = (int)std::max(1.0, std::min(6.0, floor(log(3e14) / log(std::max(g_top, 1.0 + 1e-9)))));
+  if (debug) fprintf(stderr, "[eigh_filtered] growth at the top %.3g per product: rounds of at most %d\n", g_top, dmax);
   std::vector<int> rounds;
   {
-    const int last = std::min(4, degree);
+    const int last = std::min(std::min(4, dmax), degree);
     int rest = degree - last;
-    const int nr = (int)ceil_div(rest, 6);
+    const int nr = (int)ceil_div(rest, dmax);
     for (int r = 0; r < nr; ++r) {
       const int d = (int)ceil_div(rest, nr - r);
       rounds.push_back(d);
@@ -989,7 +996,7 @@ int eigh_filtered(const double* A, int64_t lda, int64_t n, int64_t k, double* ev
     const double rel = res / std::max(lmax, 1e-300);
     if (attempt >= 3 || !(rel < 1e-2)) return decline("residual above the tolerance");
     const double rate = pow(0.05 / rel, 1.0 / (double)filter_products);     // over ALL filter products so far
-    const int extra = std::min(6, std::max(2, (int)ceil(log(rel / (0.1 * tol)) / log(std::max(rate, 1.5)))));
+    const int extra = std::min(dmax, std::max(std::min(2, dmax), (int)ceil(log(rel / (0.1 * tol)) / log(std::max(rate, 1.5)))));
     if (debug) fprintf(stderr, "[eigh_filtered] measured %.2f per product: %d more\n", rate, extra);
     const int before = products;
     rc = filter_round(extra);

@@ -375,6 +375,53 @@ def test_eigh_filtered_subspace_route_matches_lapack(ops, monkeypatch, n, k):
     assert d2 <= (1e-6 * math.sqrt(k)) ** 2 + 1e-9
 
 
+def _matrix_with_spectrum(lam, seed):
+    """Q diag(lam) Q^T with a random orthogonal Q (f64, built on the device)."""
+    n = lam.numel()
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    q, _ = torch.linalg.qr(torch.randn(n, n, generator=g, device=DEV, dtype=torch.float64))
+    a = (q * lam.to(DEV)) @ q.T
+    return 0.5 * (a + a.T)
+
+
+@pytest.mark.parametrize("family", ["geometric_1e8", "gap_at_k", "repeated_top", "heavy_tail", "rank_k_plus_floor",
+                                    "two_plateaus"])
+def test_eigh_topk_contract_over_spectrum_families(ops, monkeypatch, family):
+    """Whichever route answers (the filtered subspace iteration where its density estimate accepts the spectrum, the
+    direct reduction where it declines), ptd_eigh_topk must return the k largest eigenvalues of matrices whose spectra
+    are NOT the smooth covariance decay the route was tuned on: eight decades of geometric decay, a wide gap exactly
+    at k, an eightfold eigenvalue at the top, a heavy tail with a few dominant directions, rank k + 3 over a flat
+    floor (the requested eigenvalues end just above a degenerate cluster), two plateaus.  The spectrum is known by
+    construction: eigenvalues to 1e-12 |A|, residuals 2e-10 |A|, orthonormal columns; PTD_EIGH_FILTERED=2 lets the
+    route try at this order."""
+    n, k = 1536, 384
+    i = torch.arange(n, dtype=torch.float64)
+    if family == "geometric_1e8":
+        lam = torch.pow(10.0, -8.0 * i / (n - 1))
+    elif family == "gap_at_k":
+        lam = torch.where(i < k, 2.0 - i / k, 1e-3 * (1.0 - 0.5 * i / n))
+    elif family == "repeated_top":
+        lam = 1.0 / (1.0 + 0.02 * i)
+        lam[:8] = 3.0
+    elif family == "heavy_tail":
+        lam = 1.0 / (1.0 + i) ** 0.3
+        lam[:4] = torch.tensor([500.0, 200.0, 90.0, 40.0], dtype=torch.float64)
+    elif family == "rank_k_plus_floor":
+        lam = torch.full((n,), 1e-4, dtype=torch.float64)
+        lam[: k + 3] = 1.0 / (1.0 + 0.01 * i[: k + 3])
+    else:  # two_plateaus
+        lam = torch.where(i < 200, 1.0 + 1e-3 * (200 - i) / 200, 0.1 + 1e-3 * (n - i) / n)
+    a = _matrix_with_spectrum(lam, 31)
+    monkeypatch.setenv("PTD_EIGH_FILTERED", "2")
+    w, v, prof = _profiled_eigh(ops, monkeypatch, a, k)
+    want = torch.sort(lam).values[n - k:]
+    scale = lam.abs().max().item()
+    assert (w[n - k:] - want).abs().max().item() <= 1e-12 * scale * max(1.0, math.log10(n)), (family, prof["method"])
+    ac = a.cpu()
+    assert (ac @ v - v * w[n - k:]).norm(dim=0).max().item() <= 2e-10 * scale, (family, prof["method"])
+    assert (v.T @ v - torch.eye(k, dtype=torch.float64)).abs().max().item() <= 1e-9, (family, prof["method"])
+
+
 def test_eigh_filtered_route_retries_when_the_first_attempt_falls_short(ops, monkeypatch):
     """The degree of the filter comes from a density ESTIMATE; when it was too optimistic the residual check after the
     Rayleigh-Ritz step says so and the route spends one more round sized by the rate it measured (at most twice) instead
