@@ -364,6 +364,8 @@ def main():
                 precomputing_covariance_num_splits=1, **kw)
         return one_step
 
+    step_marks = []   # per timed() call: host-side duration of each step (ms), for the spread
+
     def timed(one_step):
         """W untimed steps, then exactly K steps between barrier + synchronize; max over ranks."""
         cfg = None
@@ -371,10 +373,13 @@ def main():
             cfg = one_step()
         barrier()
         t0 = time.perf_counter()
+        marks = []
         for _ in range(args.steps):
             cfg = one_step()
+            marks.append(time.perf_counter())     # (no synchronisation added: a step ends on the host's last decision)
         barrier()
         dt = time.perf_counter() - t0
+        step_marks.append([round((b - a) * 1e3, 3) for a, b in zip([t0] + marks[:-1], marks)])
         if world > 1:
             tmax = torch.tensor([dt], dtype=torch.float64, device=device)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -396,6 +401,7 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3,
+        "step_ms": step_marks[0],
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
