@@ -313,6 +313,8 @@ void launch_f32(const GemmF32Args& a, bool akc, bool bkc, dim3 grid, hipStream_t
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void glb_void_t;
 
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"   // (m0 is named as clobbered on purpose: the loads set it)
 template <bool STAGGER>
 __global__ __launch_bounds__(512, 1) void gemm_f32_nt_8ph_kernel(const GemmF32Args a) {
   __shared__ __attribute__((aligned(16))) char lds[8 * 16384];  // slot ((op*2 + d)*2 + h) * 16 KiB: A below 64 KiB, B above
@@ -329,25 +331,28 @@ __global__ __launch_bounds__(512, 1) void gemm_f32_nt_8ph_kernel(const GemmF32Ar
   const int m0 = ti * 256, n0 = tj * 256;
   const int nk = a.K / 32;
 
+  // staging: a wave instruction moves 8 rows x 128 B; wave w owns pieces 2w, 2w + 1 of every half tile.  Addresses are a
+  // wave-uniform tile base plus ONE 32-bit per-lane byte offset per piece (the scalar-base form of the load, written out
+  // with m0 beside it: the builtin's 64-bit per-lane address arithmetic costs registers and VALU work in every phase)
   const int srow = lane >> 3, spos = lane & 7;
-  const float *sa0, *sa1, *sb0, *sb1;
-  {
-    const int r0 = wid * 16 + srow, r1 = r0 + 8;
-    const int c0 = spos ^ ((r0 >> 1) & 7), c1 = spos ^ ((r1 >> 1) & 7);
-    sa0 = a.A + (int64_t)(m0 + r0) * a.sam + c0 * 4;
-    sa1 = a.A + (int64_t)(m0 + r1) * a.sam + c1 * 4;
-    sb0 = a.B + (int64_t)(n0 + r0) * a.sbn + c0 * 4;
-    sb1 = a.B + (int64_t)(n0 + r1) * a.sbn + c1 * 4;
-  }
-  const int64_t halfA = 128 * a.sam, halfB = 128 * a.sbn;
-  char* const mypiece = lds + wid * 2048;
+  const int sr0 = wid * 16 + srow, sr1 = sr0 + 8;
+  const unsigned voa0 = (unsigned)((sr0 * a.sam + (spos ^ ((sr0 >> 1) & 7)) * 4) * 4);
+  const unsigned voa1 = (unsigned)((sr1 * a.sam + (spos ^ ((sr1 >> 1) & 7)) * 4) * 4);
+  const unsigned vob0 = (unsigned)((sr0 * a.sbn + (spos ^ ((sr0 >> 1) & 7)) * 4) * 4);
+  const unsigned vob1 = (unsigned)((sr1 * a.sbn + (spos ^ ((sr1 >> 1) & 7)) * 4) * 4);
+  const char* const baseA = reinterpret_cast<const char*>(a.A + (int64_t)m0 * a.sam);
+  const char* const baseB = reinterpret_cast<const char*>(a.B + (int64_t)n0 * a.sbn);
+  const int64_t halfA = 512 * a.sam, halfB = 512 * a.sbn;   // bytes
+  const unsigned mypiece = (unsigned)(size_t)(lds_void_t*)lds + wid * 2048;
+#define PTD_DMA(LDSADDR, VOFF, SBASE)                                                                    \
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"                          \
+               : : "s"(LDSADDR), "v"(VOFF), "s"(SBASE) : "memory", "m0")
 #define PTD_STAGE(D, OP, H, KT)                                                                          \
   do {                                                                                                   \
-    char* slot_ = mypiece + ((((OP) * 2 + (D)) * 2 + (H)) << 14);                                        \
-    const float* s0_ = ((OP) ? sb0 + (H) * halfB : sa0 + (H) * halfA) + (int64_t)(KT) * 32;              \
-    const float* s1_ = ((OP) ? sb1 + (H) * halfB : sa1 + (H) * halfA) + (int64_t)(KT) * 32;              \
-    __builtin_amdgcn_global_load_lds((glb_void_t*)s0_, (lds_void_t*)slot_, 16, 0, 0);                    \
-    __builtin_amdgcn_global_load_lds((glb_void_t*)s1_, (lds_void_t*)(slot_ + 1024), 16, 0, 0);           \
+    const unsigned slot_ = mypiece + ((((OP) * 2 + (D)) * 2 + (H)) << 14);                               \
+    const char* base_ = ((OP) ? baseB + (H) * halfB : baseA + (H) * halfA) + (int64_t)(KT) * 128;        \
+    PTD_DMA(slot_, ((OP) ? vob0 : voa0), base_);                                                         \
+    PTD_DMA(slot_ + 1024, ((OP) ? vob1 : voa1), base_);                                                  \
   } while (0)
 
   const int fr = lane & 31, fh = lane >> 5, sw = (fr >> 1) & 7;
@@ -423,6 +428,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f32_nt_8ph_kernel(const GemmF32Ar
                                                                         PTD_SYNC_IN(0); PTD_QUAD(1, 0, b0); PTD_SYNC_OUT();
   }
   if (STAGGER && wr == 0) __builtin_amdgcn_s_barrier();
+#undef PTD_DMA
 #undef PTD_STAGE
 #undef PTD_READ_A
 #undef PTD_READ_B
@@ -463,7 +469,9 @@ __global__ __launch_bounds__(512, 1) void gemm_f32_nt_8ph_kernel(const GemmF32Ar
       }
     }
 }
+#pragma clang diagnostic pop
 
+// K split of the generic kernel for products with few output tiles: the partial tiles are added in index
 // order, so the result does not depend on scheduling.  Returns 1 when splitting does not pay.
 int gemm_f32_ksplit(int64_t M, int64_t N, int64_t K) {
   const int64_t tiles = ceil_div(M, BM) * ceil_div(N, BN);
