@@ -550,15 +550,18 @@ def run_concurrently(jobs, device: torch.device, max_streams: Optional[int] = No
     from . import _hip
 
     threads = [threading.Thread(target=worker, args=(w,), name=f"ptdeco-eigh-{w}") for w in range(workers)]
-    # interleaved chains: no kernel may claim a whole XCD for itself (ptd_set_concurrent_chains)
-    before = _hip.load().ptd_set_concurrent_chains(workers)
+    # interleaved chains: no kernel may claim a whole XCD for itself (ptd_set_concurrent_chains; the hint is kept
+    # per device and keyed by the calling thread's current device, so it is set with `device` current)
+    with torch.cuda.device(device):
+        before = _hip.load().ptd_set_concurrent_chains(workers)
     try:
         for th in threads:
             th.start()
         for th in threads:
             th.join()
     finally:
-        _hip.load().ptd_set_concurrent_chains(before)
+        with torch.cuda.device(device):
+            _hip.load().ptd_set_concurrent_chains(before)
     for st in streams:
         main.wait_stream(st)
     for res in out:  # the results were allocated on a side stream and live on under the caller's

@@ -41,7 +41,7 @@ def c3_case(model_seed: int = C3_SEEDS[0], data_seed: int = C3_SEEDS[1], depth: 
 # ---------------------------------------------------------------- C4: dwain on one full-width Llama block
 C4_KW = dict(num_data_steps=5, num_metric_steps=1, nsr_final_threshold=1.0, min_rank=32, trade_off_factor=20.0,
              reduction_factor=0.5, max_accepted_ppl_diff=0.4, decompose_in_float64=True,
-             blacklisted_module_names=["head", "blocks.0.gate", "blocks.0.up"],
+             blacklisted_module_names=["head", "blocks.0.up"],
              precomputing_covariance_num_splits=None)
 C4_SEED = 0
 D_MODEL, D_KV, D_FF = 4096, 1024, 14336

@@ -425,6 +425,86 @@ def test_dwain_c2_headline_workload_end_to_end_matches_oracle(splits):
     assert (out - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
 
 
+def test_dwain_three_layer_stack_concurrent_filtered_chains_match_oracle():
+    """The DEFAULT path of every multi-layer split (dwain.py:580-633 + 333-537): three nn.Linear(4096, 4096) in ONE
+    precompute split, so their three eigendecompositions -- each the filtered subspace iteration, each with its own
+    host-side decisions and two stream synchronisations -- run as three concurrent chains on three HIP streams
+    (_engine.run_concurrently), against the CPU oracle on the same seeded inputs: identical (layer, rank, accepted)
+    decisions, nsr / ppl within 1e-4, factor products within 1e-4 (Frobenius), outputs 1e-4.  The test also
+    asserts that the three calls really ran on three threads / streams and that the solver's route for these
+    matrices is the filtered one."""
+    import threading
+
+    import bench
+    import ptdeco_amd
+    from ptdeco_amd import ops
+
+    n_layers = 3
+    model, data, metric = bench.make_workload(n_layers, "cpu", bench.D_STEPS, 7 * bench.M_STEPS)
+    cpu = torch.device("cpu")
+    data_c, metric_c = bench.with_targets(model, data, cpu), bench.with_targets(model, metric, cpu)
+    gpu_model = copy.deepcopy(model).to(DEV)
+    data_g = [{k: v.to(DEV) for k, v in b.items()} for b in data_c]
+    metric_g = [{k: v.to(DEV) for k, v in b.items()} for b in metric_c]
+
+    ref_trace, trace = [], []
+    ref_cfg = orc.dwain_decompose(module=model, data_iterator=itertools.cycle(data_c), loss_fn=bench.ce_loss,
+                                  metric_iterator=itertools.cycle(metric_c), finetune_fn=None, trace=ref_trace,
+                                  precomputing_covariance_num_splits=1, **bench.DWAIN_KW)
+    kw = bench.DWAIN_KW
+    margins = [min(abs(t["ppl_diff"] - t["threshold"]), abs(t["ppl_diff"] - kw["max_accepted_ppl_diff"]),
+                   abs(t["nsr"] - kw["nsr_final_threshold"])) / max(abs(t["ppl_diff"]), 1e-12) for t in ref_trace]
+    assert min(margins) > 1e-2    # (5.9e-2 on the committed seeds)
+
+    calls, kept = [], []
+    real_eigh = ops.eigh
+
+    def spy(a, k=None, all_values=True):
+        calls.append((threading.get_ident(), torch.cuda.current_stream(a.device).cuda_stream, a.shape[0], k))
+        if not kept:
+            kept.append((a.clone(), k, all_values))
+        return real_eigh(a, k, all_values)
+
+    ops.eigh = spy
+    try:
+        cfg = ptdeco_amd.dwain.decompose_in_place(
+            module=gpu_model, device=DEV, data_iterator=itertools.cycle(data_g), loss_fn=bench.ce_loss,
+            metric_iterator=itertools.cycle(metric_g), finetune_fn=lambda m, d, n: m, trace=trace,
+            precomputing_covariance_num_splits=1, **bench.DWAIN_KW)
+    finally:
+        ops.eigh = real_eigh
+    streams_wanted = min(3, int(__import__("os").environ.get("PTD_EIGH_STREAMS", "3")))
+    assert len(calls) == 3 and all(c[2:] == (4096, 1024) for c in calls)
+    assert len({c[0] for c in calls}) == streams_wanted and len({c[1] for c in calls}) == streams_wanted
+    # the route the solver takes for these matrices (decided from the matrix alone): filtered subspace iteration
+    ops.EIGH_PROFILE = []
+    try:
+        real_eigh(*kept[0])
+        assert ops.EIGH_PROFILE[0]["method"] == 3
+    finally:
+        ops.EIGH_PROFILE = None
+
+    assert len(ref_trace) == 3 * 6
+    assert [(t["layer"], t["rank"], t["accepted"]) for t in trace] == \
+           [(t["layer"], t["rank"], t["accepted"]) for t in ref_trace]
+    for t, r in zip(trace, ref_trace):
+        for key in ("nsr", "ppl_deco", "ppl_diff"):
+            assert abs(t[key] - r[key]) <= 1e-4 * abs(r[key]) + 2e-6, (key, t, r)
+    assert list(cfg.keys()) == list(ref_cfg.keys()) == ["layers.2", "layers.1", "layers.0"]
+    for name in cfg:
+        assert cfg[name]["modules"] == ref_cfg[name]["modules"]
+        assert cfg[name]["__meta__"]["proportion"] == ref_cfg[name]["__meta__"]["proportion"]
+    for i in range(n_layers):
+        a_g, b_g = (gpu_model.layers[i][j].weight.detach().cpu().double() for j in (0, 1))
+        a_r, b_r = (model.layers[i][j].weight.detach().double() for j in (0, 1))
+        prod_r = b_r @ a_r
+        assert (b_g @ a_g - prod_r).norm().item() <= 1e-4 * prod_r.norm().item(), i
+    with torch.no_grad():
+        out = gpu_model({"x": data_g[0]["x"]}).cpu()
+        ref = model({"x": data_c[0]["x"]})
+    assert (out - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
+
+
 def test_llama_shaped_stack_shares_input_moments_and_matches_oracle(monkeypatch):
     """SURVEY 8f-4 on the 2-block Llama-shaped mini stack: with PTD_SHARE_INPUT_COVARIANCE=all the precompute pass
     performs 4 input-side SYRKs per calibration step (one per q/k/v group and one per gate/up group) instead of
