@@ -138,6 +138,81 @@ __global__ void nsr_partial_kernel(const T* __restrict__ x, const T* __restrict_
   }
 }
 
+// The same sums with 16-byte loads (C a multiple of V = 16 / sizeof(T), 16-byte aligned operands): a lane owns V
+// consecutive channels, a wave 64 V of them, the four waves of a block are four row lanes; four rows of x and of y are
+// requested per trip (eight 16-byte loads in flight per lane) before anything is consumed.  HBM-bound: the one-element-
+// per-lane form above keeps too few bytes in flight per CU (C2 logits: 3.4 TB/s).
+template <typename T, int V>
+__device__ __forceinline__ void nsr_unpack(const uint4& q, double (&v)[V]);
+template <>
+__device__ __forceinline__ void nsr_unpack<float, 4>(const uint4& q, double (&v)[4]) {
+  v[0] = (double)__uint_as_float(q.x); v[1] = (double)__uint_as_float(q.y);
+  v[2] = (double)__uint_as_float(q.z); v[3] = (double)__uint_as_float(q.w);
+}
+template <>
+__device__ __forceinline__ void nsr_unpack<unsigned short, 8>(const uint4& q, double (&v)[8]) {
+  v[0] = (double)__uint_as_float(q.x << 16); v[1] = (double)__uint_as_float(q.x & 0xFFFF0000u);
+  v[2] = (double)__uint_as_float(q.y << 16); v[3] = (double)__uint_as_float(q.y & 0xFFFF0000u);
+  v[4] = (double)__uint_as_float(q.z << 16); v[5] = (double)__uint_as_float(q.z & 0xFFFF0000u);
+  v[6] = (double)__uint_as_float(q.w << 16); v[7] = (double)__uint_as_float(q.w & 0xFFFF0000u);
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void nsr_partial_vec_kernel(const T* __restrict__ x, const T* __restrict__ y, int64_t R,
+                                                              int64_t C, int64_t rows_per_chunk,
+                                                              double* __restrict__ part) {
+  __shared__ double sm[3][V][64];   // one quantity at a time: [row lane 1..3][channel of the lane][lane]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int64_t c0 = ((int64_t)blockIdx.x * 64 + lane) * V;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk;
+  const int64_t r1 = min(R, r0 + rows_per_chunk);
+  const bool active = c0 < C;
+  double s1[V], s2[V], s3[V], pv[V];
+#pragma unroll
+  for (int i = 0; i < V; ++i) s1[i] = s2[i] = s3[i] = pv[i] = 0.0;
+  if (active) {
+    nsr_unpack<T, V>(*reinterpret_cast<const uint4*>(y + c0), pv);   // first row: the pivot of the variance sums
+    for (int64_t r = r0 + w; r < r1; r += 16) {
+      uint4 qy[4], qx[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t rr = min(r + 4 * u, r1 - 1);                   // (clamped rows are loaded and not counted)
+        qy[u] = *reinterpret_cast<const uint4*>(y + rr * C + c0);
+        qx[u] = *reinterpret_cast<const uint4*>(x + rr * C + c0);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (r + 4 * u >= r1) break;
+        double yv[V], xv[V];
+        nsr_unpack<T, V>(qy[u], yv);
+        nsr_unpack<T, V>(qx[u], xv);
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+          const double dy = yv[i] - pv[i], dx = xv[i] - yv[i];
+          s1[i] += dy;
+          s2[i] = fma(dy, dy, s2[i]);
+          s3[i] = fma(dx, dx, s3[i]);
+        }
+      }
+    }
+  }
+  // row lanes 1..3 hand their sums to lane 0, one quantity at a time, added in lane order
+  double* o = part + (int64_t)blockIdx.y * 3 * C + c0;
+#pragma unroll
+  for (int qn = 0; qn < 3; ++qn) {
+    double (&s)[V] = qn == 0 ? s1 : (qn == 1 ? s2 : s3);
+    if (qn) __syncthreads();
+    if (w > 0)
+#pragma unroll
+      for (int i = 0; i < V; ++i) sm[w - 1][i][lane] = s[i];
+    __syncthreads();
+    if (w == 0 && active) {
+#pragma unroll
+      for (int i = 0; i < V; ++i) o[(int64_t)qn * C + i] = ((s[i] + sm[0][i][lane]) + sm[1][i][lane]) + sm[2][i][lane];
+    }
+  }
+}
+
 // 64 channels x 4 chunk lanes per block: the chunk partials of a channel are added in a fixed order (lane q takes
 // chunks q, q + 4, ..., then lanes 0 .. 3), the block leaves the sum of its channels' ratios in blocksum[blockIdx.x],
 // and the LAST block to finish (ticket counter) adds the block sums in index order and writes the result:
@@ -247,6 +322,20 @@ struct NsrPlan {
   int64_t rows_per_chunk;
 };
 
+// the 16-byte form: `vec` channels per lane, 64 lanes per column tile, four row lanes; chunks of at least 32 rows, about
+// 1024 blocks (the partial sums are 24 C bytes per chunk: more chunks would add their traffic to the stream)
+NsrPlan nsr_plan_vec(int64_t R, int64_t C, int vec) {
+  NsrPlan p{};
+  p.Ct = 64 * vec;
+  p.Rt = 4;
+  p.coltiles = (int)ceil_div(C, p.Ct);
+  const int64_t want = std::max<int64_t>(1, 1024 / p.coltiles);
+  p.nchunk = (int)std::max<int64_t>(1, std::min<int64_t>(want, ceil_div(R, 32)));
+  p.rows_per_chunk = ceil_div(R, p.nchunk);
+  p.nchunk = (int)ceil_div(R, p.rows_per_chunk);
+  return p;
+}
+
 NsrPlan nsr_plan(int64_t R, int64_t C) {
   NsrPlan p{};
   p.Ct = (int)std::min<int64_t>(C, 256);
@@ -316,8 +405,9 @@ int colsum_accumulate(const void* y, int64_t T, int64_t n, int64_t ldy, int y_dt
 }
 
 size_t nsr_workspace_bytes(int64_t R, int64_t C) {
-  const NsrPlan p = nsr_plan(R, C);
-  return align_up((size_t)p.nchunk * C * 3 * 8, 256) + align_up((size_t)ceil_div(C, 64) * 8, 256) + 256;
+  // (the dtype is not known here: room for whichever plan has more chunks)
+  const int nchunk = std::max(std::max(nsr_plan(R, C).nchunk, nsr_plan_vec(R, C, 4).nchunk), nsr_plan_vec(R, C, 8).nchunk);
+  return align_up((size_t)nchunk * C * 3 * 8, 256) + align_up((size_t)ceil_div(C, 64) * 8, 256) + 256;
 }
 
 int nsr(const void* x, const void* y, int64_t R, int64_t C, int dtype, double eps, double* out, void* ws,
@@ -327,21 +417,34 @@ int nsr(const void* x, const void* y, int64_t R, int64_t C, int dtype, double ep
     set_error("ptd_nsr: workspace too small");
     return PTD_ERR_WORKSPACE;
   }
-  const NsrPlan p = nsr_plan(R, C);
+  NsrPlan p = nsr_plan(R, C);
   double* part = static_cast<double*>(ws);
-  dim3 grid((unsigned)p.coltiles, (unsigned)p.nchunk);
-  if (dtype == PTD_F32)
-    hipLaunchKernelGGL((nsr_partial_kernel<float>), grid, dim3(256), 0, st, (const float*)x, (const float*)y, R, C,
-                       p.Ct, p.Rt, p.rows_per_chunk, part);
-  else if (dtype == PTD_BF16)
-    hipLaunchKernelGGL((nsr_partial_kernel<unsigned short>), grid, dim3(256), 0, st, (const unsigned short*)x,
-                       (const unsigned short*)y, R, C, p.Ct, p.Rt, p.rows_per_chunk, part);
-  else if (dtype == PTD_F64)
-    hipLaunchKernelGGL((nsr_partial_kernel<double>), grid, dim3(256), 0, st, (const double*)x, (const double*)y, R,
-                       C, p.Ct, p.Rt, p.rows_per_chunk, part);
-  else {
-    set_error("ptd_nsr: unsupported dtype");
-    return PTD_ERR_UNSUPPORTED;
+  const int vec = dtype == PTD_F32 ? 4 : (dtype == PTD_BF16 ? 8 : 0);
+  const bool aligned = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
+  if (vec && C % vec == 0 && C >= 64 && aligned) {
+    p = nsr_plan_vec(R, C, vec);
+    dim3 vgrid((unsigned)p.coltiles, (unsigned)p.nchunk);
+    if (dtype == PTD_F32)
+      hipLaunchKernelGGL((nsr_partial_vec_kernel<float, 4>), vgrid, dim3(256), 0, st, (const float*)x, (const float*)y, R,
+                         C, p.rows_per_chunk, part);
+    else
+      hipLaunchKernelGGL((nsr_partial_vec_kernel<unsigned short, 8>), vgrid, dim3(256), 0, st, (const unsigned short*)x,
+                         (const unsigned short*)y, R, C, p.rows_per_chunk, part);
+  } else {
+    dim3 grid((unsigned)p.coltiles, (unsigned)p.nchunk);
+    if (dtype == PTD_F32)
+      hipLaunchKernelGGL((nsr_partial_kernel<float>), grid, dim3(256), 0, st, (const float*)x, (const float*)y, R, C,
+                         p.Ct, p.Rt, p.rows_per_chunk, part);
+    else if (dtype == PTD_BF16)
+      hipLaunchKernelGGL((nsr_partial_kernel<unsigned short>), grid, dim3(256), 0, st, (const unsigned short*)x,
+                         (const unsigned short*)y, R, C, p.Ct, p.Rt, p.rows_per_chunk, part);
+    else if (dtype == PTD_F64)
+      hipLaunchKernelGGL((nsr_partial_kernel<double>), grid, dim3(256), 0, st, (const double*)x, (const double*)y, R,
+                         C, p.Ct, p.Rt, p.rows_per_chunk, part);
+    else {
+      set_error("ptd_nsr: unsupported dtype");
+      return PTD_ERR_UNSUPPORTED;
+    }
   }
   double* blocksum = part + align_up((size_t)p.nchunk * C * 3 * 8, 256) / 8;
   const unsigned fblocks = (unsigned)ceil_div(C, 64);

@@ -90,9 +90,9 @@ def seq_ce(batch, logits):
 def c4_case(seed: int = C4_SEED, tokens: int = 1024, n_batches: int = 10):
     """One block at full width (4096 / 1024 / 14336) + the blacklisted head, f32, W ~ N(0, 1/n_in), inputs
     N(0, 1) x a decaying feature scale [1, tokens, 4096] (1024 tokens per step so that the CPU oracle fits the
-    test budget; D = 5 steps give more calibration rows than features), targets = argmax of the original logits.  gate / up
-    are blacklisted ON BOTH SIDES: their 14336^2 eigendecomposition takes the CPU oracle minutes (the factored
-    route they would take is checked at full size by test_eigh_factored_full_size_matches_the_direct_route)."""
+    test budget; D = 5 steps give more calibration rows than features), targets = argmax of the original logits.  `up`
+    is blacklisted ON BOTH SIDES (a 14336^2 eigendecomposition takes the CPU oracle about a minute on the GPU box's 16
+    granted CPUs; `gate`, the same shape, IS decomposed: the factored route end to end against the oracle)."""
     g = torch.Generator().manual_seed(seed)
     model = LlamaStack(1)
     with torch.no_grad():

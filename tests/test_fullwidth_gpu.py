@@ -64,8 +64,10 @@ def test_falor_vit_b16_width_matches_oracle():
 
 def test_dwain_llama3_8b_width_block_matches_oracle():
     """C4 (dwain.py:333-537, 677-800): ONE block at the Llama-3-8B widths (q / o 4096 -> 4096, k / v 4096 -> 1024,
-    down 14336 -> 4096; gate / up 4096 -> 14336 present in the forward and blacklisted on both sides, see
-    fullwidth_cases.c4_case), [1, 1024, 4096] calibration batches, D = 5, f32 model, f64 decomposition.  Identical
+    down 14336 -> 4096, gate 4096 -> 14336 -- the widening layer whose eigenvectors come from the n_in-sized factored
+    problem, ptd_eigh_factored, checked here END TO END against the oracle's explicit 14336^2 eigendecomposition; up is
+    present in the forward and blacklisted on both sides, see fullwidth_cases.c4_case), [1, 1024, 4096] calibration
+    batches, D = 5, f32 model, f64 decomposition.  Identical
     (layer, rank, accepted) decisions, nsr / ppl_diff within 1e-4, same config, factor products and outputs."""
     import ptdeco_amd
 
@@ -83,7 +85,8 @@ def test_dwain_llama3_8b_width_block_matches_oracle():
     margins = [min(abs(t["ppl_diff"] - t["threshold"]), abs(t["ppl_diff"] - kw["max_accepted_ppl_diff"]),
                    abs(t["nsr"] - kw["nsr_final_threshold"])) / max(abs(t["ppl_diff"]), 1e-12) for t in ref_trace]
     assert min(margins) > 5e-4, f"the oracle run is within {min(margins):.1e} (relative) of a threshold"
-    assert len(ref_trace) == 7 + 6 + 5 + 5 + 6   # down, o, v, k, q: the candidates that lower the parameter count
+    assert len(ref_trace) == 7 + 7 + 6 + 5 + 5 + 6   # down, gate, o, v, k, q: the candidates that lower the parameter count
+    assert "blocks.0.gate" in ref_cfg                # (rank 128 of 4096 on the committed seed)
     assert [(t["layer"], t["rank"], t["accepted"]) for t in trace] == \
            [(t["layer"], t["rank"], t["accepted"]) for t in ref_trace]
     for t, r in zip(trace, ref_trace):

@@ -882,7 +882,8 @@ def test_nsr_golden(ops):
 
 
 @pytest.mark.parametrize("shape,chan", [((4096, 4096), 4096), ((4096, 4096), 1), ((7, 300), 300), ((5, 10), 10),
-                                        ((33, 1000), 1000), ((2, 3, 50), 50)])
+                                        ((33, 1000), 1000), ((2, 3, 50), 50), ((130, 516), 516), ((3, 70, 1288), 1288),
+                                        ((1, 64), 64), ((2, 41, 32064), 32064)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_nsr_random(ops, shape, chan, dtype):
     y = (_rand(shape, 1) * 2 + 0.3).to(dtype)
