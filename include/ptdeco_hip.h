@@ -176,6 +176,15 @@ int ptd_tridiagonalize(const double* A, int64_t lda, int64_t n, double* d, doubl
 int ptd_band_reduce(const double* A, int64_t lda, int64_t n, int stages, double* band, void* ws,
                     size_t ws_bytes, void* stream);
 
+/* Diagnostic: the Cholesky sweep of the filtered eigensolver's orthonormalisation passes on its own (the
+ * step that replaces nothing in the reference -- torch.linalg.eigh hides it -- but is the latency-critical
+ * part of ptd_eigh_topk's filtered route).  G [m, m] row-major f64, symmetric positive definite, lower
+ * 64 x 64 tiles read, DESTROYED; Wt [m, m] receives L^-T (upper triangular, G = L L^T), so that X Wt has
+ * orthonormal columns when G = X^T X.  m a multiple of 64 in [64, 8192].  Synchronises the stream once;
+ * PTD_ERR_UNSUPPORTED when a pivot is not positive. */
+size_t ptd_chol_inverse_workspace_bytes(int64_t m);
+int ptd_chol_inverse(double* G, int64_t m, double* Wt, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- dense products (layer output, factor construction) ----------------- */
 
 /* C[M,N] = alpha * sum_k A(m,k) * B(k,n) (+ bias[n]),  f32 or bf16 operands,

@@ -35,6 +35,8 @@ SIGNATURES = {
                               c_size_t, ctypes.POINTER(c_int), c_void_p]),
     "ptd_eigh_profiled": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int64, c_void_p,
                                   c_size_t, c_void_p, c_void_p]),
+    "ptd_chol_inverse_workspace_bytes": (c_size_t, [c_int64]),
+    "ptd_chol_inverse": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
     "ptd_tridiagonalize_workspace_bytes": (c_size_t, [c_int64]),
     "ptd_tridiagonalize": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                    c_void_p]),

@@ -128,6 +128,12 @@ int ptd_eigh_profiled(const double* A, int64_t lda, int64_t n, int64_t k, int al
                        static_cast<hipStream_t>(stream));
 }
 
+size_t ptd_chol_inverse_workspace_bytes(int64_t m) { return chol_inverse_workspace_bytes(m); }
+
+int ptd_chol_inverse(double* G, int64_t m, double* Wt, void* ws, size_t ws_bytes, void* stream) {
+  return chol_inverse(G, m, Wt, ws, ws_bytes, static_cast<hipStream_t>(stream));
+}
+
 size_t ptd_tridiagonalize_workspace_bytes(int64_t n) { return tridiag_workspace_bytes(n); }
 
 int ptd_tridiagonalize(const double* A, int64_t lda, int64_t n, double* d, double* e, double* evals, void* ws,

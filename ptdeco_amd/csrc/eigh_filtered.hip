@@ -448,6 +448,124 @@ __device__ __forceinline__ void fs_chol_inv_tile(const double* __restrict__ A, d
   if (bad && tid == 0) atomicExch(fail, 1);
 }
 
+// ---- the same result, hierarchically (round 4): 16 x 16 leaves on ONE wave, everything else on the matrix cores
+// The tile is cut into 4 x 4 blocks of 16 x 16.  Blocked right-looking Cholesky: the leaf forms Linv_bb of the current
+// diagonal block, the panel L_ib = A_ib Linv_bb^T and the trailing update A_ij -= L_ib L_jb^T are 16 x 16 x 16 products
+// (four v_mfma_f64_16x16x4_f64 each).  Then X = L^-1 by block columns, wave j owning column j:
+// X_jj = Linv_jj, X_ij = -Linv_ii sum_{k=j}^{i-1} L_ik X_kj.
+// The leaf keeps the block in the registers of one wave -- lane 4 r + q holds row r, columns q, q + 4, q + 8, q + 12, the
+// full symmetric row as in fs_chol_inv_tile above (A[r][c] until column c is eliminated, X[r][c] afterwards) -- and a
+// column step is: row j's entries of the lane's column class, the pivot and the lane's own entry of column j fetched
+// with cross-lane moves (ds_bpermute: no LDS round trip, no barrier), one reciprocal, four fmas.  64 columns are 64
+// such steps of ~0.1 us instead of 32 barrier-separated two-column steps of ~1.1 us.
+constexpr int LP = 17;          // LDS pitch of a 16 x 16 block
+__device__ __forceinline__ bool fs_leaf16(const double* __restrict__ A, int lda, double* __restrict__ out, int lane) {
+  const int r = lane >> 2, q = lane & 3;
+  double y[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int c = q + 4 * s;
+    y[s] = (c <= r) ? A[r * lda + c] : A[c * lda + r];
+  }
+  bool bad = false;
+  double myd = 1.0;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int jq = j & 3, js = j >> 2;
+    double P[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) P[s] = __shfl(y[s], 4 * j + q);      // row j, this lane's column class
+    const double d = __shfl(y[js], 4 * j + jq);                       // the pivot A[j][j]
+    const double a = __shfl(y[js], (lane & ~3) | jq);                 // this row's entry of column j
+    const bool ok = d > 0.0 && d < INFINITY;
+    const double p = ok ? fs_rcp(d) : 1.0;
+    const double m = (r > j) ? a * p : 0.0;
+    bad = bad || !ok;
+    myd = (r == j && ok) ? d : myd;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) y[s] = fma(-m, P[s], y[s]);
+    if (q == jq) y[js] = (r == j) ? 1.0 : -m;                         // the slot changes hands: X[r][j] = -Lhat[r][j]
+  }
+  const double rs = 1.0 / sqrt(myd);
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int c = q + 4 * s;
+    out[r * LP + c] = (c <= r) ? y[s] * rs : 0.0;
+  }
+  return bad;
+}
+// acc += A B^T / acc += A B for 16 x 16 row-major LDS blocks (one wave); C/D map: col = lane & 15, row = (lane >> 4) + 4 reg
+__device__ __forceinline__ f64x4 fs_blk_abt(const double* __restrict__ A, int lda, const double* __restrict__ B, int ldb,
+                                            int lane, f64x4 acc) {
+  const int l15 = lane & 15, l4 = lane >> 4;
+#pragma unroll
+  for (int kk = 0; kk < 16; kk += 4)
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[l15 * lda + kk + l4], B[l15 * ldb + kk + l4], acc, 0, 0, 0);
+  return acc;
+}
+__device__ __forceinline__ f64x4 fs_blk_ab(const double* __restrict__ A, int lda, const double* __restrict__ B, int ldb,
+                                           int lane, f64x4 acc) {
+  const int l15 = lane & 15, l4 = lane >> 4;
+#pragma unroll
+  for (int kk = 0; kk < 16; kk += 4)
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[l15 * lda + kk + l4], B[(kk + l4) * ldb + l15], acc, 0, 0, 0);
+  return acc;
+}
+// T: the tile in LDS (pitch FQ, lower triangle read, destroyed); Dv: 4 x 16 x LP, Sc: 4 x 16 x LP, Xs: 64 x FQ doubles of
+// LDS; out: L^-1, 64 x 64 row-major in memory (zeros above the diagonal).  256 threads.
+__device__ __forceinline__ void fs_chol_inv_tile2(double* __restrict__ T, double* __restrict__ Dv, double* __restrict__ Sc,
+                                                  double* __restrict__ Xs, double* __restrict__ out,
+                                                  int* __restrict__ fail, int tid) {
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, l4 = lane >> 4;
+  bool bad = false;
+#pragma unroll 1
+  for (int b = 0; b < 4; ++b) {
+    if (w == 0) bad = fs_leaf16(T + (16 * b) * FQ + 16 * b, FQ, Dv + b * 16 * LP, lane) || bad;
+    __syncthreads();
+    if (w < 3 - b) {                                       // panel: L_ib = A_ib Linv_bb^T over A_ib
+      double* Aib = T + 16 * (b + 1 + w) * FQ + 16 * b;
+      const f64x4 acc = fs_blk_abt(Aib, FQ, Dv + b * 16 * LP, LP, lane, f64x4{0.0, 0.0, 0.0, 0.0});
+#pragma unroll
+      for (int q = 0; q < 4; ++q) Aib[(l4 + 4 * q) * FQ + l15] = acc[q];
+    }
+    __syncthreads();
+    const int nt = 3 - b, cnt = nt * (nt + 1) / 2;         // trailing blocks (i, j), b < j <= i; (b+1, b+1) first
+    for (int t = w; t < cnt; t += 4) {
+      int ii = 0, jj = t;
+      while (jj > ii) { jj -= ii + 1; ++ii; }
+      const int i = b + 1 + ii, j = b + 1 + jj;
+      const f64x4 acc = fs_blk_abt(T + 16 * i * FQ + 16 * b, FQ, T + 16 * j * FQ + 16 * b, FQ, lane,
+                                   f64x4{0.0, 0.0, 0.0, 0.0});
+      double* Aij = T + 16 * i * FQ + 16 * j;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) Aij[(l4 + 4 * q) * FQ + l15] -= acc[q];
+    }
+    __syncthreads();
+  }
+  {                                                        // X = L^-1: wave j owns block column j
+    const int j = w;
+    for (int e = lane; e < 256; e += 64) Xs[(16 * j + (e >> 4)) * FQ + 16 * j + (e & 15)] = Dv[j * 16 * LP + (e >> 4) * LP + (e & 15)];
+    double* S = Sc + w * 16 * LP;
+    for (int i = j + 1; i < 4; ++i) {
+      f64x4 s = f64x4{0.0, 0.0, 0.0, 0.0};
+      for (int k = j; k < i; ++k) s = fs_blk_ab(T + 16 * i * FQ + 16 * k, FQ, Xs + 16 * k * FQ + 16 * j, FQ, lane, s);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) S[(l4 + 4 * q) * LP + l15] = s[q];
+      const f64x4 x = fs_blk_ab(Dv + i * 16 * LP, LP, S, LP, lane, f64x4{0.0, 0.0, 0.0, 0.0});
+#pragma unroll
+      for (int q = 0; q < 4; ++q) Xs[(16 * i + l4 + 4 * q) * FQ + 16 * j + l15] = -x[q];
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < FB * FB; e += 256) {
+    const int rr = e >> 6, cc = e & 63;
+    out[e] = ((cc >> 4) <= (rr >> 4)) ? Xs[rr * FQ + cc] : 0.0;
+  }
+  if (bad && tid == 0) atomicExch(fail, 1);
+}
+
 __device__ __forceinline__ void fs_load_tile(double* __restrict__ dst, const double* __restrict__ src, int64_t ld, int tid) {
 #pragma unroll
   for (int p2 = 0; p2 < 8; ++p2) {
@@ -477,12 +595,14 @@ __device__ __forceinline__ void fs_zero_acc(f64x4 (&acc)[2][2]) {
 
 // Linv_0 of the first diagonal tile of G
 __global__ __launch_bounds__(256) void fs_diag0_kernel(const double* __restrict__ G, int m, double* __restrict__ linv,
-                                                       int* __restrict__ fail) {
+                                                       int* __restrict__ fail, int leaf) {
   __shared__ __attribute__((aligned(16))) double T[FB * FQ];
-  __shared__ __attribute__((aligned(16))) double Xs[512];
+  __shared__ __attribute__((aligned(16))) double Xs[FB * FQ];
+  __shared__ __attribute__((aligned(16))) double Dv[8 * 16 * LP];
   for (int e = threadIdx.x; e < FB * FB; e += 256) T[(e >> 6) * FQ + (e & 63)] = G[(int64_t)(e >> 6) * m + (e & 63)];
   __syncthreads();
-  fs_chol_inv_tile(T, Xs, linv, fail, threadIdx.x);
+  if (leaf) fs_chol_inv_tile2(T, Dv, Dv + 4 * 16 * LP, Xs, linv, fail, threadIdx.x);
+  else fs_chol_inv_tile(T, Xs, linv, fail, threadIdx.x);
 }
 
 // W work = identity
@@ -501,7 +621,7 @@ __global__ void fs_identity_kernel(double* __restrict__ W, int m) {
 // column goes to Wout), so the steps need no synchronisation beyond their launch order.
 __global__ __launch_bounds__(256) void fs_sweep_kernel(double* __restrict__ G, int m, double* __restrict__ Ww,
                                                        double* __restrict__ Wout, double* __restrict__ linv,
-                                                       int* __restrict__ fail, int k) {
+                                                       int* __restrict__ fail, int k, int leaf) {
   __shared__ __attribute__((aligned(16))) double Ps[FB * FP];
   __shared__ __attribute__((aligned(16))) double Qs[FB * FP];
   __shared__ __attribute__((aligned(16))) double Ss[FB * FP];
@@ -595,7 +715,8 @@ __global__ __launch_bounds__(256) void fs_sweep_kernel(double* __restrict__ G, i
       for (int q = 0; q < 4; ++q)
         Ps[(wr * 32 + a * 16 + l4 + 4 * q) * FQ + wc * 32 + b * 16 + l15] = upd[a][b][q] - acc[a][b][q];
   __syncthreads();
-  fs_chol_inv_tile(Ps, Ss, linv + (size_t)(k + 1) * FB * FB, fail, tid);
+  if (leaf) fs_chol_inv_tile2(Ps, Qs, Qs + 4 * 16 * LP, Ss, linv + (size_t)(k + 1) * FB * FB, fail, tid);
+  else fs_chol_inv_tile(Ps, Ss, linv + (size_t)(k + 1) * FB * FB, fail, tid);
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -652,6 +773,21 @@ bool tridiag_ql_first_row(int n, double* d, double* e, double* z, double* y) {
   return true;
 }
 
+// G = L L^T (lower tiles of the m x m matrix G, destroyed) and Wt = L^-T (upper triangular) together, one launch per
+// 64-column panel; Hw: m x m work matrix, linv: (m / 64) tiles of 64 x 64, *fail raised on a non-positive pivot
+int chol_sweep(double* G, int m, double* Hw, double* Wt, double* linv, int* fail, int leaf, hipStream_t st) {
+  PTD_CHECK_HIP(hipMemsetAsync(Wt, 0, (size_t)m * m * 8, st));
+  hipLaunchKernelGGL(fs_identity_kernel, dim3(1024), dim3(256), 0, st, Hw, m);
+  hipLaunchKernelGGL(fs_diag0_kernel, dim3(1), dim3(256), 0, st, G, m, linv, fail, leaf);
+  const int nb = m / FB;
+  for (int kk = 0; kk < nb; ++kk) {
+    const int nt = nb - kk - 1;
+    const int wgs = (kk + 1) + (kk + 1) * nt + nt * (nt + 1) / 2;
+    hipLaunchKernelGGL(fs_sweep_kernel, dim3(wgs), dim3(256), 0, st, G, m, Hw, Wt, linv, fail, kk, leaf);
+  }
+  return PTD_OK;
+}
+
 struct FilterPlan {
   int m;
   size_t off_X, off_Y, off_Z, off_H, off_G, off_W, off_linv, off_Yk, off_lam, off_lz, off_ab, off_flags, off_eigh;
@@ -699,6 +835,35 @@ double env_double(const char* name, double dflt) {
 }
 
 }  // namespace
+
+// Diagnostic (ptd_chol_inverse): the Cholesky sweep of the orthonormalisation passes on its own.
+size_t chol_inverse_workspace_bytes(int64_t m) {
+  return align_up((size_t)m * m * 8, 256) + align_up((size_t)(m / FB) * FB * FB * 8, 256) + 256;
+}
+int chol_inverse(double* G, int64_t m, double* Wt, void* ws, size_t ws_bytes, hipStream_t st) {
+  PTD_REQUIRE(G && Wt && ws && m >= FB && m % FB == 0 && m <= 8192, "ptd_chol_inverse: m must be a multiple of 64 in [64, 8192]");
+  if (ws_bytes < chol_inverse_workspace_bytes(m)) {
+    set_error("ptd_chol_inverse: workspace too small");
+    return PTD_ERR_WORKSPACE;
+  }
+  char* base = static_cast<char*>(ws);
+  double* Hw = reinterpret_cast<double*>(base);
+  double* linv = reinterpret_cast<double*>(base + align_up((size_t)m * m * 8, 256));
+  int* fail = reinterpret_cast<int*>(base + align_up((size_t)m * m * 8, 256) + align_up((size_t)(m / FB) * FB * FB * 8, 256));
+  PTD_CHECK_HIP(hipMemsetAsync(fail, 0, 256, st));
+  const int leaf = env_double("PTD_EIGH_FILTER_LEAF", 1.0) != 0.0 ? 1 : 0;
+  int rc = chol_sweep(G, (int)m, Hw, Wt, linv, fail, leaf, st);
+  if (rc != PTD_OK) return rc;
+  PTD_CHECK_LAUNCH("ptd_chol_inverse");
+  int h = 0;
+  PTD_CHECK_HIP(hipMemcpyAsync(&h, fail, sizeof(int), hipMemcpyDeviceToHost, st));
+  PTD_CHECK_HIP(hipStreamSynchronize(st));
+  if (h) {
+    set_error("ptd_chol_inverse: the matrix is not numerically positive definite");
+    return PTD_ERR_UNSUPPORTED;
+  }
+  return PTD_OK;
+}
 
 bool eigh_filtered_applies(int64_t n, int64_t k, bool all_values) {
   const char* e = getenv("PTD_EIGH_FILTERED");
@@ -891,6 +1056,8 @@ int eigh_filtered(const double* A, int64_t lda, int64_t n, int64_t k, double* ev
     return PTD_OK;
   };
   const bool checksum = getenv("PTD_FILTER_CHECKSUM") != nullptr;
+  // diagonal tiles of the Cholesky sweep: 16 x 16 register leaves + matrix-core blocks (default) or the round-3 form
+  const int leaf = env_double("PTD_EIGH_FILTER_LEAF", 1.0) != 0.0 ? 1 : 0;
   auto dump = [&](const char* what, const double* buf, size_t count) {
     if (!checksum) return;
     std::vector<double> hbuf(count);
@@ -911,15 +1078,8 @@ int eigh_filtered(const double* A, int64_t lda, int64_t n, int64_t k, double* ev
     if (r2 != PTD_OK) return r2;
     dump("gram", G, (size_t)m * m);
     if (shifted) hipLaunchKernelGGL(fs_shift_kernel, dim3(1), dim3(1024), 0, st, G, m, shift_rel);
-    PTD_CHECK_HIP(hipMemsetAsync(Wt, 0, (size_t)m * m * 8, st));
-    hipLaunchKernelGGL(fs_identity_kernel, dim3(1024), dim3(256), 0, st, H, m);   // (H is free until Rayleigh-Ritz)
-    hipLaunchKernelGGL(fs_diag0_kernel, dim3(1), dim3(256), 0, st, G, m, linv, fail);
-    const int nb = m / FB;
-    for (int kk = 0; kk < nb; ++kk) {
-      const int nt = nb - kk - 1;
-      const int wgs = (kk + 1) + (kk + 1) * nt + nt * (nt + 1) / 2;
-      hipLaunchKernelGGL(fs_sweep_kernel, dim3(wgs), dim3(256), 0, st, G, m, H, Wt, linv, fail, kk);
-    }
+    r2 = chol_sweep(G, m, H, Wt, linv, fail, leaf, st);                            // (H is free until Rayleigh-Ritz)
+    if (r2 != PTD_OK) return r2;
     dump("W = L^-T", Wt, (size_t)m * m);
     r2 = gemm_f64(X, m, 1, Wt, m, 1, Y, m, n, m, m, 1.0, false, 1, st);
     std::swap(X, Y);

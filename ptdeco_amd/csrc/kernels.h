@@ -61,6 +61,9 @@ size_t eigh_filtered_workspace_bytes(int64_t n);
 int eigh_filtered(const double* A, int64_t lda, int64_t n, int64_t k, double* evals, double* evecs, int64_t ldv,
                   void* ws, size_t ws_bytes, ptd_eigh_stats* stats, hipStream_t st);
 
+size_t chol_inverse_workspace_bytes(int64_t m);
+int chol_inverse(double* G, int64_t m, double* Wt, void* ws, size_t ws_bytes, hipStream_t st);
+
 // eigh_factored.hip
 size_t eigh_factored_workspace_bytes(int64_t n_o, int64_t n_i, int64_t k);
 int eigh_factored(const void* W, int64_t ldw, int w_dtype, int64_t n_o, int64_t n_i, const double* Ex, int64_t ldx,

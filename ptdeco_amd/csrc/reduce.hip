@@ -5,6 +5,7 @@
 //   sym_kl         symmetric-max KL of two logit matrices, one wave per row
 // All accumulate in f64; inputs are f32 or bf16 and are read once, coalesced.
 #include <algorithm>
+#include <atomic>
 
 #include "common.h"
 
@@ -101,11 +102,89 @@ __global__ void colsum_kernel(const TY* __restrict__ Y, int64_t T, int n, int64_
 }
 
 // ----------------------------------------------------------------------- nsr
+// One launch: every block leaves the partial sums of its (column tile, row chunk) in the workspace; the LAST chunk block
+// of a column tile (a ticket) adds the chunks of its channels in index order and leaves the sum of their ratios in
+// blocksum[tile]; the last column tile adds those in index order.  Deterministic, and no second launch or memset in
+// front of an HBM-bound stream of 30 us.  The tickets live in the caller's UNINITIALISED workspace: a word counts
+// arrivals only under this call's 40-bit tag (a host counter); any other content is taken for stale and replaced.
+__device__ __forceinline__ bool nsr_arrive(unsigned long long* word, unsigned long long tag, unsigned expected) {
+  unsigned long long old = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (;;) {
+    const unsigned long long want = ((old >> 24) == tag) ? old + 1 : ((tag << 24) | 1ull);
+    if (__hip_atomic_compare_exchange_strong(word, &old, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_AGENT))
+      return (unsigned)(want & 0xFFFFFFull) == expected;
+  }
+}
+
+// Called by all 256 threads of a block after its partial sums are stored (plain stores).  chans = channels per column
+// tile.  Hand-offs: storing waves drain their stores, barrier, one lane releases at agent scope and arrives; the last
+// arriver acquires at agent scope, barrier, plain loads (MI355X_MICROARCH.md, inter-workgroup visibility).
+__device__ __forceinline__ void nsr_finish(const double* __restrict__ part, int64_t R, int64_t C, int nchunk, int chans,
+                                           double eps, unsigned long long* __restrict__ words, unsigned long long tag,
+                                           double* __restrict__ blocksum, double* __restrict__ out) {
+  __shared__ bool last_s;
+  __shared__ double red[4];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    last_s = nsr_arrive(words + 1 + blockIdx.x, tag, gridDim.y);
+    if (last_s) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  }
+  __syncthreads();
+  if (!last_s) return;
+  const int64_t c_begin = (int64_t)blockIdx.x * chans;
+  const double n = (double)R;
+  double acc = 0.0;
+  for (int i = tid; i < chans; i += 256) {
+    const int64_t c = c_begin + i;
+    if (c >= C) break;
+    double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    for (int k = 0; k < nchunk; ++k) {
+      const double* p = part + (int64_t)k * 3 * C + c;
+      s1 += p[0]; s2 += p[C]; s3 += p[2 * C];
+    }
+    const double var = (s2 - s1 * s1 / n) / (n - 1.0);  // unbiased, like torch.std
+    acc += (s3 / n) / (var + eps);
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) red[w] = acc;
+  __syncthreads();
+  if (tid == 0) {
+    blocksum[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    last_s = nsr_arrive(words, tag, gridDim.x);
+    if (last_s) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  }
+  __syncthreads();
+  if (!last_s) return;
+  double t = 0.0;
+  for (unsigned i = tid; i < gridDim.x; i += 256) t += blocksum[i];
+  t = wave_sum(t);
+  if (lane == 0) red[w] = t;
+  __syncthreads();
+  if (tid == 0) out[0] = ((red[0] + red[1]) + (red[2] + red[3])) / (double)C;
+}
+
 // Threads are laid out as Rt row lanes x Ct columns (Ct = min(C, 256), Rt = 256 / Ct) so that
 // consecutive threads touch consecutive addresses for every C, including C == 1.
 template <typename T>
-__global__ void nsr_partial_kernel(const T* __restrict__ x, const T* __restrict__ y, int64_t R, int64_t C,
-                                   int Ct, int Rt, int64_t rows_per_chunk, double* __restrict__ part) {
+__global__ __launch_bounds__(256) void nsr_partial_kernel(const T* __restrict__ x, const T* __restrict__ y, int64_t R,
+                                                          int64_t C, int Ct, int Rt, int64_t rows_per_chunk,
+                                                          double* __restrict__ part, double eps,
+                                                          unsigned long long* __restrict__ words, unsigned long long tag,
+                                                          double* __restrict__ blocksum, double* __restrict__ out) {
   __shared__ double sm[3][256];
   const int tid = threadIdx.x;
   const int cl = tid % Ct, rl = tid / Ct;
@@ -136,6 +215,7 @@ __global__ void nsr_partial_kernel(const T* __restrict__ x, const T* __restrict_
     double* o = part + (int64_t)blockIdx.y * 3 * C + c;
     o[0] = s1; o[C] = s2; o[2 * C] = s3;
   }
+  nsr_finish(part, R, C, (int)gridDim.y, Ct, eps, words, tag, blocksum, out);
 }
 
 // The same sums with 16-byte loads (C a multiple of V = 16 / sizeof(T), 16-byte aligned operands): a lane owns V
@@ -160,7 +240,10 @@ __device__ __forceinline__ void nsr_unpack<unsigned short, 8>(const uint4& q, do
 template <typename T, int V>
 __global__ __launch_bounds__(256) void nsr_partial_vec_kernel(const T* __restrict__ x, const T* __restrict__ y, int64_t R,
                                                               int64_t C, int64_t rows_per_chunk,
-                                                              double* __restrict__ part) {
+                                                              double* __restrict__ part, double eps,
+                                                              unsigned long long* __restrict__ words,
+                                                              unsigned long long tag, double* __restrict__ blocksum,
+                                                              double* __restrict__ out) {
   __shared__ double sm[3][V][64];   // one quantity at a time: [row lane 1..3][channel of the lane][lane]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int64_t c0 = ((int64_t)blockIdx.x * 64 + lane) * V;
@@ -211,57 +294,7 @@ __global__ __launch_bounds__(256) void nsr_partial_vec_kernel(const T* __restric
       for (int i = 0; i < V; ++i) o[(int64_t)qn * C + i] = ((s[i] + sm[0][i][lane]) + sm[1][i][lane]) + sm[2][i][lane];
     }
   }
-}
-
-// 64 channels x 4 chunk lanes per block: the chunk partials of a channel are added in a fixed order (lane q takes
-// chunks q, q + 4, ..., then lanes 0 .. 3), the block leaves the sum of its channels' ratios in blocksum[blockIdx.x],
-// and the LAST block to finish (ticket counter) adds the block sums in index order and writes the result:
-// deterministic, and one launch instead of three (the old per-channel loop over strided partials took 21 us).
-__global__ __launch_bounds__(256) void nsr_final_kernel(const double* __restrict__ part, int64_t R, int64_t C,
-                                                        int nchunk, double eps, double* __restrict__ blocksum,
-                                                        unsigned int* __restrict__ ticket, double* __restrict__ out) {
-  __shared__ double sm[3][4][64];
-  __shared__ double red[4];
-  __shared__ bool last;
-  const int cl = threadIdx.x & 63, q = threadIdx.x >> 6;
-  const int64_t c = (int64_t)blockIdx.x * 64 + cl;
-  double s1 = 0.0, s2 = 0.0, s3 = 0.0;
-  if (c < C)
-    for (int k = q; k < nchunk; k += 4) {
-      const double* p = part + (int64_t)k * 3 * C + c;
-      s1 += p[0]; s2 += p[C]; s3 += p[2 * C];
-    }
-  sm[0][q][cl] = s1; sm[1][q][cl] = s2; sm[2][q][cl] = s3;
-  __syncthreads();
-  double acc = 0.0;
-  if (q == 0 && c < C) {
-    s1 = (sm[0][0][cl] + sm[0][1][cl]) + (sm[0][2][cl] + sm[0][3][cl]);
-    s2 = (sm[1][0][cl] + sm[1][1][cl]) + (sm[1][2][cl] + sm[1][3][cl]);
-    s3 = (sm[2][0][cl] + sm[2][1][cl]) + (sm[2][2][cl] + sm[2][3][cl]);
-    const double n = (double)R;
-    const double var = (s2 - s1 * s1 / n) / (n - 1.0);  // unbiased, like torch.std
-    acc = (s3 / n) / (var + eps);
-  }
-  if (q == 0) {
-    acc = wave_sum(acc);
-    if (cl == 0) {
-      blocksum[blockIdx.x] = acc;
-      __threadfence();
-      last = atomicAdd(ticket, 1u) == gridDim.x - 1;
-    }
-  }
-  __syncthreads();
-  if (!last) return;
-  __threadfence();
-  double t = 0.0;
-  for (unsigned i = threadIdx.x; i < gridDim.x; i += 256) t += __hip_atomic_load(&blocksum[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  t = wave_sum(t);
-  if (cl == 0) red[q] = t;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    out[0] = ((red[0] + red[1]) + (red[2] + red[3])) / (double)C;
-    *ticket = 0u;   // ready for the next call on this workspace
-  }
+  nsr_finish(part, R, C, (int)gridDim.y, 64 * V, eps, words, tag, blocksum, out);
 }
 
 // -------------------------------------------------------------------- sym_kl
@@ -404,10 +437,13 @@ int colsum_accumulate(const void* y, int64_t T, int64_t n, int64_t ldy, int y_dt
   return PTD_ERR_UNSUPPORTED;
 }
 
+// workspace: partial sums [chunk][3][C], one sum per column tile, the ticket words (one per column tile + one)
+static size_t nsr_tiles_max(int64_t C) { return (size_t)ceil_div(C, 64); }   // (no plan has narrower column tiles)
 size_t nsr_workspace_bytes(int64_t R, int64_t C) {
   // (the dtype is not known here: room for whichever plan has more chunks)
   const int nchunk = std::max(std::max(nsr_plan(R, C).nchunk, nsr_plan_vec(R, C, 4).nchunk), nsr_plan_vec(R, C, 8).nchunk);
-  return align_up((size_t)nchunk * C * 3 * 8, 256) + align_up((size_t)ceil_div(C, 64) * 8, 256) + 256;
+  return align_up((size_t)nchunk * C * 3 * 8, 256) + align_up(nsr_tiles_max(std::max<int64_t>(C, 256)) * 8, 256) +
+         align_up((nsr_tiles_max(std::max<int64_t>(C, 256)) + 1) * 8, 256);
 }
 
 int nsr(const void* x, const void* y, int64_t R, int64_t C, int dtype, double eps, double* out, void* ws,
@@ -418,40 +454,40 @@ int nsr(const void* x, const void* y, int64_t R, int64_t C, int dtype, double ep
     return PTD_ERR_WORKSPACE;
   }
   NsrPlan p = nsr_plan(R, C);
-  double* part = static_cast<double*>(ws);
   const int vec = dtype == PTD_F32 ? 4 : (dtype == PTD_BF16 ? 8 : 0);
   const bool aligned = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
-  if (vec && C % vec == 0 && C >= 64 && aligned) {
-    p = nsr_plan_vec(R, C, vec);
-    dim3 vgrid((unsigned)p.coltiles, (unsigned)p.nchunk);
-    if (dtype == PTD_F32)
-      hipLaunchKernelGGL((nsr_partial_vec_kernel<float, 4>), vgrid, dim3(256), 0, st, (const float*)x, (const float*)y, R,
-                         C, p.rows_per_chunk, part);
-    else
-      hipLaunchKernelGGL((nsr_partial_vec_kernel<unsigned short, 8>), vgrid, dim3(256), 0, st, (const unsigned short*)x,
-                         (const unsigned short*)y, R, C, p.rows_per_chunk, part);
-  } else {
-    dim3 grid((unsigned)p.coltiles, (unsigned)p.nchunk);
-    if (dtype == PTD_F32)
-      hipLaunchKernelGGL((nsr_partial_kernel<float>), grid, dim3(256), 0, st, (const float*)x, (const float*)y, R, C,
-                         p.Ct, p.Rt, p.rows_per_chunk, part);
-    else if (dtype == PTD_BF16)
-      hipLaunchKernelGGL((nsr_partial_kernel<unsigned short>), grid, dim3(256), 0, st, (const unsigned short*)x,
-                         (const unsigned short*)y, R, C, p.Ct, p.Rt, p.rows_per_chunk, part);
-    else if (dtype == PTD_F64)
-      hipLaunchKernelGGL((nsr_partial_kernel<double>), grid, dim3(256), 0, st, (const double*)x, (const double*)y, R,
-                         C, p.Ct, p.Rt, p.rows_per_chunk, part);
-    else {
-      set_error("ptd_nsr: unsupported dtype");
-      return PTD_ERR_UNSUPPORTED;
-    }
-  }
+  const bool use_vec = vec && C % vec == 0 && C >= 64 && aligned;
+  if (use_vec) p = nsr_plan_vec(R, C, vec);
+  PTD_REQUIRE(p.nchunk < (1 << 24) && p.coltiles < (1 << 24), "ptd_nsr: shape too large");
+  double* part = static_cast<double*>(ws);
+  const size_t tiles = nsr_tiles_max(std::max<int64_t>(C, 256));
   double* blocksum = part + align_up((size_t)p.nchunk * C * 3 * 8, 256) / 8;
-  const unsigned fblocks = (unsigned)ceil_div(C, 64);
-  unsigned int* ticket = reinterpret_cast<unsigned int*>(blocksum + align_up((size_t)fblocks * 8, 256) / 8);
-  // (the ticket is zeroed here: the workspace is the caller's and arrives uninitialised; the kernel resets it too)
-  PTD_CHECK_HIP(hipMemsetAsync(ticket, 0, 4, st));
-  hipLaunchKernelGGL(nsr_final_kernel, dim3(fblocks), dim3(256), 0, st, part, R, C, p.nchunk, eps, blocksum, ticket, out);
+  unsigned long long* words = reinterpret_cast<unsigned long long*>(blocksum + align_up(tiles * 8, 256) / 8);
+  // this call's tag: unique within the process (40 bits of a counter scrambled so that stale tags of a reused
+  // workspace -- or any other content -- do not match)
+  static std::atomic<unsigned long long> calls{0x9E3779B97F4Aull};
+  const unsigned long long tag = (calls.fetch_add(0x9E3779B97F4A7C15ull) >> 11) & 0xFFFFFFFFFFull;
+  dim3 grid((unsigned)p.coltiles, (unsigned)p.nchunk);
+  if (use_vec) {
+    if (dtype == PTD_F32)
+      hipLaunchKernelGGL((nsr_partial_vec_kernel<float, 4>), grid, dim3(256), 0, st, (const float*)x, (const float*)y, R,
+                         C, p.rows_per_chunk, part, eps, words, tag, blocksum, out);
+    else
+      hipLaunchKernelGGL((nsr_partial_vec_kernel<unsigned short, 8>), grid, dim3(256), 0, st, (const unsigned short*)x,
+                         (const unsigned short*)y, R, C, p.rows_per_chunk, part, eps, words, tag, blocksum, out);
+  } else if (dtype == PTD_F32) {
+    hipLaunchKernelGGL((nsr_partial_kernel<float>), grid, dim3(256), 0, st, (const float*)x, (const float*)y, R, C,
+                       p.Ct, p.Rt, p.rows_per_chunk, part, eps, words, tag, blocksum, out);
+  } else if (dtype == PTD_BF16) {
+    hipLaunchKernelGGL((nsr_partial_kernel<unsigned short>), grid, dim3(256), 0, st, (const unsigned short*)x,
+                       (const unsigned short*)y, R, C, p.Ct, p.Rt, p.rows_per_chunk, part, eps, words, tag, blocksum, out);
+  } else if (dtype == PTD_F64) {
+    hipLaunchKernelGGL((nsr_partial_kernel<double>), grid, dim3(256), 0, st, (const double*)x, (const double*)y, R,
+                       C, p.Ct, p.Rt, p.rows_per_chunk, part, eps, words, tag, blocksum, out);
+  } else {
+    set_error("ptd_nsr: unsupported dtype");
+    return PTD_ERR_UNSUPPORTED;
+  }
   PTD_CHECK_LAUNCH("nsr");
   return PTD_OK;
 }

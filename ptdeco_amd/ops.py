@@ -146,6 +146,25 @@ def eigh_factored(W: torch.Tensor, Ex: torch.Tensor, k: int) -> Optional[tuple[t
     return w, u
 
 
+def chol_inverse(G: torch.Tensor) -> Optional[torch.Tensor]:
+    """Diagnostic: W = L^-T (upper triangular, f64) with G = L L^T for a symmetric positive definite [m, m] f64
+    matrix, m a multiple of 64 (the Cholesky sweep of the filtered eigensolver's orthonormalisation passes).
+    None when a pivot is not positive.  G is not modified (the kernel works on a copy)."""
+    _dev(G)
+    assert G.dtype == torch.float64 and G.dim() == 2 and G.shape[0] == G.shape[1]
+    m = G.shape[0]
+    lib = _hip.load()
+    work = G.contiguous().clone()
+    W = torch.empty((m, m), dtype=torch.float64, device=G.device)
+    ws = torch.empty(lib.ptd_chol_inverse_workspace_bytes(m), dtype=torch.uint8, device=G.device)
+    with torch.cuda.device(G.device):
+        rc = lib.ptd_chol_inverse(work.data_ptr(), m, W.data_ptr(), ws.data_ptr(), ws.numel(), _stream(G))
+    if rc == -2:  # PTD_ERR_UNSUPPORTED
+        return None
+    _hip.check(rc, "ptd_chol_inverse")
+    return W
+
+
 def tridiagonalize(A: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """Diagnostic: (d, e, eigenvalues of T) of the Householder tridiagonalisation of symmetric f64 A."""
     _dev(A)

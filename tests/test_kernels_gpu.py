@@ -422,6 +422,35 @@ def test_eigh_topk_contract_over_spectrum_families(ops, monkeypatch, family):
     assert (v.T @ v - torch.eye(k, dtype=torch.float64)).abs().max().item() <= 1e-9, (family, prof["method"])
 
 
+@pytest.mark.parametrize("leaf", ["1", "0"])
+@pytest.mark.parametrize("m,cond", [(64, 1e2), (128, 1e6), (320, 1e3), (1280, 1e8)])
+def test_chol_inverse_sweep_matches_lapack(ops, monkeypatch, m, cond, leaf):
+    """The Cholesky sweep of the filtered eigensolver's orthonormalisation passes (ptd_chol_inverse): W = L^-T for
+    G = X^T X with a prescribed cond(X), both forms of the diagonal-tile factorisation (16 x 16 register leaves +
+    matrix-core blocks; the round-3 64-column form) against LAPACK on the host: W upper triangular, W^T G W = I and
+    W = inv(chol(G))^T to rounding times cond(G)."""
+    monkeypatch.setenv("PTD_EIGH_FILTER_LEAF", leaf)
+    g = torch.Generator().manual_seed(m)
+    q1, _ = torch.linalg.qr(torch.randn(3 * m, m, generator=g, dtype=torch.float64))
+    q2, _ = torch.linalg.qr(torch.randn(m, m, generator=g, dtype=torch.float64))
+    x = (q1 * torch.logspace(0, -math.log10(cond), m, dtype=torch.float64)) @ q2.T      # singular values 1 .. 1 / cond
+    gram = x.T @ x
+    gram = 0.5 * (gram + gram.T)
+    w = ops.chol_inverse(gram.to(DEV))
+    assert w is not None
+    w = w.cpu()
+    assert torch.equal(torch.tril(w, -1), torch.zeros_like(w))
+    ref = torch.linalg.inv(torch.linalg.cholesky(gram)).T
+    eps = 2.3e-16
+    assert (w - ref).norm().item() <= 50 * eps * cond**2 * ref.norm().item() + 1e-13 * ref.norm().item()
+    orth = w.T @ gram @ w - torch.eye(m, dtype=torch.float64)
+    assert orth.abs().max().item() <= 200 * eps * cond**2 + 1e-12
+    # a matrix that is not positive definite is refused, not factored
+    bad = gram.clone()
+    bad[m // 2, m // 2] = -1.0
+    assert ops.chol_inverse(bad.to(DEV)) is None
+
+
 def test_eigh_filtered_route_retries_when_the_first_attempt_falls_short(ops, monkeypatch):
     """The degree of the filter comes from a density ESTIMATE; when it was too optimistic the residual check after the
     Rayleigh-Ritz step says so and the route spends one more round sized by the rate it measured (at most twice) instead
@@ -883,7 +912,7 @@ def test_nsr_golden(ops):
 
 @pytest.mark.parametrize("shape,chan", [((4096, 4096), 4096), ((4096, 4096), 1), ((7, 300), 300), ((5, 10), 10),
                                         ((33, 1000), 1000), ((2, 3, 50), 50), ((130, 516), 516), ((3, 70, 1288), 1288),
-                                        ((1, 64), 64), ((2, 41, 32064), 32064)])
+                                        ((2, 64), 64), ((2, 41, 32064), 32064)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_nsr_random(ops, shape, chan, dtype):
     y = (_rand(shape, 1) * 2 + 0.3).to(dtype)
