@@ -3,29 +3,33 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-ONE workload family at every N (weak scaling, one layer per GPU): dwain.decompose_in_place of a stack of N
-nn.Linear(4096, 4096, bias=False), f32 model, f64 decomposition, B=4 x S=1024 tokens per batch,
-precomputing_covariance_num_splits=1, D = max(4, N) calibration steps, M = 2 metric steps, 7 candidate
-ranks (2048 .. 32), CE loss over the 4096 outputs, identity finetune_fn.  N = 1 is BASELINE.json
-configs[1] (SURVEY.md 8d "C2"); N > 1 is configs[3] in small: calibration steps dealt to the ranks, the N
-covariance sums reduced to their owners (packed lower triangles over RCCL), the N eigendecompositions owned
-one per rank, eigenvectors broadcast, (candidate, metric batch) pairs dealt to the ranks.  One "step" =
-one full decompose_in_place call on a fresh copy of the stack, every input already resident in HBM.
-`python bench.py --gpus N` starts its own N ranks when no launcher did (children, before any GPU call).
+ONE fixed workload at every N (strong scaling): dwain.decompose_in_place of a stack of 8 nn.Linear(4096, 4096,
+bias=False) -- BASELINE.json configs[1]'s layer, eight of them chained so that the same work can be dealt to 1 / 2 /
+4 / 8 GPUs the way configs[3] shards a Llama stack -- f32 model, f64 decomposition, B=4 x S=1024 tokens per batch,
+precomputing_covariance_num_splits=1, D = 8 calibration steps, M = 2 metric steps, 6 evaluated candidate ranks per
+layer (1024 .. 32; 2048 drops no parameters and is skipped), CE loss over the 4096 outputs, identity finetune_fn.
+With N ranks: calibration steps dealt to the ranks, the 8 covariance sums reduced to their owners (packed lower
+triangles over RCCL, started asynchronously and completed right before each owner's eigensolve), the 8
+eigendecompositions owned round-robin, eigenvectors broadcast, (candidate, metric batch) pairs dealt to the ranks.
+One "step" = one full decompose_in_place call on a fresh copy of the stack, every input already resident in HBM;
+`value` = 8 layers x K / time, "scaling": "strong".  `python bench.py --gpus N` starts its own N ranks when no launcher
+did (children, before any GPU call).
 
-The same line carries `bf16_stack`: the same family timed once more with a bf16 model (SURVEY 8d's
-throughput configuration).  The method's own whole-model forwards (2 N GEMMs per (candidate, batch) pair,
-SURVEY 3.5) grow with N; in bf16 they stay small next to the sharded part, so that curve shows the sharding.
-
-Prints ONE JSON line (rank 0) with the driver's contract fields plus
+The same line carries
+  c2_single_layer BASELINE configs[1] / SURVEY C2 itself (ONE nn.Linear(4096, 4096), D = 4, M = 2), timed with the same
+                 K / W protocol at N = 1: the workload the roofline / eigh / phases / cpu_baseline blocks describe
+  bf16_stack     the fixed stack timed once more with a bf16 model (SURVEY 8d's throughput configuration)
+  weak_family    N > 1 only: the round-3 family (a stack of N layers on N GPUs), kept for comparison
   roofline       the dominant kernel of the eigensolver against its bound: frac on SURVEY 8d's
-                 algorithmic bytes, hw_frac on the bytes the counters saw, solver_frac for the
-                 whole ptd_eigh call against the reduction's bound
+                 algorithmic work, solver_frac for the whole ptd_eigh call
   phases_ms      device-time split of one step: A accumulate, B eigh, C factors, D metrics, comm
   kernels        per-kernel device time / rates from HIP events
-  cpu_baseline   the CPU oracle (restatement of the reference, torch-CPU/MKL) on the same
+  cpu_baseline   the CPU oracle (restatement of the reference, torch-CPU/MKL) on the C2
                  workload on this box's physical host cores, rank 0, N = 1 only
   decomposed_fwd rank-r two-GEMM forward vs dense 4096x4096, bf16 (BASELINE configs[4])
+  c4_shapes      dwain on one layer of each Llama-3-8B shape (BASELINE configs[3]), f32 and bf16, three timed
+                 steps each, with the eigensolver route and its roofline block
+  c4_block       one full-width Llama-3-8B block (7 layers) end to end, f32 and bf16
 Counter-derived fields (traffic, MFMA utilisation) are quoted from committed rocprofv3 PMC
 summaries; each carries the hash of the kernel source it was measured on and is marked
 "stale": true when the source has changed since.
@@ -49,6 +53,7 @@ sys.path.insert(0, ROOT)
 N_FEAT = 4096
 BATCH, SEQ = 4, 1024
 D_STEPS, M_STEPS = 4, 2
+STACK_LAYERS, STACK_D_STEPS = 8, 8   # the fixed stack of the scaling family
 PEAK_F64_MFMA = 78.6e12   # MI355X dense f64 matrix peak
 PEAK_F32_MFMA = 157.3e12  # /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_BF16_MFMA = 2.5e15
@@ -237,6 +242,202 @@ def decomposed_forward_lines(device):
     return out
 
 
+# ---------------------------------------------------------------------------------------------- BASELINE configs[3]
+D_MODEL, D_KV, D_FF = 4096, 1024, 14336
+
+
+class LlamaBlock(torch.nn.Module):
+    """SURVEY 8d C4: RMSNorm -> {q, k, v} -> (q + repeat4(k) + repeat4(v)) -> o -> residual;
+    RMSNorm -> down(silu(gate) * up) -> residual, at the Llama-3-8B widths."""
+
+    def __init__(self):
+        super().__init__()
+        mk = lambda i, o: torch.nn.Linear(i, o, bias=False)  # noqa: E731
+        self.q, self.k, self.v, self.o = mk(D_MODEL, D_MODEL), mk(D_MODEL, D_KV), mk(D_MODEL, D_KV), mk(D_MODEL, D_MODEL)
+        self.gate, self.up, self.down = mk(D_MODEL, D_FF), mk(D_MODEL, D_FF), mk(D_FF, D_MODEL)
+
+    @staticmethod
+    def norm(x):
+        return x * torch.rsqrt(x.float().pow(2).mean(-1, keepdim=True) + 1e-6).to(x.dtype)
+
+    def forward(self, x):
+        h = self.norm(x)
+        rep = D_MODEL // D_KV
+        x = x + self.o(self.q(h) + self.k(h).repeat(1, 1, rep) + self.v(h).repeat(1, 1, rep))
+        h = self.norm(x)
+        return x + self.down(torch.nn.functional.silu(self.gate(h)) * self.up(h))
+
+
+class LlamaStack(torch.nn.Module):
+    def __init__(self, blocks: int):
+        super().__init__()
+        self.blocks = torch.nn.ModuleList(LlamaBlock() for _ in range(blocks))
+        self.head = torch.nn.Linear(D_MODEL, D_MODEL, bias=False)
+
+    def forward(self, b):
+        x = b["x"]
+        for blk in self.blocks:
+            x = blk(x)
+        return self.head(x)
+
+
+class OneLinear(torch.nn.Module):
+    def __init__(self, n_in, n_out):
+        super().__init__()
+        self.lin = torch.nn.Linear(n_in, n_out, bias=False)
+
+    def forward(self, d):
+        return self.lin(d["x"])
+
+
+def seq_ce(batch, logits):
+    return torch.nn.functional.cross_entropy(logits.float().reshape(-1, logits.shape[-1]), batch["targets"].reshape(-1),
+                                             reduction="none")
+
+
+ROUTES = {0: "jacobi", 1: "tridiagonal (direct)", 2: "two-stage tridiagonal", 3: "filtered subspace iteration"}
+
+
+def eigh_route_block(p):
+    """Roofline-style block of one profiled eigendecomposition (ops.EIGH_PROFILE entry), per route."""
+    n, k, t = p["n"], p["k"], p["total_ms"] * 1e-3
+    algo = 4.0 / 3.0 * n**3 + 2.0 * n * n * k
+    out = {"route": ROUTES[p["method"]], "n": n, "k": k, "ms": p["total_ms"],
+           "algorithmic_tflops": algo / t / 1e12, "frac_of_f64_mfma_peak_on_algorithmic_flops": algo / t / PEAK_F64_MFMA}
+    if p["method"] == 3:
+        m_blk, nprod = p["launches"][2], p["launches"][1]
+        out.update({"bound": "mfma", "products_with_C": nprod, "subspace": m_blk,
+                    "solver_frac": nprod * 2.0 * n * n * m_blk / t / PEAK_F64_MFMA,
+                    "phases_ms": {"lanczos": p["ms"][0], "filter_rounds": p["ms"][1], "rayleigh_ritz_eigh": p["ms"][2],
+                                  "ritz_products_residuals": p["ms"][3]}})
+    elif p["method"] == 1:
+        all_bytes = sum(8.0 * (n - j - 1) * (n - j - 2) for j in range(n - 1))
+        red_ms = p["ms"][0] + p["ms"][1]
+        out.update({"bound": "hbm", "solver_frac": all_bytes / (red_ms * 1e-3) / PEAK_HBM,
+                    "phases_ms": {"symv_launches": p["ms"][0], "other_reduction": p["ms"][1],
+                                  "eigenpairs_backtransform": p["ms"][3]}})
+        if p["launches"][0] > 0 and p["ms"][0] > 0:
+            out["symv"] = {"launches": p["launches"][0], "gbps_algorithmic": p["work"][0] / (p["ms"][0] * 1e-3) / 1e9,
+                           "frac_of_hbm_peak": p["work"][0] / (p["ms"][0] * 1e-3) / PEAK_HBM}
+    return out
+
+
+def llama_shape_lines(device, steps=3):
+    """BASELINE configs[3] per shape: dwain on ONE layer of each Llama-3-8B linear shape, [1, 2048, n_in] tokens per
+    step, D = 8, M = 2, f64 decomposition; f32 and bf16 model; `steps` timed steps each (+ one warm-up and one profiled)."""
+    import ptdeco_amd
+    from ptdeco_amd import ops
+
+    out = {"tokens_per_step": 2048, "D": 8, "M": 2, "timed_steps": steps}
+    shapes = (("q_o", 4096, 4096, 64), ("k_v", 4096, 1024, 64), ("gate_up", 4096, 14336, 64), ("down", 14336, 4096, 32))
+    for dt in (torch.float32, torch.bfloat16):
+        block, total = {}, 0.0
+        for name, n_in, n_out, count in shapes:
+            g = torch.Generator(device=device).manual_seed(1)
+            m0 = OneLinear(n_in, n_out).to(device)
+            with torch.no_grad():
+                m0.lin.weight.copy_(torch.randn(n_out, n_in, generator=g, device=device) / n_in**0.5)
+            m0.to(dt)
+            scale = torch.logspace(0, -2, n_in, device=device)
+            xs = [(torch.randn(1, 2048, n_in, generator=g, device=device) * scale).to(dt) for _ in range(10)]
+            with torch.no_grad():
+                bt = [{"x": x, "targets": m0({"x": x}).argmax(-1)} for x in xs]
+            kw = dict(num_data_steps=8, num_metric_steps=2, nsr_final_threshold=1.0, decompose_in_float64=True)
+
+            def step():
+                m = copy.deepcopy(m0)
+                return ptdeco_amd.dwain.decompose_in_place(module=m, device=device, data_iterator=itertools.cycle(bt),
+                                                           loss_fn=seq_ce, metric_iterator=itertools.cycle(bt[8:]),
+                                                           finetune_fn=lambda mm, d, n: mm, **kw)
+            step()
+            torch.cuda.synchronize()
+            marks = []
+            for _ in range(steps):
+                t0 = time.perf_counter()
+                step()
+                torch.cuda.synchronize()
+                marks.append((time.perf_counter() - t0) * 1e3)
+            ops.EIGH_PROFILE = []
+            step()
+            torch.cuda.synchronize()
+            prof, ops.EIGH_PROFILE = ops.EIGH_PROFILE, None
+            med = sorted(marks)[len(marks) // 2]
+            line = {"n_in": n_in, "n_out": n_out, "ms_per_layer": med, "step_ms": [round(v, 3) for v in marks],
+                    "layers_per_s": 1e3 / med}
+            if prof:
+                line["eigh"] = eigh_route_block(prof[0])
+            else:
+                line["eigh"] = {"route": "factored: W Ex W^T through an n_in-sized problem (ptd_eigh_factored); its inner "
+                                         "eigensolver is the direct route at n = n_in, k = n_in / 2"}
+            block[name] = line
+            total += med * 1e-3 * count
+            del m0, xs, bt
+        block["extrapolated_224_layers_s"] = total
+        block["extrapolated_layers_per_s_1gpu"] = 224 / total
+        block["note"] = "kernel-side per-shape figure (one layer alone); the end-to-end figure is c4_block / tools/c4_stack.py"
+        out["f32" if dt == torch.float32 else "bf16"] = block
+    return out
+
+
+C4_BLOCK_KW = dict(num_data_steps=8, num_metric_steps=2, nsr_final_threshold=1.0, min_rank=32, trade_off_factor=20.0,
+                   reduction_factor=0.5, max_accepted_ppl_diff=0.4, decompose_in_float64=True,
+                   blacklisted_module_names=["head"], precomputing_covariance_num_splits=1)
+
+
+def llama_block_lines(device):
+    """BASELINE configs[3] in small, end to end: dwain on ONE full-width Llama-3-8B block (q, k, v, o, gate, up, down at
+    4096 / 1024 / 14336 + the blacklisted head), [1, 2048, 4096] batches, D = 8, M = 2, precompute pass (one split: the
+    seven eigendecompositions run as concurrent chains), thresholds under which layers ARE replaced, so that the
+    replace -> next-layer-sees-the-changed-model path runs (dwain.py:779-787)."""
+    import ptdeco_amd
+    from ptdeco_amd import _engine as eng
+
+    out = {}
+    for dt in (torch.float32, torch.bfloat16):
+        g = torch.Generator(device=device).manual_seed(0)
+        with torch.device(device):
+            model0 = LlamaStack(1)
+        with torch.no_grad():
+            for prm in model0.parameters():
+                prm.copy_(torch.randn(prm.shape, generator=g, device=device) / prm.shape[1] ** 0.5)
+        model0.to(dt)
+        scale = torch.logspace(0, -2, D_MODEL, device=device)
+        xs = [(torch.randn(1, 2048, D_MODEL, generator=g, device=device) * scale).to(dt) for _ in range(12)]
+        with torch.no_grad():
+            bt = [{"x": x, "targets": model0({"x": x}).argmax(-1)} for x in xs]
+
+        def step(trace=None):
+            m = copy.deepcopy(model0)
+            return ptdeco_amd.dwain.decompose_in_place(module=m, device=device, data_iterator=itertools.cycle(bt),
+                                                       loss_fn=seq_ce, metric_iterator=itertools.cycle(bt[8:]),
+                                                       finetune_fn=lambda mm, d, n: mm, trace=trace, **C4_BLOCK_KW)
+        step()
+        torch.cuda.synchronize()
+        marks = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            step()
+            torch.cuda.synchronize()
+            marks.append((time.perf_counter() - t0) * 1e3)
+        eng.PHASES = eng.PhaseTimer()
+        trace = []
+        t0 = time.perf_counter()
+        cfg = step(trace)
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) * 1e3
+        ph, eng.PHASES = eng.PHASES.totals_ms(), None
+        ph["other_host_and_gaps"] = max(0.0, wall - sum(ph.values()))
+        best = min(marks)
+        out["f32" if dt == torch.float32 else "bf16"] = {
+            "layers": 7, "ms_per_block": best, "step_ms": [round(v, 1) for v in marks], "layers_per_s": 7e3 / best,
+            "phases_ms": {k: round(v, 1) for k, v in ph.items()}, "candidates_evaluated": len(trace),
+            "replaced": {k: v["__meta__"]["proportion"] for k, v in cfg.items()}}
+        del model0, xs, bt
+    out["workload"] = ("dwain.decompose_in_place, ONE Llama-3-8B-width block (7 layers) + blacklisted head, [1, 2048, 4096] "
+                       "batches, D = 8, M = 2, precompute pass (1 split), trade_off_factor 20, max_accepted_ppl_diff 0.4")
+    return out
+
+
 def pmc_traffic(n):
     """roofline.traffic: HBM-side bytes per SYMV launch from the committed rocprofv3 PMC passes
     (profiles/pmc_symv_rNN.json, made by tools/pmc_summary.py from separate FETCH_SIZE / WRITE_SIZE
@@ -305,6 +506,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip kernel / forward / cpu side measurements")
     ap.add_argument("--no-bf16-stack", action="store_true", help="skip the second (bf16 model) timed run")
+    ap.add_argument("--no-weak-family", action="store_true", help="N > 1: skip the round-3 family (N layers on N GPUs)")
+    ap.add_argument("--no-c4", action="store_true", help="skip the Llama-3-8B shape / block extras")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -332,22 +535,22 @@ def main():
     import ptdeco_amd
     from ptdeco_amd import ops
 
-    # ONE workload family at every N (weak scaling, one layer per GPU): a stack of N nn.Linear(4096, 4096), dwain
-    # with the precompute pass (1 split), D = max(4, N) calibration steps.  N = 1 is BASELINE configs[1] (C2).
-    n_layers = world
-    d_steps = max(D_STEPS, world)
-    model32, data32, metric32 = make_workload(n_layers, device, d_steps, 7 * M_STEPS)
-    model32.to(device)
-    data32, metric32 = with_targets(model32, data32, device), with_targets(model32, metric32, device)
-    kw = dict(DWAIN_KW, num_data_steps=d_steps)
+    # ONE fixed workload at every N (strong scaling): a stack of 8 nn.Linear(4096, 4096), dwain with the precompute
+    # pass (1 split), D = 8 calibration steps.  Beside it at N = 1: BASELINE configs[1] (C2, one layer, D = 4) itself.
+    def build(n_layers, d_steps):
+        model, data, metric = make_workload(n_layers, device, d_steps, 7 * M_STEPS)
+        model.to(device)
+        return (model, with_targets(model, data, device), with_targets(model, metric, device),
+                dict(DWAIN_KW, num_data_steps=d_steps))
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def family(model_dtype):
-        """(one_step, loss) of the workload with the model and its activations in `model_dtype`."""
+    def family(work, model_dtype):
+        """one_step of the workload `work` with the model and its activations in `model_dtype`."""
+        model32, data32, metric32, kw = work
         if model_dtype == torch.float32:
             model0, data, metric, loss = model32, data32, metric32, ce_loss
         else:
@@ -364,10 +567,9 @@ def main():
                 precomputing_covariance_num_splits=1, **kw)
         return one_step
 
-    step_marks = []   # per timed() call: host-side duration of each step (ms), for the spread
-
     def timed(one_step):
-        """W untimed steps, then exactly K steps between barrier + synchronize; max over ranks."""
+        """W untimed steps, then exactly K steps between barrier + synchronize; max over ranks.
+        Returns (seconds, last config, per-step host durations in ms)."""
         cfg = None
         for _ in range(args.warmup):
             cfg = one_step()
@@ -379,49 +581,76 @@ def main():
             marks.append(time.perf_counter())     # (no synchronisation added: a step ends on the host's last decision)
         barrier()
         dt = time.perf_counter() - t0
-        step_marks.append([round((b - a) * 1e3, 3) for a, b in zip([t0] + marks[:-1], marks)])
         if world > 1:
             tmax = torch.tensor([dt], dtype=torch.float64, device=device)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax.item())
-        return dt, cfg
+        return dt, cfg, [round((b - a) * 1e3, 3) for a, b in zip([t0] + marks[:-1], marks)]
 
-    one_step = family(torch.float32)
-    dt, cfg = timed(one_step)
-    what = ("dwain decompose_in_place, stack of %d x nn.Linear(4096,4096) %s (one layer per GPU; N = 1 is BASELINE "
-            "configs[1]), precompute pass (1 split), T=4x1024 tokens/batch, D=%d, M=2, 7 candidate ranks, f64 "
-            "covariance+eigh%s")
-    comm = "; packed-triangle reduce to the layer owners + eigenvector broadcast over RCCL" if world > 1 else ""
+    def kept(cfg):
+        return {k: v["__meta__"]["proportion"] for k, v in cfg.items()}
+
+    stack = build(STACK_LAYERS, STACK_D_STEPS)
+    stack_step = family(stack, torch.float32)
+    dt, cfg, marks = timed(stack_step)
+    what = ("dwain decompose_in_place of a FIXED stack of %d x nn.Linear(4096,4096) %s at every N (BASELINE configs[1]'s "
+            "layer, eight of them chained so that the same work is dealt to 1/2/4/8 GPUs as configs[3] shards its "
+            "stack), precompute pass (1 split), T=4x1024 tokens/batch, D=%d, M=2, 6 evaluated candidate ranks per "
+            "layer, f64 covariance+eigh%s")
+    comm = ("; calibration steps and (candidate, batch) pairs dealt to the ranks, packed-triangle covariance sums "
+            "reduced to the layer owners + eigenvector broadcast over RCCL") if world > 1 else ""
 
     result = {
         "metric": "layers decomposed/sec (incl. covariance+SVD)",
-        "value": n_layers * args.steps / dt,
+        "value": STACK_LAYERS * args.steps / dt,
         "unit": "layers/s",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3,
-        "step_ms": step_marks[0],
+        "step_ms": marks,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong",
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": what % (n_layers, "f32", d_steps, comm),
+        "config": {"workload": what % (STACK_LAYERS, "f32", STACK_D_STEPS, comm),
                    "model_dtype": "float32",
-                   "layers_per_step": n_layers, "parallelism": f"dp{world}" if world > 1 else "single",
-                   "ranks_kept": {k: v["__meta__"]["proportion"] for k, v in cfg.items()}},
+                   "layers_per_step": STACK_LAYERS, "parallelism": f"dp{world}" if world > 1 else "single",
+                   "ranks_kept": kept(cfg)},
     }
+    c2 = None
+    if world == 1:
+        # BASELINE configs[1] / SURVEY C2 exactly: ONE layer, D = 4 -- the workload of the roofline / eigh / phases /
+        # cpu_baseline blocks below, under the same K / W protocol
+        c2 = build(1, D_STEPS)
+        dt2, cfg2, marks2 = timed(family(c2, torch.float32))
+        result["c2_single_layer"] = {
+            "value": args.steps / dt2, "unit": "layers/s", "ms_per_step": dt2 / args.steps * 1e3, "step_ms": marks2,
+            "workload": "BASELINE configs[1]: dwain decompose_in_place of ONE nn.Linear(4096,4096) f32, precompute pass "
+                        "(1 split), T=4x1024 tokens/batch, D=4, M=2, 6 evaluated candidate ranks, f64 covariance+eigh",
+            "ranks_kept": kept(cfg2)}
     if not args.no_bf16_stack:
-        # the same family with a bf16 model ("model fp32 for parity, bf16 for throughput"), same K / W and
-        # the same barrier protocol: at N > 1 the method's own whole-model forwards (2 N GEMMs per (candidate, batch)
-        # pair) stay small next to the sharded part, so this curve shows the sharding; `value` above stays the f32 one
-        dt16, cfg16 = timed(family(torch.bfloat16))
-        result["bf16_stack"] = {"value": n_layers * args.steps / dt16, "unit": "layers/s",
-                                "ms_per_step": dt16 / args.steps * 1e3, "model_dtype": "bfloat16",
-                                "workload": what % (n_layers, "bf16", d_steps, comm),
-                                "ranks_kept": {k: v["__meta__"]["proportion"] for k, v in cfg16.items()}}
+        # the fixed stack with a bf16 model ("model fp32 for parity, bf16 for throughput"), same K / W and
+        # the same barrier protocol: the method's own whole-model forwards (16 GEMMs per (candidate, batch) pair) are
+        # small next to the covariance + eigensolver part here
+        dt16, cfg16, marks16 = timed(family(stack, torch.bfloat16))
+        result["bf16_stack"] = {"value": STACK_LAYERS * args.steps / dt16, "unit": "layers/s",
+                                "ms_per_step": dt16 / args.steps * 1e3, "step_ms": marks16, "model_dtype": "bfloat16",
+                                "workload": what % (STACK_LAYERS, "bf16", STACK_D_STEPS, comm), "ranks_kept": kept(cfg16)}
+    if world > 1 and not args.no_weak_family:
+        # the round-3 family (a stack of N layers on N GPUs, D = max(4, N)): its own forwards grow as N^2 per step
+        weak = build(world, max(D_STEPS, world))
+        dtw, cfgw, marksw = timed(family(weak, torch.float32))
+        result["weak_family"] = {"value": world * args.steps / dtw, "unit": "layers/s", "scaling": "weak",
+                                 "ms_per_step": dtw / args.steps * 1e3, "step_ms": marksw,
+                                 "workload": "stack of %d x nn.Linear(4096,4096) f32, one layer per GPU, D=%d, M=2"
+                                             % (world, max(D_STEPS, world)), "ranks_kept": kept(cfgw)}
+        del weak
 
+    # the step the phase / eigensolver blocks describe: C2 at N = 1, the fixed stack otherwise
+    one_step = family(c2, torch.float32) if c2 is not None else stack_step
+    described = "c2_single_layer" if c2 is not None else "the fixed stack (`value`)"
     prof = []
     if not args.no_extras:
         # two extra, untimed steps.  (1) phase spans of the step on the device timeline (A accumulate, B
@@ -438,6 +667,7 @@ def main():
         ph["other_host_and_gaps"] = max(0.0, wall_p - sum(ph.values()))
         ph["step_wall_ms"] = wall_p
         result["phases_ms"] = {k: round(v, 3) for k, v in ph.items()}
+        result["phases_ms"]["of"] = described
         ops.EIGH_PROFILE = []
         one_step()
         barrier()
@@ -580,6 +810,9 @@ def main():
                 result["eigh"]["gpu_library_eigh_note"] = f"torch.linalg.eigh failed: {exc}"
         result["kernels"] = {**result.get("kernels", {}), **kernel_lines(device)}
         result["decomposed_fwd"] = decomposed_forward_lines(device)
+        if world == 1 and not args.no_c4:
+            result["c4_shapes"] = llama_shape_lines(device)
+            result["c4_block"] = llama_block_lines(device)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline()
 

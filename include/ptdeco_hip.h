@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define PTD_ABI_VERSION 1
+#define PTD_ABI_VERSION 2   /* 2: ptd_nsr workspaces are initialised once (ptd_nsr_workspace_init); ptd_chol_inverse */
 
 typedef enum { PTD_F32 = 0, PTD_F64 = 1, PTD_BF16 = 2 } ptd_dtype;
 
@@ -224,7 +224,11 @@ int ptd_lowrank_forward_nchw(const void* x, int64_t batch, int64_t n_i, int64_t 
 /* out[0] (f64) = mean_c( mean_r (x-y)^2 / (var_r(y) + eps) ), x,y viewed as [R, C],
  * var unbiased.  Replaces calc_per_channel_noise_to_signal_ratio (losses.py:10-22)
  * for non_channel_dim = all leading dims. */
+/* (ABI 2) The workspace carries the arrival counters of the one-launch reduction: initialise it ONCE with
+ * ptd_nsr_workspace_init (any size >= the query for the shapes it will serve); ptd_nsr leaves it initialised, so the
+ * same workspace serves any number of stream-ordered calls.  Calls that may overlap need a workspace each. */
 size_t ptd_nsr_workspace_bytes(int64_t R, int64_t C);
+int ptd_nsr_workspace_init(void* ws, size_t ws_bytes, void* stream);
 int ptd_nsr(const void* x, const void* y, int64_t R, int64_t C, int dtype, double eps, double* out,
             void* ws, size_t ws_bytes, void* stream);
 

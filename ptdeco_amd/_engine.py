@@ -272,6 +272,27 @@ class Covariance:
             if self.ey is not None:
                 self.ey.copy_(flat[1:].to(self.ey.dtype))
 
+    def reduce_to_owner_async(self, shard, index: int):
+        """reduce_to_owner without waiting: the exchange is started (every rank, same order) and the returned
+        function completes it -- the owner calls it right before eigenvectors(), on the thread / stream that runs
+        the eigensolver, so the sums of the other layers of the pass travel while it works."""
+        with phase("comm"):
+            done_e = shard.reduce_lower_to_owner_async(self.E, index)
+        small = [torch.tensor([float(self.steps)], dtype=torch.float64, device=self.E.device)]
+        if self.ey is not None:
+            small.append(self.ey.double())
+        flat = torch.cat(small)
+        done_s = shard.reduce_small_to_owner_async(flat, index)
+
+        def complete() -> None:
+            done_e()
+            done_s()
+            if shard.owns(index):
+                self.steps = int(round(flat[0].item()))
+                if self.ey is not None:
+                    self.ey.copy_(flat[1:].to(self.ey.dtype))
+        return complete
+
     def eigenvectors(self, damp_factor: float, use_mean: bool = False, top_k: Optional[int] = None) -> torch.Tensor:
         """Finalise (divide by steps, optional mean removal, Tikhonov damping) and return the
         eigenvectors in columns, ascending, f64 (dwain.py:155-163, falor.py:192-208).  With
@@ -488,14 +509,16 @@ class SharedInputPool:
                 out.append(m.moment)
         return out
 
-    def reduce(self, shard) -> None:
+    def reduce(self, shard) -> list:
         """Sum the partial statistics over the ranks: shared moments everywhere (their layers have different
-        owners), an unshared layer's statistics on its owner only (member i of the pass is owned by rank i % G)."""
+        owners), an unshared layer's statistics on its owner only (member i of the pass is owned by rank i % G).
+        The per-layer sums are STARTED here, in member order on every rank, and completed by the functions returned
+        (one per member, None where there is nothing to wait for): the owner of member i calls its function right
+        before the eigensolve, so layer i + 1's sum is on the wire while layer i is being decomposed."""
         for mom in self.moments():
             mom.all_reduce(shard)
-        for i, m in enumerate(self.members):
-            if m.moment is None:
-                m.cov.reduce_to_owner(shard, i)
+        return [m.cov.reduce_to_owner_async(shard, i) if m.moment is None else None
+                for i, m in enumerate(self.members)]
 
     def finalize(self) -> None:
         """Shared Ex matrices, formed once on the caller's stream before the (concurrent) eigendecompositions."""

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libptdeco_hip.so")
 
 F32, F64, BF16 = 0, 1, 2
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # name -> (restype, argtypes); must list every symbol include/ptdeco_hip.h declares
 SIGNATURES = {
@@ -54,6 +54,7 @@ SIGNATURES = {
     "ptd_lowrank_forward_nchw": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p,
                                          c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "ptd_nsr_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    "ptd_nsr_workspace_init": (c_int, [c_void_p, c_size_t, c_void_p]),
     "ptd_nsr": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_double, c_void_p, c_void_p, c_size_t,
                         c_void_p]),
     "ptd_sym_kl_workspace_bytes": (c_size_t, [c_int64]),

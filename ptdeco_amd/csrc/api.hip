@@ -241,6 +241,10 @@ int ptd_lowrank_forward_nchw(const void* x, int64_t batch, int64_t n_i, int64_t 
 
 size_t ptd_nsr_workspace_bytes(int64_t R, int64_t C) { return nsr_workspace_bytes(R, C); }
 
+int ptd_nsr_workspace_init(void* ws, size_t ws_bytes, void* stream) {
+  return nsr_workspace_init(ws, ws_bytes, static_cast<hipStream_t>(stream));
+}
+
 int ptd_nsr(const void* x, const void* y, int64_t R, int64_t C, int dtype, double eps, double* out, void* ws,
             size_t ws_bytes, void* stream) {
   return nsr(x, y, R, C, dtype, eps, out, ws, ws_bytes, static_cast<hipStream_t>(stream));

@@ -76,6 +76,7 @@ int cov_finalize(const void* E, int64_t ldE, int E_dtype, const void* ey, int ey
 int colsum_accumulate(const void* y, int64_t T, int64_t n, int64_t ldy, int y_dtype, void* ey, int ey_dtype,
                       double scale, hipStream_t st);
 size_t nsr_workspace_bytes(int64_t R, int64_t C);
+int nsr_workspace_init(void* ws, size_t ws_bytes, hipStream_t st);
 int nsr(const void* x, const void* y, int64_t R, int64_t C, int dtype, double eps, double* out, void* ws,
         size_t ws_bytes, hipStream_t st);
 size_t sym_kl_workspace_bytes(int64_t B);

@@ -5,7 +5,7 @@
 //   sym_kl         symmetric-max KL of two logit matrices, one wave per row
 // All accumulate in f64; inputs are f32 or bf16 and are read once, coalesced.
 #include <algorithm>
-#include <atomic>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -105,23 +105,28 @@ __global__ void colsum_kernel(const TY* __restrict__ Y, int64_t T, int n, int64_
 // One launch: every block leaves the partial sums of its (column tile, row chunk) in the workspace; the LAST chunk block
 // of a column tile (a ticket) adds the chunks of its channels in index order and leaves the sum of their ratios in
 // blocksum[tile]; the last column tile adds those in index order.  Deterministic, and no second launch or memset in
-// front of an HBM-bound stream of 30 us.  The tickets live in the caller's UNINITIALISED workspace: a word counts
-// arrivals only under this call's 40-bit tag (a host counter); any other content is taken for stale and replaced.
-__device__ __forceinline__ bool nsr_arrive(unsigned long long* word, unsigned long long tag, unsigned expected) {
-  unsigned long long old = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  for (;;) {
-    const unsigned long long want = ((old >> 24) == tag) ? old + 1 : ((tag << 24) | 1ull);
-    if (__hip_atomic_compare_exchange_strong(word, &old, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                             __HIP_MEMORY_SCOPE_AGENT))
-      return (unsigned)(want & 0xFFFFFFull) == expected;
-  }
+// front of an HBM-bound stream of 25 us.  The tickets are plain counters at the head of the workspace: zero on entry
+// (ptd_nsr_workspace_init, once per workspace) and zero again on return (the last arriver resets its counter).
+// (A form that needed no initialisation -- words validated by a per-call tag and claimed with compare-and-swap -- cost
+// 0.1 to 0.6 ms: every failed swap of the 16 to 128 blocks that finish a tile together is another round trip.)
+__device__ __forceinline__ bool nsr_arrive(unsigned int* ticket, unsigned expected) {
+  const unsigned old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (old + 1 != expected) return false;
+  __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next call
+  return true;
 }
 
-// Called by all 256 threads of a block after its partial sums are stored (plain stores).  chans = channels per column
-// tile.  Hand-offs: storing waves drain their stores, barrier, one lane releases at agent scope and arrives; the last
-// arriver acquires at agent scope, barrier, plain loads (MI355X_MICROARCH.md, inter-workgroup visibility).
+// Called by all 256 threads of a block after its partial sums are stored.  chans = channels per column tile.
+// Hand-offs (MI355X_MICROARCH.md, inter-workgroup visibility): every handed-off value is stored WRITE-THROUGH (agent-
+// scope relaxed atomic store = `global_store ... sc1`), the storing waves drain their stores, barrier, one lane arrives;
+// the last arriver acquires at agent scope (invalidates its CU's L1), barrier, plain loads.  An agent-scope RELEASE
+// (`buffer_wbl2`) per block instead of the write-through stores made the kernel 8 x slower: 128 L2 write-backs per XCD,
+// one behind the other, 0.25 ms for a 0.03 ms stream.
+__device__ __forceinline__ void nsr_store(double* p, double v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ void nsr_finish(const double* __restrict__ part, int64_t R, int64_t C, int nchunk, int chans,
-                                           double eps, unsigned long long* __restrict__ words, unsigned long long tag,
+                                           double eps, unsigned int* __restrict__ tickets,
                                            double* __restrict__ blocksum, double* __restrict__ out) {
   __shared__ bool last_s;
   __shared__ double red[4];
@@ -129,9 +134,7 @@ __device__ __forceinline__ void nsr_finish(const double* __restrict__ part, int6
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    last_s = nsr_arrive(words + 1 + blockIdx.x, tag, gridDim.y);
+    last_s = nsr_arrive(tickets + 1 + blockIdx.x, gridDim.y);
     if (last_s) {
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -146,9 +149,20 @@ __device__ __forceinline__ void nsr_finish(const double* __restrict__ part, int6
     const int64_t c = c_begin + i;
     if (c >= C) break;
     double s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    for (int k = 0; k < nchunk; ++k) {
-      const double* p = part + (int64_t)k * 3 * C + c;
-      s1 += p[0]; s2 += p[C]; s3 += p[2 * C];
+    // (sixteen chunks requested per round: one chunk per round trip made this loop the longest part of the kernel --
+    // the partial sums were stored write-through and come back from the memory side, ~2 us a round under load)
+    constexpr int KU = 16;
+    for (int k0 = 0; k0 < nchunk; k0 += KU) {
+      double a1[KU], a2[KU], a3[KU];
+#pragma unroll
+      for (int u = 0; u < KU; ++u) {
+        const bool ok = k0 + u < nchunk;
+        const double* p = part + (int64_t)(ok ? k0 + u : k0) * 3 * C + c;
+        a1[u] = ok ? p[0] : 0.0; a2[u] = ok ? p[C] : 0.0; a3[u] = ok ? p[2 * C] : 0.0;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < KU; ++u) { s1 += a1[u]; s2 += a2[u]; s3 += a3[u]; }
     }
     const double var = (s2 - s1 * s1 / n) / (n - 1.0);  // unbiased, like torch.std
     acc += (s3 / n) / (var + eps);
@@ -157,11 +171,9 @@ __device__ __forceinline__ void nsr_finish(const double* __restrict__ part, int6
   if (lane == 0) red[w] = acc;
   __syncthreads();
   if (tid == 0) {
-    blocksum[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    nsr_store(&blocksum[blockIdx.x], (red[0] + red[1]) + (red[2] + red[3]));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    last_s = nsr_arrive(words, tag, gridDim.x);
+    last_s = nsr_arrive(tickets, gridDim.x);
     if (last_s) {
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -183,7 +195,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void nsr_partial_kernel(const T* __restrict__ x, const T* __restrict__ y, int64_t R,
                                                           int64_t C, int Ct, int Rt, int64_t rows_per_chunk,
                                                           double* __restrict__ part, double eps,
-                                                          unsigned long long* __restrict__ words, unsigned long long tag,
+                                                          unsigned int* __restrict__ tickets,
                                                           double* __restrict__ blocksum, double* __restrict__ out) {
   __shared__ double sm[3][256];
   const int tid = threadIdx.x;
@@ -213,14 +225,14 @@ __global__ __launch_bounds__(256) void nsr_partial_kernel(const T* __restrict__ 
     }
     // partials as [chunk][3][C]: the final pass reads them coalesced
     double* o = part + (int64_t)blockIdx.y * 3 * C + c;
-    o[0] = s1; o[C] = s2; o[2 * C] = s3;
+    nsr_store(o, s1); nsr_store(o + C, s2); nsr_store(o + 2 * C, s3);
   }
-  nsr_finish(part, R, C, (int)gridDim.y, Ct, eps, words, tag, blocksum, out);
+  nsr_finish(part, R, C, (int)gridDim.y, Ct, eps, tickets, blocksum, out);
 }
 
 // The same sums with 16-byte loads (C a multiple of V = 16 / sizeof(T), 16-byte aligned operands): a lane owns V
-// consecutive channels, a wave 64 V of them, the four waves of a block are four row lanes; four rows of x and of y are
-// requested per trip (eight 16-byte loads in flight per lane) before anything is consumed.  HBM-bound: the one-element-
+// consecutive channels, a wave 64 V of them, the four waves of a block are four row lanes; U = 8 rows of x and of y are
+// requested per trip (sixteen 16-byte loads in flight per lane) before anything is consumed.  HBM-bound: the one-element-
 // per-lane form above keeps too few bytes in flight per CU (C2 logits: 3.4 TB/s).
 template <typename T, int V>
 __device__ __forceinline__ void nsr_unpack(const uint4& q, double (&v)[V]);
@@ -241,9 +253,9 @@ template <typename T, int V>
 __global__ __launch_bounds__(256) void nsr_partial_vec_kernel(const T* __restrict__ x, const T* __restrict__ y, int64_t R,
                                                               int64_t C, int64_t rows_per_chunk,
                                                               double* __restrict__ part, double eps,
-                                                              unsigned long long* __restrict__ words,
-                                                              unsigned long long tag, double* __restrict__ blocksum,
-                                                              double* __restrict__ out) {
+                                                              unsigned int* __restrict__ tickets,
+                                                              double* __restrict__ blocksum, double* __restrict__ out) {
+  constexpr int U = 32 / V;   // rows per trip: 8 (f32), 4 (bf16: eight channels a lane, twice the accumulators)
   __shared__ double sm[3][V][64];   // one quantity at a time: [row lane 1..3][channel of the lane][lane]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int64_t c0 = ((int64_t)blockIdx.x * 64 + lane) * V;
@@ -255,17 +267,19 @@ __global__ __launch_bounds__(256) void nsr_partial_vec_kernel(const T* __restric
   for (int i = 0; i < V; ++i) s1[i] = s2[i] = s3[i] = pv[i] = 0.0;
   if (active) {
     nsr_unpack<T, V>(*reinterpret_cast<const uint4*>(y + c0), pv);   // first row: the pivot of the variance sums
-    for (int64_t r = r0 + w; r < r1; r += 16) {
-      uint4 qy[4], qx[4];
+    // full trips: U rows of y and of x requested before anything is consumed, no branch in between (with a guard per
+    // row inside the trip the compiler sank every load into its guarded block: one load in flight per lane)
+    int64_t r = r0 + w;
+    for (; r + 4 * (U - 1) < r1; r += 4 * U) {
+      uint4 qy[U], qx[U];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int64_t rr = min(r + 4 * u, r1 - 1);                   // (clamped rows are loaded and not counted)
-        qy[u] = *reinterpret_cast<const uint4*>(y + rr * C + c0);
-        qx[u] = *reinterpret_cast<const uint4*>(x + rr * C + c0);
+      for (int u = 0; u < U; ++u) {
+        qy[u] = *reinterpret_cast<const uint4*>(y + (r + 4 * u) * C + c0);
+        qx[u] = *reinterpret_cast<const uint4*>(x + (r + 4 * u) * C + c0);
       }
+      __builtin_amdgcn_sched_barrier(0);   // (the scheduler otherwise pairs each load with its use to save registers)
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if (r + 4 * u >= r1) break;
+      for (int u = 0; u < U; ++u) {
         double yv[V], xv[V];
         nsr_unpack<T, V>(qy[u], yv);
         nsr_unpack<T, V>(qx[u], xv);
@@ -276,6 +290,18 @@ __global__ __launch_bounds__(256) void nsr_partial_vec_kernel(const T* __restric
           s2[i] = fma(dy, dy, s2[i]);
           s3[i] = fma(dx, dx, s3[i]);
         }
+      }
+    }
+    for (; r < r1; r += 4) {                                         // the rows of a last, partial trip
+      double yv[V], xv[V];
+      nsr_unpack<T, V>(*reinterpret_cast<const uint4*>(y + r * C + c0), yv);
+      nsr_unpack<T, V>(*reinterpret_cast<const uint4*>(x + r * C + c0), xv);
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        const double dy = yv[i] - pv[i], dx = xv[i] - yv[i];
+        s1[i] += dy;
+        s2[i] = fma(dy, dy, s2[i]);
+        s3[i] = fma(dx, dx, s3[i]);
       }
     }
   }
@@ -291,10 +317,11 @@ __global__ __launch_bounds__(256) void nsr_partial_vec_kernel(const T* __restric
     __syncthreads();
     if (w == 0 && active) {
 #pragma unroll
-      for (int i = 0; i < V; ++i) o[(int64_t)qn * C + i] = ((s[i] + sm[0][i][lane]) + sm[1][i][lane]) + sm[2][i][lane];
+      for (int i = 0; i < V; ++i)
+        nsr_store(o + (int64_t)qn * C + i, ((s[i] + sm[0][i][lane]) + sm[1][i][lane]) + sm[2][i][lane]);
     }
   }
-  nsr_finish(part, R, C, (int)gridDim.y, 64 * V, eps, words, tag, blocksum, out);
+  nsr_finish(part, R, C, (int)gridDim.y, 64 * V, eps, tickets, blocksum, out);
 }
 
 // -------------------------------------------------------------------- sym_kl
@@ -356,13 +383,15 @@ struct NsrPlan {
 };
 
 // the 16-byte form: `vec` channels per lane, 64 lanes per column tile, four row lanes; chunks of at least 32 rows, about
-// 1024 blocks (the partial sums are 24 C bytes per chunk: more chunks would add their traffic to the stream)
+// 512 blocks (the partial sums are 24 C bytes per chunk and the last block of a column tile adds them: more chunks
+// lengthen that tail)
 NsrPlan nsr_plan_vec(int64_t R, int64_t C, int vec) {
   NsrPlan p{};
   p.Ct = 64 * vec;
   p.Rt = 4;
   p.coltiles = (int)ceil_div(C, p.Ct);
-  const int64_t want = std::max<int64_t>(1, 1024 / p.coltiles);
+  static const int blocks = [] { const char* e = getenv("PTD_NSR_BLOCKS"); return e ? std::max(1, atoi(e)) : 512; }();
+  const int64_t want = std::max<int64_t>(1, blocks / p.coltiles);
   p.nchunk = (int)std::max<int64_t>(1, std::min<int64_t>(want, ceil_div(R, 32)));
   p.rows_per_chunk = ceil_div(R, p.nchunk);
   p.nchunk = (int)ceil_div(R, p.rows_per_chunk);
@@ -437,13 +466,22 @@ int colsum_accumulate(const void* y, int64_t T, int64_t n, int64_t ldy, int y_dt
   return PTD_ERR_UNSUPPORTED;
 }
 
-// workspace: partial sums [chunk][3][C], one sum per column tile, the ticket words (one per column tile + one)
-static size_t nsr_tiles_max(int64_t C) { return (size_t)ceil_div(C, 64); }   // (no plan has narrower column tiles)
+// workspace: [tickets: one per column tile + one][one sum per column tile][partial sums [chunk][3][C]]
+static size_t nsr_tiles_max(int64_t C) { return (size_t)ceil_div(std::max<int64_t>(C, 256), 64); }   // (no plan has narrower tiles)
+// (a FIXED ticket area at the head of the workspace: a workspace serves calls of different shapes, and what one call
+// uses for partial sums must never be where another looks for zeroed counters)
+constexpr size_t NSR_TICKETS = 16384;
+static size_t nsr_ticket_bytes(int64_t) { return NSR_TICKETS * 4; }
 size_t nsr_workspace_bytes(int64_t R, int64_t C) {
   // (the dtype is not known here: room for whichever plan has more chunks)
   const int nchunk = std::max(std::max(nsr_plan(R, C).nchunk, nsr_plan_vec(R, C, 4).nchunk), nsr_plan_vec(R, C, 8).nchunk);
-  return align_up((size_t)nchunk * C * 3 * 8, 256) + align_up(nsr_tiles_max(std::max<int64_t>(C, 256)) * 8, 256) +
-         align_up((nsr_tiles_max(std::max<int64_t>(C, 256)) + 1) * 8, 256);
+  return nsr_ticket_bytes(C) + align_up(nsr_tiles_max(C) * 8, 256) + align_up((size_t)nchunk * C * 3 * 8, 256);
+}
+
+int nsr_workspace_init(void* ws, size_t ws_bytes, hipStream_t st) {
+  PTD_REQUIRE(ws && ws_bytes > 0, "ptd_nsr_workspace_init: bad argument");
+  PTD_CHECK_HIP(hipMemsetAsync(ws, 0, ws_bytes, st));
+  return PTD_OK;
 }
 
 int nsr(const void* x, const void* y, int64_t R, int64_t C, int dtype, double eps, double* out, void* ws,
@@ -458,32 +496,28 @@ int nsr(const void* x, const void* y, int64_t R, int64_t C, int dtype, double ep
   const bool aligned = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
   const bool use_vec = vec && C % vec == 0 && C >= 64 && aligned;
   if (use_vec) p = nsr_plan_vec(R, C, vec);
-  PTD_REQUIRE(p.nchunk < (1 << 24) && p.coltiles < (1 << 24), "ptd_nsr: shape too large");
-  double* part = static_cast<double*>(ws);
-  const size_t tiles = nsr_tiles_max(std::max<int64_t>(C, 256));
-  double* blocksum = part + align_up((size_t)p.nchunk * C * 3 * 8, 256) / 8;
-  unsigned long long* words = reinterpret_cast<unsigned long long*>(blocksum + align_up(tiles * 8, 256) / 8);
-  // this call's tag: unique within the process (40 bits of a counter scrambled so that stale tags of a reused
-  // workspace -- or any other content -- do not match)
-  static std::atomic<unsigned long long> calls{0x9E3779B97F4Aull};
-  const unsigned long long tag = (calls.fetch_add(0x9E3779B97F4A7C15ull) >> 11) & 0xFFFFFFFFFFull;
+  PTD_REQUIRE((size_t)p.coltiles + 1 <= NSR_TICKETS, "ptd_nsr: more than %zu column tiles", NSR_TICKETS - 1);
+  char* base = static_cast<char*>(ws);
+  unsigned int* tickets = reinterpret_cast<unsigned int*>(base);
+  double* blocksum = reinterpret_cast<double*>(base + nsr_ticket_bytes(C));
+  double* part = reinterpret_cast<double*>(base + nsr_ticket_bytes(C) + align_up(nsr_tiles_max(C) * 8, 256));
   dim3 grid((unsigned)p.coltiles, (unsigned)p.nchunk);
   if (use_vec) {
     if (dtype == PTD_F32)
       hipLaunchKernelGGL((nsr_partial_vec_kernel<float, 4>), grid, dim3(256), 0, st, (const float*)x, (const float*)y, R,
-                         C, p.rows_per_chunk, part, eps, words, tag, blocksum, out);
+                         C, p.rows_per_chunk, part, eps, tickets, blocksum, out);
     else
       hipLaunchKernelGGL((nsr_partial_vec_kernel<unsigned short, 8>), grid, dim3(256), 0, st, (const unsigned short*)x,
-                         (const unsigned short*)y, R, C, p.rows_per_chunk, part, eps, words, tag, blocksum, out);
+                         (const unsigned short*)y, R, C, p.rows_per_chunk, part, eps, tickets, blocksum, out);
   } else if (dtype == PTD_F32) {
     hipLaunchKernelGGL((nsr_partial_kernel<float>), grid, dim3(256), 0, st, (const float*)x, (const float*)y, R, C,
-                       p.Ct, p.Rt, p.rows_per_chunk, part, eps, words, tag, blocksum, out);
+                       p.Ct, p.Rt, p.rows_per_chunk, part, eps, tickets, blocksum, out);
   } else if (dtype == PTD_BF16) {
     hipLaunchKernelGGL((nsr_partial_kernel<unsigned short>), grid, dim3(256), 0, st, (const unsigned short*)x,
-                       (const unsigned short*)y, R, C, p.Ct, p.Rt, p.rows_per_chunk, part, eps, words, tag, blocksum, out);
+                       (const unsigned short*)y, R, C, p.Ct, p.Rt, p.rows_per_chunk, part, eps, tickets, blocksum, out);
   } else if (dtype == PTD_F64) {
     hipLaunchKernelGGL((nsr_partial_kernel<double>), grid, dim3(256), 0, st, (const double*)x, (const double*)y, R,
-                       C, p.Ct, p.Rt, p.rows_per_chunk, part, eps, words, tag, blocksum, out);
+                       C, p.Ct, p.Rt, p.rows_per_chunk, part, eps, tickets, blocksum, out);
   } else {
     set_error("ptd_nsr: unsupported dtype");
     return PTD_ERR_UNSUPPORTED;

@@ -138,15 +138,28 @@ def _precompute_covariance_matrix_decompositions(*, module, submodule_names, num
         logger.info(f"Sharing one input second moment between {group}")
     logger.info("Computing eigenvectors ...")
     u_dict: dict[str, torch.Tensor] = {}
+    pending = [None] * len(stand_ins)
     if shard.active:
         with eng.phase("comm"):
-            pool.reduce(shard)
+            pending = pool.reduce(shard)   # per-layer sums started (same order on every rank), completed below
     pool.finalize()
     # eigendecompositions of a split are owned round-robin (non-owners receive u later); the ones
-    # this rank owns are independent and run concurrently on separate streams
+    # this rank owns are independent and run concurrently on separate streams; each first completes the
+    # exchange of ITS layer's covariance sum -- the sums of the later layers travel meanwhile
     owned = [i for i in range(len(stand_ins)) if shard.owns(i)]
+
+    def job(i):
+        def run():
+            if pending[i] is not None:
+                pending[i]()
+            return stand_ins[i].get_eigenvectors()
+        return run
+
     with eng.phase("B_eigh"):
-        got = eng.run_concurrently([stand_ins[i].get_eigenvectors for i in owned], device)
+        got = eng.run_concurrently([job(i) for i in owned], device)
+    for i, done in enumerate(pending):     # the sums this rank only contributed to: their buffers may go now
+        if done is not None and not shard.owns(i):
+            done()
     for name in submodule_names:
         u_dict[name] = None
     for i, u in zip(owned, got):

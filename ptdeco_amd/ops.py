@@ -268,6 +268,29 @@ def lowrank_forward_nchw(x: torch.Tensor, A: torch.Tensor, B: torch.Tensor, bias
     return y
 
 
+# ptd_nsr workspaces: initialised once (ptd_nsr_workspace_init) and reused -- the kernel leaves its arrival counters
+# zeroed.  One per (device, stream): calls on one stream are ordered, calls on different streams may overlap.
+_NSR_WS: dict = {}
+
+
+def _nsr_workspace(device: torch.device, nbytes: int) -> torch.Tensor:
+    key = (device.index if device.index is not None else torch.cuda.current_device(), _stream_of(device))
+    ws = _NSR_WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        with torch.cuda.device(device):
+            _hip.check(_hip.load().ptd_nsr_workspace_init(ws.data_ptr(), ws.numel(), _stream_of(device)),
+                       "ptd_nsr_workspace_init")
+        if len(_NSR_WS) > 64:   # (streams come and go: do not keep every workspace ever made)
+            _NSR_WS.clear()
+        _NSR_WS[key] = ws
+    return ws
+
+
+def _stream_of(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
 def nsr(x: torch.Tensor, y: torch.Tensor, channels: int, eps: float = 1e-3) -> torch.Tensor:
     """Scalar (f64, on device): mean over the `channels` trailing-dim channels of
     mean((x-y)^2) / (var(y) + eps), x and y viewed as [-1, channels]."""
@@ -278,7 +301,7 @@ def nsr(x: torch.Tensor, y: torch.Tensor, channels: int, eps: float = 1e-3) -> t
     R = x.numel() // C
     lib = _hip.load()
     out = torch.empty(1, dtype=torch.float64, device=x.device)
-    ws = torch.empty(lib.ptd_nsr_workspace_bytes(R, C), dtype=torch.uint8, device=x.device)
+    ws = _nsr_workspace(x.device, lib.ptd_nsr_workspace_bytes(R, C))
     with torch.cuda.device(x.device):
         rc = lib.ptd_nsr(x.data_ptr(), y.data_ptr(), R, C, _code(x), float(eps), out.data_ptr(), ws.data_ptr(),
                          ws.numel(), _stream(x))

@@ -91,6 +91,31 @@ class Shard:
         if self.owns(index):
             unpack_lower(packed, E)
 
+    def reduce_lower_to_owner_async(self, E: torch.Tensor, index: int):
+        """The same sum, started without waiting for it (``async_op``): the collective runs on the communicator's own
+        stream while this rank goes on issuing work -- the owner of layer l starts its eigensolve as soon as l's sum
+        has arrived, the sums of l + 1, l + 2, ... (other owners) travel meanwhile.  Returns the function that
+        completes the exchange on the calling thread's current stream (the owner's E is final after it); every rank
+        must start the collectives of a pass in the same order."""
+        import torch.distributed as dist
+
+        packed = pack_lower(E)
+        work = dist.reduce(packed, dst=self._global_rank(self.owner(index)), op=dist.ReduceOp.SUM, group=self.group,
+                           async_op=True)
+
+        def complete() -> None:
+            work.wait()
+            if self.owns(index):
+                unpack_lower(packed, E)
+        return complete
+
+    def reduce_small_to_owner_async(self, t: torch.Tensor, index: int):
+        import torch.distributed as dist
+
+        work = dist.reduce(t, dst=self._global_rank(self.owner(index)), op=dist.ReduceOp.SUM, group=self.group,
+                           async_op=True)
+        return work.wait
+
     def all_reduce_lower(self, E: torch.Tensor) -> None:
         """Sum of the lower triangles on every rank (a statistic several owners need)."""
         import torch.distributed as dist
