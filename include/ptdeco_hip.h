@@ -107,13 +107,19 @@ int ptd_eigh(const double* A, int64_t lda, int64_t n, double* evals, double* eve
  * candidate rank it evaluates (dwain.py:407-421, 424-426), so most of the inverse iterations and of
  * the back-transformation are skipped, and a dense cluster at the low end of the spectrum no
  * longer forces the Jacobi fallback.
- * With all_values == 0, n >= 2048 (a multiple of 128) and 3 k <= n the eigenpairs come from a
+ * With all_values == 0, n >= 2048 (a multiple of 128) and 7 k <= 2 n the eigenpairs come from a
  * Chebyshev-filtered subspace iteration on the f64 matrix cores (only evals[n - k .. n) are set then,
  * NaN below; every returned pair has passed a residual check |A v - lambda v| <= 1e-10 |lambda_max|,
  * eigenvector signs: largest entry positive); where that route does not apply -- a flat spectrum, a
  * breakdown -- the direct reduction answers with the same contract.  A is read only. */
 int ptd_eigh_topk(const double* A, int64_t lda, int64_t n, int64_t k, int all_values, double* evals,
                   double* evecs, int64_t ldv, void* ws, size_t ws_bytes, int* sweeps_out, void* stream);
+
+/* The solver ptd_eigh_topk would try FIRST for this request: 3 = filtered subspace iteration (chip-filling f64
+ * products: concurrent chains gain nothing), 1 = direct tridiagonal reduction (a latency-bound chain of short
+ * launches: independent matrices overlap well on separate streams), 0 = Jacobi.  A host-side query; the filtered
+ * route may still decline at run time (flat spectrum) and hand over to the direct one. */
+int ptd_eigh_route(int64_t n, int64_t k, int all_values);
 
 /* Top-k eigenpairs of C = W Ex W^T without forming C, for a layer that widens its input
  * (n_o > n_i; Llama gate / up: 4096 -> 14336): W [n_o, n_i] (f32, bf16 or f64, ld ldw),
@@ -143,7 +149,7 @@ int ptd_eigh_factored(const void* W, int64_t ldw, int w_dtype, int64_t n_o, int6
  *                            back-transformation Q1 Q2 Y}; work = {4/3 n^3 flop, 6 n^2 b flop, 0,
  *                            4 n^2 k flop}; launches[3] = microseconds of the Q2 part of the
  *                            back-transformation
- *   method 3 (filtered subspace iteration, the route of ptd_eigh_topk with all_values = 0, n >= 2048, 3 k <= n):
+ *   method 3 (filtered subspace iteration, the route of ptd_eigh_topk with all_values = 0, n >= 2048, 7 k <= 2 n):
  *                            ms = {Lanczos bounds, filter rounds (products with C + Cholesky-QR passes), the
  *                            Rayleigh-Ritz eigenproblem of order launches[2], Ritz products + residual check};
  *                            launches = {Lanczos steps, products with C, subspace dimension m, 0};

@@ -526,7 +526,22 @@ class SharedInputPool:
             mom.finalize()
 
 
-def run_concurrently(jobs, device: torch.device, max_streams: Optional[int] = None) -> list:
+def eigh_route_hint(cov, n_out: int, top_k: Optional[int]) -> int:
+    """Which solver the eigendecomposition behind `cov` (Covariance | MomentCovariance) will be given first
+    (ptd_eigh_route): 3 = filtered subspace iteration -- chip-filling f64 products, gains nothing from running beside
+    other chains and loses its resident Rayleigh-Ritz kernels when it does --, 1 = the direct reduction, a latency-bound
+    chain of short launches that overlaps well with others."""
+    from . import _hip
+
+    if isinstance(cov, MomentCovariance):
+        n = cov.weight.shape[1] if cov.factored else n_out
+    else:
+        n = cov.E.shape[0]
+    k = n if top_k is None else max(1, min(int(top_k), n))
+    return int(_hip.load().ptd_eigh_route(n, k, 0))
+
+
+def run_concurrently(jobs, device: torch.device, max_streams: Optional[int] = None, routes: Optional[list] = None) -> list:
     """Run independent device-side jobs (callables returning tensors) from separate host threads, each on
     its own HIP stream, and return their results in order.
 
@@ -535,13 +550,28 @@ def run_concurrently(jobs, device: torch.device, max_streams: Optional[int] = No
     n = 4096 matrices: 1.5x the throughput of running them back to back, three: 1.9x).  The C ABI keeps
     no shared mutable state and releases the GIL, so the host side is plain threads.  Stream order:
     every side stream first waits for the caller's stream (inputs), the caller's stream waits for all
-    of them at the end (outputs).  PTD_EIGH_STREAMS overrides the stream count (1 = sequential)."""
+    of them at the end (outputs).  PTD_EIGH_STREAMS overrides the stream count (1 = sequential).  `routes` (one
+    ptd_eigh_route value per job): see the comment below; PTD_EIGH_STREAMS_BY_ROUTE=0 ignores it."""
     import os
     import threading
 
     jobs = list(jobs)
     device = torch.device(device)
     want = int(os.environ.get("PTD_EIGH_STREAMS", "3")) if max_streams is None else max_streams
+    if routes is not None and want > 1 and device.type == "cuda" and os.environ.get("PTD_EIGH_STREAMS_BY_ROUTE", "1") != "0":
+        # the jobs the filtered route will take run one after the other on the caller's stream (with the whole chip, and
+        # with the resident kernels of their inner eigenproblem); only the latency-bound ones share the chip
+        # (profiles/streams_r04.json: three filtered chains side by side 137-180 ms, back to back 148; the Llama block's
+        # direct-route layers 1.1 x faster on three streams)
+        alone = [i for i, r in enumerate(routes) if r == 3]
+        if alone:
+            rest = [i for i in range(len(jobs)) if routes[i] != 3]
+            out = [None] * len(jobs)
+            for i in alone:
+                out[i] = jobs[i]()
+            for i, res in zip(rest, run_concurrently([jobs[i] for i in rest], device, max_streams)):
+                out[i] = res
+            return out
     workers = max(1, min(len(jobs), want))
     if workers == 1 or device.type != "cuda":
         return [job() for job in jobs]

@@ -79,9 +79,10 @@ static int eigh_dispatch(const double* A, int64_t lda, int64_t n, int64_t k, dou
   // (flat spectrum, breakdown, residual above tolerance) with PTD_ERR_UNSUPPORTED and the direct route below runs
   if (method == 2 && A && evals && evecs && ws && lda >= n && k >= 1 && k <= n && ldv >= k && (lda % 2) == 0 &&
       (reinterpret_cast<uintptr_t>(A) & 15) == 0 &&
-      eigh_filtered_applies(n, k, all_values) && ws_bytes >= eigh_filtered_workspace_bytes(n)) {
+      eigh_filtered_applies(n, k, all_values) && ws_bytes >= eigh_filtered_workspace_bytes(n, k) &&
+      !eigh_filtered_backed_off(n, k)) {
     const int rc = eigh_filtered(A, lda, n, k, evals, evecs, ldv, ws, ws_bytes, stats, st);
-    if (rc != PTD_ERR_UNSUPPORTED) {
+    if (rc != PTD_ERR_UNSUPPORTED && rc != PTD_ERR_WORKSPACE) {
       if (sweeps_out) *sweeps_out = 0;
       return rc;
     }
@@ -96,6 +97,14 @@ static int eigh_dispatch(const double* A, int64_t lda, int64_t n, int64_t k, dou
     }
   }
   return eigh_jacobi(A, lda, n, k, evals, evecs, ldv, ws, ws_bytes, sweeps_out, stats, st);
+}
+
+int ptd_eigh_route(int64_t n, int64_t k, int all_values) {
+  // what eigh_dispatch would try first for this request (the filtered route may still decline at run time)
+  const int method = eigh_method();
+  if (method == 2 && eigh_filtered_applies(n, k, all_values != 0)) return 3;
+  if (method != 0 && (method == 1 || n >= 256) && n >= 2) return 1;
+  return 0;
 }
 
 size_t ptd_eigh_factored_workspace_bytes(int64_t n_o, int64_t n_i, int64_t k) {

@@ -22,6 +22,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <utility>
 #include <vector>
 
@@ -865,6 +866,58 @@ int chol_inverse(double* G, int64_t m, double* Wt, void* ws, size_t ws_bytes, hi
   return PTD_OK;
 }
 
+// ---- late declines are remembered (per device and shape)
+// A decline after the density estimate costs 1.5 ms of a 55 ms direct reduction; a LATE one -- a Cholesky breakdown, a
+// residual that does not come down, clustered Ritz values -- has spent some fifteen products and a Rayleigh-Ritz solve
+// first.  The layers of one model share shapes and tend to share the character of their spectra, so after a late
+// decline the next 1, 2, 4, ... 64 requests of the same (device, n, k) go straight to the direct route; a success resets
+// the count.
+namespace {
+struct DeclineNote { int device; int64_t n, k; int fails; int skip; };
+std::mutex g_decline_mu;
+std::vector<DeclineNote> g_declines;
+DeclineNote* decline_note(int device, int64_t n, int64_t k, bool create) {
+  for (auto& d : g_declines)
+    if (d.device == device && d.n == n && d.k == k) return &d;
+  if (!create) return nullptr;
+  if (g_declines.size() >= 256) g_declines.clear();
+  g_declines.push_back(DeclineNote{device, n, k, 0, 0});
+  return &g_declines.back();
+}
+int current_device() {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  return dev;
+}
+bool backoff_enabled() {     // PTD_EIGH_FILTER_BACKOFF=0: every request is tried afresh (tests)
+  const char* e = getenv("PTD_EIGH_FILTER_BACKOFF");
+  return !(e && atoi(e) == 0);
+}
+}  // namespace
+
+// true: the filtered route should not be tried for this request (a recent late decline of the same shape)
+bool eigh_filtered_backed_off(int64_t n, int64_t k) {
+  if (!backoff_enabled()) return false;
+  std::lock_guard<std::mutex> lock(g_decline_mu);
+  DeclineNote* d = decline_note(current_device(), n, k, false);
+  if (!d || d->skip <= 0) return false;
+  --d->skip;
+  return true;
+}
+static void note_outcome(int64_t n, int64_t k, bool late_decline) {
+  if (!backoff_enabled()) return;
+  std::lock_guard<std::mutex> lock(g_decline_mu);
+  DeclineNote* d = decline_note(current_device(), n, k, late_decline);
+  if (!d) return;
+  if (late_decline) {
+    d->fails = std::min(d->fails + 1, 7);
+    d->skip = 1 << (d->fails - 1);
+  } else {
+    d->fails = 0;
+    d->skip = 0;
+  }
+}
+
 bool eigh_filtered_applies(int64_t n, int64_t k, bool all_values) {
   const char* e = getenv("PTD_EIGH_FILTERED");
   const int mode = e ? atoi(e) : 1;       // 0 off, 1 auto, 2 whenever the shapes allow (tests)
@@ -872,15 +925,24 @@ bool eigh_filtered_applies(int64_t n, int64_t k, bool all_values) {
   if (n % 128 != 0 || k < 32) return false;
   if (filter_block(n, k) > n / 2) return false;           // the subspace must stay well below the matrix order
   if (mode >= 2) return n >= 512;
-  return n >= 2048 && 3 * k <= n;
+  // up to 2/7 of the spectrum: at k = n / 3 (n = 4096: a block of 1728 columns, 27 ms of filter rounds, a 14-ms
+  // Rayleigh-Ritz problem and, on covariance spectra, a second attempt) the route took 68 ms against 58 ms direct
+  return n >= 2048 && 7 * k <= 2 * n;
+}
+
+size_t eigh_filtered_workspace_bytes(int64_t n, int64_t k) {
+  if (n % 128 != 0 || n < 512 || k < 32 || filter_block(n, k) > n / 2) return 0;
+  return filter_plan(n, k).total;
 }
 
 size_t eigh_filtered_workspace_bytes(int64_t n) {
-  // the largest request the route accepts at this order
+  // an upper bound over every request the route can accept at this order (PTD_EIGH_FILTERED=2 and
+  // PTD_EIGH_FILTER_OVERSAMPLE included): the plan is monotone in the block size and in k, and no block exceeds n / 2
   if (n % 128 != 0 || n < 512) return 0;
-  int64_t k = n / 3;
-  while (k >= 32 && filter_block(n, k) > n / 2) k -= 32;
-  return k >= 32 ? filter_plan(n, k).total : 0;
+  size_t worst = 0;
+  for (int64_t k = 32; k <= n / 2; k += 32)
+    if (filter_block(n, k) <= n / 2) worst = std::max(worst, filter_plan(n, k).total);
+  return worst;
 }
 
 // PTD_OK, or PTD_ERR_UNSUPPORTED when the route declines (flat spectrum, a breakdown, residual above tolerance): the
@@ -911,21 +973,27 @@ int eigh_filtered(const double* A, int64_t lda, int64_t n, int64_t k, double* ev
   int* fail = reinterpret_cast<int*>(base + p.off_flags);
   unsigned long long* resid = reinterpret_cast<unsigned long long*>(base + p.off_flags + 64);
 
-  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  // (the statistics events live in a guard: every return path below destroys them)
+  struct Events {
+    hipEvent_t e[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    ~Events() {
+      for (auto& x : e)
+        if (x) (void)hipEventDestroy(x);
+    }
+  } events;
+  hipEvent_t (&ev)[6] = events.e;
   if (stats) {
     memset(stats, 0, sizeof(*stats));
     stats->method = 3;
     for (auto& e : ev) PTD_CHECK_HIP(hipEventCreate(&e));
     PTD_CHECK_HIP(hipEventRecord(ev[0], st));
   }
-  auto cleanup = [&]() {
-    for (auto& e : ev)
-      if (e) (void)hipEventDestroy(e);
-  };
+  auto cleanup = [&]() {};
+  bool spent = false;     // products with C have been spent: a decline from here on is a late one
+  // a decline is not an error: the caller answers on the direct route and the thread's last error stays as it was
   auto decline = [&](const char* why) {
     if (debug) fprintf(stderr, "[eigh_filtered] n=%lld k=%lld declines: %s\n", (long long)n, (long long)k, why);
-    set_error("eigh_filtered: %s", why);
-    cleanup();
+    if (spent) note_outcome(n, k, true);
     return PTD_ERR_UNSUPPORTED;
   };
 
@@ -1039,6 +1107,7 @@ int eigh_filtered(const double* A, int64_t lda, int64_t n, int64_t k, double* ev
   }
 
   // ---- 2. filter rounds
+  spent = true;
   const int64_t tot2 = (int64_t)n * m / 2;
   const double shift_rel = env_double("PTD_EIGH_FILTER_SHIFT", 6e-13);
   int products = 0, rc = PTD_OK;
@@ -1160,7 +1229,8 @@ int eigh_filtered(const double* A, int64_t lda, int64_t n, int64_t k, double* ev
               products, h.fail, res, res / std::max(lmax, 1e-300), theta_max);
     if (h.fail) return decline("Cholesky breakdown in an orthonormalisation pass");
     if (res <= tol * lmax) break;
-    // not there yet (the density estimate put lambda_k too high): one more round, sized by the rate measured so far
+    // not there yet (the density estimate put lambda_k too high): one more round, sized by the rate measured so far --
+    // at most three extra rounds (four Rayleigh-Ritz steps in all)
     const double rel = res / std::max(lmax, 1e-300);
     if (attempt >= 3 || !(rel < 1e-2)) return decline("residual above the tolerance");
     const double rate = pow(0.05 / rel, 1.0 / (double)filter_products);     // over ALL filter products so far
@@ -1198,7 +1268,7 @@ int eigh_filtered(const double* A, int64_t lda, int64_t n, int64_t k, double* ev
     stats->work[1] = 2.0 * (double)n * (double)n * (double)m * (double)products;
     stats->total_ms = t01 + t12 + t23 + t34 + t45;
   }
-  cleanup();
+  note_outcome(n, k, false);
   return PTD_OK;
 }
 

@@ -962,8 +962,9 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_8ph16p_kernel(const GemmB
   const int wr = wid >> 2, wc = wid & 3;
   const int tiles_m = a.tiles_m, tiles_n = ntiles / tiles_m;
   const int nk = a.K / 64;
-  // tile t of the walk: the one-tile kernel's XCD-aware order with t in the place of the block index (the grid is a
-  // multiple of 8, so t & 7 is this workgroup's XCD for every tile it takes)
+  // tile t of the walk: the one-tile kernel's XCD-aware order with t in the place of the block index (the grid is
+  // either 256 workgroups -- a multiple of 8, so t & 7 is this workgroup's XCD for every tile b, b + 256, ... it takes --
+  // or, below 256 tiles, one workgroup per tile: t is the block index itself.  Locality only, never correctness)
   auto origin = [&](int t, int& m0, int& n0) {
     const int q8 = ntiles >> 3, r8 = ntiles & 7, xcd = t & 7;
     const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (t >> 3);
@@ -1073,7 +1074,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_8ph16p_kernel(const GemmB
 
   // the finished tile leaves: four passes (A half i, 16-row blocks 2 mtp, 2 mtp + 1 of both wave rows) of 64 rows
   char* const img = lds + 8 * 16384;
-  auto epilogue = [&](const int m0, const int n0) {
+  auto epilogue = [&](const int m0, const int n0, const bool final) {
     // (the thread index goes through an opaque move so that the image and store addresses are formed HERE: hoisted out
     // of the tile loop they would stay live across the main loop, which has no registers to spare)
     int etid;
@@ -1135,7 +1136,9 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_8ph16p_kernel(const GemmB
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
     PTD_ZERO_ACC();
-    if (STAGGER && wr == 1) __builtin_amdgcn_s_barrier();
+    // (the wave rows fall out of step again for the next tile; after the LAST tile they stay level, so that both have
+    // executed the same number of barriers when the kernel ends)
+    if (STAGGER && wr == 1 && !final) __builtin_amdgcn_s_barrier();
   };
 
   int t = blockIdx.x;
@@ -1158,7 +1161,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_8ph16p_kernel(const GemmB
     const int kn = last ? 0 : kt + 2;
     PTD_PAIR();
     if (last) {
-      epilogue(m0, n0);
+      epilogue(m0, n0, false);
       m0 = nm0; n0 = nn0; t = tn; kt = 0;
       fresh = true;
     } else {
@@ -1177,7 +1180,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_nt_8ph16p_kernel(const GemmB
     PTD_READ_A(1, 1);                                                   PTD_SYNC_IN(0); PTD_QUAD(1, 1, b1); PTD_SYNC_OUT();
                                                                         PTD_SYNC_IN(0); PTD_QUAD(1, 0, b0); PTD_SYNC_OUT();
   }
-  epilogue(m0, n0);
+  epilogue(m0, n0, true);
 #undef PTD_DMA
 #undef PTD_STAGE
 #undef PTD_ZERO_ACC

@@ -57,7 +57,9 @@ int band_reduce_f64(const double* A, int64_t lda, int64_t n, int stages, double*
 // eigh_filtered.hip: top-k eigenpairs by Chebyshev-filtered subspace iteration (f64 MFMA products); declines with
 // PTD_ERR_UNSUPPORTED when the spectrum does not suit it
 bool eigh_filtered_applies(int64_t n, int64_t k, bool all_values);
-size_t eigh_filtered_workspace_bytes(int64_t n);
+size_t eigh_filtered_workspace_bytes(int64_t n);              // an upper bound over every k the route accepts at n
+size_t eigh_filtered_workspace_bytes(int64_t n, int64_t k);   // what eigh_filtered(n, k) needs (0: does not apply)
+bool eigh_filtered_backed_off(int64_t n, int64_t k);          // a recent late decline of this shape on this device
 int eigh_filtered(const double* A, int64_t lda, int64_t n, int64_t k, double* evals, double* evecs, int64_t ldv,
                   void* ws, size_t ws_bytes, ptd_eigh_stats* stats, hipStream_t st);
 

@@ -102,101 +102,12 @@ __global__ void colsum_kernel(const TY* __restrict__ Y, int64_t T, int n, int64_
 }
 
 // ----------------------------------------------------------------------- nsr
-// One launch: every block leaves the partial sums of its (column tile, row chunk) in the workspace; the LAST chunk block
-// of a column tile (a ticket) adds the chunks of its channels in index order and leaves the sum of their ratios in
-// blocksum[tile]; the last column tile adds those in index order.  Deterministic, and no second launch or memset in
-// front of an HBM-bound stream of 25 us.  The tickets are plain counters at the head of the workspace: zero on entry
-// (ptd_nsr_workspace_init, once per workspace) and zero again on return (the last arriver resets its counter).
-// (A form that needed no initialisation -- words validated by a per-call tag and claimed with compare-and-swap -- cost
-// 0.1 to 0.6 ms: every failed swap of the 16 to 128 blocks that finish a tile together is another round trip.)
-__device__ __forceinline__ bool nsr_arrive(unsigned int* ticket, unsigned expected) {
-  const unsigned old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (old + 1 != expected) return false;
-  __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next call
-  return true;
-}
-
-// Called by all 256 threads of a block after its partial sums are stored.  chans = channels per column tile.
-// Hand-offs (MI355X_MICROARCH.md, inter-workgroup visibility): every handed-off value is stored WRITE-THROUGH (agent-
-// scope relaxed atomic store = `global_store ... sc1`), the storing waves drain their stores, barrier, one lane arrives;
-// the last arriver acquires at agent scope (invalidates its CU's L1), barrier, plain loads.  An agent-scope RELEASE
-// (`buffer_wbl2`) per block instead of the write-through stores made the kernel 8 x slower: 128 L2 write-backs per XCD,
-// one behind the other, 0.25 ms for a 0.03 ms stream.
-__device__ __forceinline__ void nsr_store(double* p, double v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void nsr_finish(const double* __restrict__ part, int64_t R, int64_t C, int nchunk, int chans,
-                                           double eps, unsigned int* __restrict__ tickets,
-                                           double* __restrict__ blocksum, double* __restrict__ out) {
-  __shared__ bool last_s;
-  __shared__ double red[4];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (tid == 0) {
-    last_s = nsr_arrive(tickets + 1 + blockIdx.x, gridDim.y);
-    if (last_s) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-  }
-  __syncthreads();
-  if (!last_s) return;
-  const int64_t c_begin = (int64_t)blockIdx.x * chans;
-  const double n = (double)R;
-  double acc = 0.0;
-  for (int i = tid; i < chans; i += 256) {
-    const int64_t c = c_begin + i;
-    if (c >= C) break;
-    double s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    // (sixteen chunks requested per round: one chunk per round trip made this loop the longest part of the kernel --
-    // the partial sums were stored write-through and come back from the memory side, ~2 us a round under load)
-    constexpr int KU = 16;
-    for (int k0 = 0; k0 < nchunk; k0 += KU) {
-      double a1[KU], a2[KU], a3[KU];
-#pragma unroll
-      for (int u = 0; u < KU; ++u) {
-        const bool ok = k0 + u < nchunk;
-        const double* p = part + (int64_t)(ok ? k0 + u : k0) * 3 * C + c;
-        a1[u] = ok ? p[0] : 0.0; a2[u] = ok ? p[C] : 0.0; a3[u] = ok ? p[2 * C] : 0.0;
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int u = 0; u < KU; ++u) { s1 += a1[u]; s2 += a2[u]; s3 += a3[u]; }
-    }
-    const double var = (s2 - s1 * s1 / n) / (n - 1.0);  // unbiased, like torch.std
-    acc += (s3 / n) / (var + eps);
-  }
-  acc = wave_sum(acc);
-  if (lane == 0) red[w] = acc;
-  __syncthreads();
-  if (tid == 0) {
-    nsr_store(&blocksum[blockIdx.x], (red[0] + red[1]) + (red[2] + red[3]));
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    last_s = nsr_arrive(tickets, gridDim.x);
-    if (last_s) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-  }
-  __syncthreads();
-  if (!last_s) return;
-  double t = 0.0;
-  for (unsigned i = tid; i < gridDim.x; i += 256) t += blocksum[i];
-  t = wave_sum(t);
-  if (lane == 0) red[w] = t;
-  __syncthreads();
-  if (tid == 0) out[0] = ((red[0] + red[1]) + (red[2] + red[3])) / (double)C;
-}
-
 // Threads are laid out as Rt row lanes x Ct columns (Ct = min(C, 256), Rt = 256 / Ct) so that
 // consecutive threads touch consecutive addresses for every C, including C == 1.
 template <typename T>
 __global__ __launch_bounds__(256) void nsr_partial_kernel(const T* __restrict__ x, const T* __restrict__ y, int64_t R,
                                                           int64_t C, int Ct, int Rt, int64_t rows_per_chunk,
-                                                          double* __restrict__ part, double eps,
-                                                          unsigned int* __restrict__ tickets,
-                                                          double* __restrict__ blocksum, double* __restrict__ out) {
+                                                          double* __restrict__ part) {
   __shared__ double sm[3][256];
   const int tid = threadIdx.x;
   const int cl = tid % Ct, rl = tid / Ct;
@@ -225,9 +136,8 @@ __global__ __launch_bounds__(256) void nsr_partial_kernel(const T* __restrict__ 
     }
     // partials as [chunk][3][C]: the final pass reads them coalesced
     double* o = part + (int64_t)blockIdx.y * 3 * C + c;
-    nsr_store(o, s1); nsr_store(o + C, s2); nsr_store(o + 2 * C, s3);
+    o[0] = s1; o[C] = s2; o[2 * C] = s3;
   }
-  nsr_finish(part, R, C, (int)gridDim.y, Ct, eps, tickets, blocksum, out);
 }
 
 // The same sums with 16-byte loads (C a multiple of V = 16 / sizeof(T), 16-byte aligned operands): a lane owns V
@@ -252,9 +162,7 @@ __device__ __forceinline__ void nsr_unpack<unsigned short, 8>(const uint4& q, do
 template <typename T, int V>
 __global__ __launch_bounds__(256) void nsr_partial_vec_kernel(const T* __restrict__ x, const T* __restrict__ y, int64_t R,
                                                               int64_t C, int64_t rows_per_chunk,
-                                                              double* __restrict__ part, double eps,
-                                                              unsigned int* __restrict__ tickets,
-                                                              double* __restrict__ blocksum, double* __restrict__ out) {
+                                                              double* __restrict__ part) {
   constexpr int U = 32 / V;   // rows per trip: 8 (f32), 4 (bf16: eight channels a lane, twice the accumulators)
   __shared__ double sm[3][V][64];   // one quantity at a time: [row lane 1..3][channel of the lane][lane]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -317,11 +225,66 @@ __global__ __launch_bounds__(256) void nsr_partial_vec_kernel(const T* __restric
     __syncthreads();
     if (w == 0 && active) {
 #pragma unroll
-      for (int i = 0; i < V; ++i)
-        nsr_store(o + (int64_t)qn * C + i, ((s[i] + sm[0][i][lane]) + sm[1][i][lane]) + sm[2][i][lane]);
+      for (int i = 0; i < V; ++i) o[(int64_t)qn * C + i] = ((s[i] + sm[0][i][lane]) + sm[1][i][lane]) + sm[2][i][lane];
     }
   }
-  nsr_finish(part, R, C, (int)gridDim.y, 64 * V, eps, tickets, blocksum, out);
+}
+
+// 64 channels x 4 chunk lanes per block: the chunk partials of a channel are added in a fixed order (lane q takes
+// chunks q, q + 4, ..., then lanes 0 .. 3), the block leaves the sum of its channels' ratios in blocksum[blockIdx.x],
+// and the LAST block to finish (ticket counter) adds the block sums in index order and writes the result:
+// deterministic, and one launch instead of three (the old per-channel loop over strided partials took 21 us).
+// The ticket is zero on entry (ptd_nsr_workspace_init, once per workspace) and zero again on return.
+// (Round 4 tried the whole reduction in ONE launch -- the last chunk block of a column tile adding its chunks, the last
+// tile adding the tiles: two dependent ticket + agent-acquire + load rounds behind the stream cost 8-13 us against
+// 1.7 us of kernel boundary + 4 us of this kernel; with an agent-scope release per block instead of write-through
+// stores 0.25 ms; with tickets claimed by compare-and-swap in an uninitialised workspace 0.1-0.6 ms.)
+__global__ __launch_bounds__(256) void nsr_final_kernel(const double* __restrict__ part, int64_t R, int64_t C,
+                                                        int nchunk, double eps, double* __restrict__ blocksum,
+                                                        unsigned int* __restrict__ ticket, double* __restrict__ out) {
+  __shared__ double sm[3][4][64];
+  __shared__ double red[4];
+  __shared__ bool last;
+  const int cl = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int64_t c = (int64_t)blockIdx.x * 64 + cl;
+  double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  if (c < C)
+#pragma unroll 8
+    for (int k = q; k < nchunk; k += 4) {
+      const double* p = part + (int64_t)k * 3 * C + c;
+      s1 += p[0]; s2 += p[C]; s3 += p[2 * C];
+    }
+  sm[0][q][cl] = s1; sm[1][q][cl] = s2; sm[2][q][cl] = s3;
+  __syncthreads();
+  double acc = 0.0;
+  if (q == 0 && c < C) {
+    s1 = (sm[0][0][cl] + sm[0][1][cl]) + (sm[0][2][cl] + sm[0][3][cl]);
+    s2 = (sm[1][0][cl] + sm[1][1][cl]) + (sm[1][2][cl] + sm[1][3][cl]);
+    s3 = (sm[2][0][cl] + sm[2][1][cl]) + (sm[2][2][cl] + sm[2][3][cl]);
+    const double n = (double)R;
+    const double var = (s2 - s1 * s1 / n) / (n - 1.0);  // unbiased, like torch.std
+    acc = (s3 / n) / (var + eps);
+  }
+  if (q == 0) {
+    acc = wave_sum(acc);
+    if (cl == 0) {
+      blocksum[blockIdx.x] = acc;
+      __threadfence();
+      last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    }
+  }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  double t = 0.0;
+  for (unsigned i = threadIdx.x; i < gridDim.x; i += 256) t += __hip_atomic_load(&blocksum[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  t = wave_sum(t);
+  if (cl == 0) red[q] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    out[0] = ((red[0] + red[1]) + (red[2] + red[3])) / (double)C;
+    *ticket = 0u;   // ready for the next call on this workspace
+  }
 }
 
 // -------------------------------------------------------------------- sym_kl
@@ -383,14 +346,14 @@ struct NsrPlan {
 };
 
 // the 16-byte form: `vec` channels per lane, 64 lanes per column tile, four row lanes; chunks of at least 32 rows, about
-// 512 blocks (the partial sums are 24 C bytes per chunk and the last block of a column tile adds them: more chunks
-// lengthen that tail)
+// 1024 blocks (the partial sums are 24 C bytes per chunk, written once and read once by the final kernel;
+// PTD_NSR_BLOCKS overrides the target)
 NsrPlan nsr_plan_vec(int64_t R, int64_t C, int vec) {
   NsrPlan p{};
   p.Ct = 64 * vec;
   p.Rt = 4;
   p.coltiles = (int)ceil_div(C, p.Ct);
-  static const int blocks = [] { const char* e = getenv("PTD_NSR_BLOCKS"); return e ? std::max(1, atoi(e)) : 512; }();
+  static const int blocks = [] { const char* e = getenv("PTD_NSR_BLOCKS"); return e ? std::max(1, atoi(e)) : 1024; }();
   const int64_t want = std::max<int64_t>(1, blocks / p.coltiles);
   p.nchunk = (int)std::max<int64_t>(1, std::min<int64_t>(want, ceil_div(R, 32)));
   p.rows_per_chunk = ceil_div(R, p.nchunk);
@@ -466,16 +429,14 @@ int colsum_accumulate(const void* y, int64_t T, int64_t n, int64_t ldy, int y_dt
   return PTD_ERR_UNSUPPORTED;
 }
 
-// workspace: [tickets: one per column tile + one][one sum per column tile][partial sums [chunk][3][C]]
-static size_t nsr_tiles_max(int64_t C) { return (size_t)ceil_div(std::max<int64_t>(C, 256), 64); }   // (no plan has narrower tiles)
-// (a FIXED ticket area at the head of the workspace: a workspace serves calls of different shapes, and what one call
-// uses for partial sums must never be where another looks for zeroed counters)
-constexpr size_t NSR_TICKETS = 16384;
-static size_t nsr_ticket_bytes(int64_t) { return NSR_TICKETS * 4; }
+// workspace: [ticket of the final kernel (a fixed 256-byte head: a workspace serves calls of different shapes, and what
+// one call uses for partial sums must never be where another looks for its zeroed counter)][one sum per 64 channels]
+// [partial sums [chunk][3][C]]
+static size_t nsr_ticket_bytes() { return 256; }
 size_t nsr_workspace_bytes(int64_t R, int64_t C) {
   // (the dtype is not known here: room for whichever plan has more chunks)
   const int nchunk = std::max(std::max(nsr_plan(R, C).nchunk, nsr_plan_vec(R, C, 4).nchunk), nsr_plan_vec(R, C, 8).nchunk);
-  return nsr_ticket_bytes(C) + align_up(nsr_tiles_max(C) * 8, 256) + align_up((size_t)nchunk * C * 3 * 8, 256);
+  return nsr_ticket_bytes() + align_up((size_t)ceil_div(C, 64) * 8, 256) + align_up((size_t)nchunk * C * 3 * 8, 256);
 }
 
 int nsr_workspace_init(void* ws, size_t ws_bytes, hipStream_t st) {
@@ -496,32 +457,33 @@ int nsr(const void* x, const void* y, int64_t R, int64_t C, int dtype, double ep
   const bool aligned = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
   const bool use_vec = vec && C % vec == 0 && C >= 64 && aligned;
   if (use_vec) p = nsr_plan_vec(R, C, vec);
-  PTD_REQUIRE((size_t)p.coltiles + 1 <= NSR_TICKETS, "ptd_nsr: more than %zu column tiles", NSR_TICKETS - 1);
   char* base = static_cast<char*>(ws);
-  unsigned int* tickets = reinterpret_cast<unsigned int*>(base);
-  double* blocksum = reinterpret_cast<double*>(base + nsr_ticket_bytes(C));
-  double* part = reinterpret_cast<double*>(base + nsr_ticket_bytes(C) + align_up(nsr_tiles_max(C) * 8, 256));
+  unsigned int* ticket = reinterpret_cast<unsigned int*>(base);
+  double* blocksum = reinterpret_cast<double*>(base + nsr_ticket_bytes());
+  double* part = reinterpret_cast<double*>(base + nsr_ticket_bytes() + align_up((size_t)ceil_div(C, 64) * 8, 256));
   dim3 grid((unsigned)p.coltiles, (unsigned)p.nchunk);
   if (use_vec) {
     if (dtype == PTD_F32)
       hipLaunchKernelGGL((nsr_partial_vec_kernel<float, 4>), grid, dim3(256), 0, st, (const float*)x, (const float*)y, R,
-                         C, p.rows_per_chunk, part, eps, tickets, blocksum, out);
+                         C, p.rows_per_chunk, part);
     else
       hipLaunchKernelGGL((nsr_partial_vec_kernel<unsigned short, 8>), grid, dim3(256), 0, st, (const unsigned short*)x,
-                         (const unsigned short*)y, R, C, p.rows_per_chunk, part, eps, tickets, blocksum, out);
+                         (const unsigned short*)y, R, C, p.rows_per_chunk, part);
   } else if (dtype == PTD_F32) {
     hipLaunchKernelGGL((nsr_partial_kernel<float>), grid, dim3(256), 0, st, (const float*)x, (const float*)y, R, C,
-                       p.Ct, p.Rt, p.rows_per_chunk, part, eps, tickets, blocksum, out);
+                       p.Ct, p.Rt, p.rows_per_chunk, part);
   } else if (dtype == PTD_BF16) {
     hipLaunchKernelGGL((nsr_partial_kernel<unsigned short>), grid, dim3(256), 0, st, (const unsigned short*)x,
-                       (const unsigned short*)y, R, C, p.Ct, p.Rt, p.rows_per_chunk, part, eps, tickets, blocksum, out);
+                       (const unsigned short*)y, R, C, p.Ct, p.Rt, p.rows_per_chunk, part);
   } else if (dtype == PTD_F64) {
     hipLaunchKernelGGL((nsr_partial_kernel<double>), grid, dim3(256), 0, st, (const double*)x, (const double*)y, R,
-                       C, p.Ct, p.Rt, p.rows_per_chunk, part, eps, tickets, blocksum, out);
+                       C, p.Ct, p.Rt, p.rows_per_chunk, part);
   } else {
     set_error("ptd_nsr: unsupported dtype");
     return PTD_ERR_UNSUPPORTED;
   }
+  const unsigned fblocks = (unsigned)ceil_div(C, 64);
+  hipLaunchKernelGGL(nsr_final_kernel, dim3(fblocks), dim3(256), 0, st, part, R, C, p.nchunk, eps, blocksum, ticket, out);
   PTD_CHECK_LAUNCH("nsr");
   return PTD_OK;
 }

@@ -155,8 +155,9 @@ def _precompute_covariance_matrix_decompositions(*, module, submodule_names, num
             return stand_ins[i].get_eigenvectors()
         return run
 
+    routes = [eng.eigh_route_hint(stand_ins[i].cov, stand_ins[i].out_features, stand_ins[i].top_k) for i in owned]
     with eng.phase("B_eigh"):
-        got = eng.run_concurrently([job(i) for i in owned], device)
+        got = eng.run_concurrently([job(i) for i in owned], device, routes=routes)
     for i, done in enumerate(pending):     # the sums this rank only contributed to: their buffers may go now
         if done is not None and not shard.owns(i):
             done()

@@ -499,6 +499,25 @@ def test_eigh_filtered_route_declines_where_it_does_not_apply(ops, monkeypatch):
     monkeypatch.setattr(real_ops, "EIGH_PROFILE", None)
 
 
+def test_eigh_filtered_route_backs_off_after_a_late_decline(ops, monkeypatch):
+    """A decline AFTER products were spent (here: a residual bound no attempt can meet, PTD_EIGH_FILTER_TOL = 1e-18) is
+    remembered per (device, n, k): the next request of that shape goes straight to the direct route, the one after
+    that tries the filter again (back-off 1, 2, 4, ... requests; a success resets it)."""
+    monkeypatch.setenv("PTD_EIGH_FILTER_BACKOFF", "1")
+    n, k = 2048, 448                                          # (a shape no other test uses)
+    a = _twist_case_matrix(n).to(DEV)
+    w_ref = torch.linalg.eigvalsh(a.cpu())
+    assert _profiled_eigh(ops, monkeypatch, a, k)[2]["method"] == 3
+    monkeypatch.setenv("PTD_EIGH_FILTER_TOL", "1e-18")
+    w, v, prof = _profiled_eigh(ops, monkeypatch, a, k)
+    assert prof["method"] != 3                                # declined late, answered by the direct route
+    assert (w[n - k:] - w_ref[n - k:]).abs().max().item() <= 1e-11 * w_ref.abs().max().item()
+    monkeypatch.delenv("PTD_EIGH_FILTER_TOL")
+    assert _profiled_eigh(ops, monkeypatch, a, k)[2]["method"] != 3        # skipped once ...
+    assert _profiled_eigh(ops, monkeypatch, a, k)[2]["method"] == 3        # ... then tried again, and it works
+    assert _profiled_eigh(ops, monkeypatch, a, k)[2]["method"] == 3
+
+
 def test_resident_kernels_are_chosen_on_device_facts(ops, monkeypatch):
     """The whole-chip kernels of the tridiagonalisation only run on an unpartitioned 256-CU gfx950 (CU count,
     architecture and the occupancy query are read once per device).  PTD_SYTRD_FAKE_CUS stands for a device with

@@ -425,14 +425,17 @@ def test_dwain_c2_headline_workload_end_to_end_matches_oracle(splits):
     assert (out - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
 
 
-def test_dwain_three_layer_stack_concurrent_filtered_chains_match_oracle():
+@pytest.mark.parametrize("by_route", ["0", "1"])
+def test_dwain_three_layer_stack_concurrent_filtered_chains_match_oracle(monkeypatch, by_route):
     """The DEFAULT path of every multi-layer split (dwain.py:580-633 + 333-537): three nn.Linear(4096, 4096) in ONE
     precompute split, so their three eigendecompositions -- each the filtered subspace iteration, each with its own
     host-side decisions and two stream synchronisations -- run as three concurrent chains on three HIP streams
-    (_engine.run_concurrently), against the CPU oracle on the same seeded inputs: identical (layer, rank, accepted)
-    decisions, nsr / ppl within 1e-4, factor products within 1e-4 (Frobenius), outputs 1e-4.  The test also
-    asserts that the three calls really ran on three threads / streams and that the solver's route for these
-    matrices is the filtered one."""
+    (_engine.run_concurrently) with PTD_EIGH_STREAMS_BY_ROUTE=0, and one after the other on the caller's stream by
+    default (round 4: chains the filtered route will take fill the chip on their own) -- against the CPU oracle on the
+    same seeded inputs: identical (layer, rank, accepted) decisions, nsr / ppl within 1e-4, factor products within 1e-4
+    (Frobenius), outputs 1e-4.  The test also asserts on which threads / streams the three calls ran and that the
+    solver's route for these matrices is the filtered one (the deepest layer's flatter spectrum may decline it)."""
+    monkeypatch.setenv("PTD_EIGH_STREAMS_BY_ROUTE", by_route)
     import threading
 
     import bench
@@ -461,8 +464,7 @@ def test_dwain_three_layer_stack_concurrent_filtered_chains_match_oracle():
 
     def spy(a, k=None, all_values=True):
         calls.append((threading.get_ident(), torch.cuda.current_stream(a.device).cuda_stream, a.shape[0], k))
-        if not kept:
-            kept.append((a.clone(), k, all_values))
+        kept.append((a.clone(), k, all_values))
         return real_eigh(a, k, all_values)
 
     ops.eigh = spy
@@ -473,16 +475,21 @@ def test_dwain_three_layer_stack_concurrent_filtered_chains_match_oracle():
             precomputing_covariance_num_splits=1, **bench.DWAIN_KW)
     finally:
         ops.eigh = real_eigh
-    streams_wanted = min(3, int(__import__("os").environ.get("PTD_EIGH_STREAMS", "3")))
+    streams_wanted = min(3, int(__import__("os").environ.get("PTD_EIGH_STREAMS", "3"))) if by_route == "0" else 1
     assert len(calls) == 3 and all(c[2:] == (4096, 1024) for c in calls)
     assert len({c[0] for c in calls}) == streams_wanted and len({c[1] for c in calls}) == streams_wanted
-    # the route the solver takes for these matrices (decided from the matrix alone): filtered subspace iteration
+    if by_route == "1":
+        assert {c[0] for c in calls} == {threading.get_ident()}      # on the caller's own thread and stream
+    # the route the solver takes for these matrices (decided from the matrix alone): filtered subspace iteration for
+    # at least the first two layers
     ops.EIGH_PROFILE = []
     try:
-        real_eigh(*kept[0])
-        assert ops.EIGH_PROFILE[0]["method"] == 3
+        for args in kept:
+            real_eigh(*args)
+        assert sum(p["method"] == 3 for p in ops.EIGH_PROFILE) >= 2, [p["method"] for p in ops.EIGH_PROFILE]
     finally:
         ops.EIGH_PROFILE = None
+    del kept
 
     assert len(ref_trace) == 3 * 6
     assert [(t["layer"], t["rank"], t["accepted"]) for t in trace] == \
