@@ -551,18 +551,20 @@ def run_concurrently(jobs, device: torch.device, max_streams: Optional[int] = No
     no shared mutable state and releases the GIL, so the host side is plain threads.  Stream order:
     every side stream first waits for the caller's stream (inputs), the caller's stream waits for all
     of them at the end (outputs).  PTD_EIGH_STREAMS overrides the stream count (1 = sequential).  `routes` (one
-    ptd_eigh_route value per job): see the comment below; PTD_EIGH_STREAMS_BY_ROUTE=0 ignores it."""
+    ptd_eigh_route value per job): only read with PTD_EIGH_STREAMS_BY_ROUTE=1, see the comment below."""
     import os
     import threading
 
     jobs = list(jobs)
     device = torch.device(device)
     want = int(os.environ.get("PTD_EIGH_STREAMS", "3")) if max_streams is None else max_streams
-    if routes is not None and want > 1 and device.type == "cuda" and os.environ.get("PTD_EIGH_STREAMS_BY_ROUTE", "1") != "0":
-        # the jobs the filtered route will take run one after the other on the caller's stream (with the whole chip, and
-        # with the resident kernels of their inner eigenproblem); only the latency-bound ones share the chip
-        # (profiles/streams_r04.json: three filtered chains side by side 137-180 ms, back to back 148; the Llama block's
-        # direct-route layers 1.1 x faster on three streams)
+    if routes is not None and want > 1 and device.type == "cuda" and os.environ.get("PTD_EIGH_STREAMS_BY_ROUTE", "0") == "1":
+        # OPT-IN (PTD_EIGH_STREAMS_BY_ROUTE=1): the jobs the filtered route will take run one after the other on the
+        # caller's stream (with the whole chip, and with the resident kernels of their inner eigenproblem); only the
+        # latency-bound ones share the chip.  Measured and NOT the default (profiles/streams_r04.json): three filtered
+        # chains back to back 171 ms, on three streams 137-181; the 2-block Llama stack 668-681 ms with this rule
+        # against 583-622 with every chain on its own stream -- the latency-bound phases of a filtered chain (Lanczos,
+        # the Cholesky sweeps, the Rayleigh-Ritz eigenproblem) do overlap with another chain's products.
         alone = [i for i, r in enumerate(routes) if r == 3]
         if alone:
             rest = [i for i in range(len(jobs)) if routes[i] != 3]

@@ -353,7 +353,11 @@ NsrPlan nsr_plan_vec(int64_t R, int64_t C, int vec) {
   p.Ct = 64 * vec;
   p.Rt = 4;
   p.coltiles = (int)ceil_div(C, p.Ct);
-  static const int blocks = [] { const char* e = getenv("PTD_NSR_BLOCKS"); return e ? std::max(1, atoi(e)) : 1024; }();
+  // rows of 64 KiB and more (vocabulary-sized logits): the blocks that run side by side should be COLUMN neighbours --
+  // together they sweep whole rows -- so few row chunks (2048 x 128256 bf16: 170 us with 251 blocks, 216 with 2008);
+  // narrow rows (the 4096-wide C2 logits) want more blocks in flight
+  static const int forced = [] { const char* e = getenv("PTD_NSR_BLOCKS"); return e ? std::max(1, atoi(e)) : 0; }();
+  const int blocks = forced ? forced : (C * (16 / vec) >= 65536 ? 256 : 1024);
   const int64_t want = std::max<int64_t>(1, blocks / p.coltiles);
   p.nchunk = (int)std::max<int64_t>(1, std::min<int64_t>(want, ceil_div(R, 32)));
   p.rows_per_chunk = ceil_div(R, p.nchunk);

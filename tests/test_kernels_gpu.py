@@ -500,7 +500,8 @@ def test_eigh_filtered_route_declines_where_it_does_not_apply(ops, monkeypatch):
 
 
 def test_eigh_filtered_route_backs_off_after_a_late_decline(ops, monkeypatch):
-    """A decline AFTER products were spent (here: a residual bound no attempt can meet, PTD_EIGH_FILTER_TOL = 1e-18) is
+    """A decline AFTER products were spent (here: a residual bound no attempt can meet, PTD_EIGH_FILTER_TOL = 1e-18 with
+    a forced degree) is
     remembered per (device, n, k): the next request of that shape goes straight to the direct route, the one after
     that tries the filter again (back-off 1, 2, 4, ... requests; a success resets it)."""
     monkeypatch.setenv("PTD_EIGH_FILTER_BACKOFF", "1")
@@ -509,10 +510,12 @@ def test_eigh_filtered_route_backs_off_after_a_late_decline(ops, monkeypatch):
     w_ref = torch.linalg.eigvalsh(a.cpu())
     assert _profiled_eigh(ops, monkeypatch, a, k)[2]["method"] == 3
     monkeypatch.setenv("PTD_EIGH_FILTER_TOL", "1e-18")
+    monkeypatch.setenv("PTD_EIGH_FILTER_FORCE_DEGREE", "6")     # (so that the degree estimate does not decline up front)
     w, v, prof = _profiled_eigh(ops, monkeypatch, a, k)
     assert prof["method"] != 3                                # declined late, answered by the direct route
     assert (w[n - k:] - w_ref[n - k:]).abs().max().item() <= 1e-11 * w_ref.abs().max().item()
     monkeypatch.delenv("PTD_EIGH_FILTER_TOL")
+    monkeypatch.delenv("PTD_EIGH_FILTER_FORCE_DEGREE")
     assert _profiled_eigh(ops, monkeypatch, a, k)[2]["method"] != 3        # skipped once ...
     assert _profiled_eigh(ops, monkeypatch, a, k)[2]["method"] == 3        # ... then tried again, and it works
     assert _profiled_eigh(ops, monkeypatch, a, k)[2]["method"] == 3

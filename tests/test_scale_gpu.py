@@ -430,8 +430,8 @@ def test_dwain_three_layer_stack_concurrent_filtered_chains_match_oracle(monkeyp
     """The DEFAULT path of every multi-layer split (dwain.py:580-633 + 333-537): three nn.Linear(4096, 4096) in ONE
     precompute split, so their three eigendecompositions -- each the filtered subspace iteration, each with its own
     host-side decisions and two stream synchronisations -- run as three concurrent chains on three HIP streams
-    (_engine.run_concurrently) with PTD_EIGH_STREAMS_BY_ROUTE=0, and one after the other on the caller's stream by
-    default (round 4: chains the filtered route will take fill the chip on their own) -- against the CPU oracle on the
+    (_engine.run_concurrently; the default), and one after the other on the caller's stream with the opt-in rule
+    PTD_EIGH_STREAMS_BY_ROUTE=1 (chains the filtered route will take run alone) -- against the CPU oracle on the
     same seeded inputs: identical (layer, rank, accepted) decisions, nsr / ppl within 1e-4, factor products within 1e-4
     (Frobenius), outputs 1e-4.  The test also asserts on which threads / streams the three calls ran and that the
     solver's route for these matrices is the filtered one (the deepest layer's flatter spectrum may decline it)."""

@@ -81,8 +81,9 @@ if "streams" in what:
     with torch.no_grad():
         bt = [{"x": x, "targets": stack({"x": x}).argmax(-1)} for x in xs]
     from ptdeco_amd import _engine as eng
-    for streams in (1, 2, 3, 1, 2, 3):
+    for streams, by_route in ((1, "0"), (2, "0"), (3, "0"), (3, "1"), (1, "0"), (2, "0"), (3, "0"), (3, "1")):
         os.environ["PTD_EIGH_STREAMS"] = str(streams)
+        os.environ["PTD_EIGH_STREAMS_BY_ROUTE"] = by_route
         def chain3():
             m = copy.deepcopy(model)
             return ptdeco_amd.dwain.decompose_in_place(module=m, device=dev, data_iterator=itertools.cycle(data), loss_fn=bench.ce_loss,
@@ -99,7 +100,7 @@ if "streams" in what:
             eng.PHASES = eng.PhaseTimer()
             t0 = time.perf_counter(); fn(); torch.cuda.synchronize(); dt = time.perf_counter() - t0
             ph, eng.PHASES = eng.PHASES.totals_ms(), None
-            line = {"workload": name, "streams": streams, "seconds": dt, "B_eigh_ms": ph.get("B_eigh"), "A_ms": ph.get("A_accumulate"), "D_ms": ph.get("D_metrics")}
+            line = {"workload": name, "streams": streams, "filtered_chains_alone": by_route == "1", "seconds": dt, "B_eigh_ms": ph.get("B_eigh"), "A_ms": ph.get("A_accumulate"), "D_ms": ph.get("D_metrics")}
             print(json.dumps(line), file=sys.stderr, flush=True)
             res.append(line)
     out["streams"] = res
