@@ -9,6 +9,16 @@ import ptdeco_amd
 dev = torch.device("cuda", 0)
 blocks = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 dtype = torch.bfloat16 if "bf16" in sys.argv else torch.float32
+
+
+def opt(name, default):
+    return float(sys.argv[sys.argv.index(name) + 1]) if name in sys.argv else default
+
+
+# thresholds of the rank search (library defaults 0.5 / 0.1: on a random-weight stack nothing passes them; a layer's
+# share of the parameters shrinks with the depth, so --trade-off scales with the number of blocks when asked to)
+trade_off = opt("--trade-off", 0.5)
+max_ppl = opt("--max-ppl", 0.1)
 D, KV, FF = 4096, 1024, 14336
 
 
@@ -73,6 +83,7 @@ threading.Thread(target=heartbeat, daemon=True).start()
 cfg = ptdeco_amd.dwain.decompose_in_place(
     module=model, device=dev, data_iterator=itertools.cycle(bt), loss_fn=ce, metric_iterator=itertools.cycle(bt[8:]),
     num_data_steps=8, num_metric_steps=2, nsr_final_threshold=1.0, finetune_fn=lambda m, d, n: m,
+    trade_off_factor=trade_off, max_accepted_ppl_diff=max_ppl,
     blacklisted_module_names=["head"], precomputing_covariance_num_splits=4, trace=trace)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
@@ -86,5 +97,7 @@ print(json.dumps({"workload": f"dwain.decompose_in_place, Llama-3-8B-shaped stac
                               "4096 / 1024 / 14336 + blacklisted head, [1, 2048, 4096] calibration batches, D = 8, M = 2, "
                               "precomputing_covariance_num_splits = 4, f64 covariance + eigh, one MI355X",
                   "phases_ms": phases, "blocks": blocks, "dtype": str(dtype), "layers": layers, "seconds": dt, "layers_per_s": layers / dt,
-                  "candidates_evaluated": len(trace), "decomposed": {k: v["__meta__"]["proportion"] for k, v in cfg.items()},
+                  "trade_off_factor": trade_off, "max_accepted_ppl_diff": max_ppl,
+                  "candidates_evaluated": len(trace), "layers_replaced": len(cfg),
+                  "decomposed": {k: v["__meta__"]["proportion"] for k, v in cfg.items()},
                   "max_mem_gb": torch.cuda.max_memory_allocated() / 2**30}))
