@@ -1838,7 +1838,6 @@ __global__ __launch_bounds__(256) void tridiag_chain_mgs_kernel(const double* __
 // so that the back-transformation of a panel is  Y -= V_p^T (TV_p Y): two products instead of a Gram
 // product, a product, a triangular solve and a product.
 constexpr int GCH = 512;  // columns of V_p per wy_gram workgroup
-constexpr int WY_GP = 4;   // panels applied as one block reflector in the back-transformation
 
 __global__ __launch_bounds__(256) void wy_gram_kernel(const double* __restrict__ Vall, int64_t ld, int n,
                                                       double* __restrict__ Gpart, int nchunks) {
@@ -1919,10 +1918,8 @@ __global__ __launch_bounds__(256) void wy_tv_kernel(const double* __restrict__ V
   __shared__ double Ts[NB][NB + 1];
   __shared__ double Vs[NB][129];
   const int panel = blockIdx.y, tid = threadIdx.x;
-  // (from the first column of the panel's GROUP of WY_GP panels on: the reflectors are zero in front of their own
-  // panel, and so is T V -- written here as zeros, so that a group can be applied as ONE block reflector whose rows
-  // all start at the same, 256-aligned column)
-  const int c0 = (panel / WY_GP) * WY_GP * NB + blockIdx.x * 128;
+  const int r0 = panel * NB + 1;
+  const int c0 = r0 + blockIdx.x * 128;
   if (c0 >= n) return;
   const double* Vp = Vall + (int64_t)panel * NB * ld;
   for (int e = tid; e < NB * NB; e += 256) Ts[e >> 6][e & 63] = Tall[(int64_t)panel * NB * NB + e];
@@ -1946,171 +1943,6 @@ __global__ __launch_bounds__(256) void wy_tv_kernel(const double* __restrict__ V
     out[(int64_t)i0 * ld] = s0; out[(int64_t)(i0 + 1) * ld] = s1;
     out[(int64_t)(i0 + 2) * ld] = s2; out[(int64_t)(i0 + 3) * ld] = s3;
   }
-}
-
-// ---- groups of WY_GP = 4 panels as ONE block reflector of up to 256 rows (round 4) ----
-// Q_a Q_b Q_c Q_d = I - V_g^T T_g V_g with V_g the 256 reflector rows of the group and T_g^-1 = striu(V_g V_g^T) +
-// diag(1 / tau) -- the same formula at four times the width.  T_g is block upper triangular: its diagonal blocks are the
-// panels' own T_ii (wy_tfactor), the others follow from the cross Gram matrices G_ij = V_i V_j^T (i < j) by
-//   T_ij = - T_ii sum_{k = i+1 .. j} G_ik T_kj,
-// and T_g V_g = (T_ii V_i + sum_{j > i} T_ij V_j)_i.  The back-transformation then makes 16 passes over Y instead of 64
-// (the two products per pass are 256 deep / 256 tall and start at a 256-aligned row: the LDS-DMA f64 kernel takes them,
-// gemm_f64.hip), n = 4096, k = 2048: 4.9 -> ~2 ms.
-constexpr int WY_PAIRS = WY_GP * (WY_GP - 1) / 2;
-__constant__ int WY_PI[WY_PAIRS] = {0, 0, 0, 1, 1, 2};
-__constant__ int WY_PJ[WY_PAIRS] = {1, 2, 3, 2, 3, 3};
-
-// partial cross Gram matrices: Gx[(group * 6 + pair) * nchunks + chunk] = V_i V_j^T over the chunk's columns
-__global__ __launch_bounds__(256) void wy_gram_cross_kernel(const double* __restrict__ Vall, int64_t ld, int n,
-                                                            int npanels, double* __restrict__ Gx, int nchunks) {
-  __shared__ double Va[NB][65];
-  __shared__ double Vb[NB][65];
-  const int gp = blockIdx.y / WY_PAIRS, pr = blockIdx.y % WY_PAIRS, chunk = blockIdx.x, tid = threadIdx.x;
-  const int pi = WY_GP * gp + WY_PI[pr], pj = WY_GP * gp + WY_PJ[pr];
-  if (pj >= npanels) return;                                   // (never read)
-  const double* Vi = Vall + (int64_t)pi * NB * ld;
-  const double* Vj = Vall + (int64_t)pj * NB * ld;
-  const int ti = tid >> 4, tj = tid & 15;
-  double acc[4][4];
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
-  const int cbeg = pj * NB + 1 + chunk * GCH, cend = min(n, cbeg + GCH);   // V_j is zero in front of its panel
-  for (int c0 = cbeg; c0 < cend; c0 += 64) {
-    for (int e = tid; e < NB * 64; e += 256) {
-      const int r = e >> 6, c = e & 63;
-      const bool ok = c0 + c < cend;
-      Va[r][c] = ok ? Vi[(int64_t)r * ld + c0 + c] : 0.0;
-      Vb[r][c] = ok ? Vj[(int64_t)r * ld + c0 + c] : 0.0;
-    }
-    __syncthreads();
-#pragma unroll 4
-    for (int c = 0; c < 64; ++c) {
-      double va[4], vb[4];
-#pragma unroll
-      for (int a = 0; a < 4; ++a) { va[a] = Va[4 * ti + a][c]; vb[a] = Vb[4 * tj + a][c]; }
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] += va[a] * vb[b];
-    }
-    __syncthreads();
-  }
-  double* out = Gx + ((int64_t)blockIdx.y * nchunks + chunk) * NB * NB;
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) out[(4 * ti + a) * NB + 4 * tj + b] = acc[a][b];
-}
-
-// acc += A B for 64 x 64 LDS tiles of pitch 65: thread (ti, tj) owns the 4 x 4 block at rows 4 ti, columns 4 tj
-__device__ __forceinline__ void wy_mm64(const double (*A)[65], const double (*B)[65], int ti, int tj, double (&acc)[4][4]) {
-#pragma unroll 4
-  for (int k = 0; k < NB; ++k) {
-    double a[4], b[4];
-#pragma unroll
-    for (int x = 0; x < 4; ++x) { a[x] = A[4 * ti + x][k]; b[x] = B[k][4 * tj + x]; }
-#pragma unroll
-    for (int x = 0; x < 4; ++x)
-#pragma unroll
-      for (int y = 0; y < 4; ++y) acc[x][y] += a[x] * b[y];
-  }
-}
-
-// the off-diagonal blocks of a group's T: Toff[group * 6 + pair] = T_ij (one workgroup per group)
-__global__ __launch_bounds__(256) void wy_toff_kernel(const double* __restrict__ Tall, const double* __restrict__ Gx,
-                                                      int nchunks, int npanels, double* __restrict__ Toff) {
-  __shared__ double A[NB][65];
-  __shared__ double B[NB][65];
-  const int gp = blockIdx.x, tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
-  const int np = min(WY_GP, npanels - WY_GP * gp);             // panels in this group
-  auto pair_of = [](int i, int j) { return i == 0 ? j - 1 : (i == 1 ? j + 1 : 5); };   // (0,1) (0,2) (0,3) (1,2) (1,3) (2,3)
-  auto load = [&](double (*dst)[65], const double* src) {      // a 64 x 64 row-major block
-    for (int e = tid; e < NB * NB; e += 256) dst[e >> 6][e & 63] = src[e];
-  };
-  auto load_gram = [&](double (*dst)[65], int i, int k) {      // G_ik: the chunk partials added in index order
-    const double* g = Gx + ((int64_t)(gp * WY_PAIRS + pair_of(i, k)) * nchunks) * NB * NB;
-    for (int e = tid; e < NB * NB; e += 256) {
-      double t = 0.0;
-      for (int c = 0; c < nchunks; ++c) t += g[(int64_t)c * NB * NB + e];
-      dst[e >> 6][e & 63] = t;
-    }
-  };
-  for (int dist = 1; dist < np; ++dist)
-    for (int i = 0; i + dist < np; ++i) {
-      const int j = i + dist;
-      double acc[4][4];
-#pragma unroll
-      for (int x = 0; x < 4; ++x)
-#pragma unroll
-        for (int y = 0; y < 4; ++y) acc[x][y] = 0.0;
-      for (int k = i + 1; k <= j; ++k) {                       // S = sum_k G_ik T_kj
-        __syncthreads();
-        load_gram(A, i, k);
-        load(B, k == j ? Tall + (int64_t)(WY_GP * gp + j) * NB * NB
-                       : Toff + (int64_t)(gp * WY_PAIRS + pair_of(k, j)) * NB * NB);
-        __syncthreads();
-        wy_mm64(A, B, ti, tj, acc);
-      }
-      __syncthreads();
-#pragma unroll
-      for (int x = 0; x < 4; ++x)
-#pragma unroll
-        for (int y = 0; y < 4; ++y) B[4 * ti + x][4 * tj + y] = acc[x][y];
-      load(A, Tall + (int64_t)(WY_GP * gp + i) * NB * NB);
-      __syncthreads();
-      double out[4][4];
-#pragma unroll
-      for (int x = 0; x < 4; ++x)
-#pragma unroll
-        for (int y = 0; y < 4; ++y) out[x][y] = 0.0;
-      wy_mm64(A, B, ti, tj, out);                              // T_ij = - T_ii S
-      double* dst = Toff + (int64_t)(gp * WY_PAIRS + pair_of(i, j)) * NB * NB;
-#pragma unroll
-      for (int x = 0; x < 4; ++x)
-#pragma unroll
-        for (int y = 0; y < 4; ++y) dst[(4 * ti + x) * NB + 4 * tj + y] = -out[x][y];
-      __threadfence_block();                                   // (read back by this workgroup for the longer distances)
-    }
-}
-
-// TV_i += sum_{j > i, same group} T_ij V_j on a chunk of 128 columns (after wy_tv_kernel has written T_ii V_i)
-__global__ __launch_bounds__(256) void wy_tv_cross_kernel(const double* __restrict__ Vall, int64_t ld, int n, int npanels,
-                                                          const double* __restrict__ Toff, double* __restrict__ TVall) {
-  __shared__ double Ts[NB][NB + 1];
-  __shared__ double Vs[NB][129];
-  const int panel = blockIdx.y, tid = threadIdx.x;
-  const int gp = panel / WY_GP, i = panel % WY_GP;
-  const int np = min(WY_GP, npanels - WY_GP * gp);
-  if (i + 1 >= np) return;                                     // the last panel of a group has nothing to add
-  const int c0 = gp * WY_GP * NB + blockIdx.x * 128;
-  if (c0 >= n) return;
-  const int c = tid & 127, half = tid >> 7;
-  double s[32];
-#pragma unroll
-  for (int r = 0; r < 32; ++r) s[r] = 0.0;
-  for (int j = i + 1; j < np; ++j) {
-    const int pr = i == 0 ? j - 1 : (i == 1 ? j + 1 : 5);
-    const double* Vj = Vall + (int64_t)(WY_GP * gp + j) * NB * ld;
-    __syncthreads();
-    for (int e = tid; e < NB * NB; e += 256) Ts[e >> 6][e & 63] = Toff[(int64_t)(gp * WY_PAIRS + pr) * NB * NB + e];
-    for (int e = tid; e < NB * 128; e += 256) {
-      const int r = e >> 7, cc = e & 127;
-      Vs[r][cc] = (c0 + cc < n) ? Vj[(int64_t)r * ld + c0 + cc] : 0.0;
-    }
-    __syncthreads();
-#pragma unroll 4
-    for (int q = 0; q < NB; ++q) {
-      const double v = Vs[q][c];
-#pragma unroll
-      for (int r = 0; r < 32; ++r) s[r] += Ts[half * 32 + r][q] * v;
-    }
-  }
-  if (c0 + c >= n) return;
-  double* out = TVall + (int64_t)panel * NB * ld + c0 + c;
-#pragma unroll
-  for (int r = 0; r < 32; ++r) out[(int64_t)(half * 32 + r) * ld] += s[r];
 }
 
 // T / ||T|| for the Sturm counts: ds = d / ||T||, es2 = (e / ||T||)^2 (bounds[3] = ||T|| from tridiag_bounds_kernel)
@@ -2568,40 +2400,6 @@ int tridiag_vectors_and_backtransform(const TridiagPlan& p, char* base, int nvec
     hipLaunchKernelGGL(wy_tv_kernel, dim3((unsigned)ceil_div(n, 128), (unsigned)p.npanels), dim3(256), 0, st, Vall, ld,
                        n, Tall, TVall);
     PTD_CHECK_LAUNCH("wy factors");
-  }
-  // groups of WY_GP panels as one block reflector (scratch in the dead inverse-iteration factors: off_u2 / off_u3 /
-  // off_lm are n^2 doubles each); PTD_EIGH_WY_GROUPS=0 keeps the panel-by-panel form below
-  static const bool no_groups = getenv("PTD_EIGH_WY_GROUPS") && atoi(getenv("PTD_EIGH_WY_GROUPS")) == 0;
-  const int ngroups = (int)ceil_div(p.npanels, WY_GP);
-  const int nchunks_x = (int)ceil_div(n, GCH);
-  const size_t scratch = (size_t)n * n * 8;
-  if (!no_groups && p.npanels >= 2 && (size_t)ngroups * WY_PAIRS * nchunks_x * NB * NB * 8 <= scratch &&
-      (size_t)WY_GP * NB * nvec * 8 <= scratch) {
-    double* W2g = reinterpret_cast<double*>(base + p.off_u2);
-    double* Gx = reinterpret_cast<double*>(base + p.off_u3);
-    double* Toff = reinterpret_cast<double*>(base + p.off_lm);
-    double* Tall = reinterpret_cast<double*>(base + p.off_tall);
-    hipLaunchKernelGGL(wy_gram_cross_kernel, dim3((unsigned)nchunks_x, (unsigned)(ngroups * WY_PAIRS)), dim3(256), 0, st,
-                       Vall, ld, n, p.npanels, Gx, nchunks_x);
-    hipLaunchKernelGGL(wy_toff_kernel, dim3((unsigned)ngroups), dim3(256), 0, st, Tall, Gx, nchunks_x, p.npanels, Toff);
-    hipLaunchKernelGGL(wy_tv_cross_kernel, dim3((unsigned)ceil_div(n, 128), (unsigned)p.npanels), dim3(256), 0, st, Vall,
-                       ld, n, p.npanels, Toff, TVall);
-    PTD_CHECK_LAUNCH("wy group factors");
-    for (int g = ngroups - 1; g >= 0; --g) {
-      const int c0 = g * WY_GP * NB;            // first column the group's reflectors may touch (they start at c0 + 1)
-      const int rows = std::min(WY_GP * NB, p.npanels * NB - c0);
-      const int mr = n - c0;
-      if (mr <= 1) continue;
-      const double* Vg = Vall + (size_t)g * WY_GP * NB * ld;
-      const double* TVg = TVall + (size_t)g * WY_GP * NB * ld;
-      PTD_CHECK_HIP(hipMemsetAsync(W2g, 0, (size_t)rows * nvec * 8, st));
-      int rc = gemm_f64(TVg + c0, ld, 1, Y + (int64_t)c0 * ldy, ldy, 1, W2g, nvec, rows, nvec, mr, 1.0, true, 16, st);
-      if (rc != PTD_OK) return rc;
-      rc = gemm_f64(Vg + c0, 1, ld, W2g, nvec, 1, Y + (int64_t)c0 * ldy, ldy, mr, nvec, rows, -1.0, true, 1, st);
-      if (rc != PTD_OK) return rc;
-    }
-    PTD_CHECK_LAUNCH("tridiag_backtransform (groups)");
-    return PTD_OK;
   }
   for (int pn = p.npanels - 1; pn >= 0; --pn) {
     const int j0 = pn * NB;
