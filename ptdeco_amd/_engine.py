@@ -388,10 +388,13 @@ class SharedInputPool:
     D >= ~32 calibration steps of real runs; with a handful of steps y^T y is cheaper)."""
 
     # Tunables of the "auto" decision only (which of two equivalent routes is cheaper; results agree to f64
-    # rounding either way): rates of the covariance SYRK (f32 in, f64 accumulate) and of the f64 MFMA GEMM as
-    # bench.py / profiles/ report them on MI355X.  PTD_SHARE_RATE_SYRK_TFLOPS / PTD_SHARE_RATE_F64_TFLOPS override.
-    RATE_F32 = 100e12
-    RATE_F64 = 45e12
+    # rounding either way): MEASURED rates on MI355X of the covariance SYRK with an f64 accumulator (on the triangle's
+    # T n (n + 1) flops: f32 activations 104-109 TFLOP/s, bf16 490-620 at the calibration shapes -- bench.py `kernels`,
+    # profiles/pmc_syrk_r04.json) and of the f64 products W Ex W^T on the LDS-DMA kernel (55-64 TFLOP/s at these
+    # shapes, profiles/f64_gemm_probe_r03.json).  PTD_SHARE_RATE_SYRK_TFLOPS / PTD_SHARE_RATE_F64_TFLOPS override.
+    RATE_F32 = 105e12
+    RATE_BF16 = 550e12
+    RATE_F64 = 55e12
 
     def __init__(self, num_data_steps: int, float64: bool, device: torch.device, mode: Optional[str] = None):
         import os
@@ -400,7 +403,9 @@ class SharedInputPool:
         if self.mode not in ("off", "all", "auto"):
             raise ValueError(f"PTD_SHARE_INPUT_COVARIANCE={self.mode!r}: expected off, all or auto")
         self.num_data_steps, self.float64, self.device = num_data_steps, float64, device
-        self.rate_syrk = float(os.environ.get("PTD_SHARE_RATE_SYRK_TFLOPS", self.RATE_F32 / 1e12)) * 1e12
+        forced = os.environ.get("PTD_SHARE_RATE_SYRK_TFLOPS")
+        self.rate_syrk = {torch.bfloat16: float(forced) * 1e12 if forced else self.RATE_BF16}
+        self.rate_syrk_default = float(forced) * 1e12 if forced else self.RATE_F32
         self.rate_f64 = float(os.environ.get("PTD_SHARE_RATE_F64_TFLOPS", self.RATE_F64 / 1e12)) * 1e12
         self.members: list = []
         self.discovered = False
@@ -476,7 +481,8 @@ class SharedInputPool:
         wide = [m for m in members if _input_route_wanted(m.weight.shape[0], n_in, m.top_k)]
         rest = [m for m in members if m not in wide]
         d = self.num_data_steps
-        direct = {id(m): d * t_rows * m.weight.shape[0] ** 2 / self.rate_syrk for m in rest}
+        rate = self.rate_syrk.get(members[0].weight.dtype, self.rate_syrk_default)   # (activations come in the weight dtype)
+        direct = {id(m): d * t_rows * m.weight.shape[0] ** 2 / rate for m in rest}
         explicit = {id(m): (2.0 * m.weight.shape[0] * n_in * n_in + 2.0 * m.weight.shape[0] ** 2 * n_in) / self.rate_f64
                     for m in rest}
         if self.mode == "off" or len(members) < 2:
@@ -486,7 +492,7 @@ class SharedInputPool:
         else:
             shared_wide = wide if len(wide) >= 2 or (wide and rest) else []
             gain = [m for m in rest if explicit[id(m)] < direct[id(m)]]
-            moment_cost = 0.0 if shared_wide else d * t_rows * n_in * n_in / self.rate_syrk
+            moment_cost = 0.0 if shared_wide else d * t_rows * n_in * n_in / rate
             saved = sum(direct[id(m)] - explicit[id(m)] for m in gain)
             shared_rest = gain if (gain and saved > moment_cost and (shared_wide or len(gain) >= 2 or wide)) else []
             if shared_rest and not shared_wide:

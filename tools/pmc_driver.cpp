@@ -55,6 +55,38 @@ static int run_mfma() {
   return 0;
 }
 
+// mode "syrk": the bf16 covariance product (f64 accumulator) at n = T = 4096 and at the Llama-3-8B calibration shapes
+// (T = 2048 tokens per step; n = 4096: q / o / down outputs and the shared input moment of gate / up, n = 1024: k / v,
+// n = 14336: the output side of gate / up, which the factored route never forms), three launches per shape in this
+// order -- tools/pmc_syrk_summary.py groups the dispatches by it
+static int run_syrk() {
+  const int64_t shapes[4][2] = {{4096, 4096}, {4096, 2048}, {1024, 2048}, {14336, 2048}};
+  int64_t maxy = 0, maxn = 0;
+  for (auto& sh : shapes) { maxy = sh[0] * sh[1] > maxy ? sh[0] * sh[1] : maxy; maxn = sh[0] > maxn ? sh[0] : maxn; }
+  std::vector<unsigned short> hb((size_t)maxy);
+  unsigned long long s = 0x9E3779B97F4A7C15ull;
+  for (auto& v : hb) {
+    s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+    const float f = (float)((double)(s >> 11) * (2.0 / 9007199254740992.0) - 1.0);
+    unsigned u; memcpy(&u, &f, 4);
+    v = (unsigned short)((u + 0x7FFF + ((u >> 16) & 1)) >> 16);
+  }
+  unsigned short* Y; double* E;
+  if (hipMalloc(&Y, maxy * 2) || hipMalloc(&E, maxn * maxn * 8)) return 2;
+  (void)hipMemcpy(Y, hb.data(), maxy * 2, hipMemcpyHostToDevice);
+  (void)hipMemset(E, 0, maxn * maxn * 8);
+  for (auto& sh : shapes) {
+    const int64_t n = sh[0], T = sh[1];
+    for (int r = 0; r < 3; ++r) {
+      const int rc = ptd_syrk_accumulate(Y, T, n, n, PTD_BF16, E, n, PTD_F64, 1.0 / (double)T, nullptr);
+      if (rc) { fprintf(stderr, "syrk mode rc=%d: %s\n", rc, ptd_last_error()); return 1; }
+    }
+  }
+  (void)hipDeviceSynchronize();
+  printf("syrk mode done\n");
+  return 0;
+}
+
 // mode "eigh": ptd_eigh_topk(n = 4096, k = 1024, top-k only) on a covariance with a decaying spectrum -- the filtered
 // subspace-iteration route -- for counter passes over its dominant kernel:
 //   rocprofv3 --pmc FETCH_SIZE --kernel-include-regex gemm_f64_glds --kernel-trace --output-format csv -d out -- tools/pmc_driver eigh
@@ -91,6 +123,7 @@ static int run_eigh() {
 int main(int argc, char** argv) {
   if (argc > 1 && !strcmp(argv[1], "mfma")) return run_mfma();
   if (argc > 1 && !strcmp(argv[1], "eigh")) return run_eigh();
+  if (argc > 1 && !strcmp(argv[1], "syrk")) return run_syrk();
   const int64_t n = argc > 1 ? atoll(argv[1]) : 4096;
   const int reps = argc > 2 ? atoi(argv[2]) : 1;
   std::vector<double> h((size_t)n * n);

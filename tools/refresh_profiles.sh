@@ -37,6 +37,10 @@ if [ "$PART" = all ] || [ "$PART" = pmc ]; then
   done
   timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-include-regex "syrk|gemm" --kernel-trace --output-format csv -d $G/gpurun_out/pmc_mfma -- $G/tools/pmc_driver mfma > $G/gpurun_out/pmc_mfma.log 2>&1; echo "pmc_mfma rc=$?"
   timeout -k 10 300 rocprofv3 --pmc MfmaUtil --kernel-include-regex "syrk|gemm" --kernel-trace --output-format csv -d $G/gpurun_out/pmc_mfma2 -- $G/tools/pmc_driver mfma > $G/gpurun_out/pmc_mfma2.log 2>&1; echo "pmc_mfma2 rc=$?"
+  # the bf16 covariance product at n = T = 4096 and at the Llama-3-8B calibration shapes (tools/pmc_syrk_summary.py)
+  for ctr in MfmaUtil FETCH_SIZE WRITE_SIZE; do
+    timeout -k 10 300 rocprofv3 --pmc $ctr --kernel-include-regex syrk --kernel-trace --output-format csv -d $G/gpurun_out/pmcs_$ctr -- $G/tools/pmc_driver syrk > $G/gpurun_out/pmcs_$ctr.log 2>&1; echo "pmcs_$ctr rc=$?"
+  done
   # the dominant kernel of the default eigensolver route (filtered subspace iteration): the product C X
   for c in FETCH_SIZE:pmcf_fetch WRITE_SIZE:pmcf_write "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE":pmcf_mfma; do
     ctr=${c%%:*}; dir=${c##*:}
