@@ -523,6 +523,8 @@ def main():
     ap.add_argument("--no-bf16-stack", action="store_true", help="skip the second (bf16 model) timed run")
     ap.add_argument("--no-weak-family", action="store_true", help="N > 1: skip the round-3 family (N layers on N GPUs)")
     ap.add_argument("--no-c4", action="store_true", help="skip the Llama-3-8B shape / block extras")
+    ap.add_argument("--workload", choices=("stack", "c2"), default="stack",
+                    help="c2: time BASELINE configs[1] alone (one layer; for kernel traces); default: the fixed stack")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -605,6 +607,21 @@ def main():
     def kept(cfg):
         return {k: v["__meta__"]["proportion"] for k, v in cfg.items()}
 
+    if args.workload == "c2":
+        # profiling aid: BASELINE configs[1] alone under the same protocol (python bench.py --workload c2 --no-extras)
+        c2 = build(1, D_STEPS)
+        dt, cfg, marks = timed(family(c2, torch.float32))
+        if rank == 0:
+            print(json.dumps({"metric": "layers decomposed/sec (incl. covariance+SVD)", "value": args.steps / dt,
+                              "unit": "layers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "ms_per_step": dt / args.steps * 1e3, "step_ms": marks, "higher_is_better": True,
+                              "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                              "config": {"workload": "BASELINE configs[1]: dwain decompose_in_place of ONE "
+                                                     "nn.Linear(4096,4096) f32 (--workload c2)", "ranks_kept": kept(cfg)}}))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     stack = build(STACK_LAYERS, STACK_D_STEPS)
     stack_step = family(stack, torch.float32)
     dt, cfg, marks = timed(stack_step)

@@ -13,7 +13,24 @@ if [ "$PART" = all ] || [ "$PART" = main ] || [ "$PART" = bench ]; then
   timeout -k 10 500 python bench.py --steps 5 --warmup 1 > gpurun_out/bench_r$R.json 2> gpurun_out/bench_r$R.err; echo "bench rc=$?"
   cut -c1-200 gpurun_out/bench_r$R.json
   rm -rf $GRAFT_REPO_ROOT/gpurun_out/prof_r$R   # (earlier runs leave PID-named files beside the new ones)
-  (cd /tmp && export TMPDIR=/tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_r$R -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-extras > $GRAFT_REPO_ROOT/gpurun_out/prof_r$R.log 2>&1); echo "rocprof rc=$?"
+  (cd /tmp && export TMPDIR=/tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_r$R -- python3 $GRAFT_REPO_ROOT/bench.py --workload c2 --steps 3 --warmup 1 --no-extras > $GRAFT_REPO_ROOT/gpurun_out/prof_r$R.log 2>&1); echo "rocprof rc=$?"
+  # the dominant kernel's launches split by duration (the long C X products / the shorter X W ones), then drop the raw
+  # trace: gpurun copies back at most 64 MiB
+  python3 - <<PY
+import csv, glob, json
+f = glob.glob("gpurun_out/prof_r$R/*/*kernel_trace.csv")
+if f:
+    rows = [r for r in csv.DictReader(open(f[0])) if "gemm_f64_glds_kernel<5, false>" in r["Kernel_Name"]]
+    us = sorted((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3 for r in rows)
+    long_ = [u for u in us if u > 400.0]
+    short = [u for u in us if u <= 400.0]
+    json.dump({"kernel": "gemm_f64_glds_kernel<5, false>", "launches": len(us), "long_launches_K4096": len(long_),
+               "long_avg_us": sum(long_) / max(len(long_), 1), "short_launches": len(short),
+               "short_avg_us": sum(short) / max(len(short), 1),
+               "source": "rocprofv3 --kernel-trace of python bench.py --workload c2 --steps 3 --warmup 1 --no-extras"},
+              open("gpurun_out/roofline_kernel_split_r$R.json", "w"), indent=1)
+PY
+  rm -f gpurun_out/prof_r$R/*/*kernel_trace.csv
 fi
 if [ "$PART" = all ] || [ "$PART" = c4 ] || [ "$PART" = c4gpu ]; then
   timeout -k 10 300 python tools/c4_shapes.py > gpurun_out/c4_f32_r$R.json 2> gpurun_out/c4_f32.err; echo "c4 f32 rc=$?"
