@@ -2,7 +2,7 @@
 calibration shapes, three launches per shape) into profiles/pmc_syrk_rNN.json: per shape the launch time from the kernel
 trace, the matrix-pipe busy share, the memory-side bytes (2 x FETCH_SIZE + WRITE_SIZE, x 1024: MI355X_MICROARCH.md) and
 both roofs -- the MFMA peak on the triangle's flops and the HBM peak on y once + the live triangle of E read and written.
-  for c in MfmaUtil FETCH_SIZE WRITE_SIZE: rocprofv3 --pmc $c --kernel-include-regex syrk --kernel-trace --output-format csv -d gpurun_out/pmcs_$c -- tools/pmc_driver syrk
+  for c in MfmaUtil FETCH_SIZE WRITE_SIZE: rocprofv3 --pmc $c --kernel-include-regex 'syrk|gemm_bf16' --kernel-trace --output-format csv -d gpurun_out/pmcs_$c -- tools/pmc_driver syrk
 Usage: python tools/pmc_syrk_summary.py 04"""
 import csv, glob, json, os, sys
 
@@ -20,7 +20,7 @@ def per_dispatch(d, counter):
     """counter value per syrk dispatch, in dispatch order (a kernel's value = the sum over its rows: one per XCD / SE)"""
     acc = {}
     for r in rows(d, "counter_collection.csv"):
-        if "syrk" not in r["Kernel_Name"] or r["Counter_Name"] != counter:
+        if not ("syrk" in r["Kernel_Name"] or "gemm_bf16" in r["Kernel_Name"]) or r["Counter_Name"] != counter:
             continue
         acc[int(r["Dispatch_Id"])] = acc.get(int(r["Dispatch_Id"]), 0.0) + float(r["Counter_Value"])
     return [acc[k] for k in sorted(acc)]
@@ -28,13 +28,14 @@ def per_dispatch(d, counter):
 
 def durations(d):
     t = [(int(r["Dispatch_Id"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3, r["Kernel_Name"])
-         for r in rows(d, "kernel_trace.csv") if "syrk" in r["Kernel_Name"]]
+         for r in rows(d, "kernel_trace.csv") if "syrk" in r["Kernel_Name"] or "gemm_bf16" in r["Kernel_Name"]]
     return sorted(t)
 
 
 mf, fe, wr = per_dispatch("pmcs_MfmaUtil", "MfmaUtil"), per_dispatch("pmcs_FETCH_SIZE", "FETCH_SIZE"), per_dispatch("pmcs_WRITE_SIZE", "WRITE_SIZE")
 du = durations("pmcs_MfmaUtil")
-out = {"command": "rocprofv3 --pmc <MfmaUtil | FETCH_SIZE | WRITE_SIZE> --kernel-include-regex syrk --kernel-trace --output-format csv -- "
+assert len(du) == 3 * len(shapes) == len(mf) == len(fe) == len(wr), (len(du), len(mf), len(fe), len(wr))   # one kernel per call
+out = {"command": "rocprofv3 --pmc <MfmaUtil | FETCH_SIZE | WRITE_SIZE> --kernel-include-regex 'syrk|gemm_bf16' --kernel-trace --output-format csv -- "
                   "tools/pmc_driver syrk (bf16 y, f64 accumulator, three launches per shape; separate passes per counter)",
        "note": "us = launch duration in the MfmaUtil pass (profiled clocks run a few per cent low); traffic = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 "
                "bytes per launch (gfx950: FETCH_SIZE counts half of a wide streaming read); algorithmic bytes = 2 T n (y once) + 8 n (n + 1) "

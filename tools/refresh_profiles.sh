@@ -56,11 +56,19 @@ if [ "$PART" = all ] || [ "$PART" = pmc ]; then
   timeout -k 10 300 rocprofv3 --pmc MfmaUtil --kernel-include-regex "syrk|gemm" --kernel-trace --output-format csv -d $G/gpurun_out/pmc_mfma2 -- $G/tools/pmc_driver mfma > $G/gpurun_out/pmc_mfma2.log 2>&1; echo "pmc_mfma2 rc=$?"
   # the bf16 covariance product at n = T = 4096 and at the Llama-3-8B calibration shapes (tools/pmc_syrk_summary.py)
   for ctr in MfmaUtil FETCH_SIZE WRITE_SIZE; do
-    timeout -k 10 300 rocprofv3 --pmc $ctr --kernel-include-regex syrk --kernel-trace --output-format csv -d $G/gpurun_out/pmcs_$ctr -- $G/tools/pmc_driver syrk > $G/gpurun_out/pmcs_$ctr.log 2>&1; echo "pmcs_$ctr rc=$?"
+    timeout -k 10 300 rocprofv3 --pmc $ctr --kernel-include-regex "syrk|gemm_bf16" --kernel-trace --output-format csv -d $G/gpurun_out/pmcs_$ctr -- $G/tools/pmc_driver syrk > $G/gpurun_out/pmcs_$ctr.log 2>&1; echo "pmcs_$ctr rc=$?"
   done
   # the dominant kernel of the default eigensolver route (filtered subspace iteration): the product C X
   for c in FETCH_SIZE:pmcf_fetch WRITE_SIZE:pmcf_write "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE":pmcf_mfma; do
     ctr=${c%%:*}; dir=${c##*:}
     timeout -k 10 300 rocprofv3 --pmc $ctr --kernel-include-regex gemm_f64_glds --kernel-trace --output-format csv -d $G/gpurun_out/$dir -- $G/tools/pmc_driver eigh > $G/gpurun_out/$dir.log 2>&1; echo "$dir rc=$?"
   done
+  # condense on the box (gpurun copies back at most 64 MiB: the raw counter tables stay here), summaries -> gpurun_out/
+  cd $G
+  python3 tools/pmc_summary.py $R > gpurun_out/pmc_summary.log 2>&1; echo "pmc_summary rc=$?"
+  python3 tools/pmc_mfma_summary.py $R > gpurun_out/pmc_mfma_summary.log 2>&1; echo "pmc_mfma_summary rc=$?"
+  python3 tools/pmc_syrk_summary.py $R > gpurun_out/pmc_syrk_summary.log 2>&1; echo "pmc_syrk_summary rc=$?"
+  python3 tools/pmc_filtered_summary.py $R > gpurun_out/pmc_filtered_summary.log 2>&1; echo "pmc_filtered_summary rc=$?"
+  mkdir -p gpurun_out/pmc_summaries_r$R && cp profiles/pmc_*_r$R.* gpurun_out/pmc_summaries_r$R/
+  rm -rf gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_tcc gpurun_out/pmc_mfma gpurun_out/pmc_mfma2 gpurun_out/pmcs_* gpurun_out/pmcf_*
 fi
