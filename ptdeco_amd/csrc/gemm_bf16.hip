@@ -307,26 +307,24 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 1) void gemm_bf16_nt_glds_kern
     stage(0, 0);
     __syncthreads();
   } else {
-#pragma unroll
-    for (int q = 0; q < NBUF - 1; ++q)
-      if (q < nk) stage(q, q);
+    stage(0, 0);
+    if (1 < nk) stage(1, 1);
+    if (2 < nk) stage(2, 2);
   }
-  int cur = 0;                                   // kt mod NBUF (NBUF = 5 is not a power of two)
-  for (int kt = 0; kt < nk; ++kt, cur = (cur + 1 == NBUF) ? 0 : cur + 1) {
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & (NBUF - 1);
     if (NBUF == 2) {
       if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
     } else {
-      // retire this wave's pieces of step kt (8 DMA instructions per step; NBUF - 2 younger steps may stay in
-      // flight), then the barrier: every piece of step kt has landed, and every wave has finished reading step kt - 1,
-      // whose buffer the stage below refills
-      const int ahead = min(NBUF - 2, nk - 1 - kt);
-      if (ahead >= 3) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-      else if (ahead == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-      else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      // retire this wave's pieces of step kt (8 DMA instructions per step), then the barrier: every
+      // piece of step kt has landed, and every wave has finished reading step kt - 1, whose buffer
+      // the stage below refills
+      if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      if (kt + NBUF - 1 < nk) stage(cur == 0 ? NBUF - 1 : cur - 1, kt + NBUF - 1);
+      if (kt + 3 < nk) stage((kt + 3) & 3, kt + 3);
     }
     const char* As = lds + cur * 32768;
     const char* Bs = As + 16384;
@@ -387,127 +385,6 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 1) void gemm_bf16_nt_glds_kern
     const int lr = q / CHUNKS, ch = q % CHUNKS;
     const f32x4 v = *reinterpret_cast<const f32x4*>(lds + lr * CP + ch * 16);
     char* dst = reinterpret_cast<char*>(a.C) + ((int64_t)blockIdx.y * a.cslab + (int64_t)(m0 + lr) * a.ldc + n0) * ES + ch * 16;
-    *reinterpret_cast<f32x4*>(dst) = v;
-  }
-}
-
-// ---- 64 x 256 tile on the same schedule: products with N = 256 and many rows (x A^T of the decomposed forward at
-// r = 256: 16384 x 256 x 4096).  With 128 x 128 tiles that product is 256 workgroups which each stream a 1-MB row panel
-// of x, and a CU takes in an HBM-missing stream at ~24 GB/s whatever it keeps in flight (a five-buffer ring changed
-// nothing; N = 128, with half the CUs idle, takes the same 43 us): 1 MB / 24 GB/s = 42 us.  Here a workgroup owns 64
-// rows and ALL 256 columns: 0.5 MB of x per CU from HBM, the whole of A (2 MB, shared by everyone, L2-resident) beside
-// it.  Four waves side by side, each 64 rows x 64 columns (2 x 2 MFMA blocks): the x image [64][64 k] (8 KiB) is read by
-// all four, the A image [256][64 k] (32 KiB) by quarters; four buffers = 160 KiB, three K steps in flight.
-template <int EPI>
-__global__ __launch_bounds__(256, 1) void gemm_bf16_nt_glds64_kernel(const GemmBf16Args a) {
-  constexpr int STEP = 8192 + 32768;             // bytes of one K step's images: x tile, then the A panel
-  __shared__ __attribute__((aligned(16))) char lds[4 * STEP];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // XCD-aware order: blocks b and b + 8 share an XCD; each XCD takes a contiguous run of row tiles
-  const int nwg = gridDim.x, bid = blockIdx.x;
-  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
-  const int ti = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  const int m0 = ti * 64;
-  const int nk = a.K / BK;
-  const unsigned short* Ag = a.A + (int64_t)m0 * a.sam;
-  const unsigned short* Bg = a.B;
-
-  const int srow = lane >> 3, spos = lane & 7;
-  auto stage = [&](int buf, int kt) {
-    char* As = lds + buf * STEP;
-    char* Bs = As + 8192;
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {                 // x: 64 rows = 8 pieces of 8 rows, two per wave
-      const int r0 = (wn * 2 + q) * 8, r = r0 + srow;
-      const int c = spos ^ ((r >> 1) & 7);
-      __builtin_amdgcn_global_load_lds((glb_void*)(Ag + (int64_t)r * a.sam + kt * BK + c * 8), (lds_void*)(As + r0 * 128), 16, 0, 0);
-    }
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {                 // A: 256 rows = 32 pieces, eight per wave
-      const int r0 = (wn * 8 + q) * 8, r = r0 + srow;
-      const int c = spos ^ ((r >> 1) & 7);
-      __builtin_amdgcn_global_load_lds((glb_void*)(Bg + (int64_t)r * a.sbn + kt * BK + c * 8), (lds_void*)(Bs + r0 * 128), 16, 0, 0);
-    }
-  };
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int fr = lane & 31, fh = lane >> 5;
-  stage(0, 0);
-  if (1 < nk) stage(1, 1);
-  if (2 < nk) stage(2, 2);
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 3;
-    // this wave's ten pieces of step kt retired (two younger steps may stay in flight), then the barrier: every piece
-    // of step kt has landed and every wave has finished reading step kt - 1, whose buffer the stage below refills
-    if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
-    else if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (kt + 3 < nk) stage((kt + 3) & 3, kt + 3);
-    const char* As = lds + cur * STEP;
-    const char* Bs = As + 8192;
-#pragma unroll
-    for (int kk = 0; kk < BK; kk += 16) {
-      const int c = (kk >> 3) + fh;
-      s16x8 af[2], bf[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int ra = i * 32 + fr, rb = wn * 64 + i * 32 + fr;
-        af[i] = *reinterpret_cast<const s16x8*>(As + ra * 128 + ((c ^ ((ra >> 1) & 7)) << 4));
-        bf[i] = *reinterpret_cast<const s16x8*>(Bs + rb * 128 + ((c ^ ((rb >> 1) & 7)) << 4));
-      }
-      // B fragment first: the accumulator is the transposed block (a lane holds one output row)
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[0], af[0], acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[1], af[0], acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[0], af[1], acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[1], af[1], acc[1][1], 0, 0, 0);
-    }
-  }
-  __syncthreads();    // the last reads, before the epilogue reuses the image
-
-  // epilogue through LDS as in gemm_bf16_nt_glds_kernel: a [64][256] tile, 16-byte row-contiguous global stores
-  constexpr int ES = (EPI == EPI_STORE_BF16) ? 2 : 4;
-  constexpr int CP = 256 * ES + 16;
-  static_assert(64 * (256 * 4 + 16) <= sizeof(lds), "C tile must fit the staging buffers");
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int lr = i * 32 + (lane & 31);
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int lc = wn * 64 + j * 32 + 8 * g + 4 * (lane >> 5);
-        float o[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          o[e] = a.alpha * acc[i][j][4 * g + e] + (a.bias ? bf16_to_f32(a.bias[lc + e]) : 0.f);
-        if (EPI == EPI_STORE_BF16) {
-          typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-          const u32x2 pk = {pack2_bf16(o[0], o[1]), pack2_bf16(o[2], o[3])};
-          *reinterpret_cast<u32x2*>(lds + lr * CP + lc * 2) = pk;
-        } else {
-          const f32x4 v = {o[0], o[1], o[2], o[3]};
-          *reinterpret_cast<f32x4*>(lds + lr * CP + lc * 4) = v;
-        }
-      }
-    }
-  __syncthreads();
-  constexpr int CHUNKS = 256 * ES / 16;
-#pragma unroll
-  for (int p = 0; p < 64 * CHUNKS / 256; ++p) {
-    const int q = tid + 256 * p;
-    const int lr = q / CHUNKS, ch = q % CHUNKS;
-    const f32x4 v = *reinterpret_cast<const f32x4*>(lds + lr * CP + ch * 16);
-    char* dst = reinterpret_cast<char*>(a.C) + ((int64_t)(m0 + lr) * a.ldc) * ES + ch * 16;
     *reinterpret_cast<f32x4*>(dst) = v;
   }
 }
@@ -2431,22 +2308,7 @@ int gemm_bf16(const unsigned short* A, int64_t sam, int64_t sak, const unsigned 
   }
   if (!no_glds && akc && bkc && a.vecA && a.vecB && c_vec && M % BM == 0 && N % BN == 0 && K % BK == 0 && K >= BK) {
     static const bool no_deep = getenv("PTD_GEMM_NO_DEEP") != nullptr;
-    // N = 256 and enough rows for one 64-row tile per CU: a workgroup takes 64 rows and all the columns
-    static const bool no_t64 = getenv("PTD_GEMM_NO_T64") != nullptr;
-    if (!no_t64 && N == 256 && M % 64 == 0 && M / 64 >= 192 && K >= 4 * BK) {
-      const dim3 g64((unsigned)(M / 64));
-      if (c_bf16) hipLaunchKernelGGL((gemm_bf16_nt_glds64_kernel<EPI_STORE_BF16>), g64, dim3(256), 0, st, a);
-      else hipLaunchKernelGGL((gemm_bf16_nt_glds64_kernel<EPI_STORE_F32>), g64, dim3(256), 0, st, a);
-      PTD_CHECK_LAUNCH("gemm_bf16 (64 x 256 tiles)");
-      return PTD_OK;
-    }
-    // (five buffers = all 160 KiB of LDS: four K steps, 128 KiB, in flight instead of three -- this product is bound by
-    // the bytes a CU keeps in flight; PTD_GEMM_DEEP=4 keeps the four-buffer ring)
-    static const int deep = [] { const char* e = getenv("PTD_GEMM_DEEP"); return e ? atoi(e) : 5; }();
-    if (grid.x <= 256 && K >= 8 * BK && !no_deep && deep == 5) {
-      if (c_bf16) hipLaunchKernelGGL((gemm_bf16_nt_glds_kernel<EPI_STORE_BF16, 5>), grid, dim3(256), 0, st, a);
-      else hipLaunchKernelGGL((gemm_bf16_nt_glds_kernel<EPI_STORE_F32, 5>), grid, dim3(256), 0, st, a);
-    } else if (grid.x <= 256 && K >= 4 * BK && !no_deep) {  // at most one workgroup per CU: deep prefetch
+    if (grid.x <= 256 && K >= 4 * BK && !no_deep) {  // at most one workgroup per CU: deep prefetch
       if (c_bf16) hipLaunchKernelGGL((gemm_bf16_nt_glds_kernel<EPI_STORE_BF16, 4>), grid, dim3(256), 0, st, a);
       else hipLaunchKernelGGL((gemm_bf16_nt_glds_kernel<EPI_STORE_F32, 4>), grid, dim3(256), 0, st, a);
     } else if (c_bf16) hipLaunchKernelGGL((gemm_bf16_nt_glds_kernel<EPI_STORE_BF16, 2>), grid, dim3(256), 0, st, a);
