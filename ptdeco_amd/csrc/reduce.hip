@@ -107,8 +107,11 @@ __global__ void colsum_kernel(const TY* __restrict__ Y, int64_t T, int n, int64_
 template <typename T>
 __global__ __launch_bounds__(256) void nsr_partial_kernel(const T* __restrict__ x, const T* __restrict__ y, int64_t R,
                                                           int64_t C, int Ct, int Rt, int64_t rows_per_chunk,
-                                                          double* __restrict__ part) {
+                                                          double* __restrict__ part, double* __restrict__ out) {
   __shared__ double sm[3][256];
+  // (a workspace that was never initialised leaves the final kernel without a last block: the result then stays NaN
+  // instead of whatever the caller's buffer held)
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) out[0] = __builtin_nan("");
   const int tid = threadIdx.x;
   const int cl = tid % Ct, rl = tid / Ct;
   const int64_t c = (int64_t)blockIdx.x * Ct + cl;
@@ -162,7 +165,8 @@ __device__ __forceinline__ void nsr_unpack<unsigned short, 8>(const uint4& q, do
 template <typename T, int V>
 __global__ __launch_bounds__(256) void nsr_partial_vec_kernel(const T* __restrict__ x, const T* __restrict__ y, int64_t R,
                                                               int64_t C, int64_t rows_per_chunk,
-                                                              double* __restrict__ part) {
+                                                              double* __restrict__ part, double* __restrict__ out) {
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) out[0] = __builtin_nan("");   // (see nsr_partial_kernel)
   constexpr int U = 32 / V;   // rows per trip: 8 (f32), 4 (bf16: eight channels a lane, twice the accumulators)
   __shared__ double sm[3][V][64];   // one quantity at a time: [row lane 1..3][channel of the lane][lane]
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -469,19 +473,19 @@ int nsr(const void* x, const void* y, int64_t R, int64_t C, int dtype, double ep
   if (use_vec) {
     if (dtype == PTD_F32)
       hipLaunchKernelGGL((nsr_partial_vec_kernel<float, 4>), grid, dim3(256), 0, st, (const float*)x, (const float*)y, R,
-                         C, p.rows_per_chunk, part);
+                         C, p.rows_per_chunk, part, out);
     else
       hipLaunchKernelGGL((nsr_partial_vec_kernel<unsigned short, 8>), grid, dim3(256), 0, st, (const unsigned short*)x,
-                         (const unsigned short*)y, R, C, p.rows_per_chunk, part);
+                         (const unsigned short*)y, R, C, p.rows_per_chunk, part, out);
   } else if (dtype == PTD_F32) {
     hipLaunchKernelGGL((nsr_partial_kernel<float>), grid, dim3(256), 0, st, (const float*)x, (const float*)y, R, C,
-                       p.Ct, p.Rt, p.rows_per_chunk, part);
+                       p.Ct, p.Rt, p.rows_per_chunk, part, out);
   } else if (dtype == PTD_BF16) {
     hipLaunchKernelGGL((nsr_partial_kernel<unsigned short>), grid, dim3(256), 0, st, (const unsigned short*)x,
-                       (const unsigned short*)y, R, C, p.Ct, p.Rt, p.rows_per_chunk, part);
+                       (const unsigned short*)y, R, C, p.Ct, p.Rt, p.rows_per_chunk, part, out);
   } else if (dtype == PTD_F64) {
     hipLaunchKernelGGL((nsr_partial_kernel<double>), grid, dim3(256), 0, st, (const double*)x, (const double*)y, R,
-                       C, p.Ct, p.Rt, p.rows_per_chunk, part);
+                       C, p.Ct, p.Rt, p.rows_per_chunk, part, out);
   } else {
     set_error("ptd_nsr: unsupported dtype");
     return PTD_ERR_UNSUPPORTED;

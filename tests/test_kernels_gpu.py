@@ -945,6 +945,36 @@ def test_nsr_random(ops, shape, chan, dtype):
     assert got == pytest.approx(ref, rel=1e-9)
 
 
+def test_nsr_workspace_contract(ops):
+    """ABI 2: a ptd_nsr workspace is initialised once (ptd_nsr_workspace_init) and then serves any number of calls, of
+    different shapes too; a workspace that was never initialised yields NaN, not a stale number."""
+    from ptdeco_amd import _hip
+
+    lib = _hip.load()
+    st = torch.cuda.current_stream().cuda_stream
+    out = torch.full((1,), 123.0, dtype=torch.float64, device=DEV)
+    ws = torch.full((max(lib.ptd_nsr_workspace_bytes(512, 1024), lib.ptd_nsr_workspace_bytes(64, 4096)),), 0xA5,
+                    dtype=torch.uint8, device=DEV)
+
+    def call(x, y):
+        r, c = x.shape
+        rc = lib.ptd_nsr(x.data_ptr(), y.data_ptr(), r, c, _hip.F32, 1e-3, out.data_ptr(), ws.data_ptr(), ws.numel(), st)
+        assert rc == 0
+        return out.item()
+
+    y1 = _rand((512, 1024), 5).to(DEV)
+    x1 = y1 + 0.1 * _rand((512, 1024), 6).to(DEV)
+    assert math.isnan(call(x1, y1))                       # garbage where the arrival counter lives
+    assert lib.ptd_nsr_workspace_init(ws.data_ptr(), ws.numel(), st) == 0
+    ref1 = orc.nsr(x=x1.cpu().double(), y=y1.cpu().double(), non_channel_dim=(0,)).item()
+    y2 = _rand((64, 4096), 7).to(DEV)
+    x2 = y2 + 0.2 * _rand((64, 4096), 8).to(DEV)
+    ref2 = orc.nsr(x=x2.cpu().double(), y=y2.cpu().double(), non_channel_dim=(0,)).item()
+    for _ in range(3):                                     # the same workspace, alternating shapes
+        assert call(x1, y1) == pytest.approx(ref1, rel=1e-9)
+        assert call(x2, y2) == pytest.approx(ref2, rel=1e-9)
+
+
 def test_sym_kl_golden(ops):
     z = gio.npz("metrics")
     s, t = gio.t(z["kl.s"]), gio.t(z["kl.t"])
