@@ -825,8 +825,9 @@ def main():
             # eigensolver on the same box and a covariance of the same workload (all n eigenpairs: it has no top-k)
             try:
                 e = torch.zeros(n, n, dtype=torch.float64, device=device)
-                for b in data32[:D_STEPS]:
-                    ops.syrk_accumulate(e, ops.matmul(b["x"].reshape(-1, N_FEAT), model32.layers[0].weight.T), 1.0 / (BATCH * SEQ))
+                ref_model, ref_data = (c2 if c2 is not None else stack)[:2]
+                for b in ref_data[:D_STEPS]:
+                    ops.syrk_accumulate(e, ops.matmul(b["x"].reshape(-1, N_FEAT), ref_model.layers[0].weight.T), 1.0 / (BATCH * SEQ))
                 c = ops.cov_finalize(e, D_STEPS, 0.01)
                 torch.linalg.eigh(c)
                 torch.cuda.synchronize()
