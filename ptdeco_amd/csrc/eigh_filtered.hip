@@ -1072,7 +1072,9 @@ int eigh_filtered(const double* A, int64_t lda, int64_t n, int64_t k, double* ev
   const double xk = (lam_k - cc) / ee;
   const double growth = xk + sqrt(xk * xk - 1.0);
   const double tol = env_double("PTD_EIGH_FILTER_TOL", 1e-10);     // residual / |lambda_max| accepted
-  const int max_products = (int)env_double("PTD_EIGH_FILTER_MAX_PRODUCTS", 24);
+  // (up to 32 products the filter still wins: 29 products at m = 1280 cost ~19 ms, six rounds of passes ~12 ms, the
+  // Rayleigh-Ritz problem and the rest ~11.5 -- 42 ms against 55 ms for the direct reduction at n = 4096, k = 1024)
+  const int max_products = (int)env_double("PTD_EIGH_FILTER_MAX_PRODUCTS", 32);
   // measured on covariance spectra: the residual falls like 0.05 g^-d with g about three quarters of the way from 1
   // to the asymptotic factor (rounds restart the polynomial; the neighbours of the cut grow a little as well)
   const double g_eff = 1.0 + 0.9 * (growth - 1.0);
@@ -1088,10 +1090,12 @@ int eigh_filtered(const double* A, int64_t lda, int64_t n, int64_t k, double* ev
   // A round multiplies cond(X) by about g_top^d, g_top the growth per product at the top of the spectrum (~150 on
   // covariance spectra: six products reach 1e13, which the shifted Cholesky-QR pass still takes; a spectrum with a wide
   // gap right below lambda_k grows by 1e4 and more per product and broke the pass down at four).  Rounds of at most
-  // dmax = floor(log 3e14 / log g_top) <= 6 products, the last one at most 4 (it sets the final accuracy).
+  // dmax = floor(log 2e13 / log g_top) <= 6 products, the last one at most 4 (it sets the final accuracy).
   const double x_top = (hi - cc) / ee;
   const double g_top = x_top + sqrt(std::max(x_top * x_top - 1.0, 0.0));
-  const int dmax = (int)std::max(1.0, std::min(6.0, floor(log(3e14) / log(std::max(g_top, 1.0 + 1e-9)))));
+  // (round 4: 2e13 instead of 3e14 -- at g_top = 255 six products are 2.7e14, and the shifted pass broke down on the
+  // third layer of bench.py's stack AFTER 17 products: a late decline, 82 ms for that layer instead of 28)
+  const int dmax = (int)std::max(1.0, std::min(6.0, floor(log(2e13) / log(std::max(g_top, 1.0 + 1e-9)))));
   if (debug) fprintf(stderr, "[eigh_filtered] growth at the top %.3g per product: rounds of at most %d\n", g_top, dmax);
   std::vector<int> rounds;
   {
