@@ -475,7 +475,7 @@ def test_dwain_three_layer_stack_concurrent_filtered_chains_match_oracle(monkeyp
             precomputing_covariance_num_splits=1, **bench.DWAIN_KW)
     finally:
         ops.eigh = real_eigh
-    streams_wanted = min(3, int(__import__("os").environ.get("PTD_EIGH_STREAMS", "3"))) if by_route == "0" else 1
+    streams_wanted = min(3, int(__import__("os").environ.get("PTD_EIGH_STREAMS", "4"))) if by_route == "0" else 1
     assert len(calls) == 3 and all(c[2:] == (4096, 1024) for c in calls)
     assert len({c[0] for c in calls}) == streams_wanted and len({c[1] for c in calls}) == streams_wanted
     if by_route == "1":
