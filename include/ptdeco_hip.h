@@ -115,6 +115,14 @@ int ptd_eigh(const double* A, int64_t lda, int64_t n, double* evals, double* eve
 int ptd_eigh_topk(const double* A, int64_t lda, int64_t n, int64_t k, int all_values, double* evals,
                   double* evecs, int64_t ldv, void* ws, size_t ws_bytes, int* sweeps_out, void* stream);
 
+/* The f32 face of ptd_eigh_topk: A [n, n] f32 (full storage, symmetric), evals[n] and evecs [n, k] f32, same conventions.
+ * The arithmetic is f64 on a converted copy (the routes above), the results are rounded to f32 -- at least as accurate as
+ * the f32 `torch.linalg.eigh` the reference runs with decompose_in_float64=False (dwain.py:224-233, 162; falor's
+ * use_float64=False, falor.py:181-186, 207). */
+size_t ptd_eigh_f32_workspace_bytes(int64_t n, int64_t k);
+int ptd_eigh_topk_f32(const float* A, int64_t lda, int64_t n, int64_t k, int all_values, float* evals, float* evecs,
+                      int64_t ldv, void* ws, size_t ws_bytes, int* sweeps_out, void* stream);
+
 /* The solver ptd_eigh_topk would try FIRST for this request: 3 = filtered subspace iteration (chip-filling f64
  * products: concurrent chains gain nothing), 1 = direct tridiagonal reduction (a latency-bound chain of short
  * launches: independent matrices overlap well on separate streams), 0 = Jacobi.  A host-side query; the filtered

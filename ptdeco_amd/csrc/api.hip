@@ -130,6 +130,39 @@ int ptd_eigh_topk(const double* A, int64_t lda, int64_t n, int64_t k, int all_va
                        static_cast<hipStream_t>(stream));
 }
 
+// The f32 face of ptd_eigh_topk (decompose_in_float64=False runs torch.linalg.eigh on an f32 matrix, dwain.py:224-233 +
+// 162): f32 in, f32 out, the arithmetic in between in f64 -- the routes above on a converted copy -- so the result is
+// the f32 rounding of the f64 eigenpairs of the f32 matrix (at least as accurate as an f32 LAPACK call).
+size_t ptd_eigh_f32_workspace_bytes(int64_t n, int64_t k) {
+  if (n < 1) return 0;
+  k = std::max<int64_t>(1, std::min(k, n));
+  return align_up((size_t)n * n * 8, 256) + align_up((size_t)n * 8, 256) + align_up((size_t)n * k * 8, 256) +
+         ptd_eigh_workspace_bytes(n);
+}
+
+int ptd_eigh_topk_f32(const float* A, int64_t lda, int64_t n, int64_t k, int all_values, float* evals, float* evecs,
+                      int64_t ldv, void* ws, size_t ws_bytes, int* sweeps_out, void* stream) {
+  PTD_REQUIRE(A && evals && evecs && ws && n >= 1 && lda >= n && k >= 1 && k <= n && ldv >= k,
+              "ptd_eigh_topk_f32: bad argument");
+  if (ws_bytes < ptd_eigh_f32_workspace_bytes(n, k)) {
+    set_error("ptd_eigh_topk_f32: workspace %zu < required %zu bytes", ws_bytes, ptd_eigh_f32_workspace_bytes(n, k));
+    return PTD_ERR_WORKSPACE;
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  char* base = static_cast<char*>(ws);
+  double* A64 = reinterpret_cast<double*>(base);
+  double* w64 = reinterpret_cast<double*>(base + align_up((size_t)n * n * 8, 256));
+  double* v64 = reinterpret_cast<double*>(base + align_up((size_t)n * n * 8, 256) + align_up((size_t)n * 8, 256));
+  char* rest = base + align_up((size_t)n * n * 8, 256) + align_up((size_t)n * 8, 256) + align_up((size_t)n * k * 8, 256);
+  int rc = convert_f32_to_f64(A, lda, A64, n, n, n, st);
+  if (rc != PTD_OK) return rc;
+  rc = eigh_dispatch(A64, n, n, k, w64, v64, k, rest, ws_bytes - (size_t)(rest - base), sweeps_out, all_values != 0, nullptr, st);
+  if (rc != PTD_OK) return rc;
+  rc = convert_f64_to_f32(w64, n, evals, n, 1, n, st);      // (NaN where the route did not compute an eigenvalue stays NaN)
+  if (rc != PTD_OK) return rc;
+  return convert_f64_to_f32(v64, k, evecs, ldv, n, k, st);
+}
+
 int ptd_eigh_profiled(const double* A, int64_t lda, int64_t n, int64_t k, int all_values, double* evals,
                       double* evecs, int64_t ldv, void* ws, size_t ws_bytes, ptd_eigh_stats* stats, void* stream) {
   PTD_REQUIRE(stats, "ptd_eigh_profiled: stats must not be null");

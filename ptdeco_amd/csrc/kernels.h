@@ -81,6 +81,8 @@ size_t nsr_workspace_bytes(int64_t R, int64_t C);
 int nsr_workspace_init(void* ws, size_t ws_bytes, hipStream_t st);
 int nsr(const void* x, const void* y, int64_t R, int64_t C, int dtype, double eps, double* out, void* ws,
         size_t ws_bytes, hipStream_t st);
+int convert_f32_to_f64(const float* src, int64_t lds, double* dst, int64_t ldd, int64_t rows, int64_t cols, hipStream_t st);
+int convert_f64_to_f32(const double* src, int64_t lds, float* dst, int64_t ldd, int64_t rows, int64_t cols, hipStream_t st);
 size_t sym_kl_workspace_bytes(int64_t B);
 int sym_kl(const void* s, const void* t, int64_t B, int64_t C, int dtype, double* out, void* ws, size_t ws_bytes,
            hipStream_t st);

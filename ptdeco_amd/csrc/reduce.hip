@@ -496,6 +496,33 @@ int nsr(const void* x, const void* y, int64_t R, int64_t C, int dtype, double ep
   return PTD_OK;
 }
 
+// ---------------------------------------------------------------- f32 <-> f64 (the f32 face of the eigensolver)
+template <typename TS, typename TD>
+__global__ void convert_kernel(const TS* __restrict__ src, int64_t lds, TD* __restrict__ dst, int64_t ldd, int64_t rows,
+                               int64_t cols) {
+  const int64_t total = rows * cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / cols, c = i % cols;
+    dst[r * ldd + c] = (TD)src[r * lds + c];
+  }
+}
+
+int convert_f32_to_f64(const float* src, int64_t lds, double* dst, int64_t ldd, int64_t rows, int64_t cols, hipStream_t st) {
+  if (rows <= 0 || cols <= 0) return PTD_OK;
+  const unsigned grid = (unsigned)std::min<int64_t>(4096, ceil_div(rows * cols, 256));
+  hipLaunchKernelGGL((convert_kernel<float, double>), dim3(grid), dim3(256), 0, st, src, lds, dst, ldd, rows, cols);
+  PTD_CHECK_LAUNCH("convert f32 -> f64");
+  return PTD_OK;
+}
+
+int convert_f64_to_f32(const double* src, int64_t lds, float* dst, int64_t ldd, int64_t rows, int64_t cols, hipStream_t st) {
+  if (rows <= 0 || cols <= 0) return PTD_OK;
+  const unsigned grid = (unsigned)std::min<int64_t>(4096, ceil_div(rows * cols, 256));
+  hipLaunchKernelGGL((convert_kernel<double, float>), dim3(grid), dim3(256), 0, st, src, lds, dst, ldd, rows, cols);
+  PTD_CHECK_LAUNCH("convert f64 -> f32");
+  return PTD_OK;
+}
+
 size_t sym_kl_workspace_bytes(int64_t B) { return align_up((size_t)std::max<int64_t>(B, 1) * 8, 256); }
 
 int sym_kl(const void* s, const void* t, int64_t B, int64_t C, int dtype, double* out, void* ws, size_t ws_bytes,

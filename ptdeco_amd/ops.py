@@ -94,7 +94,7 @@ EIGH_PROFILE: Optional[list] = None
 
 
 def eigh(A: torch.Tensor, k: Optional[int] = None, all_values: bool = True) -> tuple[torch.Tensor, torch.Tensor]:
-    """(eigenvalues [n] ascending, eigenvectors in columns) of a symmetric PSD f64 matrix.
+    """(eigenvalues [n] ascending, eigenvectors in columns) of a symmetric PSD f64 (or f32: f32 results, f64 arithmetic) matrix.
 
     With ``k`` only the eigenvectors of the k largest eigenvalues are formed: the second result is
     [n, k] and its column c belongs to eigenvalue n - k + c, so ``v[:, v.shape[1] - r:]`` is the
@@ -102,10 +102,20 @@ def eigh(A: torch.Tensor, k: Optional[int] = None, all_values: bool = True) -> t
     solver skip the eigenvalues below the k + 1 largest (those entries of the first result are NaN
     then, unless the Jacobi route ran); the decomposition drivers never read eigenvalues."""
     _dev(A)
-    assert A.dtype == torch.float64 and A.dim() == 2 and A.shape[0] == A.shape[1] and A.stride(1) == 1
+    assert A.dtype in (torch.float64, torch.float32) and A.dim() == 2 and A.shape[0] == A.shape[1] and A.stride(1) == 1
     n = A.shape[0]
     k = n if k is None else max(1, min(int(k), n))
     lib = _hip.load()
+    if A.dtype == torch.float32:
+        # f32 in, f32 out, f64 arithmetic in between (ptd_eigh_topk_f32: the face the reference's f32 eigh call takes)
+        w = torch.empty(n, dtype=torch.float32, device=A.device)
+        v = torch.empty((n, k), dtype=torch.float32, device=A.device)
+        ws = torch.empty(lib.ptd_eigh_f32_workspace_bytes(n, k), dtype=torch.uint8, device=A.device)
+        with torch.cuda.device(A.device):
+            rc = lib.ptd_eigh_topk_f32(A.data_ptr(), A.stride(0), n, k, int(all_values), w.data_ptr(), v.data_ptr(), k,
+                                       ws.data_ptr(), ws.numel(), None, _stream(A))
+        _hip.check(rc, "ptd_eigh_topk_f32")
+        return w, v
     w = torch.empty(n, dtype=torch.float64, device=A.device)
     v = torch.empty((n, k), dtype=torch.float64, device=A.device)
     ws = torch.empty(lib.ptd_eigh_workspace_bytes(n), dtype=torch.uint8, device=A.device)

@@ -499,6 +499,26 @@ def test_eigh_filtered_route_declines_where_it_does_not_apply(ops, monkeypatch):
     monkeypatch.setattr(real_ops, "EIGH_PROFILE", None)
 
 
+@pytest.mark.parametrize("n,k", [(96, 96), (512, 128), (2048, 512)])
+def test_eigh_f32_face_matches_lapack(ops, n, k):
+    """ptd_eigh_topk_f32 (what `decompose_in_float64=False` would hand to torch.linalg.eigh in f32, dwain.py:224-233 +
+    162): f32 matrix in, f32 eigenpairs out, f64 arithmetic in between.  Against the f64 LAPACK eigenpairs of the same
+    f32 matrix: eigenvalues and the residual to f32 rounding, orthonormality, the top-r subspaces."""
+    a32 = _twist_case_matrix(n).float()
+    w, v = ops.eigh(a32.to(DEV), k, all_values=True)
+    assert w.dtype == torch.float32 and v.dtype == torch.float32 and v.shape == (n, k)
+    w, v = w.cpu().double(), v.cpu().double()
+    a = a32.double()
+    w_ref, v_ref = torch.linalg.eigh(a)
+    scale = w_ref.abs().max().item()
+    assert (w - w_ref).abs().max().item() <= 2e-7 * scale
+    assert (a @ v - v * w[n - k:]).abs().max().item() <= 4e-6 * scale
+    assert (v.T @ v - torch.eye(k, dtype=torch.float64)).abs().max().item() <= 2e-6
+    for r in sorted({k, max(1, k // 4)}):
+        d2 = 2.0 * r - 2.0 * (v[:, k - r:].T @ v_ref[:, n - r:]).pow(2).sum().item()
+        assert d2 <= 1e-8 * r + 1e-9, (r, d2)
+
+
 def test_eigh_filtered_route_backs_off_after_a_late_decline(ops, monkeypatch):
     """A decline AFTER products were spent (here: a residual bound no attempt can meet, PTD_EIGH_FILTER_TOL = 1e-18 with
     a forced degree) is
