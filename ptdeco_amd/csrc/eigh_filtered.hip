@@ -988,7 +988,6 @@ int eigh_filtered(const double* A, int64_t lda, int64_t n, int64_t k, double* ev
     for (auto& e : ev) PTD_CHECK_HIP(hipEventCreate(&e));
     PTD_CHECK_HIP(hipEventRecord(ev[0], st));
   }
-  auto cleanup = [&]() {};
   bool spent = false;     // products with C have been spent: a decline from here on is a late one
   // a decline is not an error: the caller answers on the direct route and the thread's last error stays as it was
   auto decline = [&](const char* why) {
@@ -1187,7 +1186,7 @@ int eigh_filtered(const double* A, int64_t lda, int64_t n, int64_t k, double* ev
   };
   for (size_t ri = 0; ri < rounds.size(); ++ri) {
     rc = filter_round(rounds[ri]);
-    if (rc != PTD_OK) { cleanup(); return rc; }
+    if (rc != PTD_OK) return rc;
   }
   PTD_CHECK_LAUNCH("eigh_filtered filter");
   if (stats) PTD_CHECK_HIP(hipEventRecord(ev[2], st));
@@ -1197,26 +1196,26 @@ int eigh_filtered(const double* A, int64_t lda, int64_t n, int64_t k, double* ev
   for (int attempt = 0;; ++attempt) {
     // ---- 3. Rayleigh-Ritz
     rc = gemm_f64(A, lda, 1, X, m, 1, Z, m, n, m, n, 1.0, false, 1, st);           // Z = C X
-    if (rc != PTD_OK) { cleanup(); return rc; }
+    if (rc != PTD_OK) return rc;
     ++products;
     rc = gram(X, Z, H, Y);                                                         // H = X^T Z
-    if (rc != PTD_OK) { cleanup(); return rc; }
+    if (rc != PTD_OK) return rc;
     hipLaunchKernelGGL(fs_symmetrize_kernel, dim3((unsigned)ceil_div(m, 32), (unsigned)ceil_div(m, 32)), dim3(256), 0,
                        st, H, m);
     if (stats && attempt == 0) PTD_CHECK_HIP(hipEventRecord(ev[3], st));
     dump("H", H, (size_t)m * m);
     rc = eigh_tridiag(H, m, m, k, lam, Yk, k, base + p.off_eigh, p.eigh_bytes, 1e-10, false, nullptr, st);
     if (rc == PTD_ERR_UNSUPPORTED) return decline("clustered Ritz values");
-    if (rc != PTD_OK) { cleanup(); return rc; }
+    if (rc != PTD_OK) return rc;
     if (stats && attempt == 0) PTD_CHECK_HIP(hipEventRecord(ev[4], st));
     dump("Y_k", Yk, (size_t)m * k);
     rc = gemm_f64(X, m, 1, Yk, k, 1, evecs, ldv, n, k, m, 1.0, false, 1, st);      // V = X Y_k
-    if (rc != PTD_OK) { cleanup(); return rc; }
+    if (rc != PTD_OK) return rc;
 
     // ---- 4. residuals: C V - V theta = Z Y_k - V theta
     double* T = Y;
     rc = gemm_f64(Z, m, 1, Yk, k, 1, T, k, n, k, m, 1.0, false, 1, st);
-    if (rc != PTD_OK) { cleanup(); return rc; }
+    if (rc != PTD_OK) return rc;
     PTD_CHECK_HIP(hipMemsetAsync(resid, 0, 16, st));
     // (G and W are free outside the orthonormalisation passes: column statistics and signs live there)
     hipLaunchKernelGGL(fs_colstat_kernel, dim3((unsigned)ceil_div(k, 64), FS_SLABS), dim3(256), 0, st, T, (int64_t)k, evecs,
@@ -1242,7 +1241,7 @@ int eigh_filtered(const double* A, int64_t lda, int64_t n, int64_t k, double* ev
     if (debug) fprintf(stderr, "[eigh_filtered] measured %.2f per product: %d more\n", rate, extra);
     const int before = products;
     rc = filter_round(extra);
-    if (rc != PTD_OK) { cleanup(); return rc; }
+    if (rc != PTD_OK) return rc;
     filter_products += products - before;
   }
   hipLaunchKernelGGL(fs_flip_kernel, dim3(1024), dim3(256), 0, st, evecs, ldv, (int)n, (int)k, Wt);   // signs of the accepted attempt

@@ -53,6 +53,27 @@ def test_workspace_queries_and_argument_errors(lib):
     assert rc == -1
 
 
+def test_eigh_route_query(monkeypatch):
+    """ptd_eigh_route is a host-side function of (n, k, all_values) and the environment: the filtered subspace iteration
+    for at most 2/7 of the spectrum of a large matrix whose eigenvalues below are not wanted, the direct reduction for
+    everything else from order 256 on, Jacobi for tiny matrices."""
+    from ptdeco_amd import _hip
+    l = _hip.load()
+    monkeypatch.delenv("PTD_EIGH_FILTERED", raising=False)
+    monkeypatch.delenv("PTD_EIGH_METHOD", raising=False)
+    assert l.ptd_eigh_route(4096, 1024, 0) == 3
+    assert l.ptd_eigh_route(4096, 1170, 0) == 3 and l.ptd_eigh_route(4096, 1365, 0) == 1     # the cut: 7 k <= 2 n
+    assert l.ptd_eigh_route(4096, 2048, 0) == 1 and l.ptd_eigh_route(4096, 1024, 1) == 1
+    assert l.ptd_eigh_route(1024, 256, 0) == 1 and l.ptd_eigh_route(4000, 1000, 0) == 1      # small / not a multiple of 128
+    assert l.ptd_eigh_route(128, 32, 0) == 0
+    monkeypatch.setenv("PTD_EIGH_FILTERED", "0")
+    assert l.ptd_eigh_route(4096, 1024, 0) == 1
+    monkeypatch.setenv("PTD_EIGH_METHOD", "jacobi")
+    assert l.ptd_eigh_route(4096, 1024, 0) == 0
+    # the f32 face needs room for the converted matrix, the f64 results and the f64 solver
+    assert l.ptd_eigh_f32_workspace_bytes(512, 128) >= 512 * 512 * 8 + 512 * 128 * 8 + l.ptd_eigh_workspace_bytes(512)
+
+
 def test_no_cpu_path():
     import torch
     import ptdeco_amd
