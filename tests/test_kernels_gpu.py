@@ -515,8 +515,9 @@ def test_eigh_f32_face_matches_lapack(ops, n, k):
     assert (a @ v - v * w[n - k:]).abs().max().item() <= 4e-6 * scale
     assert (v.T @ v - torch.eye(k, dtype=torch.float64)).abs().max().item() <= 2e-6
     for r in sorted({k, max(1, k // 4)}):
+        # (the f32-rounded columns are unit vectors only to ~1e-7, and 2 r - 2 |V^T V_ref|_F^2 sees that to first order)
         d2 = 2.0 * r - 2.0 * (v[:, k - r:].T @ v_ref[:, n - r:]).pow(2).sum().item()
-        assert d2 <= 1e-8 * r + 1e-9, (r, d2)
+        assert abs(d2) <= 1e-6 * r, (r, d2)
 
 
 def test_eigh_filtered_route_backs_off_after_a_late_decline(ops, monkeypatch):
