@@ -1365,6 +1365,13 @@ __global__ __launch_bounds__(64) void tridiag_invit_kernel(const double* __restr
   unsigned char* __restrict__ sw = ws.sw + k;
   double* __restrict__ y = Y + k;
 
+  // A vector from the work list starts from what the twisted-factorisation kernel left in Y -- an eigenvector up to a
+  // residual of ~1e-13 |T| that was only too large for its gap -- and ONE inverse iteration from there leaves the
+  // neighbours' components at (residual / gap) x (eigenvalue error / gap) ~ 1e-16: three passes over the rows
+  // (factorisation, forward, backward) instead of seven from a random start (3.4 -> ~1.5 ms at n = 4096; a Llama
+  // block's three (4096, 2048) problems refuse about twenty vectors each).
+  const bool from_memory = list != nullptr;
+  const int niter_eff = from_memory ? 1 : niter;
   // factorisation, with the forward sweep of the FIRST iteration riding along: the start vector is a hash of
   // (row, vector), so P L^-1 y0 needs nothing from memory and a separate latency-bound pass is saved
   double u = d[0] - lk, v = n > 1 ? e[0] : 0.0, w = 0.0;
@@ -1386,8 +1393,10 @@ __global__ __launch_bounds__(64) void tridiag_invit_kernel(const double* __restr
       u = v - m * a1; v = w - m * c1; w = 0.0;
       const double t = cur0; cur0 = nxt; nxt = t;
     }
-    y[(int64_t)i * ldy] = cur0;
-    cur0 = nxt - m * cur0;
+    if (!from_memory) {
+      y[(int64_t)i * ldy] = cur0;
+      cur0 = nxt - m * cur0;
+    }
   }
   if (fabs(u) < tiny) u = (u < 0.0) ? -tiny : tiny;
   U1i[(int64_t)(n - 1) * S] = 1.0 / u;
@@ -1396,10 +1405,11 @@ __global__ __launch_bounds__(64) void tridiag_invit_kernel(const double* __restr
   // register, so the operands of 8 steps are fetched together (one latency per 8 steps).
   constexpr int UB = 12;  // 4 arrays x 12 rows = 48 loads per lane in flight (the counter holds 63; 16 rows stall, 15 = 12)
   double carry = 1.0;  // scale of the iterate in memory, applied on the next read
-  for (int it = 0; it < niter; ++it) {
-    // forward: apply the row interchanges and L^-1 (done above for the first iteration)
-    double cur = (it == 0) ? cur0 : y[0] * carry;
-    for (int i0 = (it == 0) ? n : 0; i0 < n - 1; i0 += UB) {
+  for (int it = 0; it < niter_eff; ++it) {
+    // forward: apply the row interchanges and L^-1 (done above for the first iteration of a hashed start)
+    const bool fused = it == 0 && !from_memory;
+    double cur = fused ? cur0 : y[0] * carry;
+    for (int i0 = fused ? n : 0; i0 < n - 1; i0 += UB) {
       double yn[UB], lm[UB];
       unsigned char s8[UB];
 #pragma unroll
