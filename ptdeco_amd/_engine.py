@@ -18,7 +18,7 @@ from typing import Optional
 import torch
 
 from . import ops
-from .lowrank import fuse_pair, warn_once
+from .lowrank import LowRankConv1x1, LowRankLinear, fuse_pair, warn_once
 
 EIGEN_DAMPEN_FACTOR = 0.01  # reference dwain.py:14, falor.py:22
 
@@ -88,6 +88,144 @@ def require_device(device) -> torch.device:
     return device
 
 
+class PrefixMemo:
+    """One metric step runs the model twice on the same input -- the candidate, then the original (dwain.py:263-267,
+    falor.py:223-227) -- and the two forwards differ in the tapped layer alone: everything the model computes BEFORE
+    that layer's first call is computed twice with the same operands.  The memo keeps, during the first forward, the
+    outputs of the matrix-product modules (Linear / conv / fused rank-r pairs) that ran before the tapped layer and
+    hands them back in the second: at depth f of a stack the second forward costs 1 - f of its products.  Nothing
+    outlives the step (no reuse across batches, candidates or calls) and the numbers are the ones a second run of the
+    same kernel on the same operands gives.
+
+    Guards: recording stops at the tapped layer's first call and when the byte budget is spent (a module's kept
+    outputs are therefore always a prefix of its calls); an output that was modified in place since it was kept
+    (``relu_`` on a conv output) or whose call sees another input shape is recomputed; modules that already carry an
+    instance-level ``forward`` are left alone.  ``PTD_PREFIX_MEMO_MB`` = byte budget in MiB (default 8192, 0 = off),
+    ``PTD_PREFIX_MEMO_CHECK=1`` recomputes every kept output and raises on a difference (tests)."""
+
+    IDLE, RECORD, REPLAY = 0, 1, 2
+
+    def __init__(self, root: torch.nn.Module, layer: torch.nn.Module, budget_bytes: int, check: bool = False):
+        self.mode = self.IDLE
+        self.reached = False
+        self.full = False
+        self.bytes = 0
+        self.budget = budget_bytes
+        self.check = check
+        self.hits = 0
+        self._patched: list = []
+        fused_below: list = []
+        for name, m in root.named_modules():
+            if m is layer or any(name.startswith(p) for p in fused_below):
+                continue
+            if isinstance(m, (LowRankLinear, LowRankConv1x1)):
+                fused_below.append(name + ".")
+            elif not isinstance(m, (torch.nn.Linear, torch.nn.modules.conv._ConvNd)):
+                continue
+            if "forward" in m.__dict__:
+                continue
+            self._patch(m)
+
+    @staticmethod
+    def from_env(root: torch.nn.Module, layer: torch.nn.Module) -> Optional["PrefixMemo"]:
+        import os
+
+        mb = float(os.environ.get("PTD_PREFIX_MEMO_MB", "8192"))
+        if mb <= 0:
+            return None
+        return PrefixMemo(root, layer, int(mb * 2**20), check=os.environ.get("PTD_PREFIX_MEMO_CHECK", "0") == "1")
+
+    def _patch(self, m: torch.nn.Module) -> None:
+        import collections
+
+        inner = m.forward
+        kept: collections.deque = collections.deque()
+
+        def forward(*args, **kwargs):
+            if self.mode == self.RECORD:
+                out = inner(*args, **kwargs)
+                if not (self.reached or self.full) and isinstance(out, torch.Tensor) and args \
+                        and isinstance(args[0], torch.Tensor):
+                    nbytes = out.numel() * out.element_size()
+                    if self.bytes + nbytes <= self.budget:
+                        kept.append((out, out._version, args[0].shape))
+                        self.bytes += nbytes
+                    else:
+                        self.full = True
+                return out
+            if self.mode == self.REPLAY and kept:
+                out, version, shape = kept.popleft()
+                if out._version == version and args and isinstance(args[0], torch.Tensor) and args[0].shape == shape:
+                    if self.check:
+                        again = inner(*args, **kwargs)
+                        if not torch.equal(again, out):
+                            raise RuntimeError(f"ptdeco_amd: prefix memo mismatch in {type(m).__name__}: the model "
+                                               "does not compute the same values before the analysed layer in both "
+                                               "forwards of a metric step")
+                    self.hits += 1
+                    return out
+                kept.clear()
+            return inner(*args, **kwargs)
+
+        m.forward = forward
+        self._patched.append((m, kept))
+
+    def _drop(self) -> None:
+        for _, kept in self._patched:
+            kept.clear()
+        self.bytes = 0
+
+    def first(self):
+        """Context of the first forward of a metric step: outputs are kept."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            self._drop()
+            self.reached = self.full = False
+            self.mode = self.RECORD
+            try:
+                yield
+            finally:
+                self.mode = self.IDLE
+        return cm()
+
+    def second(self):
+        """Context of the second forward: kept outputs are handed back, then released."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            self.mode = self.REPLAY
+            try:
+                yield
+            finally:
+                self.mode = self.IDLE
+                self._drop()
+        return cm()
+
+    def close(self) -> None:
+        self._drop()
+        for m, _ in self._patched:
+            m.__dict__.pop("forward", None)
+        self._patched = []
+
+
+def forward_pair(root: torch.nn.Module, tap: "LayerTap", x, first_setup, second_setup):
+    """The two forwards of one metric step: ``first_setup()``, model, ``second_setup()``, model -- the second reusing
+    what the first computed ahead of the tapped layer (PrefixMemo) when the tap carries a memo."""
+    import contextlib
+
+    memo = tap.memo
+    first_setup()
+    with memo.first() if memo is not None else contextlib.nullcontext():
+        y_first = root(x)
+    second_setup()
+    with memo.second() if memo is not None else contextlib.nullcontext():
+        y_second = root(x)
+    return y_first, y_second
+
+
 class LayerTap:
     """Records the last input of one decomposable layer and gives a 2-D view of its weight.
 
@@ -105,13 +243,24 @@ class LayerTap:
         self.is_conv = isinstance(layer, torch.nn.Conv2d)
         self._last: Optional[torch.Tensor] = None
         self.last_features: Optional[torch.Tensor] = None  # [T, n_out] of the last use_dense forward
+        self.memo: Optional[PrefixMemo] = None
         self._handle = layer.register_forward_pre_hook(self._record)
 
     def _record(self, _module, args) -> None:
         self._last = args[0]
+        if self.memo is not None:
+            self.memo.reached = True
+
+    def enable_prefix_memo(self, root: torch.nn.Module) -> None:
+        """Metric steps of this layer's rank search share the model's work ahead of the layer (PrefixMemo)."""
+        if self.memo is None:
+            self.memo = PrefixMemo.from_env(root, self.layer)
 
     def close(self) -> None:
         self.use_module_forward()
+        if self.memo is not None:
+            self.memo.close()
+            self.memo = None
         self._handle.remove()
         self._last = None
 

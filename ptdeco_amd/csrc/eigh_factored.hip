@@ -59,18 +59,37 @@ __global__ void tril_kernel(double* __restrict__ L, int np) {
 
 // B <- (B + B^T) / 2 on the n x n leading block; identity on the padding (keeps B PSD, the
 // padded eigenvalues are exact and tiny so they never reach the top k)
-__global__ void symmetrize_kernel(double* __restrict__ B, int np, int n, double pad_diag) {
+// (average = false: only the padding is written -- the matrix holds its lower triangle alone)
+__global__ void symmetrize_kernel(double* __restrict__ B, int np, int n, double pad_diag, bool average = true) {
   const int64_t total = (int64_t)np * np;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
        e += (int64_t)gridDim.x * blockDim.x) {
     const int r = (int)(e / np), c = (int)(e % np);
     if (r >= n || c >= n) {
       B[e] = (r == c) ? pad_diag : 0.0;
-    } else if (c > r) {
+    } else if (c > r && average) {
       const double v = 0.5 * (B[e] + B[(int64_t)c * np + r]);
       B[e] = v;
       B[(int64_t)c * np + r] = v;
     }
+  }
+}
+
+// G = sum of `ns` slabs in index order (a deterministic K split), lower triangle only
+__global__ void sum_slabs_lower_kernel(double* __restrict__ G, const double* __restrict__ S, int64_t slab, int ns,
+                                       int np) {
+  const int half = np / 2;
+  const int64_t total2 = (int64_t)np * half;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total2; i += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / half), c2 = (int)(i % half);
+    if (2 * c2 > r) continue;
+    double2 acc = reinterpret_cast<const double2*>(S)[i];
+    for (int q = 1; q < ns; ++q) {
+      const double2 v = reinterpret_cast<const double2*>(S + q * slab)[i];
+      acc.x += v.x;
+      acc.y += v.y;
+    }
+    reinterpret_cast<double2*>(G)[i] = acc;
   }
 }
 
@@ -163,10 +182,31 @@ int eigh_factored(const void* W, int64_t ldw, int w_dtype, int64_t n_o, int64_t 
     return PTD_ERR_UNSUPPORTED;
   }
   PTD_CHECK_LAUNCH("widen W");
-  // G = W^T W  (+ identity on the padding so the Cholesky stays positive definite)
-  int rc = gemm_f64(W64, 1, np, W64, np, 1, G, np, np, np, n_o, 1.0, false, 1, st);
+  // G = W^T W  (+ identity on the padding so the Cholesky stays positive definite).  Only the 128 x 128 tiles that
+  // touch the lower triangle are computed (the factorisation reads nothing else and tril_kernel clears the rest
+  // afterwards): 4.8e11 flop at n_o = 14336, n_i = 4096 become 2.5e11.  The 528 tiles left are one round of the 512
+  // workgroup slots plus a nearly empty second one, so the K range is cut into slabs (summed in index order) until the
+  // last round is a small share of the launch; the slabs live in the buffers of the later steps (P, B, S, T, eigh).
+  int nslabs = 1, ksplit = 1;
+  const int64_t slab_elems = (int64_t)np * np;
+  {
+    const int64_t avail = (int64_t)((p.total - p.off_P) / ((size_t)slab_elems * 8));
+    const int tm = np / 128;
+    const int64_t tiles = (int64_t)tm * (tm + 1) / 2;
+    double best = 0.0;
+    for (int ks = 1; ks <= (int)std::min<int64_t>(avail, 16); ++ks) {
+      const int64_t kc = (int64_t)align_up((size_t)ceil_div(n_o, (int64_t)ks), 16);
+      const int64_t ns = ceil_div(n_o, kc);
+      const double cost = (double)ceil_div(tiles * ns, (int64_t)512) * (double)kc / (double)n_o + 0.01 * (ns > 1 ? ns : 0);
+      if (ks == 1 || cost < best) { best = cost; ksplit = ks; }
+    }
+  }
+  double* slabs = ksplit > 1 ? P : G;
+  int rc = gemm_f64_slabs(W64, 1, np, W64, np, 1, slabs, np, slab_elems, np, np, n_o, 1.0, ksplit, &nslabs, true, st);
   if (rc != PTD_OK) return rc;
-  if (np > n_i) hipLaunchKernelGGL(symmetrize_kernel, dim3(2048), dim3(256), 0, st, G, np, (int)n_i, 1.0);
+  if (ksplit > 1)
+    hipLaunchKernelGGL(sum_slabs_lower_kernel, dim3(2048), dim3(256), 0, st, G, slabs, slab_elems, nslabs, np);
+  if (np > n_i) hipLaunchKernelGGL(symmetrize_kernel, dim3(2048), dim3(256), 0, st, G, np, (int)n_i, 1.0, false);
   PTD_CHECK_HIP(hipMemsetAsync(fail, 0, 16, st));
   rc = cholesky_f64(G, np, linv, FB * FB, fail, st);
   if (rc != PTD_OK) return rc;
@@ -189,7 +229,7 @@ int eigh_factored(const void* W, int64_t ldw, int w_dtype, int64_t n_o, int64_t 
   if (rc != PTD_OK) return rc;
   rc = gemm_f64(G, 1, np, P, np, 1, B, np, np, np, np, 1.0, false, 1, st);   // B = L^T P
   if (rc != PTD_OK) return rc;
-  hipLaunchKernelGGL(symmetrize_kernel, dim3(2048), dim3(256), 0, st, B, np, (int)n_i, 0.0);
+  hipLaunchKernelGGL(symmetrize_kernel, dim3(2048), dim3(256), 0, st, B, np, (int)n_i, 0.0, true);
   PTD_CHECK_LAUNCH("factored products");
   // top-k eigenvectors of B
   rc = eigh_select(B, np, np, k, evals, S, k, base + p.off_eigh, p.eigh_bytes, nullptr, nullptr, st);

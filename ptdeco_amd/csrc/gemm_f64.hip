@@ -208,9 +208,25 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_glds_kernel(const GemmF64Args
   const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
   const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
   const int tiles_n = a.N / BN;
-  const int ti = wg / tiles_n, tj = wg % tiles_n;
+  int ti, tj;
+  if (a.lower) {
+    // only the tiles that touch the lower triangle exist in the grid (launch_glds counts them the same way): row ti
+    // has min(tiles_n, ceil((ti + 1) GM / BN)) of them.  Launching the full grid and leaving early would hand the
+    // last XCD -- the bottom rows -- nearly all of its tiles, and the launch would take as long as the full product.
+    int t = wg;
+    ti = 0;
+    for (;;) {
+      const int c = min(tiles_n, ((ti + 1) * GM + BN - 1) / BN);
+      if (t < c) break;
+      t -= c;
+      ++ti;
+    }
+    tj = t;
+  } else {
+    ti = wg / tiles_n;
+    tj = wg % tiles_n;
+  }
   const int m0 = ti * GM, n0 = tj * BN;
-  if (a.lower && n0 >= m0 + GM) return;   // (wave-uniform: the whole workgroup leaves)
   const int kbeg = blockIdx.y * a.kchunk;
   const int kend = min(a.K, kbeg + a.kchunk);
   const int nk = (kend - kbeg) / GK;
@@ -346,7 +362,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_glds_kernel(const GemmF64Args
 
 template <int NT, bool AM>
 static void launch_glds(const GemmF64Args& a, int ksplit, hipStream_t st) {
-  const dim3 grid((unsigned)((a.M / GM) * (a.N / (16 * NT))), (unsigned)ksplit);
+  const int tiles_m = a.M / GM, tiles_n = a.N / (16 * NT);
+  int tiles = tiles_m * tiles_n;
+  if (a.lower) {
+    tiles = 0;
+    for (int ti = 0; ti < tiles_m; ++ti) tiles += std::min(tiles_n, ((ti + 1) * GM + 16 * NT - 1) / (16 * NT));
+  }
+  const dim3 grid((unsigned)tiles, (unsigned)ksplit);
   hipLaunchKernelGGL((gemm_f64_glds_kernel<NT, AM>), grid, dim3(256), 0, st, a);
 }
 

@@ -238,15 +238,11 @@ def _compute_metrics(*, input_dict, root_module, tap: eng.LayerTap, orig_weight,
     root_module.eval()
     uk, big_u, deco_weight = candidate
     if deco_weight is None:
-        tap.use_pair(big_u, uk)
-        y_deco = root_module(input_dict)
-        tap.use_dense(orig_weight)
-        y_orig = root_module(input_dict)
+        y_deco, y_orig = eng.forward_pair(root_module, tap, input_dict, lambda: tap.use_pair(big_u, uk),
+                                          lambda: tap.use_dense(orig_weight))
     else:
-        tap.set_weight(deco_weight)
-        y_deco = root_module(input_dict)
-        tap.set_weight(orig_weight)
-        y_orig = root_module(input_dict)
+        y_deco, y_orig = eng.forward_pair(root_module, tap, input_dict, lambda: tap.set_weight(deco_weight),
+                                          lambda: tap.set_weight(orig_weight))
     loss_deco = loss_fn(input_dict, y_deco)
     loss_orig = loss_fn(input_dict, y_orig)
     nsr = utils.calc_per_channel_noise_to_signal_ratio(y=y_orig, x=y_deco, non_channel_dim=(0, 1), mode="mean")
@@ -289,6 +285,7 @@ def _process_module(*, root_module, decomposed_submodule_name, data_iterator, lo
             logger.info(f"Using pre-computed u_matrix, {u_matrix.dtype=}")
 
         tap.use_module_forward()
+        tap.enable_prefix_memo(root_module)   # the two forwards of a metric step share the work ahead of this layer
         # candidates that change the parameter count, in schedule order (:407-421)
         baseline_params = _get_params_for_proportion(1.0, dim_in, dim_out)
         candidates = []

@@ -79,15 +79,11 @@ def _compute_metrics(*, x, root_module, tap: eng.LayerTap, orig_weight, candidat
     root_module.eval()
     uk, big_u, deco_weight = candidate
     if deco_weight is None:
-        tap.use_pair(big_u, uk)
-        y_deco = root_module(x)
-        tap.use_dense(orig_weight)
-        y_orig = root_module(x)
+        y_deco, y_orig = eng.forward_pair(root_module, tap, x, lambda: tap.use_pair(big_u, uk),
+                                          lambda: tap.use_dense(orig_weight))
     else:
-        tap.set_weight(deco_weight)
-        y_deco = root_module(x)
-        tap.set_weight(orig_weight)
-        y_orig = root_module(x)
+        y_deco, y_orig = eng.forward_pair(root_module, tap, x, lambda: tap.set_weight(deco_weight),
+                                          lambda: tap.set_weight(orig_weight))
     nsr = utils.calc_per_channel_noise_to_signal_ratio(y=y_orig, x=y_deco, non_channel_dim=(0,))
     kl = utils.calc_kl_loss(y_deco, y_orig)
     return torch.stack([nsr, kl])
@@ -124,6 +120,7 @@ def _process_module(*, root_module, decomposed_submodule_name, data_iterator, ns
         # the tapped layer runs on the HIP GEMMs while it is analysed (f32 models only: falor builds
         # its factors in float32, falor.py:346)
         fast = orig_weight.dtype == torch.float32 and tap.use_dense(orig_weight)
+        tap.enable_prefix_memo(root_module)   # the two forwards of a metric step share the work ahead of this layer
         # bisection: each decision feeds the next candidate, so one host sync per candidate
         rank_best = full_rank
         nsr_best = kl_best = nsr_new = kl_new = 0.0

@@ -396,3 +396,104 @@ def test_phase_timer_counts_a_nested_span_of_the_same_name_once(monkeypatch):
     with t.span("comm"):
         pass
     assert t.totals_ms() == {"B_eigh": 1.0, "comm": 2.0} and Ev.count == 6
+
+
+# ---------------------------------------------------------------------------------- prefix memo (eng.PrefixMemo)
+class _MemoNet(torch.nn.Module):
+    """conv -> relu_ (in place on the conv output) -> flatten -> a (called twice) -> tapped -> a again -> head"""
+
+    def __init__(self):
+        super().__init__()
+        g = torch.Generator().manual_seed(5)
+        self.conv = torch.nn.Conv2d(3, 4, 1)
+        self.a = torch.nn.Linear(16, 16)
+        self.b = torch.nn.Linear(16, 16)
+        self.tapped = torch.nn.Linear(16, 16)
+        self.head = torch.nn.Linear(16, 8)
+        with torch.no_grad():
+            for p in self.parameters():
+                p.copy_(torch.randn(p.shape, generator=g) * 0.3)
+
+    def forward(self, x):
+        h = torch.relu_(self.conv(x)).flatten(1)          # [B, 16]
+        h = self.a(self.a(h)) + self.b(h)
+        h = self.tapped(h)
+        return self.head(self.a(h))
+
+
+def test_prefix_memo_replays_only_what_ran_before_the_tapped_layer():
+    from ptdeco_amd import _engine as eng
+
+    torch.manual_seed(0)
+    model = _MemoNet().eval()
+    x = torch.randn(5, 3, 2, 2)
+    real = []
+
+    def spy(name, mod):
+        inner = type(mod).forward
+
+        def fwd(self_, *a, **k):
+            real.append(name)
+            return inner(self_, *a, **k)
+        return fwd
+
+    # count REAL executions through a subclass forward (class level: the memo wraps instance level above it)
+    for n, m in list(model.named_children()):
+        m.__class__ = type(f"Spy{n}", (type(m),), {"forward": spy(n, m)})
+    with torch.no_grad():
+        want = model(x)
+        tap = eng.LayerTap(model, "tapped")
+        tap.memo = eng.PrefixMemo(model, tap.layer, 1 << 30, check=True)
+        real.clear()
+        y1, y2 = eng.forward_pair(model, tap, x, lambda: None, lambda: None)
+        assert torch.equal(y1, want) and torch.equal(y2, want)
+        # first forward: everything; second: conv again (its kept output was modified in place by relu_), a's two
+        # calls ahead of the tapped layer and b come from the memo (check=True recomputes them: counted twice here)
+        assert tap.memo.hits == 3
+        assert real[:7] == ["conv", "a", "a", "b", "tapped", "a", "head"]
+        tap.memo.check = False
+        real.clear()
+        y1, y2 = eng.forward_pair(model, tap, x, lambda: None, lambda: None)
+        assert torch.equal(y2, want)
+        assert real == ["conv", "a", "a", "b", "tapped", "a", "head", "conv", "tapped", "a", "head"]
+        # a budget that holds one [5, 16] f32 output only: the first call of `a`, nothing after it
+        tap.memo.close()
+        tap.memo = eng.PrefixMemo(model, tap.layer, 5 * 16 * 4 + 5 * 4 * 2 * 2 * 4)
+        real.clear()
+        y1, y2 = eng.forward_pair(model, tap, x, lambda: None, lambda: None)
+        assert torch.equal(y2, want)
+        assert real[7:] == ["conv", "a", "b", "tapped", "a", "head"]
+        assert all(len(kept) == 0 for _, kept in tap.memo._patched)       # nothing outlives the step
+        tap.close()
+    assert all("forward" not in m.__dict__ for m in model.modules())
+
+
+def test_prefix_memo_is_off_with_a_zero_budget(monkeypatch):
+    from ptdeco_amd import _engine as eng
+
+    model = _MemoNet().eval()
+    monkeypatch.setenv("PTD_PREFIX_MEMO_MB", "0")
+    tap = eng.LayerTap(model, "tapped")
+    tap.enable_prefix_memo(model)
+    assert tap.memo is None
+    tap.close()
+
+
+@pytest.mark.parametrize("name", ["dwain_mlp_nosplit", "dwain_conv"])
+def test_dwain_driver_with_the_prefix_memo_checked_and_without_it(name, monkeypatch):
+    scn = gio.e2e_meta()[name]
+    traces = []
+    for env in ({"PTD_PREFIX_MEMO_CHECK": "1"}, {"PTD_PREFIX_MEMO_MB": "0"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with cpu_shim.installed(monkeypatch) as pkg:
+            model = gio.build_model(scn)
+            data, metric = gio.dwain_streams(scn)
+            trace = []
+            pkg.dwain.decompose_in_place(module=model, device=CPU, data_iterator=data, metric_iterator=metric,
+                                         loss_fn=tm.ce_loss, finetune_fn=lambda m, d, n: m, trace=trace,
+                                         **scn["kwargs"])
+        traces.append(trace)
+        for k in env:
+            monkeypatch.delenv(k)
+    assert traces[0] == traces[1]     # bit-identical metrics with and without the memo
