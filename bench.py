@@ -649,6 +649,10 @@ def main():
         "config": {"workload": what % (STACK_LAYERS, "f32", STACK_D_STEPS, comm),
                    "model_dtype": "float32",
                    "layers_per_step": STACK_LAYERS, "parallelism": f"dp{world}" if world > 1 else "single",
+                   "metric_forwards": ("every (candidate, batch) pair runs the stack twice as the reference does; the "
+                                       "second run reuses the layer outputs ahead of the analysed layer that the first "
+                                       "run of the SAME pair just computed (PTD_PREFIX_MEMO_MB=0 switches that off); "
+                                       "nothing is kept across pairs, layers or steps"),
                    "ranks_kept": kept(cfg)},
     }
     c2 = None

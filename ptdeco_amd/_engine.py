@@ -104,6 +104,7 @@ class PrefixMemo:
     ``PTD_PREFIX_MEMO_CHECK=1`` recomputes every kept output and raises on a difference (tests)."""
 
     IDLE, RECORD, REPLAY = 0, 1, 2
+    total_hits = 0      # products handed back since the process started (tests, tools)
 
     def __init__(self, root: torch.nn.Module, layer: torch.nn.Module, budget_bytes: int, check: bool = False):
         self.mode = self.IDLE
@@ -163,6 +164,7 @@ class PrefixMemo:
                                                "does not compute the same values before the analysed layer in both "
                                                "forwards of a metric step")
                     self.hits += 1
+                    PrefixMemo.total_hits += 1
                     return out
                 kept.clear()
             return inner(*args, **kwargs)

@@ -26,6 +26,9 @@ except Exception:  # pragma: no cover
 # the filtered eigensolver remembers late declines per (device, shape) and skips the route for the next requests of
 # that shape: tests that provoke a decline must not change the route other tests see (one test switches it back on)
 os.environ.setdefault("PTD_EIGH_FILTER_BACKOFF", "0")
+# the second forward of a metric step reuses the products ahead of the analysed layer (_engine.PrefixMemo): under test
+# every reused output is recomputed and compared bit for bit, in every model the suite runs
+os.environ.setdefault("PTD_PREFIX_MEMO_CHECK", "1")
 
 
 def pytest_configure(config):

@@ -127,6 +127,41 @@ def test_dwain_end_to_end(name):
     assert (out - ref).abs().max().item() <= REL * ref.abs().max().item()
 
 
+@pytest.mark.parametrize("method,name", [("dwain", "dwain_mlp_nosplit"), ("dwain", "dwain_conv"),
+                                         ("falor", "falor_mlp_r9"), ("falor", "falor_conv")])
+def test_metric_steps_with_and_without_the_prefix_memo_are_bit_identical(method, name, monkeypatch):
+    """The second forward of a metric step reuses the products ahead of the analysed layer (_engine.PrefixMemo):
+    every reused output is recomputed and compared (CHECK), and the metrics equal the ones of a run without it."""
+    import ptdeco_amd
+    from ptdeco_amd import _engine as eng
+
+    scn = gio.e2e_meta()[name]
+    traces = []
+    for env in ({"PTD_PREFIX_MEMO_CHECK": "1"}, {"PTD_PREFIX_MEMO_MB": "0"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        hits0 = eng.PrefixMemo.total_hits
+        model = gio.build_model(scn).to(DEV)
+        trace = []
+        if method == "dwain":
+            data, metric = gio.dwain_streams(scn)
+            ptdeco_amd.dwain.decompose_in_place(
+                module=model, device=DEV, data_iterator=data, metric_iterator=metric, loss_fn=tm.ce_loss,
+                finetune_fn=lambda m, device, names: m, trace=trace, **scn["kwargs"])
+        else:
+            ptdeco_amd.falor.decompose_in_place(
+                module=model, device=DEV, data_iterator=tm.cycle_tensors(gio.pool(scn["pool"])), trace=trace,
+                **scn["kwargs"])
+        traces.append((trace, eng.PrefixMemo.total_hits - hits0))
+        for k in env:
+            monkeypatch.delenv(k)
+        assert all("forward" not in m.__dict__ for m in model.modules())
+    assert traces[0][0] == traces[1][0]
+    assert traces[1][1] == 0
+    if name.endswith("nosplit") or name.endswith("r9"):
+        assert traces[0][1] > 0       # the MLPs have layers ahead of fc2 / fc3
+
+
 def test_config_round_trip_and_reload():
     """README.md:56-105 of the reference: JSON config + state_dict reload onto a fresh model."""
     import ptdeco_amd
