@@ -613,14 +613,17 @@ __global__ void sytrd_wfix_kernel(int n, int r0, int ilast, int jlast, const dou
 //     fences 5.8 us).  <32, 768, false>: 256 workgroups of 150 KB LDS (one per CU), the 32 with blockIdx.x % 8 == 0 --
 //     XCC 0, checked against the hardware id -- take the last 768 columns: 4.6 us per column against 11.5.
 //   * across XCDs entries and sequence numbers are written through to memory (sc1 stores): a hand-off costs 5.3 us.
-//     <256, 2048, true>: every CU, from a trailing order of 2048 down to 768 (then the block goes back to memory for
-//     the kernel above): 9.0 us per column against ~16.4 blocked.
+//     <256, 2048, true>: every CU, from a trailing order of 2048 down to 1024 (then the block goes back to memory for
+//     the one-XCD kernels): 9.0 us per column against ~16.4 blocked.  <32, 1024, false> (four rows a wave, 249 VGPRs,
+//     no spill) takes 1024 .. 769 on one XCD at ~4.9 us per column and hands over to <32, 768, false>, which is the
+//     faster of the two below 768 (round 4: n = 1280 9.25 -> 8.52 ms, n = 1024 5.78 -> 4.97 ms).
 //   * sytrd_resident3_kernel (further down): the same on every CU for trailing orders 3072 .. 2049, three half rows
 //     per wave: ~14.7 us per column.
 // Every spin is bounded; a time-out or an XCC mismatch sets the status word and the host repeats the reduction on the
 // blocked path.  ptd_eigh_topk n = 4096, k = 1024: 68.2 -> 54.3 ms (with the twisted-factorisation eigenvectors);
 // n = 768: 9.0 -> 4.3 ms.
 constexpr int RES_MAX = 768;                             // one XCD: 32 workgroups
+constexpr int RES_MID = 1024;                            // one XCD, four rows a wave: trailing orders 1024 .. 769
 constexpr int RES_WG = 32;
 constexpr int RESG_MAX = 2048;                           // the whole chip: 256 workgroups, hand-offs through memory
 constexpr int RESG_WG = 256;
@@ -2102,7 +2105,8 @@ void probe_device(DeviceState& ds) {
   ds.cus = prop.multiProcessorCount;
   ds.gfx950 = strncmp(prop.gcnArchName, "gfx950", 6) == 0;
   // (the attribute belongs to this device's copy of the function; it is set again before every launch)
-  const void* kernels[3] = {reinterpret_cast<const void*>(sytrd_resident_kernel<RES_WG, RES_MAX, false>),
+  const void* kernels[4] = {reinterpret_cast<const void*>(sytrd_resident_kernel<RES_WG, RES_MAX, false>),
+                            reinterpret_cast<const void*>(sytrd_resident_kernel<RES_WG, RES_MID, false>),
                             reinterpret_cast<const void*>(sytrd_resident_kernel<RESG_WG, RESG_MAX, true>),
                             reinterpret_cast<const void*>(sytrd_resident3_kernel)};
   bool ok = true;
@@ -2207,6 +2211,8 @@ int sytrd_f64(const TridiagPlan& p, char* base, SymvTimer* timer, bool resident,
       const bool attr =
           hipFuncSetAttribute(reinterpret_cast<const void*>(sytrd_resident_kernel<RES_WG, RES_MAX, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)RES_LDS) == hipSuccess &&
+          hipFuncSetAttribute(reinterpret_cast<const void*>(sytrd_resident_kernel<RES_WG, RES_MID, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)RES_LDS) == hipSuccess &&
           hipFuncSetAttribute(reinterpret_cast<const void*>(sytrd_resident_kernel<RESG_WG, RESG_MAX, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)RES_LDS) == hipSuccess &&
           hipFuncSetAttribute(reinterpret_cast<const void*>(sytrd_resident3_kernel),
@@ -2222,12 +2228,23 @@ int sytrd_f64(const TridiagPlan& p, char* base, SymvTimer* timer, bool resident,
         hipLaunchKernelGGL(sytrd_resident3_kernel, dim3(RESG_WG), dim3(RES_T), RES_LDS, st, Aw, ld, n, j0, t2 - j0, Vall,
                            taus, d, e, rctl, X, epoch);
       }
-      if (n - t2 > RES_MAX) {
-        // every CU first: down to a trailing order of 768
+      const int one_xcd = resident_mode() == 1 ? RES_MAX : RES_MID;   // (mode 1: the 768 tail alone, as it was measured)
+      if (n - t2 > one_xcd) {
+        // every CU first: down to a trailing order of 1024
         const unsigned long long epoch = (calls.fetch_add(1) + 1) << 16;   // > any sequence number of an earlier launch
-        t1 = n - RES_MAX;
+        t1 = n - one_xcd;
         hipLaunchKernelGGL((sytrd_resident_kernel<RESG_WG, RESG_MAX, true>), dim3(RESG_WG), dim3(RES_T), RES_LDS, st, Aw, ld,
                            n, t2, t1 - t2, Vall, taus, d, e, rctl, X, epoch);
+      }
+      if (n - t1 > RES_MAX) {
+        // one XCD from 1024 down to 768 with four rows a wave (4.9 us a column against 9 on every CU; the same kernel
+        // is slower than the three-row form below 768 -- 4.6 against 3.9 ms at n = 768 -- so it hands over there)
+        const unsigned long long epoch = (calls.fetch_add(1) + 1) << 16;
+        const int t15 = n - RES_MAX;
+        hipLaunchKernelGGL((sytrd_resident_kernel<RES_WG, RES_MID, false>), dim3(8 * RES_WG), dim3(RES_T), RES_LDS, st, Aw,
+                           ld, n, t1, t15 - t1, Vall, taus, d, e, rctl, X, epoch);
+        PTD_CHECK_HIP(hipMemsetAsync(&rctl->reg, 0, sizeof(unsigned), st));   // the next launch registers afresh
+        t1 = t15;
       }
       const unsigned long long epoch = (calls.fetch_add(1) + 1) << 16;
       hipLaunchKernelGGL((sytrd_resident_kernel<RES_WG, RES_MAX, false>), dim3(8 * RES_WG), dim3(RES_T), RES_LDS, st, Aw, ld,
