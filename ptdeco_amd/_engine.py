@@ -101,7 +101,8 @@ class PrefixMemo:
     outputs are therefore always a prefix of its calls); an output that was modified in place since it was kept
     (``relu_`` on a conv output) or whose call sees another input shape is recomputed; modules that already carry an
     instance-level ``forward`` are left alone.  ``PTD_PREFIX_MEMO_MB`` = byte budget in MiB (default 8192, 0 = off),
-    ``PTD_PREFIX_MEMO_CHECK=1`` recomputes every kept output and raises on a difference (tests)."""
+    ``PTD_PREFIX_MEMO_CHECK=1`` recomputes every kept output and raises on a difference beyond the
+    rounding of its dtype (tests)."""
 
     IDLE, RECORD, REPLAY = 0, 1, 2
     total_hits = 0      # products handed back since the process started (tests, tools)
@@ -158,8 +159,14 @@ class PrefixMemo:
                 out, version, shape = kept.popleft()
                 if out._version == version and args and isinstance(args[0], torch.Tensor) and args[0].shape == shape:
                     if self.check:
+                        # (bit-identical for this package's kernels; a library kernel may vary from call to call on
+                        # identical input -- one MIOpen 3x3 stride-2 convolution of the ResNet-18 test does, by an ulp
+                        # -- so the bound is the rounding of the dtype, far below what a forward that is not a
+                        # function of its input -- dropout, running statistics -- would show)
                         again = inner(*args, **kwargs)
-                        if not torch.equal(again, out):
+                        tol = {torch.float64: 1e-10, torch.float32: 1e-4}.get(out.dtype, 2e-2)
+                        if not torch.equal(again, out) and not (
+                                (again.double() - out.double()).abs().max() <= tol * out.double().abs().max()):
                             raise RuntimeError(f"ptdeco_amd: prefix memo mismatch in {type(m).__name__}: the model "
                                                "does not compute the same values before the analysed layer in both "
                                                "forwards of a metric step")
