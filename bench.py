@@ -23,6 +23,7 @@ The same line carries
   roofline       the dominant kernel of the eigensolver against its bound: frac on SURVEY 8d's
                  algorithmic work, solver_frac for the whole ptd_eigh call
   phases_ms      device-time split of one step: A accumulate, B eigh, C factors, D metrics, comm
+  stack_phases_ms  the same split for one step of the fixed stack (the workload `value` is quoted on), N = 1
   kernels        per-kernel device time / rates from HIP events
   cpu_baseline   the CPU oracle (restatement of the reference, torch-CPU/MKL) on the C2
                  workload on this box's physical host cores, rank 0, N = 1 only
@@ -704,6 +705,19 @@ def main():
         ph["step_wall_ms"] = wall_p
         result["phases_ms"] = {k: round(v, 3) for k, v in ph.items()}
         result["phases_ms"]["of"] = described
+        if c2 is not None:
+            # the same split for the workload `value` is quoted on (one more untimed step of the fixed stack)
+            eng.PHASES = eng.PhaseTimer()
+            barrier()
+            t0p = time.perf_counter()
+            stack_step()
+            barrier()
+            wall_s = (time.perf_counter() - t0p) * 1e3
+            ph, eng.PHASES = eng.PHASES.totals_ms(), None
+            ph["other_host_and_gaps"] = max(0.0, wall_s - sum(ph.values()))
+            ph["step_wall_ms"] = wall_s
+            result["stack_phases_ms"] = {k: round(v, 1) for k, v in ph.items()}
+            result["stack_phases_ms"]["of"] = "the fixed stack (`value`)"
         ops.EIGH_PROFILE = []
         one_step()
         barrier()

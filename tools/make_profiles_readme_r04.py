@@ -24,7 +24,9 @@ o.append("Files (round 4):\n\n"
          "* `tools/refresh_profiles.sh 04 main|bench|pmc` reruns them on a GPU box\n\n")
 o.append("## Headline\n\n")
 o.append(f"* `value` = **{b['value']:.2f} layers/s** ({b['ms_per_step']:.0f} ms per step): the FIXED stack of 8 x nn.Linear(4096,4096), f32 model, D = 8, M = 2, one GPU -- the strong-scaling family of `bench.py` (the same work at every N).  "
-         "Of a step, ~1.38 s are the method's own whole-model forwards (8 layers x 12 (candidate, batch) pairs x 16 dense f32 GEMMs at 96 % of the f32 MFMA peak), ~0.3 s the eight eigendecompositions, ~0.1 s the covariance accumulation.  "
+         + ((lambda q: f"Of a step (`stack_phases_ms`, one extra untimed step: {q['step_wall_ms']:.0f} ms): D metrics {q['D_metrics']:.0f} ms -- the method's own whole-model forwards, 8 layers x 12 (candidate, batch) pairs x two passes over 8 dense f32 GEMMs, the second pass reusing what the first computed ahead of the analysed layer (round 4: `_engine.PrefixMemo`; 1465 ms per step without it) --, B eigh {q['B_eigh']:.0f} ms (eight eigendecompositions on four streams), A accumulate {q['A_accumulate']:.0f} ms, C factors {q['C_factors']:.0f} ms.  ")(b['stack_phases_ms']) if 'stack_phases_ms' in b else
+            "Most of a step is the method's own whole-model forwards (8 layers x 12 (candidate, batch) pairs x two passes over 8 dense f32 GEMMs, the second pass reusing what the first computed ahead of the analysed layer: round 4, `_engine.PrefixMemo`; 1465 ms per step without it), then the eight eigendecompositions (~0.2 s on four streams) and the covariance accumulation (~0.1 s).  ")
+         +
          f"The same stack with a bf16 model (`bf16_stack`): **{b['bf16_stack']['value']:.1f} layers/s** ({b['bf16_stack']['ms_per_step']:.0f} ms per step).\n")
 o.append(f"* `c2_single_layer` = BASELINE configs[1] itself: **{c2['value']:.2f} layers/s** ({c2['ms_per_step']:.1f} ms per dwain decomposition of ONE 4096x4096 Linear, f32 model, T = 4x1024, D = 4, M = 2; steps {c2['step_ms']}) -- round 3: 18.9 / 52.9 ms.  "
          f"CPU oracle on the same workload: **{cb['value']:.3f} layers/s** on {cb['cores']} host threads ({cb['sample']}).\n")
