@@ -146,8 +146,9 @@ class PrefixMemo:
         def forward(*args, **kwargs):
             if self.mode == self.RECORD:
                 out = inner(*args, **kwargs)
-                if not (self.reached or self.full) and isinstance(out, torch.Tensor) and args \
-                        and isinstance(args[0], torch.Tensor):
+                # (inference tensors carry no version counter: an in-place change could not be seen, so none is kept)
+                if not (self.reached or self.full) and isinstance(out, torch.Tensor) and not out.is_inference() \
+                        and args and isinstance(args[0], torch.Tensor):
                     nbytes = out.numel() * out.element_size()
                     if self.bytes + nbytes <= self.budget:
                         kept.append((out, out._version, args[0].shape))

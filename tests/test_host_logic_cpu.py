@@ -468,6 +468,21 @@ def test_prefix_memo_replays_only_what_ran_before_the_tapped_layer():
     assert all("forward" not in m.__dict__ for m in model.modules())
 
 
+def test_prefix_memo_keeps_nothing_under_inference_mode():
+    from ptdeco_amd import _engine as eng
+
+    model = _MemoNet().eval()
+    x = torch.randn(5, 3, 2, 2)
+    with torch.no_grad():
+        want = model(x)
+    with torch.inference_mode():
+        tap = eng.LayerTap(model, "tapped")
+        tap.memo = eng.PrefixMemo(model, tap.layer, 1 << 30, check=True)
+        y1, y2 = eng.forward_pair(model, tap, x, lambda: None, lambda: None)
+        assert tap.memo.hits == 0 and torch.equal(y1, want) and torch.equal(y2, want)
+        tap.close()
+
+
 def test_prefix_memo_is_off_with_a_zero_budget(monkeypatch):
     from ptdeco_amd import _engine as eng
 
