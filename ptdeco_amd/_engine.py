@@ -88,26 +88,67 @@ def require_device(device) -> torch.device:
     return device
 
 
+def _flat_tensors(obj, out: list) -> bool:
+    """Collects the tensors of a nest of tuples / lists / dicts; False when anything else than tensors, None and
+    plain scalars sits in it (a cache object, a module, ...)."""
+    if isinstance(obj, torch.Tensor):
+        out.append(obj)
+        return True
+    if obj is None or isinstance(obj, (bool, int, float, str, torch.dtype, torch.device, torch.Size)):
+        return True
+    if isinstance(obj, (tuple, list)):
+        return all(_flat_tensors(o, out) for o in obj)
+    if isinstance(obj, dict):
+        return all(isinstance(k, str) and _flat_tensors(v, out) for k, v in obj.items())
+    return False
+
+
+def _subtree_state(mod: torch.nn.Module) -> list:
+    """What a forward that is a function of its arguments leaves alone: training flags, which objects the modules'
+    attributes are bound to, and the version counters of parameters and buffers."""
+    st: list = []
+    for m in mod.modules():
+        st.append(m.training)
+        for k, v in m.__dict__.items():
+            if k not in ("_parameters", "_buffers", "_modules"):
+                st.append((k, id(v)))
+        for d in (m._parameters, m._buffers):
+            for k, v in d.items():
+                st.append((k, id(v), -1 if v is None or v.is_inference() else v._version))
+    return st
+
+
 class PrefixMemo:
     """One metric step runs the model twice on the same input -- the candidate, then the original (dwain.py:263-267,
     falor.py:223-227) -- and the two forwards differ in the tapped layer alone: everything the model computes BEFORE
-    that layer's first call is computed twice with the same operands.  The memo keeps, during the first forward, the
-    outputs of the matrix-product modules (Linear / conv / fused rank-r pairs) that ran before the tapped layer and
-    hands them back in the second: at depth f of a stack the second forward costs 1 - f of its products.  Nothing
-    outlives the step (no reuse across batches, candidates or calls) and the numbers are the ones a second run of the
-    same kernel on the same operands gives.
+    that layer's first call is computed twice with the same operands.  The memo keeps, during the first forward, what
+    ran before the tapped layer and hands it back in the second.  Nothing outlives the step (no reuse across batches,
+    candidates or calls) and the numbers are the ones a second run on the same operands gives.
 
-    Guards: recording stops at the tapped layer's first call and when the byte budget is spent (a module's kept
-    outputs are therefore always a prefix of its calls); an output that was modified in place since it was kept
-    (``relu_`` on a conv output) or whose call sees another input shape is recomputed; modules that already carry an
+    Units.  (1) Matrix-product modules (Linear / conv / fused rank-r pairs): always.  (2) Whole SUBTREES of the module
+    tree that do not contain the tapped layer -- the siblings along the path from the root to it: the decoder blocks
+    in front of the block under analysis, the attention block in front of an MLP layer -- so that their norms,
+    activations and attention are skipped as well and one output per block is kept instead of one per product.  A
+    subtree qualifies only if it is seen to be a function of its arguments: no forward hooks inside it (they would not
+    fire), eval mode, arguments and results that are nests of tensors / None / scalars (a cache object passed in
+    disqualifies it), and a first recorded call that leaves every attribute binding, parameter and buffer version of
+    the subtree as it found them; otherwise its products are kept one by one as in (1).
+    ``PTD_PREFIX_MEMO_UNITS=products`` keeps to (1).
+
+    Guards: recording stops at the tapped layer's first call and when the byte budget is spent; entries are keyed by
+    the call index of their module within the forward (weight sharing, a module called again behind the tapped layer);
+    a kept tensor that was modified in place since (``relu_`` on a conv output: the version counter), an inference
+    tensor (no counter) or a call that sees another input shape is recomputed; modules that already carry an
     instance-level ``forward`` are left alone.  ``PTD_PREFIX_MEMO_MB`` = byte budget in MiB (default 8192, 0 = off),
     ``PTD_PREFIX_MEMO_CHECK=1`` recomputes every kept output and raises on a difference beyond the
     rounding of its dtype (tests)."""
 
     IDLE, RECORD, REPLAY = 0, 1, 2
-    total_hits = 0      # products handed back since the process started (tests, tools)
+    UNKNOWN, PURE, IMPURE = 0, 1, 2
+    total_hits = 0      # outputs handed back since the process started (tests, tools)
 
-    def __init__(self, root: torch.nn.Module, layer: torch.nn.Module, budget_bytes: int, check: bool = False):
+    def __init__(self, root: torch.nn.Module, layer: torch.nn.Module, budget_bytes: int, check: bool = False,
+                 subtrees: bool = True):
         self.mode = self.IDLE
         self.reached = False
         self.full = False
@@ -115,18 +156,63 @@ class PrefixMemo:
         self.budget = budget_bytes
         self.check = check
         self.hits = 0
-        self._patched: list = []
-        fused_below: list = []
-        for name, m in root.named_modules():
-            if m is layer or any(name.startswith(p) for p in fused_below):
-                continue
-            if isinstance(m, (LowRankLinear, LowRankConv1x1)):
-                fused_below.append(name + ".")
-            elif not isinstance(m, (torch.nn.Linear, torch.nn.modules.conv._ConvNd)):
-                continue
-            if "forward" in m.__dict__:
-                continue
-            self._patch(m)
+        self.unit_hits = 0
+        self._gen = 0            # forward counter: per-module call indices restart with it
+        self._depth = 0          # > 0 while a subtree unit records: the products inside it keep nothing of their own
+        self._patched: list = []   # (module, kept dict)
+        import torch.nn.modules.module as _mm
+
+        if getattr(_mm, "_global_forward_hooks", None) or getattr(_mm, "_global_forward_pre_hooks", None):
+            subtrees = False
+        seen: set = set()
+
+        def products(mod):
+            fused_below: list = []
+            for name, m in mod.named_modules():
+                if m is layer or id(m) in seen or any(name.startswith(p) for p in fused_below):
+                    continue
+                if isinstance(m, (LowRankLinear, LowRankConv1x1)):
+                    fused_below.append(name + "." if name else "")
+                elif not isinstance(m, (torch.nn.Linear, torch.nn.modules.conv._ConvNd)):
+                    continue
+                if "forward" in m.__dict__:
+                    continue
+                seen.add(id(m))
+                self._patch(m, unit=False)
+
+        def is_product(m):
+            return isinstance(m, (LowRankLinear, LowRankConv1x1, torch.nn.Linear, torch.nn.modules.conv._ConvNd))
+
+        def hooks_inside(mod):
+            return any(c._forward_hooks or c._forward_pre_hooks or c._backward_hooks or "forward" in c.__dict__
+                       for c in mod.modules() if c is not mod)
+
+        def off_path(mod):
+            # a module beside the path to the tapped layer: its products, and the module as a whole if it qualifies
+            if isinstance(mod, (torch.nn.ModuleList, torch.nn.ModuleDict)):   # (no forward of their own)
+                for c in mod.children():
+                    off_path(c)
+                return
+            unit_ok = (subtrees and not is_product(mod) and id(mod) not in seen and "forward" not in mod.__dict__
+                       and any(True for _ in mod.children()) and not hooks_inside(mod))
+            products(mod)
+            if unit_ok:
+                seen.add(id(mod))
+                self._patch(mod, unit=True)
+
+        def on_path(mod):
+            for c in mod.children():
+                if c is layer:
+                    continue
+                if any(m is layer for m in c.modules()):
+                    on_path(c)
+                else:
+                    off_path(c)
+
+        if any(m is layer for m in root.modules()):
+            on_path(root)
+        else:
+            products(root)
 
     @staticmethod
     def from_env(root: torch.nn.Module, layer: torch.nn.Module) -> Optional["PrefixMemo"]:
@@ -135,46 +221,98 @@ class PrefixMemo:
         mb = float(os.environ.get("PTD_PREFIX_MEMO_MB", "8192"))
         if mb <= 0:
             return None
-        return PrefixMemo(root, layer, int(mb * 2**20), check=os.environ.get("PTD_PREFIX_MEMO_CHECK", "0") == "1")
+        return PrefixMemo(root, layer, int(mb * 2**20), check=os.environ.get("PTD_PREFIX_MEMO_CHECK", "0") == "1",
+                          subtrees=os.environ.get("PTD_PREFIX_MEMO_UNITS", "subtrees") != "products")
 
-    def _patch(self, m: torch.nn.Module) -> None:
-        import collections
+    @staticmethod
+    def _first_shape(args, kwargs):
+        flat: list = []
+        _flat_tensors(args, flat)
+        _flat_tensors(kwargs, flat)
+        return flat[0].shape if flat else None
 
+    def _compare(self, m, again, out) -> None:
+        # (bit-identical for this package's kernels; a library kernel may vary from call to call on identical input --
+        # one MIOpen 3x3 stride-2 convolution of the ResNet-18 test does, by an ulp -- so the bound is the rounding of
+        # the dtype, far below what a forward that is not a function of its input -- dropout, running statistics --
+        # would show)
+        fa: list = []
+        fb: list = []
+        same = _flat_tensors(again, fa) and _flat_tensors(out, fb) and len(fa) == len(fb)
+        for x, y in zip(fa, fb):
+            if not same:
+                break
+            if x.shape != y.shape or x.dtype != y.dtype:
+                same = False
+            elif not torch.equal(x, y):
+                tol = {torch.float64: 1e-10, torch.float32: 1e-4}.get(y.dtype, 2e-2)
+                same = bool((x.double() - y.double()).abs().max() <= tol * y.double().abs().max())
+        if not same:
+            raise RuntimeError(f"ptdeco_amd: prefix memo mismatch in {type(m).__name__}: the model does not compute "
+                               "the same values before the analysed layer in both forwards of a metric step")
+
+    def _patch(self, m: torch.nn.Module, unit: bool) -> None:
         inner = m.forward
-        kept: collections.deque = collections.deque()
+        kept: dict = {}
+        calls = [0, -1]                  # [calls of m in this forward, the forward they were counted in]
+        purity = [self.UNKNOWN if unit else self.PURE]
 
         def forward(*args, **kwargs):
+            if self.mode == self.IDLE:
+                return inner(*args, **kwargs)
+            if calls[1] != self._gen:
+                calls[0], calls[1] = 0, self._gen
+            idx = calls[0]
+            calls[0] += 1
             if self.mode == self.RECORD:
-                out = inner(*args, **kwargs)
-                # (inference tensors carry no version counter: an in-place change could not be seen, so none is kept)
-                if not (self.reached or self.full) and isinstance(out, torch.Tensor) and not out.is_inference() \
-                        and args and isinstance(args[0], torch.Tensor):
-                    nbytes = out.numel() * out.element_size()
-                    if self.bytes + nbytes <= self.budget:
-                        kept.append((out, out._version, args[0].shape))
-                        self.bytes += nbytes
-                    else:
-                        self.full = True
+                keep = not (self.reached or self.full) and purity[0] != self.IMPURE and (unit or self._depth == 0)
+                if not keep:
+                    return inner(*args, **kwargs)
+                if unit:
+                    flat_in: list = []
+                    if not (_flat_tensors(args, flat_in) and _flat_tensors(kwargs, flat_in)):
+                        purity[0] = self.IMPURE
+                        return inner(*args, **kwargs)
+                    if purity[0] == self.UNKNOWN and any(c.training for c in m.modules()):
+                        purity[0] = self.IMPURE
+                        return inner(*args, **kwargs)
+                    before = _subtree_state(m) if purity[0] == self.UNKNOWN else None
+                    self._depth += 1
+                    try:
+                        out = inner(*args, **kwargs)
+                    finally:
+                        self._depth -= 1
+                    if before is not None:
+                        purity[0] = self.PURE if before == _subtree_state(m) else self.IMPURE
+                    if purity[0] != self.PURE or self.reached:    # (the tapped layer ran inside: not a prefix unit)
+                        return out
+                else:
+                    out = inner(*args, **kwargs)
+                    if self.reached:
+                        return out
+                flat: list = []
+                if not _flat_tensors(out, flat) or not flat or any(t.is_inference() for t in flat):
+                    if unit:
+                        purity[0] = self.IMPURE
+                    return out
+                nbytes = sum(t.numel() * t.element_size() for t in {id(t): t for t in flat}.values())
+                if self.bytes + nbytes <= self.budget:
+                    kept[idx] = (out, flat, [t._version for t in flat], self._first_shape(args, kwargs))
+                    self.bytes += nbytes
+                else:
+                    self.full = True
                 return out
-            if self.mode == self.REPLAY and kept:
-                out, version, shape = kept.popleft()
-                if out._version == version and args and isinstance(args[0], torch.Tensor) and args[0].shape == shape:
+            # REPLAY
+            entry = kept.pop(idx, None)
+            if entry is not None:
+                out, flat, versions, shape = entry
+                if all(t._version == v for t, v in zip(flat, versions)) and self._first_shape(args, kwargs) == shape:
                     if self.check:
-                        # (bit-identical for this package's kernels; a library kernel may vary from call to call on
-                        # identical input -- one MIOpen 3x3 stride-2 convolution of the ResNet-18 test does, by an ulp
-                        # -- so the bound is the rounding of the dtype, far below what a forward that is not a
-                        # function of its input -- dropout, running statistics -- would show)
-                        again = inner(*args, **kwargs)
-                        tol = {torch.float64: 1e-10, torch.float32: 1e-4}.get(out.dtype, 2e-2)
-                        if not torch.equal(again, out) and not (
-                                (again.double() - out.double()).abs().max() <= tol * out.double().abs().max()):
-                            raise RuntimeError(f"ptdeco_amd: prefix memo mismatch in {type(m).__name__}: the model "
-                                               "does not compute the same values before the analysed layer in both "
-                                               "forwards of a metric step")
+                        self._compare(m, inner(*args, **kwargs), out)
                     self.hits += 1
+                    self.unit_hits += 1 if unit else 0
                     PrefixMemo.total_hits += 1
                     return out
-                kept.clear()
             return inner(*args, **kwargs)
 
         m.forward = forward
@@ -193,6 +331,8 @@ class PrefixMemo:
         def cm():
             self._drop()
             self.reached = self.full = False
+            self._gen += 1
+            self._depth = 0
             self.mode = self.RECORD
             try:
                 yield
@@ -206,6 +346,7 @@ class PrefixMemo:
 
         @contextlib.contextmanager
         def cm():
+            self._gen += 1
             self.mode = self.REPLAY
             try:
                 yield

@@ -468,6 +468,135 @@ def test_prefix_memo_replays_only_what_ran_before_the_tapped_layer():
     assert all("forward" not in m.__dict__ for m in model.modules())
 
 
+class _MemoBlock(torch.nn.Module):
+    def __init__(self, g, flavour="plain"):
+        super().__init__()
+        self.norm = torch.nn.LayerNorm(16)
+        self.fc1 = torch.nn.Linear(16, 32)
+        self.fc2 = torch.nn.Linear(32, 16)
+        self.flavour = flavour
+        self.count = 0
+        with torch.no_grad():
+            for p in self.parameters():
+                p.copy_(torch.randn(p.shape, generator=g) * 0.3)
+
+    def forward(self, x, extra=None):
+        if self.flavour == "counting":
+            self.count += 1                      # a side effect: the block is not a function of its arguments
+        return x + self.fc2(torch.relu(self.fc1(self.norm(x))))
+
+
+class _MemoStack(torch.nn.Module):
+    def __init__(self, flavours=("plain",) * 4):
+        super().__init__()
+        g = torch.Generator().manual_seed(9)
+        self.embed = torch.nn.Linear(8, 16)
+        self.blocks = torch.nn.ModuleList(_MemoBlock(g, f) for f in flavours)
+        self.head = torch.nn.Linear(16, 4)
+        self.extra = object()
+        with torch.no_grad():
+            for p in list(self.embed.parameters()) + list(self.head.parameters()):
+                p.copy_(torch.randn(p.shape, generator=g) * 0.3)
+
+    def forward(self, x):
+        h = self.embed(x)
+        for b in self.blocks:
+            h = b(h, extra=self.extra) if b.flavour == "object_arg" else b(h)
+        return self.head(h)
+
+
+def _spy_on(model, real):
+    def spy(name, mod):
+        inner = type(mod).forward
+
+        def fwd(self_, *a, **k):
+            real.append(name)
+            return inner(self_, *a, **k)
+        return fwd
+
+    for n, m in list(model.named_modules()):
+        if n and not isinstance(m, torch.nn.ModuleList):
+            m.__class__ = type("Spy" + n.replace(".", "_"), (type(m),), {"forward": spy(n, m)})
+
+
+def test_prefix_memo_replays_whole_subtrees_beside_the_path_to_the_tapped_layer():
+    from ptdeco_amd import _engine as eng
+
+    model = _MemoStack().eval()
+    x = torch.randn(6, 8)
+    real = []
+    _spy_on(model, real)
+    with torch.no_grad():
+        want = model(x)
+        tap = eng.LayerTap(model, "blocks.2.fc2")
+        tap.memo = eng.PrefixMemo(model, tap.layer, 1 << 30, check=False)
+        for step in range(2):      # (the first step also establishes that blocks 0 and 1 are functions of their input)
+            real.clear()
+            y1, y2 = eng.forward_pair(model, tap, x, lambda: None, lambda: None)
+            assert torch.equal(y1, want) and torch.equal(y2, want)
+            first = ["embed", "blocks.0", "blocks.0.norm", "blocks.0.fc1", "blocks.0.fc2", "blocks.1", "blocks.1.norm",
+                     "blocks.1.fc1", "blocks.1.fc2", "blocks.2", "blocks.2.norm", "blocks.2.fc1", "blocks.2.fc2",
+                     "blocks.3", "blocks.3.norm", "blocks.3.fc1", "blocks.3.fc2", "head"]
+            assert real[:len(first)] == first
+            # second forward: embed, blocks 0 and 1 come back whole (nothing inside them runs), block 2 runs with its
+            # fc1 handed back, everything from the tapped layer on is computed
+            assert real[len(first):] == ["blocks.2", "blocks.2.norm", "blocks.2.fc2", "blocks.3", "blocks.3.norm",
+                                         "blocks.3.fc1", "blocks.3.fc2", "head"], real[len(first):]
+            assert tap.memo.unit_hits == 2 * (step + 1)
+        # products only (PTD_PREFIX_MEMO_UNITS=products): the blocks run, their Linear layers do not
+        tap.memo.close()
+        tap.memo = eng.PrefixMemo(model, tap.layer, 1 << 30, subtrees=False)
+        real.clear()
+        y1, y2 = eng.forward_pair(model, tap, x, lambda: None, lambda: None)
+        assert torch.equal(y2, want) and tap.memo.unit_hits == 0
+        assert real[18:] == ["blocks.0", "blocks.0.norm", "blocks.1", "blocks.1.norm", "blocks.2", "blocks.2.norm",
+                             "blocks.2.fc2", "blocks.3", "blocks.3.norm", "blocks.3.fc1", "blocks.3.fc2", "head"]
+        tap.close()
+    assert all("forward" not in m.__dict__ for m in model.modules())
+
+
+def test_prefix_memo_takes_a_subtree_only_if_it_is_a_function_of_its_arguments():
+    from ptdeco_amd import _engine as eng
+
+    # block 0 counts its calls (an attribute is rebound), block 1 receives an object that is not a tensor nest,
+    # block 2 has a forward hook inside; only their products may be handed back, and every side effect happens twice
+    model = _MemoStack(("counting", "object_arg", "plain", "plain")).eval()
+    fired = []
+    model.blocks[2].fc1.register_forward_hook(lambda m, a, o: fired.append(1))
+    x = torch.randn(6, 8)
+    with torch.no_grad():
+        want = model(x)
+        c0, f0 = model.blocks[0].count, len(fired)
+        tap = eng.LayerTap(model, "blocks.3.fc2")
+        tap.memo = eng.PrefixMemo(model, tap.layer, 1 << 30, check=True)
+        for step in range(3):
+            y1, y2 = eng.forward_pair(model, tap, x, lambda: None, lambda: None)
+            assert torch.equal(y1, want) and torch.equal(y2, want)
+        assert tap.memo.unit_hits == 0
+        assert model.blocks[0].count == c0 + 6 and len(fired) == f0 + 6
+        # step 0 finds block 0 out AFTER running it (nothing inside it is kept in that step; block 1 is refused on its
+        # arguments, before it runs): embed + 2 + 2 + block 3's fc1 = 6; steps 1 and 2 keep all 8 products one by one
+        assert tap.memo.hits == 6 + 8 + 8
+        tap.close()
+
+
+def test_prefix_memo_leaves_subtrees_in_training_mode_alone():
+    from ptdeco_amd import _engine as eng
+
+    model = _MemoStack().eval()
+    model.blocks[0].train()
+    x = torch.randn(6, 8)
+    with torch.no_grad():
+        want = model(x)
+        tap = eng.LayerTap(model, "blocks.2.fc2")
+        tap.memo = eng.PrefixMemo(model, tap.layer, 1 << 30)
+        for _ in range(2):
+            y1, y2 = eng.forward_pair(model, tap, x, lambda: None, lambda: None)
+            assert torch.equal(y2, want)
+        assert tap.memo.unit_hits == 2      # block 1 only, in both steps
+        tap.close()
+
+
 def test_prefix_memo_keeps_nothing_under_inference_mode():
     from ptdeco_amd import _engine as eng
 
