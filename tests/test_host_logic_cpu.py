@@ -641,3 +641,41 @@ def test_dwain_driver_with_the_prefix_memo_checked_and_without_it(name, monkeypa
         for k in env:
             monkeypatch.delenv(k)
     assert traces[0] == traces[1]     # bit-identical metrics with and without the memo
+
+
+@pytest.mark.parametrize("use_cache", [False, True])
+def test_prefix_memo_on_a_hugging_face_llama(use_cache):
+    """The module signatures of a real decoder stack: decoder layers take keyword tensors, a tuple of position
+    embeddings and -- with use_cache=True -- a cache OBJECT that they update in place: then no whole layer may be
+    handed back (the cache would miss its entries), only the matrix products inside."""
+    transformers = pytest.importorskip("transformers")
+    from ptdeco_amd import _engine as eng
+
+    cfg = transformers.LlamaConfig(vocab_size=64, hidden_size=32, intermediate_size=64, num_hidden_layers=3,
+                                   num_attention_heads=4, num_key_value_heads=2, max_position_embeddings=64)
+    torch.manual_seed(0)
+    llama = transformers.LlamaForCausalLM(cfg).eval()
+
+    class Logits(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.m = llama
+
+        def forward(self, ids):
+            return self.m(input_ids=ids, use_cache=use_cache).logits
+
+    model = Logits().eval()
+    ids = torch.randint(0, 64, (2, 16))
+    with torch.no_grad():
+        want = model(ids)
+        tap = eng.LayerTap(model, "m.model.layers.2.mlp.down_proj")
+        tap.memo = eng.PrefixMemo(model, tap.layer, 1 << 30, check=True)
+        for _ in range(2):
+            y1, y2 = eng.forward_pair(model, tap, ids, lambda: None, lambda: None)
+            assert torch.equal(y1, want) and torch.equal(y2, want)
+        if use_cache:
+            assert tap.memo.unit_hits == 0 and tap.memo.hits == 2 * (2 * 7 + 4 + 2)   # q k v o gate up down, ...
+        else:
+            assert tap.memo.unit_hits == 2 * 3     # two decoder layers and the attention block of the third, per step
+        tap.close()
+    assert all("forward" not in m.__dict__ for m in model.modules())
