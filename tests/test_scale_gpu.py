@@ -143,6 +143,73 @@ def _seq_ce(batch, logits):
                                              reduction="none")
 
 
+@pytest.mark.parametrize("splits", [None, 2])
+def test_dwain_hugging_face_llama_matches_oracle(splits):
+    """dwain on a transformers.LlamaForCausalLM (2 decoder layers, hidden 256, GQA with 2 KV heads, MLP 640; 14
+    decomposable layers, lm_head blacklisted) against the CPU oracle: the module classes, call signatures (keyword
+    tensors, position-embedding tuples) and layer names of the real model family behind BASELINE configs[3], with and
+    without the precompute-in-splits pass.  Seed 7 was picked on the CPU (10 seeds scanned with the oracle) so that in
+    both variants every step of the oracle's run is more than 4e-3 away from every threshold."""
+    transformers = pytest.importorskip("transformers")
+    import ptdeco_amd
+
+    cfg_l = transformers.LlamaConfig(vocab_size=384, hidden_size=256, intermediate_size=640, num_hidden_layers=2,
+                                     num_attention_heads=4, num_key_value_heads=2, max_position_embeddings=128,
+                                     attn_implementation="eager")
+    llama = transformers.LlamaForCausalLM(cfg_l)
+    g = torch.Generator().manual_seed(7)
+    with torch.no_grad():
+        for p in llama.parameters():
+            if p.ndim == 2:
+                p.copy_(torch.randn(p.shape, generator=g) / p.shape[1] ** 0.5)
+
+    class Logits(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.m = llama
+
+        def forward(self, b):
+            return self.m(input_ids=b["ids"], use_cache=False).logits
+
+    model = Logits().eval()
+    ids = [torch.randint(0, 384, (2, 96), generator=g) for _ in range(10)]
+    with torch.no_grad():
+        batches = [{"ids": i, "targets": model({"ids": i}).argmax(-1)} for i in ids]
+    kw = dict(num_data_steps=3, num_metric_steps=1, nsr_final_threshold=0.4, min_rank=16, trade_off_factor=30.0,
+              reduction_factor=0.5, max_accepted_ppl_diff=0.3, decompose_in_float64=True,
+              blacklisted_module_names=["m.lm_head"], precomputing_covariance_num_splits=splits)
+    ref_model, ref_trace = copy.deepcopy(model), []
+    ref_cfg = orc.dwain_decompose(module=ref_model, data_iterator=itertools.cycle(batches), loss_fn=_seq_ce,
+                                  metric_iterator=itertools.cycle(batches[5:]), trace=ref_trace, **kw)
+    model.to(DEV)
+    trace = []
+    from ptdeco_amd import _engine as eng
+    hits0 = eng.PrefixMemo.total_hits
+    cfg = ptdeco_amd.dwain.decompose_in_place(
+        module=model, device=DEV, data_iterator=itertools.cycle(batches), loss_fn=_seq_ce,
+        metric_iterator=itertools.cycle(batches[5:]), finetune_fn=lambda m, d, n: m, trace=trace, **kw)
+    margins = [min(abs(t["ppl_diff"] - t["threshold"]), abs(t["ppl_diff"] - 0.3), abs(t["nsr"] - 0.4))
+               for t in ref_trace]
+    assert min(margins) > 1e-3, f"the oracle run is within {min(margins):.1e} of a threshold: pick another seed"
+    assert [(t["layer"], t["rank"], t["accepted"]) for t in trace] == \
+           [(t["layer"], t["rank"], t["accepted"]) for t in ref_trace]
+    for t, r in zip(trace, ref_trace):
+        assert abs(t["nsr"] - r["nsr"]) <= 1e-4 * abs(r["nsr"]) + 2e-6, (t, r)
+        assert abs(t["ppl_diff"] - r["ppl_diff"]) <= 1e-4 * abs(r["ppl_diff"]) + 2e-5, (t, r)
+    assert len(trace) == 48 and len(ref_cfg) >= 10
+    assert list(cfg.keys()) == list(ref_cfg.keys())
+    assert any(k.endswith("self_attn.k_proj") for k in cfg) and any(k.endswith("mlp.gate_proj") for k in cfg)
+    assert eng.PrefixMemo.total_hits > hits0        # (whole decoder layers come back in the second forwards)
+    for name in cfg:
+        a_g, b_g = (model.get_submodule(name)[i].weight.detach().cpu().double() for i in (0, 1))
+        a_r, b_r = (ref_model.get_submodule(name)[i].weight.detach().double() for i in (0, 1))
+        assert (b_g @ a_g - b_r @ a_r).norm().item() <= 1e-4 * (b_r @ a_r).norm().item(), name
+    with torch.no_grad():
+        out = model({"ids": ids[0].to(DEV)}).cpu()
+        ref = ref_model({"ids": ids[0]})
+    assert (out - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
+
+
 @pytest.mark.parametrize("splits", [None, 4])
 def test_dwain_llama_shaped_mini_matches_oracle(splits):
     """14 decomposable layers of four distinct shapes incl. n_out > n_in (gate/up) and
