@@ -20,6 +20,7 @@
 #include <hip/hip_ext.h>
 
 #include "common.h"
+#include "kernels.h"
 #include "twostage.h"
 
 namespace ptd {
@@ -2358,9 +2359,25 @@ int tridiag_eigenvalues(const TridiagPlan& p, char* base, int first, hipStream_t
 
 
 // eigenvectors of T for all eigenvalues into Y (= evecs, [n][ldv]), then Y <- Q Y
+namespace {
+// G (mp x mp) <- identity outside its leading nvec x nvec block (which the Gram product fills)
+__global__ void gram_pad_kernel(double* __restrict__ G, int mp, int nvec) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < (int64_t)mp * mp; e += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(e / mp), c = (int)(e % mp);
+    if (r >= nvec || c >= nvec) G[e] = r == c ? 1.0 : 0.0;
+  }
+}
+}  // namespace
+
+// long_chains: more than 48 consecutive eigenvalues closer than ortol |T| (a dominant outlier above a dense bulk makes
+// every spacing of the bulk small RELATIVE TO |T|): the chain-by-chain modified Gram-Schmidt would take O(L^2) dependent
+// passes, so ALL vectors are orthonormalised at once by one Cholesky-QR pass instead (Gram matrix, Cholesky sweep, one
+// product: ~2 ms at k = 1024).  The computed vectors are orthogonal to ~eps |T| / gap <= 1e-6 already, so the Gram
+// matrix is I + O(1e-6) and one pass is exact to rounding; the triangular factor mixes a vector only with its
+// predecessors in eigenvalue order, by those same tiny amounts.
 int tridiag_vectors_and_backtransform(const TridiagPlan& p, char* base, int nvec, double* Y, int64_t ldy,
                                       double ortol, int niter, bool two, hipEvent_t ev_vec, hipEvent_t ev_q2,
-                                      hipStream_t st) {
+                                      hipStream_t st, bool long_chains = false) {
   const int n = p.n;
   const int64_t ld = p.ld;
   double* d = reinterpret_cast<double*>(base + p.off_d);
@@ -2406,10 +2423,37 @@ int tridiag_vectors_and_backtransform(const TridiagPlan& p, char* base, int nvec
   }
   hipLaunchKernelGGL(invit_scale_kernel, dim3((unsigned)ceil_div(nvec, 256), 256), dim3(256), 0, st, Y, ldy, n, nvec,
                      ws.Lm);
-  if (ortol > 0.0)
+  if (ortol > 0.0 && !long_chains)
     hipLaunchKernelGGL(tridiag_chain_mgs_kernel, dim3((unsigned)nvec), dim3(256), 0, st, lamk, n, nvec, bounds, ortol,
                        Y, ldy);
   PTD_CHECK_LAUNCH("tridiag_invit");
+  if (ortol > 0.0 && long_chains) {
+    // (the inverse-iteration buffers u1 .. lm are dead behind the kernels above; the working copy of A is free until
+    // the back-transformation fills it with T_p V_p)
+    const int64_t mp = (int64_t)align_up((size_t)nvec, 64);
+    double* G = reinterpret_cast<double*>(base + p.off_u1);
+    double* Wt = G + mp * mp;
+    char* cws = reinterpret_cast<char*>(Wt + mp * mp);
+    const size_t cbytes = chol_inverse_workspace_bytes(mp);
+    // (one-stage: the working copy of A is free here; two-stage: it holds the stage-1 reflectors, so the new block
+    // goes behind the Cholesky workspace)
+    char* after = cws + align_up(cbytes, 256);
+    double* Ynew = two ? reinterpret_cast<double*>(after) : reinterpret_cast<double*>(base + p.off_A);
+    const size_t used = (size_t)(after - (base + p.off_u1)) + (two ? (size_t)n * nvec * 8 : 0);
+    if (used > (size_t)(p.off_sw - p.off_u1) || (!two && (size_t)n * nvec * 8 > (size_t)(p.off_V - p.off_A))) {
+      set_error("eigh_tridiag: no room to orthonormalise %d clustered vectors", nvec);
+      return PTD_ERR_UNSUPPORTED;
+    }
+    hipLaunchKernelGGL(gram_pad_kernel, dim3(1024), dim3(256), 0, st, G, (int)mp, nvec);
+    int rc = gemm_f64(Y, 1, ldy, Y, ldy, 1, G, mp, nvec, nvec, n, 1.0, false, 1, st);
+    if (rc != PTD_OK) return rc;
+    rc = chol_inverse(G, mp, Wt, cws, cbytes, st);
+    if (rc != PTD_OK) return rc == PTD_ERR_WORKSPACE ? PTD_ERR_UNSUPPORTED : rc;
+    rc = gemm_f64(Y, ldy, 1, Wt, mp, 1, Ynew, nvec, n, nvec, nvec, 1.0, false, 1, st);
+    if (rc != PTD_OK) return rc;
+    PTD_CHECK_HIP(hipMemcpy2DAsync(Y, (size_t)ldy * 8, Ynew, (size_t)nvec * 8, (size_t)nvec * 8, (size_t)n,
+                                   hipMemcpyDeviceToDevice, st));
+  }
   if (ev_vec) PTD_CHECK_HIP(hipEventRecord(ev_vec, st));
   if (two)  // Z = Q1 (Q2 Y); the inverse-iteration factors (off_u1) are dead by now and hold T_p V_p
     return twostage_backtransform(p.ts, base + p.off_ts, reinterpret_cast<const double*>(base + p.off_A), Vall, ld,
@@ -2445,6 +2489,75 @@ int tridiag_vectors_and_backtransform(const TridiagPlan& p, char* base, int nvec
     if (rc != PTD_OK) return rc;
   }
   PTD_CHECK_LAUNCH("tridiag_backtransform");
+  return PTD_OK;
+}
+
+// ---- a cluster at the BOTTOM of the spectrum that reaches into the requested eigenvalues
+// A rank-deficient covariance with the drivers' damping (C + d I, d = 0.01 mean diag) has n - r eigenvalues equal to d
+// to working precision; when the request asks for more than r eigenvectors, k - r of them belong to that cluster.
+// Inverse iteration cannot separate them -- and does not have to: EVERY unit vector orthogonal to the eigenvectors of
+// the eigenvalues above the cluster is an eigenvector of it (the cluster holds all the rest of the spectrum), with a
+// residual of the cluster's width.  So the r vectors above are computed as usual and the block is completed with an
+// orthonormal basis of their complement: random columns, two projections against the computed vectors, two
+// Cholesky-QR passes (all f64 matrix-core products).  Before this the whole matrix went to the Jacobi solver:
+// ~0.5 s at n = 4096 against ~65 ms.
+namespace {
+__global__ void random_fill_kernel(double* __restrict__ R, int64_t total, unsigned long long seed) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    unsigned long long z = seed + (unsigned long long)i * 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    z ^= z >> 31;
+    R[i] = (double)(z >> 11) * (2.0 / 9007199254740992.0) - 1.0;
+  }
+}
+}  // namespace
+
+// V [n][ldv]: columns [m, k) hold orthonormal vectors; columns [0, m) receive orthonormal vectors orthogonal to them.
+// PTD_ERR_UNSUPPORTED when the workspace is too small or a Gram matrix is not positive definite.
+static int complete_basis(double* V, int64_t ldv, int64_t n, int64_t m, int64_t k, char* ws, size_t ws_bytes,
+                          hipStream_t st) {
+  const int64_t kz = k - m;
+  const int64_t mp = (int64_t)align_up((size_t)m, 64);
+  if (mp > n - kz) return PTD_ERR_UNSUPPORTED;          // (the padding columns need room in the complement too)
+  size_t o = 0;
+  auto take = [&](size_t bytes) { size_t at = o; o += align_up(bytes, 256); return at; };
+  const size_t off_r0 = take((size_t)n * mp * 8), off_r1 = take((size_t)n * mp * 8);
+  const size_t off_p = take((size_t)std::max<int64_t>(kz, 1) * mp * 8);
+  const size_t off_g = take((size_t)mp * mp * 8), off_w = take((size_t)mp * mp * 8);
+  const size_t chol_bytes = chol_inverse_workspace_bytes(mp);
+  const size_t off_c = take(chol_bytes);
+  if (o > ws_bytes) return PTD_ERR_UNSUPPORTED;
+  double* R0 = reinterpret_cast<double*>(ws + off_r0);
+  double* R1 = reinterpret_cast<double*>(ws + off_r1);
+  double* P = reinterpret_cast<double*>(ws + off_p);
+  double* G = reinterpret_cast<double*>(ws + off_g);
+  double* Wt = reinterpret_cast<double*>(ws + off_w);
+  const double* Z = V + m;
+  hipLaunchKernelGGL(random_fill_kernel, dim3(2048), dim3(256), 0, st, R0, n * mp, 0x5DEECE66DULL);
+  PTD_CHECK_LAUNCH("complete_basis (fill)");
+  int rc = PTD_OK;
+  for (int pass = 0; pass < 2 && kz > 0; ++pass) {
+    // P = Z^T R, R -= Z P
+    rc = gemm_f64(Z, 1, ldv, R0, mp, 1, P, mp, kz, mp, n, 1.0, false, 1, st);
+    if (rc != PTD_OK) return rc;
+    rc = gemm_f64(Z, ldv, 1, P, mp, 1, R0, mp, n, mp, kz, -1.0, true, 1, st);
+    if (rc != PTD_OK) return rc;
+  }
+  double* cur = R0;
+  double* nxt = R1;
+  for (int pass = 0; pass < 2; ++pass) {
+    // G = R^T R = L L^T, R <- R L^-T
+    rc = gemm_f64(cur, 1, mp, cur, mp, 1, G, mp, mp, mp, n, 1.0, false, 1, st);
+    if (rc != PTD_OK) return rc;
+    rc = chol_inverse(G, mp, Wt, ws + off_c, chol_bytes, st);
+    if (rc != PTD_OK) return rc == PTD_ERR_WORKSPACE ? PTD_ERR_UNSUPPORTED : rc;
+    rc = gemm_f64(cur, mp, 1, Wt, mp, 1, nxt, mp, n, mp, mp, 1.0, false, 1, st);
+    if (rc != PTD_OK) return rc;
+    std::swap(cur, nxt);
+  }
+  PTD_CHECK_HIP(hipMemcpy2DAsync(V, (size_t)ldv * 8, cur, (size_t)mp * 8, (size_t)m * 8, (size_t)n,
+                                 hipMemcpyDeviceToDevice, st));
   return PTD_OK;
 }
 
@@ -2541,19 +2654,80 @@ int eigh_tridiag(const double* A, int64_t lda, int64_t n, int64_t k, double* eva
   if (getenv("PTD_JACOBI_DEBUG"))
     fprintf(stderr, "[eigh_tridiag] n=%lld %s min relative gap %.3e, longest chain of gaps below %.0e: %d\n",
             (long long)n, two ? "two-stage" : "one-stage", h_gap[0], ortol, (int)h_gap[1]);
-  if (n > 1 && (!(h_gap[0] > cluster_tol) || h_gap[1] > 48.0)) {
-    set_error("eigh_tridiag: clustered eigenvalues (min relative gap %.3e, chain of %d)", h_gap[0], (int)h_gap[1] + 1);
-    cleanup2();
-    return PTD_ERR_UNSUPPORTED;
+  int64_t kreal = k;     // requested eigenvalues above a cluster at the bottom of the spectrum (k: no such cluster)
+  static const bool no_long_chains = getenv("PTD_EIGH_LONG_CHAINS") && atoi(getenv("PTD_EIGH_LONG_CHAINS")) == 0;
+  // Neighbours closer than cluster_tol |T| (1e-10) or chains of more than 48 close ones used to be refused.  With every
+  // computed vector orthonormalised by one Cholesky-QR pass (tridiag_vectors_and_backtransform, long_chains) the limit
+  // is where two inverse-iteration vectors stop being independent: eigenvalues are exact to ~1e-16 |T|, so at a gap of
+  // 1e-13 |T| the mutual contamination is still ~1e-3 and the Gram matrix well conditioned.  Below that only a
+  // cluster at the bottom of the spectrum is served (complete_basis).
+  const double hard_tol = 1e-3 * cluster_tol;
+  bool force_qr = false;
+  if (n > 1 && (!(h_gap[0] > cluster_tol) || h_gap[1] > 48.0) && !no_long_chains && h_gap[0] > hard_tol) force_qr = true;
+  if (n > 1 && !force_qr && (!(h_gap[0] > cluster_tol) || h_gap[1] > 48.0)) {
+    // clustered.  The one case served here: the cluster is the bottom of the spectrum (see complete_basis)
+    static const bool no_completion = getenv("PTD_EIGH_NULL_COMPLETION") && atoi(getenv("PTD_EIGH_NULL_COMPLETION")) == 0;
+    bool served = false;
+    if (!no_completion && k < n) {
+      if (!all_values) {
+        rc = tridiag_eigenvalues(p, base, 0, st);
+        if (rc != PTD_OK) { cleanup2(); return rc; }
+      }
+      std::vector<double> hl((size_t)n);
+      double hb[4] = {0, 0, 0, 0};
+      PTD_CHECK_HIP(hipMemcpyAsync(hl.data(), lam, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+      PTD_CHECK_HIP(hipMemcpyAsync(hb, bounds, 32, hipMemcpyDeviceToHost, st));
+      PTD_CHECK_HIP(hipStreamSynchronize(st));
+      const double tnorm = std::max(hb[3], 2.2250738585072014e-308);
+      int64_t jt = 0;                                   // the cluster: indices 0 .. jt, within 1e-9 |T| of lambda_0
+      while (jt + 1 < n && hl[(size_t)jt + 1] - hl[0] <= 1e-9 * tnorm) ++jt;
+      if (jt >= n - k && jt >= 1 && jt + 1 < n + 1) {
+        double gmin = INFINITY;
+        int run = 0, longest = 0;
+        for (int64_t i = jt + 1; i < n; ++i) {
+          const double gap = hl[(size_t)i] - hl[(size_t)i - 1];
+          gmin = std::min(gmin, gap);
+          run = (i > jt + 1 && gap < ortol * tnorm) ? run + 1 : 0;
+          longest = std::max(longest, run);
+        }
+        if (jt + 1 == n || (gmin / tnorm > cluster_tol && longest <= 48) || (!no_long_chains && gmin / tnorm > hard_tol)) {
+          force_qr = jt + 1 < n && !(gmin / tnorm > cluster_tol && longest <= 48);
+          kreal = n - 1 - jt;
+          h_gap[0] = jt + 1 == n ? 1.0 : gmin / tnorm;
+          h_gap[1] = (double)longest;
+          served = true;
+          if (getenv("PTD_JACOBI_DEBUG"))
+            fprintf(stderr, "[eigh_tridiag] n=%lld k=%lld: %lld eigenvalues within 1e-9 |T| of the smallest: %lld vectors "
+                    "computed, %lld completed from their complement\n", (long long)n, (long long)k, (long long)(jt + 1),
+                    (long long)kreal, (long long)(k - kreal));
+        }
+      }
+    }
+    if (!served) {
+      set_error("eigh_tridiag: clustered eigenvalues (min relative gap %.3e, chain of %d)", h_gap[0], (int)h_gap[1] + 1);
+      cleanup2();
+      return PTD_ERR_UNSUPPORTED;
+    }
   }
   // Inverse iteration from a random start with eigenvalues exact to working precision: an iteration damps the
   // component along a neighbour by ~eps |T| / gap, so with every relative gap above 1e-5 two iterations leave it
   // below 1e-21; closer spectra keep the third (and the re-orthogonalisation above 1e-7)
   static const int force_iter = getenv("PTD_INVIT_ITERS") ? atoi(getenv("PTD_INVIT_ITERS")) : 0;
   const int niter = force_iter > 0 ? force_iter : (h_gap[0] > 1e-5 ? 2 : 3);
-  rc = tridiag_vectors_and_backtransform(p, base, (int)k, evecs, ldv, h_gap[1] > 0.0 ? ortol : 0.0, niter, two,
-                                         two ? ev : nullptr, two ? eq : nullptr, st);
-  if (rc != PTD_OK) { cleanup2(); return rc; }
+  if (kreal > 0) {
+    rc = tridiag_vectors_and_backtransform(p, base, (int)kreal, evecs + (k - kreal), ldv, h_gap[1] > 0.0 ? ortol : 0.0,
+                                           niter, two, two ? ev : nullptr, two ? eq : nullptr, st, force_qr);
+    if (rc != PTD_OK) { cleanup2(); return rc; }
+  }
+  if (kreal < k) {
+    // (the inverse-iteration factors u1 .. lm, four n x n buffers in a row, are dead behind the back-transformation)
+    rc = complete_basis(evecs, ldv, n, k - kreal, k, base + p.off_u1, (size_t)(p.off_sw - p.off_u1), st);
+    if (rc != PTD_OK) {
+      if (rc == PTD_ERR_UNSUPPORTED) set_error("eigh_tridiag: the complement of the computed eigenvectors could not be completed");
+      cleanup2();
+      return rc;
+    }
+  }
   PTD_CHECK_HIP(hipMemcpyAsync(evals, lam, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
   if (stats) {
     PTD_CHECK_HIP(hipEventRecord(e2, st));
