@@ -89,8 +89,14 @@ int ptd_cov_finalize(const void* E, int64_t ldE, int E_dtype, const void* ey, in
  *   tridiagonal route (n >= 256 in auto): blocked Householder reduction whose per-column
  *     SYMV streams the trailing matrix from HBM / Infinity Cache, eigenvalues by multisection,
  *     eigenvectors by inverse iteration, compact-WY back-transformation on the f64 matrix
- *     cores; used unless two eigenvalues are closer than 1e-10 |A| (or too many than 1e-7 |A|);
- *   one-sided block Jacobi on the f64 matrix cores: any PSD matrix, incl. rank deficient.
+ *     cores.  Requested eigenvalues closer than 1e-10 |A|, or chains of more than 48 closer than 1e-7 |A| (a
+ *     dominant outlier above a dense bulk), get all computed vectors orthonormalised by one Cholesky-QR pass; a
+ *     cluster at the BOTTOM of the spectrum that reaches into the request (a rank-deficient covariance on its
+ *     damping floor) is completed with an orthonormal basis of the complement of the vectors above it, each of
+ *     which is an eigenvector of the cluster.  Refused -- and handed to the solver below -- only when requested
+ *     eigenvalues elsewhere are closer than 1e-13 |A| (PTD_EIGH_LONG_CHAINS=0, PTD_EIGH_NULL_COMPLETION=0:
+ *     the earlier, stricter rule);
+ *   one-sided block Jacobi on the f64 matrix cores: any PSD matrix.
  * NOT fully asynchronous: synchronises `stream` to read small decisions back (cluster
  * check, Jacobi convergence flag).  sweeps_out (host pointer, may be NULL) receives the number
  * of Jacobi sweeps (0 for the tridiagonal route).
