@@ -1114,6 +1114,12 @@ int eigh_filtered(const double* A, int64_t lda, int64_t n, int64_t k, double* ev
     const double rate = pow(0.05 / rel, 1.0 / (double)filter_products);     // over ALL filter products so far
     const int extra = std::min(dmax, std::max(std::min(2, dmax), (int)ceil(log(rel / (0.1 * tol)) / log(std::max(rate, 1.5)))));
     if (debug) fprintf(stderr, "[eigh_filtered] measured %.2f per product: %d more\n", rate, extra);
+    // what the rate measured so far says the residual still needs, against what the remaining rounds can deliver (and
+    // the product budget): a spectrum that converges at 1.4 per product from 1e-5 needs ~35 more -- three capped rounds
+    // (and three Rayleigh-Ritz solves) later the answer would be the same decline
+    const double need = log(rel / tol) / log(std::max(rate, 1.05));
+    if (need > (double)((3 - attempt) * dmax) || (double)products + need > (double)max_products + dmax)
+      return decline("residual above the tolerance and out of reach at the measured rate");
     const int before = products;
     rc = filter_round(extra);
     if (rc != PTD_OK) return rc;
