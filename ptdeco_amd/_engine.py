@@ -847,7 +847,21 @@ def eigh_route_hint(cov, n_out: int, top_k: Optional[int]) -> int:
     return int(_hip.load().ptd_eigh_route(n, k, 0))
 
 
-def run_concurrently(jobs, device: torch.device, max_streams: Optional[int] = None, routes: Optional[list] = None) -> list:
+def eigh_cost_hint(cov, n_out: int, top_k: Optional[int]) -> float:
+    """Relative cost of the eigendecomposition behind `cov`, for the order in which concurrent chains are started
+    (longest first): the order of the eigenproblem cubed, the filtered route at about half of a direct reduction, the
+    factored route (Llama gate / up) with its products over the n_out rows on top."""
+    n = cov.weight.shape[1] if isinstance(cov, MomentCovariance) and cov.factored else \
+        (n_out if isinstance(cov, MomentCovariance) else cov.E.shape[0])
+    route = eigh_route_hint(cov, n_out, top_k)
+    cost = float(n) ** 3 * (0.45 if route == 3 else 1.0)
+    if isinstance(cov, MomentCovariance) and cov.factored:
+        cost += 0.25 * float(n_out) * float(n) ** 2
+    return cost
+
+
+def run_concurrently(jobs, device: torch.device, max_streams: Optional[int] = None, routes: Optional[list] = None,
+                     costs: Optional[list] = None) -> list:
     """Run independent device-side jobs (callables returning tensors) from separate host threads, each on
     its own HIP stream, and return their results in order.
 
@@ -858,7 +872,10 @@ def run_concurrently(jobs, device: torch.device, max_streams: Optional[int] = No
     no shared mutable state and releases the GIL, so the host side is plain threads.  Stream order:
     every side stream first waits for the caller's stream (inputs), the caller's stream waits for all
     of them at the end (outputs).  PTD_EIGH_STREAMS overrides the stream count (1 = sequential).  `routes` (one
-    ptd_eigh_route value per job): only read with PTD_EIGH_STREAMS_BY_ROUTE=1, see the comment below."""
+    ptd_eigh_route value per job): only read with PTD_EIGH_STREAMS_BY_ROUTE=1, see the comment below.  `costs` (one
+    relative cost per job, eigh_cost_hint): with PTD_EIGH_LONGEST_FIRST=1 the workers take the jobs longest first
+    (opt-in: the seven layers of a Llama block 226 -> 214 ms when two chains share a hardware queue, 188 -> 190 ms
+    when they do not)."""
     import os
     import threading
 
@@ -878,7 +895,8 @@ def run_concurrently(jobs, device: torch.device, max_streams: Optional[int] = No
             out = [None] * len(jobs)
             for i in alone:
                 out[i] = jobs[i]()
-            for i, res in zip(rest, run_concurrently([jobs[i] for i in rest], device, max_streams)):
+            for i, res in zip(rest, run_concurrently([jobs[i] for i in rest], device, max_streams,
+                                                     costs=None if costs is None else [costs[i] for i in rest])):
                 out[i] = res
             return out
     workers = max(1, min(len(jobs), want))
@@ -887,6 +905,11 @@ def run_concurrently(jobs, device: torch.device, max_streams: Optional[int] = No
     index = device.index if device.index is not None else torch.cuda.current_device()
     device = torch.device("cuda", index)
     main = torch.cuda.current_stream(device)
+    # Fresh streams from torch's pool at every call.  Measured (tools/block_b_eigh.py, the seven chains of a Llama
+    # block on four streams): streams used for the first time overlap well (B_eigh 185 ms); the SAME four streams at
+    # every call settle at 226 ms, and so does every 8th call here, when the pool of 32 wraps around; with
+    # GPU_MAX_HW_QUEUES=8 in the environment (the ROCm runtime maps streams onto 4 hardware queues by default, two
+    # chains then share one) every call takes 188 ms whichever streams it gets.
     streams = [torch.cuda.Stream(device=device) for _ in range(workers)]
     for st in streams:
         st.wait_stream(main)
@@ -894,6 +917,9 @@ def run_concurrently(jobs, device: torch.device, max_streams: Optional[int] = No
     errors: list = []
     lock = threading.Lock()
     cursor = [0]
+    order = list(range(len(jobs)))
+    if costs is not None and len(costs) == len(jobs) and os.environ.get("PTD_EIGH_LONGEST_FIRST", "0") == "1":
+        order.sort(key=lambda i: -costs[i])      # (stable: equal costs keep the model's order)
 
     def worker(w: int) -> None:
         try:
@@ -901,10 +927,11 @@ def run_concurrently(jobs, device: torch.device, max_streams: Optional[int] = No
             with torch.no_grad(), torch.cuda.stream(streams[w]):
                 while not errors:
                     with lock:
-                        i = cursor[0]
+                        c = cursor[0]
                         cursor[0] += 1
-                    if i >= len(jobs):
+                    if c >= len(jobs):
                         break
+                    i = order[c]
                     out[i] = jobs[i]()
         except BaseException as exc:  # re-raised on the calling thread
             errors.append(exc)

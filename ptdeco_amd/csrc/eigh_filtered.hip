@@ -745,8 +745,8 @@ int chol_inverse(double* G, int64_t m, double* Wt, void* ws, size_t ws_bytes, hi
 // A decline after the density estimate costs 1.5 ms of a 55 ms direct reduction; a LATE one -- a Cholesky breakdown, a
 // residual that does not come down, clustered Ritz values -- has spent some fifteen products and a Rayleigh-Ritz solve
 // first.  The layers of one model share shapes and tend to share the character of their spectra, so after a late
-// decline the next 1, 2, 4, ... 64 requests of the same (device, n, k) go straight to the direct route; a success resets
-// the count.
+// decline THAT FOLLOWS ANOTHER (no success in between) the next 1, 2, 4, ... 64 requests of the same (device, n, k) go
+// straight to the direct route; a success resets the count.
 namespace {
 struct DeclineNote { int device; int64_t n, k; int fails; int skip; };
 std::mutex g_decline_mu;
@@ -785,8 +785,11 @@ static void note_outcome(int64_t n, int64_t k, bool late_decline) {
   DeclineNote* d = decline_note(current_device(), n, k, late_decline);
   if (!d) return;
   if (late_decline) {
-    d->fails = std::min(d->fails + 1, 7);
-    d->skip = 1 << (d->fails - 1);
+    // (the first late decline of a run changes nothing: layers of one shape alternate in a model -- Llama's q and o
+    // are both 4096 x 4096 -- and one of the two declining must not send the other to the direct route; from the
+    // second consecutive one on, 1, 2, 4, ... requests are skipped)
+    d->fails = std::min(d->fails + 1, 8);
+    d->skip = d->fails >= 2 ? 1 << (d->fails - 2) : 0;
   } else {
     d->fails = 0;
     d->skip = 0;

@@ -156,8 +156,9 @@ def _precompute_covariance_matrix_decompositions(*, module, submodule_names, num
         return run
 
     routes = [eng.eigh_route_hint(stand_ins[i].cov, stand_ins[i].out_features, stand_ins[i].top_k) for i in owned]
+    costs = [eng.eigh_cost_hint(stand_ins[i].cov, stand_ins[i].out_features, stand_ins[i].top_k) for i in owned]
     with eng.phase("B_eigh"):
-        got = eng.run_concurrently([job(i) for i in owned], device, routes=routes)
+        got = eng.run_concurrently([job(i) for i in owned], device, routes=routes, costs=costs)
     for i, done in enumerate(pending):     # the sums this rank only contributed to: their buffers may go now
         if done is not None and not shard.owns(i):
             done()

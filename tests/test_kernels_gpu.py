@@ -576,8 +576,9 @@ def test_eigh_f32_face_matches_lapack(ops, n, k):
 def test_eigh_filtered_route_backs_off_after_a_late_decline(ops, monkeypatch):
     """A decline AFTER products were spent (here: a residual bound no attempt can meet, PTD_EIGH_FILTER_TOL = 1e-18 with
     a forced degree) is
-    remembered per (device, n, k): the next request of that shape goes straight to the direct route, the one after
-    that tries the filter again (back-off 1, 2, 4, ... requests; a success resets it)."""
+    remembered per (device, n, k): after two of them in a row the next request of that shape goes straight to the
+    direct route, the one after that tries the filter again (back-off 1, 2, 4, ... requests; a success resets it; a
+    single late decline between successes changes nothing -- layers of one shape alternate in a model)."""
     monkeypatch.setenv("PTD_EIGH_FILTER_BACKOFF", "1")
     n, k = 2048, 448                                          # (a shape no other test uses)
     a = _twist_case_matrix(n).to(DEV)
@@ -588,6 +589,7 @@ def test_eigh_filtered_route_backs_off_after_a_late_decline(ops, monkeypatch):
     w, v, prof = _profiled_eigh(ops, monkeypatch, a, k)
     assert prof["method"] != 3                                # declined late, answered by the direct route
     assert (w[n - k:] - w_ref[n - k:]).abs().max().item() <= 1e-11 * w_ref.abs().max().item()
+    assert _profiled_eigh(ops, monkeypatch, a, k)[2]["method"] != 3        # tried again (one decline is no pattern), declined again
     monkeypatch.delenv("PTD_EIGH_FILTER_TOL")
     monkeypatch.delenv("PTD_EIGH_FILTER_FORCE_DEGREE")
     assert _profiled_eigh(ops, monkeypatch, a, k)[2]["method"] != 3        # skipped once ...

@@ -1,0 +1,43 @@
+"""B_eigh of bench.py's full-width Llama block (bf16) over several passes, with the concurrent chains started longest
+first (default) and in model order (PTD_EIGH_LONGEST_FIRST=0).  Usage: python tools/block_b_eigh.py [passes]"""
+import copy, itertools, json, os, sys, time, torch
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, root)
+import bench, ptdeco_amd
+from ptdeco_amd import _engine as eng
+dev = torch.device("cuda", 0)
+passes = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+g = torch.Generator(device=dev).manual_seed(0)
+with torch.device(dev):
+    model0 = bench.LlamaStack(1)
+with torch.no_grad():
+    for prm in model0.parameters():
+        prm.copy_(torch.randn(prm.shape, generator=g, device=dev) / prm.shape[1] ** 0.5)
+model0.to(torch.bfloat16)
+scale = torch.logspace(0, -2, bench.D_MODEL, device=dev)
+xs = [(torch.randn(1, 2048, bench.D_MODEL, generator=g, device=dev) * scale).to(torch.bfloat16) for _ in range(12)]
+with torch.no_grad():
+    bt = [{"x": x, "targets": model0({"x": x}).argmax(-1)} for x in xs]
+
+
+def step():
+    if os.environ.get("EMPTY"):
+        torch.cuda.empty_cache()
+    m = copy.deepcopy(model0)
+    eng.PHASES = eng.PhaseTimer()
+    t0 = time.perf_counter()
+    ptdeco_amd.dwain.decompose_in_place(module=m, device=dev, data_iterator=itertools.cycle(bt), loss_fn=bench.seq_ce,
+                                        metric_iterator=itertools.cycle(bt[8:]), finetune_fn=lambda mm, d, n: mm,
+                                        **bench.C4_BLOCK_KW)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ph, eng.PHASES = eng.PHASES.totals_ms(), None
+    return round(dt * 1e3, 1), round(ph["B_eigh"], 1)
+
+
+import gc
+if os.environ.get("NOGC"): gc.disable()
+step()
+for mode in ("1", "0", "1", "0"):
+    os.environ["PTD_EIGH_LONGEST_FIRST"] = mode
+    print(json.dumps({"longest_first": mode == "1", "step_ms, B_eigh_ms": [step() for _ in range(passes)]}), flush=True)
