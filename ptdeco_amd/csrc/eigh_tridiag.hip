@@ -2518,8 +2518,8 @@ __global__ void random_fill_kernel(double* __restrict__ R, int64_t total, unsign
 static int complete_basis(double* V, int64_t ldv, int64_t n, int64_t m, int64_t k, char* ws, size_t ws_bytes,
                           hipStream_t st) {
   const int64_t kz = k - m;
-  const int64_t mp = (int64_t)align_up((size_t)m, 64);
-  if (mp > n - kz) return PTD_ERR_UNSUPPORTED;          // (the padding columns need room in the complement too)
+  const int64_t mp = (int64_t)align_up((size_t)m, 64);  // leading dimension and order of the padded Gram matrix
+  if (m > n - kz) return PTD_ERR_UNSUPPORTED;
   size_t o = 0;
   auto take = [&](size_t bytes) { size_t at = o; o += align_up(bytes, 256); return at; };
   const size_t off_r0 = take((size_t)n * mp * 8), off_r1 = take((size_t)n * mp * 8);
@@ -2534,25 +2534,27 @@ static int complete_basis(double* V, int64_t ldv, int64_t n, int64_t m, int64_t 
   double* G = reinterpret_cast<double*>(ws + off_g);
   double* Wt = reinterpret_cast<double*>(ws + off_w);
   const double* Z = V + m;
+  // m random columns (rows of length mp: the padding columns stay unread -- every product below takes m of them)
   hipLaunchKernelGGL(random_fill_kernel, dim3(2048), dim3(256), 0, st, R0, n * mp, 0x5DEECE66DULL);
   PTD_CHECK_LAUNCH("complete_basis (fill)");
   int rc = PTD_OK;
   for (int pass = 0; pass < 2 && kz > 0; ++pass) {
     // P = Z^T R, R -= Z P
-    rc = gemm_f64(Z, 1, ldv, R0, mp, 1, P, mp, kz, mp, n, 1.0, false, 1, st);
+    rc = gemm_f64(Z, 1, ldv, R0, mp, 1, P, mp, kz, m, n, 1.0, false, 1, st);
     if (rc != PTD_OK) return rc;
-    rc = gemm_f64(Z, ldv, 1, P, mp, 1, R0, mp, n, mp, kz, -1.0, true, 1, st);
+    rc = gemm_f64(Z, ldv, 1, P, mp, 1, R0, mp, n, m, kz, -1.0, true, 1, st);
     if (rc != PTD_OK) return rc;
   }
   double* cur = R0;
   double* nxt = R1;
   for (int pass = 0; pass < 2; ++pass) {
-    // G = R^T R = L L^T, R <- R L^-T
-    rc = gemm_f64(cur, 1, mp, cur, mp, 1, G, mp, mp, mp, n, 1.0, false, 1, st);
+    // G = R^T R = L L^T (padded with the identity to whole 64 x 64 tiles), R <- R L^-T
+    hipLaunchKernelGGL(gram_pad_kernel, dim3(1024), dim3(256), 0, st, G, (int)mp, (int)m);
+    rc = gemm_f64(cur, 1, mp, cur, mp, 1, G, mp, m, m, n, 1.0, false, 1, st);
     if (rc != PTD_OK) return rc;
     rc = chol_inverse(G, mp, Wt, ws + off_c, chol_bytes, st);
     if (rc != PTD_OK) return rc == PTD_ERR_WORKSPACE ? PTD_ERR_UNSUPPORTED : rc;
-    rc = gemm_f64(cur, mp, 1, Wt, mp, 1, nxt, mp, n, mp, mp, 1.0, false, 1, st);
+    rc = gemm_f64(cur, mp, 1, Wt, mp, 1, nxt, mp, n, m, m, 1.0, false, 1, st);
     if (rc != PTD_OK) return rc;
     std::swap(cur, nxt);
   }
