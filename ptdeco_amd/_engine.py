@@ -909,7 +909,10 @@ def run_concurrently(jobs, device: torch.device, max_streams: Optional[int] = No
     # block on four streams): streams used for the first time overlap well (B_eigh 185 ms); the SAME four streams at
     # every call settle at 226 ms, and so does every 8th call here, when the pool of 32 wraps around; with
     # GPU_MAX_HW_QUEUES=8 in the environment (the ROCm runtime maps streams onto 4 hardware queues by default, two
-    # chains then share one) every call takes 188 ms whichever streams it gets.
+    # chains then share one) every call takes 188 ms whichever streams it gets.  In the slow calls ONE chain is starved
+    # (PTD_EIGH_JOB_LOG=1: the filtered chain of `q` ends at 188 ms instead of 89 while the three others finish
+    # earlier than usual): its stream shares a hardware queue with another chain's.  Brand-new HIP streams per call
+    # (hipStreamCreate / Destroy) are always in the slow mode.
     streams = [torch.cuda.Stream(device=device) for _ in range(workers)]
     for st in streams:
         st.wait_stream(main)
@@ -918,6 +921,10 @@ def run_concurrently(jobs, device: torch.device, max_streams: Optional[int] = No
     lock = threading.Lock()
     cursor = [0]
     order = list(range(len(jobs)))
+    joblog = [] if os.environ.get("PTD_EIGH_JOB_LOG") else None      # (diagnostic: start / end of every job, ms)
+    import time as _time
+
+    tstart = _time.perf_counter()
     if costs is not None and len(costs) == len(jobs) and os.environ.get("PTD_EIGH_LONGEST_FIRST", "0") == "1":
         order.sort(key=lambda i: -costs[i])      # (stable: equal costs keep the model's order)
 
@@ -932,7 +939,15 @@ def run_concurrently(jobs, device: torch.device, max_streams: Optional[int] = No
                     if c >= len(jobs):
                         break
                     i = order[c]
-                    out[i] = jobs[i]()
+                    if joblog is None:
+                        out[i] = jobs[i]()
+                    else:
+                        import time as _t
+
+                        t0 = _t.perf_counter()
+                        out[i] = jobs[i]()
+                        streams[w].synchronize()
+                        joblog.append((i, w, round((t0 - tstart) * 1e3, 1), round((_t.perf_counter() - tstart) * 1e3, 1)))
         except BaseException as exc:  # re-raised on the calling thread
             errors.append(exc)
 
@@ -957,6 +972,11 @@ def run_concurrently(jobs, device: torch.device, max_streams: Optional[int] = No
         for t in (res if isinstance(res, (tuple, list)) else (res,)):
             if isinstance(t, torch.Tensor) and t.is_cuda:
                 t.record_stream(main)
+    if joblog is not None:
+        import sys
+
+        print("[run_concurrently] streams " + " ".join(hex(st.cuda_stream) for st in streams) + " jobs (i, worker, start, end): "
+              + str(sorted(joblog)), file=sys.stderr, flush=True)
     if errors:
         raise errors[0]
     return out
