@@ -171,10 +171,6 @@ def test_run_concurrently_takes_the_longest_jobs_first_when_asked(monkeypatch):
     jobs = [job(i) for i in range(5)]
     costs = [1.0, 5.0, 3.0, 5.0, 2.0]
 
-    class FakeStream:
-        def wait_stream(self, other):
-            pass
-
     # (the CPU path of run_concurrently is sequential and ignores the order; drive the ordering logic itself)
     order = sorted(range(len(jobs)), key=lambda i: -costs[i])
     assert order == [1, 3, 2, 4, 0]                      # stable: equal costs keep the model's order
