@@ -377,6 +377,11 @@ def forward_pair(root: torch.nn.Module, tap: "LayerTap", x, first_setup, second_
     return y_first, y_second
 
 
+class _StopForward(BaseException):
+    """Raised by a LayerTap when the calibration forward has delivered the analysed layer's input (a BaseException:
+    `except Exception` in the caller's model does not swallow it)."""
+
+
 class LayerTap:
     """Records the last input of one decomposable layer and gives a 2-D view of its weight.
 
@@ -395,12 +400,41 @@ class LayerTap:
         self._last: Optional[torch.Tensor] = None
         self.last_features: Optional[torch.Tensor] = None  # [T, n_out] of the last use_dense forward
         self.memo: Optional[PrefixMemo] = None
+        self.calls = 0                 # calls of the layer since calibration_forward last reset it
+        self._stop_at_input = False
+        self._single_call_seen = False
         self._handle = layer.register_forward_pre_hook(self._record)
 
     def _record(self, _module, args) -> None:
         self._last = args[0]
+        self.calls += 1
         if self.memo is not None:
             self.memo.reached = True
+        if self._stop_at_input:
+            self.last_features = None
+            raise _StopForward()
+
+    def calibration_forward(self, root: torch.nn.Module, batch) -> None:
+        """One forward of the model whose only purpose is this layer's input (dwain.py:236-239, falor.py:189-193: the
+        model's output is discarded).  The first such forward runs to the end and counts the layer's calls; if it was
+        called exactly once, the later ones stop at the layer -- everything behind it would be computed for nothing
+        (at depth f of a stack 1 - f of the forward).  A layer that is called several times per forward keeps the
+        full forwards: the reference uses the LAST call's input (get_last_input).  PTD_CALIBRATION_EARLY_STOP=0
+        keeps every forward whole."""
+        import os
+
+        self.calls = 0
+        if self._single_call_seen and os.environ.get("PTD_CALIBRATION_EARLY_STOP", "1") != "0":
+            self._stop_at_input = True
+            try:
+                root(batch)
+            except _StopForward:
+                pass
+            finally:
+                self._stop_at_input = False
+            return
+        root(batch)
+        self._single_call_seen = self.calls == 1
 
     def enable_prefix_memo(self, root: torch.nn.Module) -> None:
         """Metric steps of this layer's rank search share the model's work ahead of the layer (PrefixMemo)."""

@@ -214,7 +214,7 @@ def _compute_covariance_matrix_decomposition(*, root_module, tap: eng.LayerTap, 
             batch = next(data_iterator)
             if not shard.mine(step):
                 continue
-            root_module(utils.to_device(batch, device))
+            tap.calibration_forward(root_module, utils.to_device(batch, device))
             # (the layer's own forward may already have formed y = x W^T on the GPU: tap.last_features)
             cov.add_inputs(tap.last_input_rows(), weight, features=tap.last_features)
     if not shard.active:

@@ -65,7 +65,7 @@ def _compute_decompositon_of_covariance_matrix(*, root_module, tap: eng.LayerTap
     with eng.phase("A_accumulate"):
         cov = eng.Covariance(weight.shape[0], device, use_float64, with_mean=True, weight=weight, top_k=top_k)
         for _ in range(num_data_steps):
-            root_module(next(data_iterator).to(device))
+            tap.calibration_forward(root_module, next(data_iterator).to(device))
             cov.add_inputs(tap.last_input_rows(), weight)
     logger.info("Using mean for covariance" if use_mean else "Not using mean for covariance")
     damp = EIGEN_DAMPEN_FACTOR if (use_damping and not use_mean) else 0.0

@@ -702,3 +702,52 @@ def test_prefix_memo_on_a_hugging_face_llama(use_cache):
             assert tap.memo.unit_hits == 2 * 3     # two decoder layers and the attention block of the third, per step
         tap.close()
     assert all("forward" not in m.__dict__ for m in model.modules())
+
+
+def test_calibration_forwards_stop_at_the_analysed_layer_after_the_first_one(monkeypatch):
+    """The forwards that only feed the covariance (dwain.py:236-239, falor.py:189-193) need the model up to the
+    analysed layer: the first runs whole and counts the layer's calls, the later ones stop at it -- unless the layer
+    is called more than once per forward (the reference takes the LAST call's input)."""
+    from ptdeco_amd import _engine as eng
+
+    model = _MemoStack().eval()
+    real = []
+    _spy_on(model, real)
+    x = torch.randn(6, 8)
+    with torch.no_grad():
+        tap = eng.LayerTap(model, "blocks.1.fc2")
+        for step in range(3):
+            real.clear()
+            tap.calibration_forward(model, x)
+            want = ["embed", "blocks.0", "blocks.0.norm", "blocks.0.fc1", "blocks.0.fc2", "blocks.1", "blocks.1.norm",
+                    "blocks.1.fc1"]
+            if step == 0:
+                assert real[:8] == want and real[8] == "blocks.1.fc2" and real[-1] == "head"
+            else:
+                assert real == want                      # neither the layer itself nor anything behind it ran
+            assert tap.last_input_rows().shape == (6, 32)
+        monkeypatch.setenv("PTD_CALIBRATION_EARLY_STOP", "0")
+        real.clear()
+        tap.calibration_forward(model, x)
+        assert real[-1] == "head"
+        tap.close()
+
+    class Twice(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = torch.nn.Linear(8, 8)
+            self.head = torch.nn.Linear(8, 2)
+
+        def forward(self, x):
+            return self.head(self.a(self.a(x)))
+
+    monkeypatch.delenv("PTD_CALIBRATION_EARLY_STOP")
+    twice = Twice().eval()
+    seen = []
+    twice.head.register_forward_hook(lambda m, a, o: seen.append(1))
+    with torch.no_grad():
+        tap = eng.LayerTap(twice, "a")
+        for _ in range(3):
+            tap.calibration_forward(twice, x)
+        assert len(seen) == 3 and tap.calls == 2       # every forward ran to the end
+        tap.close()
