@@ -77,7 +77,11 @@ o.append(f"\nExtrapolated to 224 layers (kernel-side, one layer alone): f32 {c4[
 o.append(f"One full-width block end to end (`c4_block`; 7 layers, thresholds under which 5 are replaced): f32 **{blk['f32']['ms_per_block']:.0f} ms** (phases {blk['f32']['phases_ms']}), bf16 **{blk['bf16']['ms_per_block']:.0f} ms** (phases {blk['bf16']['phases_ms']}); replaced: {blk['bf16']['replaced']}.\n\n")
 o.append(f"Full depth (`c4_stack_32blocks_bf16_r04.json`): 32 blocks, 224 layers, bf16: **{s32['seconds']:.0f} s = {s32['layers_per_s']:.2f} layers/s**, {s32['layers_replaced']} layers replaced, {s32['candidates_evaluated']} candidates; phases {s32['phases_ms']} -- "
          "the run is the user model's own forwards (two whole-model forwards per candidate and batch, in torch / hipBLASLt); the covariance and eigensolver kernels are 8.5 s of it.\n\n")
+
+hf = json.load(open(os.path.join(root, "c4_hf_llama3_8b_r04.json"))) if os.path.exists(os.path.join(root, "c4_hf_llama3_8b_r04.json")) else None
+if hf:
+    o.append(f"The same on a `transformers.LlamaForCausalLM` with the Llama-3-8B architecture (`c4_hf_llama3_8b_r04.json`): {hf['decoder_layers']} decoder layers, {hf['layers']} Linear layers, vocabulary 128256, bf16: **{hf['seconds']:.0f} s = {hf['layers_per_s']:.2f} layers/s**, {hf['layers_replaced']} layers replaced; phases {hf['phases_ms']}.\n\n")
 o.append("## Streams (`streams_r04.json`)\n\nB_eigh in ms, two runs each, interleaved: three 4096^2 layers in one split -- 1 stream 171 / 171, 2 streams 207 / 163, 3 streams 181 / 137, by-route rule 171 / 171; "
-         "2-block Llama stack bf16 -- 667 / 668, 596 / 684, 622 / 583, 681 / 668.  Default: three streams, every chain on its own.\n")
+         "2-block Llama stack bf16 -- 667 / 668, 596 / 684, 622 / 583, 681 / 668.  Default since the second sweep (DESIGN 3): four streams, every chain on its own.\n")
 open(os.path.join(root, "README.md"), "w").write("".join(o))
 print("profiles/README.md written,", sum(len(x) for x in o), "bytes")
