@@ -162,6 +162,32 @@ def test_metric_steps_with_and_without_the_prefix_memo_are_bit_identical(method,
         assert traces[0][1] > 0       # the MLPs have layers ahead of fc2 / fc3
 
 
+@pytest.mark.parametrize("method,name", [("dwain", "dwain_mlp_nosplit"), ("falor", "falor_mlp_r9"), ("falor", "falor_conv")])
+def test_calibration_forwards_cut_at_the_layer_change_nothing(method, name, monkeypatch):
+    """Where the covariance is accumulated layer by layer the forwards behind the first stop at the analysed layer
+    (LayerTap.calibration_forward): the trace -- every metric of every candidate -- equals the one of whole forwards
+    (PTD_CALIBRATION_EARLY_STOP=0) bit for bit."""
+    import ptdeco_amd
+
+    scn = gio.e2e_meta()[name]
+    traces = []
+    for stop in ("1", "0"):
+        monkeypatch.setenv("PTD_CALIBRATION_EARLY_STOP", stop)
+        model = gio.build_model(scn).to(DEV)
+        trace = []
+        if method == "dwain":
+            data, metric = gio.dwain_streams(scn)
+            ptdeco_amd.dwain.decompose_in_place(
+                module=model, device=DEV, data_iterator=data, metric_iterator=metric, loss_fn=tm.ce_loss,
+                finetune_fn=lambda m, device, names: m, trace=trace, **scn["kwargs"])
+        else:
+            ptdeco_amd.falor.decompose_in_place(
+                module=model, device=DEV, data_iterator=tm.cycle_tensors(gio.pool(scn["pool"])), trace=trace,
+                **scn["kwargs"])
+        traces.append(trace)
+    assert traces[0] == traces[1] and len(traces[0]) > 0
+
+
 def test_config_round_trip_and_reload():
     """README.md:56-105 of the reference: JSON config + state_dict reload onto a fresh model."""
     import ptdeco_amd
