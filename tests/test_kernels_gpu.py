@@ -559,6 +559,34 @@ def test_eigh_with_a_dominant_outlier_above_a_dense_bulk(ops, monkeypatch, n, k,
     assert (v.T @ v - torch.eye(k, dtype=torch.float64)).abs().max().item() <= 1e-10
 
 
+@pytest.mark.parametrize("gap,method", [(3e-12, 1), (0.0, 0)])
+def test_eigh_with_nearly_and_exactly_repeated_eigenvalues_among_the_requested(ops, monkeypatch, gap, method):
+    """Twenty pairs of requested eigenvalues 3e-12 |A| apart: below the old refusal threshold (1e-10), above the one
+    that holds with the Cholesky-QR orthonormalisation (1e-13): the tridiagonal route answers (method 1) with residuals
+    and orthonormality at the usual level and the right two-dimensional invariant subspace per pair.  Exactly repeated
+    eigenvalues in the middle of the request are still the Jacobi solver's (method 0)."""
+    n, k = 1024, 512
+    g = torch.Generator().manual_seed(77)
+    q, _ = torch.linalg.qr(torch.randn(n, n, generator=g, dtype=torch.float64))
+    lam = torch.linspace(1.0, 100.0, n, dtype=torch.float64)
+    pairs = list(range(n - 400, n - 360, 2))
+    for i in pairs:
+        lam[i + 1] = lam[i] + gap * 100.0
+    c = (q * lam) @ q.T
+    c = 0.5 * (c + c.T)
+    monkeypatch.setenv("PTD_EIGH_FILTERED", "0")
+    w, v, prof = _profiled_eigh(ops, monkeypatch, c.to(DEV), k)
+    assert prof["method"] == method, prof["method"]
+    w_ref = torch.linalg.eigvalsh(c)
+    assert (w[n - k:] - w_ref[n - k:]).abs().max().item() <= 1e-11 * 100.0
+    assert (c @ v - v * w[n - k:]).norm(dim=0).max().item() <= 1e-9 * 100.0
+    assert (v.T @ v - torch.eye(k, dtype=torch.float64)).abs().max().item() <= 1e-10
+    for i in pairs:                                   # the plane of each pair, whatever basis of it was returned
+        cols = v[:, [i - (n - k), i + 1 - (n - k)]]
+        true = q[:, [i, i + 1]]
+        assert (cols @ cols.T - true @ true.T).abs().max().item() <= 1e-7, i
+
+
 @pytest.mark.parametrize("n,k", [(96, 96), (512, 128), (2048, 512)])
 def test_eigh_f32_face_matches_lapack(ops, n, k):
     """ptd_eigh_topk_f32 (what `decompose_in_float64=False` would hand to torch.linalg.eigh in f32, dwain.py:224-233 +
