@@ -22,6 +22,7 @@ o.append("Files (round 4):\n\n"
          "* `c4_stack_32blocks_bf16_r04.json` -- `PTD_PHASES=1 python tools/c4_stack.py 32 bf16 --trade-off 640 --max-ppl 0.4`: BASELINE configs[3] at full depth on one GPU with thresholds under which layers are replaced\n"
          "* `c4_hf_llama3_8b_r04.json` -- `PTD_PHASES=1 python tools/c4_hf_llama.py 32`: BASELINE configs[3] on the real model family -- a `transformers.LlamaForCausalLM` with the Llama-3-8B architecture (32 decoder layers, 224 Linear layers, vocabulary 128256, lm_head blacklisted), random bf16 weights, token batches [1, 2048], D = 8, M = 2, 4 splits, one GPU: **226 s**, 219 layers replaced; A 1.4 s, B 6.9 s (16.0 s before rank-deficient / outlier-dominated covariances stopped going to the Jacobi solver), D 217 s of whole-model forwards\n"
          "* `c3_vit_falor_phases_r04.json` -- `PTD_PHASES=1 python tools/c3_vit.py`: BASELINE configs[2] (falor on a ViT-B/16-shaped model, 49 layers, 441 bisection steps): 9.8 s -- D metrics 8.5 s, A accumulate 1.0 s (1.45 s before the calibration forwards stopped at the analysed layer), B eigh 0.22 s (0.72 s before clustered covariances stayed on the tridiagonal route) -- against 13.6 s / D 11.3 s without the prefix memo (11.3 / 9.1 with matrix products as its only units)\n"
+         "* `bench_r04_rehearsal_2ranks_1gpu.json` -- `PTD_BENCH_REHEARSE=1 python bench.py --gpus 2 --steps 2 --warmup 1`: the N = 2 code path (self-launched ranks, dealing, reduce-to-owner, broadcast) with BOTH ranks on the one GPU of the box: a check that the path runs, not a scaling number\n"
          "* `gpu_tests_r04.log` -- `python -m pytest tests -q -m gpu`\n"
          "* `tools/refresh_profiles.sh 04 main|bench|pmc` reruns them on a GPU box\n\n")
 o.append("## Headline\n\n")
