@@ -31,7 +31,8 @@
 extern "C" {
 #endif
 
-#define PTD_ABI_VERSION 2   /* 2: ptd_nsr workspaces are initialised once (ptd_nsr_workspace_init); ptd_chol_inverse */
+#define PTD_ABI_VERSION 3   /* 2: ptd_nsr workspaces are initialised once (ptd_nsr_workspace_init); ptd_chol_inverse
+                             * 3: ptd_stream_pair_wall_us, ptd_syrk_accumulate_multi */
 
 typedef enum { PTD_F32 = 0, PTD_F64 = 1, PTD_BF16 = 2 } ptd_dtype;
 
@@ -56,6 +57,16 @@ const char* ptd_last_error(void);
  * unpartitioned 256-CU gfx950 whose occupancy query admits them; every inter-workgroup wait in them is bounded by a
  * 10 ms wall-clock time-out after which the reduction is repeated on the blocked path. */
 int ptd_set_concurrent_chains(int chains);
+
+/* Host query (round 5, synchronous): do two streams sit on DIFFERENT hardware queues?  The ROCm runtime maps the
+ * streams of a process onto 4 hardware queues per priority level; two chains of dependent launches whose streams
+ * share one are executed one packet after the other (measured: the seven eigendecompositions of a Llama block on four
+ * streams take 187 ms when the four queues are distinct and 226-300 ms when two chains share one).  Launches one
+ * single-wave kernel that holds its queue for `spin_us` microseconds on each stream and returns the wall time of the
+ * pair in *wall_us: about spin_us when they ran side by side, about 2 x spin_us when they were serialised.  Both
+ * streams are synchronised before and after.  No reference counterpart (torch.linalg.eigh calls are serial,
+ * dwain.py:155-163); used by ptdeco_amd._engine.chain_streams to pick the streams of concurrent eigendecompositions. */
+int ptd_stream_pair_wall_us(void* stream_a, void* stream_b, int spin_us, double* wall_us);
 
 /* ---- covariance accumulation ------------------------------------------- */
 

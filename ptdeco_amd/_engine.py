@@ -894,6 +894,77 @@ def eigh_cost_hint(cov, n_out: int, top_k: Optional[int]) -> float:
     return cost
 
 
+_CHAIN_STREAMS: dict = {}      # device index -> (streams on pairwise distinct hardware queues, candidates exhausted?)
+_CHAIN_STREAMS_LOCK = None
+
+
+def chain_streams(device: torch.device, want: int) -> list:
+    """Up to `want` HIP streams of `device` that sit on pairwise DIFFERENT hardware queues, for chains of dependent
+    launches that are meant to interleave on the GPU (run_concurrently).
+
+    The ROCm runtime multiplexes the streams of a process onto 4 hardware queues per priority level
+    (tools/probes/launch_rate_probe.hip: of eight streams created in a row, 0/7, 1/6, 2/5 and 3/4 share a queue; the
+    high-priority streams have four queues of their own) and two chains on one queue are executed packet by packet, in
+    turn.  Which streams share is a fact of the process (creation order of every stream in it, torch's pools included),
+    so it is MEASURED, once per device: candidates from torch's high-priority pool, then from the normal one, are tested
+    pairwise with ptd_stream_pair_wall_us (two single-wave kernels that hold their queue for 150 us: side by side
+    ~0.16 ms, serialised ~0.31 ms) and taken greedily while they overlap with every stream taken before.  The streams
+    are kept for the life of the process (the mapping of an existing stream does not change: the probe's matrix is
+    identical before and after use).  Fewer than `want` distinct queues -> fewer streams are returned.
+    PTD_CHAIN_STREAMS_VERIFY=0 skips the measurement (pool streams as they come, the round-4 behaviour)."""
+    import os
+    import threading
+    import ctypes
+
+    from . import _hip
+
+    global _CHAIN_STREAMS_LOCK
+    if _CHAIN_STREAMS_LOCK is None:
+        _CHAIN_STREAMS_LOCK = threading.Lock()
+    device = torch.device(device)
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    device = torch.device("cuda", index)
+    want = max(1, int(want))
+    if os.environ.get("PTD_CHAIN_STREAMS_VERIFY", "1") == "0":
+        return [torch.cuda.Stream(device=device) for _ in range(want)]
+    with _CHAIN_STREAMS_LOCK:
+        have, exhausted = _CHAIN_STREAMS.get(index, ([], False))
+        if len(have) >= want or exhausted:
+            return list(have[:want])
+        lib = _hip.load()
+        spin_us = 150
+        wall = ctypes.c_double(0.0)
+
+        def overlap(a, b) -> bool:
+            _hip.check(lib.ptd_stream_pair_wall_us(a.cuda_stream, b.cuda_stream, spin_us, ctypes.byref(wall)),
+                       "ptd_stream_pair_wall_us")
+            return wall.value < 1.6 * spin_us
+
+        with torch.cuda.device(device):
+            tried = 0
+            for priority in (-1, 0):
+                for _ in range(8):
+                    if len(have) >= want:
+                        break
+                    cand = torch.cuda.Stream(device=device, priority=priority)
+                    tried += 1
+                    if any(cand.cuda_stream == h.cuda_stream for h in have):
+                        continue
+                    if all(overlap(h, cand) for h in have):
+                        have.append(cand)
+            exhausted = len(have) < want
+        _CHAIN_STREAMS[index] = (have, exhausted)
+        _log_chain_streams(index, have, tried)
+        return list(have[:want])
+
+
+def _log_chain_streams(index: int, have: list, tried: int) -> None:
+    import logging
+
+    logging.getLogger(__name__).info("cuda:%d: %d streams on distinct hardware queues out of %d candidates: %s", index,
+                                     len(have), tried, " ".join(hex(h.cuda_stream) for h in have))
+
+
 def run_concurrently(jobs, device: torch.device, max_streams: Optional[int] = None, routes: Optional[list] = None,
                      costs: Optional[list] = None) -> list:
     """Run independent device-side jobs (callables returning tensors) from separate host threads, each on
@@ -939,15 +1010,14 @@ def run_concurrently(jobs, device: torch.device, max_streams: Optional[int] = No
     index = device.index if device.index is not None else torch.cuda.current_device()
     device = torch.device("cuda", index)
     main = torch.cuda.current_stream(device)
-    # Fresh streams from torch's pool at every call.  Measured (tools/block_b_eigh.py, the seven chains of a Llama
-    # block on four streams): streams used for the first time overlap well (B_eigh 185 ms); the SAME four streams at
-    # every call settle at 226 ms, and so does every 8th call here, when the pool of 32 wraps around; with
-    # GPU_MAX_HW_QUEUES=8 in the environment (the ROCm runtime maps streams onto 4 hardware queues by default, two
-    # chains then share one) every call takes 188 ms whichever streams it gets.  In the slow calls ONE chain is starved
-    # (PTD_EIGH_JOB_LOG=1: the filtered chain of `q` ends at 188 ms instead of 89 while the three others finish
-    # earlier than usual): its stream shares a hardware queue with another chain's.  Brand-new HIP streams per call
-    # (hipStreamCreate / Destroy) are always in the slow mode.
-    streams = [torch.cuda.Stream(device=device) for _ in range(workers)]
+    # The chains' streams: kept per device and VERIFIED to sit on pairwise different hardware queues (chain_streams).
+    # Round 4 took fresh streams from torch's pool at every call and was bimodal -- B_eigh of a Llama block 187 ms or
+    # 226-300 ms: whenever two of the four streams shared a hardware queue, two chains of ~8000 dependent launches ran one
+    # packet after the other (PTD_EIGH_JOB_LOG=1: `v`, a 10-ms problem, ended at 148 ms beside `o` on the same queue).
+    streams = chain_streams(device, workers)
+    workers = len(streams)
+    if workers == 1:
+        return [job() for job in jobs]
     for st in streams:
         st.wait_stream(main)
     out: list = [None] * len(jobs)

@@ -14,13 +14,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libptdeco_hip.so")
 
 F32, F64, BF16 = 0, 1, 2
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # name -> (restype, argtypes); must list every symbol include/ptdeco_hip.h declares
 SIGNATURES = {
     "ptd_version": (c_int, []),
     "ptd_last_error": (c_char_p, []),
     "ptd_set_concurrent_chains": (c_int, [c_int]),
+    "ptd_stream_pair_wall_us": (c_int, [c_void_p, c_void_p, c_int, ctypes.POINTER(c_double)]),
     "ptd_syrk_accumulate": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_int64, c_int,
                                     c_double, c_void_p]),
     "ptd_colsum_accumulate": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_int, c_double,

@@ -1,5 +1,6 @@
 // extern "C" surface of libptdeco_hip.so (declared in include/ptdeco_hip.h).
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdlib>
 #include <cstring>
@@ -22,6 +23,12 @@ void set_error(const char* fmt, ...) {
 
 using namespace ptd;
 
+// one wave that holds its hardware queue for `ticks` of the 100 MHz wall clock (ptd_stream_pair_wall_us)
+__global__ void stream_spin_kernel(long long ticks) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+
 extern "C" {
 
 int ptd_version(void) { return PTD_ABI_VERSION; }
@@ -29,6 +36,22 @@ int ptd_version(void) { return PTD_ABI_VERSION; }
 const char* ptd_last_error(void) { return g_err; }
 
 int ptd_set_concurrent_chains(int chains) { return concurrent_chains_exchange(chains < 1 ? 1 : chains); }
+
+int ptd_stream_pair_wall_us(void* stream_a, void* stream_b, int spin_us, double* wall_us) {
+  PTD_REQUIRE(wall_us && spin_us >= 1 && spin_us <= 100000, "ptd_stream_pair_wall_us: bad argument");
+  hipStream_t a = static_cast<hipStream_t>(stream_a), b = static_cast<hipStream_t>(stream_b);
+  PTD_CHECK_HIP(hipStreamSynchronize(a));
+  PTD_CHECK_HIP(hipStreamSynchronize(b));
+  const long long ticks = (long long)spin_us * 100;
+  const auto t0 = std::chrono::steady_clock::now();
+  hipLaunchKernelGGL(stream_spin_kernel, dim3(1), dim3(64), 0, a, ticks);
+  hipLaunchKernelGGL(stream_spin_kernel, dim3(1), dim3(64), 0, b, ticks);
+  PTD_CHECK_HIP(hipStreamSynchronize(a));
+  PTD_CHECK_HIP(hipStreamSynchronize(b));
+  *wall_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+  PTD_CHECK_LAUNCH("ptd_stream_pair_wall_us");
+  return PTD_OK;
+}
 
 int ptd_syrk_accumulate(const void* y, int64_t T, int64_t n, int64_t ldy, int y_dtype, void* E, int64_t ldE,
                         int E_dtype, double scale, void* stream) {

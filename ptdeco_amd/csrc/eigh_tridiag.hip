@@ -1349,12 +1349,20 @@ __global__ __launch_bounds__(64) void tridiag_invit_kernel(const double* __restr
                                                           int n, const double* __restrict__ lam,
                                                           const double* __restrict__ bounds, int nvec, InvitWs ws,
                                                           double* __restrict__ Y, int64_t ldy, const int niter,
-                                                          const int* __restrict__ list, const int* __restrict__ count) {
-  // with a work list (the vectors the twisted-factorisation kernel gave up on): entry blockIdx.x * 64 + lane of it
+                                                          const int* __restrict__ list, const int* __restrict__ count,
+                                                          const int list_first) {
+  // with a work list (the vectors the twisted-factorisation kernel gave up on): entry list_first + blockIdx.x * 64 +
+  // lane of it (the entries below list_first are the wave kernel's).  An entry k >= 0 restarts from the twisted vector
+  // in column k of Y, an entry ~k < 0 from the hashed vector (the twisted vector is zero, not finite or not an
+  // eigenvector to rounding: tridiag_twist_kernel).
   int k = blockIdx.x * blockDim.x + threadIdx.x;
+  bool from_memory = false;
   if (list) {
+    k += list_first;
     if (k >= *count) return;
     k = list[k];
+    from_memory = k >= 0;
+    if (k < 0) k = ~k;
   } else if (k >= nvec) {
     return;
   }
@@ -1374,7 +1382,6 @@ __global__ __launch_bounds__(64) void tridiag_invit_kernel(const double* __restr
   // neighbours' components at (residual / gap) x (eigenvalue error / gap) ~ 1e-16: three passes over the rows
   // (factorisation, forward, backward) instead of seven from a random start (3.4 -> ~1.5 ms at n = 4096; a Llama
   // block's three (4096, 2048) problems refuse about twenty vectors each).
-  const bool from_memory = list != nullptr;
   const int niter_eff = from_memory ? 1 : niter;
   // factorisation, with the forward sweep of the FIRST iteration riding along: the start vector is a hash of
   // (row, vector), so P L^-1 y0 needs nothing from memory and a separate latency-bound pass is saved
@@ -1474,6 +1481,152 @@ __global__ __launch_bounds__(64) void tridiag_invit_kernel(const double* __restr
   Lm[0] = carry;
 }
 
+// ---- inverse iteration, one WAVE per vector (round 5): the work list of the twisted-factorisation kernel.
+// The kernel above runs one vector per LANE: every row step waits for memory once per 12 rows and the launch takes
+// 3.4 ms at n = 4096 whether the list holds two vectors or two thousand (a (4096, 2048) problem refuses about twenty).
+// Here a wave owns ONE vector.  The arithmetic is the lane kernel's, step for step -- pivoted LU of T - lambda I, the
+// forward sweep riding in the factorisation, back substitution, 2-norm -- but the rows are fetched 64 at a time (lane
+// l holds row i0 + l: one coalesced request per array and chunk, the next chunk's already in flight), the 64 dependent
+// steps of a chunk run on wave-uniform values broadcast from the owning lane with v_readlane, and lane q keeps row q's
+// results until the chunk is stored.  The factors of list entry j live in rows [j n, (j + 1) n) of the factor arrays
+// (the multipliers behind the first nvec entries of Lm, which are the scale factors invit_scale_kernel reads).
+__device__ __forceinline__ double bcast_lane(double x, int q) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(x), q);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(x), q);
+  return __hiloint2double(hi, lo);
+}
+
+__global__ __launch_bounds__(64) void tridiag_invit_wave_kernel(const double* __restrict__ d, const double* __restrict__ e,
+                                                               int n, const double* __restrict__ lam,
+                                                               const double* __restrict__ bounds, int nvec, InvitWs ws,
+                                                               double* Y, int64_t ldy, const int niter,
+                                                               const int* __restrict__ list,
+                                                               const int* __restrict__ count, const int wave_max) {
+  const int j = blockIdx.x;
+  if (j >= min(*count, wave_max)) return;
+  int k = list[j];
+  const bool from_memory = k >= 0;       // (wave-uniform)
+  if (k < 0) k = ~k;
+  const int lane = threadIdx.x;
+  const double tnorm = bounds[3];
+  const double tiny = fmax(2.220446049250313e-16 * tnorm, 2.2250738585072014e-308 * 4.0);
+  const double lk = lam[k];
+  double* U1i = ws.U1i + (int64_t)j * n;
+  double* U2 = ws.U2 + (int64_t)j * n;
+  double* U3 = ws.U3 + (int64_t)j * n;
+  double* Lm = ws.Lm + nvec + (int64_t)j * n;
+  unsigned char* sw = ws.sw + (int64_t)j * n;
+  double* y = Y + k;
+  const int niter_eff = from_memory ? 1 : niter;
+
+  // factorisation + the forward sweep of the first iteration
+  double u = d[0] - lk, v = n > 1 ? e[0] : 0.0, w = 0.0;
+  double cur0 = from_memory ? y[0] : hash_uniform(0u, (unsigned)k);
+  // chunk operands of lane l: row i = i0 + l; b = e[i], a1 = d[i + 1] - lambda, c1 = e[i + 1], start value of row i + 1
+  auto load_chunk = [&](int i0, double& eb, double& da, double& ec, double& ys) {
+    const int i = i0 + lane;
+    const bool live = i < n - 1;
+    eb = live ? e[i] : 1.0;
+    da = live ? d[i + 1] - lk : 0.0;
+    ec = (i + 2 < n) ? e[i + 1] : 0.0;
+    ys = !live ? 0.0 : (from_memory ? y[(int64_t)(i + 1) * ldy] : hash_uniform((unsigned)(i + 1), (unsigned)k));
+  };
+  double eb, da, ec, ys;
+  load_chunk(0, eb, da, ec, ys);
+  for (int i0 = 0; i0 < n - 1; i0 += 64) {
+    double eb_n = 0.0, da_n = 0.0, ec_n = 0.0, ys_n = 0.0;
+    if (i0 + 64 < n - 1) load_chunk(i0 + 64, eb_n, da_n, ec_n, ys_n);
+    double o_u1 = 0.0, o_u2 = 0.0, o_u3 = 0.0, o_lm = 0.0, o_y = 0.0;
+    int o_sw = 0;
+    const int cnt = min(64, n - 1 - i0);
+    for (int q = 0; q < cnt; ++q) {
+      const double b = bcast_lane(eb, q), a1 = bcast_lane(da, q), c1 = bcast_lane(ec, q);
+      double nxt = bcast_lane(ys, q);
+      double m, r1, r2, r3;
+      int s;
+      if (fabs(u) >= fabs(b)) {
+        if (fabs(u) < tiny) u = (u < 0.0) ? -tiny : tiny;
+        const double ui = 1.0 / u;
+        m = b * ui;
+        r1 = ui; r2 = v; r3 = w; s = 0;
+        u = a1 - m * v; v = c1 - m * w; w = 0.0;
+      } else {
+        const double bi = 1.0 / b;
+        m = u * bi;
+        r1 = bi; r2 = a1; r3 = c1; s = 1;
+        u = v - m * a1; v = w - m * c1; w = 0.0;
+        const double t = cur0; cur0 = nxt; nxt = t;
+      }
+      if (lane == q) { o_u1 = r1; o_u2 = r2; o_u3 = r3; o_lm = m; o_sw = s; o_y = cur0; }
+      cur0 = nxt - m * cur0;
+    }
+    const int i = i0 + lane;
+    if (i < n - 1) {
+      U1i[i] = o_u1; U2[i] = o_u2; U3[i] = o_u3; Lm[i] = o_lm; sw[i] = (unsigned char)o_sw;
+      y[(int64_t)i * ldy] = o_y;
+    }
+    eb = eb_n; da = da_n; ec = ec_n; ys = ys_n;
+  }
+  if (fabs(u) < tiny) u = (u < 0.0) ? -tiny : tiny;
+  const double u1_last = 1.0 / u;
+
+  double carry = 1.0;   // scale of the iterate in memory, applied on the next read
+  for (int it = 0; it < niter_eff; ++it) {
+    double cur = cur0;
+    if (it > 0) {
+      // forward: row interchanges and L^-1 on the iterate in memory
+      cur = y[0] * carry;
+      for (int i0 = 0; i0 < n - 1; i0 += 64) {
+        const int i = i0 + lane;
+        const bool live = i < n - 1;
+        const double yn = live ? y[(int64_t)(i + 1) * ldy] * carry : 0.0;
+        const double lm = live ? Lm[i] : 0.0;
+        const int s8 = live ? (int)sw[i] : 0;
+        double o_y = 0.0;
+        const int cnt = min(64, n - 1 - i0);
+        for (int q = 0; q < cnt; ++q) {
+          double nxt = bcast_lane(yn, q);
+          const double m = bcast_lane(lm, q);
+          if (__builtin_amdgcn_readlane(s8, q)) { const double t = cur; cur = nxt; nxt = t; }
+          if (lane == q) o_y = cur;
+          cur = nxt - m * cur;
+        }
+        if (live) y[(int64_t)i * ldy] = o_y;
+      }
+    }
+    // backward: U x = y
+    double x2 = 0.0, x1 = cur * u1_last;
+    if (lane == 0) y[(int64_t)(n - 1) * ldy] = x1;
+    double ss = x1 * x1, big = fabs(x1);
+    for (int i0 = n - 2; i0 >= 0; i0 -= 64) {
+      const int i = i0 - lane;
+      const bool live = i >= 0;
+      const double yv = live ? y[(int64_t)i * ldy] : 0.0;
+      const double u1 = live ? U1i[i] : 0.0, u2 = live ? U2[i] : 0.0, u3 = live ? U3[i] : 0.0;
+      double o_x = 0.0;
+      const int cnt = min(64, i0 + 1);
+      for (int q = 0; q < cnt; ++q) {
+        const double x0 = (bcast_lane(yv, q) - bcast_lane(u2, q) * x1 - bcast_lane(u3, q) * x2) * bcast_lane(u1, q);
+        if (lane == q) o_x = x0;
+        x2 = x1; x1 = x0;
+        big = fmax(big, fabs(x0));
+        ss += x0 * x0;
+      }
+      if (live) y[(int64_t)i * ldy] = o_x;
+    }
+    // normalisation factor (guard the sum of squares against overflow through the max entry)
+    if (big > 1e140 || !(ss < INFINITY)) {
+      double s2 = 0.0;
+      for (int i = lane; i < n; i += 64) { const double t = y[(int64_t)i * ldy] / big; s2 += t * t; }
+      for (int off = 32; off > 0; off >>= 1) s2 += __shfl_xor(s2, off);
+      carry = 1.0 / (big * sqrt(s2));
+    } else {
+      carry = ss > 0.0 ? 1.0 / sqrt(ss) : 0.0;
+    }
+  }
+  if (lane == 0) ws.Lm[k] = carry;      // invit_scale_kernel multiplies column k by this
+}
+
 // ---- eigenvectors of T by twisted factorisations, one WAVE per eigenvector, the recurrences as scans ----
 // The inverse iteration above runs one eigenvector per LANE: 4 n sequential steps each, a memory round trip per 12
 // rows, 16 waves on a chip of 1024 SIMDs (3.3 ms at n = 4096, k = 1024).  Here lane c owns rows 64 c .. 64 c + 63.
@@ -1535,7 +1688,8 @@ __global__ __launch_bounds__(64) void tridiag_twist_kernel(const double* __restr
                                                            const double* __restrict__ bounds, int nvec,
                                                            double* __restrict__ Y, int64_t ldy,
                                                            double* __restrict__ scale_out, int* __restrict__ fail_list,
-                                                           int* __restrict__ fail_count, int has_below) {
+                                                           int* __restrict__ fail_count, int has_below,
+                                                           int break_every) {
   extern __shared__ __attribute__((aligned(16))) char tw_smem[];
   double* S = reinterpret_cast<double*>(tw_smem);        // [R][64]: forward pivots, then z mantissas, then z
   double* Tt = S + 64 * 64;                               // [R][64]: backward pivots, then z exponents
@@ -1729,6 +1883,8 @@ __global__ __launch_bounds__(64) void tridiag_twist_kernel(const double* __restr
   }
   __syncthreads();   // (one wave; the barrier keeps the compiler from moving the neighbour reads above the writes)
   // ---- residual of (T - lambda) z, in units of |T| with |z|_2 = 1, and the output
+  // (test hook PTD_TWIST_TEST_BREAK=m: every m-th vector leaves as a zero / NaN column on the list, as after a breakdown)
+  const bool force_break = break_every > 0 && (k % break_every) == 0;
   double res = 0.0;
   for (int il = 0; il < R; ++il) {
     const int i = i0 + il;
@@ -1740,7 +1896,7 @@ __global__ __launch_bounds__(64) void tridiag_twist_kernel(const double* __restr
     const double eu = il == 0 ? (lane == 0 ? 0.0 : e_above) : TW_E(il - 1);
     const double rr = i == r ? 0.0 : fabs(eu * zu + TW_A(il) * z + TW_E(il) * zd) * nrm;
     res = fmax(res, rr);
-    Y[(int64_t)i * ldy + k] = z * nrm;
+    Y[(int64_t)i * ldy + k] = force_break ? (((k / break_every) & 1) ? NAN : 0.0) : z * nrm;
   }
   for (int off = 32; off > 0; off >>= 1) res = fmax(res, __shfl_xor(res, off));
   if (lane == 0) {
@@ -1751,7 +1907,11 @@ __global__ __launch_bounds__(64) void tridiag_twist_kernel(const double* __restr
     if (k > 0 || has_below) gap = fmin(gap, lam[k] - lam[k - 1]);
     gap = tnorm > 0.0 ? gap / tnorm : gap;
     const double tol = fmin(TW_TOL, TW_ORTH * gap);
-    if (!(res <= tol) || !(ss > 0.0)) fail_list[atomicAdd(fail_count, 1)] = k;
+    // Refused.  A finite, non-zero vector that is an eigenvector to rounding and only too close to a neighbour for its
+    // residual is restarted FROM (entry k); a breakdown (zero or non-finite vector, residual above TW_TOL) is restarted
+    // from the hashed vector (entry ~k): one inverse iteration from a zero or NaN column would return it unchanged.
+    const bool broken = !(ss > 0.0) || !(ss < INFINITY) || !(res <= TW_TOL) || force_break;
+    if (broken || !(res <= tol)) fail_list[atomicAdd(fail_count, 1)] = broken ? ~k : k;
   }
 #undef TW_A
 #undef TW_E
@@ -2406,11 +2566,20 @@ int tridiag_vectors_and_backtransform(const TridiagPlan& p, char* base, int nvec
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 65536) == hipSuccess;
     PTD_REQUIRE(attr, "tridiag_twist: cannot reserve LDS");
     hipLaunchKernelGGL(tw_prepare_kernel, dim3(TW_MAXN / 256), dim3(256), 0, st, d, e, n, bounds, dsT, esT, cnt);
+    const char* brk = getenv("PTD_TWIST_TEST_BREAK");
     hipLaunchKernelGGL(tridiag_twist_kernel, dim3((unsigned)nvec), dim3(64), 65536, st, dsT, esT, n, lamk, bounds, nvec,
-                       Y, ldy, ws.Lm, list, cnt, nvec < n ? 1 : 0);
-    // the vectors whose residual was refused (normally none): inverse iteration
-    hipLaunchKernelGGL(tridiag_invit_kernel, dim3((unsigned)ceil_div(nvec, 64)), dim3(64), 0, st, d, e, n, lamk, bounds,
-                       nvec, ws, Y, ldy, niter, list, cnt);
+                       Y, ldy, ws.Lm, list, cnt, nvec < n ? 1 : 0, brk ? atoi(brk) : 0);
+    // the vectors whose residual was refused (normally a handful): inverse iteration, one WAVE per list entry for the
+    // first wave_max entries (both launches exit at once on an empty list); a list longer than that -- a spectrum that
+    // is one dense cluster -- leaves the rest to the one-vector-per-lane kernel
+    static const bool no_wave = getenv("PTD_EIGH_INVIT_WAVE") && atoi(getenv("PTD_EIGH_INVIT_WAVE")) == 0;
+    const int wave_max = no_wave ? 0 : std::max(0, std::min(nvec - 1, 2048));
+    if (wave_max > 0)
+      hipLaunchKernelGGL(tridiag_invit_wave_kernel, dim3((unsigned)wave_max), dim3(64), 0, st, d, e, n, lamk, bounds,
+                         nvec, ws, Y, ldy, niter, list, cnt, wave_max);
+    if (nvec > wave_max)
+      hipLaunchKernelGGL(tridiag_invit_kernel, dim3((unsigned)ceil_div(nvec - wave_max, 64)), dim3(64), 0, st, d, e, n,
+                         lamk, bounds, nvec, ws, Y, ldy, niter, list, cnt, wave_max);
     if (getenv("PTD_JACOBI_DEBUG")) {
       int h = 0;
       PTD_CHECK_HIP(hipMemcpyAsync(&h, cnt, 4, hipMemcpyDeviceToHost, st));
@@ -2419,7 +2588,7 @@ int tridiag_vectors_and_backtransform(const TridiagPlan& p, char* base, int nvec
     }
   } else {
     hipLaunchKernelGGL(tridiag_invit_kernel, dim3((unsigned)ceil_div(nvec, 64)), dim3(64), 0, st, d, e, n, lamk, bounds,
-                       nvec, ws, Y, ldy, niter, (const int*)nullptr, (const int*)nullptr);
+                       nvec, ws, Y, ldy, niter, (const int*)nullptr, (const int*)nullptr, 0);
   }
   hipLaunchKernelGGL(invit_scale_kernel, dim3((unsigned)ceil_div(nvec, 256), 256), dim3(256), 0, st, Y, ldy, n, nvec,
                      ws.Lm);

@@ -587,6 +587,69 @@ def test_eigh_with_nearly_and_exactly_repeated_eigenvalues_among_the_requested(o
         assert (cols @ cols.T - true @ true.T).abs().max().item() <= 1e-7, i
 
 
+@pytest.mark.parametrize("n,k,every,wave", [(1024, 512, 7, "1"), (1024, 512, 7, "0"), (2048, 2048, 64, "1"),
+                                           (640, 639, 1, "1")])
+def test_eigh_recovers_from_a_twisted_factorisation_breakdown(ops, monkeypatch, n, k, every, wave):
+    """a vector the twisted-factorisation kernel gives up on because it BROKE DOWN (zero or NaN column, or a
+    residual above rounding) must not be 'refined' by one inverse iteration from that column -- zero stays zero, NaN stays
+    NaN and the call returned PTD_OK.  The kernel now says why it refused (list entry k: restart from the twisted vector;
+    ~k: restart from the hashed vector with the full iteration count).  PTD_TWIST_TEST_BREAK=m makes every m-th vector
+    leave the kernel as a zero (even multiples) or NaN (odd multiples) column: residuals, orthonormality and the
+    invariant subspace must be what they are without the hook, on the one-wave-per-vector kernel (default; m = 1 with
+    k = n - 1 also fills its list beyond the entries it takes and hands the last one to the one-vector-per-lane kernel)
+    and on the lane kernel alone (PTD_EIGH_INVIT_WAVE=0 is read once per process: that case runs in a child)."""
+    code = f"""
+import math, os, sys, torch
+sys.path[:0] = [{os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r}]
+from ptdeco_amd import ops
+n, k = {n}, {k}
+g = torch.Generator().manual_seed(9)
+y = torch.randn(2 * n + 3, n, generator=g, dtype=torch.float64) * torch.logspace(0, -2, n, dtype=torch.float64)
+a = y.T @ y / y.shape[0]
+a = a + torch.eye(n, dtype=torch.float64) * (0.01 * torch.diag(a).mean())
+w, v = ops.eigh(a.cuda(), k)
+w, v = w.cpu(), v.cpu()
+assert torch.isfinite(v).all()
+w_ref, v_ref = torch.linalg.eigh(a)
+assert (w[n - k:] - w_ref[n - k:]).abs().max().item() <= 1e-12 * w_ref.max().item()
+assert (v.norm(dim=0) - 1).abs().max().item() <= 1e-10
+assert (v.T @ v - torch.eye(k, dtype=torch.float64)).abs().max().item() <= 5e-9
+assert (a @ v - v * w[n - k:]).abs().max().item() <= 1e-11 * w_ref.max().item()
+p, p_ref = v @ v.T, v_ref[:, n - k:] @ v_ref[:, n - k:].T
+assert (p - p_ref).norm().item() <= 1e-6 * math.sqrt(k)
+print("ok")
+"""
+    import subprocess
+    import sys
+    env = dict(os.environ, PTD_EIGH_METHOD="tridiag", PTD_EIGH_FILTERED="0", PTD_TWIST_TEST_BREAK=str(every),
+               PTD_EIGH_INVIT_WAVE=wave)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+
+
+def test_chain_streams_sit_on_distinct_hardware_queues(ops):
+    """the streams of concurrent eigendecompositions are measured to overlap pairwise
+    (ptd_stream_pair_wall_us: two single-wave kernels that hold their queue for 150 us), are kept per device, and a
+    stream paired with itself reads as serialised."""
+    import ctypes
+    from ptdeco_amd import _engine as eng, _hip
+    dev = torch.device("cuda", 0)
+    st = eng.chain_streams(dev, 4)
+    assert len(st) == 4 and len({s.cuda_stream for s in st}) == 4
+    again = eng.chain_streams(dev, 4)
+    assert [s.cuda_stream for s in again] == [s.cuda_stream for s in st]
+    lib, wall = _hip.load(), ctypes.c_double(0.0)
+    for i in range(4):
+        for j in range(i + 1, 4):
+            _hip.check(lib.ptd_stream_pair_wall_us(st[i].cuda_stream, st[j].cuda_stream, 150, ctypes.byref(wall)), "pair")
+            assert wall.value < 240.0, (i, j, wall.value)
+    _hip.check(lib.ptd_stream_pair_wall_us(st[0].cuda_stream, st[0].cuda_stream, 150, ctypes.byref(wall)), "pair")
+    assert wall.value > 280.0, wall.value
+    more = eng.chain_streams(dev, 7)      # the runtime has 4 queues per priority level: 5 to 7 distinct ones exist
+    assert 4 <= len(more) <= 7 and [s.cuda_stream for s in more[:4]] == [s.cuda_stream for s in st]
+    assert lib.ptd_stream_pair_wall_us(None, None, 0, ctypes.byref(wall)) == -1
+
+
 @pytest.mark.parametrize("n,k", [(96, 96), (512, 128), (2048, 512)])
 def test_eigh_f32_face_matches_lapack(ops, n, k):
     """ptd_eigh_topk_f32 (what `decompose_in_float64=False` would hand to torch.linalg.eigh in f32, dwain.py:224-233 +
