@@ -400,7 +400,7 @@ C4_BLOCK_KW = dict(num_data_steps=8, num_metric_steps=2, nsr_final_threshold=1.0
                    blacklisted_module_names=["head"], precomputing_covariance_num_splits=1)
 
 
-def llama_block_lines(device):
+def llama_block_lines(device, blocks=1, dtypes=(torch.float32, torch.bfloat16), timed=5):
     """BASELINE configs[3] in small, end to end: dwain on ONE full-width Llama-3-8B block (q, k, v, o, gate, up, down at
     4096 / 1024 / 14336 + the blacklisted head), [1, 2048, 4096] batches, D = 8, M = 2, precompute pass (one split: the
     seven eigendecompositions run as concurrent chains), thresholds under which layers ARE replaced, so that the
@@ -409,10 +409,12 @@ def llama_block_lines(device):
     from ptdeco_amd import _engine as eng
 
     out = {}
-    for dt in (torch.float32, torch.bfloat16):
+    # (a layer's share of the parameters shrinks with the depth: the trade-off factor scales with the number of blocks)
+    kw = dict(C4_BLOCK_KW, trade_off_factor=C4_BLOCK_KW["trade_off_factor"] * blocks)
+    for dt in dtypes:
         g = torch.Generator(device=device).manual_seed(0)
         with torch.device(device):
-            model0 = LlamaStack(1)
+            model0 = LlamaStack(blocks)
         with torch.no_grad():
             for prm in model0.parameters():
                 prm.copy_(torch.randn(prm.shape, generator=g, device=device) / prm.shape[1] ** 0.5)
@@ -426,11 +428,11 @@ def llama_block_lines(device):
             m = copy.deepcopy(model0)
             return ptdeco_amd.dwain.decompose_in_place(module=m, device=device, data_iterator=itertools.cycle(bt),
                                                        loss_fn=seq_ce, metric_iterator=itertools.cycle(bt[8:]),
-                                                       finetune_fn=lambda mm, d, n: mm, trace=trace, **C4_BLOCK_KW)
+                                                       finetune_fn=lambda mm, d, n: mm, trace=trace, **kw)
         step()
         torch.cuda.synchronize()
         marks = []
-        for _ in range(2):
+        for _ in range(timed):
             t0 = time.perf_counter()
             step()
             torch.cuda.synchronize()
@@ -443,14 +445,18 @@ def llama_block_lines(device):
         wall = (time.perf_counter() - t0) * 1e3
         ph, eng.PHASES = eng.PHASES.totals_ms(), None
         ph["other_host_and_gaps"] = max(0.0, wall - sum(ph.values()))
-        best = min(marks)
+        med = sorted(marks)[len(marks) // 2]
         out["f32" if dt == torch.float32 else "bf16"] = {
-            "layers": 7, "ms_per_block": best, "step_ms": [round(v, 1) for v in marks], "layers_per_s": 7e3 / best,
+            "layers": 7 * blocks, "ms_per_step": med, "ms_per_step_max": max(marks), "ms_per_step_min": min(marks),
+            "ms_per_block": med / blocks, "step_ms": [round(v, 1) for v in marks], "layers_per_s": 7e3 * blocks / med,
+            "spread": (max(marks) - min(marks)) / med, "timed_steps": timed, "statistic": "median of step_ms",
             "phases_ms": {k: round(v, 1) for k, v in ph.items()}, "candidates_evaluated": len(trace),
             "replaced": {k: v["__meta__"]["proportion"] for k, v in cfg.items()}}
         del model0, xs, bt
-    out["workload"] = ("dwain.decompose_in_place, ONE Llama-3-8B-width block (7 layers) + blacklisted head, [1, 2048, 4096] "
-                       "batches, D = 8, M = 2, precompute pass (1 split), trade_off_factor 20, max_accepted_ppl_diff 0.4")
+    out["workload"] = ("dwain.decompose_in_place, %d Llama-3-8B-width block(s) (%d layers) + blacklisted head, [1, 2048, 4096] "
+                       "batches, D = 8, M = 2, precompute pass (1 split), trade_off_factor %g, max_accepted_ppl_diff 0.4; "
+                       "layers are replaced as the search goes, so the later layers' metric forwards run the changed model"
+                       % (blocks, 7 * blocks, kw["trade_off_factor"]))
     return out
 
 
@@ -494,8 +500,11 @@ def cpu_baseline():
     dt = time.perf_counter() - t0
     prop = cfg["layers.0"]["__meta__"]["proportion"] if cfg else 1.0
     return {"value": 1.0 / dt, "unit": "layers/s", "cores": cores, "kind": "port",
+            "workload": "c2_single_layer (BASELINE configs[1]: dwain of ONE nn.Linear(4096,4096) f32, D=4, M=2) -- NOT the "
+                        "8-layer stack `value` is quoted on; the GPU figure for the same workload is gpu_same_workload",
             "physical_cores": physical, "logical_cpus": os.cpu_count(), "usable_cpus": usable,   # usable = affinity and cgroup quota
-            "sample": f"1 layer = the full N=1 workload once ({dt:.1f} s, torch threads = {cores}); "
+            "sample": f"the c2_single_layer workload once = 1 layer ({dt:.1f} s, torch threads = {cores}); one eighth of "
+                      f"the layers of the stack `value` times, whose per-layer CPU cost is higher (deeper forwards); "
                       f"chosen proportion {prop}"}
 
 
@@ -688,6 +697,12 @@ def main():
     # the step the phase / eigensolver blocks describe: C2 at N = 1, the fixed stack otherwise
     one_step = family(c2, torch.float32) if c2 is not None else stack_step
     described = "c2_single_layer" if c2 is not None else "the fixed stack (`value`)"
+    if c2 is not None:
+        result["config"]["c2_single_layer_layers_per_s"] = result["c2_single_layer"]["value"]
+        result["config"]["c2_single_layer_ms_per_step"] = result["c2_single_layer"]["ms_per_step"]
+        result["config"]["blocks_of"] = ("value / ms_per_step: the fixed 8-layer stack; roofline, eigh, phases_ms, kernels and "
+                                         "cpu_baseline: c2_single_layer (BASELINE configs[1], one layer) -- each block names "
+                                         "its workload in `of` / `workload`")
     prof = []
     if not args.no_extras:
         # two extra, untimed steps.  (1) phase spans of the step on the device timeline (A accumulate, B
@@ -859,13 +874,23 @@ def main():
             except Exception as exc:  # the library call is context: never fail the bench for it
                 result["eigh"]["gpu_library_eigh_ms"] = None
                 result["eigh"]["gpu_library_eigh_note"] = f"torch.linalg.eigh failed: {exc}"
+        if "roofline" in result:
+            result["roofline"]["of"] = ("the dominant kernel of ptd_eigh_topk inside one step of `%s` (NOT of the 8-layer "
+                                        "stack `value` is quoted on, whose step is 70 %% model forwards)" % described)
+        if "eigh" in result:
+            result["eigh"]["of"] = described
         result["kernels"] = {**result.get("kernels", {}), **kernel_lines(device)}
         result["decomposed_fwd"] = decomposed_forward_lines(device)
         if world == 1 and not args.no_c4:
             result["c4_shapes"] = llama_shape_lines(device)
             result["c4_block"] = llama_block_lines(device)
+            # two full-width blocks end to end: replace -> next-layer-sees-it at depth > 1
+            result["c4_stack"] = llama_block_lines(device, blocks=2, dtypes=(torch.bfloat16,), timed=3)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline()
+            if c2 is not None:
+                result["cpu_baseline"]["gpu_same_workload"] = {"value": result["c2_single_layer"]["value"], "unit": "layers/s",
+                                                               "ms_per_step": result["c2_single_layer"]["ms_per_step"]}
 
     if rank == 0:
         print(json.dumps(result))

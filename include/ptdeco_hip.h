@@ -77,6 +77,17 @@ int ptd_stream_pair_wall_us(void* stream_a, void* stream_b, int spin_us, double*
 int ptd_syrk_accumulate(const void* y, int64_t T, int64_t n, int64_t ldy, int y_dtype,
                         void* E, int64_t ldE, int E_dtype, double scale, void* stream);
 
+/* The same sum over `steps` calibration steps in ONE pass over E (round 5, ABI 3):
+ *   E[i][j] += sum_s ( scale * sum_t Y_s[t][i] * Y_s[t][j] ),  i >= j,
+ * `ys` a HOST array of `steps` device pointers to [T, n] matrices of one dtype and row pitch.  dwain.py:147-152 is
+ * called once per calibration step (D times per layer) and each call reads and writes the live triangle of the f64
+ * accumulator: 8 n (n + 1) bytes against 2 T n of bf16 activations -- at n = 4096, T = 2048 that traffic, not the
+ * matrix cores, bounds the call.  Here a tile's f64 sum stays in registers across the steps (each step's f32 product
+ * is promoted at its end, in step order) and E is read and written once.  bf16: one launch per 8 steps; f32 (bound by
+ * the matrix cores): step by step, identical to `steps` calls of ptd_syrk_accumulate. */
+int ptd_syrk_accumulate_multi(const void* const* ys, int steps, int64_t T, int64_t n, int64_t ldy, int y_dtype,
+                              void* E, int64_t ldE, int E_dtype, double scale, void* stream);
+
 /* ey[j] += scale * sum_t Y[t][j].   Replaces `Ey += y.mean(dim=0)`: falor.py:161. */
 int ptd_colsum_accumulate(const void* y, int64_t T, int64_t n, int64_t ldy, int y_dtype,
                           void* ey, int ey_dtype, double scale, void* stream);

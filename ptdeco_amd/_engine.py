@@ -72,6 +72,20 @@ def phase(name: str):
     return PHASES.span(name) if PHASES is not None else contextlib.nullcontext()
 
 
+def warn_if_not_finite(nsr_values, layer_name: str) -> None:
+    """ a NaN metric reads as 'accepted' in dwain's three >= tests and as 'rejected' in falor's < tests, like
+    in the reference; when it is not the model's own doing (a ptd_nsr whose cached workspace was left with a raised
+    ticket by an aborted launch returns NaN from then on) that is silent damage.  The cached workspaces are dropped, so
+    the next call starts from an initialised one, and the event is logged once per layer."""
+    import math
+
+    if all(math.isfinite(v) for v in nsr_values):
+        return
+    ops.drop_cached_workspaces()
+    warn_once(f"nsr-nan:{layer_name}", f"ptdeco_amd: a non-finite NSR came back while searching the rank of {layer_name}; "
+              "the cached ptd_nsr workspaces were re-initialised -- if the model's own outputs are finite, rerun this layer")
+
+
 def is_decomposeable_module(module: torch.nn.Module) -> bool:
     """nn.Linear, or nn.Conv2d with a 1x1 kernel and groups == 1 (dwain.py:540-546, falor.py:402-408)."""
     if isinstance(module, torch.nn.Linear):
@@ -103,15 +117,51 @@ def _flat_tensors(obj, out: list) -> bool:
     return False
 
 
+def _container_print(v):
+    """A cheap fingerprint of a mutable container bound to a module attribute: its length and the identities of (up to
+    64 of) its elements -- an in-place `append`, `pop`, `update` or `clear` keeps the container's own id."""
+    import collections
+
+    if isinstance(v, (list, collections.deque)):
+        return (len(v), tuple(id(o) for o in list(v)[:64]))
+    if isinstance(v, dict):
+        return (len(v), tuple((id(k), id(o)) for k, o in list(v.items())[:64]))
+    if isinstance(v, (set, bytearray)):
+        return (len(v),)
+    return None
+
+
+def _rng_state() -> tuple:
+    """The generators a forward could draw from without it showing in its arguments: Python's and numpy's global ones
+    and torch's default CPU / current-device generators (hashes of the states: compared, never restored)."""
+    import random
+
+    st = [hash(random.getstate())]
+    try:
+        import sys
+
+        np = sys.modules.get("numpy")
+        if np is not None:
+            st.append(hash(np.random.get_state()[1].tobytes()))
+    except Exception:
+        pass
+    st.append(hash(torch.get_rng_state().numpy().tobytes()))
+    if torch.cuda.is_available() and torch.cuda.is_initialized():
+        gen = torch.cuda.default_generators[torch.cuda.current_device()]
+        st.append((gen.initial_seed(), int(gen.get_offset()) if hasattr(gen, "get_offset") else 0))
+    return tuple(st)
+
+
 def _subtree_state(mod: torch.nn.Module) -> list:
     """What a forward that is a function of its arguments leaves alone: training flags, which objects the modules'
-    attributes are bound to, and the version counters of parameters and buffers."""
-    st: list = []
+    attributes are bound to, the contents of list / dict / set attributes (fingerprints: an in-place append keeps the
+    binding), the version counters of parameters and buffers, and the random generators of the process."""
+    st: list = [_rng_state()]
     for m in mod.modules():
         st.append(m.training)
         for k, v in m.__dict__.items():
             if k not in ("_parameters", "_buffers", "_modules"):
-                st.append((k, id(v)))
+                st.append((k, id(v), _container_print(v)))
         for d in (m._parameters, m._buffers):
             for k, v in d.items():
                 st.append((k, id(v), -1 if v is None or v.is_inference() else v._version))
@@ -144,22 +194,37 @@ class PrefixMemo:
     rounding of its dtype (tests)."""
 
     IDLE, RECORD, REPLAY = 0, 1, 2
-    UNKNOWN, PURE, IMPURE = 0, 1, 2
+    UNKNOWN, PURE, IMPURE, RANDOM = 0, 1, 2, 3     # RANDOM: the subtree drew from a global random generator -- what runs
+                                                   # behind it sees other values in the second forward: recording stops there
     total_hits = 0      # outputs handed back since the process started (tests, tools)
+    # Self-check (round 5): the FIRST metric step of every layer recomputes each output it is about to hand back and
+    # compares (one extra partial forward per layer).  A mismatch -- a model that is not a function of its input ahead
+    # of the layer in a way the purity test did not see -- costs nothing but speed: the recomputed value is used, one
+    # WARNING is logged, and the memo is off for this model from then on (level[id(root)] = 2; 1 = products only is
+    # reserved for PTD_PREFIX_MEMO_UNITS=products).
+    level: dict = {}
 
     def __init__(self, root: torch.nn.Module, layer: torch.nn.Module, budget_bytes: int, check: bool = False,
-                 subtrees: bool = True):
+                 subtrees: bool = True, self_check: bool = False):
         self.mode = self.IDLE
         self.reached = False
         self.full = False
         self.bytes = 0
         self.budget = budget_bytes
         self.check = check
+        self.root_id = id(root)
+        self.self_check = self_check   # the first `second()` of this memo's life compares; cleared after it
+        self.disabled = PrefixMemo.level.get(self.root_id, 0) >= 2
+        if PrefixMemo.level.get(self.root_id, 0) >= 1:
+            subtrees = False
         self.hits = 0
         self.unit_hits = 0
-        self._gen = 0            # forward counter: per-module call indices restart with it
-        self._depth = 0          # > 0 while a subtree unit records: the products inside it keep nothing of their own
+        self._gen = 0            # forward counter
+        self._seq = 0            # calls that reached a patched forward at depth 0 in this forward: the entries' keys
+        self._as_unit: set = set()   # keys of the calls that ran a subtree as ONE unit while recording
+        self._depth = 0          # > 0 while a subtree runs as a unit: the patched modules inside it are transparent
         self._patched: list = []   # (module, kept dict)
+        self._units: list = []     # (module, kept dict, is a subtree unit, [purity])
         import torch.nn.modules.module as _mm
 
         if getattr(_mm, "_global_forward_hooks", None) or getattr(_mm, "_global_forward_pre_hooks", None):
@@ -222,7 +287,8 @@ class PrefixMemo:
         if mb <= 0:
             return None
         return PrefixMemo(root, layer, int(mb * 2**20), check=os.environ.get("PTD_PREFIX_MEMO_CHECK", "0") == "1",
-                          subtrees=os.environ.get("PTD_PREFIX_MEMO_UNITS", "subtrees") != "products")
+                          subtrees=os.environ.get("PTD_PREFIX_MEMO_UNITS", "subtrees") != "products",
+                          self_check=os.environ.get("PTD_PREFIX_MEMO_SELF_CHECK", "1") != "0")
 
     @staticmethod
     def _first_shape(args, kwargs):
@@ -230,6 +296,37 @@ class PrefixMemo:
         _flat_tensors(args, flat)
         _flat_tensors(kwargs, flat)
         return flat[0].shape if flat else None
+
+    def _step_down(self, m, unit: bool) -> None:
+        """A kept output differed from its recomputation: what runs behind this module sees other values in the second
+        forward than in the first, so nothing may be handed back any more -- the memo is off for this model, now and
+        for the memos of its later layers (level 2; only a mismatch can tell a forward whose VALUES change from one
+        that merely has side effects, and nothing short of off is safe for the former)."""
+        import logging
+
+        PrefixMemo.level[self.root_id] = 2
+        logging.getLogger(__name__).warning(
+            "ptdeco_amd: the model does not compute the same values ahead of the analysed layer in both forwards of a "
+            "metric step (%s %s): the prefix memo is off for this model -- both forwards of every metric step run whole, "
+            "as in the reference", "subtree" if unit else "module", type(m).__name__)
+        for mod, kept, is_unit, purity in self._units:
+            purity[0] = self.IMPURE
+            kept.clear()
+        self.disabled = True
+
+    def _same(self, again, out) -> bool:
+        fa: list = []
+        fb: list = []
+        same = _flat_tensors(again, fa) and _flat_tensors(out, fb) and len(fa) == len(fb)
+        for x, y in zip(fa, fb):
+            if not same:
+                break
+            if x.shape != y.shape or x.dtype != y.dtype:
+                same = False
+            elif not torch.equal(x, y):
+                tol = {torch.float64: 1e-10, torch.float32: 1e-4}.get(y.dtype, 2e-2)
+                same = bool((x.double() - y.double()).abs().max() <= tol * y.double().abs().max())
+        return same
 
     def _compare(self, m, again, out) -> None:
         # (bit-identical for this package's kernels; a library kernel may vary from call to call on identical input --
@@ -254,18 +351,29 @@ class PrefixMemo:
     def _patch(self, m: torch.nn.Module, unit: bool) -> None:
         inner = m.forward
         kept: dict = {}
-        calls = [0, -1]                  # [calls of m in this forward, the forward they were counted in]
         purity = [self.UNKNOWN if unit else self.PURE]
 
-        def forward(*args, **kwargs):
-            if self.mode == self.IDLE:
+        def whole(args, kwargs):
+            # the module run as ONE unit: the patched modules inside it neither keep, replay nor count calls
+            self._depth += 1
+            try:
                 return inner(*args, **kwargs)
-            if calls[1] != self._gen:
-                calls[0], calls[1] = 0, self._gen
-            idx = calls[0]
-            calls[0] += 1
+            finally:
+                self._depth -= 1
+
+        def forward(*args, **kwargs):
+            if self.mode == self.IDLE or self._depth > 0:
+                return inner(*args, **kwargs)
+            # Entries are keyed by the position of the call among the calls that reach this point in the forward (ADVICE
+            # r4: per-module call indices shifted when a replayed subtree skipped the calls inside it -- a weight-tied
+            # Linear called once inside a subtree and again behind it could be handed the wrong output).  Both forwards
+            # count the same calls: what ran as one unit while recording runs as one unit in the replay too.
+            idx = self._seq
+            self._seq += 1
             if self.mode == self.RECORD:
-                keep = not (self.reached or self.full) and purity[0] != self.IMPURE and (unit or self._depth == 0)
+                if purity[0] == self.RANDOM:
+                    self.full = True          # nothing from here on is kept in this forward
+                keep = not (self.reached or self.full) and purity[0] != self.IMPURE
                 if not keep:
                     return inner(*args, **kwargs)
                 if unit:
@@ -277,13 +385,13 @@ class PrefixMemo:
                         purity[0] = self.IMPURE
                         return inner(*args, **kwargs)
                     before = _subtree_state(m) if purity[0] == self.UNKNOWN else None
-                    self._depth += 1
-                    try:
-                        out = inner(*args, **kwargs)
-                    finally:
-                        self._depth -= 1
+                    self._as_unit.add(idx)
+                    out = whole(args, kwargs)
                     if before is not None:
-                        purity[0] = self.PURE if before == _subtree_state(m) else self.IMPURE
+                        after = _subtree_state(m)
+                        purity[0] = self.PURE if before == after else (self.RANDOM if before[0] != after[0] else self.IMPURE)
+                        if purity[0] == self.RANDOM:
+                            self.full = True
                     if purity[0] != self.PURE or self.reached:    # (the tapped layer ran inside: not a prefix unit)
                         return out
                 else:
@@ -303,20 +411,27 @@ class PrefixMemo:
                     self.full = True
                 return out
             # REPLAY
+            as_unit = unit and idx in self._as_unit
             entry = kept.pop(idx, None)
             if entry is not None:
                 out, flat, versions, shape = entry
                 if all(t._version == v for t, v in zip(flat, versions)) and self._first_shape(args, kwargs) == shape:
                     if self.check:
-                        self._compare(m, inner(*args, **kwargs), out)
+                        self._compare(m, whole(args, kwargs) if as_unit else inner(*args, **kwargs), out)
+                    elif self.self_check:
+                        again = whole(args, kwargs) if as_unit else inner(*args, **kwargs)
+                        if not self._same(again, out):
+                            self._step_down(m, unit)
+                            return again
                     self.hits += 1
                     self.unit_hits += 1 if unit else 0
                     PrefixMemo.total_hits += 1
                     return out
-            return inner(*args, **kwargs)
+            return whole(args, kwargs) if as_unit else inner(*args, **kwargs)
 
         m.forward = forward
         self._patched.append((m, kept))
+        self._units.append((m, kept, unit, purity))
 
     def _drop(self) -> None:
         for _, kept in self._patched:
@@ -332,8 +447,10 @@ class PrefixMemo:
             self._drop()
             self.reached = self.full = False
             self._gen += 1
+            self._seq = 0
+            self._as_unit = set()
             self._depth = 0
-            self.mode = self.RECORD
+            self.mode = self.IDLE if self.disabled else self.RECORD
             try:
                 yield
             finally:
@@ -347,11 +464,14 @@ class PrefixMemo:
         @contextlib.contextmanager
         def cm():
             self._gen += 1
-            self.mode = self.REPLAY
+            self._seq = 0
+            self._depth = 0
+            self.mode = self.IDLE if self.disabled else self.REPLAY
             try:
                 yield
             finally:
                 self.mode = self.IDLE
+                self.self_check = False
                 self._drop()
         return cm()
 
@@ -403,6 +523,8 @@ class LayerTap:
         self.calls = 0                 # calls of the layer since calibration_forward last reset it
         self._stop_at_input = False
         self._single_call_seen = False
+        self._cal_forwards = 0
+        self._plain_ancestors: Optional[bool] = None
         self._handle = layer.register_forward_pre_hook(self._record)
 
     def _record(self, _module, args) -> None:
@@ -424,7 +546,14 @@ class LayerTap:
         import os
 
         self.calls = 0
-        if self._single_call_seen and os.environ.get("PTD_CALIBRATION_EARLY_STOP", "1") != "0":
+        self._cal_forwards += 1
+        #  the call count of ONE batch is not a fact about every batch (data-dependent control flow), so every
+        # 8th forward runs whole again and re-establishes it; and the unwinding exception skips whatever the modules
+        # around the layer do behind their inner forward: with a hook or an instance-level forward on any ancestor
+        # (accelerate's offload hooks are such wrappers) the forwards stay whole
+        revalidate = self._cal_forwards % 8 == 0
+        if (self._single_call_seen and not revalidate and self._ancestors_plain(root)
+                and os.environ.get("PTD_CALIBRATION_EARLY_STOP", "1") != "0"):
             self._stop_at_input = True
             try:
                 root(batch)
@@ -435,6 +564,22 @@ class LayerTap:
             return
         root(batch)
         self._single_call_seen = self.calls == 1
+
+    def _ancestors_plain(self, root: torch.nn.Module) -> bool:
+        """No module on the path from the root to the layer carries hooks or an instance-level forward."""
+        if self._plain_ancestors is None:
+            ok = True
+            parts = self.name.split(".")
+            mod = root
+            for part in [None] + parts[:-1]:
+                if part is not None:
+                    mod = getattr(mod, part)
+                if (mod._forward_hooks or mod._forward_pre_hooks or mod._backward_hooks or "forward" in mod.__dict__
+                        or getattr(mod, "_hf_hook", None) is not None):
+                    ok = False
+                    break
+            self._plain_ancestors = ok
+        return self._plain_ancestors
 
     def enable_prefix_memo(self, root: torch.nn.Module) -> None:
         """Metric steps of this layer's rank search share the model's work ahead of the layer (PrefixMemo)."""
@@ -552,6 +697,48 @@ def _input_route_wanted(n_out: int, n_in: int, top_k: Optional[int]) -> bool:
     return True if flag == "1" else n_out >= n_in + n_in // 2
 
 
+class StepBatch:
+    """The bf16 activation matrices of up to PTD_SYRK_STEPS (default 8) calibration steps, held back so that their
+    covariance sums reach the f64 accumulator in ONE pass (ops.syrk_accumulate_multi): dwain.py:147-152 runs once per
+    step and every call reads and writes the live triangle of E -- 134 MB at n = 4096 against 17 MB of activations at
+    2048 tokens -- which, not the matrix cores, bounds it.  A matrix the caller may still write to
+    (a view of a module's input or output) is copied into the batch; one nobody else holds (the product the stand-in
+    formed itself) is kept by reference.  Everything held is added before E is read (`flush`).  The bytes held by all
+    batches of the process are bounded (PTD_SYRK_BUFFER_MB, default 4096): beyond that a step is added at once, as in
+    round 4.  f32 activations are never held (their product is bound by the matrix cores)."""
+
+    held_bytes = 0           # over every batch of the process
+
+    def __init__(self, E: torch.Tensor):
+        import os
+
+        self.E = E
+        self.max_steps = max(1, int(os.environ.get("PTD_SYRK_STEPS", "8")))
+        self.budget = int(os.environ.get("PTD_SYRK_BUFFER_MB", "4096")) << 20
+        self.pending: list = []
+
+    def add(self, y: torch.Tensor, private: bool = False) -> None:
+        nbytes = y.numel() * y.element_size()
+        if (self.max_steps == 1 or y.dtype != torch.bfloat16 or not y.is_cuda or y.dim() != 2
+                or StepBatch.held_bytes + nbytes > self.budget):
+            self.flush()
+            ops.syrk_accumulate(self.E, y, 1.0 / y.shape[0])
+            return
+        if self.pending and (self.pending[0].shape != y.shape):
+            self.flush()
+        self.pending.append(y if private else y.clone(memory_format=torch.contiguous_format))
+        StepBatch.held_bytes += nbytes
+        if len(self.pending) >= self.max_steps:
+            self.flush()
+
+    def flush(self) -> None:
+        if not self.pending:
+            return
+        ys, self.pending = self.pending, []
+        StepBatch.held_bytes -= sum(y.numel() * y.element_size() for y in ys)
+        ops.syrk_accumulate_multi(self.E, ys, 1.0 / ys[0].shape[0])
+
+
 class Covariance:
     """sum over calibration steps of y^T y / T (and of mean_rows(y)) for one layer, in HBM.
 
@@ -570,12 +757,14 @@ class Covariance:
         # mean of the accumulated rows (falor): of y, or of x on the input route (Ey = W mean(x))
         self.ey = torch.zeros(m, dtype=dt, device=device) if with_mean else None
         self.steps = 0
+        self.batch = StepBatch(self.E)
 
-    def add_features(self, y: torch.Tensor) -> None:
-        """y: [T, n] layer output rows (dwain.py:147-152; falor.py:160-161)."""
+    def add_features(self, y: torch.Tensor, private: bool = False) -> None:
+        """y: [T, n] layer output rows (dwain.py:147-152; falor.py:160-161).  `private`: nobody else holds or will
+        write to `y` (it may be kept by reference until the batch of steps is added)."""
         assert not self.input_route
         t = y.shape[0]
-        ops.syrk_accumulate(self.E, y, 1.0 / t)
+        self.batch.add(y, private)
         if self.ey is not None:
             ops.colsum_accumulate(self.ey, y, 1.0 / t)
         self.steps += 1
@@ -584,16 +773,20 @@ class Covariance:
         """x_rows [T, n_in], weight2d [n, n_in].  Direct route: y = x W^T on the matrix cores (or the
         caller's `features` if it already has them), then Y^T Y.  Input route: X^T X only."""
         if self.input_route:
-            ops.syrk_accumulate(self.E, x_rows, 1.0 / x_rows.shape[0])
+            self.batch.add(x_rows)
             if self.ey is not None:
                 ops.colsum_accumulate(self.ey, x_rows, 1.0 / x_rows.shape[0])
             self.steps += 1
             return
-        self.add_features(features if features is not None else ops.matmul(x_rows, weight2d.T))
+        if features is not None:
+            self.add_features(features)
+        else:
+            self.add_features(ops.matmul(x_rows, weight2d.T), private=True)
 
     def reduce_to_owner(self, shard, index: int) -> None:
         """Sum the partial statistics of all ranks on the owner of `index` (the one bulk exchange of the path:
         RCCL over xGMI; packed lower triangle, see sharding.py).  Only the owner may call eigenvectors()."""
+        self.batch.flush()
         with phase("comm"):
             shard.reduce_lower_to_owner(self.E, index)
         small = [torch.tensor([float(self.steps)], dtype=torch.float64, device=self.E.device)]
@@ -610,6 +803,7 @@ class Covariance:
         """reduce_to_owner without waiting: the exchange is started (every rank, same order) and the returned
         function completes it -- the owner calls it right before eigenvectors(), on the thread / stream that runs
         the eigensolver, so the sums of the other layers of the pass travel while it works."""
+        self.batch.flush()
         with phase("comm"):
             done_e = shard.reduce_lower_to_owner_async(self.E, index)
         small = [torch.tensor([float(self.steps)], dtype=torch.float64, device=self.E.device)]
@@ -631,6 +825,7 @@ class Covariance:
         """Finalise (divide by steps, optional mean removal, Tikhonov damping) and return the
         eigenvectors in columns, ascending, f64 (dwain.py:155-163, falor.py:192-208).  With
         ``top_k`` only the last top_k columns (largest eigenvalues) are formed: [n, top_k]."""
+        self.batch.flush()
         if self.input_route:
             # cov = W (Ex - mx mx^T) W^T when the mean is removed (falor.py:196-199); damping only shifts eigenvalues
             ex = ops.cov_finalize(self.E, self.steps, 0.0, self.ey if use_mean else None)
@@ -669,19 +864,22 @@ class InputMoment:
         self.ex: Optional[torch.Tensor] = None
         self.step_id = -1     # the pool's step in which the moment was last added to
         self.step_key = None  # identity of that step's input tensor
+        self.batch = StepBatch(self.E)
 
     def add(self, x_rows: torch.Tensor) -> None:
-        ops.syrk_accumulate(self.E, x_rows, 1.0 / x_rows.shape[0])
+        self.batch.add(x_rows)
         self.steps += 1
 
     def all_reduce(self, shard) -> None:
         """A shared moment feeds layers with different owners: its lower triangle is summed on every rank."""
+        self.batch.flush()
         shard.all_reduce_lower(self.E)
         steps = torch.tensor([self.steps], dtype=torch.int64, device=self.E.device)
         shard.all_reduce_small(steps)
         self.steps = int(steps.item())
 
     def finalize(self) -> None:
+        self.batch.flush()
         self.ex = ops.cov_finalize(self.E, self.steps, 0.0)
 
 

@@ -24,6 +24,8 @@ SIGNATURES = {
     "ptd_stream_pair_wall_us": (c_int, [c_void_p, c_void_p, c_int, ctypes.POINTER(c_double)]),
     "ptd_syrk_accumulate": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_int64, c_int,
                                     c_double, c_void_p]),
+    "ptd_syrk_accumulate_multi": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int64, c_int, c_void_p, c_int64, c_int,
+                                          c_double, c_void_p]),
     "ptd_colsum_accumulate": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_int, c_double,
                                       c_void_p]),
     "ptd_cov_finalize_workspace_bytes": (c_size_t, [c_int64]),

@@ -69,6 +69,30 @@ int ptd_syrk_accumulate(const void* y, int64_t T, int64_t n, int64_t ldy, int y_
   return PTD_ERR_UNSUPPORTED;
 }
 
+int ptd_syrk_accumulate_multi(const void* const* ys, int steps, int64_t T, int64_t n, int64_t ldy, int y_dtype, void* E,
+                              int64_t ldE, int E_dtype, double scale, void* stream) {
+  PTD_REQUIRE(ys && E && steps >= 0 && steps <= 4096, "ptd_syrk_accumulate_multi: bad argument");
+  for (int s = 0; s < steps; ++s) PTD_REQUIRE(ys[s], "ptd_syrk_accumulate_multi: null pointer (step %d)", s);
+  PTD_REQUIRE(T >= 0 && n >= 0 && ldy >= n && ldE >= n, "ptd_syrk_accumulate_multi: bad shape T=%lld n=%lld ldy=%lld ldE=%lld",
+              (long long)T, (long long)n, (long long)ldy, (long long)ldE);
+  PTD_REQUIRE(E_dtype == PTD_F64 || E_dtype == PTD_F32, "ptd_syrk_accumulate_multi: E must be f64 or f32");
+  PTD_REQUIRE(T < (1ll << 31) && n < (1ll << 31), "ptd_syrk_accumulate_multi: dimension too large");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (y_dtype == PTD_BF16)
+    return syrk_bf16_multi(reinterpret_cast<const unsigned short* const*>(ys), steps, T, n, ldy, E, ldE,
+                           E_dtype == PTD_F64, scale, st);
+  if (y_dtype == PTD_F32) {
+    // the f32 product is bound by the matrix cores, not by the accumulator's read-modify-write: step by step
+    for (int s = 0; s < steps; ++s) {
+      const int rc = syrk_f32(static_cast<const float*>(ys[s]), T, n, ldy, E, ldE, E_dtype == PTD_F64, scale, st);
+      if (rc != PTD_OK) return rc;
+    }
+    return PTD_OK;
+  }
+  set_error("ptd_syrk_accumulate_multi: y dtype must be f32 or bf16");
+  return PTD_ERR_UNSUPPORTED;
+}
+
 int ptd_colsum_accumulate(const void* y, int64_t T, int64_t n, int64_t ldy, int y_dtype, void* ey, int ey_dtype,
                           double scale, void* stream) {
   return colsum_accumulate(y, T, n, ldy, y_dtype, ey, ey_dtype, scale, static_cast<hipStream_t>(stream));

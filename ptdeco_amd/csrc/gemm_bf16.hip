@@ -18,6 +18,7 @@
 //       the four k rows of a half wave on disjoint bank quarters -> conflict free.
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 
@@ -540,6 +541,370 @@ __global__ __launch_bounds__(256, 2) void syrk_bf16_glds_kernel(const GemmBf16Ar
     const int s = b - nbig - ndiag, d = ndiag + s / PEEL_K, q = s % PEEL_K;
     const int kc = (a.K / BK + PEEL_K - 1) / PEEL_K * BK;
     syrk_bf16_glds_tile<EPI, 128>(a, d, d, lds, q * kc, kc, true);
+  }
+}
+
+// ---- covariance product, round 5: persistent workgroups, a ring of K steps in flight, the tile's sum resident ----
+// What bounded syrk_bf16_glds_kernel at the calibration shapes (T = 2048 rows a step, n = 4096: 69.5 us against an HBM
+// bound of 19) was (1) ONE K step in flight per workgroup behind a barrier that drains the DMA (`vmcnt(0)`): a CU took in
+// ~50 GB/s = bytes in flight / latency, (2) the accumulator's read-modify-write as an epilogue nothing overlapped
+// (~20 us: four dependent rounds of 16 loads), paid once per calibration step.  Here
+//  * one 256-thread workgroup per CU owns all of its LDS as a ring of NBUF K steps (TS = 128: 4 x 32 KiB, TS = 64:
+//    8 x 16 KiB); NBUF - 1 steps stay in flight across raw barriers, a counted `s_waitcnt vmcnt(N)` retires only the step
+//    about to be read (vmcnt counts loads, LDS-DMA and stores together, in issue order);
+//  * the K loop runs over the rows of up to 8 calibration steps (ptd_syrk_accumulate_multi): at each step boundary the
+//    f32 accumulators are promoted into f64 sums that stay in registers (one wave per SIMD: 512 registers a lane), and
+//    the old values of E are requested in the LAST ring slots' issue positions (the tail iterations stage nothing), so
+//    they arrive under the last K steps; E is read and written ONCE per call;
+//  * workgroups are persistent over a list of work items of about equal cost: the strictly-lower tiles in the XCD-aware
+//    walk of the kernel above, then the diagonal tiles in PAIRS (a diagonal tile stages one operand: half the bytes of
+//    a lower one).  n = 4096: 496 + 16 = 512 items = two per CU, nothing left over (the K-range peel with f64
+//    atomics of the old kernel is gone: every element has one adder, results do not depend on scheduling).
+// With steps = 1 the value stored is E_old + scale * acc as before; with several steps E_old + sum_s scale * acc_s
+// (the sum formed in f64 in step order).
+struct SyrkRingArgs {
+  const unsigned short* y[8];   // the calibration steps' activations [T, n], row pitch ld
+  int steps;                    // 1 .. 8
+  int nkps;                     // K steps (64 rows) per calibration step
+  int64_t ld;
+  void* E;
+  int64_t ldE;
+  double scale;
+  int tiles_m;                  // n / TS
+  int nlower;                   // tiles_m (tiles_m - 1) / 2
+  int nitems;                   // nlower + ceil(tiles_m / 2)
+  int dbg;                      // timing experiments (PTD_SYRK_RING_DBG): 1 = no MFMA / fragment reads, 2 = no staging
+};
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+template <int I, int N, typename Fn>
+__device__ __forceinline__ void static_for(Fn&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+// NW = 4: waves 2 x 2, a wave owns a square of TS / 2 and, alone on its SIMD, requests the fragments of step g + 1 into
+// a second register set while the MFMAs of step g run from the first.  NW = 8 (TS = 128): waves 2 x 4, a wave owns
+// 64 x 32, two waves per SIMD cover each other's fragment reads (no second set: with the f64 sums the 4-wave form needed
+// more than the 512 registers of a lane and spilled).
+template <int EPI, int TS, int NBUF, bool SAME, int NW>
+__device__ __forceinline__ void syrk_ring_tile(const SyrkRingArgs& a, const int ti, const int tj, char* lds) {
+  constexpr int ROWB = TS * 2;             // bytes per k-row of an operand image
+  constexpr int OPB = BK * ROWB;           // one operand, one K step
+  constexpr int BUFB = 2 * OPB;
+  constexpr int KPI = 1024 / ROWB;         // k-rows per DMA wave instruction
+  constexpr int NI = BK / (NW * KPI);      // DMA instructions per wave, operand and K step
+  constexpr int CPR = ROWB / 16;           // 16-byte chunks per k-row
+  constexpr int WCOLS = NW / 2;            // waves across the tile's columns
+  constexpr int WSM = TS / 2, WSN = TS / WCOLS;   // a wave's rows x columns
+  constexpr int FM = WSM / 32, FN = WSN / 32;     // 32-wide fragments per wave: A side, B side
+  constexpr bool DB = NW == 4;             // register double buffering of the fragments
+  constexpr int DPS = NI * (SAME ? 1 : 2); // DMA instructions per wave and K step
+  constexpr int NE = 16 * FM * FN;         // old values of E per lane
+  static_assert(NI >= 1 && FM >= 1 && FN >= 1, "tile too small for this wave grid");
+  // the old values are requested in pieces of 16, one per tail iteration (NBUF - 1 of them stage nothing) and one beside
+  // the last step's MFMAs
+  constexpr int PIECE = 16;
+  constexpr int NPIECE = NE / PIECE;
+  static_assert(NBUF >= 4 && NPIECE <= NBUF && NE % PIECE == 0, "one piece per tail position");
+  typedef typename std::conditional<EPI == EPI_ACC_F64, double, float>::type ET;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid / WCOLS, wn = wid % WCOLS;
+  const int m0 = ti * TS, n0 = tj * TS;
+  const bool dead = SAME && wn * WSN >= (wm + 1) * WSM;     // a wave whose columns all lie right of its last row
+  const int NK = a.steps * a.nkps;
+  const int64_t ld = a.ld;
+
+  // staging cursor: K step s_kt of calibration step s_step
+  int s_step = 0, s_kt = 0;
+  const unsigned short* s_base = a.y[0];
+  const int skr = lane / CPR, sc = lane % CPR;
+  // The loads are written out (global_load_lds_dwordx4 v_off, s[base], m0 = LDS address): the compiler then knows
+  // nothing of the LDS writes -- with the builtin it put a vmcnt(0) in front of every fragment read, which drains the
+  // ring at every K step -- and a lane keeps ONE 32-bit offset per piece: k-row k of the piece, source chunk cs.
+  unsigned voff[NI];
+#pragma unroll
+  for (int q = 0; q < NI; ++q) {
+    const int k = (wid * NI + q) * KPI + skr;
+    const int cs = sc ^ ((TS == 128 ? (k & 3) : ((k >> 1) & 1)) << 2);   // source chunk that belongs at position sc
+    voff[q] = (unsigned)(((int64_t)k * ld + cs * 8) * 2);
+  }
+  const unsigned lds0 = (unsigned)(size_t)(lds_void*)lds;
+  auto stage_next = [&](int buf) {
+    const char* baseA = reinterpret_cast<const char*>(s_base + m0 + (int64_t)s_kt * BK * ld);
+    const char* baseB = reinterpret_cast<const char*>(s_base + n0 + (int64_t)s_kt * BK * ld);
+#pragma unroll
+    for (int q = 0; q < NI; ++q) {
+      if (a.dbg == 2) break;
+      const unsigned slot = lds0 + buf * BUFB + (wid * NI + q) * KPI * ROWB;   // wave-uniform 1-KiB piece
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                   : : "s"(slot), "v"(voff[q]), "s"(baseA) : "memory", "m0");
+      if (!SAME)
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                     : : "s"(slot + OPB), "v"(voff[q]), "s"(baseB) : "memory", "m0");
+    }
+    if (++s_kt == a.nkps) {
+      s_kt = 0;
+      ++s_step;
+      const unsigned short* nb = a.y[0];
+#pragma unroll
+      for (int q = 1; q < 8; ++q) nb = s_step == q ? a.y[q] : nb;
+      s_base = nb;
+    }
+  };
+  const int fg = lane >> 4, fq = (lane >> 2) & 3, fp = lane & 3;
+  const int fk = 8 * (fg >> 1) + fq;
+  const int fsw = TS == 128 ? fq : (fq >> 1);
+  const int fro = (16 * (fg & 1) + 4 * fp) * 2;
+  auto fragment = [&](const char* L, int r0, int kk) -> s16x8 {
+    const char* p = L + (kk + fk) * ROWB + (((r0 >> 5) ^ fsw) << 6) + fro;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * ROWB));
+    return s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  };
+
+  f32x16 acc[FM][FN];
+  ET sum[FM][FN][16], oldp[2][PIECE];     // (the old values pass through two alternating pieces of registers)
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; sum[i][j][r] = (ET)0; }
+
+  // lane l holds column (l & 31) and rows (r & 3) + 8 (r >> 2) + 4 (l >> 5) of each 32 x 32 block.  An address is a
+  // wave-uniform part (block, register) + ONE 32-bit lane offset for all of a lane's values: written so that the
+  // compiler takes the scalar-base form of the load / store (64 addresses of 64 bits a lane spilled).
+  ET* const Eb = reinterpret_cast<ET*>(a.E);
+  const unsigned e_lane = (unsigned)(((int64_t)(4 * (lane >> 5)) * a.ldE + (lane & 31)) * sizeof(ET));
+  auto e_ptr = [&](int i, int j, int r) -> ET* {
+    const int64_t urow = m0 + wm * WSM + i * 32 + (r & 3) + 8 * (r >> 2);      // wave-uniform
+    ET* ub = Eb + urow * a.ldE + (n0 + wn * WSN + j * 32);
+    return reinterpret_cast<ET*>(reinterpret_cast<char*>(ub) + e_lane);
+  };
+  // (every wave requests the same number of old values, a wave right of the diagonal too: the waits below count them)
+  auto load_old = [&](auto piece) {
+    constexpr int P = decltype(piece)::value;
+#pragma unroll
+    for (int e = P * PIECE; e < (P + 1) * PIECE && e < NE; ++e) {
+      const int i = e / (16 * FN), j = (e / 16) % FN, r = e % 16;
+      oldp[P & 1][e - P * PIECE] = *e_ptr(i, j, r);
+    }
+  };
+  // sum += old values of a piece.  Called one tail position after the piece was requested and AFTER the next piece's
+  // loads were issued: the compiler's own wait for the piece then counts that next piece as the only younger operations
+  // (it does not see the LDS-DMA of the asm statements), which is what is outstanding behind it in the tail.
+  auto fold_old = [&](auto piece) {
+    constexpr int P = decltype(piece)::value;
+#pragma unroll
+    for (int e = P * PIECE; e < (P + 1) * PIECE && e < NE; ++e) {
+      const int i = e / (16 * FN), j = (e / 16) % FN, r = e % 16;
+      sum[i][j][r] += oldp[P & 1][e - P * PIECE];
+    }
+  };
+  s16x8 fa[DB ? 2 : 1][BK / 16][FM], fb[DB ? 2 : 1][BK / 16][FN];
+  auto read_step = [&](auto pp, int buf) {
+    constexpr int P = decltype(pp)::value;
+    const char* As = lds + buf * BUFB;
+    const char* Bs = SAME ? As : As + OPB;
+    if (!dead && a.dbg != 1) {
+#pragma unroll
+      for (int q = 0; q < BK / 16; ++q) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i) fa[P][q][i] = fragment(As, wm * WSM + i * 32, q * 16);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) fb[P][q][j] = fragment(Bs, wn * WSN + j * 32, q * 16);
+      }
+    }
+  };
+  auto mfma_step = [&](auto pp) {
+    constexpr int P = decltype(pp)::value;
+    if (!dead && a.dbg != 1) {
+#pragma unroll
+      for (int q = 0; q < BK / 16; ++q)
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[P][q][i], fb[P][q][j], acc[i][j], 0, 0, 0);
+    }
+  };
+  int c_kt = 0;
+  auto step_end = [&]() {
+    if (++c_kt == a.nkps) {       // a calibration step is complete: promote its f32 sums
+      c_kt = 0;
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            sum[i][j][r] += (ET)(a.scale * (double)acc[i][j][r]);
+            acc[i][j][r] = 0.f;
+          }
+    }
+  };
+  typedef std::integral_constant<int, 0> P0;
+  typedef std::integral_constant<int, 1> P1;
+  // the old values of E: piece `pos` is requested at tail position pos (the NBUF - 1 iterations that stage nothing, then
+  // the last step), piece pos - 1 is folded into the sums right behind it
+  auto old_values = [&](auto pos_) {
+    constexpr int pos = decltype(pos_)::value;
+    if constexpr (pos < NPIECE) load_old(pos_);
+    if constexpr (pos >= 1 && pos - 1 < NPIECE) fold_old(std::integral_constant<int, pos - 1>{});
+  };
+
+  // (the previous tile's reads of the ring are behind its closing barrier; its stores are older than everything below)
+  if constexpr (DB) {
+#pragma unroll
+    for (int p = 0; p < NBUF; ++p) stage_next(p);
+    wait_vmcnt<(NBUF - 1) * DPS>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    read_step(P0{}, 0);
+    int slot = 0;       // the ring slot of step g
+    // Iteration g: the fragments of step g are in registers (requested last iteration; lgkmcnt(0) before the barrier,
+    // so behind it every wave HAS them and the slot is free), step g + 1 has landed (counted wait: steps g + 2 ..
+    // stay in flight), step g + NBUF is staged into step g's slot, step g + 1 is read into the other register set,
+    // step g is multiplied.
+    auto iteration = [&](auto pp) {
+      constexpr int P = decltype(pp)::value;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      wait_vmcnt<(NBUF - 2) * DPS>();
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      stage_next(slot);
+      slot = slot + 1 == NBUF ? 0 : slot + 1;
+      read_step(std::integral_constant<int, 1 - P>{}, slot);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_step(pp);
+      step_end();
+    };
+    int left = NK - NBUF;      // iterations that still stage a step
+    if (left & 1) {            // an odd count: one iteration, then the sets change places once so that the tail below
+      iteration(P0{});         // always starts from set 0
+#pragma unroll
+      for (int q = 0; q < BK / 16; ++q) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i) fa[0][q][i] = fa[DB ? 1 : 0][q][i];
+#pragma unroll
+        for (int j = 0; j < FN; ++j) fb[0][q][j] = fb[DB ? 1 : 0][q][j];
+      }
+      --left;
+    }
+    for (; left > 0; left -= 2) {
+      iteration(P0{});
+      iteration(P1{});
+    }
+    // tail: NBUF - 1 iterations read a step but stage nothing
+    static_for<0, NBUF - 1>([&](auto tt) {
+      constexpr int t = decltype(tt)::value;
+      constexpr int P = DB ? (t & 1) : 0;
+      // younger than step g + 1's pieces: the staged steps still ahead and the pieces of old values requested so far
+      constexpr int ahead = (NBUF - 2 - t) * DPS + (t < NPIECE ? t : NPIECE) * PIECE;
+      static_assert(ahead <= 63, "vmcnt is a 6-bit counter");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      wait_vmcnt<ahead>();
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      old_values(tt);
+      slot = slot + 1 == NBUF ? 0 : slot + 1;
+      read_step(std::integral_constant<int, DB ? 1 - P : 0>{}, slot);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_step(std::integral_constant<int, P>{});
+      step_end();
+    });
+    old_values(std::integral_constant<int, NBUF - 1>{});
+    mfma_step(std::integral_constant<int, DB ? ((NBUF - 1) & 1) : 0>{});     // the last step
+    step_end();
+  } else {
+    // two waves per SIMD: read and multiply step g in the same iteration; NBUF - 1 steps are staged ahead
+#pragma unroll
+    for (int p = 0; p < NBUF - 1; ++p) stage_next(p);
+    int slot = 0;
+    for (int g = 0; g + NBUF - 1 < NK; ++g) {
+      wait_vmcnt<(NBUF - 2) * DPS>();      // step g has landed; steps g + 1 .. g + NBUF - 2 stay in flight
+      __builtin_amdgcn_s_barrier();        // ... and every wave has multiplied step g - 1: its slot is free
+      asm volatile("" ::: "memory");
+      stage_next(slot == 0 ? NBUF - 1 : slot - 1);
+      read_step(P0{}, slot);
+      mfma_step(P0{});
+      step_end();
+      slot = slot + 1 == NBUF ? 0 : slot + 1;
+    }
+    static_for<0, NBUF - 1>([&](auto tt) {
+      constexpr int t = decltype(tt)::value;
+      constexpr int ahead = (NBUF - 2 - t) * DPS + (t < NPIECE ? t : NPIECE) * PIECE;
+      static_assert(ahead <= 63, "vmcnt is a 6-bit counter");
+      wait_vmcnt<ahead>();
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      old_values(tt);
+      read_step(P0{}, slot);
+      mfma_step(P0{});
+      step_end();
+      slot = slot + 1 == NBUF ? 0 : slot + 1;
+    });
+    old_values(std::integral_constant<int, NBUF - 1>{});
+  }
+  wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();      // every wave is done with the ring: the next tile may stage
+  static_for<0, NPIECE>([&](auto pp) {
+    if constexpr (decltype(pp)::value + 1 > NBUF - 1) fold_old(pp);     // a piece requested at the last tail position
+  });
+  if (dead) return;
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        ET* e = e_ptr(i, j, r);
+        const bool ok = !SAME || (wn * WSN + j * 32 + (lane & 31)) <= (wm * WSM + i * 32 + 4 * (lane >> 5) + (r & 3) + 8 * (r >> 2));
+        if (ok) *e = sum[i][j][r];
+      }
+}
+
+template <int EPI, int TS, int NBUF, int NW>
+__global__ __launch_bounds__(NW * 64, 1) void syrk_bf16_ring_kernel(const SyrkRingArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char ring_lds[];
+  const int nbig = a.nlower, nt = a.tiles_m;
+  for (int item = blockIdx.x; item < a.nitems; item += gridDim.x) {
+    if (item < nbig) {
+      // the walk of syrk_bf16_glds_kernel: groups of 8 tile rows, column by column, a contiguous run per XCD
+      const int q8 = nbig >> 3, r8 = nbig & 7, xcd = item & 7;
+      int rem = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (item >> 3);
+      int G = 0, gr = min(8, nt);
+      for (;;) {
+        const int cnt = gr * 8 * G + gr * (gr - 1) / 2;
+        if (rem < cnt) break;
+        rem -= cnt;
+        ++G;
+        gr = min(8, nt - 8 * G);
+      }
+      int ti, tj;
+      if (rem < gr * 8 * G) {
+        tj = rem / gr;
+        ti = 8 * G + rem % gr;
+      } else {
+        rem -= gr * 8 * G;
+        int c = 0;
+        while (rem >= gr - 1 - c) { rem -= gr - 1 - c; ++c; }
+        tj = 8 * G + c;
+        ti = 8 * G + c + 1 + rem;
+      }
+      syrk_ring_tile<EPI, TS, NBUF, false, NW>(a, ti, tj, ring_lds);
+    } else {
+      const int d = 2 * (item - nbig);
+      syrk_ring_tile<EPI, TS, NBUF, true, NW>(a, d, d, ring_lds);
+      if (d + 1 < nt) syrk_ring_tile<EPI, TS, NBUF, true, NW>(a, d + 1, d + 1, ring_lds);
+    }
   }
 }
 
@@ -2344,8 +2709,10 @@ int gemm_bf16_batched(const unsigned short* A, int64_t sam, int64_t sak, int64_t
   return PTD_OK;
 }
 
-int syrk_bf16(const unsigned short* Y, int64_t T, int64_t n, int64_t ldy, void* E, int64_t ldE, bool e_f64,
-              double scale, hipStream_t st) {
+// single-step product on the round-2 kernels: the LDS-DMA kernel from 192 to 2080 tiles, the register-staged
+// generic kernel otherwise (few tiles: split K with atomics) and for the ragged last rows of T
+static int syrk_bf16_single(const unsigned short* Y, int64_t T, int64_t n, int64_t ldy, void* E, int64_t ldE, bool e_f64,
+                            double scale, bool allow_glds, hipStream_t st) {
   if (n == 0 || T == 0) return PTD_OK;
   GemmBf16Args a{};
   a.A = Y; a.sam = 1; a.sak = ldy;
@@ -2361,7 +2728,7 @@ int syrk_bf16(const unsigned short* Y, int64_t T, int64_t n, int64_t ldy, void* 
   // The LDS-DMA kernel where it was measured faster than the register-staged one (T = 4096: n = 4096 0.121 vs 0.144 ms,
   // T = 16384 0.387 vs 0.469 ms); with few tiles (split K, n = 2048: 0.080 vs 0.074 ms) or many rounds (n = 14336:
   // 1.32 vs 1.28 ms) the generic kernel is as fast or faster.
-  const bool glds = !no_glds && n % BM == 0 && T >= BK && aligned16(Y) && ldy % 8 == 0 && tiles >= 192 && tiles <= 2080;
+  const bool glds = allow_glds && !no_glds && n % BM == 0 && T >= BK && aligned16(Y) && ldy % 8 == 0 && tiles >= 192 && tiles <= 2080;
   // rows of Y handled by this launch: the LDS-DMA kernel takes whole K steps, the generic kernel the rest
   const int64_t T_main = glds ? T - T % BK : T;
   int ksplit = 1;
@@ -2394,6 +2761,91 @@ int syrk_bf16(const unsigned short* Y, int64_t T, int64_t n, int64_t ldy, void* 
   else hipLaunchKernelGGL((gemm_bf16_kernel<false, false, EPI_ACC_F32>), grid, dim3(256), 0, st, a);
   PTD_CHECK_LAUNCH("syrk_bf16");
   return PTD_OK;
+}
+
+static int device_cu_count() {
+  static int cus[16] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;
+  if (cus[dev] == 0) {
+    int c = 0;
+    cus[dev] = (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && c > 0) ? c : 256;
+  }
+  return cus[dev];
+}
+
+template <int EPI, int TS, int NBUF, int NW>
+static int launch_syrk_ring(const SyrkRingArgs& r, int grid, hipStream_t st) {
+  constexpr int LDS = NBUF * 2 * BK * TS * 2;
+  PTD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(syrk_bf16_ring_kernel<EPI, TS, NBUF, NW>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+  hipLaunchKernelGGL((syrk_bf16_ring_kernel<EPI, TS, NBUF, NW>), dim3((unsigned)grid), dim3(NW * 64), LDS, st, r);
+  PTD_CHECK_LAUNCH("syrk_bf16 (ring)");
+  return PTD_OK;
+}
+
+// E (lower triangle) += scale * sum_s Ys[s]^T Ys[s]: the covariance sum of `steps` calibration steps in one pass over E
+// (ptd_syrk_accumulate_multi; ptd_syrk_accumulate is steps = 1).  Ys is a HOST array of device pointers.
+int syrk_bf16_multi(const unsigned short* const* Ys, int steps, int64_t T, int64_t n, int64_t ldy, void* E, int64_t ldE,
+                    bool e_f64, double scale, hipStream_t st) {
+  if (n == 0 || T == 0 || steps == 0) return PTD_OK;
+  static const bool no_ring = getenv("PTD_SYRK_RING") && atoi(getenv("PTD_SYRK_RING")) == 0;
+  bool aligned = ldy % 8 == 0;
+  for (int s = 0; s < steps; ++s) aligned = aligned && aligned16(Ys[s]);
+  const int64_t nkps = T / BK;
+  int ts = 0;
+  if (!no_ring && aligned && nkps >= 1) {
+    const int64_t t128 = n / 128, t64 = n / 64;
+    if (n % 128 == 0 && t128 * (t128 - 1) / 2 + (t128 + 1) / 2 >= 192 && nkps * std::min(steps, 8) >= 4) ts = 128;
+    else if (n % 64 == 0 && t64 * (t64 - 1) / 2 + (t64 + 1) / 2 >= 96 && nkps * std::min(steps, 8) >= 8) ts = 64;
+  }
+  if (ts == 0) {
+    for (int s = 0; s < steps; ++s) {
+      const int rc = syrk_bf16_single(Ys[s], T, n, ldy, E, ldE, e_f64, scale, true, st);
+      if (rc != PTD_OK) return rc;
+    }
+    return PTD_OK;
+  }
+  const int cus = device_cu_count();
+  for (int s0 = 0; s0 < steps; s0 += 8) {
+    SyrkRingArgs r{};
+    r.steps = std::min(8, steps - s0);
+    // (a last chunk too short to fill the ring joins the generic path below)
+    if (nkps * r.steps < (ts == 128 ? 4 : 8)) {
+      for (int s = s0; s < steps; ++s) {
+        const int rc = syrk_bf16_single(Ys[s], T - T % BK, n, ldy, E, ldE, e_f64, scale, true, st);
+        if (rc != PTD_OK) return rc;
+      }
+      break;
+    }
+    for (int s = 0; s < 8; ++s) r.y[s] = Ys[s0 + std::min(s, r.steps - 1)];
+    r.nkps = (int)nkps;
+    r.ld = ldy;
+    r.E = E;
+    r.ldE = ldE;
+    r.scale = scale;
+    r.tiles_m = (int)(n / ts);
+    r.nlower = r.tiles_m * (r.tiles_m - 1) / 2;
+    r.nitems = r.nlower + (r.tiles_m + 1) / 2;
+    r.dbg = getenv("PTD_SYRK_RING_DBG") ? atoi(getenv("PTD_SYRK_RING_DBG")) : 0;
+    const int grid = std::min(r.nitems, cus);
+    int rc;
+    if (ts == 128) rc = e_f64 ? launch_syrk_ring<EPI_ACC_F64, 128, 4, 8>(r, grid, st) : launch_syrk_ring<EPI_ACC_F32, 128, 4, 8>(r, grid, st);
+    else rc = e_f64 ? launch_syrk_ring<EPI_ACC_F64, 64, 8, 4>(r, grid, st) : launch_syrk_ring<EPI_ACC_F32, 64, 8, 4>(r, grid, st);
+    if (rc != PTD_OK) return rc;
+  }
+  if (T % BK) {     // the ragged last rows of every step: the register-staged kernel
+    for (int s = 0; s < steps; ++s) {
+      const int rc = syrk_bf16_single(Ys[s] + (T - T % BK) * ldy, T % BK, n, ldy, E, ldE, e_f64, scale, false, st);
+      if (rc != PTD_OK) return rc;
+    }
+  }
+  return PTD_OK;
+}
+
+int syrk_bf16(const unsigned short* Y, int64_t T, int64_t n, int64_t ldy, void* E, int64_t ldE, bool e_f64,
+              double scale, hipStream_t st) {
+  return syrk_bf16_multi(&Y, 1, T, n, ldy, E, ldE, e_f64, scale, st);
 }
 
 }  // namespace ptd

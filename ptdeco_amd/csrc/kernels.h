@@ -27,6 +27,8 @@ int gemm_bf16_batched(const unsigned short* A, int64_t sam, int64_t sak, int64_t
                       hipStream_t st);
 int syrk_bf16(const unsigned short* Y, int64_t T, int64_t n, int64_t ldy, void* E, int64_t ldE, bool e_f64,
               double scale, hipStream_t st);
+int syrk_bf16_multi(const unsigned short* const* Ys, int steps, int64_t T, int64_t n, int64_t ldy, void* E, int64_t ldE,
+                    bool e_f64, double scale, hipStream_t st);
 
 // eigh_jacobi.hip
 size_t eigh_workspace_bytes(int64_t n);

@@ -324,6 +324,7 @@ def _process_module(*, root_module, decomposed_submodule_name, data_iterator, lo
                 shard.all_reduce_small(sums)
         with eng.phase("D_metrics"):
             table = (sums / num_metric_steps).tolist()  # the one host sync of the rank search
+        eng.warn_if_not_finite([row[0] for row in table], name)
 
         rank_best, nsr_best, ppl_deco_best = full_rank, 0.0, 0.0
         for i, ((rank_new, drop), (nsr_new, ppl_deco_new, ppl_diff_new)) in enumerate(zip(candidates, table), 1):

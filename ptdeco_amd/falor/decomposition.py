@@ -138,6 +138,7 @@ def _process_module(*, root_module, decomposed_submodule_name, data_iterator, ns
                     acc += _compute_metrics(x=next(data_iterator).to(device), root_module=root_module, tap=tap,
                                             orig_weight=orig_weight, candidate=candidate)
                 nsr_new, kl_new = (acc / num_metric_steps).tolist()
+                eng.warn_if_not_finite([nsr_new], decomposed_submodule_name)
             accepted = nsr_new < nsr_final_threshold and kl_new < kl_final_threshold
             if accepted:
                 rank_best, nsr_best, kl_best = rank_new, nsr_new, kl_new

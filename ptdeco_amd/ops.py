@@ -64,6 +64,31 @@ def syrk_accumulate(E: torch.Tensor, y: torch.Tensor, scale: float) -> None:
     _hip.check(rc, "ptd_syrk_accumulate")
 
 
+def syrk_accumulate_multi(E: torch.Tensor, ys, scale: float) -> None:
+    """E[i, j] += sum_s scale * (ys[s]^T ys[s])[i, j] for i >= j: the covariance sums of several calibration steps in
+    one pass over the accumulator (ptd_syrk_accumulate_multi).  The matrices share shape, dtype and row pitch; those
+    that do not are added one by one."""
+    ys = [_rows2d(y) for y in ys]
+    if not ys:
+        return
+    _dev(E, *ys)
+    n = ys[0].shape[1]
+    assert E.shape == (n, n) and E.stride(1) == 1
+    first = ys[0]
+    same = all(y.shape == first.shape and y.dtype == first.dtype and y.stride() == first.stride() for y in ys)
+    if not same or len(ys) == 1:
+        for y in ys:
+            syrk_accumulate(E, y, scale)
+        return
+    import ctypes
+
+    ptrs = (ctypes.c_void_p * len(ys))(*[y.data_ptr() for y in ys])
+    with torch.cuda.device(E.device):
+        rc = _hip.load().ptd_syrk_accumulate_multi(ptrs, len(ys), first.shape[0], n, first.stride(0), _code(first),
+                                                   E.data_ptr(), E.stride(0), _code(E), float(scale), _stream(E))
+    _hip.check(rc, "ptd_syrk_accumulate_multi")
+
+
 def colsum_accumulate(ey: torch.Tensor, y: torch.Tensor, scale: float) -> None:
     _dev(ey, y)
     y = _rows2d(y)
@@ -315,8 +340,20 @@ def nsr(x: torch.Tensor, y: torch.Tensor, channels: int, eps: float = 1e-3) -> t
     with torch.cuda.device(x.device):
         rc = lib.ptd_nsr(x.data_ptr(), y.data_ptr(), R, C, _code(x), float(eps), out.data_ptr(), ws.data_ptr(),
                          ws.numel(), _stream(x))
+    if rc != 0:
+        #  a launch that failed midway may have left the workspace's ticket non-zero: every later call on this
+        # stream would then return the NaN the partial kernel presets -- drop the cached workspaces, the next call
+        # initialises a fresh one
+        _NSR_WS.clear()
     _hip.check(rc, "ptd_nsr")
     return out[0]
+
+
+def drop_cached_workspaces() -> None:
+    """Forget the per-(device, stream) ptd_nsr workspaces (they are re-made and re-initialised on the next call).  The
+    drivers call this when a metric comes back non-finite: a kernel that was aborted between its partial and its final
+    launch leaves the workspace's ticket non-zero, and every later ptd_nsr on that stream would return NaN."""
+    _NSR_WS.clear()
 
 
 def sym_kl(s: torch.Tensor, t: torch.Tensor) -> torch.Tensor:

@@ -603,6 +603,161 @@ def test_prefix_memo_takes_a_subtree_only_if_it_is_a_function_of_its_arguments()
         tap.close()
 
 
+class _SideEffectBlock(torch.nn.Module):
+    """A block whose forward is NOT a function of its arguments, in ways the round-4 purity test did not see."""
+
+    def __init__(self, kind):
+        super().__init__()
+        self.kind = kind
+        self.flavour = "plain"
+        self.fc = torch.nn.Linear(16, 16)
+        self.seen = []                   # mutated in place: the attribute binding never changes
+        self.calls = {"n": 0}
+
+    def forward(self, x):
+        import random
+        if self.kind == "list_append":
+            self.seen.append(x.shape[0])
+        elif self.kind == "dict_update":
+            self.calls["n"] += 1
+        elif self.kind == "python_rng":
+            x = x * (1.0 + 1e-3 * random.random())
+        elif self.kind == "torch_rng":
+            x = x + 1e-3 * torch.rand(())
+        return x + self.fc(x)
+
+
+@pytest.mark.parametrize("kind", ["list_append", "dict_update", "python_rng", "torch_rng"])
+def test_prefix_memo_treats_mutated_containers_and_random_generators_as_impure(kind):
+    """a subtree that appends to a list attribute, updates a dict attribute in place or draws from a
+    global random generator is not a function of its arguments: it is never handed back whole (its Linear still is), its
+    side effects happen in both forwards, and the values are what two plain forwards give."""
+    import random
+    from ptdeco_amd import _engine as eng
+
+    model = _MemoStack().eval()
+    model.blocks[1] = _SideEffectBlock(kind).eval()
+    x = torch.randn(6, 8)
+    with torch.no_grad():
+        tap = eng.LayerTap(model, "blocks.3.fc2")
+        tap.memo = eng.PrefixMemo(model, tap.layer, 1 << 30)
+        random.seed(5); torch.manual_seed(5)
+        got = [eng.forward_pair(model, tap, x, lambda: None, lambda: None) for _ in range(3)]
+        units = tap.memo.unit_hits
+        tap.close()
+        random.seed(5); torch.manual_seed(5)
+        model.blocks[1].seen.clear(); model.blocks[1].calls["n"] = 0
+        want = [(model(x), model(x)) for _ in range(3)]
+    for (a1, a2), (b1, b2) in zip(got, want):
+        assert torch.equal(a1, b1) and torch.equal(a2, b2)
+    # a block with side effects only never comes back whole, blocks 0 and 2 do; behind a block that draws random numbers
+    # nothing is kept at all (block 2 sees other values in the second forward)
+    assert units == (3 * 2 if kind in ("list_append", "dict_update") else 3 * 1)
+    if kind == "list_append":
+        assert len(model.blocks[1].seen) == 6
+    if kind == "dict_update":
+        assert model.blocks[1].calls["n"] == 6
+
+
+def test_prefix_memo_checks_itself_on_the_first_metric_step_and_switches_off(caplog):
+    """A block that reads state OUTSIDE the module tree (a module-level counter here) passes every purity test.  The
+    first metric step of a layer recomputes what it is about to hand back: the difference is found, the recomputed value
+    is used (the result is what two plain forwards give), one WARNING is logged and the memo is off for this model --
+    for this layer's later steps and for the memos of its other layers."""
+    import logging
+    from ptdeco_amd import _engine as eng
+
+    ticks = [0]
+
+    class Sneaky(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.flavour = "plain"
+            self.fc = torch.nn.Linear(16, 16)
+
+        def forward(self, x):
+            ticks[0] += 1
+            return x + self.fc(x) * (1.0 + 0.01 * ticks[0])
+
+    model = _MemoStack().eval()
+    model.blocks[1] = Sneaky().eval()
+    x = torch.randn(6, 8)
+    eng.PrefixMemo.level.pop(id(model), None)
+    with torch.no_grad(), caplog.at_level(logging.WARNING, logger="ptdeco_amd._engine"):
+        tap = eng.LayerTap(model, "blocks.3.fc2")
+        tap.memo = eng.PrefixMemo(model, tap.layer, 1 << 30, self_check=True)
+        got = [eng.forward_pair(model, tap, x, lambda: None, lambda: None) for _ in range(3)]
+        assert eng.PrefixMemo.level[id(model)] == 2 and tap.memo.disabled
+        hits = tap.memo.hits
+        tap.close()
+        ticks[0] = 0
+        want = [(model(x), model(x)) for _ in range(3)]
+        for (a1, a2), (b1, b2) in zip(got, want):
+            assert torch.equal(a1, b1) and torch.equal(a2, b2)
+        assert hits == 2          # embed and block 0, handed back in the first step before the difference showed
+        assert sum("does not compute the same values" in r.message for r in caplog.records) == 1
+        # the next layer's memo is off from the start
+        tap = eng.LayerTap(model, "blocks.2.fc2")
+        tap.memo = eng.PrefixMemo(model, tap.layer, 1 << 30, self_check=True)
+        eng.forward_pair(model, tap, x, lambda: None, lambda: None)
+        assert tap.memo.hits == 0 and tap.memo.disabled
+        tap.close()
+    eng.PrefixMemo.level.pop(id(model), None)
+    # a model that IS a function of its input passes the self-check and keeps its subtree units
+    model = _MemoStack().eval()
+    with torch.no_grad():
+        want = model(x)
+        tap = eng.LayerTap(model, "blocks.3.fc2")
+        tap.memo = eng.PrefixMemo(model, tap.layer, 1 << 30, self_check=True)
+        for step in range(2):
+            y1, y2 = eng.forward_pair(model, tap, x, lambda: None, lambda: None)
+            assert torch.equal(y1, want) and torch.equal(y2, want)
+        assert tap.memo.unit_hits == 2 * 3 and id(model) not in eng.PrefixMemo.level
+        tap.close()
+
+
+def test_prefix_memo_with_a_weight_tied_layer_inside_and_behind_a_replayed_subtree():
+    """a Linear that is called once INSIDE a subtree that comes back whole and twice more directly ahead of
+    the analysed layer.  Keyed by a per-module call index, the replay (which skips the call inside the subtree) handed
+    the second direct call the first one's output.  Keys are positions in the forward now."""
+    from ptdeco_amd import _engine as eng
+
+    class Inner(torch.nn.Module):
+        def __init__(self, shared):
+            super().__init__()
+            self.shared = shared
+            self.own = torch.nn.Linear(16, 16)
+
+        def forward(self, x):
+            return self.own(torch.relu(self.shared(x)))
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            torch.manual_seed(3)
+            self.block = Inner(torch.nn.Linear(16, 16))      # (registered first: the block qualifies as a unit)
+            self.shared = self.block.shared
+            self.tapped = torch.nn.Linear(16, 16)
+
+        def forward(self, x):
+            h = self.block(x)
+            h = self.shared(h)                  # the shared layer's second call in the forward
+            h = self.shared(torch.tanh(h))      # ... and third
+            return self.tapped(h)
+
+    model = Net().eval()
+    x = torch.randn(5, 16)
+    with torch.no_grad():
+        want = model(x)
+        tap = eng.LayerTap(model, "tapped")
+        tap.memo = eng.PrefixMemo(model, tap.layer, 1 << 30)
+        for _ in range(3):
+            y1, y2 = eng.forward_pair(model, tap, x, lambda: None, lambda: None)
+            assert torch.equal(y1, want) and torch.equal(y2, want)
+        assert tap.memo.unit_hits == 3 and tap.memo.hits == 3 * 3
+        tap.close()
+
+
 def test_prefix_memo_leaves_subtrees_in_training_mode_alone():
     from ptdeco_amd import _engine as eng
 
@@ -751,3 +906,39 @@ def test_calibration_forwards_stop_at_the_analysed_layer_after_the_first_one(mon
             tap.calibration_forward(twice, x)
         assert len(seen) == 3 and tap.calls == 2       # every forward ran to the end
         tap.close()
+
+    #  every 8th forward runs whole again and re-counts the calls: a layer that is called once on most
+    # batches and twice on some keeps whole forwards from the moment that is seen; and a hook on a module AROUND the
+    # layer (its post-forward work would be skipped by the unwinding) keeps every forward whole
+    class Sometimes(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = torch.nn.Linear(8, 8)
+            self.head = torch.nn.Linear(8, 2)
+            self.n = 0
+
+        def forward(self, x):
+            self.n += 1
+            h = self.a(x)
+            if self.n >= 8:
+                h = self.a(h)
+            return self.head(h)
+
+    model = Sometimes().eval()
+    ends = []
+    model.head.register_forward_hook(lambda m, a, o: ends.append(model.n))
+    with torch.no_grad():
+        tap = eng.LayerTap(model, "a")
+        for _ in range(12):
+            tap.calibration_forward(model, x)
+        tap.close()
+    assert ends == [1, 8, 9, 10, 11, 12]      # forwards 2 .. 7 stopped at the layer; the 8th ran whole and saw two calls
+    wrapped = _MemoStack().eval()
+    done = []
+    wrapped.blocks[1].register_forward_hook(lambda m, a, o: done.append(1))
+    with torch.no_grad():
+        tap = eng.LayerTap(wrapped, "blocks.1.fc2")
+        for _ in range(3):
+            tap.calibration_forward(wrapped, x)
+        tap.close()
+    assert len(done) == 3

@@ -70,6 +70,72 @@ def test_syrk_bf16_lds_dma_kernel_is_exact_on_small_integers(ops, T, n, ld, edt)
     assert torch.equal(torch.triu(e, 1), torch.full_like(e, 5.0).triu(1))
 
 
+@pytest.mark.parametrize("T,n,ld,steps", [
+    (192, 4096, 4096, 1),      # TS = 128 ring at its shortest (3 K steps), 512 items = two per CU
+    (2048, 4096, 4096, 1),     # the calibration shape of a Llama q / o layer
+    (2048, 1024, 1024, 1),     # TS = 64 ring (k / v): 128 items
+    (448, 2048, 2056, 1),      # TS = 64 ring at its shortest (7 K steps), padded row pitch, 512 items
+    (333, 2560, 2568, 3),      # TS = 128, 200 items (fewer than CUs), ragged rows through the generic kernel, 3 steps
+    (128, 4096, 4096, 8),      # 8 steps of 2 K steps each in one launch
+    (64, 4224, 4224, 11),      # 11 steps: one launch of 8 and one of 3 (3 K steps: the shortest ring)
+    (64, 1088, 1088, 9),       # TS = 64: a launch of 8 steps and a last step too short for the ring (generic kernel)
+    (576, 4160, 4160, 2),      # n a multiple of 64 only -> TS = 64, 2113 items over 256 workgroups
+    (256, 14336, 14336, 2),    # 112 tile rows: 6272 items
+])
+@pytest.mark.parametrize("edt", [torch.float64, torch.float32])
+def test_syrk_bf16_ring_kernel_and_multi_step_entry_are_exact_on_small_integers(ops, T, n, ld, steps, edt):
+    """Round 5: the persistent ring kernel behind ptd_syrk_accumulate / ptd_syrk_accumulate_multi (bf16 activations):
+    both tile sizes, both accumulator dtypes, the strictly-lower walk and the diagonal pairs, an odd number of tile
+    rows (a diagonal tile without a partner), grids below and far above the CU count, the step boundaries inside one
+    K loop, chunks of 8 steps, the shortest K ranges the ring accepts, ragged rows.  Entries in -2 .. 2 keep every sum
+    an integer below 2^24: E must equal the integer result exactly, and the strict upper triangle must stay untouched."""
+    if n > 8192 and edt == torch.float32:
+        pytest.skip("one accumulator dtype is enough at 14336")
+    g = torch.Generator().manual_seed(T * 7 + n + steps)
+    bigs = [torch.randint(-2, 3, (T, ld), generator=g).to(torch.bfloat16).to(DEV) for _ in range(steps)]
+    ys = [b[:, :n] for b in bigs]
+    e = torch.full((n, n), 5.0, dtype=edt, device=DEV)
+    if steps == 1:
+        ops.syrk_accumulate(e, ys[0], 2.0)
+    else:
+        ops.syrk_accumulate_multi(e, ys, 2.0)
+    ref = torch.full((n, n), 5.0, dtype=torch.float64, device=DEV)
+    for y in ys:
+        yi = y.to(torch.float64)
+        ref += 2.0 * (yi.T @ yi)
+    assert torch.equal(torch.tril(e.double()), torch.tril(ref))
+    assert torch.equal(torch.triu(e, 1), torch.full_like(e, 5.0).triu(1))
+
+
+def test_syrk_multi_step_entry_equals_the_sum_of_single_steps(ops):
+    """ptd_syrk_accumulate_multi on real-valued activations against D calls of ptd_syrk_accumulate: the f32 products are
+    the same, only the f64 additions associate differently (E + (d1 + d2 + ..) instead of ((E + d1) + d2) + ..):
+    agreement to a few ulps of the f64 sums; f32 activations go step by step and agree exactly."""
+    n, T, D = 2560, 512, 5
+    g = torch.Generator().manual_seed(3)
+    ys = [(torch.randn(T, n, generator=g) * torch.logspace(0, -2, n)).to(torch.bfloat16).to(DEV) for _ in range(D)]
+    e0 = torch.randn(n, n, generator=g, dtype=torch.float64).to(DEV)
+    a, b = e0.clone(), e0.clone()
+    ops.syrk_accumulate_multi(a, ys, 1.0 / T)
+    for y in ys:
+        ops.syrk_accumulate(b, y, 1.0 / T)
+    assert (torch.tril(a) - torch.tril(b)).abs().max().item() <= 1e-14 * b.abs().max().item()
+    assert torch.equal(torch.triu(a, 1), torch.triu(e0, 1))
+    ys32 = [y.float() for y in ys]
+    a, b = e0.clone(), e0.clone()
+    ops.syrk_accumulate_multi(a, ys32, 1.0 / T)
+    for y in ys32:
+        ops.syrk_accumulate(b, y, 1.0 / T)
+    assert torch.equal(a, b)
+    # matrices of different shapes are added one by one
+    c = e0.clone()
+    ops.syrk_accumulate_multi(c, [ys[0], ys[1][:256]], 0.5)
+    d = e0.clone()
+    ops.syrk_accumulate(d, ys[0], 0.5)
+    ops.syrk_accumulate(d, ys[1][:256], 0.5)
+    assert torch.equal(c, d)
+
+
 def test_syrk_matches_oracle_product_in_activation_dtype(ops):
     """dwain.py:152: the oracle forms y^T y / T in y's dtype (f32) then adds into f64."""
     z = gio.npz("prim")
