@@ -32,7 +32,7 @@ extern "C" {
 #endif
 
 #define PTD_ABI_VERSION 3   /* 2: ptd_nsr workspaces are initialised once (ptd_nsr_workspace_init); ptd_chol_inverse
-                             * 3: ptd_stream_pair_wall_us, ptd_syrk_accumulate_multi */
+                             * 3: ptd_stream_pair_wall_us, ptd_streams_wall_us, ptd_syrk_accumulate_multi */
 
 typedef enum { PTD_F32 = 0, PTD_F64 = 1, PTD_BF16 = 2 } ptd_dtype;
 
@@ -67,6 +67,11 @@ int ptd_set_concurrent_chains(int chains);
  * streams are synchronised before and after.  No reference counterpart (torch.linalg.eigh calls are serial,
  * dwain.py:155-163); used by ptdeco_amd._engine.chain_streams to pick the streams of concurrent eigendecompositions. */
 int ptd_stream_pair_wall_us(void* stream_a, void* stream_b, int spin_us, double* wall_us);
+/* The same for `count` streams at once (a HOST array of hipStream_t): one kernel of `spin_us` on each; about spin_us when
+ * all of them ran side by side, a multiple when some were serialised.  run_concurrently re-checks its streams with it at
+ * every call (0.2 ms): which streams share a hardware queue was seen to CHANGE within a process (bench.py: four streams
+ * verified distinct early on, two of them serialised a minute later). */
+int ptd_streams_wall_us(void* const* streams, int count, int spin_us, double* wall_us);
 
 /* ---- covariance accumulation ------------------------------------------- */
 

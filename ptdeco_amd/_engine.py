@@ -1127,11 +1127,25 @@ def chain_streams(device: torch.device, want: int) -> list:
         return [torch.cuda.Stream(device=device) for _ in range(want)]
     with _CHAIN_STREAMS_LOCK:
         have, exhausted = _CHAIN_STREAMS.get(index, ([], False))
-        if len(have) >= want or exhausted:
-            return list(have[:want])
         lib = _hip.load()
         spin_us = 150
         wall = ctypes.c_double(0.0)
+        if have and (len(have) >= want or exhausted):
+            # Re-check the kept streams, all at once (one 150-us kernel on each: 0.2 ms): the mapping of streams onto
+            # hardware queues was seen to change within a process -- bench.py: four streams verified distinct at the first
+            # call, two of them serialised a minute later (B_eigh 243 instead of 187 ms, one chain ending at 390 ms) --
+            # so a verdict is only good for the call it was measured in.
+            group = have[:want]
+            arr = (ctypes.c_void_p * len(group))(*[h.cuda_stream for h in group])
+            with torch.cuda.device(device):
+                _hip.check(lib.ptd_streams_wall_us(arr, len(group), spin_us, ctypes.byref(wall)), "ptd_streams_wall_us")
+            if wall.value < 1.6 * spin_us:
+                return list(group)
+            import logging
+
+            logging.getLogger(__name__).info("cuda:%d: the kept streams no longer overlap (%.0f us for %d x %d us): "
+                                             "choosing again", index, wall.value, len(group), spin_us)
+            have, exhausted = [], False
 
         def overlap(a, b) -> bool:
             _hip.check(lib.ptd_stream_pair_wall_us(a.cuda_stream, b.cuda_stream, spin_us, ctypes.byref(wall)),
@@ -1140,8 +1154,12 @@ def chain_streams(device: torch.device, want: int) -> list:
 
         with torch.cuda.device(device):
             tried = 0
-            for priority in (-1, 0):
-                for _ in range(8):
+            # (normal priority only.  The high-priority pool has four hardware queues of its own, but chains on
+            # high-priority streams were measured SLOWER inside bench.py's process -- B_eigh 243 ms against 187 -- although
+            # the streams passed this very test; on normal-priority streams the test's verdict held)
+            prios = [int(p_) for p_ in os.environ.get("PTD_CHAIN_STREAM_PRIORITIES", "0").split(",")]
+            for priority in prios:
+                for _ in range(16):
                     if len(have) >= want:
                         break
                     cand = torch.cuda.Stream(device=device, priority=priority)

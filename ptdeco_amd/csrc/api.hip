@@ -37,20 +37,23 @@ const char* ptd_last_error(void) { return g_err; }
 
 int ptd_set_concurrent_chains(int chains) { return concurrent_chains_exchange(chains < 1 ? 1 : chains); }
 
-int ptd_stream_pair_wall_us(void* stream_a, void* stream_b, int spin_us, double* wall_us) {
-  PTD_REQUIRE(wall_us && spin_us >= 1 && spin_us <= 100000, "ptd_stream_pair_wall_us: bad argument");
-  hipStream_t a = static_cast<hipStream_t>(stream_a), b = static_cast<hipStream_t>(stream_b);
-  PTD_CHECK_HIP(hipStreamSynchronize(a));
-  PTD_CHECK_HIP(hipStreamSynchronize(b));
+int ptd_streams_wall_us(void* const* streams, int count, int spin_us, double* wall_us) {
+  PTD_REQUIRE(streams && wall_us && count >= 1 && count <= 64 && spin_us >= 1 && spin_us <= 100000,
+              "ptd_streams_wall_us: bad argument");
+  for (int i = 0; i < count; ++i) PTD_CHECK_HIP(hipStreamSynchronize(static_cast<hipStream_t>(streams[i])));
   const long long ticks = (long long)spin_us * 100;
   const auto t0 = std::chrono::steady_clock::now();
-  hipLaunchKernelGGL(stream_spin_kernel, dim3(1), dim3(64), 0, a, ticks);
-  hipLaunchKernelGGL(stream_spin_kernel, dim3(1), dim3(64), 0, b, ticks);
-  PTD_CHECK_HIP(hipStreamSynchronize(a));
-  PTD_CHECK_HIP(hipStreamSynchronize(b));
+  for (int i = 0; i < count; ++i)
+    hipLaunchKernelGGL(stream_spin_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(streams[i]), ticks);
+  for (int i = 0; i < count; ++i) PTD_CHECK_HIP(hipStreamSynchronize(static_cast<hipStream_t>(streams[i])));
   *wall_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
-  PTD_CHECK_LAUNCH("ptd_stream_pair_wall_us");
+  PTD_CHECK_LAUNCH("ptd_streams_wall_us");
   return PTD_OK;
+}
+
+int ptd_stream_pair_wall_us(void* stream_a, void* stream_b, int spin_us, double* wall_us) {
+  void* pair[2] = {stream_a, stream_b};
+  return ptd_streams_wall_us(pair, 2, spin_us, wall_us);
 }
 
 int ptd_syrk_accumulate(const void* y, int64_t T, int64_t n, int64_t ldy, int y_dtype, void* E, int64_t ldE,

@@ -796,12 +796,20 @@ static void note_outcome(int64_t n, int64_t k, bool late_decline) {
   }
 }
 
+// The widest block the route accepts at order n: n / 2 (the subspace must stay well below the matrix order);
+// PTD_EIGH_FILTER_BLOCK_EIGHTHS=5 admits 5 n / 8 -- k = n / 2 with a quarter more: 2560 of 4096 -- (experiments)
+static int64_t filter_max_block(int64_t n) {
+  const char* e = getenv("PTD_EIGH_FILTER_BLOCK_EIGHTHS");
+  const int eighths = e ? std::min(6, std::max(1, atoi(e))) : 4;
+  return n * eighths / 8;
+}
+
 bool eigh_filtered_applies(int64_t n, int64_t k, bool all_values) {
   const char* e = getenv("PTD_EIGH_FILTERED");
   const int mode = e ? atoi(e) : 1;       // 0 off, 1 auto, 2 whenever the shapes allow (tests)
   if (mode == 0 || all_values) return false;
   if (n % 128 != 0 || k < 32) return false;
-  if (filter_block(n, k) > n / 2) return false;           // the subspace must stay well below the matrix order
+  if (filter_block(n, k) > filter_max_block(n)) return false;
   if (mode >= 2) return n >= 512;
   // up to 2/7 of the spectrum: at k = n / 3 (n = 4096: a block of 1728 columns, 27 ms of filter rounds, a 14-ms
   // Rayleigh-Ritz problem and, on covariance spectra, a second attempt) the route took 68 ms against 58 ms direct
@@ -809,7 +817,7 @@ bool eigh_filtered_applies(int64_t n, int64_t k, bool all_values) {
 }
 
 size_t eigh_filtered_workspace_bytes(int64_t n, int64_t k) {
-  if (n % 128 != 0 || n < 512 || k < 32 || filter_block(n, k) > n / 2) return 0;
+  if (n % 128 != 0 || n < 512 || k < 32 || filter_block(n, k) > filter_max_block(n)) return 0;
   return filter_plan(n, k).total;
 }
 
@@ -818,8 +826,8 @@ size_t eigh_filtered_workspace_bytes(int64_t n) {
   // PTD_EIGH_FILTER_OVERSAMPLE included): the plan is monotone in the block size and in k, and no block exceeds n / 2
   if (n % 128 != 0 || n < 512) return 0;
   size_t worst = 0;
-  for (int64_t k = 32; k <= n / 2; k += 32)
-    if (filter_block(n, k) <= n / 2) worst = std::max(worst, filter_plan(n, k).total);
+  for (int64_t k = 32; k <= filter_max_block(n); k += 32)
+    if (filter_block(n, k) <= filter_max_block(n)) worst = std::max(worst, filter_plan(n, k).total);
   return worst;
 }
 

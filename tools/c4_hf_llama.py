@@ -59,6 +59,11 @@ ids = [torch.randint(0, 128256, (1, 2048), generator=g, device=dev) for _ in ran
 with torch.no_grad():
     bt = [{"ids": i, "targets": model({"ids": i}).argmax(-1)} for i in ids]
 torch.cuda.synchronize()
+# sample check (tools/sample_check.py): a few layers of the first precompute split are armed before the run
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import sample_check
+all_names = [n for n, m in model.named_modules() if isinstance(m, torch.nn.Linear) and not n.endswith("lm_head")]
+armed = sample_check.arm(model, all_names[:max(1, len(all_names) // 4)], bt[:8])
 if os.environ.get("PTD_PHASES"):
     eng.PHASES = eng.PhaseTimer()
 trace = []
@@ -86,7 +91,9 @@ if eng.PHASES is not None:
     phases = {k: round(v, 1) for k, v in eng.PHASES.totals_ms().items()}
     phases["other_host_and_gaps"] = round(dt * 1e3 - sum(phases.values()), 1)
 n_layers = 7 * layers
-print(json.dumps({"workload": f"dwain.decompose_in_place, transformers.LlamaForCausalLM (transformers {transformers.__version__}), "
+checked = sample_check.verify(armed, model, cfg)
+print(json.dumps({"sample_check": checked,
+                  "workload": f"dwain.decompose_in_place, transformers.LlamaForCausalLM (transformers {transformers.__version__}), "
                               f"Llama-3-8B architecture at {layers} decoder layers ({n_layers} Linear layers; lm_head 4096 -> 128256 "
                               f"blacklisted), attention = {attn}, random bf16 weights, token batches [1, 2048], D = 8, M = 2, "
                               "precomputing_covariance_num_splits = 4, f64 covariance + eigh, one MI355X",

@@ -4,6 +4,7 @@ calibration [1, 2048, 4096], D = 8, M = 2, precomputing_covariance_num_splits = 
 Usage: python tools/c4_stack.py [blocks] [bf16]"""
 import itertools, json, os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import ptdeco_amd
 
 dev = torch.device("cuda", 0)
@@ -68,6 +69,10 @@ xs = [torch.randn(1, 2048, D, generator=g, device=dev).to(dtype) for _ in range(
 with torch.no_grad():
     bt = [{"x": x, "targets": model({"x": x}).argmax(-1)} for x in xs]
 torch.cuda.synchronize()
+# sample check (tools/sample_check.py): a few layers of the first precompute split are armed before the run
+import sample_check
+all_names = [n for n, m in model.named_modules() if isinstance(m, torch.nn.Linear) and n != "head"]
+armed = sample_check.arm(model, all_names[:max(1, len(all_names) // 4)], bt[:8])
 trace = []
 from ptdeco_amd import _engine as eng
 if os.environ.get("PTD_PHASES"):
@@ -93,7 +98,9 @@ if eng.PHASES is not None:
     phases = {k: round(v, 1) for k, v in eng.PHASES.totals_ms().items()}
     phases["other_host_and_gaps"] = round(dt * 1e3 - sum(phases.values()), 1)
 layers = 7 * blocks
-print(json.dumps({"workload": f"dwain.decompose_in_place, Llama-3-8B-shaped stack, {blocks} blocks x (q, k, v, o, gate, up, down) at "
+checked = sample_check.verify(armed, model, cfg)
+print(json.dumps({"sample_check": checked,
+                  "workload": f"dwain.decompose_in_place, Llama-3-8B-shaped stack, {blocks} blocks x (q, k, v, o, gate, up, down) at "
                               "4096 / 1024 / 14336 + blacklisted head, [1, 2048, 4096] calibration batches, D = 8, M = 2, "
                               "precomputing_covariance_num_splits = 4, f64 covariance + eigh, one MI355X",
                   "phases_ms": phases, "blocks": blocks, "dtype": str(dtype), "layers": layers, "seconds": dt, "layers_per_s": layers / dt,
