@@ -201,11 +201,11 @@ def kernel_lines(device):
     return lines
 
 
-def decomposed_forward_lines(device):
-    """BASELINE configs[4]: rank-r two-GEMM forward vs dense 4096x4096, bf16, T = 16384 rows."""
+def decomposed_forward_lines(device, t_rows=16384, full=True):
+    """BASELINE configs[4]: rank-r two-GEMM forward vs dense 4096x4096, bf16, T = t_rows rows (4096, 16384,
+    65536).  full=False: the package's pair, the library pair and the dense layer on one resident input only."""
     from ptdeco_amd import ops
 
-    t_rows = 16384
     g = torch.Generator().manual_seed(5)
     x = torch.randn(t_rows, N_FEAT, generator=g).bfloat16().to(device)
     w = (torch.randn(N_FEAT, N_FEAT, generator=g) / 64).bfloat16().to(device)
@@ -216,11 +216,19 @@ def decomposed_forward_lines(device):
            "dense_torch_hipblaslt_ms": lib_t * 1e3,
            "dense_torch_hipblaslt_tflops": 2 * t_rows * N_FEAT * N_FEAT / lib_t / 1e12}
     import itertools
-    rot = itertools.cycle([x] + [torch.randn(t_rows, N_FEAT, device=device).bfloat16() for _ in range(5)])
+    rot = itertools.cycle([x] + [torch.randn(t_rows, N_FEAT, device=device).bfloat16() for _ in range(5 if full else 0)])
     for r in (256, 512, 1024):
         a = (torch.randn(r, N_FEAT, generator=g) / 64).bfloat16().to(device)
         b = (torch.randn(N_FEAT, r, generator=g) / r**0.5).bfloat16().to(device)
         t = time_events(lambda: ops.lowrank_forward(x, a, b, None), iters=10)
+        if not full:
+            lib_pair = time_events(lambda: torch.nn.functional.linear(torch.nn.functional.linear(x, a), b), iters=10)
+            fl = 2 * t_rows * r * 2 * N_FEAT
+            by = 2 * (2 * t_rows * N_FEAT + 2 * r * N_FEAT)
+            out[f"r{r}"] = {"ms": t * 1e3, "gflops": fl / t / 1e9, "speedup_vs_dense": dense_t / t,
+                            "torch_hipblaslt_pair_ms": lib_pair * 1e3, "frac_of_bf16_mfma_peak": fl / t / PEAK_BF16_MFMA,
+                            "hbm_gbps_algorithmic": by / t / 1e9, "frac_of_hbm_peak": by / t / PEAK_HBM}
+            continue
         # the same with the input rotating over buffers larger than the 256-MB Infinity Cache: x comes from HBM at
         # every launch, as in a forward pass of a model (the single-buffer loop above re-reads a cached x)
         # (two rounds each, the faster kept: the first launches of a shape can hit the caching allocator's first
@@ -241,13 +249,14 @@ def decomposed_forward_lines(device):
             pair[0].weight.copy_(a); pair[1].weight.copy_(b)
             mod_t = time_events(lambda: pair(x), iters=10)
         out[f"r{r}"] = {"ms": t * 1e3, "gflops": fl / t / 1e9, "speedup_vs_dense": dense_t / t,
+                        "frac_of_hbm_peak": by / t / PEAK_HBM,
                         "speedup_vs_dense_torch_hipblaslt": lib_t / t, "torch_hipblaslt_pair_ms": lib_pair * 1e3,
                         "ms_rotating_inputs": t_cold * 1e3, "torch_hipblaslt_pair_ms_rotating_inputs": lib_cold * 1e3,
                         "module_ms": mod_t * 1e3,
                         "module_runs": "package kernels",
                         "frac_of_bf16_mfma_peak": fl / t / PEAK_BF16_MFMA, "hbm_gbps_algorithmic": by / t / 1e9}
     # MFMA utilisation of the two rank-256 kernels from the committed counter pass (tools/pmc_driver mfma)
-    pmc = pmc_file("pmc_mfma_r*.json", ("gemm_f32.hip", "gemm_bf16.hip"))
+    pmc = pmc_file("pmc_mfma_r*.json", ("gemm_f32.hip", "gemm_bf16.hip")) if full else None
     if pmc:
         kern = pmc["data"]["kernels"]
         for label, key in (("x_At", "gemm_bf16_nt_glds_kernel<0, 4>"), ("h_Bt", "gemm_bf16_shortk4_kernel<4>")):
@@ -881,6 +890,9 @@ def main():
             result["eigh"]["of"] = described
         result["kernels"] = {**result.get("kernels", {}), **kernel_lines(device)}
         result["decomposed_fwd"] = decomposed_forward_lines(device)
+        # SURVEY 8d C5 lists T = 4096 / 16384 / 65536: the other two row counts, package pair against library pair
+        result["decomposed_fwd"]["rows_4096"] = decomposed_forward_lines(device, 4096, full=False)
+        result["decomposed_fwd"]["rows_65536"] = decomposed_forward_lines(device, 65536, full=False)
         if world == 1 and not args.no_c4:
             result["c4_shapes"] = llama_shape_lines(device)
             result["c4_block"] = llama_block_lines(device)

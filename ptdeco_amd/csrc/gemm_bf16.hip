@@ -641,7 +641,7 @@ __device__ __forceinline__ void syrk_ring_tile(const SyrkRingArgs& a, const int 
     const char* baseB = reinterpret_cast<const char*>(s_base + n0 + (int64_t)s_kt * BK * ld);
 #pragma unroll
     for (int q = 0; q < NI; ++q) {
-      if (a.dbg == 2) break;
+      if (a.dbg & 2) break;
       const unsigned slot = lds0 + buf * BUFB + (wid * NI + q) * KPI * ROWB;   // wave-uniform 1-KiB piece
       asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
                    : : "s"(slot), "v"(voff[q]), "s"(baseA) : "memory", "m0");
@@ -713,7 +713,7 @@ __device__ __forceinline__ void syrk_ring_tile(const SyrkRingArgs& a, const int 
     constexpr int P = decltype(pp)::value;
     const char* As = lds + buf * BUFB;
     const char* Bs = SAME ? As : As + OPB;
-    if (!dead && a.dbg != 1) {
+    if (!dead && a.dbg != 1 && !(a.dbg & 4)) {
 #pragma unroll
       for (int q = 0; q < BK / 16; ++q) {
 #pragma unroll
@@ -725,7 +725,7 @@ __device__ __forceinline__ void syrk_ring_tile(const SyrkRingArgs& a, const int 
   };
   auto mfma_step = [&](auto pp) {
     constexpr int P = decltype(pp)::value;
-    if (!dead && a.dbg != 1) {
+    if (!dead && a.dbg != 1 && !(a.dbg & 8)) {
 #pragma unroll
       for (int q = 0; q < BK / 16; ++q)
 #pragma unroll
@@ -824,33 +824,83 @@ __device__ __forceinline__ void syrk_ring_tile(const SyrkRingArgs& a, const int 
     mfma_step(std::integral_constant<int, DB ? ((NBUF - 1) & 1) : 0>{});     // the last step
     step_end();
   } else {
-    // two waves per SIMD: read and multiply step g in the same iteration; NBUF - 1 steps are staged ahead
+    // Two waves per SIMD, half a K step apart.  In lockstep (read, then multiply, every wave at once) the LDS pipe and
+    // the matrix pipe took turns: reads alone 31 us, MFMAs alone 35 us, together 50 us per 2048-row step
+    // (PTD_SYRK_RING_DBG).  The waves of the tile's upper half (wm = 0: the first wave of each SIMD) read step g in the
+    // first half of iteration g and multiply it in the second; those of the lower half (`late`) multiply step g - 1 in
+    // the first half and read step g in the second -- each SIMD always has one wave on either pipe.  Two barriers an
+    // iteration.  A slot is restaged right behind the first barrier of the NEXT iteration: by then the early waves
+    // have multiplied from it and the late ones have waited for their reads (lgkmcnt(0) in front of the barrier).
+    const bool late = wid >= NW / 2;
 #pragma unroll
     for (int p = 0; p < NBUF - 1; ++p) stage_next(p);
-    int slot = 0;
-    for (int g = 0; g + NBUF - 1 < NK; ++g) {
-      wait_vmcnt<(NBUF - 2) * DPS>();      // step g has landed; steps g + 1 .. g + NBUF - 2 stay in flight
-      __builtin_amdgcn_s_barrier();        // ... and every wave has multiplied step g - 1: its slot is free
-      asm volatile("" ::: "memory");
-      stage_next(slot == 0 ? NBUF - 1 : slot - 1);
-      read_step(P0{}, slot);
-      mfma_step(P0{});
-      step_end();
-      slot = slot + 1 == NBUF ? 0 : slot + 1;
-    }
-    static_for<0, NBUF - 1>([&](auto tt) {
-      constexpr int t = decltype(tt)::value;
-      constexpr int ahead = (NBUF - 2 - t) * DPS + (t < NPIECE ? t : NPIECE) * PIECE;
-      static_assert(ahead <= 63, "vmcnt is a 6-bit counter");
-      wait_vmcnt<ahead>();
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      old_values(tt);
-      read_step(P0{}, slot);
-      mfma_step(P0{});
-      step_end();
-      slot = slot + 1 == NBUF ? 0 : slot + 1;
-    });
+    // (the two roles are two straight-line copies of the loop: with a branch per half iteration the register
+    // allocator spilled a thousand registers)
+    auto run = [&](auto late_c) {
+      constexpr bool LATE = decltype(late_c)::value;
+      int slot = 0;
+      auto iteration = [&](bool has_prev) {
+        stage_next(slot == 0 ? NBUF - 1 : slot - 1);
+        if constexpr (!LATE) {
+          read_step(P0{}, slot);
+        } else {
+          if (has_prev) {
+            mfma_step(P0{});
+            step_end();
+          }
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if constexpr (!LATE) {
+          mfma_step(P0{});
+          step_end();
+        } else {
+          read_step(P0{}, slot);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        slot = slot + 1 == NBUF ? 0 : slot + 1;
+      };
+      for (int g = 0; g + NBUF - 1 < NK; ++g) {
+        wait_vmcnt<(NBUF - 2) * DPS>();      // step g has landed; steps g + 1 .. g + NBUF - 2 stay in flight
+        __builtin_amdgcn_s_barrier();        // ... and nobody reads step g - 1's slot any more
+        asm volatile("" ::: "memory");
+        iteration(g > 0);
+      }
+      static_for<0, NBUF - 1>([&](auto tt) {
+        constexpr int t = decltype(tt)::value;
+        constexpr int ahead = (NBUF - 2 - t) * DPS + (t < NPIECE ? t : NPIECE) * PIECE;
+        static_assert(ahead <= 63, "vmcnt is a 6-bit counter");
+        wait_vmcnt<ahead>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        old_values(tt);
+        // (in the tail nothing is staged: the cursor has run out -- stage_next is not called)
+        if constexpr (!LATE) {
+          read_step(P0{}, slot);
+        } else {
+          if (t > 0 || NK > NBUF - 1) {
+            mfma_step(P0{});
+            step_end();
+          }
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if constexpr (!LATE) {
+          mfma_step(P0{});
+          step_end();
+        } else {
+          read_step(P0{}, slot);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        slot = slot + 1 == NBUF ? 0 : slot + 1;
+      });
+      if constexpr (LATE) {                  // the late waves' last step
+        mfma_step(P0{});
+        step_end();
+      }
+    };
+    if (late) run(std::true_type{});
+    else run(std::false_type{});
     old_values(std::integral_constant<int, NBUF - 1>{});
   }
   wait_vmcnt<0>();

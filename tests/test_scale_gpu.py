@@ -683,3 +683,40 @@ def test_llama_shaped_stack_shares_input_moments_and_matches_oracle(monkeypatch)
         out = model({"x": xs[0].to(DEV)}).cpu()
         ref = ref_model({"x": xs[0]})
     assert (out - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
+
+
+def test_dwain_stack_under_the_production_backoff_setting_takes_the_same_decisions(monkeypatch):
+    """the late-decline memory of the filtered eigensolver (`eigh_filtered_backed_off`, keyed by device and
+    shape) is process-wide state that concurrent chains update in whatever order they finish, and the suite pins it off
+    (conftest: PTD_EIGH_FILTER_BACKOFF=0).  Here the DEFAULT setting runs: the 8-layer stack of bench.py (its deeper
+    layers decline late on some boxes), three times in one process, against a run with the memory off -- which route a
+    layer takes may differ from run to run, the (layer, rank, accepted) decisions may not, and the metrics agree to the
+    two routes' agreement (nsr 1e-6 relative; ppl_diff, an f32 quantity, to its rounding)."""
+    import bench
+    import ptdeco_amd
+
+    model, data, metric = bench.make_workload(8, "cpu", bench.STACK_D_STEPS, 7 * bench.M_STEPS)
+    cpu = torch.device("cpu")
+    data_c, metric_c = bench.with_targets(model, data, cpu), bench.with_targets(model, metric, cpu)
+    data_g = [{k: v.to(DEV) for k, v in b.items()} for b in data_c]
+    metric_g = [{k: v.to(DEV) for k, v in b.items()} for b in metric_c]
+
+    def run():
+        m = copy.deepcopy(model).to(DEV)
+        trace = []
+        ptdeco_amd.dwain.decompose_in_place(
+            module=m, device=DEV, data_iterator=itertools.cycle(data_g), loss_fn=bench.ce_loss,
+            metric_iterator=itertools.cycle(metric_g), finetune_fn=lambda mm, d, n: mm, trace=trace,
+            precomputing_covariance_num_splits=1, **dict(bench.DWAIN_KW, num_data_steps=bench.STACK_D_STEPS))
+        return trace
+
+    monkeypatch.setenv("PTD_EIGH_FILTER_BACKOFF", "0")
+    ref = run()
+    monkeypatch.delenv("PTD_EIGH_FILTER_BACKOFF")
+    for _ in range(3):
+        got = run()
+        assert [(t["layer"], t["rank"], t["accepted"]) for t in got] == [(t["layer"], t["rank"], t["accepted"]) for t in ref]
+        for a, b in zip(ref, got):
+            assert abs(a["nsr"] - b["nsr"]) <= 1e-6 * abs(a["nsr"]) + 1e-12
+            # (ppl_diff is formed in the loss dtype, f32: the routes' 1e-11 shows as rounding noise of the perplexities)
+            assert abs(a["ppl_diff"] - b["ppl_diff"]) <= 1e-4 * abs(a["ppl_diff"]) + 2e-6

@@ -12,7 +12,7 @@ def ev_time(fn, iters=10, warm=2):
 n, t, steps = 4096, 2048, 8
 ys = [torch.randn(t, n, device=dev).to(torch.bfloat16) for _ in range(steps)]
 e = torch.zeros(n, n, dtype=torch.float64, device=dev)
-for dbg in ("0", "1", "2"):
+for dbg in ("0", "1", "2", "6", "10"):
     os.environ["PTD_SYRK_RING_DBG"] = dbg
     ms = ev_time(lambda: ops.syrk_accumulate_multi(e, ys, 1.0 / t)) / steps
     ms1 = ev_time(lambda: ops.syrk_accumulate(e, ys[0], 1.0 / t))
