@@ -168,6 +168,30 @@ def kernel_lines(device):
     fl = 2 * t_tok * N_FEAT * N_FEAT
     lines["gemm_bf16_nt"] = {"ms": t * 1e3, "algorithmic_flops": fl, "tflops": fl / t / 1e12,
                              "frac_of_bf16_mfma_peak": fl / t / PEAK_BF16_MFMA}
+    # the bf16 covariance product at the Llama calibration shapes (2048 tokens a step): one call per step against the
+    # multi-step entry (8 steps in one pass over the f64 accumulator); bounds on 2 T n bytes of activations per step +
+    # 8 n (n + 1) bytes of accumulator per CALL and T n (n + 1) flop per step
+    cal = {}
+    for n_c in (4096, 1024, 14336):
+        ys = [torch.randn(2048, n_c, device=device).bfloat16() for _ in range(8)]
+        e_c = torch.zeros(n_c, n_c, dtype=torch.float64, device=device)
+
+        def one_by_one():
+            for y_c in ys:
+                ops.syrk_accumulate(e_c, y_c, 1.0 / 2048)
+
+        t1 = time_events(one_by_one, iters=10) / 8
+        t8 = time_events(lambda: ops.syrk_accumulate_multi(e_c, ys, 1.0 / 2048), iters=10) / 8
+        by1 = 2 * 2048 * n_c + 8 * n_c * (n_c + 1)
+        by8 = 2 * 2048 * n_c + n_c * (n_c + 1)
+        fl = 2048 * n_c * (n_c + 1)
+        cal[f"n{n_c}"] = {"T": 2048, "us_per_step_single_call": t1 * 1e6, "us_per_step_multi_8": t8 * 1e6,
+                          "hbm_bound_us_single": by1 / PEAK_HBM * 1e6, "hbm_bound_us_multi_8": by8 / PEAK_HBM * 1e6,
+                          "mfma_bound_us": fl / PEAK_BF16_MFMA * 1e6,
+                          "frac_of_bound_single": max(by1 / PEAK_HBM, fl / PEAK_BF16_MFMA) / t1,
+                          "frac_of_bound_multi_8": max(by8 / PEAK_HBM, fl / PEAK_BF16_MFMA) / t8}
+        del ys, e_c
+    lines["syrk_bf16_calibration_shapes"] = cal
     # ptd_nsr through the C ABI with prepared arguments (the Python front end costs as much host time per call as this
     # kernel pair takes on the device): the C2 logits [4 x 1024, 4096] f32 and a vocabulary-sized bf16 case
     from ptdeco_amd import _hip

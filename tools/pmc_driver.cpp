@@ -72,14 +72,25 @@ static int run_syrk() {
     v = (unsigned short)((u + 0x7FFF + ((u >> 16) & 1)) >> 16);
   }
   unsigned short* Y; double* E;
-  if (hipMalloc(&Y, maxy * 2) || hipMalloc(&E, maxn * maxn * 8)) return 2;
-  (void)hipMemcpy(Y, hb.data(), maxy * 2, hipMemcpyHostToDevice);
+  if (hipMalloc(&Y, 8 * maxy * 2) || hipMalloc(&E, maxn * maxn * 8)) return 2;      // eight distinct step matrices
+  for (int st = 0; st < 8; ++st) (void)hipMemcpy(Y + st * maxy, hb.data(), maxy * 2, hipMemcpyHostToDevice);
   (void)hipMemset(E, 0, maxn * maxn * 8);
   for (auto& sh : shapes) {
     const int64_t n = sh[0], T = sh[1];
     for (int r = 0; r < 3; ++r) {
       const int rc = ptd_syrk_accumulate(Y, T, n, n, PTD_BF16, E, n, PTD_F64, 1.0 / (double)T, nullptr);
       if (rc) { fprintf(stderr, "syrk mode rc=%d: %s\n", rc, ptd_last_error()); return 1; }
+    }
+  }
+  // round 5: the multi-step entry at the calibration shapes -- 8 steps of 2048 rows in one pass over E (eight
+  // distinct step matrices)
+  for (int q = 1; q < 4; ++q) {
+    const int64_t n = shapes[q][0], T = shapes[q][1];
+    const void* ys[8];
+    for (int st = 0; st < 8; ++st) ys[st] = Y + st * maxy;
+    for (int r = 0; r < 3; ++r) {
+      const int rc = ptd_syrk_accumulate_multi(ys, 8, T, n, n, PTD_BF16, E, n, PTD_F64, 1.0 / (double)T, nullptr);
+      if (rc) { fprintf(stderr, "syrk multi rc=%d: %s\n", rc, ptd_last_error()); return 1; }
     }
   }
   (void)hipDeviceSynchronize();

@@ -8,7 +8,8 @@ import csv, glob, json, os, sys
 
 rnd = sys.argv[1] if len(sys.argv) > 1 else "04"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-shapes = [(4096, 4096), (4096, 2048), (1024, 2048), (14336, 2048)]
+shapes = [(4096, 4096, 1), (4096, 2048, 1), (1024, 2048, 1), (14336, 2048, 1),      # (n, T, calibration steps per launch)
+          (4096, 2048, 8), (1024, 2048, 8), (14336, 2048, 8)]                      # ptd_syrk_accumulate_multi (round 5)
 
 
 def rows(d, suffix):
@@ -39,13 +40,15 @@ out = {"command": "rocprofv3 --pmc <MfmaUtil | FETCH_SIZE | WRITE_SIZE> --kernel
                   "tools/pmc_driver syrk (bf16 y, f64 accumulator, three launches per shape; separate passes per counter)",
        "note": "us = launch duration in the MfmaUtil pass (profiled clocks run a few per cent low); traffic = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 "
                "bytes per launch (gfx950: FETCH_SIZE counts half of a wide streaming read); algorithmic bytes = 2 T n (y once) + 8 n (n + 1) "
-               "(the live triangle of E read and written); flops = T n (n + 1)", "shapes": []}
-for i, (n, t) in enumerate(shapes):
+               "(the live triangle of E read and written ONCE per launch); flops = T n (n + 1) per step; steps_per_launch = 8: "
+               "ptd_syrk_accumulate_multi", "shapes": []}
+for i, (n, t, steps) in enumerate(shapes):
     sl = slice(3 * i, 3 * i + 3)
     us = sum(x[1] for x in du[sl]) / 3
-    flops, byts = t * n * (n + 1), 2 * t * n + 8 * n * (n + 1)
+    flops, byts = steps * t * n * (n + 1), steps * 2 * t * n + 8 * n * (n + 1)
     traffic = (2 * sum(fe[sl]) / 3 + sum(wr[sl]) / 3) * 1024
-    out["shapes"].append({"n": n, "T": t, "kernel": du[3 * i][2].replace("ptd::(anonymous namespace)::", "").split("(")[0], "us": us,
+    out["shapes"].append({"n": n, "T": t, "steps_per_launch": steps, "us_per_step": us / steps,
+                          "kernel": du[3 * i][2].replace("ptd::(anonymous namespace)::", "").split("(")[0], "us": us,
                           "MfmaUtil": sum(mf[sl]) / 3, "tflops": flops / us / 1e6, "frac_of_bf16_mfma_peak": flops / us / 1e6 / 2500,
                           "traffic_bytes": traffic, "algorithmic_bytes": byts, "traffic_over_algorithmic": traffic / byts,
                           "algorithmic_gbps": byts / us / 1e3, "frac_of_hbm_peak": byts / us / 1e3 / 8000,

@@ -31,6 +31,11 @@ if f:
               open("gpurun_out/roofline_kernel_split_r$R.json", "w"), indent=1)
 PY
   rm -f gpurun_out/prof_r$R/*/*kernel_trace.csv
+  # the same for the DEFAULT command the driver runs (the fixed stack as `value`, every side block; the CPU baseline, which
+  # launches no kernels, left out): which kernels the whole bench spends its device time in
+  rm -rf $GRAFT_REPO_ROOT/gpurun_out/prof_default_r$R
+  (cd /tmp && export TMPDIR=/tmp && timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_default_r$R -- python3 $GRAFT_REPO_ROOT/bench.py --gpus 1 --steps 5 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/prof_default_r$R.log 2>&1); echo "rocprof default rc=$?"
+  rm -f gpurun_out/prof_default_r$R/*/*kernel_trace.csv
 fi
 if [ "$PART" = all ] || [ "$PART" = c4 ] || [ "$PART" = c4gpu ]; then
   timeout -k 10 300 python tools/c4_shapes.py > gpurun_out/c4_f32_r$R.json 2> gpurun_out/c4_f32.err; echo "c4 f32 rc=$?"
