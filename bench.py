@@ -127,17 +127,23 @@ DWAIN_KW = dict(num_data_steps=D_STEPS, num_metric_steps=M_STEPS, nsr_final_thre
                 trade_off_factor=0.5, reduction_factor=0.5, max_accepted_ppl_diff=0.1, decompose_in_float64=True)
 
 
-def time_events(fn, iters=20, warm=3):
+def time_events(fn, iters=20, warm=3, rounds=3):
+    """Seconds per call: `rounds` timed loops of `iters` calls each between two HIP events, the MEDIAN loop reported -- one
+    stall of the box inside a loop (an 80-ms one made a 0.12-ms line read 8.2 ms in a round-5 run) does not become the
+    figure, and neither does the best loop."""
     for _ in range(warm):
         fn()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    e0.record()
-    for _ in range(iters):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / iters * 1e-3
+    got = []
+    for _ in range(rounds):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        got.append(e0.elapsed_time(e1) / iters * 1e-3)
+    return sorted(got)[len(got) // 2]
 
 
 def kernel_lines(device):
@@ -205,7 +211,7 @@ def kernel_lines(device):
         st = torch.cuda.current_stream(device).cuda_stream
         _hip.check(lib.ptd_nsr_workspace_init(ws.data_ptr(), ws.numel(), st), "ptd_nsr_workspace_init")
         args = (xx.data_ptr(), yy.data_ptr(), rows, chans, code, 1e-3, outp.data_ptr(), ws.data_ptr(), ws.numel(), st)
-        tt = min(time_events(lambda: lib.ptd_nsr(*args), iters=50) for _ in range(2))
+        tt = time_events(lambda: lib.ptd_nsr(*args), iters=50)
         nbytes = 2 * yy.numel() * yy.element_size()
         return {"ms": tt * 1e3, "algorithmic_bytes": nbytes, "gbps": nbytes / tt / 1e9, "frac_of_hbm_peak": nbytes / tt / PEAK_HBM,
                 "shape": [rows, chans], "launches": "stream kernel + 64-channel final kernel"}
@@ -255,11 +261,10 @@ def decomposed_forward_lines(device, t_rows=16384, full=True):
             continue
         # the same with the input rotating over buffers larger than the 256-MB Infinity Cache: x comes from HBM at
         # every launch, as in a forward pass of a model (the single-buffer loop above re-reads a cached x)
-        # (two rounds each, the faster kept: the first launches of a shape can hit the caching allocator's first
-        # allocation of the 134-MB output blocks)
-        t_cold = min(time_events(lambda: ops.lowrank_forward(next(rot), a, b, None), iters=12) for _ in range(2))
-        lib_cold = min(time_events(lambda: torch.nn.functional.linear(torch.nn.functional.linear(next(rot), a), b), iters=12)
-                       for _ in range(2))
+        # (time_events reports the median of three loops: the first launches of a shape can hit the caching allocator's
+        # first allocation of the 134-MB output blocks)
+        t_cold = time_events(lambda: ops.lowrank_forward(next(rot), a, b, None), iters=12)
+        lib_cold = time_events(lambda: torch.nn.functional.linear(torch.nn.functional.linear(next(rot), a), b), iters=12)
         fl = 2 * t_rows * r * 2 * N_FEAT
         by = 2 * (2 * t_rows * N_FEAT + 2 * r * N_FEAT)
         # the same pair as two torch.nn.functional.linear calls (hipBLASLt): what apply_decompose_config_in_place's
@@ -730,6 +735,8 @@ def main():
     # the step the phase / eigensolver blocks describe: C2 at N = 1, the fixed stack otherwise
     one_step = family(c2, torch.float32) if c2 is not None else stack_step
     described = "c2_single_layer" if c2 is not None else "the fixed stack (`value`)"
+    from ptdeco_amd import _engine as _eng_stats
+    result["config"]["chain_streams"] = dict(_eng_stats.CHAIN_STREAM_STATS)     # (run_concurrently's stream checks so far)
     if c2 is not None:
         result["config"]["c2_single_layer_layers_per_s"] = result["c2_single_layer"]["value"]
         result["config"]["c2_single_layer_ms_per_step"] = result["c2_single_layer"]["ms_per_step"]
@@ -929,6 +936,7 @@ def main():
                                                                "ms_per_step": result["c2_single_layer"]["ms_per_step"]}
 
     if rank == 0:
+        result["config"]["chain_streams_at_exit"] = dict(_eng_stats.CHAIN_STREAM_STATS)
         print(json.dumps(result))
     if world > 1:
         dist.barrier()  # rank 0 may still be in its side measurements

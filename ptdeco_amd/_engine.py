@@ -1093,6 +1093,7 @@ def eigh_cost_hint(cov, n_out: int, top_k: Optional[int]) -> float:
 
 
 _CHAIN_STREAMS: dict = {}      # device index -> (streams on pairwise distinct hardware queues, candidates exhausted?)
+CHAIN_STREAM_STATS = {"calls": 0, "selections": 0, "rechecks_failed": 0}     # (bench.py reports them)
 _CHAIN_STREAMS_LOCK = None
 
 
@@ -1105,8 +1106,8 @@ def chain_streams(device: torch.device, want: int) -> list:
     high-priority streams have four queues of their own) and two chains on one queue are executed packet by packet, in
     turn.  Which streams share is a fact of the process (creation order of every stream in it, torch's pools included),
     so it is MEASURED, once per device: candidates from torch's high-priority pool, then from the normal one, are tested
-    pairwise with ptd_stream_pair_wall_us (two single-wave kernels that hold their queue for 150 us: side by side
-    ~0.16 ms, serialised ~0.31 ms) and taken greedily while they overlap with every stream taken before.  The streams
+    pairwise with ptd_stream_pair_wall_us (two single-wave kernels that hold their queue for 400 us: side by side
+    ~0.42 ms, serialised ~0.82 ms) and taken greedily while they overlap with every stream taken before.  The streams
     are kept for the life of the process (the mapping of an existing stream does not change: the probe's matrix is
     identical before and after use).  Fewer than `want` distinct queues -> fewer streams are returned.
     PTD_CHAIN_STREAMS_VERIFY=0 skips the measurement (pool streams as they come, the round-4 behaviour)."""
@@ -1128,8 +1129,12 @@ def chain_streams(device: torch.device, want: int) -> list:
     with _CHAIN_STREAMS_LOCK:
         have, exhausted = _CHAIN_STREAMS.get(index, ([], False))
         lib = _hip.load()
-        spin_us = 150
+        # (400 us per kernel: a serialised pair shows as +400 us, far above what a descheduled host thread or a slow
+        # launch adds -- at 150 us a 65-us hiccup of the host read as "serialised" and set off a re-selection: bench.py on a
+        # busy box, bf16 stack 388 -> 509 ms per step)
+        spin_us = 400
         wall = ctypes.c_double(0.0)
+        CHAIN_STREAM_STATS["calls"] += 1
         if have and (len(have) >= want or exhausted):
             # Re-check the kept streams, all at once (one 150-us kernel on each: 0.2 ms): the mapping of streams onto
             # hardware queues was seen to change within a process -- bench.py: four streams verified distinct at the first
@@ -1138,9 +1143,11 @@ def chain_streams(device: torch.device, want: int) -> list:
             group = have[:want]
             arr = (ctypes.c_void_p * len(group))(*[h.cuda_stream for h in group])
             with torch.cuda.device(device):
-                _hip.check(lib.ptd_streams_wall_us(arr, len(group), spin_us, ctypes.byref(wall)), "ptd_streams_wall_us")
-            if wall.value < 1.6 * spin_us:
-                return list(group)
+                for attempt in range(2):       # (a failed check is repeated once before it counts)
+                    _hip.check(lib.ptd_streams_wall_us(arr, len(group), spin_us, ctypes.byref(wall)), "ptd_streams_wall_us")
+                    if wall.value < 1.5 * spin_us:
+                        return list(group)
+            CHAIN_STREAM_STATS["rechecks_failed"] += 1
             import logging
 
             logging.getLogger(__name__).info("cuda:%d: the kept streams no longer overlap (%.0f us for %d x %d us): "
@@ -1150,7 +1157,7 @@ def chain_streams(device: torch.device, want: int) -> list:
         def overlap(a, b) -> bool:
             _hip.check(lib.ptd_stream_pair_wall_us(a.cuda_stream, b.cuda_stream, spin_us, ctypes.byref(wall)),
                        "ptd_stream_pair_wall_us")
-            return wall.value < 1.6 * spin_us
+            return wall.value < 1.5 * spin_us
 
         with torch.cuda.device(device):
             tried = 0
@@ -1170,6 +1177,7 @@ def chain_streams(device: torch.device, want: int) -> list:
                         have.append(cand)
             exhausted = len(have) < want
         _CHAIN_STREAMS[index] = (have, exhausted)
+        CHAIN_STREAM_STATS["selections"] += 1
         _log_chain_streams(index, have, tried)
         return list(have[:want])
 
