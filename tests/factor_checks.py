@@ -1,5 +1,7 @@
-"""Sample check for the full-depth runs (tools/c4_stack.py, tools/c4_hf_llama.py): the runs take
-minutes and used to assert nothing but "ran, N replaced".  Before the run a few layers of the FIRST precompute split are
+"""Check of installed rank-r pairs against f64 reference arithmetic on captured calibration data -- used by the bf16
+full-width test (tests/test_fullwidth_gpu.py) on every replaced layer and by the full-depth tools (tools/c4_stack.py,
+tools/c4_hf_llama.py) on one replaced layer chosen at random: those runs take minutes and used to
+assert nothing but "ran, N replaced".  Before the run a few layers of the FIRST precompute split are
 armed -- their original weight is copied and their inputs over the calibration batches are recorded from the untouched
 model (the first split's covariances are taken before anything is replaced).  After the run ONE armed layer that was
 replaced, chosen at random, is checked against f64 reference arithmetic on the captured data:
@@ -34,12 +36,14 @@ def arm(model, names, batches, max_layers=6, seed=0):
     return state
 
 
-def verify(state, model, cfg, damp=0.01):
-    """-> dict with the layer checked and the three figures; raises AssertionError when one is out of bounds."""
+def verify(state, model, cfg, damp=0.01, name=None):
+    """-> dict with the layer checked and the three figures; raises AssertionError when one is out of bounds.  `name`:
+    the layer to check (default: one replaced armed layer chosen at random)."""
     replaced = [n for n in state["order"] if n in cfg]
     if not replaced:
         return {"checked": None, "note": "none of the armed layers was replaced"}
-    name = state["rng"].choice(replaced)
+    if name is None:
+        name = state["rng"].choice(replaced)
     pair = model.get_submodule(name)
     first, second = pair[0].weight.detach().double(), pair[1].weight.detach().double()   # [r, n_in], [n_out, r]
     w = state["weights"][name].double()

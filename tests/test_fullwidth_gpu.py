@@ -101,3 +101,42 @@ def test_dwain_llama3_8b_width_block_matches_oracle():
         out = model({"x": dev_batches[0]["x"]}).cpu()
         ref = ref_model({"x": batches[0]["x"]})
     assert (out - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("syrk_steps", ["8", "1"])
+def test_dwain_bf16_llama_block_installs_optimal_projections(monkeypatch, syrk_steps):
+    """The configuration every throughput figure quotes -- a bf16 model, [1, 2048, 4096] batches, D = 8, all seven layers of
+    a full-width Llama-3-8B block (up included) -- has no CPU oracle run to compare with (the oracle's 14336^2
+    eigendecompositions take minutes).  What the method PROMISES of every replaced layer is checked instead, against f64
+    reference arithmetic on the captured calibration data (tests/factor_checks.py): the second factor has orthonormal
+    columns, the first is (second)^T W -- the pair is the projection of the original weight onto that span,
+    dwain.py:424-429 -- and the span captures as much of the layer's feature covariance as the r leading eigenvectors the
+    library eigensolver finds (>= 0.99 of the optimum; bf16 factors).  With the calibration steps reaching the accumulator
+    eight per call (ptd_syrk_accumulate_multi through _engine.StepBatch: the default) and one per call."""
+    import itertools
+
+    import bench
+    import factor_checks
+    import ptdeco_amd
+
+    monkeypatch.setenv("PTD_SYRK_STEPS", syrk_steps)
+    g = torch.Generator(device=DEV).manual_seed(0)
+    with torch.device(DEV):
+        model = bench.LlamaStack(1)
+    with torch.no_grad():
+        for prm in model.parameters():
+            prm.copy_(torch.randn(prm.shape, generator=g, device=DEV) / prm.shape[1] ** 0.5)
+    model.to(torch.bfloat16)
+    scale = torch.logspace(0, -2, bench.D_MODEL, device=DEV)
+    xs = [(torch.randn(1, 2048, bench.D_MODEL, generator=g, device=DEV) * scale).to(torch.bfloat16) for _ in range(12)]
+    with torch.no_grad():
+        bt = [{"x": x, "targets": model({"x": x}).argmax(-1)} for x in xs]
+    names = [f"blocks.0.{n}" for n in ("q", "k", "v", "o", "gate", "up", "down")]
+    armed = factor_checks.arm(model, names, bt[:8], max_layers=7)
+    cfg = ptdeco_amd.dwain.decompose_in_place(module=model, device=DEV, data_iterator=itertools.cycle(bt),
+                                              loss_fn=bench.seq_ce, metric_iterator=itertools.cycle(bt[8:]),
+                                              finetune_fn=lambda mm, d, n: mm, **bench.C4_BLOCK_KW)
+    assert len(cfg) >= 4, list(cfg)
+    for name in cfg:
+        got = factor_checks.verify(armed, model, cfg, name=name)
+        assert got["checked"] == name and got["captured_energy_over_optimal"] >= 0.99, got

@@ -59,9 +59,9 @@ ids = [torch.randint(0, 128256, (1, 2048), generator=g, device=dev) for _ in ran
 with torch.no_grad():
     bt = [{"ids": i, "targets": model({"ids": i}).argmax(-1)} for i in ids]
 torch.cuda.synchronize()
-# sample check (tools/sample_check.py): a few layers of the first precompute split are armed before the run
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-import sample_check
+# sample check (tests/factor_checks.py): a few layers of the first precompute split are armed before the run
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import factor_checks as sample_check
 all_names = [n for n, m in model.named_modules() if isinstance(m, torch.nn.Linear) and not n.endswith("lm_head")]
 armed = sample_check.arm(model, all_names[:max(1, len(all_names) // 4)], bt[:8])
 if os.environ.get("PTD_PHASES"):

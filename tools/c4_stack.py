@@ -4,7 +4,7 @@ calibration [1, 2048, 4096], D = 8, M = 2, precomputing_covariance_num_splits = 
 Usage: python tools/c4_stack.py [blocks] [bf16]"""
 import itertools, json, os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import ptdeco_amd
 
 dev = torch.device("cuda", 0)
@@ -69,8 +69,8 @@ xs = [torch.randn(1, 2048, D, generator=g, device=dev).to(dtype) for _ in range(
 with torch.no_grad():
     bt = [{"x": x, "targets": model({"x": x}).argmax(-1)} for x in xs]
 torch.cuda.synchronize()
-# sample check (tools/sample_check.py): a few layers of the first precompute split are armed before the run
-import sample_check
+# sample check (tests/factor_checks.py): a few layers of the first precompute split are armed before the run
+import factor_checks as sample_check
 all_names = [n for n, m in model.named_modules() if isinstance(m, torch.nn.Linear) and n != "head"]
 armed = sample_check.arm(model, all_names[:max(1, len(all_names) // 4)], bt[:8])
 trace = []
