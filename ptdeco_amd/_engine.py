@@ -708,6 +708,8 @@ class StepBatch:
     round 4.  f32 activations are never held (their product is bound by the matrix cores)."""
 
     held_bytes = 0           # over every batch of the process
+    import threading as _threading
+    _lock = _threading.Lock()
 
     def __init__(self, E: torch.Tensor):
         import os
@@ -727,7 +729,8 @@ class StepBatch:
         if self.pending and (self.pending[0].shape != y.shape):
             self.flush()
         self.pending.append(y if private else y.clone(memory_format=torch.contiguous_format))
-        StepBatch.held_bytes += nbytes
+        with StepBatch._lock:
+            StepBatch.held_bytes += nbytes
         if len(self.pending) >= self.max_steps:
             self.flush()
 
@@ -735,8 +738,16 @@ class StepBatch:
         if not self.pending:
             return
         ys, self.pending = self.pending, []
-        StepBatch.held_bytes -= sum(y.numel() * y.element_size() for y in ys)
+        with StepBatch._lock:
+            StepBatch.held_bytes -= sum(y.numel() * y.element_size() for y in ys)
         ops.syrk_accumulate_multi(self.E, ys, 1.0 / ys[0].shape[0])
+        # (a flush from a worker thread of run_concurrently runs on that thread's side stream while the matrices were
+        # allocated on the caller's: the allocator must not hand their memory out again before this stream is done
+        # with it.  The drivers flush on the caller's stream before the concurrent section -- SharedInputPool.finalize,
+        # the reductions -- so this is the safety net, not the rule.)
+        cur = torch.cuda.current_stream(self.E.device)
+        for y in ys:
+            y.record_stream(cur)
 
 
 class Covariance:
@@ -1059,9 +1070,14 @@ class SharedInputPool:
                 for i, m in enumerate(self.members)]
 
     def finalize(self) -> None:
-        """Shared Ex matrices, formed once on the caller's stream before the (concurrent) eigendecompositions."""
+        """Shared Ex matrices, formed once on the caller's stream before the (concurrent) eigendecompositions; the
+        calibration steps the members' own statistics still hold back are added here too, on the caller's stream."""
         for mom in self.moments():
             mom.finalize()
+        for m in self.members:
+            batch = getattr(m.cov, "batch", None)
+            if batch is not None:
+                batch.flush()
 
 
 def eigh_route_hint(cov, n_out: int, top_k: Optional[int]) -> int:
