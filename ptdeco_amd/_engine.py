@@ -719,10 +719,15 @@ class StepBatch:
         self.budget = int(os.environ.get("PTD_SYRK_BUFFER_MB", "4096")) << 20
         self.pending: list = []
 
+    @staticmethod
+    def holdable(y: torch.Tensor) -> bool:
+        """bf16 matrices on the device: their covariance product is bound by the accumulator's traffic (f32 ones by
+        the matrix cores: nothing to gain from holding them)."""
+        return y.dtype == torch.bfloat16 and y.is_cuda and y.dim() == 2
+
     def add(self, y: torch.Tensor, private: bool = False) -> None:
         nbytes = y.numel() * y.element_size()
-        if (self.max_steps == 1 or y.dtype != torch.bfloat16 or not y.is_cuda or y.dim() != 2
-                or StepBatch.held_bytes + nbytes > self.budget):
+        if self.max_steps == 1 or not self.holdable(y) or StepBatch.held_bytes + nbytes > self.budget:
             self.flush()
             ops.syrk_accumulate(self.E, y, 1.0 / y.shape[0])
             return
@@ -745,9 +750,10 @@ class StepBatch:
         # allocated on the caller's: the allocator must not hand their memory out again before this stream is done
         # with it.  The drivers flush on the caller's stream before the concurrent section -- SharedInputPool.finalize,
         # the reductions -- so this is the safety net, not the rule.)
-        cur = torch.cuda.current_stream(self.E.device)
-        for y in ys:
-            y.record_stream(cur)
+        if self.E.is_cuda:
+            cur = torch.cuda.current_stream(self.E.device)
+            for y in ys:
+                y.record_stream(cur)
 
 
 class Covariance:

@@ -942,3 +942,62 @@ def test_calibration_forwards_stop_at_the_analysed_layer_after_the_first_one(mon
             tap.calibration_forward(wrapped, x)
         tap.close()
     assert len(done) == 3
+
+
+def test_step_batch_holds_calibration_steps_and_adds_them_in_one_call(monkeypatch):
+    """_engine.StepBatch (round 5): bf16 activation matrices of up to PTD_SYRK_STEPS steps reach the accumulator in ONE
+    ops.syrk_accumulate_multi call.  A matrix the caller may still write to is copied (changing it afterwards must not
+    change the sum), one nobody else holds is kept by reference, everything held is added before E is read, a change of
+    shape or a spent byte budget falls back to adding at once, f32 matrices are never held.  (Host logic on the CPU: the
+    two ops are replaced by f64 arithmetic and `holdable` by its dtype test.)"""
+    from ptdeco_amd import _engine as eng, ops
+
+    calls = []
+
+    def multi(E, ys, scale):
+        calls.append(("multi", len(ys)))
+        for y in ys:
+            E += scale * torch.tril(y.double().T @ y.double())
+
+    def single(E, y, scale):
+        calls.append(("single", 1))
+        E += scale * torch.tril(y.double().T @ y.double())
+
+    monkeypatch.setattr(ops, "syrk_accumulate_multi", multi)
+    monkeypatch.setattr(ops, "syrk_accumulate", single)
+    monkeypatch.setattr(eng.StepBatch, "holdable", staticmethod(lambda y: y.dtype == torch.bfloat16 and y.dim() == 2))
+    monkeypatch.setenv("PTD_SYRK_STEPS", "4")
+    g = torch.Generator().manual_seed(1)
+    ys = [torch.randn(16, 8, generator=g).bfloat16() for _ in range(10)]
+    want = sum(torch.tril(y.double().T @ y.double()) / 16 for y in ys)
+    cov = eng.Covariance(8, torch.device("cpu"), True)
+    held0 = eng.StepBatch.held_bytes
+    for i, y in enumerate(ys):
+        exposed = y.clone()
+        cov.add_features(exposed, private=(i % 2 == 1))
+        if i % 2 == 0:
+            exposed.zero_()                      # the caller reuses its buffer: the batch holds a copy
+    assert calls == [("multi", 4), ("multi", 4)] and len(cov.batch.pending) == 2
+    assert eng.StepBatch.held_bytes == held0 + 2 * 16 * 8 * 2
+    cov.batch.flush()                            # (what eigenvectors / reductions / finalize do first)
+    assert calls[-1] == ("multi", 2) and eng.StepBatch.held_bytes == held0 and cov.steps == 10
+    assert torch.allclose(cov.E, want, rtol=1e-12, atol=1e-12)
+    # a change of shape adds what is held first; f32 goes straight through; so does everything once the budget is spent
+    calls.clear()
+    cov2 = eng.Covariance(8, torch.device("cpu"), True)
+    cov2.add_features(ys[0].clone()); cov2.add_features(ys[1][:8].clone())
+    assert calls == [("multi", 1)] and len(cov2.batch.pending) == 1
+    cov2.add_features(ys[2].float())
+    assert calls == [("multi", 1), ("multi", 1), ("single", 1)] and not cov2.batch.pending
+    monkeypatch.setenv("PTD_SYRK_BUFFER_MB", "0")
+    cov3 = eng.Covariance(8, torch.device("cpu"), True)
+    calls.clear()
+    cov3.add_features(ys[0].clone())
+    assert calls == [("single", 1)] and not cov3.batch.pending
+    # PTD_SYRK_STEPS=1: every step at once, as in round 4
+    monkeypatch.setenv("PTD_SYRK_BUFFER_MB", "4096")
+    monkeypatch.setenv("PTD_SYRK_STEPS", "1")
+    cov4 = eng.Covariance(8, torch.device("cpu"), True)
+    calls.clear()
+    cov4.add_features(ys[0].clone())
+    assert calls == [("single", 1)]
