@@ -1220,7 +1220,8 @@ def run_concurrently(jobs, device: torch.device, max_streams: Optional[int] = No
     idle; chains of different layers issued on different streams interleave on the device (two
     n = 4096 matrices: 1.5x the throughput of running them back to back, three: 1.9x; round 4, with the filtered route
     in the mix: the seven layers of a Llama block 339 ms back to back, 250 on three streams, 204 on four, 211 on five).  The C ABI keeps
-    no shared mutable state and releases the GIL, so the host side is plain threads.  Stream order:
+    no shared mutable state and releases the GIL, so the host side is plain threads.  The streams are the device's
+    chain streams (`chain_streams`: measured to sit on distinct hardware queues, re-checked at every call).  Stream order:
     every side stream first waits for the caller's stream (inputs), the caller's stream waits for all
     of them at the end (outputs).  PTD_EIGH_STREAMS overrides the stream count (1 = sequential).  `routes` (one
     ptd_eigh_route value per job): only read with PTD_EIGH_STREAMS_BY_ROUTE=1, see the comment below.  `costs` (one
