@@ -127,22 +127,32 @@ DWAIN_KW = dict(num_data_steps=D_STEPS, num_metric_steps=M_STEPS, nsr_final_thre
                 trade_off_factor=0.5, reduction_factor=0.5, max_accepted_ppl_diff=0.1, decompose_in_float64=True)
 
 
-def time_events(fn, iters=20, warm=3, rounds=3):
-    """Seconds per call: `rounds` timed loops of `iters` calls each between two HIP events, the MEDIAN loop reported -- one
-    stall of the box inside a loop (an 80-ms one made a 0.12-ms line read 8.2 ms in a round-5 run) does not become the
-    figure, and neither does the best loop."""
+MIN_LOOP_MS = 40.0
+
+
+def time_events(fn, iters=20, warm=3, rounds=3, min_loop_ms=MIN_LOOP_MS):
+    """Seconds per call: `rounds` timed loops between two HIP events, the MEDIAN loop reported -- one stall of the box
+    inside a loop (an 80-ms one made a 0.12-ms line read 8.2 ms in a round-5 run) does not become the figure, and neither
+    does the best loop.  A loop holds at least `iters` calls and at least `min_loop_ms` of device work: the card leaves
+    its idle clocks over the first milliseconds of a loop, and a 4-ms loop of 0.4-ms launches read 480 us a launch where
+    a 40-ms loop of the same launches reads 374 (tools/probes/fwd_protocol.py; the library kernels move alike)."""
     for _ in range(warm):
         fn()
-    got = []
-    for _ in range(rounds):
+
+    def loop(count):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         e0.record()
-        for _ in range(iters):
+        for _ in range(count):
             fn()
         e1.record()
         torch.cuda.synchronize()
-        got.append(e0.elapsed_time(e1) / iters * 1e-3)
+        return e0.elapsed_time(e1)
+
+    first = loop(iters)
+    if first < min_loop_ms:
+        iters = min(int(iters * min_loop_ms / max(first, 1e-3)) + 1, 4000)
+    got = [loop(iters) / iters * 1e-3 for _ in range(rounds)]
     return sorted(got)[len(got) // 2]
 
 

@@ -639,6 +639,18 @@ constexpr unsigned long long RES_TIMEOUT_TICKS = 1000000ULL;
 constexpr int RES_CHECK = 256;
 constexpr int RES_MAX_POLLS = 20000000;   // second guard, in polls (seconds): the wait ends even if the clock did not advance
 
+#ifdef PTD_RES_PROF
+__device__ unsigned long long res_prof[2][16];
+#define RES_T0(K) unsigned long long prof_t = wall_clock64(); const int prof_k = (K); const bool prof_on = blockIdx.x == 17 && threadIdx.x == 0
+#define RES_MARK(I) do { if (prof_on) { const unsigned long long nw = wall_clock64(); res_prof[prof_k][I] += nw - prof_t; prof_t = nw; } } while (0)
+extern "C" void ptd_debug_res_prof(unsigned long long* out, int reset) {
+  if (reset) { unsigned long long z[32] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(res_prof), z, sizeof(z)); }
+  else (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(res_prof), 32 * sizeof(unsigned long long));
+}
+#else
+#define RES_T0(K)
+#define RES_MARK(I)
+#endif
 struct ResCtl {
   unsigned long long fp[RESG_WG];       // per workgroup: sequence number of its last published entries
   unsigned reg;    unsigned pad1[31];   // registration (agent scope)
@@ -836,7 +848,9 @@ __global__ __launch_bounds__(RES_T) void sytrd_resident_kernel(double* __restric
 #pragma unroll
   for (int i = 0; i < RI; ++i) { vrow_[i] = 0.0; wrow_[i] = 0.0; }
   bool pending = false;
+  RES_T0(0);
   for (int jl = 0; jl < ncols; ++jl) {
+    RES_MARK(7);
     const unsigned long long seq = epoch + (unsigned long long)jl + 1;
     double* Pb = Xbuf + ((jl + 1) & 1) * 2 * RES_XS;        // this column's p entries, then its b entries
     double* Bb = Pb + RES_XS;
@@ -870,6 +884,7 @@ __global__ __launch_bounds__(RES_T) void sytrd_resident_kernel(double* __restric
       if (writer && tid == 0) { taus[t0 + jl] = tau; e[t0 + jl] = beta; d[t0 + jl] = dnext; }
     }
     __syncthreads();
+    RES_MARK(0);
     // ---- the pending update, then p = tau A v and b = A[:, jl + 1] - p for this workgroup's rows
     {
       double acc[RI];
@@ -905,13 +920,16 @@ __global__ __launch_bounds__(RES_T) void sytrd_resident_kernel(double* __restric
         }
       }
     }
+    RES_MARK(1);
     res_publish<GLOBAL>(ctl->fp, slot, seq);
+    RES_MARK(2);
     if (GLOBAL) {
       // one wave watches the 256 numbers (eight waves of 256 workgroups polling four lines were a storm of their own)
       if (wid == 0) { const bool ok = res_wait<NWG>(ctl->fp, seq, lane, ctl); if (lane == 0) flag = ok; }
       __syncthreads();
       if (!flag) return;
     } else if (!res_wait<NWG>(ctl->fp, seq, lane, ctl)) return;
+    RES_MARK(3);
     double pv_[CT], bv_[CT];
     {
       double dp = 0.0;
@@ -928,6 +946,7 @@ __global__ __launch_bounds__(RES_T) void sytrd_resident_kernel(double* __restric
       if (lane == 0) scr[16 + wid] = dp;
     }
     __syncthreads();
+    RES_MARK(4);
     double dot = 0.0;
 #pragma unroll
     for (int w = 0; w < NW; ++w) dot += scr[16 + w];
@@ -954,6 +973,7 @@ __global__ __launch_bounds__(RES_T) void sytrd_resident_kernel(double* __restric
       if (lane == 0) scr[wid] = sq;
     }
     __syncthreads();
+    RES_MARK(5);
     dnext = scr[10];
     // ---- the update A -= v w^T + w v^T waits for the next column's pass (or the one behind the loop)
 #pragma unroll
@@ -997,8 +1017,8 @@ __global__ __launch_bounds__(RES_T) void sytrd_resident3_kernel(double* __restri
                                                                 double* __restrict__ Xbuf, unsigned long long epoch) {
   constexpr int NWG = RESG_WG, NW = RES_T / 64;
   extern __shared__ __attribute__((aligned(16))) char res_smem[];
-  double* vs = reinterpret_cast<double*>(res_smem);
-  double* wv = vs + R3_MAX;
+  double* vsb = reinterpret_cast<double*>(res_smem);   // two v vectors: column jl's in half jl & 1, the pending update's in the other
+  double* wv = vsb + 2 * R3_MAX;
   double* xs = wv + R3_MAX;                   // the current column below its diagonal
   double* part = xs + R3_MAX;                 // [24] partial row products
   double* scr = part + 32;                    // [0, 8) per-wave sums of x^2, [8] alpha, [9] p[jl+1], [10] next diagonal, [16, 24) p^T v
@@ -1033,39 +1053,43 @@ __global__ __launch_bounds__(RES_T) void sytrd_resident3_kernel(double* __restri
         if (lr[i] < m) res_st_f64<true>(Xbuf + RES_XS + lr[i], a[i][0]);
     res_publish<true>(ctl->fp, slot, epoch);
     if (!wait_all(epoch)) return;
+    // its x, the sums of its reflector (alpha = x[1], x^2 over the rows below), and zeros where the first pass looks
+    // for a pending update
+    double sq = 0.0;
 #pragma unroll
     for (int t = 0; t < R3_CT; ++t) {
       const int c = tid + RES_T * t;
-      xs[c] = (c >= 1 && c < m) ? res_ld_f64(Xbuf + RES_XS + c) : 0.0;
+      const double x = (c >= 1 && c < m) ? res_ld_f64(Xbuf + RES_XS + c) : 0.0;
+      xs[c] = x;
+      if (c >= 2) sq += x * x;
+      if (c == 1) scr[8] = x;
+      vsb[R3_MAX + c] = 0.0;
+      wv[c] = 0.0;
     }
     dnext = res_ld_f64(Xbuf + RES_XS);
+    sq = res_wave_sum(sq);
+    if (lane == 0) scr[wid] = sq;
+    __syncthreads();
   }
-  // the rank-2 update of column jl - 1 rides in the product pass of column jl (see sytrd_resident_kernel); the old v
-  // of the lane's columns cannot stay in registers here, so it is kept in a third LDS vector
-  double* vo = scr + 32;                      // [3072] v of the pending update
+  // The rank-2 update of column jl - 1 rides in the product pass of column jl (see sytrd_resident_kernel); the old v of
+  // the lane's columns cannot stay in registers here: the two v vectors alternate between two LDS buffers.  The pass is
+  // straight-line code over all 24 register columns and three half rows: where a row or a column has retired, or no
+  // update is pending, v and w of the update are ZERO there (v_j and w_j vanish up to index j, and tau = 0 gives w = 0),
+  // and the new v is zero over the retired columns -- the arithmetic is a no-op without a predicate.  (With a branch
+  // per register column and a predicate per row the pass took 5.9 us of a 13.8-us column: 517 branches and 27 spilled
+  // registers in the loop, tools/probes/res_prof.py.)
   double vrow_[R3_HR], wrow_[R3_HR];
 #pragma unroll
   for (int i = 0; i < R3_HR; ++i) { vrow_[i] = 0.0; wrow_[i] = 0.0; }
-  bool pending = false;
+  RES_T0(1);
   for (int jl = 0; jl < ncols; ++jl) {
+    RES_MARK(7);
     const unsigned long long seq = epoch + (unsigned long long)jl + 1;
     double* Pb = Xbuf + ((jl + 1) & 1) * 2 * RES_XS;
     double* Bb = Pb + RES_XS;
-    const int kmin = max(0, (jl + 1 - half * R3_HALF) >> 6);     // this half's register columns below are retired
-    // ---- the reflector of column jl: the same arithmetic in every workgroup
-    {
-      double sq = 0.0;
-#pragma unroll
-      for (int t = 0; t < R3_CT; ++t) {
-        const int c = tid + RES_T * t;
-        const double x = xs[c];
-        if (c >= jl + 2) sq += x * x;
-        if (c == jl + 1) scr[8] = x;
-      }
-      sq = res_wave_sum(sq);
-      if (lane == 0) scr[wid] = sq;
-    }
-    __syncthreads();
+    double* vs = vsb + (jl & 1) * R3_MAX;
+    const double* vo = vsb + ((jl & 1) ^ 1) * R3_MAX;
+    // ---- the reflector of column jl: the same arithmetic in every workgroup (its sums came through the last barrier)
     double xn2 = 0.0;
 #pragma unroll
     for (int w = 0; w < NW; ++w) xn2 += scr[w];
@@ -1092,35 +1116,33 @@ __global__ __launch_bounds__(RES_T) void sytrd_resident3_kernel(double* __restri
       if (writer && tid == 0) { taus[t0 + jl] = tau; e[t0 + jl] = beta; d[t0 + jl] = dnext; }
     }
     __syncthreads();
+    RES_MARK(0);
     // ---- the pending update, then the partial products of the half rows
     {
       double acc[R3_HR];
 #pragma unroll
       for (int i = 0; i < R3_HR; ++i) acc[i] = 0.0;
-      const int kold = max(0, (jl - half * R3_HALF) >> 6);
+      const int kold = (jl - half * R3_HALF) >> 6;     // register columns below hold only retired columns (negative: none)
 #pragma unroll
       for (int k = 0; k < R3_CK; ++k) {
-        if (k < kold) continue;
+        if (k < kold) continue;          // (wave-uniform; the branch also keeps the compiler from hoisting all 72 LDS reads)
         const int c = cbase + 64 * k;
-        const double vnew = vs[c];
-        if (pending) {
-          const double wk = wv[c], vold = vo[c];
+        const double vnew = vs[c], wk = wv[c], vold = vo[c];
 #pragma unroll
-          for (int i = 0; i < R3_HR; ++i)
-            if (lr[i] >= jl && lr[i] < m) a[i][k] -= vrow_[i] * wk + wrow_[i] * vold;
+        for (int i = 0; i < R3_HR; ++i) {
+          a[i][k] -= vrow_[i] * wk + wrow_[i] * vold;
+          acc[i] += a[i][k] * vnew;
         }
-        if (k >= kmin)
-#pragma unroll
-          for (int i = 0; i < R3_HR; ++i) acc[i] += a[i][k] * vnew;
       }
 #pragma unroll
       for (int i = 0; i < R3_HR; ++i) {
         const double sacc = res_wave_sum(acc[i]);
         if (lane == 0) part[wid + NW * i] = sacc;
-        vrow_[i] = vs[min(lr[i], R3_MAX - 1)];
+        vrow_[i] = vs[lr[i]];
       }
     }
     __syncthreads();
+    RES_MARK(1);
     // ---- p = tau A v and b = A[:, jl + 1] - p, stored by the lane that holds column jl + 1 of the row
     {
       const int half1 = (jl + 1) >= R3_HALF ? 1 : 0;
@@ -1140,8 +1162,11 @@ __global__ __launch_bounds__(RES_T) void sytrd_resident3_kernel(double* __restri
         }
       }
     }
+    RES_MARK(6);
     res_publish<true>(ctl->fp, slot, seq);
+    RES_MARK(2);
     if (!wait_all(seq)) return;
+    RES_MARK(3);
     double pv_[R3_CT], bv_[R3_CT];
     {
       double dp = 0.0;
@@ -1158,42 +1183,46 @@ __global__ __launch_bounds__(RES_T) void sytrd_resident3_kernel(double* __restri
       if (lane == 0) scr[16 + wid] = dp;
     }
     __syncthreads();
+    RES_MARK(4);
     double dot = 0.0;
 #pragma unroll
     for (int w = 0; w < NW; ++w) dot += scr[16 + w];
     const double hk = 0.5 * tau * dot;
     const double g = scr[9] - 2.0 * hk;
+    {
+      // w, the next column and -- through the same barrier -- the sums of ITS reflector: alpha = x[jl + 2], x^2 below
+      double sq = 0.0;
 #pragma unroll
-    for (int t = 0; t < R3_CT; ++t) {
-      const int c = tid + RES_T * t;
-      const double v = vs[c];
-      wv[c] = pv_[t] - hk * v;
-      const double xn = bv_[t] - v * g;
-      if (c == jl + 1) scr[10] = xn;
-      xs[c] = (c >= jl + 2) ? xn : 0.0;
+      for (int t = 0; t < R3_CT; ++t) {
+        const int c = tid + RES_T * t;
+        const double v = vs[c];
+        wv[c] = pv_[t] - hk * v;
+        const double xn = bv_[t] - v * g;
+        if (c == jl + 1) scr[10] = xn;
+        if (c == jl + 2) scr[8] = xn;
+        xs[c] = (c >= jl + 2) ? xn : 0.0;
+        if (c >= jl + 3) sq += xn * xn;
+      }
+      sq = res_wave_sum(sq);
+      if (lane == 0) scr[wid] = sq;
     }
     __syncthreads();
+    RES_MARK(5);
     dnext = scr[10];
-    // ---- the update waits for the next column's pass; its v moves to vo (vs is rewritten at the top of the loop)
+    // ---- the update waits for the next column's pass (vs of this column is its `vo`)
 #pragma unroll
-    for (int t = 0; t < R3_CT; ++t) {
-      const int c = tid + RES_T * t;
-      vo[c] = vs[c];
-    }
-#pragma unroll
-    for (int i = 0; i < R3_HR; ++i) wrow_[i] = wv[min(lr[i], R3_MAX - 1)];
-    pending = tau != 0.0;
-    // (vo is read in the next pass behind the barrier after the vs writes)
+    for (int i = 0; i < R3_HR; ++i) wrow_[i] = wv[lr[i]];
   }
   if (ncols == m - 1) {
     if (slot == 0 && tid == 0) d[t0 + m - 1] = dnext;
   } else {
+    const double* vo = vsb + ((ncols - 1) & 1) * R3_MAX;
 #pragma unroll
     for (int i = 0; i < R3_HR; ++i)
 #pragma unroll
       for (int k = 0; k < R3_CK; ++k) {
         const int c = cbase + 64 * k;
-        if (pending) a[i][k] -= vrow_[i] * wv[c] + wrow_[i] * vo[c];
+        if (ncols > 0) a[i][k] -= vrow_[i] * wv[c] + wrow_[i] * vo[c];
         if (lr[i] >= ncols && lr[i] < m && c >= ncols && c < m) Aw[(int64_t)(t0 + lr[i]) * ld + t0 + c] = a[i][k];
       }
   }
