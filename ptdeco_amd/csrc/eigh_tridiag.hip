@@ -469,7 +469,9 @@ __global__ __launch_bounds__(256) void sytrd_alpha_kernel(const double* __restri
     const int J0 = jn / TC;
     if (r < n) {
       const int nrow = r / TC - J0 + 1, i0 = r / TR, cnt = nrow + sp.nI - i0;
-      constexpr int SDU = 8;
+      // (up to 16 + n / 64 partials a row: at n <= 4096 every wave asks for all of its 20 at once -- in batches of 8 the
+      // three dependent round trips to memory were ~0.8 us of this launch)
+      constexpr int SDU = 20;
       for (int k0 = wid; k0 < cnt; k0 += 4 * SDU) {
         double v[SDU];
 #pragma unroll
@@ -480,7 +482,10 @@ __global__ __launch_bounds__(256) void sytrd_alpha_kernel(const double* __restri
             v[q] = (k < nrow) ? sp.rowpart[(int64_t)(J0 + k) * sp.ldp + r]
                               : sp.colpart[(int64_t)(i0 + k - nrow) * sp.ldp + r];
         }
-        sdacc += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        double s4[SDU / 4];
+#pragma unroll
+        for (int q = 0; q < SDU / 4; ++q) s4[q] = (v[4 * q] + v[4 * q + 1]) + (v[4 * q + 2] + v[4 * q + 3]);
+        sdacc += ((s4[0] + s4[1]) + (s4[2] + s4[3])) + s4[4];
       }
     }
     const int i0 = jn / TR, cnt = 1 + sp.nI - i0;
