@@ -270,6 +270,13 @@ __device__ __forceinline__ void symv2_tile_body(const double2 (&a0)[16], const d
   }
 }
 
+#ifdef PTD_RES_PROF
+__device__ int symv_dbg;      // probe build: 1 return at once, 2 return when the tile has arrived, 4 no partial-sum stores
+extern "C" void ptd_debug_symv(int v) { (void)hipMemcpyToSymbol(HIP_SYMBOL(symv_dbg), &v, sizeof(int)); }
+#define SYMV_DBG(BIT) (symv_dbg & (BIT))
+#else
+#define SYMV_DBG(BIT) false
+#endif
 __global__ __launch_bounds__(256) void sytrd_symv2_kernel(const double* __restrict__ A, int64_t ld, int n, int j, int i,
                                                           const double* __restrict__ colbuf,
                                                           const double* __restrict__ Vp,
@@ -286,6 +293,7 @@ __global__ __launch_bounds__(256) void sytrd_symv2_kernel(const double* __restri
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int b = blockIdx.x;
   const double* vprev = Vp + (int64_t)max(i - 1, 0) * ldv;  // multiplied by delta == 0 when i == 0
+  if (SYMV_DBG(1)) return;
   if (b < ntiles) {
     // ---- tile (I, J)
     const int g0 = (j + 1) / TC;
@@ -304,6 +312,13 @@ __global__ __launch_bounds__(256) void sytrd_symv2_kernel(const double* __restri
       const double* rowp = A + (int64_t)min(rbase + t, n - 1) * ld;
       a0[t] = *reinterpret_cast<const double2*>(rowp + cA);
       a1[t] = *reinterpret_cast<const double2*>(rowp + cB);
+    }
+    if (SYMV_DBG(2)) {
+      double sink = 0.0;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) sink += a0[t].x + a0[t].y + a1[t].x + a1[t].y;
+      if (sink == 1.2345e-300) xs[0] = sink;
+      return;
     }
     double2 xa = *reinterpret_cast<const double2*>(colbuf + cA);
     double2 xb = *reinterpret_cast<const double2*>(colbuf + cB);
