@@ -660,12 +660,12 @@ constexpr int RES_CHECK = 256;
 constexpr int RES_MAX_POLLS = 20000000;   // second guard, in polls (seconds): the wait ends even if the clock did not advance
 
 #ifdef PTD_RES_PROF
-__device__ unsigned long long res_prof[2][16];
-#define RES_T0(K) unsigned long long prof_t = wall_clock64(); const int prof_k = (K); const bool prof_on = blockIdx.x == 17 && threadIdx.x == 0
+__device__ unsigned long long res_prof[4][16];
+#define RES_T0(K) unsigned long long prof_t = wall_clock64(); const int prof_k = (K); const bool prof_on = blockIdx.x == ((K) >= 2 ? 16 : 17) && threadIdx.x == 0
 #define RES_MARK(I) do { if (prof_on) { const unsigned long long nw = wall_clock64(); res_prof[prof_k][I] += nw - prof_t; prof_t = nw; } } while (0)
 extern "C" void ptd_debug_res_prof(unsigned long long* out, int reset) {
-  if (reset) { unsigned long long z[32] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(res_prof), z, sizeof(z)); }
-  else (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(res_prof), 32 * sizeof(unsigned long long));
+  if (reset) { unsigned long long z[64] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(res_prof), z, sizeof(z)); }
+  else (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(res_prof), 64 * sizeof(unsigned long long));
 }
 #else
 #define RES_T0(K)
@@ -865,16 +865,16 @@ __global__ __launch_bounds__(RES_T) void sytrd_resident_kernel(double* __restric
   double vreg[CK], vrow_[RI], wrow_[RI];
 #pragma unroll
   for (int k = 0; k < CK; ++k) vreg[k] = 0.0;
+  for (int c = tid; c < MAXM; c += RES_T) wv[c] = 0.0;     // (the first pass applies an update of zeros)
 #pragma unroll
   for (int i = 0; i < RI; ++i) { vrow_[i] = 0.0; wrow_[i] = 0.0; }
   bool pending = false;
-  RES_T0(0);
+  RES_T0(GLOBAL ? 0 : (MAXM == RES_MID ? 2 : 3));
   for (int jl = 0; jl < ncols; ++jl) {
     RES_MARK(7);
     const unsigned long long seq = epoch + (unsigned long long)jl + 1;
     double* Pb = Xbuf + ((jl + 1) & 1) * 2 * RES_XS;        // this column's p entries, then its b entries
     double* Bb = Pb + RES_XS;
-    const int kmin = (jl + 1) >> 6;                         // register columns below hold only retired columns
     const int k1 = (jl + 1) >> 6, l1 = (jl + 1) & 63;       // where column jl + 1 sits in the registers
     // ---- the reflector of column jl: the same arithmetic in every workgroup
     double vv[CT];
@@ -910,21 +910,22 @@ __global__ __launch_bounds__(RES_T) void sytrd_resident_kernel(double* __restric
       double acc[RI];
 #pragma unroll
       for (int i = 0; i < RI; ++i) acc[i] = 0.0;
+      // Straight arithmetic on every live register column: where a row or a column has retired, or no update is
+      // pending, v and w of the update are zero (v_j and w_j vanish up to index j; tau = 0 gives w = 0) and the new v is
+      // zero over retired columns, so neither a predicate per row nor a test per column is needed (they were 4 x the
+      // arithmetic: 2.6 us of a 5.5-us column in <32, 1024>, tools/probes/res_prof.py).
       const int kold = jl >> 6;                             // first live register column of the pending update
 #pragma unroll
       for (int k = 0; k < CK; ++k) {
-        if (k < kold) continue;                             // (wave-uniform)
+        if (k < kold) continue;                             // (wave-uniform; also bounds how far the LDS reads are hoisted)
         const double vnew = vs[lane + 64 * k];
-        if (pending) {
-          const double wk = wv[lane + 64 * k];
+        const double wk = wv[lane + 64 * k];
 #pragma unroll
-          for (int i = 0; i < RI; ++i)
-            if (lr[i] >= jl && lr[i] < m) a[i][k] -= vrow_[i] * wk + wrow_[i] * vreg[k];
+        for (int i = 0; i < RI; ++i) {
+          a[i][k] -= vrow_[i] * wk + wrow_[i] * vreg[k];
+          acc[i] += a[i][k] * vnew;
         }
         vreg[k] = vnew;
-        if (k >= kmin)
-#pragma unroll
-          for (int i = 0; i < RI; ++i) acc[i] += a[i][k] * vnew;
       }
 #pragma unroll
       for (int i = 0; i < RI; ++i) vrow_[i] = vs[min(lr[i], MAXM - 1)];
