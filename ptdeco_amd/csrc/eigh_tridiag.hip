@@ -2142,8 +2142,8 @@ __global__ __launch_bounds__(256) void wy_tv_kernel(const double* __restrict__ V
   __shared__ double Ts[NB][NB + 1];
   __shared__ double Vs[NB][129];
   const int panel = blockIdx.y, tid = threadIdx.x;
-  const int r0 = panel * NB + 1;
-  const int c0 = r0 + blockIdx.x * 128;
+  const int r0 = (panel * NB) & ~127;       // (from the 128-column boundary below the panel: zeros up to column j0, which
+  const int c0 = r0 + blockIdx.x * 128;     // the aligned products of the back-transformation read)
   if (c0 >= n) return;
   const double* Vp = Vall + (int64_t)panel * NB * ld;
   for (int e = tid; e < NB * NB; e += 256) Ts[e >> 6][e & 63] = Tall[(int64_t)panel * NB * NB + e];
@@ -2694,9 +2694,13 @@ int tridiag_vectors_and_backtransform(const TridiagPlan& p, char* base, int nvec
   for (int pn = p.npanels - 1; pn >= 0; --pn) {
     const int j0 = pn * NB;
     const int cols = std::min(NB, n - j0);
-    const int r0 = j0 + 1;          // first row any reflector of this panel touches
+    if (n - (j0 + 1) <= 0) continue;          // (j0 + 1: the first row any reflector of this panel touches)
+    // the products start at the 128-row boundary at or below j0: V_p and T_p V_p are zero in the columns before j0 + 1
+    // (Vall is cleared before the reduction), so the extra rows add nothing -- and the operands are 16-byte aligned and
+    // the row count a multiple of 128 where n is, which is what the LDS-DMA kernel of the second product asks for
+    // (from row j0 + 1 both products ran on the generic 64 x 64 kernel: 40 us for a 10-us stream over Y)
+    const int r0 = j0 & ~127;
     const int mr = n - r0;
-    if (mr <= 0) continue;
     const double* Vp = Vall + (size_t)pn * NB * ld;
     const double* TVp = TVall + (size_t)pn * NB * ld;
     // W2 = TV_p Y  (cols x nvec)
