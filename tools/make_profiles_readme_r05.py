@@ -24,6 +24,7 @@ o.append("Files (round 5):\n\n"
          "* `streams_r05.json` -- `tools/r05_probe.py block`: B_eigh of the full-width Llama block over five passes at PTD_EIGH_STREAMS 4 / 6 / 7 (high- and normal-priority candidates: the measurement that sent the default to normal priority, four streams)\n"
          "* `c4_stack_32blocks_bf16_r05.json`, `c4_hf_llama3_8b_r05.json` -- the full-depth runs (`tools/c4_stack.py 32 bf16 --trade-off 640 --max-ppl 0.4`, `tools/c4_hf_llama.py 32`), now with a sample check of one replaced layer (`tools/sample_check.py`)\n"
          "* `bench_r05_rehearsal_2ranks_1gpu.json` -- `PTD_BENCH_REHEARSE=1 python bench.py --gpus 2 --steps 2 --warmup 1`: the N = 2 code path with BOTH ranks on the one GPU of the box: a check that the path runs, not a scaling number\n"
+         "* `fwd_split_r05.txt` -- `tools/fwd_split.py`: the two products of the decomposed forward one by one, package and library, at T = 4096 / 16384 / 65536\n"
          "* `gpu_tests_r05.log` -- `python -m pytest tests -q -m gpu`\n"
          "* `tools/refresh_profiles.sh 05 main|bench|pmc` reruns them on a GPU box\n\n")
 o.append("## Headline\n\n")
@@ -37,7 +38,7 @@ o.append(f"* phases of a C2 step (`phases_ms`): A accumulate {ph['A_accumulate']
 o.append(f"* dominant kernel of the C2 step `gemm_f64_glds_kernel<5, false>` (C X of the Chebyshev filter, 4096 x 4096 x 1280 f64): {ro['achieved']:.1f} TFLOP/s = **{ro['frac']:.2f}** of the 78.6 TFLOP/s f64 MFMA peak, {ro['avg_launch_us']:.0f} us per launch (HIP events inside bench.py; "
          f"rocprofv3 on another box: {sp['long_launches_K4096']} K = 4096 launches average {sp['long_avg_us']:.0f} us, the {sp['short_launches']} shorter X W launches {sp['short_avg_us']:.0f} us); "
          f"`traffic` {ro['traffic'] / 1e6:.0f} MB per launch = {g64['traffic_over_algorithmic']:.2f} x the algorithmic bytes (X once per XCD), matrix-pipe busy {g64['mfma_busy_over_cu_busy_x4_percent']:.0f} %; `solver_frac` {ro['solver_frac']:.2f}.\n")
-o.append(f"* whole eigensolver (filtered route, n = 4096, k = 1024): **{eg['ms_per_matrix']:.1f} ms**; direct route (n = 4096, k = 2048, `c4_shapes.*.down.eigh`): **{c4['f32']['down']['eigh']['ms']:.1f} ms** (round 4: 59.0; the twisted-factorisation work list on one wave per vector: 3.47 -> 1.0 ms); "
+o.append(f"* whole eigensolver (filtered route, n = 4096, k = 1024): **{eg['ms_per_matrix']:.1f} ms**; direct route (n = 4096, k = 2048, `c4_shapes.*.down.eigh`): **{c4['f32']['down']['eigh']['ms']:.1f} ms** (round 4: 59.0; the twisted-factorisation work list on one wave per vector and the resident kernels' pass without predicates, DESIGN section 7 item 1); "
          "three such chains at once on the blocked path: 109.5 ms = 36.5 ms per matrix (`tools/probes/filtered_half.py`).\n\n")
 o.append("## Concurrent chains (`c4_block`, `c4_stack`; five / three timed steps, median reported)\n\n| workload | ms per step (median) | steps | spread | B_eigh | A | D |\n|---|---|---|---|---|---|---|\n")
 for name, d in (("c4_block f32", blk["f32"]), ("c4_block bf16", blk["bf16"]), ("c4_stack bf16 (2 blocks)", stk["bf16"])):
@@ -45,7 +46,7 @@ for name, d in (("c4_block f32", blk["f32"]), ("c4_block bf16", blk["bf16"]), ("
     o.append(f"| {name} | {d['ms_per_step']:.1f} | {d['step_ms']} | {100 * d['spread']:.1f} % | {p_['B_eigh']:.0f} | {p_['A_accumulate']:.1f} | {p_['D_metrics']:.0f} |\n")
 cs = b["config"].get("chain_streams_at_exit", {})
 o.append(f"\nStream checks in that process (`config.chain_streams_at_exit`): {cs}.  Round 4's line had 394.5 / 345.5 ms for two steps of `c4_block` bf16 in one process.\n\n")
-o.append("## Kernels (HIP events in bench.py, median of three loops; MfmaUtil from `pmc_mfma_r05.json`)\n\n| line | ms | rate | of peak | MfmaUtil |\n|---|---|---|---|---|\n")
+o.append("## Kernels (HIP events in bench.py, median of three loops of at least 40 ms each; MfmaUtil from `pmc_mfma_r05.json`)\n\n| line | ms | rate | of peak | MfmaUtil |\n|---|---|---|---|---|\n")
 
 
 def mu(key):
