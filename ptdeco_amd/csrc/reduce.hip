@@ -272,14 +272,16 @@ __global__ __launch_bounds__(256) void nsr_final_kernel(const double* __restrict
   if (q == 0) {
     acc = wave_sum(acc);
     if (cl == 0) {
-      blocksum[blockIdx.x] = acc;
-      __threadfence();
-      last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+      // written through to memory and acknowledged before the ticket is drawn; the last block reads the sums past its
+      // caches (device-scope loads).  A __threadfence() here is a write-back of the whole L2 -- behind the layer
+      // products of a metric forward it made this 4-us kernel take 16 (rocprofv3, C2 workload).
+      __hip_atomic_store(&blocksum[blockIdx.x], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
     }
   }
   __syncthreads();
   if (!last) return;
-  __threadfence();
   double t = 0.0;
   for (unsigned i = threadIdx.x; i < gridDim.x; i += 256) t += __hip_atomic_load(&blocksum[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   t = wave_sum(t);
