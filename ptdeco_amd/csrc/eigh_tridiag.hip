@@ -2142,8 +2142,8 @@ __global__ __launch_bounds__(256) void wy_tv_kernel(const double* __restrict__ V
   __shared__ double Ts[NB][NB + 1];
   __shared__ double Vs[NB][129];
   const int panel = blockIdx.y, tid = threadIdx.x;
-  const int r0 = (panel * NB) & ~127;       // (from the 128-column boundary below the panel: zeros up to column j0, which
-  const int c0 = r0 + blockIdx.x * 128;     // the aligned products of the back-transformation read)
+  const int r0 = (panel & ~3) * NB;         // (from the first column of the panel's GROUP of four: zeros up to the panel's
+  const int c0 = r0 + blockIdx.x * 128;     // own column j0, which the grouped products of the back-transformation read)
   if (c0 >= n) return;
   const double* Vp = Vall + (int64_t)panel * NB * ld;
   for (int e = tid; e < NB * NB; e += 256) Ts[e >> 6][e & 63] = Tall[(int64_t)panel * NB * NB + e];
@@ -2166,6 +2166,134 @@ __global__ __launch_bounds__(256) void wy_tv_kernel(const double* __restrict__ V
     }
     out[(int64_t)i0 * ld] = s0; out[(int64_t)(i0 + 1) * ld] = s1;
     out[(int64_t)(i0 + 2) * ld] = s2; out[(int64_t)(i0 + 3) * ld] = s3;
+  }
+}
+
+// ---- four panels as ONE block reflector of 256 rows.  A panel's two products of the back-transformation have K = 64 or
+// M = 64: 25 us each for a 5 / 10-us stream over Y, 64 times.  For consecutive panels a < b < c < d (applied d first)
+//   Q_a Q_b Q_c Q_d Y = Y - [V_a; V_b; V_c; V_d]^T [W_a; W_b; W_c; W_d],   W_d = TV_d Y,  W_c = TV_c Y - S_cd W_d,
+//   W_b = TV_b Y - S_bc W_c - S_bd W_d, ...   with S_xy = TV_x V_y^T (64 x 64),
+// so with TV'_d = TV_d, TV'_c = TV_c - S_cd TV'_d, TV'_b = TV_b - S_bc TV'_c - S_bd TV'_d, ... the group is applied as
+// Y -= V_g^T (TV'_g Y): two products of 256 rows / K = 256 per FOUR panels.  Three launches for all groups up front:
+//   wy_cross      partial S_xy over column chunks (the six pairs of every group)
+//   wy_cross_sum  their sums in chunk order
+//   wy_merge      the substitution above on 64-column slabs of TV (in place)
+constexpr int WYG = 4;        // panels per group
+constexpr int XCH = 1024;     // columns per wy_cross workgroup
+__device__ __constant__ const int wy_pair_x[6] = {0, 0, 0, 1, 1, 2};
+__device__ __constant__ const int wy_pair_y[6] = {1, 2, 3, 2, 3, 3};
+
+__global__ __launch_bounds__(256) void wy_cross_kernel(const double* __restrict__ TVall, const double* __restrict__ Vall,
+                                                       int64_t ld, int n, int npanels, double* __restrict__ Spart,
+                                                       int nchunks) {
+  __shared__ double As[NB][65];
+  __shared__ double Bs[NB][65];
+  const int chunk = blockIdx.x, q = blockIdx.y, g = blockIdx.z, tid = threadIdx.x;
+  const int px = WYG * g + wy_pair_x[q], py = WYG * g + wy_pair_y[q];
+  if (py >= npanels) return;
+  const int cbeg = WYG * NB * g + chunk * XCH, cend = min(n, cbeg + XCH);
+  const int ti = tid >> 4, tj = tid & 15;
+  double acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+  const double* Ax = TVall + (int64_t)px * NB * ld;
+  const double* By = Vall + (int64_t)py * NB * ld;
+  for (int c0 = cbeg; c0 < cend; c0 += 64) {
+    for (int e = tid; e < NB * 64; e += 256) {
+      const int r = e >> 6, c = e & 63;
+      const bool ok = c0 + c < cend;
+      As[r][c] = ok ? Ax[(int64_t)r * ld + c0 + c] : 0.0;
+      Bs[r][c] = ok ? By[(int64_t)r * ld + c0 + c] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int c = 0; c < 64; ++c) {
+      double va[4], vb[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) { va[a] = As[4 * ti + a][c]; vb[a] = Bs[4 * tj + a][c]; }
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] += va[a] * vb[b];
+    }
+    __syncthreads();
+  }
+  double* out = Spart + (((int64_t)g * 6 + q) * nchunks + chunk) * NB * NB;
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) out[(4 * ti + a) * NB + 4 * tj + b] = acc[a][b];
+}
+
+__global__ __launch_bounds__(256) void wy_cross_sum_kernel(const double* __restrict__ Spart, int n, int nchunks,
+                                                           double* __restrict__ S) {
+  const int gq = blockIdx.x, g = gq / 6;
+  const int used = (int)((n - WYG * NB * g + XCH - 1) / XCH);     // chunks of this group that lie inside the matrix
+  for (int e = threadIdx.x; e < NB * NB; e += 256) {
+    double t = 0.0;
+    for (int c = 0; c < used; ++c) t += Spart[((int64_t)gq * nchunks + c) * NB * NB + e];   // fixed order
+    S[(int64_t)gq * NB * NB + e] = t;
+  }
+}
+
+// one 64-column slab of a group's TV rows: P_x <- TV_x - sum_{y > x} S_xy P_y, x = gsize - 2 .. 0 (P_y: the finished slabs)
+__global__ __launch_bounds__(256) void wy_merge_kernel(double* __restrict__ TVall, int64_t ld, int n, int npanels,
+                                                       const double* __restrict__ S) {
+  extern __shared__ __attribute__((aligned(16))) double mg_smem[];
+  double (*P)[NB][65] = reinterpret_cast<double (*)[NB][65]>(mg_smem);          // [3]: finished slabs of panels 1 .. 3
+  double (*Ss)[65] = reinterpret_cast<double (*)[65]>(mg_smem + 3 * NB * 65);
+  const int g = blockIdx.y, tid = threadIdx.x;
+  const int gsize = min(WYG, npanels - WYG * g);
+  const int c0 = WYG * NB * g + blockIdx.x * 64;
+  if (c0 >= n || gsize < 2) return;
+  const int ti = tid >> 4, tj = tid & 15;
+  const int ncol = min(64, n - c0);
+  // the last panel of the group is its own P
+  {
+    const double* src = TVall + (int64_t)(WYG * g + gsize - 1) * NB * ld + c0;
+    for (int e = tid; e < NB * 64; e += 256) {
+      const int r = e >> 6, c = e & 63;
+      P[gsize - 2][r][c] = c < ncol ? src[(int64_t)r * ld + c] : 0.0;
+    }
+  }
+  for (int x = gsize - 2; x >= 0; --x) {
+    double* dst = TVall + (int64_t)(WYG * g + x) * NB * ld + c0;
+    double acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int c = 4 * tj + b;
+        acc[a][b] = c < ncol ? dst[(int64_t)(4 * ti + a) * ld + c] : 0.0;
+      }
+    for (int y = x + 1; y < gsize; ++y) {
+      int q = 0;
+      for (int t = 0; t < 6; ++t) if (wy_pair_x[t] == x && wy_pair_y[t] == y) q = t;
+      __syncthreads();                              // (the previous S block and, the first time, P are complete / consumed)
+      for (int e = tid; e < NB * NB; e += 256) Ss[e >> 6][e & 63] = S[((int64_t)g * 6 + q) * NB * NB + e];
+      __syncthreads();
+      const double (*Py)[65] = P[y - 1];
+#pragma unroll 4
+      for (int k = 0; k < NB; ++k) {
+        double sv[4], pv[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) { sv[a] = Ss[4 * ti + a][k]; pv[a] = Py[k][4 * tj + a]; }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) acc[a][b] -= sv[a] * pv[b];
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int c = 4 * tj + b;
+        if (c < ncol) dst[(int64_t)(4 * ti + a) * ld + c] = acc[a][b];
+        if (x >= 1) P[x - 1][4 * ti + a][c] = acc[a][b];
+      }
   }
 }
 
@@ -2691,24 +2819,49 @@ int tridiag_vectors_and_backtransform(const TridiagPlan& p, char* base, int nvec
                        n, Tall, TVall);
     PTD_CHECK_LAUNCH("wy factors");
   }
-  for (int pn = p.npanels - 1; pn >= 0; --pn) {
+  // groups of four panels as one block reflector (see wy_cross_kernel); PTD_EIGH_WY_GROUP=0: panel by panel
+  static const bool no_group = getenv("PTD_EIGH_WY_GROUP") && atoi(getenv("PTD_EIGH_WY_GROUP")) == 0;
+  const int ngroups = (int)ceil_div(p.npanels, WYG);
+  const int xchunks = (int)ceil_div(n, XCH);
+  // (the factors of the inverse iteration are dead by now: the group's W, the partial and the summed S live there)
+  double* Wg = reinterpret_cast<double*>(base + p.off_u1);
+  double* Spart = Wg + (size_t)WYG * NB * nvec;
+  double* Sall = Spart + (size_t)ngroups * 6 * xchunks * NB * NB;
+  const bool grouped = !no_group && n >= 2048 &&      // (below, the three extra launches cost what the fewer products save)
+                       ((size_t)WYG * NB * nvec + (size_t)ngroups * 6 * (xchunks + 1) * NB * NB) * 8 <= (size_t)(p.off_u2 - p.off_u1);
+  if (grouped) {
+    constexpr int MERGE_LDS = (3 * NB * 65 + NB * 65) * 8;
+    const bool attr = hipFuncSetAttribute(reinterpret_cast<const void*>(wy_merge_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, MERGE_LDS) == hipSuccess;
+    PTD_REQUIRE(attr, "tridiag_backtransform: cannot reserve LDS");
+    hipLaunchKernelGGL(wy_cross_kernel, dim3((unsigned)xchunks, 6, (unsigned)ngroups), dim3(256), 0, st, TVall, Vall, ld, n,
+                       p.npanels, Spart, xchunks);
+    hipLaunchKernelGGL(wy_cross_sum_kernel, dim3((unsigned)(6 * ngroups)), dim3(256), 0, st, Spart, n, xchunks, Sall);
+    hipLaunchKernelGGL(wy_merge_kernel, dim3((unsigned)ceil_div(n, 64), (unsigned)ngroups), dim3(256), MERGE_LDS, st, TVall,
+                       ld, n, p.npanels, Sall);
+    PTD_CHECK_LAUNCH("wy groups");
+  }
+  const int step = grouped ? WYG : 1;
+  for (int gi = (p.npanels - 1) / step; gi >= 0; --gi) {
+    const int pn = gi * step;                          // first panel of the group
     const int j0 = pn * NB;
-    const int cols = std::min(NB, n - j0);
-    if (n - (j0 + 1) <= 0) continue;          // (j0 + 1: the first row any reflector of this panel touches)
-    // the products start at the 128-row boundary at or below j0: V_p and T_p V_p are zero in the columns before j0 + 1
-    // (Vall is cleared before the reduction), so the extra rows add nothing -- and the operands are 16-byte aligned and
-    // the row count a multiple of 128 where n is, which is what the LDS-DMA kernel of the second product asks for
-    // (from row j0 + 1 both products ran on the generic 64 x 64 kernel: 40 us for a 10-us stream over Y)
+    const int rows = std::min(step * NB, n - j0);      // reflectors of the group
+    if (n - (j0 + 1) <= 0) continue;          // (j0 + 1: the first row any reflector of this group touches)
+    // the products start at the 128-row boundary at or below j0: V_p and T_p V_p are zero in the columns before a panel's
+    // first reflector (Vall is cleared before the reduction, wy_tv writes zeros from the group's first column), so the
+    // extra rows add nothing -- and the operands are 16-byte aligned and the row count a multiple of 128 where n is, which
+    // is what the LDS-DMA kernel asks for (from row j0 + 1 both products ran on the generic 64 x 64 kernel)
     const int r0 = j0 & ~127;
     const int mr = n - r0;
     const double* Vp = Vall + (size_t)pn * NB * ld;
     const double* TVp = TVall + (size_t)pn * NB * ld;
-    // W2 = TV_p Y  (cols x nvec)
-    PTD_CHECK_HIP(hipMemsetAsync(W2, 0, (size_t)NB * nvec * 8, st));
-    int rc = gemm_f64(TVp + r0, ld, 1, Y + (int64_t)r0 * ldy, ldy, 1, W2, nvec, cols, nvec, mr, 1.0, true, 16, st);
+    double* Wp2 = grouped ? Wg : W2;
+    // W = TV_g Y  (rows x nvec)
+    PTD_CHECK_HIP(hipMemsetAsync(Wp2, 0, (size_t)rows * nvec * 8, st));
+    int rc = gemm_f64(TVp + r0, ld, 1, Y + (int64_t)r0 * ldy, ldy, 1, Wp2, nvec, rows, nvec, mr, 1.0, true, 16, st);
     if (rc != PTD_OK) return rc;
-    // Y[r0:, :] -= V^T W2
-    rc = gemm_f64(Vp + r0, 1, ld, W2, nvec, 1, Y + (int64_t)r0 * ldy, ldy, mr, nvec, cols, -1.0, true, 1, st);
+    // Y[r0:, :] -= V_g^T W
+    rc = gemm_f64(Vp + r0, 1, ld, Wp2, nvec, 1, Y + (int64_t)r0 * ldy, ldy, mr, nvec, rows, -1.0, true, 1, st);
     if (rc != PTD_OK) return rc;
   }
   PTD_CHECK_LAUNCH("tridiag_backtransform");
