@@ -1307,13 +1307,18 @@ __device__ __forceinline__ int sturm_count(Row row, int n, double xs) {
   int cnt = p < 0.0;
   int k = 1;
   for (; k + 8 <= n; k += 8) {
+    // sign changes of the eight steps as bits: the high words' signs xor-ed, shifted into `bits` (v_xor + v_alignbit a
+    // row instead of two f64 compares and their mask arithmetic -- the loop is bound by its VALU instruction count,
+    // ~10 a row: 134 cycles a row-step with two waves a SIMD), counted once per group
+    unsigned bits = 0;
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const double2 t = row(k + u);
       const double pn = fma(t.x - xs, p, -(t.y * pm));
-      cnt += (pn < 0.0) != (p < 0.0);
+      bits = __builtin_amdgcn_alignbit(bits, (unsigned)(__double2hiint(pn) ^ __double2hiint(p)), 31);
       pm = p; p = pn;
     }
+    cnt += __builtin_popcount(bits);
     // renormalise: max(|p|, |pm|) back to [1, 2); two zero minors in a row (a split matrix hit exactly)
     // restart the sequence below the split
     const double m = fmax(fabs(p), fabs(pm));
