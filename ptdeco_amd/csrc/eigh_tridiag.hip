@@ -649,7 +649,7 @@ constexpr int RES_WG = 32;
 constexpr int RESG_MAX = 2048;                           // the whole chip: 256 workgroups, hand-offs through memory
 constexpr int RESG_WG = 256;
 constexpr int RES_T = 512;
-constexpr int RES_XS = 3072 + 64;                        // one exchange vector (the widest kernel: R3_MAX)
+constexpr int RES_XS = 3328 + 64;                        // one exchange vector (the widest kernel: R4_MAX)
 constexpr size_t RES_LDS = 150 * 1024;   // two vectors and scalars; sized so that a CU takes exactly one workgroup
 // Waits are bounded in TIME (wall_clock64: the 100 MHz constant clock), not in polls: 10 ms is three orders above
 // the longest legitimate wait (a hand-off: microseconds) and short against the blocked repeat it triggers.  The clock
@@ -660,12 +660,12 @@ constexpr int RES_CHECK = 256;
 constexpr int RES_MAX_POLLS = 20000000;   // second guard, in polls (seconds): the wait ends even if the clock did not advance
 
 #ifdef PTD_RES_PROF
-__device__ unsigned long long res_prof[4][16];
+__device__ unsigned long long res_prof[5][16];
 #define RES_T0(K) unsigned long long prof_t = wall_clock64(); const int prof_k = (K); const bool prof_on = blockIdx.x == ((K) >= 2 ? 16 : 17) && threadIdx.x == 0
 #define RES_MARK(I) do { if (prof_on) { const unsigned long long nw = wall_clock64(); res_prof[prof_k][I] += nw - prof_t; prof_t = nw; } } while (0)
 extern "C" void ptd_debug_res_prof(unsigned long long* out, int reset) {
-  if (reset) { unsigned long long z[64] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(res_prof), z, sizeof(z)); }
-  else (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(res_prof), 64 * sizeof(unsigned long long));
+  if (reset) { unsigned long long z[80] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(res_prof), z, sizeof(z)); }
+  else (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(res_prof), 80 * sizeof(unsigned long long));
 }
 #else
 #define RES_T0(K)
@@ -1245,6 +1245,234 @@ __global__ __launch_bounds__(RES_T) void sytrd_resident3_kernel(double* __restri
         const int c = cbase + 64 * k;
         if (ncols > 0) a[i][k] -= vrow_[i] * wv[c] + wrow_[i] * vo[c];
         if (lr[i] >= ncols && lr[i] < m && c >= ncols && c < m) Aw[(int64_t)(t0 + lr[i]) * ld + t0 + c] = a[i][k];
+      }
+  }
+}
+
+// The whole-chip kernel in FRONT of the half-row one: trailing orders 3328 .. 3073, 13 rows a workgroup on FOUR waves
+// (one per SIMD: 512 registers a lane).  Wave w holds column quarter w (832 columns = 13 register columns) of all 13
+// rows of the workgroup -- 169 doubles a lane, of which the compiler keeps what does not fit the 256 architectural
+// registers in the accumulation file -- so a lane reads v, w and the old v of its 13 columns once for 13 rows (39 LDS
+// reads a column where the half-row kernel has 72), and a row's product is the sum over the 256 lanes that hold a
+// piece of it: every lane leaves its 13 partial sums in LDS and sixteen threads per row add them up.  A column moved
+// from the blocked path (two launches, ~21 us + the panel updates) into this kernel costs what a hand-off costs plus
+// its pass; the kernel stops at 3072, where the half-row kernel's pass is cheaper (72 doubles in plain registers).
+constexpr int R4_MAX = 3328;
+constexpr int R4_T = 256;
+constexpr int R4_ROWS = R4_MAX / RESG_WG;   // 13 rows of a workgroup
+constexpr int R4_Q = R4_MAX / 4;            // columns of a wave's quarter
+constexpr int R4_CK = R4_Q / 64;            // register columns per lane and row
+constexpr int R4_CT = R4_MAX / R4_T;        // vector entries formed per thread
+static_assert(R4_MAX + 64 <= RES_XS, "exchange vectors");
+
+__global__ __launch_bounds__(R4_T) void sytrd_resident4_kernel(double* __restrict__ Aw, int64_t ld, int n, int t0,
+                                                               int ncols, double* __restrict__ Vall,
+                                                               double* __restrict__ taus, double* __restrict__ d,
+                                                               double* __restrict__ e, ResCtl* __restrict__ ctl,
+                                                               double* __restrict__ Xbuf, unsigned long long epoch) {
+  constexpr int NWG = RESG_WG, NW = R4_T / 64;
+  extern __shared__ __attribute__((aligned(16))) char res_smem[];
+  double* vsb = reinterpret_cast<double*>(res_smem);   // two v vectors: column jl's in half jl & 1, the pending update's in the other
+  double* wv = vsb + 2 * R4_MAX;
+  double* xs = wv + R4_MAX;                   // the current column below its diagonal
+  double* red = xs + R4_MAX;                  // [13][256] every lane's partial row products
+  double* aj = red + R4_ROWS * R4_T;          // [16] A[row q][jl + 1] (after the pending update)
+  double* scr = aj + 16;                      // [0, 4) per-wave sums of x^2, [8] alpha, [9] p[jl+1], [10] next diagonal, [16, 20) p^T v
+  __shared__ int flag;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int slot = blockIdx.x;
+  const int m = n - t0;
+  const int cbase = wid * R4_Q + lane;
+  double a[R4_ROWS][R4_CK];
+#pragma unroll
+  for (int q = 0; q < R4_ROWS; ++q) {
+    const int row = slot + NWG * q;
+    const double* src = Aw + (int64_t)(t0 + min(row, m - 1)) * ld + t0;
+#pragma unroll
+    for (int k = 0; k < R4_CK; ++k) {
+      const int c = cbase + 64 * k;
+      a[q][k] = (row < m && c < m) ? src[c] : 0.0;
+    }
+  }
+  auto wait_all = [&](unsigned long long seq) -> bool {
+    if (wid == 0) { const bool ok = res_wait<NWG>(ctl->fp, seq, lane, ctl); if (lane == 0) flag = ok; }
+    __syncthreads();
+    return flag != 0;
+  };
+  double dnext;
+  {
+    // column 0 is gathered as it lies: b = A[:, 0], p = 0
+    if (wid == 0 && lane == 0)
+#pragma unroll
+      for (int q = 0; q < R4_ROWS; ++q)
+        if (slot + NWG * q < m) res_st_f64<true>(Xbuf + RES_XS + slot + NWG * q, a[q][0]);
+    res_publish<true>(ctl->fp, slot, epoch);
+    if (!wait_all(epoch)) return;
+    double sq = 0.0;
+#pragma unroll
+    for (int t = 0; t < R4_CT; ++t) {
+      const int c = tid + R4_T * t;
+      const double x = (c >= 1 && c < m) ? res_ld_f64(Xbuf + RES_XS + c) : 0.0;
+      xs[c] = x;
+      if (c >= 2) sq += x * x;
+      if (c == 1) scr[8] = x;
+      vsb[R4_MAX + c] = 0.0;
+      wv[c] = 0.0;
+    }
+    dnext = res_ld_f64(Xbuf + RES_XS);
+    sq = res_wave_sum(sq);
+    if (lane == 0) scr[wid] = sq;
+    __syncthreads();
+  }
+  double vrow_[R4_ROWS], wrow_[R4_ROWS];
+#pragma unroll
+  for (int q = 0; q < R4_ROWS; ++q) { vrow_[q] = 0.0; wrow_[q] = 0.0; }
+  RES_T0(4);
+  for (int jl = 0; jl < ncols; ++jl) {
+    RES_MARK(7);
+    const unsigned long long seq = epoch + (unsigned long long)jl + 1;
+    double* Pb = Xbuf + ((jl + 1) & 1) * 2 * RES_XS;
+    double* Bb = Pb + RES_XS;
+    double* vs = vsb + (jl & 1) * R4_MAX;
+    const double* vo = vsb + ((jl & 1) ^ 1) * R4_MAX;
+    // ---- the reflector of column jl: the same arithmetic in every workgroup (its sums came through the last barrier)
+    double xn2 = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) xn2 += scr[w];
+    const double alpha = scr[8];
+    double tau, beta, scale;
+    if (xn2 == 0.0) {
+      tau = 0.0; beta = alpha; scale = 0.0;
+    } else {
+      const double nrm = sqrt(alpha * alpha + xn2);
+      beta = alpha >= 0.0 ? -nrm : nrm;
+      tau = (beta - alpha) / beta;
+      scale = 1.0 / (alpha - beta);
+    }
+    {
+      double* vrow = Vall + (int64_t)(t0 + jl) * ld + t0;
+      const bool writer = slot == (jl & (NWG - 1));
+#pragma unroll
+      for (int t = 0; t < R4_CT; ++t) {
+        const int c = tid + R4_T * t;
+        const double v = (c == jl + 1) ? 1.0 : ((c > jl + 1) ? xs[c] * scale : 0.0);
+        vs[c] = v;
+        if (writer && c > jl && c < m) vrow[c] = v;
+      }
+      if (writer && tid == 0) { taus[t0 + jl] = tau; e[t0 + jl] = beta; d[t0 + jl] = dnext; }
+    }
+    __syncthreads();
+    RES_MARK(0);
+    // ---- the pending update, then every lane's partial products of the 13 rows (straight arithmetic: see the half-row
+    // kernel); the lane that holds column jl + 1 leaves the updated entries of that column for the b values
+    {
+      double acc[R4_ROWS];
+#pragma unroll
+      for (int q = 0; q < R4_ROWS; ++q) acc[q] = 0.0;
+      const int kold = (jl - wid * R4_Q) >> 6;         // register columns below hold only retired columns (negative: none)
+      const int w1 = (jl + 1) / R4_Q;
+      const int l1 = (jl + 1 - w1 * R4_Q) & 63, k1 = (jl + 1 - w1 * R4_Q) >> 6;
+#pragma unroll
+      for (int k = 0; k < R4_CK; ++k) {
+        if (k < kold) continue;          // (wave-uniform)
+        const int c = cbase + 64 * k;
+        const double vnew = vs[c], wk = wv[c], vold = vo[c];
+#pragma unroll
+        for (int q = 0; q < R4_ROWS; ++q) {
+          a[q][k] -= vrow_[q] * wk + wrow_[q] * vold;
+          acc[q] += a[q][k] * vnew;
+        }
+        if (wid == w1 && k == k1) {      // (wave-uniform)
+          if (lane == l1)
+#pragma unroll
+            for (int q = 0; q < R4_ROWS; ++q) aj[q] = a[q][k];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < R4_ROWS; ++q) {
+        red[q * R4_T + tid] = acc[q];
+        vrow_[q] = vs[slot + NWG * q];
+      }
+    }
+    __syncthreads();
+    RES_MARK(1);
+    // ---- p = tau A v and b = A[:, jl + 1] - p: sixteen threads add up a row's 256 partial sums
+    if (tid < 16 * R4_ROWS) {
+      const int q = tid >> 4, sub = tid & 15;
+      double sacc = 0.0;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) sacc += red[q * R4_T + sub + 16 * i];
+      sacc += res_dpp<0xB1>(sacc);
+      sacc += res_dpp<0x4E>(sacc);
+      sacc += res_dpp<0x124>(sacc);
+      sacc += res_dpp<0x128>(sacc);
+      const int row = slot + NWG * q;
+      if (sub == 0 && row > jl && row < m) {
+        const double pi = tau * sacc;
+        res_st_f64<true>(Pb + row, pi);
+        res_st_f64<true>(Bb + row, aj[q] - pi);
+      }
+    }
+    RES_MARK(6);
+    res_publish<true>(ctl->fp, slot, seq);
+    RES_MARK(2);
+    if (!wait_all(seq)) return;
+    RES_MARK(3);
+    double pv_[R4_CT], bv_[R4_CT];
+    {
+      double dp = 0.0;
+#pragma unroll
+      for (int t = 0; t < R4_CT; ++t) {
+        const int c = tid + R4_T * t;
+        const bool ok = c > jl && c < m;
+        pv_[t] = ok ? res_ld_f64(Pb + c) : 0.0;
+        bv_[t] = ok ? res_ld_f64(Bb + c) : 0.0;
+        dp += pv_[t] * vs[c];
+        if (c == jl + 1) scr[9] = pv_[t];
+      }
+      dp = res_wave_sum(dp);
+      if (lane == 0) scr[16 + wid] = dp;
+    }
+    __syncthreads();
+    RES_MARK(4);
+    double dot = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) dot += scr[16 + w];
+    const double hk = 0.5 * tau * dot;
+    const double g = scr[9] - 2.0 * hk;
+    {
+      double sq = 0.0;
+#pragma unroll
+      for (int t = 0; t < R4_CT; ++t) {
+        const int c = tid + R4_T * t;
+        const double v = vs[c];
+        wv[c] = pv_[t] - hk * v;
+        const double xn = bv_[t] - v * g;
+        if (c == jl + 1) scr[10] = xn;
+        if (c == jl + 2) scr[8] = xn;
+        xs[c] = (c >= jl + 2) ? xn : 0.0;
+        if (c >= jl + 3) sq += xn * xn;
+      }
+      sq = res_wave_sum(sq);
+      if (lane == 0) scr[wid] = sq;
+    }
+    __syncthreads();
+    RES_MARK(5);
+    dnext = scr[10];
+#pragma unroll
+    for (int q = 0; q < R4_ROWS; ++q) wrow_[q] = wv[slot + NWG * q];
+  }
+  if (ncols == m - 1) {
+    if (slot == 0 && tid == 0) d[t0 + m - 1] = dnext;
+  } else {
+    const double* vo = vsb + ((ncols - 1) & 1) * R4_MAX;
+#pragma unroll
+    for (int q = 0; q < R4_ROWS; ++q)
+#pragma unroll
+      for (int k = 0; k < R4_CK; ++k) {
+        const int c = cbase + 64 * k, row = slot + NWG * q;
+        if (ncols > 0) a[q][k] -= vrow_[q] * wv[c] + wrow_[q] * vo[c];
+        if (row >= ncols && row < m && c >= ncols && c < m) Aw[(int64_t)(t0 + row) * ld + t0 + c] = a[q][k];
       }
   }
 }
@@ -2449,24 +2677,27 @@ void probe_device(DeviceState& ds) {
   ds.cus = prop.multiProcessorCount;
   ds.gfx950 = strncmp(prop.gcnArchName, "gfx950", 6) == 0;
   // (the attribute belongs to this device's copy of the function; it is set again before every launch)
-  const void* kernels[4] = {reinterpret_cast<const void*>(sytrd_resident_kernel<RES_WG, RES_MAX, false>),
+  const void* kernels[5] = {reinterpret_cast<const void*>(sytrd_resident_kernel<RES_WG, RES_MAX, false>),
                             reinterpret_cast<const void*>(sytrd_resident_kernel<RES_WG, RES_MID, false>),
                             reinterpret_cast<const void*>(sytrd_resident_kernel<RESG_WG, RESG_MAX, true>),
-                            reinterpret_cast<const void*>(sytrd_resident3_kernel)};
+                            reinterpret_cast<const void*>(sytrd_resident3_kernel),
+                            reinterpret_cast<const void*>(sytrd_resident4_kernel)};
   bool ok = true;
   for (const void* f : kernels) {
     int blocks = 0;
+    const int threads = f == kernels[4] ? R4_T : RES_T;
     ok = ok && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RES_LDS) == hipSuccess &&
-         hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, f, RES_T, RES_LDS) == hipSuccess && blocks >= 1;
+         hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, f, threads, RES_LDS) == hipSuccess && blocks >= 1;
   }
   ds.occupancy_ok = ok;
 }
 
 // PTD_SYTRD_RESIDENT: 0 off; 1 the one-XCD tail only; 2 test hook, see sytrd_f64; 3 whole-chip kernel from a trailing
-// order of 2048, then the one-XCD tail; 4 (default) the half-row whole-chip kernel from 3072 in front of those
+// order of 2048, then the one-XCD tail; 4 the half-row whole-chip kernel from 3072 in front of those; 5 (default) the
+// four-wave quarter-row kernel from 3328 in front of that
 int resident_mode() {
   const char* env = getenv("PTD_SYTRD_RESIDENT");
-  return env ? atoi(env) : 4;
+  return env ? atoi(env) : 5;
 }
 // first column of the resident part: the first panel boundary with a trailing order the kernels take; n itself
 // (= nothing resident) when they may not run here and now
@@ -2488,7 +2719,7 @@ int resident_start(int n) {
   int left = ds.skip.load(std::memory_order_relaxed);
   while (left > 0)
     if (ds.skip.compare_exchange_weak(left, left - 1, std::memory_order_relaxed)) return n;
-  const int cap = n <= RES_MAX ? RES_MAX : (mode == 4 ? R3_MAX : (mode == 3 ? RESG_MAX : RES_MAX));
+  const int cap = n <= RES_MAX ? RES_MAX : (mode >= 5 ? R4_MAX : (mode == 4 ? R3_MAX : (mode == 3 ? RESG_MAX : RES_MAX)));
   return n <= cap ? 0 : (int)align_up((size_t)(n - cap), NB);
 }
 void resident_failed(int status) {
@@ -2560,16 +2791,26 @@ int sytrd_f64(const TridiagPlan& p, char* base, SymvTimer* timer, bool resident,
           hipFuncSetAttribute(reinterpret_cast<const void*>(sytrd_resident_kernel<RESG_WG, RESG_MAX, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)RES_LDS) == hipSuccess &&
           hipFuncSetAttribute(reinterpret_cast<const void*>(sytrd_resident3_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)RES_LDS) == hipSuccess &&
+          hipFuncSetAttribute(reinterpret_cast<const void*>(sytrd_resident4_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)RES_LDS) == hipSuccess;
       PTD_REQUIRE(attr, "sytrd_f64: cannot reserve the LDS of the resident tail");
       static std::atomic<unsigned long long> calls{0};
       static_assert(RESG_MAX < (1 << 16), "sequence numbers of one launch: epoch .. epoch + m");
-      int t1 = j0, t2 = j0;
-      if (n - j0 > RESG_MAX) {
-        // half rows first: down to a trailing order of 2048
+      int t1 = j0, t2 = j0, t3 = j0;
+      if (n - j0 > R3_MAX) {
+        // quarter rows on four waves first: down to a trailing order of 3072
+        const unsigned long long epoch = (calls.fetch_add(1) + 1) << 16;
+        t3 = n - R3_MAX;
+        hipLaunchKernelGGL(sytrd_resident4_kernel, dim3(RESG_WG), dim3(R4_T), RES_LDS, st, Aw, ld, n, j0, t3 - j0, Vall,
+                           taus, d, e, rctl, X, epoch);
+      }
+      t2 = t3;
+      if (n - t3 > RESG_MAX) {
+        // half rows: down to a trailing order of 2048
         const unsigned long long epoch = (calls.fetch_add(1) + 1) << 16;
         t2 = n - RESG_MAX;
-        hipLaunchKernelGGL(sytrd_resident3_kernel, dim3(RESG_WG), dim3(RES_T), RES_LDS, st, Aw, ld, n, j0, t2 - j0, Vall,
+        hipLaunchKernelGGL(sytrd_resident3_kernel, dim3(RESG_WG), dim3(RES_T), RES_LDS, st, Aw, ld, n, t3, t2 - t3, Vall,
                            taus, d, e, rctl, X, epoch);
       }
       const int one_xcd = resident_mode() == 1 ? RES_MAX : RES_MID;   // (mode 1: the 768 tail alone, as it was measured)

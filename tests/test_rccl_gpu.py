@@ -102,8 +102,9 @@ def test_three_layer_split_through_a_one_rank_rccl_group_equals_the_unsharded_ru
     # back-transformation's K-split partial sums with atomics: eigenvectors repeat to ~1e-15), which is
     # what two UNSHARDED runs differ by as well
     assert [(t["layer"], t["rank"], t["accepted"]) for t in trace1] == [(t["layer"], t["rank"], t["accepted"]) for t in trace0]
+    # (ppl_diff is a difference of two f32 losses of order one: a last-place flip of either is 6e-8)
     for a, b in zip(trace0, trace1):
-        assert abs(a["nsr"] - b["nsr"]) <= 1e-8 * abs(a["nsr"]) and abs(a["ppl_diff"] - b["ppl_diff"]) <= 1e-6 * max(abs(a["ppl_diff"]), 1e-6), (a, b)
+        assert abs(a["nsr"] - b["nsr"]) <= 1e-8 * abs(a["nsr"]) and abs(a["ppl_diff"] - b["ppl_diff"]) <= 1e-6 * abs(a["ppl_diff"]) + 3e-7, (a, b)
     assert cfg1.keys() == cfg0.keys()
     for name in cfg0:
         m0_, m1_ = cfg0[name]["__meta__"], cfg1[name]["__meta__"]

@@ -23,13 +23,14 @@ reps = 3
 for _ in range(reps):
     ops.eigh(c, 2048, all_values=False)
 torch.cuda.synchronize()
-buf = (ctypes.c_ulonglong * 64)()
+buf = (ctypes.c_ulonglong * 80)()
 raw.ptd_debug_res_prof(buf, 0)
 names = {0: "reflector (to the barrier behind vs)", 1: "update + product pass (+ part barrier in r3)", 6: "p, b stores (r3)",
          2: "publish (drain, barrier, number)", 3: "wait for the 256 numbers", 4: "load p, b + dot, barrier",
          5: "w, next x, barrier", 7: "loop tail (vo copy, wrow)"}
 for k, (label, cols) in enumerate((("resident<256,2048> 2048 -> 1024", 1024), ("resident3 3072 -> 2048", 1024),
-                                  ("resident<32,1024> (one XCD) 1024 -> 768", 256), ("resident<32,768> (one XCD) 768 -> 1", 767))):
+                                  ("resident<32,1024> (one XCD) 1024 -> 768", 256), ("resident<32,768> (one XCD) 768 -> 1", 767),
+                                  ("resident4 (quarter rows, four waves) 3328 -> 3072", 256))):
     tot = sum(buf[16 * k + i] for i in range(16))
     print(f"{label}: {tot * 0.01 / reps / cols:.2f} us per column")
     for i in (0, 1, 6, 2, 3, 4, 5, 7):
