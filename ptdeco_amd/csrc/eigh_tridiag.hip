@@ -649,7 +649,7 @@ constexpr int RES_WG = 32;
 constexpr int RESG_MAX = 2048;                           // the whole chip: 256 workgroups, hand-offs through memory
 constexpr int RESG_WG = 256;
 constexpr int RES_T = 512;
-constexpr int RES_XS = 3328 + 64;                        // one exchange vector (the widest kernel: R4_MAX)
+constexpr int RES_XS = 3584 + 64;                        // one exchange vector (the widest kernel: R4B_MAX)
 constexpr size_t RES_LDS = 150 * 1024;   // two vectors and scalars; sized so that a CU takes exactly one workgroup
 // Waits are bounded in TIME (wall_clock64: the 100 MHz constant clock), not in polls: 10 ms is three orders above
 // the longest legitimate wait (a hand-off: microseconds) and short against the blocked repeat it triggers.  The clock
@@ -1257,25 +1257,30 @@ __global__ __launch_bounds__(RES_T) void sytrd_resident3_kernel(double* __restri
 // piece of it: every lane leaves its 13 partial sums in LDS and sixteen threads per row add them up.  A column moved
 // from the blocked path (two launches, ~21 us + the panel updates) into this kernel costs what a hand-off costs plus
 // its pass; the kernel stops at 3072, where the half-row kernel's pass is cheaper (72 doubles in plain registers).
-constexpr int R4_MAX = 3328;
+// MAXM = 3584 (14 rows, 196 doubles a lane) in front of MAXM = 3328: there the p and b entries a thread gathers go
+// straight into LDS (where w and the next column are formed from them) instead of through 28 more registers (PBL).
+constexpr int R4_MAX = 3328, R4B_MAX = 3584;
 constexpr int R4_T = 256;
-constexpr int R4_ROWS = R4_MAX / RESG_WG;   // 13 rows of a workgroup
-constexpr int R4_Q = R4_MAX / 4;            // columns of a wave's quarter
-constexpr int R4_CK = R4_Q / 64;            // register columns per lane and row
-constexpr int R4_CT = R4_MAX / R4_T;        // vector entries formed per thread
-static_assert(R4_MAX + 64 <= RES_XS, "exchange vectors");
+static_assert(R4B_MAX + 64 <= RES_XS, "exchange vectors");
 
+template <int MAXM, bool PBL>
 __global__ __launch_bounds__(R4_T) void sytrd_resident4_kernel(double* __restrict__ Aw, int64_t ld, int n, int t0,
                                                                int ncols, double* __restrict__ Vall,
                                                                double* __restrict__ taus, double* __restrict__ d,
                                                                double* __restrict__ e, ResCtl* __restrict__ ctl,
                                                                double* __restrict__ Xbuf, unsigned long long epoch) {
   constexpr int NWG = RESG_WG, NW = R4_T / 64;
+  constexpr int R4_ROWS = MAXM / RESG_WG;   // rows of a workgroup
+  constexpr int R4_Q = MAXM / 4;            // columns of a wave's quarter
+  constexpr int R4_CK = R4_Q / 64;          // register columns per lane and row
+  constexpr int R4_CT = MAXM / R4_T;        // vector entries formed per thread
+  static_assert(R4_ROWS * RESG_WG == MAXM && R4_CK * 256 == MAXM && R4_ROWS <= 16, "13 or 14 rows");
+  static_assert((4 * MAXM + R4_ROWS * R4_T + 64) * 8 <= (int)RES_LDS, "LDS");
   extern __shared__ __attribute__((aligned(16))) char res_smem[];
   double* vsb = reinterpret_cast<double*>(res_smem);   // two v vectors: column jl's in half jl & 1, the pending update's in the other
-  double* wv = vsb + 2 * R4_MAX;
-  double* xs = wv + R4_MAX;                   // the current column below its diagonal
-  double* red = xs + R4_MAX;                  // [13][256] every lane's partial row products
+  double* wv = vsb + 2 * MAXM;
+  double* xs = wv + MAXM;                   // the current column below its diagonal
+  double* red = xs + MAXM;                  // [13][256] every lane's partial row products
   double* aj = red + R4_ROWS * R4_T;          // [16] A[row q][jl + 1] (after the pending update)
   double* scr = aj + 16;                      // [0, 4) per-wave sums of x^2, [8] alpha, [9] p[jl+1], [10] next diagonal, [16, 20) p^T v
   __shared__ int flag;
@@ -1316,7 +1321,7 @@ __global__ __launch_bounds__(R4_T) void sytrd_resident4_kernel(double* __restric
       xs[c] = x;
       if (c >= 2) sq += x * x;
       if (c == 1) scr[8] = x;
-      vsb[R4_MAX + c] = 0.0;
+      vsb[MAXM + c] = 0.0;
       wv[c] = 0.0;
     }
     dnext = res_ld_f64(Xbuf + RES_XS);
@@ -1324,17 +1329,14 @@ __global__ __launch_bounds__(R4_T) void sytrd_resident4_kernel(double* __restric
     if (lane == 0) scr[wid] = sq;
     __syncthreads();
   }
-  double vrow_[R4_ROWS], wrow_[R4_ROWS];
-#pragma unroll
-  for (int q = 0; q < R4_ROWS; ++q) { vrow_[q] = 0.0; wrow_[q] = 0.0; }
   RES_T0(4);
   for (int jl = 0; jl < ncols; ++jl) {
     RES_MARK(7);
     const unsigned long long seq = epoch + (unsigned long long)jl + 1;
     double* Pb = Xbuf + ((jl + 1) & 1) * 2 * RES_XS;
     double* Bb = Pb + RES_XS;
-    double* vs = vsb + (jl & 1) * R4_MAX;
-    const double* vo = vsb + ((jl & 1) ^ 1) * R4_MAX;
+    double* vs = vsb + (jl & 1) * MAXM;
+    const double* vo = vsb + ((jl & 1) ^ 1) * MAXM;
     // ---- the reflector of column jl: the same arithmetic in every workgroup (its sums came through the last barrier)
     double xn2 = 0.0;
 #pragma unroll
@@ -1365,33 +1367,43 @@ __global__ __launch_bounds__(R4_T) void sytrd_resident4_kernel(double* __restric
     RES_MARK(0);
     // ---- the pending update, then every lane's partial products of the 13 rows (straight arithmetic: see the half-row
     // kernel); the lane that holds column jl + 1 leaves the updated entries of that column for the b values
+    // (the rows in two groups: a group's values of the pending v and w -- read from LDS, where they still lie -- and its
+    // accumulators are all that lives beside the matrix; v, w and the old v of the lane's columns are read once per
+    // group)
     {
-      double acc[R4_ROWS];
-#pragma unroll
-      for (int q = 0; q < R4_ROWS; ++q) acc[q] = 0.0;
       const int kold = (jl - wid * R4_Q) >> 6;         // register columns below hold only retired columns (negative: none)
       const int w1 = (jl + 1) / R4_Q;
       const int l1 = (jl + 1 - w1 * R4_Q) & 63, k1 = (jl + 1 - w1 * R4_Q) >> 6;
+      constexpr int GR = PBL ? (R4_ROWS + 3) / 4 : R4_ROWS;     // (14 rows: four groups -- what fits the registers)
 #pragma unroll
-      for (int k = 0; k < R4_CK; ++k) {
-        if (k < kold) continue;          // (wave-uniform)
-        const int c = cbase + 64 * k;
-        const double vnew = vs[c], wk = wv[c], vold = vo[c];
+      for (int g0 = 0; g0 < R4_ROWS; g0 += GR) {
+        double vr[GR], wr[GR], acc[GR];
 #pragma unroll
-        for (int q = 0; q < R4_ROWS; ++q) {
-          a[q][k] -= vrow_[q] * wk + wrow_[q] * vold;
-          acc[q] += a[q][k] * vnew;
+        for (int q = 0; q < GR; ++q) {
+          const int row = slot + NWG * min(g0 + q, R4_ROWS - 1);
+          vr[q] = vo[row]; wr[q] = wv[row]; acc[q] = 0.0;
         }
-        if (wid == w1 && k == k1) {      // (wave-uniform)
-          if (lane == l1)
 #pragma unroll
-            for (int q = 0; q < R4_ROWS; ++q) aj[q] = a[q][k];
+        for (int k = 0; k < R4_CK; ++k) {
+          if (k < kold) continue;          // (wave-uniform)
+          const int c = cbase + 64 * k;
+          const double vnew = vs[c], wk = wv[c], vold = vo[c];
+#pragma unroll
+          for (int q = 0; q < GR; ++q)
+            if (g0 + q < R4_ROWS) {
+              a[g0 + q][k] -= vr[q] * wk + wr[q] * vold;
+              acc[q] += a[g0 + q][k] * vnew;
+            }
+          if (wid == w1 && k == k1) {      // (wave-uniform)
+            if (lane == l1)
+#pragma unroll
+              for (int q = 0; q < GR; ++q)
+                if (g0 + q < R4_ROWS) aj[g0 + q] = a[g0 + q][k];
+          }
         }
-      }
 #pragma unroll
-      for (int q = 0; q < R4_ROWS; ++q) {
-        red[q * R4_T + tid] = acc[q];
-        vrow_[q] = vs[slot + NWG * q];
+        for (int q = 0; q < GR; ++q)
+          if (g0 + q < R4_ROWS) red[(g0 + q) * R4_T + tid] = acc[q];
       }
     }
     __syncthreads();
@@ -1418,17 +1430,19 @@ __global__ __launch_bounds__(R4_T) void sytrd_resident4_kernel(double* __restric
     RES_MARK(2);
     if (!wait_all(seq)) return;
     RES_MARK(3);
-    double pv_[R4_CT], bv_[R4_CT];
+    double pv_[PBL ? 1 : R4_CT], bv_[PBL ? 1 : R4_CT];
     {
       double dp = 0.0;
 #pragma unroll
       for (int t = 0; t < R4_CT; ++t) {
         const int c = tid + R4_T * t;
         const bool ok = c > jl && c < m;
-        pv_[t] = ok ? res_ld_f64(Pb + c) : 0.0;
-        bv_[t] = ok ? res_ld_f64(Bb + c) : 0.0;
-        dp += pv_[t] * vs[c];
-        if (c == jl + 1) scr[9] = pv_[t];
+        const double pc = ok ? res_ld_f64(Pb + c) : 0.0;
+        const double bc = ok ? res_ld_f64(Bb + c) : 0.0;
+        if (PBL) { wv[c] = pc; xs[c] = bc; }
+        else { pv_[t] = pc; bv_[t] = bc; }
+        dp += pc * vs[c];
+        if (c == jl + 1) scr[9] = pc;
       }
       dp = res_wave_sum(dp);
       if (lane == 0) scr[16 + wid] = dp;
@@ -1446,8 +1460,9 @@ __global__ __launch_bounds__(R4_T) void sytrd_resident4_kernel(double* __restric
       for (int t = 0; t < R4_CT; ++t) {
         const int c = tid + R4_T * t;
         const double v = vs[c];
-        wv[c] = pv_[t] - hk * v;
-        const double xn = bv_[t] - v * g;
+        const double pc = PBL ? wv[c] : pv_[t], bc = PBL ? xs[c] : bv_[t];
+        wv[c] = pc - hk * v;
+        const double xn = bc - v * g;
         if (c == jl + 1) scr[10] = xn;
         if (c == jl + 2) scr[8] = xn;
         xs[c] = (c >= jl + 2) ? xn : 0.0;
@@ -1459,19 +1474,17 @@ __global__ __launch_bounds__(R4_T) void sytrd_resident4_kernel(double* __restric
     __syncthreads();
     RES_MARK(5);
     dnext = scr[10];
-#pragma unroll
-    for (int q = 0; q < R4_ROWS; ++q) wrow_[q] = wv[slot + NWG * q];
   }
   if (ncols == m - 1) {
     if (slot == 0 && tid == 0) d[t0 + m - 1] = dnext;
   } else {
-    const double* vo = vsb + ((ncols - 1) & 1) * R4_MAX;
+    const double* vo = vsb + ((ncols - 1) & 1) * MAXM;
 #pragma unroll
     for (int q = 0; q < R4_ROWS; ++q)
 #pragma unroll
       for (int k = 0; k < R4_CK; ++k) {
         const int c = cbase + 64 * k, row = slot + NWG * q;
-        if (ncols > 0) a[q][k] -= vrow_[q] * wv[c] + wrow_[q] * vo[c];
+        if (ncols > 0) a[q][k] -= vo[row] * wv[c] + wv[row] * vo[c];
         if (row >= ncols && row < m && c >= ncols && c < m) Aw[(int64_t)(t0 + row) * ld + t0 + c] = a[q][k];
       }
   }
@@ -2677,15 +2690,16 @@ void probe_device(DeviceState& ds) {
   ds.cus = prop.multiProcessorCount;
   ds.gfx950 = strncmp(prop.gcnArchName, "gfx950", 6) == 0;
   // (the attribute belongs to this device's copy of the function; it is set again before every launch)
-  const void* kernels[5] = {reinterpret_cast<const void*>(sytrd_resident_kernel<RES_WG, RES_MAX, false>),
+  const void* kernels[6] = {reinterpret_cast<const void*>(sytrd_resident_kernel<RES_WG, RES_MAX, false>),
                             reinterpret_cast<const void*>(sytrd_resident_kernel<RES_WG, RES_MID, false>),
                             reinterpret_cast<const void*>(sytrd_resident_kernel<RESG_WG, RESG_MAX, true>),
                             reinterpret_cast<const void*>(sytrd_resident3_kernel),
-                            reinterpret_cast<const void*>(sytrd_resident4_kernel)};
+                            reinterpret_cast<const void*>(sytrd_resident4_kernel<R4_MAX, false>),
+                            reinterpret_cast<const void*>(sytrd_resident4_kernel<R4B_MAX, true>)};
   bool ok = true;
   for (const void* f : kernels) {
     int blocks = 0;
-    const int threads = f == kernels[4] ? R4_T : RES_T;
+    const int threads = (f == kernels[4] || f == kernels[5]) ? R4_T : RES_T;
     ok = ok && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RES_LDS) == hipSuccess &&
          hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, f, threads, RES_LDS) == hipSuccess && blocks >= 1;
   }
@@ -2694,10 +2708,10 @@ void probe_device(DeviceState& ds) {
 
 // PTD_SYTRD_RESIDENT: 0 off; 1 the one-XCD tail only; 2 test hook, see sytrd_f64; 3 whole-chip kernel from a trailing
 // order of 2048, then the one-XCD tail; 4 the half-row whole-chip kernel from 3072 in front of those; 5 (default) the
-// four-wave quarter-row kernel from 3328 in front of that
+// four-wave quarter-row kernel from 3328 in front of that; 6 (default) the same kernel with 14 rows from 3584 in front
 int resident_mode() {
   const char* env = getenv("PTD_SYTRD_RESIDENT");
-  return env ? atoi(env) : 5;
+  return env ? atoi(env) : 6;
 }
 // first column of the resident part: the first panel boundary with a trailing order the kernels take; n itself
 // (= nothing resident) when they may not run here and now
@@ -2719,7 +2733,7 @@ int resident_start(int n) {
   int left = ds.skip.load(std::memory_order_relaxed);
   while (left > 0)
     if (ds.skip.compare_exchange_weak(left, left - 1, std::memory_order_relaxed)) return n;
-  const int cap = n <= RES_MAX ? RES_MAX : (mode >= 5 ? R4_MAX : (mode == 4 ? R3_MAX : (mode == 3 ? RESG_MAX : RES_MAX)));
+  const int cap = n <= RES_MAX ? RES_MAX : (mode >= 6 ? R4B_MAX : (mode == 5 ? R4_MAX : (mode == 4 ? R3_MAX : (mode == 3 ? RESG_MAX : RES_MAX))));
   return n <= cap ? 0 : (int)align_up((size_t)(n - cap), NB);
 }
 void resident_failed(int status) {
@@ -2792,18 +2806,28 @@ int sytrd_f64(const TridiagPlan& p, char* base, SymvTimer* timer, bool resident,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)RES_LDS) == hipSuccess &&
           hipFuncSetAttribute(reinterpret_cast<const void*>(sytrd_resident3_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)RES_LDS) == hipSuccess &&
-          hipFuncSetAttribute(reinterpret_cast<const void*>(sytrd_resident4_kernel),
+          hipFuncSetAttribute(reinterpret_cast<const void*>(sytrd_resident4_kernel<R4_MAX, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)RES_LDS) == hipSuccess &&
+          hipFuncSetAttribute(reinterpret_cast<const void*>(sytrd_resident4_kernel<R4B_MAX, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)RES_LDS) == hipSuccess;
       PTD_REQUIRE(attr, "sytrd_f64: cannot reserve the LDS of the resident tail");
       static std::atomic<unsigned long long> calls{0};
       static_assert(RESG_MAX < (1 << 16), "sequence numbers of one launch: epoch .. epoch + m");
-      int t1 = j0, t2 = j0, t3 = j0;
-      if (n - j0 > R3_MAX) {
-        // quarter rows on four waves first: down to a trailing order of 3072
+      int t1 = j0, t2 = j0, t3 = j0, t4 = j0;
+      if (n - j0 > R4_MAX) {
+        // quarter rows on four waves, 14 rows a workgroup: down to a trailing order of 3328
+        const unsigned long long epoch = (calls.fetch_add(1) + 1) << 16;
+        t4 = n - R4_MAX;
+        hipLaunchKernelGGL((sytrd_resident4_kernel<R4B_MAX, true>), dim3(RESG_WG), dim3(R4_T), RES_LDS, st, Aw, ld, n, j0,
+                           t4 - j0, Vall, taus, d, e, rctl, X, epoch);
+      }
+      t3 = t4;
+      if (n - t4 > R3_MAX) {
+        // 13 rows a workgroup: down to a trailing order of 3072
         const unsigned long long epoch = (calls.fetch_add(1) + 1) << 16;
         t3 = n - R3_MAX;
-        hipLaunchKernelGGL(sytrd_resident4_kernel, dim3(RESG_WG), dim3(R4_T), RES_LDS, st, Aw, ld, n, j0, t3 - j0, Vall,
-                           taus, d, e, rctl, X, epoch);
+        hipLaunchKernelGGL((sytrd_resident4_kernel<R4_MAX, false>), dim3(RESG_WG), dim3(R4_T), RES_LDS, st, Aw, ld, n, t4,
+                           t3 - t4, Vall, taus, d, e, rctl, X, epoch);
       }
       t2 = t3;
       if (n - t3 > RESG_MAX) {
