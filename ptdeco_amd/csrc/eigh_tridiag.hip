@@ -34,6 +34,7 @@ int gemm_f64_pair(const double* A, const double* B, const double* A2, const doub
 namespace {
 
 constexpr int NB = 64;          // reflectors per panel
+typedef __attribute__((address_space(3))) void lds_void_t;
 
 __device__ __forceinline__ double wave_sum_d(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -1257,13 +1258,12 @@ __global__ __launch_bounds__(RES_T) void sytrd_resident3_kernel(double* __restri
 // piece of it: every lane leaves its 13 partial sums in LDS and sixteen threads per row add them up.  A column moved
 // from the blocked path (two launches, ~21 us + the panel updates) into this kernel costs what a hand-off costs plus
 // its pass; the kernel stops at 3072, where the half-row kernel's pass is cheaper (72 doubles in plain registers).
-// MAXM = 3584 (14 rows, 196 doubles a lane) in front of MAXM = 3328: there the p and b entries a thread gathers go
-// straight into LDS (where w and the next column are formed from them) instead of through 28 more registers (PBL).
+// MAXM = 3584 (14 rows, 196 doubles a lane) in front of MAXM = 3328: its rows are passed in four groups.
 constexpr int R4_MAX = 3328, R4B_MAX = 3584;
 constexpr int R4_T = 256;
 static_assert(R4B_MAX + 64 <= RES_XS, "exchange vectors");
 
-template <int MAXM, bool PBL>
+template <int MAXM>
 __global__ __launch_bounds__(R4_T) void sytrd_resident4_kernel(double* __restrict__ Aw, int64_t ld, int n, int t0,
                                                                int ncols, double* __restrict__ Vall,
                                                                double* __restrict__ taus, double* __restrict__ d,
@@ -1374,7 +1374,7 @@ __global__ __launch_bounds__(R4_T) void sytrd_resident4_kernel(double* __restric
       const int kold = (jl - wid * R4_Q) >> 6;         // register columns below hold only retired columns (negative: none)
       const int w1 = (jl + 1) / R4_Q;
       const int l1 = (jl + 1 - w1 * R4_Q) & 63, k1 = (jl + 1 - w1 * R4_Q) >> 6;
-      constexpr int GR = PBL ? (R4_ROWS + 3) / 4 : R4_ROWS;     // (14 rows: four groups -- what fits the registers)
+      constexpr int GR = R4_ROWS >= 14 ? (R4_ROWS + 3) / 4 : R4_ROWS;     // (14 rows: four groups -- what fits the registers)
 #pragma unroll
       for (int g0 = 0; g0 < R4_ROWS; g0 += GR) {
         double vr[GR], wr[GR], acc[GR];
@@ -1430,17 +1430,31 @@ __global__ __launch_bounds__(R4_T) void sytrd_resident4_kernel(double* __restric
     RES_MARK(2);
     if (!wait_all(seq)) return;
     RES_MARK(3);
-    double pv_[PBL ? 1 : R4_CT], bv_[PBL ? 1 : R4_CT];
+    // ---- the gathered p and b go from memory into LDS -- where w and the next column are formed from them -- by LDS-DMA
+    // at device scope: no registers (28 of them would not fit beside 14 rows), and one round trip for both vectors
+    {
+      constexpr int NCH = MAXM * 8 / 1024;      // 1-KiB pieces of a vector (64 lanes x 16 bytes an instruction)
+      static_assert(NCH * 1024 == MAXM * 8, "whole pieces");
+      const unsigned lds_w = (unsigned)(size_t)(lds_void_t*)wv, lds_x = (unsigned)(size_t)(lds_void_t*)xs;
+      const unsigned voff = (unsigned)lane * 16u;
+      const int swid = __builtin_amdgcn_readfirstlane(wid);
+      for (int i = swid; i < NCH; i += NW) {
+        const char* gp = reinterpret_cast<const char*>(Pb) + i * 1024;
+        const char* gb = reinterpret_cast<const char*>(Bb) + i * 1024;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 sc1"
+                     : : "s"(lds_w + i * 1024), "v"(voff), "s"(gp) : "memory", "m0");
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 sc1"
+                     : : "s"(lds_x + i * 1024), "v"(voff), "s"(gb) : "memory", "m0");
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
     {
       double dp = 0.0;
 #pragma unroll
       for (int t = 0; t < R4_CT; ++t) {
         const int c = tid + R4_T * t;
-        const bool ok = c > jl && c < m;
-        const double pc = ok ? res_ld_f64(Pb + c) : 0.0;
-        const double bc = ok ? res_ld_f64(Bb + c) : 0.0;
-        if (PBL) { wv[c] = pc; xs[c] = bc; }
-        else { pv_[t] = pc; bv_[t] = bc; }
+        const double pc = (c > jl && c < m) ? wv[c] : 0.0;     // (entries of retired rows are two columns old)
         dp += pc * vs[c];
         if (c == jl + 1) scr[9] = pc;
       }
@@ -1460,7 +1474,8 @@ __global__ __launch_bounds__(R4_T) void sytrd_resident4_kernel(double* __restric
       for (int t = 0; t < R4_CT; ++t) {
         const int c = tid + R4_T * t;
         const double v = vs[c];
-        const double pc = PBL ? wv[c] : pv_[t], bc = PBL ? xs[c] : bv_[t];
+        const bool ok = c > jl && c < m;
+        const double pc = ok ? wv[c] : 0.0, bc = ok ? xs[c] : 0.0;
         wv[c] = pc - hk * v;
         const double xn = bc - v * g;
         if (c == jl + 1) scr[10] = xn;
@@ -2694,8 +2709,8 @@ void probe_device(DeviceState& ds) {
                             reinterpret_cast<const void*>(sytrd_resident_kernel<RES_WG, RES_MID, false>),
                             reinterpret_cast<const void*>(sytrd_resident_kernel<RESG_WG, RESG_MAX, true>),
                             reinterpret_cast<const void*>(sytrd_resident3_kernel),
-                            reinterpret_cast<const void*>(sytrd_resident4_kernel<R4_MAX, false>),
-                            reinterpret_cast<const void*>(sytrd_resident4_kernel<R4B_MAX, true>)};
+                            reinterpret_cast<const void*>(sytrd_resident4_kernel<R4_MAX>),
+                            reinterpret_cast<const void*>(sytrd_resident4_kernel<R4B_MAX>)};
   bool ok = true;
   for (const void* f : kernels) {
     int blocks = 0;
@@ -2806,9 +2821,9 @@ int sytrd_f64(const TridiagPlan& p, char* base, SymvTimer* timer, bool resident,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)RES_LDS) == hipSuccess &&
           hipFuncSetAttribute(reinterpret_cast<const void*>(sytrd_resident3_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)RES_LDS) == hipSuccess &&
-          hipFuncSetAttribute(reinterpret_cast<const void*>(sytrd_resident4_kernel<R4_MAX, false>),
+          hipFuncSetAttribute(reinterpret_cast<const void*>(sytrd_resident4_kernel<R4_MAX>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)RES_LDS) == hipSuccess &&
-          hipFuncSetAttribute(reinterpret_cast<const void*>(sytrd_resident4_kernel<R4B_MAX, true>),
+          hipFuncSetAttribute(reinterpret_cast<const void*>(sytrd_resident4_kernel<R4B_MAX>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)RES_LDS) == hipSuccess;
       PTD_REQUIRE(attr, "sytrd_f64: cannot reserve the LDS of the resident tail");
       static std::atomic<unsigned long long> calls{0};
@@ -2818,7 +2833,7 @@ int sytrd_f64(const TridiagPlan& p, char* base, SymvTimer* timer, bool resident,
         // quarter rows on four waves, 14 rows a workgroup: down to a trailing order of 3328
         const unsigned long long epoch = (calls.fetch_add(1) + 1) << 16;
         t4 = n - R4_MAX;
-        hipLaunchKernelGGL((sytrd_resident4_kernel<R4B_MAX, true>), dim3(RESG_WG), dim3(R4_T), RES_LDS, st, Aw, ld, n, j0,
+        hipLaunchKernelGGL((sytrd_resident4_kernel<R4B_MAX>), dim3(RESG_WG), dim3(R4_T), RES_LDS, st, Aw, ld, n, j0,
                            t4 - j0, Vall, taus, d, e, rctl, X, epoch);
       }
       t3 = t4;
@@ -2826,7 +2841,7 @@ int sytrd_f64(const TridiagPlan& p, char* base, SymvTimer* timer, bool resident,
         // 13 rows a workgroup: down to a trailing order of 3072
         const unsigned long long epoch = (calls.fetch_add(1) + 1) << 16;
         t3 = n - R3_MAX;
-        hipLaunchKernelGGL((sytrd_resident4_kernel<R4_MAX, false>), dim3(RESG_WG), dim3(R4_T), RES_LDS, st, Aw, ld, n, t4,
+        hipLaunchKernelGGL((sytrd_resident4_kernel<R4_MAX>), dim3(RESG_WG), dim3(R4_T), RES_LDS, st, Aw, ld, n, t4,
                            t3 - t4, Vall, taus, d, e, rctl, X, epoch);
       }
       t2 = t3;
