@@ -1374,7 +1374,7 @@ __global__ __launch_bounds__(R4_T) void sytrd_resident4_kernel(double* __restric
       const int kold = (jl - wid * R4_Q) >> 6;         // register columns below hold only retired columns (negative: none)
       const int w1 = (jl + 1) / R4_Q;
       const int l1 = (jl + 1 - w1 * R4_Q) & 63, k1 = (jl + 1 - w1 * R4_Q) >> 6;
-      constexpr int GR = R4_ROWS >= 14 ? (R4_ROWS + 3) / 4 : R4_ROWS;     // (14 rows: four groups -- what fits the registers)
+      constexpr int GR = R4_ROWS >= 14 ? (R4_ROWS + 2) / 3 : R4_ROWS;     // (14 rows: three groups -- what fits the registers without scratch)
 #pragma unroll
       for (int g0 = 0; g0 < R4_ROWS; g0 += GR) {
         double vr[GR], wr[GR], acc[GR];
