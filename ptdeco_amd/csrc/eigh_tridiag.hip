@@ -3143,7 +3143,8 @@ int tridiag_vectors_and_backtransform(const TridiagPlan& p, char* base, int nvec
     double* Wp2 = grouped ? Wg : W2;
     // W = TV_g Y  (rows x nvec)
     PTD_CHECK_HIP(hipMemsetAsync(Wp2, 0, (size_t)rows * nvec * 8, st));
-    int rc = gemm_f64(TVp + r0, ld, 1, Y + (int64_t)r0 * ldy, ldy, 1, Wp2, nvec, rows, nvec, mr, 1.0, true, 16, st);
+    // (K ranges added with atomics: 16 for a 64-row panel, 8 for a group's 256 rows -- 4 x the tiles per range)
+    int rc = gemm_f64(TVp + r0, ld, 1, Y + (int64_t)r0 * ldy, ldy, 1, Wp2, nvec, rows, nvec, mr, 1.0, true, grouped ? 8 : 16, st);
     if (rc != PTD_OK) return rc;
     // Y[r0:, :] -= V_g^T W
     rc = gemm_f64(Vp + r0, 1, ld, Wp2, nvec, 1, Y + (int64_t)r0 * ldy, ldy, mr, nvec, rows, -1.0, true, 1, st);
