@@ -1044,6 +1044,7 @@ __global__ __launch_bounds__(RES_T) void sytrd_resident3_kernel(double* __restri
   double* xs = wv + R3_MAX;                   // the current column below its diagonal
   double* part = xs + R3_MAX;                 // [24] partial row products
   double* scr = part + 32;                    // [0, 8) per-wave sums of x^2, [8] alpha, [9] p[jl+1], [10] next diagonal, [16, 24) p^T v
+  double* aj = scr + 32;                      // [12] A[row q][jl + 1] (after the pending update)
   __shared__ int flag;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int slot = blockIdx.x;
@@ -1145,6 +1146,8 @@ __global__ __launch_bounds__(RES_T) void sytrd_resident3_kernel(double* __restri
 #pragma unroll
       for (int i = 0; i < R3_HR; ++i) acc[i] = 0.0;
       const int kold = (jl - half * R3_HALF) >> 6;     // register columns below hold only retired columns (negative: none)
+      const int half1 = (jl + 1) >= R3_HALF ? 1 : 0;
+      const int l1 = (jl + 1 - half1 * R3_HALF) & 63, k1 = (jl + 1 - half1 * R3_HALF) >> 6;
 #pragma unroll
       for (int k = 0; k < R3_CK; ++k) {
         if (k < kold) continue;          // (wave-uniform; the branch also keeps the compiler from hoisting all 72 LDS reads)
@@ -1154,6 +1157,11 @@ __global__ __launch_bounds__(RES_T) void sytrd_resident3_kernel(double* __restri
         for (int i = 0; i < R3_HR; ++i) {
           a[i][k] -= vrow_[i] * wk + wrow_[i] * vold;
           acc[i] += a[i][k] * vnew;
+        }
+        if (half == half1 && k == k1) {      // (wave-uniform) the updated entries of column jl + 1, for the b values
+          if (lane == l1)
+#pragma unroll
+            for (int i = 0; i < R3_HR; ++i) aj[(wid + NW * i) >> 1] = a[i][k];
         }
       }
 #pragma unroll
@@ -1166,22 +1174,12 @@ __global__ __launch_bounds__(RES_T) void sytrd_resident3_kernel(double* __restri
     __syncthreads();
     RES_MARK(1);
     // ---- p = tau A v and b = A[:, jl + 1] - p, stored by the lane that holds column jl + 1 of the row
-    {
-      const int half1 = (jl + 1) >= R3_HALF ? 1 : 0;
-      const int l1 = (jl + 1 - half1 * R3_HALF) & 63, k1 = (jl + 1 - half1 * R3_HALF) >> 6;
-      if (half == half1 && lane == l1) {
-#pragma unroll
-        for (int i = 0; i < R3_HR; ++i) {
-          const int h0 = (wid + NW * i) & ~1;
-          const double pi = tau * (part[h0] + part[h0 + 1]);
-          double aj1 = 0.0;
-#pragma unroll
-          for (int k = 0; k < R3_CK; ++k) aj1 = (k == k1) ? a[i][k] : aj1;
-          if (lr[i] > jl && lr[i] < m) {
-            res_st_f64<true>(Pb + lr[i], pi);
-            res_st_f64<true>(Bb + lr[i], aj1 - pi);
-          }
-        }
+    if (tid < 12) {                        // row q = tid of the workgroup: its two half products, its entry of column jl + 1
+      const int row = slot + NWG * tid;
+      if (row > jl && row < m) {
+        const double pi = tau * (part[2 * tid] + part[2 * tid + 1]);
+        res_st_f64<true>(Pb + row, pi);
+        res_st_f64<true>(Bb + row, aj[tid] - pi);
       }
     }
     RES_MARK(6);
@@ -1189,17 +1187,32 @@ __global__ __launch_bounds__(RES_T) void sytrd_resident3_kernel(double* __restri
     RES_MARK(2);
     if (!wait_all(seq)) return;
     RES_MARK(3);
-    double pv_[R3_CT], bv_[R3_CT];
+    // (p and b from memory into LDS -- where w and the next column are formed from them -- by LDS-DMA at device scope:
+    // see sytrd_resident4_kernel)
+    {
+      constexpr int NCH = R3_MAX * 8 / 1024;
+      const unsigned lds_w = (unsigned)(size_t)(lds_void_t*)wv, lds_x = (unsigned)(size_t)(lds_void_t*)xs;
+      const unsigned voff = (unsigned)lane * 16u;
+      const int swid = __builtin_amdgcn_readfirstlane(wid);
+      for (int i = swid; i < NCH; i += NW) {
+        const char* gp = reinterpret_cast<const char*>(Pb) + i * 1024;
+        const char* gb = reinterpret_cast<const char*>(Bb) + i * 1024;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 sc1"
+                     : : "s"(lds_w + i * 1024), "v"(voff), "s"(gp) : "memory", "m0");
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 sc1"
+                     : : "s"(lds_x + i * 1024), "v"(voff), "s"(gb) : "memory", "m0");
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
     {
       double dp = 0.0;
 #pragma unroll
       for (int t = 0; t < R3_CT; ++t) {
         const int c = tid + RES_T * t;
-        const bool ok = c > jl && c < m;
-        pv_[t] = ok ? res_ld_f64(Pb + c) : 0.0;
-        bv_[t] = ok ? res_ld_f64(Bb + c) : 0.0;
-        dp += pv_[t] * vs[c];
-        if (c == jl + 1) scr[9] = pv_[t];
+        const double pc = (c > jl && c < m) ? wv[c] : 0.0;     // (entries of retired rows are two columns old)
+        dp += pc * vs[c];
+        if (c == jl + 1) scr[9] = pc;
       }
       dp = res_wave_sum(dp);
       if (lane == 0) scr[16 + wid] = dp;
@@ -1218,8 +1231,10 @@ __global__ __launch_bounds__(RES_T) void sytrd_resident3_kernel(double* __restri
       for (int t = 0; t < R3_CT; ++t) {
         const int c = tid + RES_T * t;
         const double v = vs[c];
-        wv[c] = pv_[t] - hk * v;
-        const double xn = bv_[t] - v * g;
+        const bool ok = c > jl && c < m;
+        const double pc = ok ? wv[c] : 0.0, bc = ok ? xs[c] : 0.0;
+        wv[c] = pc - hk * v;
+        const double xn = bc - v * g;
         if (c == jl + 1) scr[10] = xn;
         if (c == jl + 2) scr[8] = xn;
         xs[c] = (c >= jl + 2) ? xn : 0.0;
