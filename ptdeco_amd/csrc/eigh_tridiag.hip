@@ -1158,11 +1158,13 @@ __global__ __launch_bounds__(RES_T) void sytrd_resident3_kernel(double* __restri
           a[i][k] -= vrow_[i] * wk + wrow_[i] * vold;
           acc[i] += a[i][k] * vnew;
         }
-        if (half == half1 && k == k1) {      // (wave-uniform) the updated entries of column jl + 1, for the b values
-          if (lane == l1)
+      }
+      if (half == half1) {                   // (wave-uniform) the updated entries of column jl + 1, for the b values
+#pragma unroll
+        for (int k = 0; k < R3_CK; ++k)
+          if (k == k1 && lane == l1)
 #pragma unroll
             for (int i = 0; i < R3_HR; ++i) aj[(wid + NW * i) >> 1] = a[i][k];
-        }
       }
 #pragma unroll
       for (int i = 0; i < R3_HR; ++i) {
@@ -1409,12 +1411,14 @@ __global__ __launch_bounds__(R4_T) void sytrd_resident4_kernel(double* __restric
               a[g0 + q][k] -= vr[q] * wk + wr[q] * vold;
               acc[q] += a[g0 + q][k] * vnew;
             }
-          if (wid == w1 && k == k1) {      // (wave-uniform)
-            if (lane == l1)
+        }
+        if (wid == w1) {                     // (wave-uniform) the updated entries of column jl + 1, for the b values
+#pragma unroll
+          for (int k = 0; k < R4_CK; ++k)
+            if (k == k1 && lane == l1)
 #pragma unroll
               for (int q = 0; q < GR; ++q)
                 if (g0 + q < R4_ROWS) aj[g0 + q] = a[g0 + q][k];
-          }
         }
 #pragma unroll
         for (int q = 0; q < GR; ++q)
