@@ -1129,12 +1129,23 @@ __global__ __launch_bounds__(RES_T) void sytrd_resident3_kernel(double* __restri
     {
       double* vrow = Vall + (int64_t)(t0 + jl) * ld + t0;
       const bool writer = slot == (jl & (NWG - 1));
+      // (two consecutive entries a thread: 16-byte LDS accesses)
 #pragma unroll
-      for (int t = 0; t < R3_CT; ++t) {
-        const int c = tid + RES_T * t;
-        const double v = (c == jl + 1) ? 1.0 : ((c > jl + 1) ? xs[c] * scale : 0.0);
-        vs[c] = v;
-        if (writer && c > jl && c < m) vrow[c] = v;
+      for (int t = 0; t < (R3_MAX / 2 + RES_T - 1) / RES_T; ++t) {
+        const int c = 2 * (tid + RES_T * t);
+        if (c >= R3_MAX) break;
+        const double2 x2 = *reinterpret_cast<const double2*>(xs + c);
+        double2 v2;
+        v2.x = (c == jl + 1) ? 1.0 : ((c > jl + 1) ? x2.x * scale : 0.0);
+        v2.y = (c + 1 == jl + 1) ? 1.0 : ((c + 1 > jl + 1) ? x2.y * scale : 0.0);
+        *reinterpret_cast<double2*>(vs + c) = v2;
+        if (writer) {
+          if (c > jl && c + 1 < m) *reinterpret_cast<double2*>(vrow + c) = v2;
+          else {
+            if (c > jl && c < m) vrow[c] = v2.x;
+            if (c + 1 > jl && c + 1 < m) vrow[c + 1] = v2.y;
+          }
+        }
       }
       if (writer && tid == 0) { taus[t0 + jl] = tau; e[t0 + jl] = beta; d[t0 + jl] = dnext; }
     }
@@ -1210,11 +1221,15 @@ __global__ __launch_bounds__(RES_T) void sytrd_resident3_kernel(double* __restri
     {
       double dp = 0.0;
 #pragma unroll
-      for (int t = 0; t < R3_CT; ++t) {
-        const int c = tid + RES_T * t;
-        const double pc = (c > jl && c < m) ? wv[c] : 0.0;     // (entries of retired rows are two columns old)
-        dp += pc * vs[c];
-        if (c == jl + 1) scr[9] = pc;
+      for (int t = 0; t < (R3_MAX / 2 + RES_T - 1) / RES_T; ++t) {
+        const int c = 2 * (tid + RES_T * t);
+        if (c >= R3_MAX) break;
+        const double2 p2 = *reinterpret_cast<const double2*>(wv + c), v2 = *reinterpret_cast<const double2*>(vs + c);
+        const double p0 = (c > jl && c < m) ? p2.x : 0.0;      // (entries of retired rows are two columns old)
+        const double p1 = (c + 1 > jl && c + 1 < m) ? p2.y : 0.0;
+        dp += p0 * v2.x + p1 * v2.y;
+        if (c == jl + 1) scr[9] = p0;
+        if (c + 1 == jl + 1) scr[9] = p1;
       }
       dp = res_wave_sum(dp);
       if (lane == 0) scr[16 + wid] = dp;
@@ -1230,17 +1245,22 @@ __global__ __launch_bounds__(RES_T) void sytrd_resident3_kernel(double* __restri
       // w, the next column and -- through the same barrier -- the sums of ITS reflector: alpha = x[jl + 2], x^2 below
       double sq = 0.0;
 #pragma unroll
-      for (int t = 0; t < R3_CT; ++t) {
-        const int c = tid + RES_T * t;
-        const double v = vs[c];
-        const bool ok = c > jl && c < m;
-        const double pc = ok ? wv[c] : 0.0, bc = ok ? xs[c] : 0.0;
-        wv[c] = pc - hk * v;
-        const double xn = bc - v * g;
-        if (c == jl + 1) scr[10] = xn;
-        if (c == jl + 2) scr[8] = xn;
-        xs[c] = (c >= jl + 2) ? xn : 0.0;
-        if (c >= jl + 3) sq += xn * xn;
+      for (int t = 0; t < (R3_MAX / 2 + RES_T - 1) / RES_T; ++t) {
+        const int c = 2 * (tid + RES_T * t);
+        if (c >= R3_MAX) break;
+        const double2 v2 = *reinterpret_cast<const double2*>(vs + c), p2 = *reinterpret_cast<const double2*>(wv + c),
+                      b2 = *reinterpret_cast<const double2*>(xs + c);
+        const bool ok0 = c > jl && c < m, ok1 = c + 1 > jl && c + 1 < m;
+        const double p0 = ok0 ? p2.x : 0.0, p1 = ok1 ? p2.y : 0.0, b0 = ok0 ? b2.x : 0.0, b1 = ok1 ? b2.y : 0.0;
+        *reinterpret_cast<double2*>(wv + c) = double2{p0 - hk * v2.x, p1 - hk * v2.y};
+        const double x0 = b0 - v2.x * g, x1 = b1 - v2.y * g;
+        if (c == jl + 1) scr[10] = x0;
+        if (c + 1 == jl + 1) scr[10] = x1;
+        if (c == jl + 2) scr[8] = x0;
+        if (c + 1 == jl + 2) scr[8] = x1;
+        *reinterpret_cast<double2*>(xs + c) = double2{(c >= jl + 2) ? x0 : 0.0, (c + 1 >= jl + 2) ? x1 : 0.0};
+        if (c >= jl + 3) sq += x0 * x0;
+        if (c + 1 >= jl + 3) sq += x1 * x1;
       }
       sq = res_wave_sum(sq);
       if (lane == 0) scr[wid] = sq;
@@ -1371,12 +1391,23 @@ __global__ __launch_bounds__(R4_T) void sytrd_resident4_kernel(double* __restric
     {
       double* vrow = Vall + (int64_t)(t0 + jl) * ld + t0;
       const bool writer = slot == (jl & (NWG - 1));
+      // (two consecutive entries a thread: 16-byte LDS accesses)
 #pragma unroll
-      for (int t = 0; t < R4_CT; ++t) {
-        const int c = tid + R4_T * t;
-        const double v = (c == jl + 1) ? 1.0 : ((c > jl + 1) ? xs[c] * scale : 0.0);
-        vs[c] = v;
-        if (writer && c > jl && c < m) vrow[c] = v;
+      for (int t = 0; t < (MAXM / 2 + R4_T - 1) / R4_T; ++t) {
+        const int c = 2 * (tid + R4_T * t);
+        if (c >= MAXM) break;
+        const double2 x2 = *reinterpret_cast<const double2*>(xs + c);
+        double2 v2;
+        v2.x = (c == jl + 1) ? 1.0 : ((c > jl + 1) ? x2.x * scale : 0.0);
+        v2.y = (c + 1 == jl + 1) ? 1.0 : ((c + 1 > jl + 1) ? x2.y * scale : 0.0);
+        *reinterpret_cast<double2*>(vs + c) = v2;
+        if (writer) {
+          if (c > jl && c + 1 < m) *reinterpret_cast<double2*>(vrow + c) = v2;
+          else {
+            if (c > jl && c < m) vrow[c] = v2.x;
+            if (c + 1 > jl && c + 1 < m) vrow[c + 1] = v2.y;
+          }
+        }
       }
       if (writer && tid == 0) { taus[t0 + jl] = tau; e[t0 + jl] = beta; d[t0 + jl] = dnext; }
     }
@@ -1471,11 +1502,15 @@ __global__ __launch_bounds__(R4_T) void sytrd_resident4_kernel(double* __restric
     {
       double dp = 0.0;
 #pragma unroll
-      for (int t = 0; t < R4_CT; ++t) {
-        const int c = tid + R4_T * t;
-        const double pc = (c > jl && c < m) ? wv[c] : 0.0;     // (entries of retired rows are two columns old)
-        dp += pc * vs[c];
-        if (c == jl + 1) scr[9] = pc;
+      for (int t = 0; t < (MAXM / 2 + R4_T - 1) / R4_T; ++t) {
+        const int c = 2 * (tid + R4_T * t);
+        if (c >= MAXM) break;
+        const double2 p2 = *reinterpret_cast<const double2*>(wv + c), v2 = *reinterpret_cast<const double2*>(vs + c);
+        const double p0 = (c > jl && c < m) ? p2.x : 0.0;      // (entries of retired rows are two columns old)
+        const double p1 = (c + 1 > jl && c + 1 < m) ? p2.y : 0.0;
+        dp += p0 * v2.x + p1 * v2.y;
+        if (c == jl + 1) scr[9] = p0;
+        if (c + 1 == jl + 1) scr[9] = p1;
       }
       dp = res_wave_sum(dp);
       if (lane == 0) scr[16 + wid] = dp;
@@ -1490,17 +1525,22 @@ __global__ __launch_bounds__(R4_T) void sytrd_resident4_kernel(double* __restric
     {
       double sq = 0.0;
 #pragma unroll
-      for (int t = 0; t < R4_CT; ++t) {
-        const int c = tid + R4_T * t;
-        const double v = vs[c];
-        const bool ok = c > jl && c < m;
-        const double pc = ok ? wv[c] : 0.0, bc = ok ? xs[c] : 0.0;
-        wv[c] = pc - hk * v;
-        const double xn = bc - v * g;
-        if (c == jl + 1) scr[10] = xn;
-        if (c == jl + 2) scr[8] = xn;
-        xs[c] = (c >= jl + 2) ? xn : 0.0;
-        if (c >= jl + 3) sq += xn * xn;
+      for (int t = 0; t < (MAXM / 2 + R4_T - 1) / R4_T; ++t) {
+        const int c = 2 * (tid + R4_T * t);
+        if (c >= MAXM) break;
+        const double2 v2 = *reinterpret_cast<const double2*>(vs + c), p2 = *reinterpret_cast<const double2*>(wv + c),
+                      b2 = *reinterpret_cast<const double2*>(xs + c);
+        const bool ok0 = c > jl && c < m, ok1 = c + 1 > jl && c + 1 < m;
+        const double p0 = ok0 ? p2.x : 0.0, p1 = ok1 ? p2.y : 0.0, b0 = ok0 ? b2.x : 0.0, b1 = ok1 ? b2.y : 0.0;
+        *reinterpret_cast<double2*>(wv + c) = double2{p0 - hk * v2.x, p1 - hk * v2.y};
+        const double x0 = b0 - v2.x * g, x1 = b1 - v2.y * g;
+        if (c == jl + 1) scr[10] = x0;
+        if (c + 1 == jl + 1) scr[10] = x1;
+        if (c == jl + 2) scr[8] = x0;
+        if (c + 1 == jl + 2) scr[8] = x1;
+        *reinterpret_cast<double2*>(xs + c) = double2{(c >= jl + 2) ? x0 : 0.0, (c + 1 >= jl + 2) ? x1 : 0.0};
+        if (c >= jl + 3) sq += x0 * x0;
+        if (c + 1 >= jl + 3) sq += x1 * x1;
       }
       sq = res_wave_sum(sq);
       if (lane == 0) scr[wid] = sq;
