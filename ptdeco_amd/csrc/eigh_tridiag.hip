@@ -930,15 +930,22 @@ __global__ __launch_bounds__(RES_T) void sytrd_resident_kernel(double* __restric
       }
 #pragma unroll
       for (int i = 0; i < RI; ++i) vrow_[i] = vs[min(lr[i], MAXM - 1)];
+      // (the rows' entries of column jl + 1: one wave-uniform test per register column instead of a select per row and
+      // column)
+      double aj1[RI];
+#pragma unroll
+      for (int i = 0; i < RI; ++i) aj1[i] = 0.0;
+#pragma unroll
+      for (int k = 0; k < CK; ++k)
+        if (k == k1)
+#pragma unroll
+          for (int i = 0; i < RI; ++i) aj1[i] = a[i][k];
 #pragma unroll
       for (int i = 0; i < RI; ++i) {
         const double pi = tau * res_wave_sum(acc[i]);
-        double aj1 = 0.0;
-#pragma unroll
-        for (int k = 0; k < CK; ++k) aj1 = (k == k1) ? a[i][k] : aj1;
         if (lane == l1 && lr[i] > jl && lr[i] < m) {
           res_st_f64<GLOBAL>(Pb + lr[i], pi);
-          res_st_f64<GLOBAL>(Bb + lr[i], aj1 - pi);
+          res_st_f64<GLOBAL>(Bb + lr[i], aj1[i] - pi);
         }
       }
     }
