@@ -640,7 +640,10 @@ __global__ void sytrd_wfix_kernel(int n, int r0, int ilast, int jlast, const dou
 //     no spill) takes 1024 .. 769 on one XCD at ~4.9 us per column and hands over to <32, 768, false>, which is the
 //     faster of the two below 768 (round 4: n = 1280 9.25 -> 8.52 ms, n = 1024 5.78 -> 4.97 ms).
 //   * sytrd_resident3_kernel (further down): the same on every CU for trailing orders 3072 .. 2049, three half rows
-//     per wave: ~14.7 us per column.
+//     per wave: ~9.1 us per column (14.7 before round 5 took the predicates out of its pass).
+//   * sytrd_resident4_kernel<3328> / <3584> (further down): trailing orders 3584 .. 3073 on four waves a CU with 512
+//     registers a lane, quarter rows: ~11.5 / ~13.5 us per column against ~22 blocked.
+// (Round-5 figures per column, tools/probes/res_prof.py: whole chip <256, 2048> 7.8 us, one XCD 4.0 and 3.2 us.)
 // Every spin is bounded; a time-out or an XCC mismatch sets the status word and the host repeats the reduction on the
 // blocked path.  ptd_eigh_topk n = 4096, k = 1024: 68.2 -> 54.3 ms (with the twisted-factorisation eigenvectors);
 // n = 768: 9.0 -> 4.3 ms.
