@@ -2395,16 +2395,17 @@ constexpr int GCH = 512;  // columns of V_p per wy_gram workgroup
 
 __global__ __launch_bounds__(256) void wy_gram_kernel(const double* __restrict__ Vall, int64_t ld, int n,
                                                       double* __restrict__ Gpart, int nchunks) {
+  // (f64 matrix cores: wave w forms rows 16 w .. 16 w + 15 of the 64 x 64 Gram block, four 16 x 16 tiles, from a
+  // 128-column image of the panel in LDS; MFMA operand map: a = A[row = lane & 15][k = lane >> 4],
+  // b = B[k = lane >> 4][col = lane & 15], d[r] = D[row = (lane >> 4) + 4 r][col = lane & 15])
   __shared__ double Vs[NB][129];
   const int panel = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
   const int r0 = panel * NB + 1;
   const double* Vp = Vall + (int64_t)panel * NB * ld;
-  const int ti = tid >> 4, tj = tid & 15;
-  double acc[4][4];
+  f64x4 acc[4];
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+  for (int cb = 0; cb < 4; ++cb) acc[cb] = f64x4{0.0, 0.0, 0.0, 0.0};
   const int cbeg = r0 + chunk * GCH, cend = min(n, cbeg + GCH);
   for (int c0 = cbeg; c0 < cend; c0 += 128) {
     for (int e = tid; e < NB * 128; e += 256) {
@@ -2413,22 +2414,19 @@ __global__ __launch_bounds__(256) void wy_gram_kernel(const double* __restrict__
     }
     __syncthreads();
 #pragma unroll 4
-    for (int c = 0; c < 128; ++c) {
-      double va[4], vb[4];
+    for (int kk = 0; kk < 128; kk += 4) {
+      const double av = Vs[16 * wid + l15][kk + l4];
 #pragma unroll
-      for (int a = 0; a < 4; ++a) { va[a] = Vs[4 * ti + a][c]; vb[a] = Vs[4 * tj + a][c]; }
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] += va[a] * vb[b];
+      for (int cb = 0; cb < 4; ++cb)
+        acc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Vs[16 * cb + l15][kk + l4], acc[cb], 0, 0, 0);
     }
     __syncthreads();
   }
   double* out = Gpart + ((int64_t)panel * nchunks + chunk) * NB * NB;
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) out[(4 * ti + a) * NB + 4 * tj + b] = acc[a][b];
+    for (int r = 0; r < 4; ++r) out[(16 * wid + l4 + 4 * r) * NB + 16 * cb + l15] = acc[cb][r];
 }
 
 __global__ __launch_bounds__(256) void wy_tfactor_kernel(const double* __restrict__ Gpart, int nchunks,
@@ -2482,21 +2480,34 @@ __global__ __launch_bounds__(256) void wy_tv_kernel(const double* __restrict__ V
     Vs[r][c] = (c0 + c < n) ? Vp[(int64_t)r * ld + c0 + c] : 0.0;
   }
   __syncthreads();
-  const int c = tid & 127, half = tid >> 7;
-  if (c0 + c >= n) return;
-  double* out = TVall + (int64_t)panel * NB * ld + c0 + c;
-  // four output rows at a time over the full q range (T is upper triangular: the entries below the
-  // diagonal are stored as zeros), so that the LDS reads pipeline instead of feeding one dependent chain
-  for (int i0 = half * 32; i0 < half * 32 + 32; i0 += 4) {
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-#pragma unroll 8
-    for (int q = 0; q < NB; ++q) {
-      const double v = Vs[q][c];
-      s0 += Ts[i0][q] * v; s1 += Ts[i0 + 1][q] * v; s2 += Ts[i0 + 2][q] * v; s3 += Ts[i0 + 3][q] * v;
-    }
-    out[(int64_t)i0 * ld] = s0; out[(int64_t)(i0 + 1) * ld] = s1;
-    out[(int64_t)(i0 + 2) * ld] = s2; out[(int64_t)(i0 + 3) * ld] = s3;
+  // f64 matrix cores (operand map: see wy_gram_kernel): wave w forms the 64 rows of columns 32 w .. 32 w + 31
+  const int lane = tid & 63, wid = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+  f64x4 acc[4][2];
+#pragma unroll
+  for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+  for (int kk = 0; kk < NB; kk += 4) {
+    double av[4], bv[2];
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) av[rb] = Ts[16 * rb + l15][kk + l4];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) bv[cb] = Vs[kk + l4][32 * wid + 16 * cb + l15];
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[rb], bv[cb], acc[rb][cb], 0, 0, 0);
   }
+#pragma unroll
+  for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      const int col = c0 + 32 * wid + 16 * cb + l15;
+      if (col < n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) TVall[((int64_t)panel * NB + 16 * rb + l4 + 4 * r) * ld + col] = acc[rb][cb][r];
+    }
 }
 
 // ---- four panels as ONE block reflector of 256 rows.  A panel's two products of the back-transformation have K = 64 or
@@ -2522,12 +2533,11 @@ __global__ __launch_bounds__(256) void wy_cross_kernel(const double* __restrict_
   const int px = WYG * g + wy_pair_x[q], py = WYG * g + wy_pair_y[q];
   if (py >= npanels) return;
   const int cbeg = WYG * NB * g + chunk * XCH, cend = min(n, cbeg + XCH);
-  const int ti = tid >> 4, tj = tid & 15;
-  double acc[4][4];
+  // (f64 matrix cores, operand map as in wy_gram_kernel: wave w forms rows 16 w .. of S_xy)
+  const int lane = tid & 63, wid = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+  f64x4 acc[4];
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+  for (int cb = 0; cb < 4; ++cb) acc[cb] = f64x4{0.0, 0.0, 0.0, 0.0};
   const double* Ax = TVall + (int64_t)px * NB * ld;
   const double* By = Vall + (int64_t)py * NB * ld;
   for (int c0 = cbeg; c0 < cend; c0 += 64) {
@@ -2539,22 +2549,19 @@ __global__ __launch_bounds__(256) void wy_cross_kernel(const double* __restrict_
     }
     __syncthreads();
 #pragma unroll 4
-    for (int c = 0; c < 64; ++c) {
-      double va[4], vb[4];
+    for (int kk = 0; kk < 64; kk += 4) {
+      const double av = As[16 * wid + l15][kk + l4];
 #pragma unroll
-      for (int a = 0; a < 4; ++a) { va[a] = As[4 * ti + a][c]; vb[a] = Bs[4 * tj + a][c]; }
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] += va[a] * vb[b];
+      for (int cb = 0; cb < 4; ++cb)
+        acc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Bs[16 * cb + l15][kk + l4], acc[cb], 0, 0, 0);
     }
     __syncthreads();
   }
   double* out = Spart + (((int64_t)g * 6 + q) * nchunks + chunk) * NB * NB;
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) out[(4 * ti + a) * NB + 4 * tj + b] = acc[a][b];
+    for (int r = 0; r < 4; ++r) out[(16 * wid + l4 + 4 * r) * NB + 16 * cb + l15] = acc[cb][r];
 }
 
 __global__ __launch_bounds__(256) void wy_cross_sum_kernel(const double* __restrict__ Spart, int n, int nchunks,
@@ -2578,7 +2585,7 @@ __global__ __launch_bounds__(256) void wy_merge_kernel(double* __restrict__ TVal
   const int gsize = min(WYG, npanels - WYG * g);
   const int c0 = WYG * NB * g + blockIdx.x * 64;
   if (c0 >= n || gsize < 2) return;
-  const int ti = tid >> 4, tj = tid & 15;
+  const int lane = tid & 63, wid = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
   const int ncol = min(64, n - c0);
   // the last panel of the group is its own P
   {
@@ -2588,15 +2595,16 @@ __global__ __launch_bounds__(256) void wy_merge_kernel(double* __restrict__ TVal
       P[gsize - 2][r][c] = c < ncol ? src[(int64_t)r * ld + c] : 0.0;
     }
   }
+  // (f64 matrix cores, operand map as in wy_gram_kernel: wave w holds rows 16 w .. of the slab, four 16 x 16 tiles)
   for (int x = gsize - 2; x >= 0; --x) {
     double* dst = TVall + (int64_t)(WYG * g + x) * NB * ld + c0;
-    double acc[4][4];
+    f64x4 acc[4];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        const int c = 4 * tj + b;
-        acc[a][b] = c < ncol ? dst[(int64_t)(4 * ti + a) * ld + c] : 0.0;
+      for (int r = 0; r < 4; ++r) {
+        const int c = 16 * cb + l15;
+        acc[cb][r] = c < ncol ? dst[(int64_t)(16 * wid + l4 + 4 * r) * ld + c] : 0.0;
       }
     for (int y = x + 1; y < gsize; ++y) {
       int q = 0;
@@ -2606,23 +2614,20 @@ __global__ __launch_bounds__(256) void wy_merge_kernel(double* __restrict__ TVal
       __syncthreads();
       const double (*Py)[65] = P[y - 1];
 #pragma unroll 4
-      for (int k = 0; k < NB; ++k) {
-        double sv[4], pv[4];
+      for (int kk = 0; kk < NB; kk += 4) {
+        const double av = -Ss[16 * wid + l15][kk + l4];
 #pragma unroll
-        for (int a = 0; a < 4; ++a) { sv[a] = Ss[4 * ti + a][k]; pv[a] = Py[k][4 * tj + a]; }
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-          for (int b = 0; b < 4; ++b) acc[a][b] -= sv[a] * pv[b];
+        for (int cb = 0; cb < 4; ++cb)
+          acc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Py[kk + l4][16 * cb + l15], acc[cb], 0, 0, 0);
       }
     }
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        const int c = 4 * tj + b;
-        if (c < ncol) dst[(int64_t)(4 * ti + a) * ld + c] = acc[a][b];
-        if (x >= 1) P[x - 1][4 * ti + a][c] = acc[a][b];
+      for (int r = 0; r < 4; ++r) {
+        const int c = 16 * cb + l15, row = 16 * wid + l4 + 4 * r;
+        if (c < ncol) dst[(int64_t)row * ld + c] = acc[cb][r];
+        if (x >= 1) P[x - 1][row][c] = acc[cb][r];
       }
   }
 }
