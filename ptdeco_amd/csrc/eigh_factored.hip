@@ -118,6 +118,73 @@ __global__ void diag_range_kernel(const double* __restrict__ L, int np, int n, d
   }
 }
 
+// Inverse of the 256 x 256 diagonal blocks of L (lower triangular) from the inverses of their four 64 x 64 diagonal
+// tiles (`linv`, from the factorisation): X_ii = linv_i,  X_ij = -linv_i sum_{k = j}^{i - 1} L_ik X_kj  for i > j --
+// 16 products of 64 x 64 tiles a block on the f64 matrix cores, one workgroup per block.  With it the back substitution
+// T = L^-T S runs in np / 256 steps of two products with K = 256 instead of np / 64 steps of thin ones (128 launches,
+// 4.8 ms at np = 4096, k = 2048).  out: [np / 256][256][256], upper blocks zero.
+__global__ __launch_bounds__(256) void tri_inv256_kernel(const double* __restrict__ L, int np,
+                                                         const double* __restrict__ linv, double* __restrict__ out) {
+  __shared__ double As[FB][FB + 1];
+  __shared__ double Bs[FB][FB + 1];
+  const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+  double* O = out + (size_t)g * 256 * 256;
+  const double* Lg = L + ((size_t)g * 256) * np + (size_t)g * 256;     // the block's corner in L
+  auto load = [&](double (*dst)[FB + 1], const double* src, int ld) {
+    for (int e = tid; e < FB * FB; e += 256) dst[e >> 6][e & 63] = src[(size_t)(e >> 6) * ld + (e & 63)];
+  };
+  auto store = [&](const f64x4 (&acc)[4], int bi, int bj, double sign) {
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        O[(size_t)(64 * bi + 16 * wid + l4 + 4 * r) * 256 + 64 * bj + 16 * cb + l15] = sign * acc[cb][r];
+  };
+  auto mma = [&](f64x4 (&acc)[4]) {       // acc += As Bs (operand map: a = A[row = lane & 15][k = lane >> 4], ...)
+#pragma unroll 4
+    for (int kk = 0; kk < FB; kk += 4) {
+      const double av = As[16 * wid + l15][kk + l4];
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb)
+        acc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Bs[kk + l4][16 * cb + l15], acc[cb], 0, 0, 0);
+    }
+  };
+  // zeros above the diagonal, the tiles' own inverses on it
+  for (int e = tid; e < 256 * 256; e += 256) {
+    const int r = e >> 8, c = e & 255;
+    if ((c >> 6) > (r >> 6)) O[e] = 0.0;
+    else if ((c >> 6) == (r >> 6)) O[e] = linv[((size_t)(4 * g + (r >> 6)) * FB + (r & 63)) * FB + (c & 63)];
+  }
+  __syncthreads();
+  for (int j = 0; j < 3; ++j)
+    for (int i = j + 1; i < 4; ++i) {
+      f64x4 acc[4];
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) acc[cb] = f64x4{0.0, 0.0, 0.0, 0.0};
+      for (int k = j; k < i; ++k) {
+        __syncthreads();                                   // (the operands of the previous product are consumed)
+        load(As, Lg + (size_t)(64 * i) * np + 64 * k, np);
+        load(Bs, O + (size_t)(64 * k) * 256 + 64 * j, 256);     // X_kj (finished: k < i; written by this workgroup)
+        __syncthreads();
+        mma(acc);
+      }
+      __syncthreads();
+      // X_ij = -linv_i acc
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Bs[16 * wid + l4 + 4 * r][16 * cb + l15] = acc[cb][r];
+      load(As, linv + (size_t)(4 * g + i) * FB * FB, FB);
+      __syncthreads();
+      f64x4 x[4];
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) x[cb] = f64x4{0.0, 0.0, 0.0, 0.0};
+      mma(x);
+      store(x, i, j, -1.0);
+      __threadfence_block();
+    }
+}
+
 }  // namespace
 
 struct FactoredPlan {
@@ -249,8 +316,26 @@ int eigh_factored(const void* W, int64_t ldw, int w_dtype, int64_t n_o, int64_t 
   // top-k eigenvectors of B
   rc = eigh_select(B, np, np, k, evals, S, k, base + p.off_eigh, p.eigh_bytes, nullptr, nullptr, st);
   if (rc != PTD_OK) return rc;
-  // T = L^-T S : blocked back substitution with the stored inverses of the diagonal blocks
-  const int nblk = np / FB;
+  // T = L^-T S : blocked back substitution with the inverses of the diagonal blocks -- 256 x 256 ones where np allows
+  // (tri_inv256_kernel; they live in P, which is dead by now)
+  static const bool no_inv256 = getenv("PTD_FACTORED_INV256") && atoi(getenv("PTD_FACTORED_INV256")) == 0;
+  const int nblk = (np % 256 == 0 && np >= 512 && !no_inv256) ? 0 : np / FB;
+  if (nblk == 0) {
+    double* Li = P;
+    hipLaunchKernelGGL(tri_inv256_kernel, dim3((unsigned)(np / 256)), dim3(256), 0, st, G, np, linv, Li);
+    for (int g = np / 256 - 1; g >= 0; --g) {
+      // T_g = (L_gg^-1)^T S_g
+      rc = gemm_f64(Li + (size_t)g * 256 * 256, 1, 256, S + (size_t)g * 256 * k, k, 1, T + (size_t)g * 256 * k, k, 256, k,
+                    256, 1.0, false, 1, st);
+      if (rc != PTD_OK) return rc;
+      // S[0 : 256 g] -= L[the block's rows, 0 : 256 g]^T T_g
+      if (g > 0) {
+        rc = gemm_f64(G + (size_t)g * 256 * np, 1, np, T + (size_t)g * 256 * k, k, 1, S, k, (int64_t)g * 256, k, 256, -1.0,
+                      true, 1, st);
+        if (rc != PTD_OK) return rc;
+      }
+    }
+  }
   for (int b = nblk - 1; b >= 0; --b) {
     // T_b = (L_bb^-1)^T S_b
     rc = gemm_f64(linv + (size_t)b * FB * FB, 1, FB, S + (size_t)b * FB * k, k, 1, T + (size_t)b * FB * k, k, FB, k, FB,
