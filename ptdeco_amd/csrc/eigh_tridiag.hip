@@ -653,7 +653,7 @@ constexpr int RES_WG = 32;
 constexpr int RESG_MAX = 2048;                           // the whole chip: 256 workgroups, hand-offs through memory
 constexpr int RESG_WG = 256;
 constexpr int RES_T = 512;
-constexpr int RES_XS = 3584 + 64;                        // one exchange vector (the widest kernel: R4B_MAX)
+constexpr int RES_XS = 3840 + 64;                        // one exchange vector (the widest kernel: R4C_MAX)
 constexpr size_t RES_LDS = 150 * 1024;   // two vectors and scalars; sized so that a CU takes exactly one workgroup
 // Waits are bounded in TIME (wall_clock64: the 100 MHz constant clock), not in polls: 10 ms is three orders above
 // the longest legitimate wait (a hand-off: microseconds) and short against the blocked repeat it triggers.  The clock
@@ -1306,9 +1306,9 @@ __global__ __launch_bounds__(RES_T) void sytrd_resident3_kernel(double* __restri
 // from the blocked path (two launches, ~21 us + the panel updates) into this kernel costs what a hand-off costs plus
 // its pass; the kernel stops at 3072, where the half-row kernel's pass is cheaper (72 doubles in plain registers).
 // MAXM = 3584 (14 rows, 196 doubles a lane) in front of MAXM = 3328: its rows are passed in four groups.
-constexpr int R4_MAX = 3328, R4B_MAX = 3584;
+constexpr int R4_MAX = 3328, R4B_MAX = 3584, R4C_MAX = 3840;
 constexpr int R4_T = 256;
-static_assert(R4B_MAX + 64 <= RES_XS, "exchange vectors");
+static_assert(R4C_MAX + 64 <= RES_XS, "exchange vectors");
 
 template <int MAXM>
 __global__ __launch_bounds__(R4_T) void sytrd_resident4_kernel(double* __restrict__ Aw, int64_t ld, int n, int t0,
@@ -1322,13 +1322,14 @@ __global__ __launch_bounds__(R4_T) void sytrd_resident4_kernel(double* __restric
   constexpr int R4_CK = R4_Q / 64;          // register columns per lane and row
   constexpr int R4_CT = MAXM / R4_T;        // vector entries formed per thread
   static_assert(R4_ROWS * RESG_WG == MAXM && R4_CK * 256 == MAXM && R4_ROWS <= 16, "13 or 14 rows");
-  static_assert((4 * MAXM + R4_ROWS * R4_T + 64) * 8 <= (int)RES_LDS, "LDS");
+  static_assert((4 * MAXM + 64) * 8 <= (int)RES_LDS && R4_ROWS * R4_T <= MAXM, "LDS");
   extern __shared__ __attribute__((aligned(16))) char res_smem[];
   double* vsb = reinterpret_cast<double*>(res_smem);   // two v vectors: column jl's in half jl & 1, the pending update's in the other
   double* wv = vsb + 2 * MAXM;
   double* xs = wv + MAXM;                   // the current column below its diagonal
-  double* red = xs + MAXM;                  // [13][256] every lane's partial row products
-  double* aj = red + R4_ROWS * R4_T;          // [16] A[row q][jl + 1] (after the pending update)
+  double* red = xs;                           // [rows][256] every lane's partial row products: between the reflector's read of
+                                              // the column and the gather of b the space of xs is free
+  double* aj = xs + MAXM;                     // [16] A[row q][jl + 1] (after the pending update)
   double* scr = aj + 16;                      // [0, 4) per-wave sums of x^2, [8] alpha, [9] p[jl+1], [10] next diagonal, [16, 20) p^T v
   __shared__ int flag;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -1432,7 +1433,7 @@ __global__ __launch_bounds__(R4_T) void sytrd_resident4_kernel(double* __restric
       const int kold = (jl - wid * R4_Q) >> 6;         // register columns below hold only retired columns (negative: none)
       const int w1 = (jl + 1) / R4_Q;
       const int l1 = (jl + 1 - w1 * R4_Q) & 63, k1 = (jl + 1 - w1 * R4_Q) >> 6;
-      constexpr int GR = R4_ROWS >= 14 ? (R4_ROWS + 2) / 3 : R4_ROWS;     // (14 rows: three groups -- what fits the registers without scratch)
+      constexpr int GR = R4_ROWS >= 15 ? 3 : (R4_ROWS >= 14 ? (R4_ROWS + 2) / 3 : R4_ROWS);     // (14 rows: three groups -- what fits the registers without scratch)
 #pragma unroll
       for (int g0 = 0; g0 < R4_ROWS; g0 += GR) {
         double vr[GR], wr[GR], acc[GR];
@@ -2779,16 +2780,17 @@ void probe_device(DeviceState& ds) {
   ds.cus = prop.multiProcessorCount;
   ds.gfx950 = strncmp(prop.gcnArchName, "gfx950", 6) == 0;
   // (the attribute belongs to this device's copy of the function; it is set again before every launch)
-  const void* kernels[6] = {reinterpret_cast<const void*>(sytrd_resident_kernel<RES_WG, RES_MAX, false>),
+  const void* kernels[7] = {reinterpret_cast<const void*>(sytrd_resident_kernel<RES_WG, RES_MAX, false>),
                             reinterpret_cast<const void*>(sytrd_resident_kernel<RES_WG, RES_MID, false>),
                             reinterpret_cast<const void*>(sytrd_resident_kernel<RESG_WG, RESG_MAX, true>),
                             reinterpret_cast<const void*>(sytrd_resident3_kernel),
                             reinterpret_cast<const void*>(sytrd_resident4_kernel<R4_MAX>),
-                            reinterpret_cast<const void*>(sytrd_resident4_kernel<R4B_MAX>)};
+                            reinterpret_cast<const void*>(sytrd_resident4_kernel<R4B_MAX>),
+                            reinterpret_cast<const void*>(sytrd_resident4_kernel<R4C_MAX>)};
   bool ok = true;
   for (const void* f : kernels) {
     int blocks = 0;
-    const int threads = (f == kernels[4] || f == kernels[5]) ? R4_T : RES_T;
+    const int threads = (f == kernels[4] || f == kernels[5] || f == kernels[6]) ? R4_T : RES_T;
     ok = ok && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RES_LDS) == hipSuccess &&
          hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, f, threads, RES_LDS) == hipSuccess && blocks >= 1;
   }
@@ -2797,10 +2799,11 @@ void probe_device(DeviceState& ds) {
 
 // PTD_SYTRD_RESIDENT: 0 off; 1 the one-XCD tail only; 2 test hook, see sytrd_f64; 3 whole-chip kernel from a trailing
 // order of 2048, then the one-XCD tail; 4 the half-row whole-chip kernel from 3072 in front of those; 5 (default) the
-// four-wave quarter-row kernel from 3328 in front of that; 6 (default) the same kernel with 14 rows from 3584 in front
+// four-wave quarter-row kernel from 3328 in front of that; 6 the same kernel with 14 rows from 3584 in front; 7
+// (default) and with 15 rows from 3840 in front of that
 int resident_mode() {
   const char* env = getenv("PTD_SYTRD_RESIDENT");
-  return env ? atoi(env) : 6;
+  return env ? atoi(env) : 7;
 }
 // first column of the resident part: the first panel boundary with a trailing order the kernels take; n itself
 // (= nothing resident) when they may not run here and now
@@ -2822,7 +2825,7 @@ int resident_start(int n) {
   int left = ds.skip.load(std::memory_order_relaxed);
   while (left > 0)
     if (ds.skip.compare_exchange_weak(left, left - 1, std::memory_order_relaxed)) return n;
-  const int cap = n <= RES_MAX ? RES_MAX : (mode >= 6 ? R4B_MAX : (mode == 5 ? R4_MAX : (mode == 4 ? R3_MAX : (mode == 3 ? RESG_MAX : RES_MAX))));
+  const int cap = n <= RES_MAX ? RES_MAX : (mode >= 7 ? R4C_MAX : (mode == 6 ? R4B_MAX : (mode == 5 ? R4_MAX : (mode == 4 ? R3_MAX : (mode == 3 ? RESG_MAX : RES_MAX)))));
   return n <= cap ? 0 : (int)align_up((size_t)(n - cap), NB);
 }
 void resident_failed(int status) {
@@ -2898,17 +2901,27 @@ int sytrd_f64(const TridiagPlan& p, char* base, SymvTimer* timer, bool resident,
           hipFuncSetAttribute(reinterpret_cast<const void*>(sytrd_resident4_kernel<R4_MAX>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)RES_LDS) == hipSuccess &&
           hipFuncSetAttribute(reinterpret_cast<const void*>(sytrd_resident4_kernel<R4B_MAX>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)RES_LDS) == hipSuccess &&
+          hipFuncSetAttribute(reinterpret_cast<const void*>(sytrd_resident4_kernel<R4C_MAX>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)RES_LDS) == hipSuccess;
       PTD_REQUIRE(attr, "sytrd_f64: cannot reserve the LDS of the resident tail");
       static std::atomic<unsigned long long> calls{0};
       static_assert(RESG_MAX < (1 << 16), "sequence numbers of one launch: epoch .. epoch + m");
-      int t1 = j0, t2 = j0, t3 = j0, t4 = j0;
-      if (n - j0 > R4_MAX) {
+      int t1 = j0, t2 = j0, t3 = j0, t4 = j0, t5 = j0;
+      if (n - j0 > R4B_MAX) {
+        // 15 rows a workgroup: down to a trailing order of 3584
+        const unsigned long long epoch = (calls.fetch_add(1) + 1) << 16;
+        t5 = n - R4B_MAX;
+        hipLaunchKernelGGL((sytrd_resident4_kernel<R4C_MAX>), dim3(RESG_WG), dim3(R4_T), RES_LDS, st, Aw, ld, n, j0,
+                           t5 - j0, Vall, taus, d, e, rctl, X, epoch);
+      }
+      t4 = t5;
+      if (n - t5 > R4_MAX) {
         // quarter rows on four waves, 14 rows a workgroup: down to a trailing order of 3328
         const unsigned long long epoch = (calls.fetch_add(1) + 1) << 16;
         t4 = n - R4_MAX;
-        hipLaunchKernelGGL((sytrd_resident4_kernel<R4B_MAX>), dim3(RESG_WG), dim3(R4_T), RES_LDS, st, Aw, ld, n, j0,
-                           t4 - j0, Vall, taus, d, e, rctl, X, epoch);
+        hipLaunchKernelGGL((sytrd_resident4_kernel<R4B_MAX>), dim3(RESG_WG), dim3(R4_T), RES_LDS, st, Aw, ld, n, t5,
+                           t4 - t5, Vall, taus, d, e, rctl, X, epoch);
       }
       t3 = t4;
       if (n - t4 > R3_MAX) {

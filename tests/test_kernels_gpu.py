@@ -350,17 +350,17 @@ def test_eigh_mid_size_against_lapack(ops, method):
         assert (p - p_ref).norm().item() <= 1e-6 * math.sqrt(r)
 
 
-@pytest.mark.parametrize("n", [130, 500, 768, 1000, 1500, 2048, 2300, 2600, 3200, 3500])
+@pytest.mark.parametrize("n", [130, 500, 768, 1000, 1500, 2048, 2300, 2600, 3200, 3500, 3700])
 def test_resident_tail_of_the_reduction_matches_the_blocked_path(ops, monkeypatch, n):
     """From a trailing order of 3584 the tridiagonalisation runs resident in registers (eigh_tridiag.hip): the
     quarter-row kernels on four waves down to 3328 and 3072 columns (sytrd_resident4_kernel, 14 and 13 rows a
     workgroup), the half-row kernel on every CU down to 2048 (sytrd_resident3_kernel), the one-row-per-wave kernel on
     every CU down to 768, one XCD for the rest (sytrd_resident_kernel).  The same spectrum as the blocked path and as
     LAPACK -- for orders the kernels take whole (n <= 768: one XCD; n <= 2048: two kernels; n <= 3072: three;
-    n <= 3328: four; n <= 3584: five, no blocked panel), with ragged row distributions (n = 130, 500, 1000, 1500, 2300,
-    2600, 3200, 3500: not multiples of 32 / 64 / 256).
+    n <= 3328: four; n <= 3584: five; n <= 3840: six, no blocked panel), with ragged row distributions (n = 130, 500,
+    1000, 1500, 2300, 2600, 3200, 3500, 3700: not multiples of 32 / 64 / 256).
     PTD_SYTRD_RESIDENT=1 is the one-XCD tail alone, 3 without the half-row kernel, 4 without the quarter-row kernels,
-    5 without the 14-row one, 2 reports the tail as failed after the launch: the caller must repeat the reduction on
+    5 without the 14-row one, 6 without the 15-row one, 2 reports the tail as failed after the launch: the caller must repeat the reduction on
     the blocked path and return exactly what that path returns."""
     monkeypatch.setenv("PTD_EIGH_METHOD", "tridiag")
     y = _rand((2 * n + 3, n), 900 + n).double() * torch.logspace(0, -2, n, dtype=torch.float64)
@@ -369,7 +369,7 @@ def test_resident_tail_of_the_reduction_matches_the_blocked_path(ops, monkeypatc
     w_ref = torch.linalg.eigvalsh(a)
     scale = w_ref.abs().max().item()
     got = {}
-    for mode in ("0", "1", "2", "3", "4", "5", "6"):
+    for mode in ("0", "1", "2", "3", "4", "5", "6", "7"):
         monkeypatch.setenv("PTD_SYTRD_RESIDENT", mode)
         _, _, w = ops.tridiagonalize(a.to(DEV))
         got[mode] = w.cpu()
@@ -378,14 +378,14 @@ def test_resident_tail_of_the_reduction_matches_the_blocked_path(ops, monkeypatc
     # several chains at once (ptd_set_concurrent_chains, what _engine.run_concurrently announces): no kernel may hold
     # an XCD for itself, so the blocked path runs to the end
     from ptdeco_amd import _hip
-    monkeypatch.setenv("PTD_SYTRD_RESIDENT", "6")
+    monkeypatch.setenv("PTD_SYTRD_RESIDENT", "7")
     before = _hip.load().ptd_set_concurrent_chains(3)
     try:
         assert before == 1
         assert torch.equal(ops.tridiagonalize(a.to(DEV))[2].cpu(), got["0"])
     finally:
         assert _hip.load().ptd_set_concurrent_chains(before) == 3
-    for mode in (("1", "2", "3", "4", "5", "6") if n <= 1000 else ("6",)):   # (each check is a LAPACK eigh on the host)
+    for mode in (("1", "2", "3", "4", "5", "6", "7") if n <= 1000 else ("7",)):   # (each check is a LAPACK eigh on the host)
         monkeypatch.setenv("PTD_SYTRD_RESIDENT", mode)
         _check_eigh(ops, a)
 
