@@ -30,7 +30,7 @@ names = {0: "reflector (to the barrier behind vs)", 1: "update + product pass (+
          5: "w, next x, barrier", 7: "loop tail (vo copy, wrow)"}
 for k, (label, cols) in enumerate((("resident<256,2048> 2048 -> 1024", 1024), ("resident3 3072 -> 2048", 1024),
                                   ("resident<32,1024> (one XCD) 1024 -> 768", 256), ("resident<32,768> (one XCD) 768 -> 1", 767),
-                                  ("resident4 (quarter rows, four waves) 3584 -> 3328 and 3328 -> 3072 together", 512))):
+                                  ("resident4 (quarter rows, four waves) 3840 -> 3584 -> 3328 -> 3072 together", 768))):
     tot = sum(buf[16 * k + i] for i in range(16))
     print(f"{label}: {tot * 0.01 / reps / cols:.2f} us per column")
     for i in (0, 1, 6, 2, 3, 4, 5, 7):
