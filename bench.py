@@ -1,39 +1,28 @@
 #!/usr/bin/env python3
-"""Headline benchmark: dwain layers decomposed per second on MI355X.
+"""Headline benchmark: dwain layers decomposed per second on MI355X (BASELINE.json `metric`).
 
     python bench.py --gpus N --steps K --warmup W
 
-ONE fixed workload at every N (strong scaling): dwain.decompose_in_place of a stack of 8 nn.Linear(4096, 4096,
-bias=False) -- BASELINE.json configs[1]'s layer, eight of them chained so that the same work can be dealt to 1 / 2 /
-4 / 8 GPUs the way configs[3] shards a Llama stack -- f32 model, f64 decomposition, B=4 x S=1024 tokens per batch,
-precomputing_covariance_num_splits=1, D = 8 calibration steps, M = 2 metric steps, 6 evaluated candidate ranks per
-layer (1024 .. 32; 2048 drops no parameters and is skipped), CE loss over the 4096 outputs, identity finetune_fn.
-With N ranks: calibration steps dealt to the ranks, the 8 covariance sums reduced to their owners (packed lower
-triangles over RCCL, started asynchronously and completed right before each owner's eigensolve), the 8
-eigendecompositions owned round-robin, eigenvectors broadcast, (candidate, metric batch) pairs dealt to the ranks.
-One "step" = one full decompose_in_place call on a fresh copy of the stack, every input already resident in HBM;
-`value` = 8 layers x K / time, "scaling": "strong".  `python bench.py --gpus N` starts its own N ranks when no launcher
-did (children, before any GPU call).
+ONE fixed workload at every N (strong scaling): BASELINE configs[3] at reduced depth -- dwain.decompose_in_place
+(reference src/ptdeco/dwain/decomposition.py:677-800) of a stack of TWO Llama-3-8B-width blocks (q, k, v, o, gate, up,
+down at 4096 / 1024 / 14336 = 14 layers, + a blacklisted 4096 x 4096 head), bf16 model, f64 covariance + eigh,
+[1, 2048, 4096] token batches, D = 8 calibration steps, M = 2 metric steps, precomputing_covariance_num_splits = 1,
+thresholds under which layers ARE replaced (the next layer then sees the changed model, dwain.py:779-787), identity
+finetune_fn.  One "step" = one full decompose_in_place call on a fresh copy of the stack, every input already
+resident in HBM; `value` = 14 layers x K / time.  With N ranks: calibration steps and (candidate, batch) pairs dealt to
+the ranks, packed covariance sums reduced to the layer owners over RCCL, eigenvectors broadcast (sharding.py).
+`python bench.py --gpus N` starts its own N ranks when no launcher did (children, before any GPU call).
 
-The same line carries
-  c2_single_layer BASELINE configs[1] / SURVEY C2 itself (ONE nn.Linear(4096, 4096), D = 4, M = 2), timed with the same
-                 K / W protocol at N = 1: the workload the roofline / eigh / phases / cpu_baseline blocks describe
-  bf16_stack     the fixed stack timed once more with a bf16 model (SURVEY 8d's throughput configuration)
-  weak_family    N > 1 only: the round-3 family (a stack of N layers on N GPUs), kept for comparison
-  roofline       the dominant kernel of the eigensolver against its bound: frac on SURVEY 8d's
-                 algorithmic work, solver_frac for the whole ptd_eigh call
-  phases_ms      device-time split of one step: A accumulate, B eigh, C factors, D metrics, comm
-  stack_phases_ms  the same split for one step of the fixed stack (the workload `value` is quoted on), N = 1
-  kernels        per-kernel device time / rates from HIP events
-  cpu_baseline   the CPU oracle (restatement of the reference, torch-CPU/MKL) on the C2
-                 workload on this box's physical host cores, rank 0, N = 1 only
-  decomposed_fwd rank-r two-GEMM forward vs dense 4096x4096, bf16 (BASELINE configs[4])
-  c4_shapes      dwain on one layer of each Llama-3-8B shape (BASELINE configs[3]), f32 and bf16, three timed
-                 steps each, with the eigensolver route and its roofline block
-  c4_block       one full-width Llama-3-8B block (7 layers) end to end, f32 and bf16
-Counter-derived fields (traffic, MFMA utilisation) are quoted from committed rocprofv3 PMC
-summaries; each carries the hash of the kernel source it was measured on and is marked
-"stale": true when the source has changed since.
+Output: the LAST stdout line is ONE compact JSON object (<= 4096 bytes: the driver keeps the tail of stdout) with the
+contract keys, `roofline` (the dominant package kernel of the headline step, measured live with HIP events) and
+`cpu_baseline` (the CPU oracle on one layer of the stack's shapes, host cores of this box), plus scalars for the
+other BASELINE configs: c2_* (configs[1]: ONE nn.Linear(4096, 4096), D = 4, M = 2), c3_* (configs[2]: falor on a
+ViT-B/16-shaped clone, depth 12, batch 8, D = 5, M = 5, use_mean=False, use_damping=True), c1_cpu_s (configs[0]: the
+CPU oracle's falor on the resnet18-shaped clone, one batch).  Everything else -- per-kernel lines, the decomposed
+forward (configs[4]), per-shape and one-block Llama lines, eigensolver phases -- goes to bench_detail.json beside this
+file (and to gpurun_out/bench_detail.json, which travels back from the GPU box); an earlier stdout line names it.
+Counter-derived fields (traffic, MFMA utilisation) are quoted from committed rocprofv3 PMC summaries; each carries the
+hash of the kernel source it was measured on and is marked "stale": true when the source has changed since.
 """
 
 from __future__ import annotations
@@ -54,7 +43,9 @@ sys.path.insert(0, ROOT)
 N_FEAT = 4096
 BATCH, SEQ = 4, 1024
 D_STEPS, M_STEPS = 4, 2
-STACK_LAYERS, STACK_D_STEPS = 8, 8   # the fixed stack of the scaling family
+HEADLINE_BLOCKS = 2                  # Llama-3-8B-width blocks of the headline workload (configs[3] at reduced depth)
+METRIC = "layers decomposed/sec (incl. covariance+SVD)"
+LINE_LIMIT = 4096                    # bytes of the last stdout line (the driver parses the tail of stdout)
 PEAK_F64_MFMA = 78.6e12   # MI355X dense f64 matrix peak
 PEAK_F32_MFMA = 157.3e12  # /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_BF16_MFMA = 2.5e15
@@ -448,35 +439,66 @@ C4_BLOCK_KW = dict(num_data_steps=8, num_metric_steps=2, nsr_final_threshold=1.0
                    blacklisted_module_names=["head"], precomputing_covariance_num_splits=1)
 
 
-def llama_block_lines(device, blocks=1, dtypes=(torch.float32, torch.bfloat16), timed=5):
-    """BASELINE configs[3] in small, end to end: dwain on ONE full-width Llama-3-8B block (q, k, v, o, gate, up, down at
-    4096 / 1024 / 14336 + the blacklisted head), [1, 2048, 4096] batches, D = 8, M = 2, precompute pass (one split: the
-    seven eigendecompositions run as concurrent chains), thresholds under which layers ARE replaced, so that the
-    replace -> next-layer-sees-the-changed-model path runs (dwain.py:779-787)."""
+def llama_workload(device, blocks, dt):
+    """BASELINE configs[3] in small: a stack of `blocks` full-width Llama-3-8B blocks (q, k, v, o, gate, up, down at 4096 /
+    1024 / 14336 + the blacklisted head), seeded weights and [1, 2048, 4096] batches already on the device, and
+    step(trace=None) -> decompose_config of ONE dwain.decompose_in_place call on a fresh copy (precompute pass, one split).
+    Identical on every rank (same seeds).  Returns (step, keyword arguments)."""
     import ptdeco_amd
-    from ptdeco_amd import _engine as eng
 
-    out = {}
     # (a layer's share of the parameters shrinks with the depth: the trade-off factor scales with the number of blocks)
     kw = dict(C4_BLOCK_KW, trade_off_factor=C4_BLOCK_KW["trade_off_factor"] * blocks)
-    for dt in dtypes:
-        g = torch.Generator(device=device).manual_seed(0)
-        with torch.device(device):
-            model0 = LlamaStack(blocks)
-        with torch.no_grad():
-            for prm in model0.parameters():
-                prm.copy_(torch.randn(prm.shape, generator=g, device=device) / prm.shape[1] ** 0.5)
-        model0.to(dt)
-        scale = torch.logspace(0, -2, D_MODEL, device=device)
-        xs = [(torch.randn(1, 2048, D_MODEL, generator=g, device=device) * scale).to(dt) for _ in range(12)]
-        with torch.no_grad():
-            bt = [{"x": x, "targets": model0({"x": x}).argmax(-1)} for x in xs]
+    g = torch.Generator(device=device).manual_seed(0)
+    with torch.device(device):
+        model0 = LlamaStack(blocks)
+    with torch.no_grad():
+        for prm in model0.parameters():
+            prm.copy_(torch.randn(prm.shape, generator=g, device=device) / prm.shape[1] ** 0.5)
+    model0.to(dt)
+    scale = torch.logspace(0, -2, D_MODEL, device=device)
+    xs = [(torch.randn(1, 2048, D_MODEL, generator=g, device=device) * scale).to(dt) for _ in range(12)]
+    with torch.no_grad():
+        bt = [{"x": x, "targets": model0({"x": x}).argmax(-1)} for x in xs]
 
-        def step(trace=None):
-            m = copy.deepcopy(model0)
-            return ptdeco_amd.dwain.decompose_in_place(module=m, device=device, data_iterator=itertools.cycle(bt),
-                                                       loss_fn=seq_ce, metric_iterator=itertools.cycle(bt[8:]),
-                                                       finetune_fn=lambda mm, d, n: mm, trace=trace, **kw)
+    def step(trace=None):
+        m = copy.deepcopy(model0)
+        return ptdeco_amd.dwain.decompose_in_place(module=m, device=device, data_iterator=itertools.cycle(bt),
+                                                   loss_fn=seq_ce, metric_iterator=itertools.cycle(bt[8:]),
+                                                   finetune_fn=lambda mm, d, n: mm, trace=trace, **kw)
+    return step, kw
+
+
+def llama_workload_text(blocks, kw, dt):
+    name = dt if isinstance(dt, str) else ("bf16" if dt == torch.bfloat16 else "f32")
+    return ("dwain.decompose_in_place, %d Llama-3-8B-width block(s) (%d layers) + blacklisted head, %s model, f64 "
+            "covariance + eigh, [1, 2048, 4096] batches, D = 8, M = 2, precompute pass (1 split), trade_off_factor %g, "
+            "max_accepted_ppl_diff 0.4; layers are replaced as the search goes"
+            % (blocks, 7 * blocks, name, kw["trade_off_factor"]))
+
+
+def phase_split(step):
+    """One more, untimed step with the phase spans armed: (phases_ms incl. other_host_and_gaps, trace, config)."""
+    from ptdeco_amd import _engine as eng
+
+    eng.PHASES = eng.PhaseTimer()
+    trace = []
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    cfg = step(trace)
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) * 1e3
+    ph, eng.PHASES = eng.PHASES.totals_ms(), None
+    ph["other_host_and_gaps"] = max(0.0, wall - sum(ph.values()))
+    return {k: round(v, 1) for k, v in ph.items()}, trace, cfg
+
+
+def llama_block_lines(device, blocks=1, dtypes=(torch.float32, torch.bfloat16), timed=5):
+    """BASELINE configs[3] in small, end to end: dwain on `blocks` full-width Llama-3-8B block(s), f32 and bf16 model;
+    one warm-up step, `timed` timed steps (median reported), one more with the phase spans."""
+    out = {}
+    kw = None
+    for dt in dtypes:
+        step, kw = llama_workload(device, blocks, dt)
         step()
         torch.cuda.synchronize()
         marks = []
@@ -485,26 +507,16 @@ def llama_block_lines(device, blocks=1, dtypes=(torch.float32, torch.bfloat16), 
             step()
             torch.cuda.synchronize()
             marks.append((time.perf_counter() - t0) * 1e3)
-        eng.PHASES = eng.PhaseTimer()
-        trace = []
-        t0 = time.perf_counter()
-        cfg = step(trace)
-        torch.cuda.synchronize()
-        wall = (time.perf_counter() - t0) * 1e3
-        ph, eng.PHASES = eng.PHASES.totals_ms(), None
-        ph["other_host_and_gaps"] = max(0.0, wall - sum(ph.values()))
+        ph, trace, cfg = phase_split(step)
         med = sorted(marks)[len(marks) // 2]
         out["f32" if dt == torch.float32 else "bf16"] = {
             "layers": 7 * blocks, "ms_per_step": med, "ms_per_step_max": max(marks), "ms_per_step_min": min(marks),
             "ms_per_block": med / blocks, "step_ms": [round(v, 1) for v in marks], "layers_per_s": 7e3 * blocks / med,
             "spread": (max(marks) - min(marks)) / med, "timed_steps": timed, "statistic": "median of step_ms",
-            "phases_ms": {k: round(v, 1) for k, v in ph.items()}, "candidates_evaluated": len(trace),
+            "phases_ms": ph, "candidates_evaluated": len(trace),
             "replaced": {k: v["__meta__"]["proportion"] for k, v in cfg.items()}}
-        del model0, xs, bt
-    out["workload"] = ("dwain.decompose_in_place, %d Llama-3-8B-width block(s) (%d layers) + blacklisted head, [1, 2048, 4096] "
-                       "batches, D = 8, M = 2, precompute pass (1 split), trade_off_factor %g, max_accepted_ppl_diff 0.4; "
-                       "layers are replaced as the search goes, so the later layers' metric forwards run the changed model"
-                       % (blocks, 7 * blocks, kw["trade_off_factor"]))
+        del step
+    out["workload"] = llama_workload_text(blocks, kw, "f32 / bf16")
     return out
 
 
@@ -523,40 +535,158 @@ def pmc_traffic(n):
     return {"traffic": None}
 
 
-def cpu_baseline():
-    """The CPU oracle on the same C2 workload (1 layer), host cores of this box."""
+def host_cores():
+    """(threads to use, physical cores, CPUs the affinity mask and the cgroup quota grant)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import ptdeco_oracle as orc
-
-    # physical cores of this box (SURVEY 8d): torch defaults to the logical count, which oversubscribes MKL
     try:
         import psutil
         physical = psutil.cpu_count(logical=False) or os.cpu_count()
     except Exception:
         physical = os.cpu_count()
-    # ... and a cgroup CPU quota below the visible count throttles a pool sized by it (oracle/cpu_quota.py)
-    from cpu_quota import usable_cpus
+    from cpu_quota import usable_cpus    # a cgroup quota below the visible count throttles a pool sized by it
     usable = usable_cpus()
-    cores = max(1, min(physical, usable))
+    return max(1, min(physical, usable)), physical, usable
+
+
+# what the oracle took per layer on a GPU box's 16 granted cores (profiles/c4_shapes_cpu_r03.json), used only to SIZE the
+# live sample below and for the gate / up shape, whose 14336^2 LAPACK eigh (65 s) does not fit a bounded sample
+CPU_SHAPE_SECONDS_R03 = {"q_o": 5.5, "k_v": 0.81, "gate_up": 65.0, "down": 10.7}
+
+
+def cpu_baseline(full=False):
+    """The CPU oracle (oracle/ptdeco_oracle.py: the restatement of the reference, torch-CPU / MKL, pinned by the
+    reference-generated fixtures of tests/golden) on ONE layer of the headline stack's shapes ("for C4 time one
+    layer of each of the 4 distinct shapes"), same synthetic inputs as c4_shapes ([1, 2048, n_in] tokens, D = 8, M = 2,
+    f64 decomposition), host cores of this box.  A bounded sample: q/o, k/v and down live (about 17 s); gate/up (one
+    14336^2 eigh: 65 s) only with full=True, otherwise taken from the committed run of the same code on the same kind of
+    box and labelled so.  value = the 14-layer stack's layers per second from the per-shape seconds (a lower bound on the
+    CPU's cost: a layer alone is cheaper than the same layer inside the stack, whose metric forwards run 14 layers)."""
+    import ptdeco_oracle as orc    # (host_cores() put oracle/ on the path)
+
+    cores, physical, usable = host_cores()
     torch.set_num_threads(cores)
-    model, data, metric = make_workload(1, "cpu", D_STEPS, 7 * M_STEPS)
-    cpu = torch.device("cpu")
-    data, metric = with_targets(model, data, cpu), with_targets(model, metric, cpu)
+    secs, live = {}, []
+    for name, n_in, n_out in (("q_o", 4096, 4096), ("k_v", 4096, 1024), ("down", 14336, 4096), ("gate_up", 4096, 14336)):
+        if name == "gate_up" and not full:
+            secs[name] = CPU_SHAPE_SECONDS_R03[name]
+            continue
+        g = torch.Generator().manual_seed(1)
+        m = OneLinear(n_in, n_out)
+        with torch.no_grad():
+            m.lin.weight.copy_(torch.randn(n_out, n_in, generator=g) / n_in**0.5)
+        scale = torch.logspace(0, -2, n_in)
+        xs = [torch.randn(1, 2048, n_in, generator=g) * scale for _ in range(10)]
+        with torch.no_grad():
+            bt = [{"x": x, "targets": m({"x": x}).argmax(-1)} for x in xs]
+        t0 = time.perf_counter()
+        orc.dwain_decompose(module=m, data_iterator=itertools.cycle(bt), loss_fn=seq_ce, metric_iterator=itertools.cycle(bt[8:]),
+                            finetune_fn=None, num_data_steps=8, num_metric_steps=2, nsr_final_threshold=1.0,
+                            decompose_in_float64=True)
+        secs[name] = time.perf_counter() - t0
+        live.append(name)
+        del m, xs, bt
+    per_block = 2 * secs["q_o"] + 2 * secs["k_v"] + 2 * secs["gate_up"] + secs["down"]
+    return {"value": 7.0 / per_block, "unit": "layers/s", "cores": cores, "kind": "port",
+            "sample": "1 layer each of %s live (%.1f s); %s" % (
+                ", ".join(live), sum(secs[n] for n in live),
+                "all four shapes live" if full else "gate_up (one 14336^2 LAPACK eigh) 65.0 s from profiles/c4_shapes_cpu_r03.json"),
+            "workload": "oracle dwain on one layer of each Llama-3-8B shape, [1,2048,n_in] tokens, D=8, M=2, f64; value = 7 "
+                        "layers / (2 q_o + 2 k_v + 2 gate_up + down) seconds",
+            "s_per_layer": {k: round(v, 2) for k, v in secs.items()},
+            "physical_cores": physical, "usable_cpus": usable}
+
+
+def c1_cpu_line():
+    """BASELINE configs[0]: the CPU oracle's falor on the resnet18-shaped clone (tests/toy_models.ResNet18: torchvision
+    layout, 3 stride-2 1x1 downsample convolutions + fc), one fixed batch (5, 3, 224, 224), D = M = 1, use_mean=False,
+    use_damping=True, thresholds 0.01, proportion_threshold 0.9.  Seconds of one call."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ptdeco_oracle as orc
+    import toy_models as tm
+
+    cores, _, _ = host_cores()
+    torch.set_num_threads(cores)
+    torch.manual_seed(271828)
+    model = tm.ResNet18().eval()
+    g = torch.Generator().manual_seed(1314159)
+    x = torch.rand(5, 3, 224, 224, generator=g)
     t0 = time.perf_counter()
-    cfg = orc.dwain_decompose(module=model, data_iterator=itertools.cycle(data), loss_fn=ce_loss,
-                              metric_iterator=itertools.cycle(metric), finetune_fn=None, **DWAIN_KW)
-    dt = time.perf_counter() - t0
-    prop = cfg["layers.0"]["__meta__"]["proportion"] if cfg else 1.0
-    return {"value": 1.0 / dt, "unit": "layers/s", "cores": cores, "kind": "port",
-            "workload": "c2_single_layer (BASELINE configs[1]: dwain of ONE nn.Linear(4096,4096) f32, D=4, M=2) -- NOT the "
-                        "8-layer stack `value` is quoted on; the GPU figure for the same workload is gpu_same_workload",
-            "physical_cores": physical, "logical_cpus": os.cpu_count(), "usable_cpus": usable,   # usable = affinity and cgroup quota
-            "sample": f"the c2_single_layer workload once = 1 layer ({dt:.1f} s, torch threads = {cores}); one eighth of "
-                      f"the layers of the stack `value` times, whose per-layer CPU cost is higher (deeper forwards); "
-                      f"chosen proportion {prop}"}
+    cfg = orc.falor_decompose(module=model, data_iterator=itertools.repeat(x), proportion_threshold=0.9,
+                              nsr_final_threshold=0.01, kl_final_threshold=0.01, num_data_steps=1, num_metric_steps=1,
+                              use_float64=True, use_mean=False, use_damping=True)
+    return {"seconds": time.perf_counter() - t0, "layers": 4, "decomposed": len(cfg), "cores": cores}
 
 
-def launch_ranks(args) -> int:
+def c3_line(device, depth=12, batch=8):
+    """BASELINE configs[2]: falor.decompose_in_place (reference falor.py:424-511) on the ViT-B/16-shaped clone
+    (tests/toy_models.ViT: timm vit_base_patch16_224 layer names and shapes, 48 block Linears + head = 49 layers at depth 12),
+    random weights, synthetic [8, 3, 224, 224] images, the reference trainer's settings: D = 5, M = 5
+    (decompose_falor.yaml:21-22), thresholds 0.01 (:18-19), proportion_threshold 0.9, use_float64, use_mean=False,
+    use_damping=True (run_decompose_falor.py:92-93).  One warm-up call at depth 1, then ONE timed call at full depth."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ptdeco_amd
+    import toy_models as tm
+    from ptdeco_amd import _engine as eng
+
+    kw = dict(proportion_threshold=0.9, nsr_final_threshold=0.01, kl_final_threshold=0.01, num_data_steps=5,
+              num_metric_steps=5, use_float64=True, use_mean=False, use_damping=True)
+    g = torch.Generator().manual_seed(1)
+    pool = [torch.randn(batch, 3, 224, 224, generator=g).to(device) for _ in range(24)]
+
+    def run(d, phases):
+        model = tm.ViT(depth=d)
+        tm.init_randn(model, 0)
+        model.to(device).eval()
+        trace = []
+        if phases:
+            eng.PHASES = eng.PhaseTimer()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        cfg = ptdeco_amd.falor.decompose_in_place(module=model, device=device, data_iterator=itertools.cycle(pool),
+                                                  trace=trace, **kw)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        ph = None
+        if phases:
+            ph, eng.PHASES = {k: round(v, 1) for k, v in eng.PHASES.totals_ms().items()}, None
+        return dt, cfg, trace, ph
+
+    run(1, False)
+    dt, cfg, trace, ph = run(depth, True)
+    layers = 4 * depth + 1
+    return {"seconds": dt, "layers": layers, "layers_per_s": layers / dt, "candidates_evaluated": len(trace),
+            "decomposed": len(cfg), "phases_ms": ph,
+            "workload": "falor.decompose_in_place, ViT-B/16-shaped clone depth %d (%d Linear layers), f32 model, f64 covariance "
+                        "+ eigh, [%d,3,224,224] images, D=5, M=5, use_mean=False, use_damping=True, thresholds 0.01 / 0.9"
+                        % (depth, layers, batch)}
+
+
+def roofline_from_profile(prof, device):
+    """`roofline` of the headline step from the per-call eigensolver profiles of ONE step (ops.EIGH_PROFILE: HIP events on
+    the launch stream): the dominant package kernel of the step is the per-column SYMV of the direct tridiagonalisation
+    (HBM bound: SURVEY 8d, 8/3 n^3 bytes streamed per matrix) -- its launches of the largest direct problem."""
+    direct = [p for p in prof if p["method"] == 1 and p["launches"][0] > 0 and p["ms"][0] > 0]
+    if not direct:
+        return None
+    p = max(direct, key=lambda q: (q["n"], q["k"]))
+    n, cnt, ms, byts = p["n"], p["launches"][0], p["ms"][0], p["work"][0]
+    tr = pmc_traffic(n)
+    red_ms = p["ms"][0] + p["ms"][1]
+    all_bytes = sum(8.0 * (n - j - 1) * (n - j - 2) for j in range(n - 1))
+    out = {"bound": "hbm", "achieved": byts / (ms * 1e-3) / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
+           "frac": byts / (ms * 1e-3) / PEAK_HBM, "traffic": tr.get("traffic"),
+           "kernel": "sytrd_symv2_kernel (per-column SYMV of the Householder tridiagonalisation, lower-triangle tiles)",
+           "n": n, "k": p["k"], "launches": cnt, "avg_launch_us": ms / cnt * 1e3,
+           "algorithmic_bytes_per_launch": byts / cnt,
+           "solver_frac": all_bytes / (red_ms * 1e-3) / PEAK_HBM, "eigh_ms": p["total_ms"],
+           "of": "the (%d, %d) direct eigendecompositions inside one headline step" % (n, p["k"])}
+    if tr.get("traffic"):
+        out["traffic_stale"] = tr.get("traffic_stale")
+        out["traffic_source"] = tr.get("traffic_source")
+    return out
+
+
+def launch_ranks(args_list, gpus) -> int:
     """`python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes of this one
     (python -m torch.distributed.run, rendezvous on 127.0.0.1) before anything here has touched the GPU, pass
     their output through (rank 0 prints the JSON line) and return their exit code."""
@@ -566,30 +696,33 @@ def launch_ranks(args) -> int:
     with socket.socket() as sock:
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(args_list)
     return subprocess.call(cmd)
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip kernel / forward / cpu side measurements")
-    ap.add_argument("--no-bf16-stack", action="store_true", help="skip the second (bf16 model) timed run")
-    ap.add_argument("--no-weak-family", action="store_true", help="N > 1: skip the round-3 family (N layers on N GPUs)")
-    ap.add_argument("--no-c4", action="store_true", help="skip the Llama-3-8B shape / block extras")
-    ap.add_argument("--workload", choices=("stack", "c2"), default="stack",
-                    help="c2: time BASELINE configs[1] alone (one layer; for kernel traces); default: the fixed stack")
-    args = ap.parse_args()
+    ap.add_argument("--cpu-full", action="store_true", help="cpu_baseline: time the gate/up shape live too (+65 s)")
+    ap.add_argument("--no-extras", action="store_true", help="only the timed headline (+ C2 at N = 1): no side measurements")
+    ap.add_argument("--no-c3", action="store_true", help="skip BASELINE configs[2] (falor ViT-B/16 clone) and configs[0]")
+    ap.add_argument("--no-c4", action="store_true", help="skip the per-shape / one-block Llama detail lines")
+    ap.add_argument("--blocks", type=int, default=HEADLINE_BLOCKS, help="Llama blocks of the headline stack")
+    ap.add_argument("--workload", choices=("c4", "c2"), default="c4",
+                    help="c2: time BASELINE configs[1] alone (one layer; for kernel traces); default: the Llama stack")
+    ap.add_argument("--detail", default=os.path.join(ROOT, "bench_detail.json"))
+    return ap.parse_args(argv)
 
+
+def measure(args):
+    """Everything that needs the GPU.  Returns the full result dict on rank 0 (None on the other ranks)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world == 1 and args.gpus > 1:
-        raise SystemExit(launch_ranks(args))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
@@ -608,39 +741,13 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     import ptdeco_amd
+    from ptdeco_amd import _engine as eng
     from ptdeco_amd import ops
-
-    # ONE fixed workload at every N (strong scaling): a stack of 8 nn.Linear(4096, 4096), dwain with the precompute
-    # pass (1 split), D = 8 calibration steps.  Beside it at N = 1: BASELINE configs[1] (C2, one layer, D = 4) itself.
-    def build(n_layers, d_steps):
-        model, data, metric = make_workload(n_layers, device, d_steps, 7 * M_STEPS)
-        model.to(device)
-        return (model, with_targets(model, data, device), with_targets(model, metric, device),
-                dict(DWAIN_KW, num_data_steps=d_steps))
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-
-    def family(work, model_dtype):
-        """one_step of the workload `work` with the model and its activations in `model_dtype`."""
-        model32, data32, metric32, kw = work
-        if model_dtype == torch.float32:
-            model0, data, metric, loss = model32, data32, metric32, ce_loss
-        else:
-            model0 = copy.deepcopy(model32).to(model_dtype)
-            data = [{"x": b["x"].to(model_dtype), "targets": b["targets"]} for b in data32]
-            metric = [{"x": b["x"].to(model_dtype), "targets": b["targets"]} for b in metric32]
-            loss = lambda b, y: ce_loss(b, y.float())  # noqa: E731
-
-        def one_step():
-            model = copy.deepcopy(model0)
-            return ptdeco_amd.dwain.decompose_in_place(
-                module=model, device=device, data_iterator=itertools.cycle(data), loss_fn=loss,
-                metric_iterator=itertools.cycle(metric), finetune_fn=lambda m, d, names: m,
-                precomputing_covariance_num_splits=1, **kw)
-        return one_step
 
     def timed(one_step):
         """W untimed steps, then exactly K steps between barrier + synchronize; max over ranks.
@@ -660,298 +767,203 @@ def main():
             tmax = torch.tensor([dt], dtype=torch.float64, device=device)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax.item())
-        return dt, cfg, [round((b - a) * 1e3, 3) for a, b in zip([t0] + marks[:-1], marks)]
+        return dt, cfg, [round((b - a) * 1e3, 1) for a, b in zip([t0] + marks[:-1], marks)]
 
     def kept(cfg):
         return {k: v["__meta__"]["proportion"] for k, v in cfg.items()}
 
+    def c2_family():
+        model, data, metric = make_workload(1, device, D_STEPS, 7 * M_STEPS)
+        model.to(device)
+        data, metric = with_targets(model, data, device), with_targets(model, metric, device)
+
+        def one_step():
+            m = copy.deepcopy(model)
+            return ptdeco_amd.dwain.decompose_in_place(
+                module=m, device=device, data_iterator=itertools.cycle(data), loss_fn=ce_loss,
+                metric_iterator=itertools.cycle(metric), finetune_fn=lambda mm, d, names: mm,
+                precomputing_covariance_num_splits=1, **DWAIN_KW)
+        return one_step
+
+    c2_text = ("BASELINE configs[1]: dwain decompose_in_place of ONE nn.Linear(4096,4096) f32, precompute pass (1 split), "
+               "T=4x1024 tokens/batch, D=4, M=2, 6 evaluated candidate ranks, f64 covariance+eigh")
     if args.workload == "c2":
         # profiling aid: BASELINE configs[1] alone under the same protocol (python bench.py --workload c2 --no-extras)
-        c2 = build(1, D_STEPS)
-        dt, cfg, marks = timed(family(c2, torch.float32))
-        if rank == 0:
-            print(json.dumps({"metric": "layers decomposed/sec (incl. covariance+SVD)", "value": args.steps / dt,
-                              "unit": "layers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                              "ms_per_step": dt / args.steps * 1e3, "step_ms": marks, "higher_is_better": True,
-                              "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-                              "config": {"workload": "BASELINE configs[1]: dwain decompose_in_place of ONE "
-                                                     "nn.Linear(4096,4096) f32 (--workload c2)", "ranks_kept": kept(cfg)}}))
+        dt, cfg, marks = timed(c2_family())
+        res = {"metric": METRIC, "value": args.steps / dt, "unit": "layers/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "step_ms": marks, "higher_is_better": True,
+               "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": c2_text + " (--workload c2)", "ranks_kept": kept(cfg)}}
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
-        return
-    stack = build(STACK_LAYERS, STACK_D_STEPS)
-    stack_step = family(stack, torch.float32)
-    dt, cfg, marks = timed(stack_step)
-    what = ("dwain decompose_in_place of a FIXED stack of %d x nn.Linear(4096,4096) %s at every N (BASELINE configs[1]'s "
-            "layer, eight of them chained so that the same work is dealt to 1/2/4/8 GPUs as configs[3] shards its "
-            "stack), precompute pass (1 split), T=4x1024 tokens/batch, D=%d, M=2, 6 evaluated candidate ranks per "
-            "layer, f64 covariance+eigh%s")
-    comm = ("; calibration steps and (candidate, batch) pairs dealt to the ranks, packed-triangle covariance sums "
-            "reduced to the layer owners + eigenvector broadcast over RCCL") if world > 1 else ""
+        return res if rank == 0 else None
 
+    # ---- the headline: BASELINE configs[3] at reduced depth, bf16 model, the same work at every N
+    step, kw = llama_workload(device, args.blocks, torch.bfloat16)
+    layers = 7 * args.blocks
+    dt, cfg, marks = timed(step)
+    comm = ("; calibration steps and (candidate, batch) pairs dealt to the ranks, packed covariance sums reduced to the layer "
+            "owners + eigenvector broadcast over RCCL") if world > 1 else ""
+    med = sorted(marks)[len(marks) // 2]
     result = {
-        "metric": "layers decomposed/sec (incl. covariance+SVD)",
-        "value": STACK_LAYERS * args.steps / dt,
-        "unit": "layers/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3,
-        "step_ms": marks,
-        "higher_is_better": True,
-        "scaling": "strong",
-        "vs_baseline": None,
-        "dtype": "f64",
-        "data": "synthetic",
-        "config": {"workload": what % (STACK_LAYERS, "f32", STACK_D_STEPS, comm),
-                   "model_dtype": "float32",
-                   "layers_per_step": STACK_LAYERS, "parallelism": f"dp{world}" if world > 1 else "single",
-                   "metric_forwards": ("every (candidate, batch) pair runs the stack twice as the reference does; the "
-                                       "second run reuses the layer outputs ahead of the analysed layer that the first "
-                                       "run of the SAME pair just computed (PTD_PREFIX_MEMO_MB=0 switches that off); "
-                                       "nothing is kept across pairs, layers or steps"),
-                   "ranks_kept": kept(cfg)},
+        "metric": METRIC, "value": layers * args.steps / dt, "unit": "layers/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[3] at reduced depth: " + llama_workload_text(args.blocks, kw, torch.bfloat16) + comm,
+                   "model_dtype": "bfloat16", "layers_per_step": layers, "blocks": args.blocks,
+                   "parallelism": f"dp{world}" if world > 1 else "single"},
+        "spread": (max(marks) - min(marks)) / med,
     }
-    c2 = None
-    if world == 1:
-        # BASELINE configs[1] / SURVEY C2 exactly: ONE layer, D = 4 -- the workload of the roofline / eigh / phases /
-        # cpu_baseline blocks below, under the same K / W protocol
-        c2 = build(1, D_STEPS)
-        dt2, cfg2, marks2 = timed(family(c2, torch.float32))
-        result["c2_single_layer"] = {
-            "value": args.steps / dt2, "unit": "layers/s", "ms_per_step": dt2 / args.steps * 1e3, "step_ms": marks2,
-            "workload": "BASELINE configs[1]: dwain decompose_in_place of ONE nn.Linear(4096,4096) f32, precompute pass "
-                        "(1 split), T=4x1024 tokens/batch, D=4, M=2, 6 evaluated candidate ranks, f64 covariance+eigh",
-            "ranks_kept": kept(cfg2)}
-    if not args.no_bf16_stack:
-        # the fixed stack with a bf16 model ("model fp32 for parity, bf16 for throughput"), same K / W and
-        # the same barrier protocol: the method's own whole-model forwards (16 GEMMs per (candidate, batch) pair) are
-        # small next to the covariance + eigensolver part here
-        dt16, cfg16, marks16 = timed(family(stack, torch.bfloat16))
-        result["bf16_stack"] = {"value": STACK_LAYERS * args.steps / dt16, "unit": "layers/s",
-                                "ms_per_step": dt16 / args.steps * 1e3, "step_ms": marks16, "model_dtype": "bfloat16",
-                                "workload": what % (STACK_LAYERS, "bf16", STACK_D_STEPS, comm), "ranks_kept": kept(cfg16)}
-    if world > 1 and not args.no_weak_family:
-        # the round-3 family (a stack of N layers on N GPUs, D = max(4, N)): its own forwards grow as N^2 per step
-        weak = build(world, max(D_STEPS, world))
-        dtw, cfgw, marksw = timed(family(weak, torch.float32))
-        result["weak_family"] = {"value": world * args.steps / dtw, "unit": "layers/s", "scaling": "weak",
-                                 "ms_per_step": dtw / args.steps * 1e3, "step_ms": marksw,
-                                 "workload": "stack of %d x nn.Linear(4096,4096) f32, one layer per GPU, D=%d, M=2"
-                                             % (world, max(D_STEPS, world)), "ranks_kept": kept(cfgw)}
-        del weak
+    detail = {"step_ms": marks, "replaced": kept(cfg),
+              "metric_forwards": "every (candidate, batch) pair runs the stack twice as the reference does; the second run "
+                                 "reuses the layer outputs ahead of the analysed layer that the first run of the SAME pair just "
+                                 "computed (PTD_PREFIX_MEMO_MB=0 switches that off); nothing is kept across pairs, layers or steps"}
 
-    # the step the phase / eigensolver blocks describe: C2 at N = 1, the fixed stack otherwise
-    one_step = family(c2, torch.float32) if c2 is not None else stack_step
-    described = "c2_single_layer" if c2 is not None else "the fixed stack (`value`)"
-    from ptdeco_amd import _engine as _eng_stats
-    result["config"]["chain_streams"] = dict(_eng_stats.CHAIN_STREAM_STATS)     # (run_concurrently's stream checks so far)
-    if c2 is not None:
-        result["config"]["c2_single_layer_layers_per_s"] = result["c2_single_layer"]["value"]
-        result["config"]["c2_single_layer_ms_per_step"] = result["c2_single_layer"]["ms_per_step"]
-        result["config"]["blocks_of"] = ("value / ms_per_step: the fixed 8-layer stack; roofline, eigh, phases_ms, kernels and "
-                                         "cpu_baseline: c2_single_layer (BASELINE configs[1], one layer) -- each block names "
-                                         "its workload in `of` / `workload`")
-    prof = []
+    # ---- one more, untimed step with the phase spans (every rank takes part: the step contains collectives)
     if not args.no_extras:
-        # two extra, untimed steps.  (1) phase spans of the step on the device timeline (A accumulate, B
-        # eigh, C factors, D metrics, comm); (2) per-phase HIP-event timings inside the eigensolver.  Every rank takes
-        # part (the steps contain collectives); rank 0 keeps the numbers.
-        from ptdeco_amd import _engine as eng
         eng.PHASES = eng.PhaseTimer()
         barrier()
         t0p = time.perf_counter()
-        one_step()
+        trace = []
+        step(trace)
         barrier()
         wall_p = (time.perf_counter() - t0p) * 1e3
         ph, eng.PHASES = eng.PHASES.totals_ms(), None
         ph["other_host_and_gaps"] = max(0.0, wall_p - sum(ph.values()))
-        ph["step_wall_ms"] = wall_p
-        result["phases_ms"] = {k: round(v, 3) for k, v in ph.items()}
-        result["phases_ms"]["of"] = described
-        if c2 is not None:
-            # the same split for the workload `value` is quoted on (one more untimed step of the fixed stack)
-            eng.PHASES = eng.PhaseTimer()
-            barrier()
-            t0p = time.perf_counter()
-            stack_step()
-            barrier()
-            wall_s = (time.perf_counter() - t0p) * 1e3
-            ph, eng.PHASES = eng.PHASES.totals_ms(), None
-            ph["other_host_and_gaps"] = max(0.0, wall_s - sum(ph.values()))
-            ph["step_wall_ms"] = wall_s
-            result["stack_phases_ms"] = {k: round(v, 1) for k, v in ph.items()}
-            result["stack_phases_ms"]["of"] = "the fixed stack (`value`)"
+        if world > 1:
+            # per-rank maxima: a straggling owner shows here, not in rank 0's own spans
+            keys = ("A_accumulate", "B_eigh", "C_factors", "D_metrics", "comm")
+            t = torch.tensor([ph.get(k, 0.0) for k in keys], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            vals = t.tolist()
+            result["comm_ms"] = round(vals[4], 1)
+            result["b_eigh_ms_max"] = round(vals[1], 1)
+            result["d_metrics_ms_max"] = round(vals[3], 1)
+            result["rccl_ranks"] = world if not rehearse else 0
+            result["cov_collective"] = os.environ.get("PTD_COV_COLLECTIVE", "reduce")
+        result["phases_ms"] = {k: round(v, 1) for k, v in ph.items()}
+        detail["candidates_evaluated"] = len(trace)
+        # per-call eigensolver profiles of one more step (HIP events on the launch streams)
         ops.EIGH_PROFILE = []
-        one_step()
+        step()
         barrier()
         prof, ops.EIGH_PROFILE = ops.EIGH_PROFILE, None
-    if rank == 0 and not args.no_extras:
-        if prof:
-            p = prof[0]
-            n = p["n"]
-            t = p["total_ms"] * 1e-3
-            k = p["k"]  # eigenvectors formed: the largest candidate rank that is evaluated (n / 4 for a square layer)
-            algo_flops = 4.0 / 3.0 * n**3 + 2.0 * n * n * k
-            kl = {}
-            if p["method"] == 1:
-                # tridiagonal route: the dominant kernel is the per-column SYMV, bound by the stream
-                # of the trailing matrix (8/3 n^3 bytes per matrix for a one-stage reduction)
-                ms, cnt, byts = p["ms"][0], p["launches"][0], p["work"][0]
-                tr = pmc_traffic(n)
-                hw = {}
-                if tr.get("traffic"):
-                    # what the memory side actually moved per launch (the symmetric kernel reads one triangle) over the
-                    # same launch time: the hardware-side bandwidth fraction, below `frac` by construction
-                    hw = {"hw_achieved": tr["traffic"] * cnt / (ms * 1e-3) / 1e9,
-                          "hw_frac": tr["traffic"] * cnt / (ms * 1e-3) / PEAK_HBM}
-                # the whole reduction against the same bound: 8/3 n^3 bytes at the HBM peak vs the time from the first
-                # launch of the reduction to the tridiagonal matrix (SYMV + per-column kernels + rank-2k updates + gaps)
-                red_ms = p["ms"][0] + p["ms"][1]
-                all_bytes = sum(8.0 * (n - j - 1) * (n - j - 2) for j in range(n - 1))  # every column, resident ones too
-                result["roofline"] = {
-                    "bound": "hbm", "achieved": byts / (ms * 1e-3) / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
-                    "frac": byts / (ms * 1e-3) / PEAK_HBM, **tr, **hw,
-                    "solver_frac": all_bytes / (red_ms * 1e-3) / PEAK_HBM,
-                    "solver_note": "solver_frac = the algorithmic bytes of ALL columns (8/3 n^3) over the WHOLE reduction "
-                                   "time (%.1f ms: SYMV launches + per-column kernels + rank-2k updates + the resident "
-                                   "kernels + launch gaps); the full ptd_eigh call takes %.1f ms" % (red_ms, p["total_ms"]),
-                    "kernel": "sytrd_symv2_kernel / sytrd_symv_kernel (Householder tridiagonalisation, one SYMV launch "
-                              "per column down to a trailing order of 3072, symmetric lower-triangle tiles; the last "
-                              "3072 columns run in three launches, resident in registers -- every CU down to 768 "
-                              "columns, one XCD for the rest -- and read nothing from HBM)",
-                    "n": n, "launches": cnt, "avg_launch_us": ms / max(cnt, 1) * 1e3,
-                    "algorithmic_bytes_per_launch": byts / max(cnt, 1),
-                    "note": "algorithmic bytes = 8 (n-j-1)(n-j-2) per column j (rows j+1.., columns j+2.. of the "
-                            "trailing matrix, f64), summed over the columns that have a SYMV launch (all columns: "
-                            "8/3 n^3, SURVEY 8d: the stream of a one-stage SYMV); the symmetric kernel reads only the "
-                            "lower triangle, so its measured traffic is below that figure"}
-                kl["sytrd_symv_kernels"] = {"launches": cnt, "avg_us": ms / max(cnt, 1) * 1e3, "total_ms": ms,
-                                           "gbps": byts / (ms * 1e-3) / 1e9}
-                kl["sytrd_other_per_column"] = {"total_ms": p["ms"][1],
-                                                "note": "alpha kernels + rank-2k updates + resident kernels + launch gaps"}
-                kl["eigvals_invit_backtransform"] = {"total_ms": p["ms"][3]}
-            elif p["method"] == 0:
-                names = ("jac_gram_kernel", "jac_inner_kernel", "jac_update_kernel")
-                for i, nm in enumerate(names):
-                    ms, cnt, fl = p["ms"][i], p["launches"][i], p["work"][i]
-                    kl[nm] = {"launches": cnt, "avg_us": ms / max(cnt, 1) * 1e3, "total_ms": ms}
-                    if fl:
-                        kl[nm]["executed_tflops"] = fl / (ms * 1e-3) / 1e12
-                        kl[nm]["frac_of_f64_mfma_peak"] = fl / (ms * 1e-3) / PEAK_F64_MFMA
-                result["roofline"] = {"bound": "mfma", "achieved": algo_flops / t / 1e12, "peak": PEAK_F64_MFMA / 1e12,
-                                      "unit": "TFLOP/s", "frac": algo_flops / t / PEAK_F64_MFMA, "traffic": None,
-                                      "kernel": "ptd_eigh (one-sided block Jacobi: jac_gram + jac_inner + jac_update)",
-                                      "n": n, "sweeps": p["sweeps"], "algorithmic_flops": algo_flops}
-            if p["method"] == 3:
-                # filtered subspace iteration (the default route for k <= n / 3): every large step is an f64 product on
-                # the matrix cores; the dominant kernel is the product C X of the filter (n x n x m), timed here on the
-                # same shapes with HIP events on the launch stream
-                m_blk = p["launches"][2]
-                nprod = p["launches"][1]
-                gx = torch.Generator(device=device).manual_seed(11)
-                cm = torch.randn(n, n, generator=gx, device=device, dtype=torch.float64)
-                xm = torch.randn(n, m_blk, generator=gx, device=device, dtype=torch.float64)
-                t_prod = time_events(lambda: ops.matmul(cm, xm), iters=20)
-                fl = 2.0 * n * n * m_blk
-                del cm, xm
-                # HBM-side bytes per launch and the matrix-pipe busy share from the committed counter passes over the
-                # same kernel (tools/pmc_driver eigh, tools/pmc_filtered_summary.py); counters cannot be read in-process
-                trf = {"traffic": None}
-                pmc = pmc_file("pmc_gemm_f64_r*.json", ("gemm_f64.hip", "eigh_filtered.hip"))
-                if pmc and pmc["data"].get("traffic_bytes_per_launch"):
-                    dd = pmc["data"]
-                    trf = {"traffic": dd["traffic_bytes_per_launch"],
-                           "traffic_source": pmc["source"] + ": (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per launch, %.2f x the "
-                                             "algorithmic bytes 8 (n^2 + 2 n m)" % dd["traffic_over_algorithmic"],
-                           "traffic_stale": pmc["stale"]}
-                    if dd.get("mfma_busy_over_cu_busy_x4_percent") is not None:
-                        trf["mfma_util_pmc_percent"] = dd["mfma_busy_over_cu_busy_x4_percent"]
-                result["roofline"] = {
-                    "bound": "mfma", "achieved": fl / t_prod / 1e12, "peak": PEAK_F64_MFMA / 1e12, "unit": "TFLOP/s",
-                    "frac": fl / t_prod / PEAK_F64_MFMA, **trf,
-                    "kernel": "gemm_f64_glds_kernel<5, false> (C X of the Chebyshev filter: %d x %d x %d f64, "
-                              "v_mfma_f64_16x16x4_f64, LDS-DMA staged 128 x 80 tiles)" % (n, n, m_blk),
-                    "n": n, "m": m_blk, "launches": nprod, "avg_launch_us": t_prod * 1e6,
-                    "algorithmic_flops_per_launch": fl,
-                    "solver_frac": nprod * fl / (p["total_ms"] * 1e-3) / PEAK_F64_MFMA,
-                    "solver_note": "solver_frac = the flop of the %d products with C over the WHOLE ptd_eigh_topk call "
-                                   "(%.1f ms: Lanczos bounds %.1f, filter rounds incl. Cholesky-QR passes %.1f, the %d x %d "
-                                   "Rayleigh-Ritz eigenproblem %.1f, Ritz products + residual check %.1f)"
-                                   % (nprod, p["total_ms"], p["ms"][0], p["ms"][1], m_blk, m_blk, p["ms"][2], p["ms"][3]),
-                    "note": "algorithmic flops of one launch = 2 n^2 m; the solver's own count (SURVEY 8d) is 4/3 n^3 + "
-                            "2 n^2 k for a direct reduction -- the filtered route executes more flops (%d products) on "
-                            "the matrix cores instead of a latency-bound Householder reduction" % nprod}
-                kl = {"lanczos_bounds": {"total_ms": p["ms"][0], "steps": p["launches"][0]},
-                      "filter_rounds": {"total_ms": p["ms"][1], "products_with_C": nprod,
-                                        "product_ms_each": t_prod * 1e3},
-                      "rayleigh_ritz_eigh": {"total_ms": p["ms"][2], "order": m_blk},
-                      "ritz_products_and_residuals": {"total_ms": p["ms"][3]}}
-            if p["method"] == 2:
-                # two-stage route (opt-in): stage 1 is the f64-MFMA-bound kernel family
-                result["roofline"] = {"bound": "mfma", "achieved": p["work"][0] / (p["ms"][0] * 1e-3) / 1e12,
-                                      "peak": PEAK_F64_MFMA / 1e12, "unit": "TFLOP/s",
-                                      "frac": p["work"][0] / (p["ms"][0] * 1e-3) / PEAK_F64_MFMA, "traffic": None,
-                                      "kernel": "two-stage reduction, stage 1 (dense -> band 32): 4/3 n^3 flop on the f64 "
-                                                "matrix cores", "n": n}
-                kl = {"stage1_dense_to_band": {"total_ms": p["ms"][0]}, "stage2_bulge_chase": {"total_ms": p["ms"][1]},
-                      "tridiagonal_eigenpairs": {"total_ms": p["ms"][2]},
-                      "backtransform_q2_q1": {"total_ms": p["ms"][3], "q2_ms": p["launches"][3] / 1e3}}
-            result["eigh"] = {"method": {0: "jacobi", 1: "tridiagonal", 2: "two-stage tridiagonal",
-                                         3: "filtered subspace iteration"}[p["method"]], "n": n, "k": k,
-                              "ms_per_matrix": p["total_ms"],
-                              "algorithmic_tflops": algo_flops / t / 1e12,
-                              "frac_of_f64_mfma_peak_on_algorithmic_flops": algo_flops / t / PEAK_F64_MFMA}
-            result["kernels"] = kl
-            # context, not credit: the reference's own device path is torch.linalg.eigh (dwain.py:162) -- the library
-            # eigensolver on the same box and a covariance of the same workload (all n eigenpairs: it has no top-k)
-            try:
-                e = torch.zeros(n, n, dtype=torch.float64, device=device)
-                ref_model, ref_data = (c2 if c2 is not None else stack)[:2]
-                for b in ref_data[:D_STEPS]:
-                    ops.syrk_accumulate(e, ops.matmul(b["x"].reshape(-1, N_FEAT), ref_model.layers[0].weight.T), 1.0 / (BATCH * SEQ))
-                c = ops.cov_finalize(e, D_STEPS, 0.01)
-                torch.linalg.eigh(c)
-                torch.cuda.synchronize()
-                t0l = time.perf_counter()
-                torch.linalg.eigh(c)
-                torch.cuda.synchronize()
-                result["eigh"]["gpu_library_eigh_ms"] = (time.perf_counter() - t0l) * 1e3
-                result["eigh"]["gpu_library_eigh_note"] = ("torch.linalg.eigh on the device, same n and a covariance of the "
-                                                           "same workload, all eigenpairs (context only)")
-                del e, c
-            except Exception as exc:  # the library call is context: never fail the bench for it
-                result["eigh"]["gpu_library_eigh_ms"] = None
-                result["eigh"]["gpu_library_eigh_note"] = f"torch.linalg.eigh failed: {exc}"
-        if "roofline" in result:
-            result["roofline"]["of"] = ("the dominant kernel of ptd_eigh_topk inside one step of `%s` (NOT of the 8-layer "
-                                        "stack `value` is quoted on, whose step is 70 %% model forwards)" % described)
-        if "eigh" in result:
-            result["eigh"]["of"] = described
-        result["kernels"] = {**result.get("kernels", {}), **kernel_lines(device)}
-        result["decomposed_fwd"] = decomposed_forward_lines(device)
-        # SURVEY 8d C5 lists T = 4096 / 16384 / 65536: the other two row counts, package pair against library pair
-        result["decomposed_fwd"]["rows_4096"] = decomposed_forward_lines(device, 4096, full=False)
-        result["decomposed_fwd"]["rows_65536"] = decomposed_forward_lines(device, 65536, full=False)
-        if world == 1 and not args.no_c4:
-            result["c4_shapes"] = llama_shape_lines(device)
-            result["c4_block"] = llama_block_lines(device)
-            # two full-width blocks end to end: replace -> next-layer-sees-it at depth > 1
-            result["c4_stack"] = llama_block_lines(device, blocks=2, dtypes=(torch.bfloat16,), timed=3)
-        if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline()
-            if c2 is not None:
-                result["cpu_baseline"]["gpu_same_workload"] = {"value": result["c2_single_layer"]["value"], "unit": "layers/s",
-                                                               "ms_per_step": result["c2_single_layer"]["ms_per_step"]}
-
-    if rank == 0:
-        result["config"]["chain_streams_at_exit"] = dict(_eng_stats.CHAIN_STREAM_STATS)
-        print(json.dumps(result))
+        if rank == 0:
+            rl = roofline_from_profile(prof, device)
+            if rl:
+                result["roofline"] = rl
+            detail["eigh_calls"] = [eigh_route_block(p) for p in prof]
+    del step
     if world > 1:
-        dist.barrier()  # rank 0 may still be in its side measurements
+        if rank == 0:
+            detail["chain_streams"] = dict(eng.CHAIN_STREAM_STATS)
+            result["detail"] = detail
+        dist.barrier()
         dist.destroy_process_group()
+        return result if rank == 0 else None
+
+    # ---- N = 1: the other BASELINE configs and the side measurements
+    dt2, cfg2, marks2 = timed(c2_family())
+    result["c2_layers_per_s"] = args.steps / dt2
+    result["c2_ms_per_step"] = dt2 / args.steps * 1e3
+    detail["c2_single_layer"] = {"workload": c2_text, "step_ms": marks2, "ranks_kept": kept(cfg2)}
+    if not args.no_extras:
+        if not args.no_c3:
+            c3 = c3_line(device)
+            result["c3_s"] = c3["seconds"]
+            result["c3_layers_per_s"] = c3["layers_per_s"]
+            detail["c3"] = c3
+        detail["kernels"] = kernel_lines(device)
+        fwd = decomposed_forward_lines(device)
+        # SURVEY 8d C5 lists T = 4096 / 16384 / 65536: the other two row counts, package pair against library pair
+        fwd["rows_4096"] = decomposed_forward_lines(device, 4096, full=False)
+        fwd["rows_65536"] = decomposed_forward_lines(device, 65536, full=False)
+        detail["decomposed_fwd"] = fwd
+        # BASELINE's second metric (decomposed-fwd GFLOP/s), configs[4] at T = 16384
+        result["fwd_gflops"] = {f"r{r}": round(fwd[f"r{r}"]["gflops"]) for r in (256, 512, 1024)}
+        result["fwd_vs_lib_pair"] = {f"r{r}": round(fwd[f"r{r}"]["torch_hipblaslt_pair_ms"] / fwd[f"r{r}"]["ms"], 3)
+                                     for r in (256, 512, 1024)}
+        if not args.no_c4:
+            detail["c4_shapes"] = llama_shape_lines(device)
+            detail["c4_block"] = llama_block_lines(device)
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(full=args.cpu_full)
+            if not args.no_c3:
+                c1 = c1_cpu_line()
+                result["c1_cpu_s"] = c1["seconds"]
+                detail["c1_cpu"] = c1
+    detail["chain_streams"] = dict(eng.CHAIN_STREAM_STATS)
+    result["detail"] = detail
+    return result
+
+
+CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                 "vs_baseline", "dtype", "data", "config")
+
+
+def compact_line(result: dict, detail_path: str) -> str:
+    """The ONE line the driver parses: the contract keys, `roofline`, `cpu_baseline` and the scalar side figures, never
+    more than LINE_LIMIT bytes -- optional keys are shortened, then dropped (longest first), until it fits."""
+    line = {k: v for k, v in result.items() if k != "detail"}
+    line["detail"] = os.path.relpath(detail_path, ROOT) if detail_path else None
+
+    def rounded(v):
+        if isinstance(v, float):
+            return float(f"{v:.6g}")
+        if isinstance(v, dict):
+            return {k: rounded(x) for k, x in v.items()}
+        if isinstance(v, list):
+            return [rounded(x) for x in v]
+        return v
+    line = rounded(line)
+    text = json.dumps(line)
+    if len(text.encode()) > LINE_LIMIT:
+        for blk in ("roofline", "cpu_baseline"):    # long provenance strings first
+            for key in ("traffic_source", "solver_note", "note", "workload", "s_per_layer"):
+                if isinstance(line.get(blk), dict):
+                    line[blk].pop(key, None)
+        text = json.dumps(line)
+    optional = [k for k in line if k not in CONTRACT_KEYS and k not in ("roofline", "cpu_baseline", "detail")]
+    while len(text.encode()) > LINE_LIMIT and optional:
+        victim = max(optional, key=lambda k: len(json.dumps(line[k])))
+        optional.remove(victim)
+        del line[victim]
+        text = json.dumps(line)
+    if len(text.encode()) > LINE_LIMIT:
+        line["config"] = {"workload": str(line["config"].get("workload"))[:600]}
+        for blk in ("roofline", "cpu_baseline"):
+            if isinstance(line.get(blk), dict):
+                line[blk] = {k: v for k, v in line[blk].items() if not isinstance(v, str) or len(v) <= 80}
+        text = json.dumps(line)
+    assert len(text.encode()) <= LINE_LIMIT, len(text.encode())
+    return text
+
+
+def main(argv=None, measure_fn=None) -> int:
+    args = parse_args(argv)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if measure_fn is None and world == 1 and args.gpus > 1:
+        return launch_ranks(sys.argv[1:] if argv is None else argv, args.gpus)
+    result = (measure_fn or measure)(args)
+    if result is None:          # ranks other than 0
+        return 0
+    detail_path = None
+    if "detail" in result:
+        full = dict(result)
+        detail_path = args.detail
+        blob = json.dumps(full, indent=1)
+        for path in (detail_path, os.path.join(ROOT, "gpurun_out", "bench_detail.json")):
+            try:
+                os.makedirs(os.path.dirname(path), exist_ok=True)
+                with open(path, "w") as fh:
+                    fh.write(blob)
+            except OSError as exc:      # a read-only tree must not cost the line
+                print(f"bench.py: could not write {path}: {exc}", file=sys.stderr)
+        print(f"bench.py: detail blocks written to {detail_path} (and gpurun_out/bench_detail.json)", flush=True)
+    print(compact_line(result, detail_path), flush=True)
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    raise SystemExit(main())
