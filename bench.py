@@ -561,9 +561,9 @@ def cpu_baseline(full=False):
     14336^2 eigh: 65 s) only with full=True, otherwise taken from the committed run of the same code on the same kind of
     box and labelled so.  value = the 14-layer stack's layers per second from the per-shape seconds (a lower bound on the
     CPU's cost: a layer alone is cheaper than the same layer inside the stack, whose metric forwards run 14 layers)."""
-    import ptdeco_oracle as orc    # (host_cores() put oracle/ on the path)
+    cores, physical, usable = host_cores()      # (puts oracle/ on the path)
+    import ptdeco_oracle as orc
 
-    cores, physical, usable = host_cores()
     torch.set_num_threads(cores)
     secs, live = {}, []
     for name, n_in, n_out in (("q_o", 4096, 4096), ("k_v", 4096, 1024), ("down", 14336, 4096), ("gate_up", 4096, 14336)):
@@ -601,10 +601,10 @@ def c1_cpu_line():
     layout, 3 stride-2 1x1 downsample convolutions + fc), one fixed batch (5, 3, 224, 224), D = M = 1, use_mean=False,
     use_damping=True, thresholds 0.01, proportion_threshold 0.9.  Seconds of one call."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
+    cores, _, _ = host_cores()                  # (puts oracle/ on the path)
     import ptdeco_oracle as orc
     import toy_models as tm
 
-    cores, _, _ = host_cores()
     torch.set_num_threads(cores)
     torch.manual_seed(271828)
     model = tm.ResNet18().eval()
@@ -868,31 +868,52 @@ def measure(args):
     result["c2_layers_per_s"] = args.steps / dt2
     result["c2_ms_per_step"] = dt2 / args.steps * 1e3
     detail["c2_single_layer"] = {"workload": c2_text, "step_ms": marks2, "ranks_kept": kept(cfg2)}
+    def side(name, fn):
+        """A side measurement must never cost the headline line: its failure is recorded in the detail file."""
+        try:
+            return fn()
+        except Exception as exc:  # noqa: BLE001
+            import traceback
+            detail[name + "_error"] = "%s: %s" % (type(exc).__name__, exc)
+            print("bench.py: side measurement %s failed:\n%s" % (name, traceback.format_exc()), file=sys.stderr, flush=True)
+            return None
+
     if not args.no_extras:
         if not args.no_c3:
-            c3 = c3_line(device)
-            result["c3_s"] = c3["seconds"]
-            result["c3_layers_per_s"] = c3["layers_per_s"]
-            detail["c3"] = c3
-        detail["kernels"] = kernel_lines(device)
-        fwd = decomposed_forward_lines(device)
-        # SURVEY 8d C5 lists T = 4096 / 16384 / 65536: the other two row counts, package pair against library pair
-        fwd["rows_4096"] = decomposed_forward_lines(device, 4096, full=False)
-        fwd["rows_65536"] = decomposed_forward_lines(device, 65536, full=False)
-        detail["decomposed_fwd"] = fwd
-        # BASELINE's second metric (decomposed-fwd GFLOP/s), configs[4] at T = 16384
-        result["fwd_gflops"] = {f"r{r}": round(fwd[f"r{r}"]["gflops"]) for r in (256, 512, 1024)}
-        result["fwd_vs_lib_pair"] = {f"r{r}": round(fwd[f"r{r}"]["torch_hipblaslt_pair_ms"] / fwd[f"r{r}"]["ms"], 3)
-                                     for r in (256, 512, 1024)}
+            c3 = side("c3", lambda: c3_line(device))
+            if c3:
+                result["c3_s"] = c3["seconds"]
+                result["c3_layers_per_s"] = c3["layers_per_s"]
+                detail["c3"] = c3
+        kl = side("kernels", lambda: kernel_lines(device))
+        if kl:
+            detail["kernels"] = kl
+
+        def forward_lines():
+            fwd = decomposed_forward_lines(device)
+            # SURVEY 8d C5 lists T = 4096 / 16384 / 65536: the other two row counts, package pair against library pair
+            fwd["rows_4096"] = decomposed_forward_lines(device, 4096, full=False)
+            fwd["rows_65536"] = decomposed_forward_lines(device, 65536, full=False)
+            return fwd
+        fwd = side("decomposed_fwd", forward_lines)
+        if fwd:
+            detail["decomposed_fwd"] = fwd
+            # BASELINE's second metric (decomposed-fwd GFLOP/s), configs[4] at T = 16384
+            result["fwd_gflops"] = {f"r{r}": round(fwd[f"r{r}"]["gflops"]) for r in (256, 512, 1024)}
+            result["fwd_vs_lib_pair"] = {f"r{r}": round(fwd[f"r{r}"]["torch_hipblaslt_pair_ms"] / fwd[f"r{r}"]["ms"], 3)
+                                         for r in (256, 512, 1024)}
         if not args.no_c4:
-            detail["c4_shapes"] = llama_shape_lines(device)
-            detail["c4_block"] = llama_block_lines(device)
+            detail["c4_shapes"] = side("c4_shapes", lambda: llama_shape_lines(device))
+            detail["c4_block"] = side("c4_block", lambda: llama_block_lines(device))
         if not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(full=args.cpu_full)
+            cb = side("cpu_baseline", lambda: cpu_baseline(full=args.cpu_full))
+            if cb:
+                result["cpu_baseline"] = cb
             if not args.no_c3:
-                c1 = c1_cpu_line()
-                result["c1_cpu_s"] = c1["seconds"]
-                detail["c1_cpu"] = c1
+                c1 = side("c1_cpu", c1_cpu_line)
+                if c1:
+                    result["c1_cpu_s"] = c1["seconds"]
+                    detail["c1_cpu"] = c1
     detail["chain_streams"] = dict(eng.CHAIN_STREAM_STATS)
     result["detail"] = detail
     return result

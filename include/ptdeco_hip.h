@@ -31,8 +31,10 @@
 extern "C" {
 #endif
 
-#define PTD_ABI_VERSION 3   /* 2: ptd_nsr workspaces are initialised once (ptd_nsr_workspace_init); ptd_chol_inverse
-                             * 3: ptd_stream_pair_wall_us, ptd_streams_wall_us, ptd_syrk_accumulate_multi */
+#define PTD_ABI_VERSION 4   /* 2: ptd_nsr workspaces are initialised once (ptd_nsr_workspace_init); ptd_chol_inverse
+                             * 3: ptd_stream_pair_wall_us, ptd_streams_wall_us, ptd_syrk_accumulate_multi
+                             * 4: ptd_eigh_topk_batched, ptd_eigh_factored_prepare / _finish; ptd_band_reduce and the
+                             *    two-stage reduction behind it are gone (2.2 x behind the default for three rounds) */
 
 typedef enum { PTD_F32 = 0, PTD_F64 = 1, PTD_BF16 = 2 } ptd_dtype;
 
@@ -156,6 +158,23 @@ size_t ptd_eigh_f32_workspace_bytes(int64_t n, int64_t k);
 int ptd_eigh_topk_f32(const float* A, int64_t lda, int64_t n, int64_t k, int all_values, float* evals, float* evecs,
                       int64_t ldv, void* ws, size_t ws_bytes, int* sweeps_out, void* stream);
 
+/* ptd_eigh_topk for `count` matrices of ONE order and ONE k in a single call (ABI 4): As / evals / evecs are HOST arrays
+ * of `count` device pointers, every matrix [n, n] with leading dimension lda, every evecs [n, k] with ldv; results and
+ * contract per matrix exactly as ptd_eigh_topk.  Replaces the LOOP of `torch.linalg.eigh` calls of dwain's precompute
+ * pass (dwain.py:580-633 calls get_eigenvectors -> :162 once per layer of a split): the direct reduction is a chain
+ * of ~2 n dependent launches per matrix, so the matrices advance column by column in lockstep and every launch
+ * serves all of them (blockIdx.y = matrix) -- one host thread, one stream, one host synchronisation for the batch,
+ * where round 5 ran one thread and one stream per layer.  Requests the filtered route serves (see above) and single
+ * matrices are solved one after the other exactly as ptd_eigh_topk would; two matrices are batched from n = 1025 on
+ * (PTD_EIGH_BATCH_MIN_N), three or more always; PTD_EIGH_BATCHED=0: never.  stats (HOST pointer, may be NULL): the
+ * ptd_eigh_profiled figures of the batch (method 1: `sweeps` = matrices per launch, work[0] = algorithmic bytes of
+ * all of them) or of the last matrix when solved one by one.  Workspace: ptd_eigh_batched_workspace_bytes. */
+size_t ptd_eigh_batched_workspace_bytes(int64_t n, int64_t k, int count);
+struct ptd_eigh_stats_s;
+int ptd_eigh_topk_batched(const double* const* As, int64_t lda, int count, int64_t n, int64_t k, int all_values,
+                          double* const* evals, double* const* evecs, int64_t ldv, void* ws, size_t ws_bytes,
+                          struct ptd_eigh_stats_s* stats, void* stream);
+
 /* The solver ptd_eigh_topk would try FIRST for this request: 3 = filtered subspace iteration (chip-filling f64
  * products: concurrent chains gain nothing), 1 = direct tridiagonal reduction (a latency-bound chain of short
  * launches: independent matrices overlap well on separate streams), 0 = Jacobi.  A host-side query; the filtered
@@ -176,6 +195,21 @@ int ptd_eigh_factored(const void* W, int64_t ldw, int w_dtype, int64_t n_o, int6
                       const double* Ex, int64_t ldx, int64_t k, double* evals_k, double* U, int64_t ldu,
                       void* ws, size_t ws_bytes, void* stream);
 
+/* ptd_eigh_factored in two halves around an eigendecomposition the CALLER runs (ABI 4), so that the inner n_i-sized
+ * problems of several layers (Llama gate, up) and the same-sized covariances of others (down) share one
+ * ptd_eigh_topk_batched call.  prepare: G = W^T W = L L^T, B = L^T Ex L; *B_out (HOST pointers to results) receives the
+ * device address of B [np, np] (f64, full symmetric, ld np) inside the workspace and *np_out = np = n_i rounded up to
+ * 64 (the padding carries exact, tiny eigenvalues that never reach the top k).  Synchronises the stream once (the
+ * Cholesky status); PTD_ERR_UNSUPPORTED as ptd_eigh_factored.  finish: evals [np] ascending and S [np, k] (ld lds)
+ * = eigenvectors of B's k largest eigenvalues -> U [n_o, k] = W L^-T S, evals_k (may be NULL).  The SAME workspace
+ * (ptd_eigh_factored_workspace_bytes(n_o, n_i, k)), untouched in between.  Same reference lines as ptd_eigh_factored
+ * (dwain.py:147-163). */
+int ptd_eigh_factored_prepare(const void* W, int64_t ldw, int w_dtype, int64_t n_o, int64_t n_i, const double* Ex,
+                              int64_t ldx, int64_t k, void* ws, size_t ws_bytes, double** B_out, int64_t* np_out,
+                              void* stream);
+int ptd_eigh_factored_finish(int64_t n_o, int64_t n_i, int64_t k, const double* evals, const double* S, int64_t lds,
+                             double* evals_k, double* U, int64_t ldu, void* ws, size_t ws_bytes, void* stream);
+
 /* Same, with per-phase device timing (HIP events on `stream` around the launches of each
  * phase; a few percent slower, for bench.py's roofline lines).  `stats` is a HOST pointer.
  *   method 0 (Jacobi):       phase 0 jac_gram, 1 jac_inner, 2 jac_update            (work = f64 flops executed)
@@ -185,19 +219,14 @@ int ptd_eigh_factored(const void* W, int64_t ldw, int w_dtype, int64_t n_o, int6
  *                            reduction (alpha kernels, rank-2k updates, launch gaps), 2 work only
  *                            (flops of the rank-2k updates), 3 eigenvalues + inverse iteration +
  *                            back-transformation
- *   method 2 (two-stage tridiagonal, n a multiple of 32 in [128, 8192]): ms = {stage 1 dense -> band of
- *                            width 32 on the f64 matrix cores, stage 2 bulge chasing, eigenpairs of T,
- *                            back-transformation Q1 Q2 Y}; work = {4/3 n^3 flop, 6 n^2 b flop, 0,
- *                            4 n^2 k flop}; launches[3] = microseconds of the Q2 part of the
- *                            back-transformation
  *   method 3 (filtered subspace iteration, the route of ptd_eigh_topk with all_values = 0, n >= 2048, 7 k <= 2 n):
  *                            ms = {Lanczos bounds, filter rounds (products with C + Cholesky-QR passes), the
  *                            Rayleigh-Ritz eigenproblem of order launches[2], Ritz products + residual check};
  *                            launches = {Lanczos steps, products with C, subspace dimension m, 0};
  *                            work[1] = flop of the products with C (2 n^2 m each) */
-typedef struct {
+typedef struct ptd_eigh_stats_s {
   int method;
-  int sweeps;        /* Jacobi sweeps; 0 for the tridiagonal route */
+  int sweeps;        /* Jacobi sweeps; 0 for the tridiagonal route (ptd_eigh_topk_batched: matrices per launch) */
   int launches[4];
   float ms[4];       /* summed device time of the phase's launches */
   double work[4];
@@ -212,16 +241,6 @@ int ptd_eigh_profiled(const double* A, int64_t lda, int64_t n, int64_t k, int al
 size_t ptd_tridiagonalize_workspace_bytes(int64_t n);
 int ptd_tridiagonalize(const double* A, int64_t lda, int64_t n, double* d, double* e, double* evals,
                        void* ws, size_t ws_bytes, void* stream);
-
-/* Diagnostic: the two-stage reduction (dense -> band of width PTD_BAND -> tridiagonal) stopped after
- * `stages` (1 or 2) stages.  band [n][PTD_BAND_LD]: entry (i, j) of the band matrix, 0 <= i - j <=
- * 2 PTD_BAND, at band[i * PTD_BAND_LD + (j - i + 2 PTD_BAND)] (lower part; the matrix is symmetric).
- * Workspace: ptd_tridiagonalize_workspace_bytes(n).  PTD_ERR_UNSUPPORTED if the two-stage route does
- * not apply to n. */
-#define PTD_BAND 32
-#define PTD_BAND_LD 66
-int ptd_band_reduce(const double* A, int64_t lda, int64_t n, int stages, double* band, void* ws,
-                    size_t ws_bytes, void* stream);
 
 /* Diagnostic: the Cholesky sweep of the filtered eigensolver's orthonormalisation passes on its own (the
  * step that replaces nothing in the reference -- torch.linalg.eigh hides it -- but is the latency-critical

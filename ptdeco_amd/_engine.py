@@ -838,37 +838,108 @@ class Covariance:
                     self.ey.copy_(flat[1:].to(self.ey.dtype))
         return complete
 
-    def eigenvectors(self, damp_factor: float, use_mean: bool = False, top_k: Optional[int] = None) -> torch.Tensor:
-        """Finalise (divide by steps, optional mean removal, Tikhonov damping) and return the
-        eigenvectors in columns, ascending, f64 (dwain.py:155-163, falor.py:192-208).  With
-        ``top_k`` only the last top_k columns (largest eigenvalues) are formed: [n, top_k]."""
+    def eigen_order(self, top_k: Optional[int]) -> tuple:
+        """(order, k) of the eigenproblem `problem` will pose -- known without touching the device, so that the
+        problems of a precompute pass can be grouped before any of them is formed."""
+        if self.input_route:
+            n = (self.weight.shape[1] + 63) // 64 * 64       # (the factored problem is padded to whole 64 x 64 tiles)
+            return n, max(1, min(int(top_k), self.weight.shape[1]))
+        n = self.E.shape[0]
+        return n, (n if top_k is None else max(1, min(int(top_k), n)))
+
+    def problem(self, damp_factor: float, use_mean: bool = False, top_k: Optional[int] = None) -> "EighProblem":
+        """Finalise (divide by steps, optional mean removal, Tikhonov damping) and pose the eigenproblem whose solution
+        gives the layer's eigenvectors (dwain.py:155-163, falor.py:192-208)."""
         self.batch.flush()
         if self.input_route:
             # cov = W (Ex - mx mx^T) W^T when the mean is removed (falor.py:196-199); damping only shifts eigenvalues
             ex = ops.cov_finalize(self.E, self.steps, 0.0, self.ey if use_mean else None)
-            return eigenvectors_from_input_moment(self.weight, ex, damp_factor, top_k, factored=True)
+            return problem_from_input_moment(self.weight, ex, damp_factor, top_k, factored=True)
         c = ops.cov_finalize(self.E, self.steps, damp_factor, self.ey if use_mean else None)
-        _, u = ops.eigh(c, top_k, all_values=False)
-        return u
+        return EighProblem(c, top_k)
+
+    def eigenvectors(self, damp_factor: float, use_mean: bool = False, top_k: Optional[int] = None) -> torch.Tensor:
+        """The eigenvectors in columns, ascending, f64.  With ``top_k`` only the last top_k columns (largest
+        eigenvalues) are formed: [n, top_k]."""
+        return self.problem(damp_factor, use_mean, top_k).solve()
 
 
-def eigenvectors_from_input_moment(weight: torch.Tensor, ex: torch.Tensor, damp_factor: float, top_k: Optional[int],
-                                   factored: bool) -> torch.Tensor:
-    """Eigenvectors (columns, ascending, f64) of the feature covariance C = W Ex W^T of y = x W^T, given the
-    finalised INPUT second moment Ex [n_in, n_in] (f64, full symmetric).  ``factored``: through the n_in-sized
+class EighProblem:
+    """One symmetric eigenproblem of the path: `matrix` [n, n] f64 (finalised, damped), the k largest eigenpairs wanted,
+    and `finish(w, v)` that turns them into the layer's eigenvectors (identity for a feature covariance; u = W L^-T s for
+    the factored problem of a widening layer).  Posed by Covariance / MomentCovariance, solved alone (`solve`) or together
+    with others of the same order (`solve_eigenproblems`)."""
+
+    def __init__(self, matrix: torch.Tensor, k: Optional[int], finish=None):
+        n = matrix.shape[0]
+        self.matrix = matrix
+        self.k = n if k is None else max(1, min(int(k), n))
+        self.finish = finish if finish is not None else (lambda w, v: v)
+
+    @property
+    def key(self) -> tuple:
+        return (self.matrix.shape[0], self.k, self.matrix.stride(0))
+
+    def solve(self) -> torch.Tensor:
+        w, v = ops.eigh(self.matrix, self.k, all_values=False)
+        return self.finish(w, v)
+
+
+def problem_from_input_moment(weight: torch.Tensor, ex: torch.Tensor, damp_factor: float, top_k: Optional[int],
+                              factored: bool) -> EighProblem:
+    """The eigenproblem behind the eigenvectors of the feature covariance C = W Ex W^T of y = x W^T, given the
+    finalised INPUT second moment Ex [n_in, n_in] (f64, full symmetric).  ``factored``: the n_in-sized
     problem of ``ops.eigh_factored`` (legal for top_k <= n_in); otherwise, or when W^T W is not safely positive
-    definite, C is formed explicitly by two f64 MFMA products and decomposed directly."""
+    definite, C is formed explicitly by two f64 MFMA products."""
     w2d = weight if weight.dim() == 2 else weight[..., 0, 0]
     if factored and top_k is not None and top_k <= w2d.shape[1]:
-        got = ops.eigh_factored(w2d, ex, top_k)
-        if got is not None:
-            return got[1]
+        fp = ops.eigh_factored_prepare(w2d, ex, top_k)
+        if fp is not None:
+            return EighProblem(fp.matrix, fp.k, finish=lambda w, v: fp.finish(w, v)[1])
         warn_once("factored-refused", "ptdeco_amd: W^T W of a widening layer is not safely positive definite; "
                   "its feature covariance W Ex W^T is decomposed directly (n_out-sized eigenproblem)")
     w64 = w2d.double()
     # ptd_cov_finalize mirrors the lower triangle (exact symmetry) and adds the damping
     c = ops.cov_finalize(ops.matmul(ops.matmul(w64, ex), w64.T), 1, damp_factor)
-    return ops.eigh(c, top_k, all_values=False)[1]
+    return EighProblem(c, top_k)
+
+
+def eigenvectors_from_input_moment(weight: torch.Tensor, ex: torch.Tensor, damp_factor: float, top_k: Optional[int],
+                                   factored: bool) -> torch.Tensor:
+    return problem_from_input_moment(weight, ex, damp_factor, top_k, factored).solve()
+
+
+def solve_eigenproblems(posers: list, orders: list, device: torch.device) -> list:
+    """The eigendecompositions of one precompute pass (dwain.py:580-633: a loop of get_eigenvectors calls), on the
+    caller's stream from the caller's thread.  posers[i]() -> EighProblem, orders[i] = (n, k) it will have.  Problems of
+    one (n, k) are formed and solved PTD_EIGH_BATCH_MAX (default 4) at a time by one ops.eigh_batched call -- their
+    reductions advance in lockstep, every launch serves all of them -- and finished before the next chunk is formed, so at
+    most that many matrices and factored workspaces are alive at once.  Groups are taken in the order of their first
+    member; the result list is in the order of `posers`."""
+    import os
+
+    cap = max(1, int(os.environ.get("PTD_EIGH_BATCH_MAX", "4")))
+    groups: dict = {}
+    for i, key in enumerate(orders):
+        groups.setdefault(tuple(key), []).append(i)
+    out: list = [None] * len(posers)
+    for key, members in groups.items():
+        for c0 in range(0, len(members), cap):
+            chunk = members[c0:c0 + cap]
+            problems = [posers[i]() for i in chunk]
+            # (a poser may fall back to another order -- a refused factored problem: those are solved alone)
+            same = [j for j, p in enumerate(problems) if p.key == problems[0].key]
+            if len(same) >= 2:
+                pairs = ops.eigh_batched([problems[j].matrix for j in same], problems[0].k, all_values=False)
+                for j, (w, v) in zip(same, pairs):
+                    out[chunk[j]] = problems[j].finish(w, v)
+            else:
+                same = []
+            for j, p in enumerate(problems):
+                if j not in same:
+                    out[chunk[j]] = p.solve()
+            del problems
+    return out
 
 
 class InputMoment:
@@ -906,9 +977,18 @@ class MomentCovariance:
     def __init__(self, weight: torch.Tensor, moment: InputMoment, factored: bool):
         self.weight, self.moment, self.factored = weight, moment, factored
 
-    def eigenvectors(self, damp_factor: float, use_mean: bool = False, top_k: Optional[int] = None) -> torch.Tensor:
+    def eigen_order(self, top_k: Optional[int]) -> tuple:
+        n_out, n_in = self.weight.shape[0], self.weight.shape[1]
+        if self.factored and top_k is not None and top_k <= n_in:
+            return (n_in + 63) // 64 * 64, max(1, min(int(top_k), n_in))
+        return n_out, (n_out if top_k is None else max(1, min(int(top_k), n_out)))
+
+    def problem(self, damp_factor: float, use_mean: bool = False, top_k: Optional[int] = None) -> EighProblem:
         assert not use_mean and self.moment.ex is not None, "SharedInputPool.finalize() must run first"
-        return eigenvectors_from_input_moment(self.weight, self.moment.ex, damp_factor, top_k, self.factored)
+        return problem_from_input_moment(self.weight, self.moment.ex, damp_factor, top_k, self.factored)
+
+    def eigenvectors(self, damp_factor: float, use_mean: bool = False, top_k: Optional[int] = None) -> torch.Tensor:
+        return self.problem(damp_factor, use_mean, top_k).solve()
 
 
 def _tensor_key(t: torch.Tensor):

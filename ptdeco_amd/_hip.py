@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libptdeco_hip.so")
 
 F32, F64, BF16 = 0, 1, 2
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # name -> (restype, argtypes); must list every symbol include/ptdeco_hip.h declares
 SIGNATURES = {
@@ -48,7 +48,13 @@ SIGNATURES = {
     "ptd_tridiagonalize_workspace_bytes": (c_size_t, [c_int64]),
     "ptd_tridiagonalize": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                    c_void_p]),
-    "ptd_band_reduce": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "ptd_eigh_batched_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int]),
+    "ptd_eigh_topk_batched": (c_int, [c_void_p, c_int64, c_int, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int64,
+                                      c_void_p, c_size_t, c_void_p, c_void_p]),
+    "ptd_eigh_factored_prepare": (c_int, [c_void_p, c_int64, c_int, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p,
+                                          c_size_t, ctypes.POINTER(c_void_p), ctypes.POINTER(c_int64), c_void_p]),
+    "ptd_eigh_factored_finish": (c_int, [c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
+                                         c_void_p, c_size_t, c_void_p]),
     "ptd_eigh_factored_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int64]),
     "ptd_eigh_factored": (c_int, [c_void_p, c_int64, c_int, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p,
                                   c_void_p, c_int64, c_void_p, c_size_t, c_void_p]),

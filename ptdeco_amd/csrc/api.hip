@@ -157,8 +157,80 @@ int ptd_eigh_route(int64_t n, int64_t k, int all_values) {
   return 0;
 }
 
+// ---- several matrices of one order in one call
+// count == 2 matrices are batched from this order on (below it two single calls with their resident kernels, ~3-5 us a
+// column and matrix on one XCD, are as fast as a shared blocked column of ~10 us); count >= 3: always
+static int batch_min_n() {
+  const char* e = getenv("PTD_EIGH_BATCH_MIN_N");
+  return e ? atoi(e) : 1025;
+}
+
+static bool batch_route(int count, int64_t n, int64_t k, bool all_values) {
+  const int method = eigh_method();
+  if (count < 2 || method == 0 || n < 256) return false;
+  if (method == 2 && eigh_filtered_applies(n, k, all_values)) return false;   // chip-filling f64 products: one by one
+  const char* off = getenv("PTD_EIGH_BATCHED");
+  if (off && atoi(off) == 0) return false;
+  return count >= 3 || n >= batch_min_n();
+}
+
+size_t ptd_eigh_batched_workspace_bytes(int64_t n, int64_t k, int count) {
+  (void)k;
+  return std::max(ptd_eigh_workspace_bytes(n), tridiag_batched_workspace_bytes(n, count));
+}
+
+int ptd_eigh_topk_batched(const double* const* As, int64_t lda, int count, int64_t n, int64_t k, int all_values,
+                          double* const* evals, double* const* evecs, int64_t ldv, void* ws, size_t ws_bytes,
+                          ptd_eigh_stats* stats, void* stream) {
+  PTD_REQUIRE(As && evals && evecs && ws && count >= 1 && count <= 64 && n >= 1 && lda >= n && k >= 1 && k <= n && ldv >= k,
+              "ptd_eigh_topk_batched: bad argument");
+  for (int b = 0; b < count; ++b)
+    PTD_REQUIRE(As[b] && evals[b] && evecs[b], "ptd_eigh_topk_batched: null pointer (matrix %d)", b);
+  if (ws_bytes < ptd_eigh_batched_workspace_bytes(n, k, count)) {
+    set_error("ptd_eigh_topk_batched: workspace %zu < required %zu bytes", ws_bytes,
+              ptd_eigh_batched_workspace_bytes(n, k, count));
+    return PTD_ERR_WORKSPACE;
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (stats) memset(stats, 0, sizeof(*stats));
+  if (!batch_route(count, n, k, all_values != 0)) {
+    // one by one, each with the whole chip (the filtered route's products fill it; a single direct reduction keeps
+    // its resident kernels); stats describe the LAST matrix
+    for (int b = 0; b < count; ++b) {
+      const int rc = eigh_dispatch(As[b], lda, n, k, evals[b], evecs[b], ldv, ws, ws_bytes, nullptr, all_values != 0,
+                                   stats, st);
+      if (rc != PTD_OK) return rc;
+    }
+    return PTD_OK;
+  }
+  int rcs[64];
+  const char* ct = getenv("PTD_EIGH_CLUSTER_TOL");
+  int rc = eigh_tridiag_batched(As, lda, count, n, k, evals, evecs, ldv, ws, ws_bytes, ct ? atof(ct) : 1e-10,
+                                all_values != 0, rcs, stats, st);
+  if (rc != PTD_OK) return rc;
+  for (int b = 0; b < count; ++b)
+    if (rcs[b] == PTD_ERR_UNSUPPORTED) {     // clustered beyond what the tridiagonal route serves: Jacobi needs no gap
+      rc = eigh_jacobi(As[b], lda, n, k, evals[b], evecs[b], ldv, ws, ws_bytes, nullptr, nullptr, st);
+      if (rc != PTD_OK) return rc;
+    }
+  return PTD_OK;
+}
+
 size_t ptd_eigh_factored_workspace_bytes(int64_t n_o, int64_t n_i, int64_t k) {
   return eigh_factored_workspace_bytes(n_o, n_i, k);
+}
+
+int ptd_eigh_factored_prepare(const void* W, int64_t ldw, int w_dtype, int64_t n_o, int64_t n_i, const double* Ex,
+                              int64_t ldx, int64_t k, void* ws, size_t ws_bytes, double** B_out, int64_t* np_out,
+                              void* stream) {
+  return eigh_factored_prepare(W, ldw, w_dtype, n_o, n_i, Ex, ldx, k, ws, ws_bytes, B_out, np_out,
+                               static_cast<hipStream_t>(stream));
+}
+
+int ptd_eigh_factored_finish(int64_t n_o, int64_t n_i, int64_t k, const double* evals, const double* S, int64_t lds,
+                             double* evals_k, double* U, int64_t ldu, void* ws, size_t ws_bytes, void* stream) {
+  return eigh_factored_finish(n_o, n_i, k, evals, S, lds, evals_k, U, ldu, ws, ws_bytes,
+                              static_cast<hipStream_t>(stream));
 }
 
 int ptd_eigh_factored(const void* W, int64_t ldw, int w_dtype, int64_t n_o, int64_t n_i, const double* Ex,
@@ -231,11 +303,6 @@ size_t ptd_tridiagonalize_workspace_bytes(int64_t n) { return tridiag_workspace_
 int ptd_tridiagonalize(const double* A, int64_t lda, int64_t n, double* d, double* e, double* evals, void* ws,
                        size_t ws_bytes, void* stream) {
   return tridiagonalize_f64(A, lda, n, d, e, evals, ws, ws_bytes, static_cast<hipStream_t>(stream));
-}
-
-int ptd_band_reduce(const double* A, int64_t lda, int64_t n, int stages, double* band, void* ws, size_t ws_bytes,
-                    void* stream) {
-  return band_reduce_f64(A, lda, n, stages, band, ws, ws_bytes, static_cast<hipStream_t>(stream));
 }
 
 int ptd_gemm(const void* A, int64_t sam, int64_t sak, const void* B, int64_t sbk, int64_t sbn, void* C, int64_t ldc,

@@ -215,10 +215,12 @@ static FactoredPlan factored_plan(int64_t n_o, int64_t n_i, int64_t k) {
 
 size_t eigh_factored_workspace_bytes(int64_t n_o, int64_t n_i, int64_t k) { return factored_plan(n_o, n_i, k).total; }
 
-int eigh_factored(const void* W, int64_t ldw, int w_dtype, int64_t n_o, int64_t n_i, const double* Ex, int64_t ldx,
-                  int64_t k, double* evals_k, double* U, int64_t ldu, void* ws, size_t ws_bytes, hipStream_t st) {
-  PTD_REQUIRE(W && Ex && U && ws, "ptd_eigh_factored: null pointer");
-  PTD_REQUIRE(n_i >= 1 && n_o >= n_i && k >= 1 && k <= n_i && ldw >= n_i && ldx >= n_i && ldu >= k,
+// ---- first half: everything up to B = L^T Ex L (left in the workspace, [np][np])
+int eigh_factored_prepare(const void* W, int64_t ldw, int w_dtype, int64_t n_o, int64_t n_i, const double* Ex,
+                          int64_t ldx, int64_t k, void* ws, size_t ws_bytes, double** B_out, int64_t* np_out,
+                          hipStream_t st) {
+  PTD_REQUIRE(W && Ex && ws, "ptd_eigh_factored: null pointer");
+  PTD_REQUIRE(n_i >= 1 && n_o >= n_i && k >= 1 && k <= n_i && ldw >= n_i && ldx >= n_i,
               "ptd_eigh_factored: bad shape n_o=%lld n_i=%lld k=%lld", (long long)n_o, (long long)n_i, (long long)k);
   const FactoredPlan p = factored_plan(n_o, n_i, k);
   if (ws_bytes < p.total) {
@@ -233,9 +235,6 @@ int eigh_factored(const void* W, int64_t ldw, int w_dtype, int64_t n_o, int64_t 
   double* B = reinterpret_cast<double*>(base + p.off_B);
   double* linv = reinterpret_cast<double*>(base + p.off_linv);
   int* fail = reinterpret_cast<int*>(base + p.off_fail);
-  double* S = reinterpret_cast<double*>(base + p.off_S);     // [np][k] eigenvectors of B
-  double* T = reinterpret_cast<double*>(base + p.off_T);     // [np][k] L^-T S
-  double* evals = reinterpret_cast<double*>(base + p.off_evals);
 
   // W in f64 (zero padded to np columns)
   if (w_dtype == PTD_F32)
@@ -313,9 +312,33 @@ int eigh_factored(const void* W, int64_t ldw, int w_dtype, int64_t n_o, int64_t 
   }
   hipLaunchKernelGGL(symmetrize_kernel, dim3(2048), dim3(256), 0, st, B, np, (int)n_i, 0.0, 2);
   PTD_CHECK_LAUNCH("factored products");
-  // top-k eigenvectors of B
-  rc = eigh_select(B, np, np, k, evals, S, k, base + p.off_eigh, p.eigh_bytes, nullptr, nullptr, st);
-  if (rc != PTD_OK) return rc;
+  if (B_out) *B_out = B;
+  if (np_out) *np_out = np;
+  return PTD_OK;
+}
+
+// ---- second half: u = W L^-T s for the top-k eigenvectors S [np][lds >= k] of B (evals [np], ascending; only the last
+// k are read).  The workspace is the one eigh_factored_prepare filled (W64, L and linv are read from it).
+int eigh_factored_finish(int64_t n_o, int64_t n_i, int64_t k, const double* evals, const double* Sin, int64_t lds,
+                         double* evals_k, double* U, int64_t ldu, void* ws, size_t ws_bytes, hipStream_t st) {
+  PTD_REQUIRE(Sin && U && ws && evals && ldu >= k && lds >= k, "ptd_eigh_factored_finish: bad argument");
+  const FactoredPlan p = factored_plan(n_o, n_i, k);
+  if (ws_bytes < p.total) {
+    set_error("ptd_eigh_factored_finish: workspace %zu < required %zu bytes", ws_bytes, p.total);
+    return PTD_ERR_WORKSPACE;
+  }
+  char* base = static_cast<char*>(ws);
+  const int np = p.np;
+  double* W64 = reinterpret_cast<double*>(base + p.off_W);
+  double* G = reinterpret_cast<double*>(base + p.off_G);
+  double* P = reinterpret_cast<double*>(base + p.off_P);
+  double* linv = reinterpret_cast<double*>(base + p.off_linv);
+  double* S = reinterpret_cast<double*>(base + p.off_S);     // [np][k] eigenvectors of B (destroyed by the substitution)
+  double* T = reinterpret_cast<double*>(base + p.off_T);     // [np][k] L^-T S
+  if (Sin != S)
+    PTD_CHECK_HIP(hipMemcpy2DAsync(S, (size_t)k * 8, Sin, (size_t)lds * 8, (size_t)k * 8, (size_t)np,
+                                   hipMemcpyDeviceToDevice, st));
+  int rc = PTD_OK;
   // T = L^-T S : blocked back substitution with the inverses of the diagonal blocks -- 256 x 256 ones where np allows
   // (tri_inv256_kernel; they live in P, which is dead by now)
   static const bool no_inv256 = getenv("PTD_FACTORED_INV256") && atoi(getenv("PTD_FACTORED_INV256")) == 0;
@@ -354,6 +377,23 @@ int eigh_factored(const void* W, int64_t ldw, int w_dtype, int64_t n_o, int64_t 
   if (evals_k)
     PTD_CHECK_HIP(hipMemcpyAsync(evals_k, evals + (np - k), (size_t)k * 8, hipMemcpyDeviceToDevice, st));
   return PTD_OK;
+}
+
+int eigh_factored(const void* W, int64_t ldw, int w_dtype, int64_t n_o, int64_t n_i, const double* Ex, int64_t ldx,
+                  int64_t k, double* evals_k, double* U, int64_t ldu, void* ws, size_t ws_bytes, hipStream_t st) {
+  PTD_REQUIRE(U && ldu >= k, "ptd_eigh_factored: bad output");
+  double* B = nullptr;
+  int64_t np = 0;
+  int rc = eigh_factored_prepare(W, ldw, w_dtype, n_o, n_i, Ex, ldx, k, ws, ws_bytes, &B, &np, st);
+  if (rc != PTD_OK) return rc;
+  const FactoredPlan p = factored_plan(n_o, n_i, k);
+  char* base = static_cast<char*>(ws);
+  double* S = reinterpret_cast<double*>(base + p.off_S);
+  double* evals = reinterpret_cast<double*>(base + p.off_evals);
+  // top-k eigenvectors of B
+  rc = eigh_select(B, np, np, k, evals, S, k, base + p.off_eigh, p.eigh_bytes, nullptr, nullptr, st);
+  if (rc != PTD_OK) return rc;
+  return eigh_factored_finish(n_o, n_i, k, evals, S, k, evals_k, U, ldu, ws, ws_bytes, st);
 }
 
 }  // namespace ptd

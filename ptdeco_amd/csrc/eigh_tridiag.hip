@@ -21,7 +21,6 @@
 
 #include "common.h"
 #include "kernels.h"
-#include "twostage.h"
 
 namespace ptd {
 
@@ -29,7 +28,7 @@ int gemm_f64(const double* A, int64_t sam, int64_t sak, const double* B, int64_t
              int64_t ldc, int64_t M, int64_t N, int64_t K, double alpha, bool beta1, int ksplit, hipStream_t st);
 int gemm_f64_pair(const double* A, const double* B, const double* A2, const double* B2, int64_t sam, int64_t sak,
                   int64_t sbk, int64_t sbn, double* C, int64_t ldc, int64_t M, int64_t N, int64_t K, double alpha,
-                  double* row0_out, hipStream_t st);
+                  double* row0_out, hipStream_t st, int batch = 1, int64_t bstride_elems = 0);
 
 namespace {
 
@@ -68,9 +67,19 @@ struct ColState {
   double alpha;  // x_j[j+1]
 };
 
+// Batched launches (eigh_tridiag_batched): blockIdx.y is the matrix, every workspace pointer of the launch moves by
+// y * bstride bytes (the workspaces of the batch are copies of one plan, bstride apart; bstride = 0: one matrix).
+template <typename T>
+__device__ __forceinline__ T* batch_ptr(T* p, size_t boff) {
+  return reinterpret_cast<T*>(reinterpret_cast<uintptr_t>(p) + boff);
+}
+#define PTD_BATCH(P) P = batch_ptr(P, boff_)
+
 // first column of a panel: base = A[j][j:]
 __global__ void sytrd_colinit_kernel(const double* __restrict__ A, int64_t ld, int n, int j,
-                                     double* __restrict__ colbuf) {
+                                     double* __restrict__ colbuf, size_t bstride) {
+  const size_t boff_ = (size_t)blockIdx.y * bstride;
+  PTD_BATCH(A); PTD_BATCH(colbuf);
   const int r = j + blockIdx.x * blockDim.x + threadIdx.x;
   if (r < n) colbuf[r] = A[(int64_t)j * ld + r];
 }
@@ -88,9 +97,12 @@ __global__ __launch_bounds__(256) void sytrd_symv_kernel(const double* __restric
                                                          const double* __restrict__ taus,
                                                          double* __restrict__ sd, double* __restrict__ qv,
                                                          double* __restrict__ cb, double* __restrict__ px2,
-                                                         ColState* __restrict__ cs) {
+                                                         ColState* __restrict__ cs, size_t bstride) {
   __shared__ double part[4][SROWS];
   __shared__ double delta_s;
+  const size_t boff_ = (size_t)blockIdx.y * bstride;
+  PTD_BATCH(A); PTD_BATCH(colbuf); PTD_BATCH(Vp); PTD_BATCH(Wp); PTD_BATCH(wraw_prev); PTD_BATCH(partial2);
+  PTD_BATCH(taus); PTD_BATCH(sd); PTD_BATCH(qv); PTD_BATCH(cb); PTD_BATCH(px2); PTD_BATCH(cs);
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   if (wid == 0) {
     double dl = 0.0;
@@ -287,7 +299,11 @@ __global__ __launch_bounds__(256) void sytrd_symv2_kernel(const double* __restri
                                                           const double* __restrict__ taus, SymPart sp, int ntiles,
                                                           int nextra, double* __restrict__ qv,
                                                           double* __restrict__ cb, double* __restrict__ px2,
-                                                          ColState* __restrict__ cs) {
+                                                          ColState* __restrict__ cs, size_t bstride) {
+  const size_t boff_ = (size_t)blockIdx.y * bstride;
+  PTD_BATCH(A); PTD_BATCH(colbuf); PTD_BATCH(Vp); PTD_BATCH(Wp); PTD_BATCH(wraw_prev); PTD_BATCH(partial2);
+  PTD_BATCH(taus); PTD_BATCH(sp.rowpart); PTD_BATCH(sp.colpart); PTD_BATCH(qv); PTD_BATCH(cb); PTD_BATCH(px2);
+  PTD_BATCH(cs);
   __shared__ __attribute__((aligned(16))) double xs[TR];
   __shared__ __attribute__((aligned(16))) double colred[4][TC];
   __shared__ double part[4][SROWS];
@@ -438,7 +454,11 @@ __global__ __launch_bounds__(256) void sytrd_alpha_kernel(const double* __restri
                                                           const ColState* __restrict__ cs,
                                                           double* __restrict__ partial2, double* __restrict__ d,
                                                           double* __restrict__ e, double* __restrict__ taus,
-                                                          SymPart sp) {
+                                                          SymPart sp, size_t bstride) {
+  const size_t boff_ = (size_t)blockIdx.y * bstride;
+  PTD_BATCH(A); PTD_BATCH(Vp); PTD_BATCH(Wp); PTD_BATCH(wraw_prev); PTD_BATCH(wraw_cur); PTD_BATCH(colbuf);
+  PTD_BATCH(sd); PTD_BATCH(qv); PTD_BATCH(cb); PTD_BATCH(px2); PTD_BATCH(cs); PTD_BATCH(partial2); PTD_BATCH(d);
+  PTD_BATCH(e); PTD_BATCH(taus); PTD_BATCH(sp.rowpart); PTD_BATCH(sp.colpart);
   __shared__ double c1[NB], c2[NB], wj1[NB], vj1[NB];
   __shared__ double part1[4][64], part2[4][64];
   __shared__ double vs[64], wfs[64];
@@ -613,7 +633,9 @@ __global__ __launch_bounds__(256) void sytrd_alpha_kernel(const double* __restri
 __global__ void sytrd_wfix_kernel(int n, int r0, int ilast, int jlast, const double* __restrict__ Vp,
                                   double* __restrict__ Wp, int64_t ldv, const double* __restrict__ wraw,
                                   const double* __restrict__ partial2, int nparts2,
-                                  const double* __restrict__ taus) {
+                                  const double* __restrict__ taus, size_t bstride) {
+  const size_t boff_ = (size_t)blockIdx.y * bstride;
+  PTD_BATCH(Vp); PTD_BATCH(Wp); PTD_BATCH(wraw); PTD_BATCH(partial2); PTD_BATCH(taus);
   __shared__ double a2s;
   if (threadIdx.x < 64) {
     const double t = wave_total(partial2, nparts2, threadIdx.x);
@@ -1578,7 +1600,9 @@ __global__ __launch_bounds__(R4_T) void sytrd_resident4_kernel(double* __restric
 // very last diagonal entry: d[n-1] = base[n-1] - delta (delta = 0 if the column opens a panel)
 __global__ void sytrd_last_kernel(int n, int i, const double* __restrict__ colbuf,
                                   const double* __restrict__ partial2, int nparts2,
-                                  const double* __restrict__ taus, double* __restrict__ d) {
+                                  const double* __restrict__ taus, double* __restrict__ d, size_t bstride) {
+  const size_t boff_ = (size_t)blockIdx.y * bstride;
+  PTD_BATCH(colbuf); PTD_BATCH(partial2); PTD_BATCH(taus); PTD_BATCH(d);
   double dl = 0.0;
   if (i > 0) dl = -taus[n - 2] * wave_total(partial2, nparts2, threadIdx.x);
   if (threadIdx.x == 0) d[n - 1] = colbuf[n - 1] - dl;
@@ -2666,9 +2690,6 @@ struct TridiagPlan {
   size_t off_u1, off_u2, off_u3, off_lm, off_sw, off_G, off_T, off_W1, off_W2, off_wraw, off_wraw2, off_part2, off_cbuf;
   size_t off_qv, off_px2, off_rowpart, off_colpart, off_gpart, off_tall, off_res, off_twd, off_twe, off_twl;
   int64_t ldp;     // leading dimension of the symmetric SYMV's partial-result arrays
-  bool two;        // two-stage reduction (eigh_twostage.hip) available for this order
-  TwoStagePlan ts;
-  size_t off_ts;
   size_t total;
 };
 
@@ -2726,11 +2747,6 @@ TridiagPlan tridiag_plan(int64_t n) {
   p.off_twd = take((size_t)TW_MAXN * 8);             // twisted factorisations: d / |T|, e / |T| by lane chunks,
   p.off_twe = take((size_t)TW_MAXN * 8);
   p.off_twl = take((size_t)(n + 16) * 4);            // ... [0] count, [16 ..] list of the vectors left to inverse iteration
-  p.two = twostage_supported(n);
-  if (p.two) {
-    p.ts = twostage_plan(n, p.ld);
-    p.off_ts = take(p.ts.total);
-  }
   p.total = o;
   return p;
 }
@@ -2840,10 +2856,19 @@ struct InflightGuard {
   ~InflightGuard() { ds.inflight.fetch_sub(1); }
 };
 
+template <typename T>
+static inline T* batch_host(T* p, size_t off) { return reinterpret_cast<T*>(reinterpret_cast<char*>(p) + off); }
+
 int* resident_status(const TridiagPlan& p, char* base) { return &reinterpret_cast<ResCtl*>(base + p.off_res)->fail; }
 
-int sytrd_f64(const TridiagPlan& p, char* base, SymvTimer* timer, bool resident, hipStream_t st) {
+// count > 1: `count` matrices of order n in workspaces bstride bytes apart, one launch per kernel and column for all of
+// them (blocked path to the end: see eigh_tridiag_batched)
+int sytrd_f64(const TridiagPlan& p, char* base, SymvTimer* timer, bool resident, hipStream_t st, int count = 1,
+              size_t bstride = 0) {
   const int n = p.n;
+  const unsigned nb = (unsigned)std::max(count, 1);
+  if (nb > 1) resident = false;
+  if (nb == 1) bstride = 0;
   const int64_t ld = p.ld;
   double* Aw = reinterpret_cast<double*>(base + p.off_A);
   double* Vall = reinterpret_cast<double*>(base + p.off_V);
@@ -2869,20 +2894,23 @@ int sytrd_f64(const TridiagPlan& p, char* base, SymvTimer* timer, bool resident,
   const int sym_min = (symv_env && !strcmp(symv_env, "full")) ? INT32_MAX
                       : std::max(512, symv_min_env ? atoi(symv_min_env) : 1024);
   bool prev_sym = false;  // how the open column's SYMV was computed
-  PTD_CHECK_HIP(hipMemsetAsync(Vall, 0, (size_t)p.npanels * NB * ld * 8, st));
-  PTD_CHECK_HIP(hipMemsetAsync(taus, 0, (size_t)n * 8, st));
-  PTD_CHECK_HIP(hipMemsetAsync(e, 0, (size_t)n * 8, st));
-  PTD_CHECK_HIP(hipMemsetAsync(colbuf, 0, (size_t)(p.ldp + 8) * 8, st));
-  // W panel: entries below a row's first written column are multiplied by zero but must be finite;
-  // later panels find the previous panel's (finite) values there
-  PTD_CHECK_HIP(hipMemsetAsync(Wp, 0, (size_t)NB * ld * 8, st));
-  PTD_CHECK_HIP(hipMemsetAsync(wr[0], 0, (size_t)(n + 8) * 8, st));
-  PTD_CHECK_HIP(hipMemsetAsync(wr[1], 0, (size_t)(n + 8) * 8, st));
+  for (unsigned b = 0; b < nb; ++b) {
+    const size_t bo = b * bstride;
+    PTD_CHECK_HIP(hipMemsetAsync(batch_host(Vall, bo), 0, (size_t)p.npanels * NB * ld * 8, st));
+    PTD_CHECK_HIP(hipMemsetAsync(batch_host(taus, bo), 0, (size_t)n * 8, st));
+    PTD_CHECK_HIP(hipMemsetAsync(batch_host(e, bo), 0, (size_t)n * 8, st));
+    PTD_CHECK_HIP(hipMemsetAsync(batch_host(colbuf, bo), 0, (size_t)(p.ldp + 8) * 8, st));
+    // W panel: entries below a row's first written column are multiplied by zero but must be finite;
+    // later panels find the previous panel's (finite) values there
+    PTD_CHECK_HIP(hipMemsetAsync(batch_host(Wp, bo), 0, (size_t)NB * ld * 8, st));
+    PTD_CHECK_HIP(hipMemsetAsync(batch_host(wr[0], bo), 0, (size_t)(n + 8) * 8, st));
+    PTD_CHECK_HIP(hipMemsetAsync(batch_host(wr[1], bo), 0, (size_t)(n + 8) * 8, st));
+  }
   bool colbuf_ready = false;
   const int t_res = resident ? resident_start(n) : n;
   if (timer) timer->limit = t_res;
   ResCtl* rctl = reinterpret_cast<ResCtl*>(base + p.off_res);
-  PTD_CHECK_HIP(hipMemsetAsync(rctl, 0, sizeof(ResCtl), st));
+  for (unsigned b = 0; b < nb; ++b) PTD_CHECK_HIP(hipMemsetAsync(batch_host(rctl, b * bstride), 0, sizeof(ResCtl), st));
   for (int pn = 0; pn < p.npanels; ++pn) {
     const int j0 = pn * NB;
     if (j0 == t_res && n - j0 >= 2) {
@@ -2973,16 +3001,16 @@ int sytrd_f64(const TridiagPlan& p, char* base, SymvTimer* timer, bool resident,
       const int j = j0 + i;
       if (i == 0) {
         if (!colbuf_ready)  // the previous panel's trailing update has already left row j in colbuf
-          hipLaunchKernelGGL(sytrd_colinit_kernel, dim3((unsigned)ceil_div(n - j, 256)), dim3(256), 0, st, Aw, ld, n,
-                             j, colbuf);
+          hipLaunchKernelGGL(sytrd_colinit_kernel, dim3((unsigned)ceil_div(n - j, 256), nb), dim3(256), 0, st, Aw, ld, n,
+                             j, colbuf, bstride);
         colbuf_ready = false;
       } else {
         const int blocks = (int)ceil_div(n - j, 64);
         SymPart spa = sp;
         spa.enabled = prev_sym;
-        hipLaunchKernelGGL(sytrd_alpha_kernel, dim3(blocks), dim3(256), 0, st, Aw, ld, n, j, i, 1, Vp, Wp, ld,
+        hipLaunchKernelGGL(sytrd_alpha_kernel, dim3(blocks, nb), dim3(256), 0, st, Aw, ld, n, j, i, 1, Vp, Wp, ld,
                            wr[(i & 1)], wr[(i - 1) & 1], colbuf, sd, qv, cbuf, px2, npx2, cs, partial2, d, e, taus,
-                           spa);
+                           spa, bstride);
         nparts2 = blocks;
       }
       const int m = n - j - 1;
@@ -2991,11 +3019,11 @@ int sytrd_f64(const TridiagPlan& p, char* base, SymvTimer* timer, bool resident,
         const int ntiles = TQ / 2 * U * (U + 1);
         const int nextra = (int)ceil_div(2 * i, SROWS);
         npx2 = (int)ceil_div(m, 256);
-        const dim3 grid((unsigned)(ntiles + nextra + npx2));
+        const dim3 grid((unsigned)(ntiles + nextra + npx2), nb);
         const bool timed = timer && timer->sampled(j);
         hipEvent_t ev0 = timed ? timer->start(j) : nullptr, ev1 = timed ? timer->stop(j) : nullptr;
         hipExtLaunchKernelGGL(sytrd_symv2_kernel, grid, dim3(256), 0, st, ev0, ev1, 0, Aw, ld, n, j, i, colbuf, Vp, Wp,
-                              ld, wr[(i + 1) & 1], partial2, nparts2, taus, sp, ntiles, nextra, qv, cbuf, px2, cs);
+                              ld, wr[(i + 1) & 1], partial2, nparts2, taus, sp, ntiles, nextra, qv, cbuf, px2, cs, bstride);
         prev_sym = true;
         open = true;
       } else if (m > 0) {
@@ -3005,16 +3033,16 @@ int sytrd_f64(const TridiagPlan& p, char* base, SymvTimer* timer, bool resident,
         if (timer && timer->sampled(j)) {
           // start / stop events attached to the dispatch itself: the same begin / end timestamps
           // of the kernel's completion signal that rocprofv3 reports
-          hipExtLaunchKernelGGL(sytrd_symv_kernel, dim3(npx2), dim3(256), 0, st, timer->start(j),
+          hipExtLaunchKernelGGL(sytrd_symv_kernel, dim3(npx2, nb), dim3(256), 0, st, timer->start(j),
                                 timer->stop(j), 0, Aw, ld, n, j, i, colbuf, Vp, Wp, ld,
-                                wr[(i + 1) & 1], partial2, nparts2, taus, sd, qv, cbuf, px2, cs);
+                                wr[(i + 1) & 1], partial2, nparts2, taus, sd, qv, cbuf, px2, cs, bstride);
         } else {
-          hipLaunchKernelGGL(sytrd_symv_kernel, dim3(npx2), dim3(256), 0, st, Aw, ld, n, j, i, colbuf, Vp, Wp, ld,
-                             wr[(i + 1) & 1], partial2, nparts2, taus, sd, qv, cbuf, px2, cs);
+          hipLaunchKernelGGL(sytrd_symv_kernel, dim3(npx2, nb), dim3(256), 0, st, Aw, ld, n, j, i, colbuf, Vp, Wp, ld,
+                             wr[(i + 1) & 1], partial2, nparts2, taus, sd, qv, cbuf, px2, cs, bstride);
         }
         open = true;
       } else {
-        hipLaunchKernelGGL(sytrd_last_kernel, dim3(1), dim3(64), 0, st, n, i, colbuf, partial2, nparts2, taus, d);
+        hipLaunchKernelGGL(sytrd_last_kernel, dim3(1, nb), dim3(64), 0, st, n, i, colbuf, partial2, nparts2, taus, d, bstride);
         open = false;
       }
     }
@@ -3024,18 +3052,18 @@ int sytrd_f64(const TridiagPlan& p, char* base, SymvTimer* timer, bool resident,
       const int blocks = (int)ceil_div(n - t0, 64);
       SymPart spa = sp;
       spa.enabled = prev_sym;
-      hipLaunchKernelGGL(sytrd_alpha_kernel, dim3(std::max(blocks, 1)), dim3(256), 0, st, Aw, ld, n, t0, cols, 0, Vp,
+      hipLaunchKernelGGL(sytrd_alpha_kernel, dim3(std::max(blocks, 1), nb), dim3(256), 0, st, Aw, ld, n, t0, cols, 0, Vp,
                          Wp, ld, wr[(cols & 1)], wr[(cols - 1) & 1], colbuf, sd, qv, cbuf, px2, npx2, cs, partial2,
-                         d, e, taus, spa);
+                         d, e, taus, spa, bstride);
       const int mt = n - t0;
       if (mt > 0) {
-        hipLaunchKernelGGL(sytrd_wfix_kernel, dim3((unsigned)ceil_div(mt, 256)), dim3(256), 0, st, n, t0, cols - 1,
-                           t0 - 1, Vp, Wp, ld, wr[(cols - 1) & 1], partial2, std::max(blocks, 1), taus);
+        hipLaunchKernelGGL(sytrd_wfix_kernel, dim3((unsigned)ceil_div(mt, 256), nb), dim3(256), 0, st, n, t0, cols - 1,
+                           t0 - 1, Vp, Wp, ld, wr[(cols - 1) & 1], partial2, std::max(blocks, 1), taus, bstride);
         // trailing update A[T0:, T0:] -= V W^T + W V^T
         double* At = Aw + (int64_t)t0 * ld + t0;
         // ... and the updated row t0 goes straight into colbuf: the next panel's first column (colinit)
         const int rc = gemm_f64_pair(Vp + t0, Wp + t0, Wp + t0, Vp + t0, 1, ld, ld, 1, At, ld, mt, mt, cols, -1.0,
-                                     colbuf + t0, st);
+                                     colbuf + t0, st, (int)nb, (int64_t)(bstride / 8));
         colbuf_ready = true;
         if (rc != PTD_OK) return rc;
       }
@@ -3086,8 +3114,7 @@ __global__ void gram_pad_kernel(double* __restrict__ G, int mp, int nvec) {
 // matrix is I + O(1e-6) and one pass is exact to rounding; the triangular factor mixes a vector only with its
 // predecessors in eigenvalue order, by those same tiny amounts.
 int tridiag_vectors_and_backtransform(const TridiagPlan& p, char* base, int nvec, double* Y, int64_t ldy,
-                                      double ortol, int niter, bool two, hipEvent_t ev_vec, hipEvent_t ev_q2,
-                                      hipStream_t st, bool long_chains = false) {
+                                      double ortol, int niter, hipStream_t st, bool long_chains = false) {
   const int n = p.n;
   const int64_t ld = p.ld;
   double* d = reinterpret_cast<double*>(base + p.off_d);
@@ -3154,12 +3181,11 @@ int tridiag_vectors_and_backtransform(const TridiagPlan& p, char* base, int nvec
     double* Wt = G + mp * mp;
     char* cws = reinterpret_cast<char*>(Wt + mp * mp);
     const size_t cbytes = chol_inverse_workspace_bytes(mp);
-    // (one-stage: the working copy of A is free here; two-stage: it holds the stage-1 reflectors, so the new block
-    // goes behind the Cholesky workspace)
+    // (the working copy of A is free here: the new block goes there)
     char* after = cws + align_up(cbytes, 256);
-    double* Ynew = two ? reinterpret_cast<double*>(after) : reinterpret_cast<double*>(base + p.off_A);
-    const size_t used = (size_t)(after - (base + p.off_u1)) + (two ? (size_t)n * nvec * 8 : 0);
-    if (used > (size_t)(p.off_sw - p.off_u1) || (!two && (size_t)n * nvec * 8 > (size_t)(p.off_V - p.off_A))) {
+    double* Ynew = reinterpret_cast<double*>(base + p.off_A);
+    const size_t used = (size_t)(after - (base + p.off_u1));
+    if (used > (size_t)(p.off_sw - p.off_u1) || (size_t)n * nvec * 8 > (size_t)(p.off_V - p.off_A)) {
       set_error("eigh_tridiag: no room to orthonormalise %d clustered vectors", nvec);
       return PTD_ERR_UNSUPPORTED;
     }
@@ -3173,10 +3199,6 @@ int tridiag_vectors_and_backtransform(const TridiagPlan& p, char* base, int nvec
     PTD_CHECK_HIP(hipMemcpy2DAsync(Y, (size_t)ldy * 8, Ynew, (size_t)nvec * 8, (size_t)nvec * 8, (size_t)n,
                                    hipMemcpyDeviceToDevice, st));
   }
-  if (ev_vec) PTD_CHECK_HIP(hipEventRecord(ev_vec, st));
-  if (two)  // Z = Q1 (Q2 Y); the inverse-iteration factors (off_u1) are dead by now and hold T_p V_p
-    return twostage_backtransform(p.ts, base + p.off_ts, reinterpret_cast<const double*>(base + p.off_A), Vall, ld,
-                                  reinterpret_cast<double*>(base + p.off_u1), Y, ldy, nvec, ev_q2, st);
   // Y <- Q_0 Q_1 ... Q_last Y : apply the panels' block reflectors from the last to the first,
   // Q_p Y = Y - V_p^T (TV_p Y) with TV_p = T_p V_p formed for all panels up front
   double* TVall = reinterpret_cast<double*>(base + p.off_A);  // the working copy of A is dead by now
@@ -3312,99 +3334,21 @@ static int complete_basis(double* V, int64_t ldv, int64_t n, int64_t m, int64_t 
   return PTD_OK;
 }
 
-// Eigenvalues (all n) and the eigenvectors of the k largest ones ([n][k], ascending) through
-// the tridiagonal route.  Returns PTD_ERR_UNSUPPORTED (and
-// leaves the outputs untouched) when two eigenvalues are closer than `cluster_tol` * |T|: the
-// caller then uses the Jacobi solver, which needs no gap.
-int eigh_tridiag(const double* A, int64_t lda, int64_t n, int64_t k, double* evals, double* evecs, int64_t ldv,
-                 void* ws, size_t ws_bytes, double cluster_tol, bool all_values, ptd_eigh_stats* stats,
-                 hipStream_t st) {
-  const TridiagPlan p = tridiag_plan(n);
-  if (ws_bytes < p.total) {
-    set_error("eigh_tridiag: workspace %zu < required %zu bytes", ws_bytes, p.total);
-    return PTD_ERR_WORKSPACE;
-  }
-  InflightGuard in_flight;
-  char* base = static_cast<char*>(ws);
-  double* Aw = reinterpret_cast<double*>(base + p.off_A);
-  SymvTimer timer;
-  hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
-  if (stats) {
-    memset(stats, 0, sizeof(*stats));
-    stats->method = 1;
-    timer.stride = n >= 512 ? 8 : 1;
-    timer.ev.resize(2 * (size_t)(n / timer.stride + 1));
-    for (auto& e : timer.ev) PTD_CHECK_HIP(hipEventCreate(&e));
-    PTD_CHECK_HIP(hipEventCreate(&e0));
-    PTD_CHECK_HIP(hipEventCreate(&e1));
-    PTD_CHECK_HIP(hipEventCreate(&e2));
-    PTD_CHECK_HIP(hipEventRecord(e0, st));
-  }
-  auto cleanup = [&]() {
-    for (auto& e : timer.ev) (void)hipEventDestroy(e);
-    if (e0) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2); }
-  };
-  // Two-stage reduction (dense -> band -> tridiagonal, eigh_twostage.hip) where it applies; its failure words
-  // (a Cholesky breakdown in a panel factorisation: a numerically rank-deficient panel; a chase time-out) are
-  // read at the host synchronisation below and send the matrix through the one-stage reduction instead.
-  bool two = p.two;
-  bool resident = true;   // the resident tail of the one-stage reduction; its status word is read below as well
-  hipEvent_t em = nullptr, ev = nullptr, eq = nullptr;  // stage 1 | stage 2, vectors | Q2, Q2 | Q1
-  if (stats && two) {
-    PTD_CHECK_HIP(hipEventCreate(&em));
-    PTD_CHECK_HIP(hipEventCreate(&ev));
-    PTD_CHECK_HIP(hipEventCreate(&eq));
-  }
-  auto cleanup2 = [&]() {
-    cleanup();
-    if (em) { (void)hipEventDestroy(em); (void)hipEventDestroy(ev); (void)hipEventDestroy(eq); }
-  };
-  const int first = (int)std::max<int64_t>(0, n - k - 1);
+// ---- after the reduction: the decisions that depend on the spectrum of T, then eigenvectors and back-transformation.
+// h_gap = {smallest relative gap among the requested eigenvalues, longest chain of gaps below ortol} as min_gap_kernel
+// left them (read back by the caller behind ONE host synchronisation, which the batched driver shares between its
+// matrices).  PTD_ERR_UNSUPPORTED (outputs untouched) when requested eigenvalues are closer than the route serves.
+constexpr double TRIDIAG_ORTOL = 1e-7;  // neighbours closer than this (relative to |T|) are re-orthogonalised
+
+static int tridiag_finish(const TridiagPlan& p, char* base, int64_t n, int64_t k, double* evals, double* evecs,
+                          int64_t ldv, double cluster_tol, bool all_values, double (&h_gap)[2], hipStream_t st) {
+  const double ortol = TRIDIAG_ORTOL;
   double* lam = reinterpret_cast<double*>(base + p.off_lam);
   double* bounds = reinterpret_cast<double*>(base + p.off_bounds);
-  const double ortol = 1e-7;  // neighbours closer than this (relative to |T|) are re-orthogonalised
-  double h_gap[2] = {0.0, 0.0};
   int rc = PTD_OK;
-  for (;;) {
-    hipLaunchKernelGGL(copy_pad_kernel, dim3(2048), dim3(256), 0, st, A, lda, (int)n, Aw, p.ld);
-    if (two)
-      rc = twostage_reduce(p.ts, base + p.off_ts, Aw, reinterpret_cast<double*>(base + p.off_V), p.ld,
-                           reinterpret_cast<double*>(base + p.off_d), reinterpret_cast<double*>(base + p.off_e), em, st);
-    else
-      rc = sytrd_f64(p, base, stats ? &timer : nullptr, resident, st);
-    if (rc != PTD_OK) { cleanup2(); return rc; }
-    if (stats) PTD_CHECK_HIP(hipEventRecord(e1, st));
-    // only the gaps that touch one of the k requested (largest) eigenvalues matter, and unless the caller
-    // wants every eigenvalue only those k + 1 are computed (one wave each: 5.4 ms for all 4096)
-    rc = tridiag_eigenvalues(p, base, all_values ? 0 : first, st);
-    if (rc != PTD_OK) { cleanup2(); return rc; }
-    hipLaunchKernelGGL(min_gap_kernel, dim3(1), dim3(1024), 0, st, lam + first, (int)n - first, bounds, ortol,
-                       bounds + 4);
-    int h_status[2] = {0, 0}, h_res = 0;
-    PTD_CHECK_HIP(hipMemcpyAsync(h_gap, bounds + 4, 16, hipMemcpyDeviceToHost, st));
-    if (!two) PTD_CHECK_HIP(hipMemcpyAsync(&h_res, resident_status(p, base), 4, hipMemcpyDeviceToHost, st));
-    if (two)
-      PTD_CHECK_HIP(hipMemcpyAsync(h_status, twostage_status(p.ts, base + p.off_ts), 8, hipMemcpyDeviceToHost, st));
-    PTD_CHECK_HIP(hipStreamSynchronize(st));
-    if (two && (h_status[0] || h_status[1])) {
-      if (getenv("PTD_JACOBI_DEBUG"))
-        fprintf(stderr, "[eigh_tridiag] two-stage reduction refused (cholesky %d, chase %d): one-stage\n", h_status[0],
-                h_status[1]);
-      two = false;
-      continue;
-    }
-    if (h_res) {
-      if (getenv("PTD_JACOBI_DEBUG"))
-        fprintf(stderr, "[eigh_tridiag] resident tail gave up (status %d): blocked path to the end\n", h_res);
-      resident_failed(h_res);
-      resident = false;
-      continue;
-    }
-    break;
-  }
   if (getenv("PTD_JACOBI_DEBUG"))
-    fprintf(stderr, "[eigh_tridiag] n=%lld %s min relative gap %.3e, longest chain of gaps below %.0e: %d\n",
-            (long long)n, two ? "two-stage" : "one-stage", h_gap[0], ortol, (int)h_gap[1]);
+    fprintf(stderr, "[eigh_tridiag] n=%lld min relative gap %.3e, longest chain of gaps below %.0e: %d\n",
+            (long long)n, h_gap[0], ortol, (int)h_gap[1]);
   int64_t kreal = k;     // requested eigenvalues above a cluster at the bottom of the spectrum (k: no such cluster)
   static const bool no_long_chains = getenv("PTD_EIGH_LONG_CHAINS") && atoi(getenv("PTD_EIGH_LONG_CHAINS")) == 0;
   // Neighbours closer than cluster_tol |T| (1e-10) or chains of more than 48 close ones used to be refused.  With every
@@ -3422,7 +3366,7 @@ int eigh_tridiag(const double* A, int64_t lda, int64_t n, int64_t k, double* eva
     if (!no_completion && k < n) {
       if (!all_values) {
         rc = tridiag_eigenvalues(p, base, 0, st);
-        if (rc != PTD_OK) { cleanup2(); return rc; }
+        if (rc != PTD_OK) return rc;
       }
       std::vector<double> hl((size_t)n);
       double hb[4] = {0, 0, 0, 0};
@@ -3456,7 +3400,6 @@ int eigh_tridiag(const double* A, int64_t lda, int64_t n, int64_t k, double* eva
     }
     if (!served) {
       set_error("eigh_tridiag: clustered eigenvalues (min relative gap %.3e, chain of %d)", h_gap[0], (int)h_gap[1] + 1);
-      cleanup2();
       return PTD_ERR_UNSUPPORTED;
     }
   }
@@ -3467,19 +3410,85 @@ int eigh_tridiag(const double* A, int64_t lda, int64_t n, int64_t k, double* eva
   const int niter = force_iter > 0 ? force_iter : (h_gap[0] > 1e-5 ? 2 : 3);
   if (kreal > 0) {
     rc = tridiag_vectors_and_backtransform(p, base, (int)kreal, evecs + (k - kreal), ldv, h_gap[1] > 0.0 ? ortol : 0.0,
-                                           niter, two, two ? ev : nullptr, two ? eq : nullptr, st, force_qr);
-    if (rc != PTD_OK) { cleanup2(); return rc; }
+                                           niter, st, force_qr);
+    if (rc != PTD_OK) return rc;
   }
   if (kreal < k) {
     // (the inverse-iteration factors u1 .. lm, four n x n buffers in a row, are dead behind the back-transformation)
     rc = complete_basis(evecs, ldv, n, k - kreal, k, base + p.off_u1, (size_t)(p.off_sw - p.off_u1), st);
     if (rc != PTD_OK) {
       if (rc == PTD_ERR_UNSUPPORTED) set_error("eigh_tridiag: the complement of the computed eigenvectors could not be completed");
-      cleanup2();
       return rc;
     }
   }
   PTD_CHECK_HIP(hipMemcpyAsync(evals, lam, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
+  return PTD_OK;
+}
+
+// Eigenvalues (all n) and the eigenvectors of the k largest ones ([n][k], ascending) through
+// the tridiagonal route.  Returns PTD_ERR_UNSUPPORTED (and
+// leaves the outputs untouched) when two eigenvalues are closer than `cluster_tol` * |T|: the
+// caller then uses the Jacobi solver, which needs no gap.
+int eigh_tridiag(const double* A, int64_t lda, int64_t n, int64_t k, double* evals, double* evecs, int64_t ldv,
+                 void* ws, size_t ws_bytes, double cluster_tol, bool all_values, ptd_eigh_stats* stats,
+                 hipStream_t st) {
+  const TridiagPlan p = tridiag_plan(n);
+  if (ws_bytes < p.total) {
+    set_error("eigh_tridiag: workspace %zu < required %zu bytes", ws_bytes, p.total);
+    return PTD_ERR_WORKSPACE;
+  }
+  InflightGuard in_flight;
+  char* base = static_cast<char*>(ws);
+  double* Aw = reinterpret_cast<double*>(base + p.off_A);
+  SymvTimer timer;
+  hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+  if (stats) {
+    memset(stats, 0, sizeof(*stats));
+    stats->method = 1;
+    timer.stride = n >= 512 ? 8 : 1;
+    timer.ev.resize(2 * (size_t)(n / timer.stride + 1));
+    for (auto& e : timer.ev) PTD_CHECK_HIP(hipEventCreate(&e));
+    PTD_CHECK_HIP(hipEventCreate(&e0));
+    PTD_CHECK_HIP(hipEventCreate(&e1));
+    PTD_CHECK_HIP(hipEventCreate(&e2));
+    PTD_CHECK_HIP(hipEventRecord(e0, st));
+  }
+  auto cleanup = [&]() {
+    for (auto& e : timer.ev) (void)hipEventDestroy(e);
+    if (e0) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2); }
+  };
+  bool resident = true;   // the resident tail of the reduction; its status word is read below
+  const int first = (int)std::max<int64_t>(0, n - k - 1);
+  double* lam = reinterpret_cast<double*>(base + p.off_lam);
+  double* bounds = reinterpret_cast<double*>(base + p.off_bounds);
+  double h_gap[2] = {0.0, 0.0};
+  int rc = PTD_OK;
+  for (;;) {
+    hipLaunchKernelGGL(copy_pad_kernel, dim3(2048), dim3(256), 0, st, A, lda, (int)n, Aw, p.ld);
+    rc = sytrd_f64(p, base, stats ? &timer : nullptr, resident, st);
+    if (rc != PTD_OK) { cleanup(); return rc; }
+    if (stats) PTD_CHECK_HIP(hipEventRecord(e1, st));
+    // only the gaps that touch one of the k requested (largest) eigenvalues matter, and unless the caller
+    // wants every eigenvalue only those k + 1 are computed (one wave each: 5.4 ms for all 4096)
+    rc = tridiag_eigenvalues(p, base, all_values ? 0 : first, st);
+    if (rc != PTD_OK) { cleanup(); return rc; }
+    hipLaunchKernelGGL(min_gap_kernel, dim3(1), dim3(1024), 0, st, lam + first, (int)n - first, bounds, TRIDIAG_ORTOL,
+                       bounds + 4);
+    int h_res = 0;
+    PTD_CHECK_HIP(hipMemcpyAsync(h_gap, bounds + 4, 16, hipMemcpyDeviceToHost, st));
+    PTD_CHECK_HIP(hipMemcpyAsync(&h_res, resident_status(p, base), 4, hipMemcpyDeviceToHost, st));
+    PTD_CHECK_HIP(hipStreamSynchronize(st));
+    if (h_res) {
+      if (getenv("PTD_JACOBI_DEBUG"))
+        fprintf(stderr, "[eigh_tridiag] resident tail gave up (status %d): blocked path to the end\n", h_res);
+      resident_failed(h_res);
+      resident = false;
+      continue;
+    }
+    break;
+  }
+  rc = tridiag_finish(p, base, n, k, evals, evecs, ldv, cluster_tol, all_values, h_gap, st);
+  if (rc != PTD_OK) { cleanup(); return rc; }
   if (stats) {
     PTD_CHECK_HIP(hipEventRecord(e2, st));
     PTD_CHECK_HIP(hipEventSynchronize(e2));
@@ -3487,29 +3496,6 @@ int eigh_tridiag(const double* A, int64_t lda, int64_t n, int64_t k, double* eva
     (void)hipEventElapsedTime(&t_red, e0, e1);
     (void)hipEventElapsedTime(&t_tail, e1, e2);
     stats->total_ms = t_red + t_tail;
-    if (two) {
-      // method 2: ms = {stage 1 (dense -> band), stage 2 (bulge chasing), eigenpairs of T, back-transformation};
-      // work = {4/3 n^3 flop of stage 1, 6 n^2 b flop of stage 2, 0, 4 n^2 k flop of Q2 and Q1};
-      // launches[3] holds the microseconds of the Q2 part of the back-transformation
-      float t1 = 0.f, t_vec = 0.f, t_q2 = 0.f;
-      (void)hipEventElapsedTime(&t1, e0, em);
-      (void)hipEventElapsedTime(&t_vec, e1, ev);
-      (void)hipEventElapsedTime(&t_q2, ev, eq);
-      stats->method = 2;
-      stats->ms[0] = t1;
-      stats->ms[1] = t_red - t1;
-      stats->ms[2] = t_vec;
-      stats->ms[3] = t_tail - t_vec;
-      stats->launches[0] = p.ts.npanels * 9;
-      stats->launches[1] = 1;
-      stats->launches[3] = (int)(t_q2 * 1000.f);
-      const double dn = (double)n;
-      stats->work[0] = 4.0 / 3.0 * dn * dn * dn;
-      stats->work[1] = 6.0 * dn * dn * TS_BAND;
-      stats->work[3] = 4.0 * dn * dn * (double)k;
-      cleanup2();
-      return PTD_OK;
-    }
     // SYMV launches: every stride-th column carries events; the columns of one stride block have
     // nearly the same trailing order, so the block's time is stride x its sample
     double timed_ms = 0.0;
@@ -3530,12 +3516,114 @@ int eigh_tridiag(const double* A, int64_t lda, int64_t n, int64_t k, double* eva
     stats->launches[1] = 2 * (int)n;
     stats->ms[3] = t_tail;
     stats->work[2] = 4.0 / 3.0 * (double)n * (double)n * (double)n;  // rank-2k updates of the full trailing square
-    cleanup2();
+    cleanup();
   }
   return PTD_OK;
 }
 
 size_t tridiag_workspace_bytes(int64_t n) { return tridiag_plan(n).total; }
+
+// ---- several matrices of one order per launch
+// dwain's precompute pass (dwain.py:580-633) is a loop of independent torch.linalg.eigh calls (:162) on the layers of a
+// split.  One direct reduction is a chain of ~2 n dependent launches (alpha, SYMV) whose cost per column is launch
+// latency once the trailing block is small and the stream of the triangle while it is large; matrices of the same
+// order advance column by column in lockstep, so ONE launch per kernel and column serves all of them: blockIdx.y is
+// the matrix, every workspace pointer moves by y * bstride (the workspaces are `count` copies of one plan, bstride
+// apart).  The latency one chain cannot hide is shared by the batch -- by construction, on one stream, from one host
+// thread -- where round 5 interleaved the chains of concurrent host threads on streams probed for distinct hardware
+// queues.  The resident kernels (one matrix in the registers of the whole chip) do not take part: `count` of them would
+// run one after the other at 8-18 us a column and matrix; the batched columns cost less per matrix from count = 2 on.
+size_t tridiag_batched_workspace_bytes(int64_t n, int count) {
+  return align_up(tridiag_plan(n).total, 4096) * (size_t)std::max(count, 1);
+}
+
+// rcs[b]: PTD_OK or PTD_ERR_UNSUPPORTED (matrix b's requested eigenvalues are clustered beyond what the route serves:
+// its outputs are untouched, the caller hands it to the Jacobi solver); any other failure is returned at once.
+// stats (optional): method 1, the figures of the WHOLE batch -- ms[0] / launches[0] / work[0] the sampled SYMV launches
+// (each serves `count` matrices: work[0] counts their bytes together).
+int eigh_tridiag_batched(const double* const* As, int64_t lda, int count, int64_t n, int64_t k, double* const* evals,
+                         double* const* evecs, int64_t ldv, void* ws, size_t ws_bytes, double cluster_tol,
+                         bool all_values, int* rcs, ptd_eigh_stats* stats, hipStream_t st) {
+  const TridiagPlan p = tridiag_plan(n);
+  const size_t bstride = align_up(p.total, 4096);
+  if (ws_bytes < bstride * (size_t)count) {
+    set_error("eigh_tridiag_batched: workspace %zu < required %zu bytes", ws_bytes, bstride * (size_t)count);
+    return PTD_ERR_WORKSPACE;
+  }
+  InflightGuard in_flight;
+  char* base = static_cast<char*>(ws);
+  SymvTimer timer;
+  hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+  if (stats) {
+    memset(stats, 0, sizeof(*stats));
+    stats->method = 1;
+    timer.stride = n >= 512 ? 8 : 1;
+    timer.ev.resize(2 * (size_t)(n / timer.stride + 1));
+    for (auto& e : timer.ev) PTD_CHECK_HIP(hipEventCreate(&e));
+    PTD_CHECK_HIP(hipEventCreate(&e0));
+    PTD_CHECK_HIP(hipEventCreate(&e1));
+    PTD_CHECK_HIP(hipEventCreate(&e2));
+    PTD_CHECK_HIP(hipEventRecord(e0, st));
+  }
+  auto cleanup = [&]() {
+    for (auto& e : timer.ev) (void)hipEventDestroy(e);
+    if (e0) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2); }
+  };
+  for (int b = 0; b < count; ++b)
+    hipLaunchKernelGGL(copy_pad_kernel, dim3(2048), dim3(256), 0, st, As[b], lda, (int)n,
+                       reinterpret_cast<double*>(base + b * bstride + p.off_A), p.ld);
+  int rc = sytrd_f64(p, base, stats ? &timer : nullptr, false, st, count, bstride);
+  if (rc != PTD_OK) { cleanup(); return rc; }
+  if (stats) PTD_CHECK_HIP(hipEventRecord(e1, st));
+  const int first = (int)std::max<int64_t>(0, n - k - 1);
+  std::vector<double> gaps(2 * (size_t)count, 0.0);
+  for (int b = 0; b < count; ++b) {
+    char* bb = base + b * bstride;
+    rc = tridiag_eigenvalues(p, bb, all_values ? 0 : first, st);
+    if (rc != PTD_OK) { cleanup(); return rc; }
+    double* lam = reinterpret_cast<double*>(bb + p.off_lam);
+    double* bounds = reinterpret_cast<double*>(bb + p.off_bounds);
+    hipLaunchKernelGGL(min_gap_kernel, dim3(1), dim3(1024), 0, st, lam + first, (int)n - first, bounds, TRIDIAG_ORTOL,
+                       bounds + 4);
+    PTD_CHECK_HIP(hipMemcpyAsync(&gaps[2 * (size_t)b], bounds + 4, 16, hipMemcpyDeviceToHost, st));
+  }
+  PTD_CHECK_HIP(hipStreamSynchronize(st));     // the ONE host synchronisation of the batch (clustered spectra aside)
+  for (int b = 0; b < count; ++b) {
+    double h_gap[2] = {gaps[2 * (size_t)b], gaps[2 * (size_t)b + 1]};
+    rcs[b] = tridiag_finish(p, base + b * bstride, n, k, evals[b], evecs[b], ldv, cluster_tol, all_values, h_gap, st);
+    if (rcs[b] != PTD_OK && rcs[b] != PTD_ERR_UNSUPPORTED) { cleanup(); return rcs[b]; }
+  }
+  if (stats) {
+    PTD_CHECK_HIP(hipEventRecord(e2, st));
+    PTD_CHECK_HIP(hipEventSynchronize(e2));
+    float t_red = 0.f, t_tail = 0.f;
+    (void)hipEventElapsedTime(&t_red, e0, e1);
+    (void)hipEventElapsedTime(&t_tail, e1, e2);
+    stats->total_ms = t_red + t_tail;
+    stats->sweeps = count;      // (Jacobi sweeps are zero on this route: the field carries the batch size here)
+    double timed_ms = 0.0;
+    for (int64_t j = 0; j < n - 1; ++j) {
+      if (n - j - 1 < 1) break;
+      if (timer.sampled((int)j)) {
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, timer.start((int)j), timer.stop((int)j));
+        const int64_t blk0 = j / timer.stride * timer.stride;
+        const int64_t cols = std::min<int64_t>(blk0 + timer.stride, n - 1) - blk0;
+        timed_ms += (double)ms * (double)cols;
+      }
+      stats->launches[0] += 1;
+      const double m = (double)(n - j - 1);
+      stats->work[0] += (double)count * 8.0 * m * (m - 1.0);
+    }
+    stats->ms[0] = (float)timed_ms;
+    stats->ms[1] = t_red - stats->ms[0];
+    stats->launches[1] = 2 * (int)n;
+    stats->ms[3] = t_tail;
+    stats->work[2] = (double)count * 4.0 / 3.0 * (double)n * (double)n * (double)n;
+    cleanup();
+  }
+  return PTD_OK;
+}
 
 int concurrent_chains_exchange(int chains) { return device_state().chains.exchange(chains); }
 
@@ -3552,33 +3640,15 @@ int tridiagonalize_f64(const double* A, int64_t lda, int64_t n, double* d_out, d
   char* base = static_cast<char*>(ws);
   double* Aw = reinterpret_cast<double*>(base + p.off_A);
   hipLaunchKernelGGL(copy_pad_kernel, dim3(2048), dim3(256), 0, st, A, lda, (int)n, Aw, p.ld);
-  int rc;
-  bool two = p.two;
-  if (two) {
-    rc = twostage_reduce(p.ts, base + p.off_ts, Aw, reinterpret_cast<double*>(base + p.off_V), p.ld,
-                         reinterpret_cast<double*>(base + p.off_d), reinterpret_cast<double*>(base + p.off_e), nullptr, st);
-    if (rc != PTD_OK) return rc;
-    // the failure words of the two-stage reduction (Cholesky breakdown in a panel, chase time-out): as in
-    // eigh_tridiag, such a matrix goes through the one-stage reduction
-    int h_status[2] = {0, 0};
-    PTD_CHECK_HIP(hipMemcpyAsync(h_status, twostage_status(p.ts, base + p.off_ts), 8, hipMemcpyDeviceToHost, st));
-    PTD_CHECK_HIP(hipStreamSynchronize(st));
-    if (h_status[0] || h_status[1]) {
-      two = false;
-      hipLaunchKernelGGL(copy_pad_kernel, dim3(2048), dim3(256), 0, st, A, lda, (int)n, Aw, p.ld);
-    }
-  }
-  if (!two) {
-    rc = sytrd_f64(p, base, nullptr, true, st);
-    if (rc != PTD_OK) return rc;
-    int h_res = 0;
-    PTD_CHECK_HIP(hipMemcpyAsync(&h_res, resident_status(p, base), 4, hipMemcpyDeviceToHost, st));
-    PTD_CHECK_HIP(hipStreamSynchronize(st));
-    if (h_res) {   // the resident tail gave up: once more on the blocked path
-      resident_failed(h_res);
-      hipLaunchKernelGGL(copy_pad_kernel, dim3(2048), dim3(256), 0, st, A, lda, (int)n, Aw, p.ld);
-      rc = sytrd_f64(p, base, nullptr, false, st);
-    }
+  int rc = sytrd_f64(p, base, nullptr, true, st);
+  if (rc != PTD_OK) return rc;
+  int h_res = 0;
+  PTD_CHECK_HIP(hipMemcpyAsync(&h_res, resident_status(p, base), 4, hipMemcpyDeviceToHost, st));
+  PTD_CHECK_HIP(hipStreamSynchronize(st));
+  if (h_res) {   // the resident tail gave up: once more on the blocked path
+    resident_failed(h_res);
+    hipLaunchKernelGGL(copy_pad_kernel, dim3(2048), dim3(256), 0, st, A, lda, (int)n, Aw, p.ld);
+    rc = sytrd_f64(p, base, nullptr, false, st);
   }
   if (rc != PTD_OK) return rc;
   rc = tridiag_eigenvalues(p, base, 0, st);
@@ -3586,40 +3656,6 @@ int tridiagonalize_f64(const double* A, int64_t lda, int64_t n, double* d_out, d
   if (d_out) PTD_CHECK_HIP(hipMemcpyAsync(d_out, base + p.off_d, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
   if (e_out) PTD_CHECK_HIP(hipMemcpyAsync(e_out, base + p.off_e, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
   if (evals_out) PTD_CHECK_HIP(hipMemcpyAsync(evals_out, base + p.off_lam, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
-  return PTD_OK;
-}
-
-// Diagnostic entry: the band matrix after stage 1 (stages = 1) or after both stages (stages = 2) of the
-// two-stage reduction, as band rows [n][TS_LDBAND] (entry (i, j), 0 <= i - j <= 2 b, at [i][j - i + 2 b]).
-int band_reduce_f64(const double* A, int64_t lda, int64_t n, int stages, double* band_out, void* ws, size_t ws_bytes,
-                    hipStream_t st) {
-  PTD_REQUIRE(A && ws && band_out && n >= 1 && lda >= n, "ptd_band_reduce: bad argument");
-  const TridiagPlan p = tridiag_plan(n);
-  if (!p.two) {
-    set_error("ptd_band_reduce: the two-stage reduction does not apply to n = %lld", (long long)n);
-    return PTD_ERR_UNSUPPORTED;
-  }
-  if (ws_bytes < p.total) {
-    set_error("ptd_band_reduce: workspace %zu < required %zu bytes", ws_bytes, p.total);
-    return PTD_ERR_WORKSPACE;
-  }
-  char* base = static_cast<char*>(ws);
-  double* Aw = reinterpret_cast<double*>(base + p.off_A);
-  hipLaunchKernelGGL(copy_pad_kernel, dim3(2048), dim3(256), 0, st, A, lda, (int)n, Aw, p.ld);
-  const int rc = twostage_reduce_stages(p.ts, base + p.off_ts, Aw, reinterpret_cast<double*>(base + p.off_V), p.ld,
-                                        reinterpret_cast<double*>(base + p.off_d),
-                                        reinterpret_cast<double*>(base + p.off_e), nullptr, stages, st);
-  if (rc != PTD_OK) return rc;
-  int h_status[2] = {0, 0};
-  PTD_CHECK_HIP(hipMemcpyAsync(h_status, twostage_status(p.ts, base + p.off_ts), 8, hipMemcpyDeviceToHost, st));
-  PTD_CHECK_HIP(hipStreamSynchronize(st));
-  if (h_status[0] || h_status[1]) {
-    set_error("ptd_band_reduce: the two-stage reduction refused this matrix (cholesky %d, chase %d)", h_status[0],
-              h_status[1]);
-    return PTD_ERR_UNSUPPORTED;
-  }
-  PTD_CHECK_HIP(hipMemcpyAsync(band_out, base + p.off_ts + p.ts.off_band, (size_t)n * TS_LDBAND * 8,
-                               hipMemcpyDeviceToDevice, st));
   return PTD_OK;
 }
 

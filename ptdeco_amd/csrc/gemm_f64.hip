@@ -38,6 +38,7 @@ struct GemmF64Args {
   const double* A2;  // optional second operand pair with the same strides: C gets A B + A2 B2 in one pass
   const double* B2;  // over C (the symmetric rank-2k update V^T W + W^T V)
   double* row0_out;  // optional: the updated first row of C is also written here (the next panel's first column)
+  int64_t bstride;   // 64 x 64 kernel only: blockIdx.z is a batch index, every operand pointer moves by z * bstride elements
 };
 
 // this thread's 2 x (2 doubles) of a 64 (r) x 16 (k) operand tile
@@ -79,13 +80,14 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(const GemmF64Args a) {
   __shared__ __attribute__((aligned(16))) double Bs[DK * DP];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wr = wid >> 1, wc = wid & 1;
+  const int64_t zoff = (int64_t)blockIdx.z * a.bstride;
   const int ti = blockIdx.x % a.tiles_m, tj = blockIdx.x / a.tiles_m;
   const int m0 = ti * DM, n0 = tj * DN;
   const int kbeg = blockIdx.y * a.kchunk;
   const int kend = min(a.K, kbeg + a.kchunk);
   const int nk = (kend - kbeg + DK - 1) / DK;
-  const double* Ap = a.A + (int64_t)m0 * a.sam + (int64_t)kbeg * a.sak;
-  const double* Bp = a.B + (int64_t)n0 * a.sbn + (int64_t)kbeg * a.sbk;
+  const double* Ap = a.A + zoff + (int64_t)m0 * a.sam + (int64_t)kbeg * a.sak;
+  const double* Bp = a.B + zoff + (int64_t)n0 * a.sbn + (int64_t)kbeg * a.sbk;
   const int64_t sa = AKC ? a.sam : a.sak, sb = BKC ? a.sbn : a.sbk;
   const int64_t astep = (int64_t)DK * a.sak, bstep = (int64_t)DK * a.sbk;
   const int m_lim = a.M - m0, n_lim = a.N - n0;
@@ -101,8 +103,8 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(const GemmF64Args a) {
   const int npass = a.A2 ? 2 : 1;
   for (int pass = 0; pass < npass; ++pass) {
   if (pass == 1) {
-    Ap = a.A2 + (int64_t)m0 * a.sam + (int64_t)kbeg * a.sak;
-    Bp = a.B2 + (int64_t)n0 * a.sbn + (int64_t)kbeg * a.sbk;
+    Ap = a.A2 + zoff + (int64_t)m0 * a.sam + (int64_t)kbeg * a.sak;
+    Bp = a.B2 + zoff + (int64_t)n0 * a.sbn + (int64_t)kbeg * a.sbk;
   }
   if (nk > 0) {
     fetch64<AKC>(Ap, sa, m_lim, kend - kbeg, tid, ra);
@@ -147,14 +149,14 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(const GemmF64Args a) {
         const int row = m0 + wr * 32 + i * 16 + l4 + 4 * r;
         const int col = n0 + wc * 32 + j * 16 + l15;
         if (row >= a.M || col >= a.N) continue;
-        double* c = a.C + (int64_t)blockIdx.y * a.slab + (int64_t)row * a.ldc + col;
+        double* c = a.C + zoff + (int64_t)blockIdx.y * a.slab + (int64_t)row * a.ldc + col;
         const double v = a.alpha * acc[i][j][r];
         if (a.atomic) {
           atomicAdd(c, v);
         } else {
           const double nv = a.beta1 ? *c + v : v;
           *c = nv;
-          if (a.row0_out && row == 0) a.row0_out[col] = nv;
+          if (a.row0_out && row == 0) a.row0_out[zoff + col] = nv;
         }
       }
 }
@@ -394,7 +396,7 @@ static int glds_nt(int64_t M, int64_t N, int64_t K, int ksplit) {
 static int gemm_f64_impl(const double* A, int64_t sam, int64_t sak, const double* B, int64_t sbk, int64_t sbn,
                          const double* A2, const double* B2, double* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
                          double alpha, bool beta1, int ksplit, double* row0_out, hipStream_t st, int64_t slab = 0,
-                         bool lower_only = false);
+                         bool lower_only = false, int batch = 1, int64_t bstride = 0);
 
 int gemm_f64(const double* A, int64_t sam, int64_t sak, const double* B, int64_t sbk, int64_t sbn, double* C,
              int64_t ldc, int64_t M, int64_t N, int64_t K, double alpha, bool beta1, int ksplit, hipStream_t st) {
@@ -413,16 +415,18 @@ int gemm_f64_slabs(const double* A, int64_t sam, int64_t sak, const double* B, i
 }
 
 // C += alpha * (A B + A2 B2), both pairs with the same strides, in ONE pass over C
+// batch > 1: the same update on `batch` operand sets that lie bstride ELEMENTS apart (every pointer moves alike)
 int gemm_f64_pair(const double* A, const double* B, const double* A2, const double* B2, int64_t sam, int64_t sak,
                   int64_t sbk, int64_t sbn, double* C, int64_t ldc, int64_t M, int64_t N, int64_t K, double alpha,
-                  double* row0_out, hipStream_t st) {
-  return gemm_f64_impl(A, sam, sak, B, sbk, sbn, A2, B2, C, ldc, M, N, K, alpha, true, 1, row0_out, st);
+                  double* row0_out, hipStream_t st, int batch, int64_t bstride) {
+  return gemm_f64_impl(A, sam, sak, B, sbk, sbn, A2, B2, C, ldc, M, N, K, alpha, true, 1, row0_out, st, 0, false, batch,
+                       bstride);
 }
 
 static int gemm_f64_impl(const double* A, int64_t sam, int64_t sak, const double* B, int64_t sbk, int64_t sbn,
                          const double* A2, const double* B2, double* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
                          double alpha, bool beta1, int ksplit, double* row0_out, hipStream_t st, int64_t slab,
-                         bool lower_only) {
+                         bool lower_only, int batch, int64_t bstride) {
   if (M <= 0 || N <= 0) return PTD_OK;
   GemmF64Args a{};
   a.A = A; a.sam = sam; a.sak = sak;
@@ -440,10 +444,11 @@ static int gemm_f64_impl(const double* A, int64_t sam, int64_t sak, const double
   a.atomic = ksplit > 1 && slab == 0;
   a.slab = slab;
   a.lower = 0;
+  a.bstride = batch > 1 ? bstride : 0;
   const bool akc = (sak == 1), bkc = (sbk == 1);
   // the LDS-DMA kernel: B rows N-contiguous, A rows K- or M-contiguous, 16-byte aligned everything
   static const bool no_glds = getenv("PTD_GEMM_F64_NO_GLDS") != nullptr;
-  if (!no_glds && !A2 && !row0_out && sbn == 1 && (sak == 1 || sam == 1) && M >= 256 && N >= 64 && K >= 64 &&
+  if (!no_glds && batch <= 1 && !A2 && !row0_out && sbn == 1 && (sak == 1 || sam == 1) && M >= 256 && N >= 64 && K >= 64 &&
       a.kchunk % GK == 0 && (sak == 1 ? sam : sak) % 2 == 0 && sbk % 2 == 0 && ldc % 2 == 0 &&
       ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B) | reinterpret_cast<uintptr_t>(C)) & 15) == 0) {
     const int nt = glds_nt(M, N, K, ksplit);
@@ -464,7 +469,7 @@ static int gemm_f64_impl(const double* A, int64_t sam, int64_t sak, const double
       return PTD_OK;
     }
   }
-  dim3 grid((unsigned)(a.tiles_m * ceil_div(N, DN)), (unsigned)ksplit);
+  dim3 grid((unsigned)(a.tiles_m * ceil_div(N, DN)), (unsigned)ksplit, (unsigned)std::max(batch, 1));
   if (akc && bkc) hipLaunchKernelGGL((gemm_f64_kernel<true, true>), grid, dim3(256), 0, st, a);
   else if (akc && !bkc) hipLaunchKernelGGL((gemm_f64_kernel<true, false>), grid, dim3(256), 0, st, a);
   else if (!akc && bkc) hipLaunchKernelGGL((gemm_f64_kernel<false, true>), grid, dim3(256), 0, st, a);

@@ -53,8 +53,11 @@ int eigh_tridiag(const double* A, int64_t lda, int64_t n, int64_t k, double* eva
 int tridiagonalize_f64(const double* A, int64_t lda, int64_t n, double* d_out, double* e_out, double* evals_out,
                        void* ws, size_t ws_bytes, hipStream_t st);
 
-int band_reduce_f64(const double* A, int64_t lda, int64_t n, int stages, double* band_out, void* ws, size_t ws_bytes,
-                    hipStream_t st);
+// `count` matrices of one order per launch (blockIdx.y = matrix); rcs[b] = PTD_OK | PTD_ERR_UNSUPPORTED per matrix
+size_t tridiag_batched_workspace_bytes(int64_t n, int count);
+int eigh_tridiag_batched(const double* const* As, int64_t lda, int count, int64_t n, int64_t k, double* const* evals,
+                         double* const* evecs, int64_t ldv, void* ws, size_t ws_bytes, double cluster_tol,
+                         bool all_values, int* rcs, ptd_eigh_stats* stats, hipStream_t st);
 
 // eigh_filtered.hip: top-k eigenpairs by Chebyshev-filtered subspace iteration (f64 MFMA products); declines with
 // PTD_ERR_UNSUPPORTED when the spectrum does not suit it
@@ -72,6 +75,14 @@ int chol_inverse(double* G, int64_t m, double* Wt, void* ws, size_t ws_bytes, hi
 size_t eigh_factored_workspace_bytes(int64_t n_o, int64_t n_i, int64_t k);
 int eigh_factored(const void* W, int64_t ldw, int w_dtype, int64_t n_o, int64_t n_i, const double* Ex, int64_t ldx,
                   int64_t k, double* evals_k, double* U, int64_t ldu, void* ws, size_t ws_bytes, hipStream_t st);
+// the same in two halves around an eigendecomposition the CALLER runs (so that the inner problems of several layers
+// can share one batched call): prepare leaves B = L^T Ex L [np, np] (np = n_i rounded up to 64) in the workspace and
+// returns its address; finish takes the eigenvalues [np] / top-k eigenvectors S [np, k] of B
+int eigh_factored_prepare(const void* W, int64_t ldw, int w_dtype, int64_t n_o, int64_t n_i, const double* Ex,
+                          int64_t ldx, int64_t k, void* ws, size_t ws_bytes, double** B_out, int64_t* np_out,
+                          hipStream_t st);
+int eigh_factored_finish(int64_t n_o, int64_t n_i, int64_t k, const double* evals, const double* S, int64_t lds,
+                         double* evals_k, double* U, int64_t ldu, void* ws, size_t ws_bytes, hipStream_t st);
 
 // reduce.hip
 size_t cov_finalize_workspace_bytes(int64_t n);

@@ -20,6 +20,7 @@ from __future__ import annotations
 
 import collections.abc
 import logging
+import os
 import time
 from typing import Any, Optional
 
@@ -95,6 +96,16 @@ class CovarianceComputingLinearModule(torch.nn.Module):
         # the reference parks u on the CPU (:208); with 288 GB of HBM it stays resident
         return self.cov.eigenvectors(EIGEN_DAMPEN_FACTOR, top_k=self.top_k).to(self.weight.dtype)
 
+    def eigen_order(self) -> tuple:
+        return self.cov.eigen_order(self.top_k)
+
+    def eigen_problem(self) -> eng.EighProblem:
+        """get_eigenvectors as a problem the precompute pass can solve together with the other layers' (:162, :206-208)."""
+        p = self.cov.problem(EIGEN_DAMPEN_FACTOR, top_k=self.top_k)
+        inner, dtype = p.finish, self.weight.dtype
+        p.finish = lambda w, v: inner(w, v).to(dtype)
+        return p
+
 
 def _max_candidate_rank(dim_in: int, dim_out: int, min_rank: int, reduction_factor: float) -> int:
     """Largest rank the search of :407-421 can EVALUATE (>= 1): eigenvectors below it are never read.
@@ -155,10 +166,23 @@ def _precompute_covariance_matrix_decompositions(*, module, submodule_names, num
             return stand_ins[i].get_eigenvectors()
         return run
 
-    routes = [eng.eigh_route_hint(stand_ins[i].cov, stand_ins[i].out_features, stand_ins[i].top_k) for i in owned]
-    costs = [eng.eigh_cost_hint(stand_ins[i].cov, stand_ins[i].out_features, stand_ins[i].top_k) for i in owned]
-    with eng.phase("B_eigh"):
-        got = eng.run_concurrently([job(i) for i in owned], device, routes=routes, costs=costs)
+    if os.environ.get("PTD_EIGH_BATCHED", "1") != "0":
+        # one host thread, one stream: the layers' eigenproblems grouped by order, same-order reductions batched
+        def poser(i):
+            def pose():
+                if pending[i] is not None:
+                    pending[i]()
+                return stand_ins[i].eigen_problem()
+            return pose
+
+        with eng.phase("B_eigh"):
+            got = eng.solve_eigenproblems([poser(i) for i in owned], [stand_ins[i].eigen_order() for i in owned], device)
+    else:
+        # round 5's form: one host thread and one stream per chain (PTD_EIGH_BATCHED=0, kept for A/B)
+        routes = [eng.eigh_route_hint(stand_ins[i].cov, stand_ins[i].out_features, stand_ins[i].top_k) for i in owned]
+        costs = [eng.eigh_cost_hint(stand_ins[i].cov, stand_ins[i].out_features, stand_ins[i].top_k) for i in owned]
+        with eng.phase("B_eigh"):
+            got = eng.run_concurrently([job(i) for i in owned], device, routes=routes, costs=costs)
     for i, done in enumerate(pending):     # the sums this rank only contributed to: their buffers may go now
         if done is not None and not shard.owns(i):
             done()

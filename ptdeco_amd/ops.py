@@ -181,6 +181,90 @@ def eigh_factored(W: torch.Tensor, Ex: torch.Tensor, k: int) -> Optional[tuple[t
     return w, u
 
 
+def eigh_batched(mats, k: Optional[int] = None, all_values: bool = False) -> list:
+    """ops.eigh for several f64 matrices of ONE order in one ptd_eigh_topk_batched call: a list of (eigenvalues [n],
+    eigenvectors [n, k]) in the order of `mats`.  The loop of torch.linalg.eigh calls of dwain's precompute pass
+    (dwain.py:580-633, :162) -- the matrices advance through the tridiagonalisation in lockstep, every launch serves all of
+    them (one stream, one host thread).  One matrix, or a request the filtered route serves: solved one by one by the
+    library, exactly as ops.eigh would."""
+    mats = list(mats)
+    assert mats, "eigh_batched: no matrix"
+    a0 = mats[0]
+    n = a0.shape[0]
+    for a in mats:
+        _dev(a)
+        assert a.dtype == torch.float64 and a.dim() == 2 and a.shape == (n, n) and a.stride(1) == 1 \
+            and a.stride(0) == a0.stride(0) and a.device == a0.device
+    k = n if k is None else max(1, min(int(k), n))
+    lib = _hip.load()
+    count = len(mats)
+    ws_out = [torch.empty(n, dtype=torch.float64, device=a0.device) for _ in mats]
+    vs = [torch.empty((n, k), dtype=torch.float64, device=a0.device) for _ in mats]
+    ws = torch.empty(lib.ptd_eigh_batched_workspace_bytes(n, k, count), dtype=torch.uint8, device=a0.device)
+    arr = ctypes.c_void_p * count
+    a_ptrs = arr(*[a.data_ptr() for a in mats])
+    w_ptrs = arr(*[w.data_ptr() for w in ws_out])
+    v_ptrs = arr(*[v.data_ptr() for v in vs])
+    st = _hip.EighStats() if EIGH_PROFILE is not None else None
+    with torch.cuda.device(a0.device):
+        rc = lib.ptd_eigh_topk_batched(a_ptrs, a0.stride(0), count, n, k, int(all_values), w_ptrs, v_ptrs, k,
+                                       ws.data_ptr(), ws.numel(), ctypes.byref(st) if st is not None else None,
+                                       _stream(a0))
+    _hip.check(rc, "ptd_eigh_topk_batched")
+    if st is not None:
+        EIGH_PROFILE.append({"n": n, "k": k, "count": count, "method": st.method, "sweeps": st.sweeps,
+                             "launches": list(st.launches), "ms": list(st.ms), "total_ms": st.total_ms,
+                             "work": list(st.work)})
+    return list(zip(ws_out, vs))
+
+
+class FactoredProblem:
+    """The n_i-sized eigenproblem behind the top-k eigenvectors of W Ex W^T (ops.eigh_factored), exposed so that the
+    caller can solve `matrix` (B = L^T Ex L, [np, np] f64, a view into the workspace this object owns) together with
+    other matrices of the same order -- ops.eigh_batched -- and hand the eigenpairs back to `finish`."""
+
+    def __init__(self, W: torch.Tensor, ws: torch.Tensor, matrix: torch.Tensor, k: int):
+        self.n_o, self.n_i = W.shape
+        self.k, self.ws, self.matrix, self.device = k, ws, matrix, W.device
+
+    def finish(self, evals: torch.Tensor, S: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+        """evals [np] ascending, S [np, k] eigenvectors of `matrix` -> (eigenvalues [k], U [n_o, k]) of W Ex W^T."""
+        lib = _hip.load()
+        assert S.dtype == torch.float64 and S.shape == (self.matrix.shape[0], self.k) and S.stride(1) == 1
+        w = torch.empty(self.k, dtype=torch.float64, device=self.device)
+        u = torch.empty((self.n_o, self.k), dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = lib.ptd_eigh_factored_finish(self.n_o, self.n_i, self.k, evals.data_ptr(), S.data_ptr(), S.stride(0),
+                                              w.data_ptr(), u.data_ptr(), self.k, self.ws.data_ptr(), self.ws.numel(),
+                                              torch.cuda.current_stream(self.device).cuda_stream)
+        _hip.check(rc, "ptd_eigh_factored_finish")
+        return w, u
+
+
+def eigh_factored_prepare(W: torch.Tensor, Ex: torch.Tensor, k: int) -> Optional[FactoredProblem]:
+    """First half of ops.eigh_factored (G = W^T W = L L^T, B = L^T Ex L).  None when W^T W is not numerically positive
+    definite (the caller then works on the n_o x n_o matrix)."""
+    _dev(W, Ex)
+    assert W.dim() == 2 and Ex.dtype == torch.float64 and Ex.shape == (W.shape[1], W.shape[1])
+    W, Ex = _rows2d(W), _rows2d(Ex)
+    n_o, n_i = W.shape
+    k = max(1, min(int(k), n_i))
+    lib = _hip.load()
+    ws = torch.empty(lib.ptd_eigh_factored_workspace_bytes(n_o, n_i, k), dtype=torch.uint8, device=W.device)
+    b_ptr, np_ = ctypes.c_void_p(0), ctypes.c_int64(0)
+    with torch.cuda.device(W.device):
+        rc = lib.ptd_eigh_factored_prepare(W.data_ptr(), W.stride(0), _code(W), n_o, n_i, Ex.data_ptr(), Ex.stride(0), k,
+                                           ws.data_ptr(), ws.numel(), ctypes.byref(b_ptr), ctypes.byref(np_), _stream(W))
+    if rc == -2:  # PTD_ERR_UNSUPPORTED
+        return None
+    _hip.check(rc, "ptd_eigh_factored_prepare")
+    npad = int(np_.value)
+    off = int(b_ptr.value) - ws.data_ptr()
+    assert off >= 0 and off % 8 == 0 and off + npad * npad * 8 <= ws.numel()
+    matrix = ws[off:off + npad * npad * 8].view(torch.float64).view(npad, npad)
+    return FactoredProblem(W, ws, matrix, k)
+
+
 def chol_inverse(G: torch.Tensor) -> Optional[torch.Tensor]:
     """Diagnostic: W = L^-T (upper triangular, f64) with G = L L^T for a symmetric positive definite [m, m] f64
     matrix, m a multiple of 64 (the Cholesky sweep of the filtered eigensolver's orthonormalisation passes).
@@ -213,29 +297,6 @@ def tridiagonalize(A: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor, torch.T
                                     ws.data_ptr(), ws.numel(), _stream(A))
     _hip.check(rc, "ptd_tridiagonalize")
     return d, e, w
-
-
-def band_reduce(A: torch.Tensor, stages: int = 1) -> torch.Tensor:
-    """Diagnostic: dense symmetric [n, n] matrix with the band of the two-stage reduction after `stages` stages
-    (bandwidth 32 after stage 1, tridiagonal after stage 2; orthogonally similar to A)."""
-    _dev(A)
-    assert A.dtype == torch.float64 and A.dim() == 2 and A.shape[0] == A.shape[1] and A.stride(1) == 1
-    n = A.shape[0]
-    lib = _hip.load()
-    band = torch.empty((n, 66), dtype=torch.float64, device=A.device)
-    ws = torch.empty(lib.ptd_tridiagonalize_workspace_bytes(n), dtype=torch.uint8, device=A.device)
-    with torch.cuda.device(A.device):
-        rc = lib.ptd_band_reduce(A.data_ptr(), A.stride(0), n, int(stages), band.data_ptr(), ws.data_ptr(), ws.numel(),
-                                 _stream(A))
-    _hip.check(rc, "ptd_band_reduce")
-    band = band.cpu()
-    dense = torch.zeros((n, n), dtype=torch.float64)
-    for k in range(65):
-        off = 64 - k  # i - j
-        idx = torch.arange(off, n)
-        dense[idx, idx - off] = band[idx, k]
-    dense = torch.tril(dense) + torch.tril(dense, -1).T
-    return dense
 
 
 def matmul(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = None, alpha: float = 1.0,

@@ -53,6 +53,29 @@ def eigh_factored(W, Ex, k):
     return lam[lam.shape[0] - k:], w @ t
 
 
+class _Factored:
+    """ops.FactoredProblem in f64 LAPACK (same algebra: matrix = L^T Ex L, finish: u = W L^-T s)."""
+
+    def __init__(self, W, Ex, k):
+        self.w = W.double()
+        self.ell = torch.linalg.cholesky(self.w.T @ self.w)
+        b = self.ell.T @ Ex @ self.ell
+        self.matrix = 0.5 * (b + b.T)
+        self.k = max(1, min(int(k), self.matrix.shape[0]))
+
+    def finish(self, evals, S):
+        t = torch.linalg.solve_triangular(self.ell.T, S, upper=True)
+        return evals[evals.shape[0] - self.k:], self.w @ t
+
+
+def eigh_factored_prepare(W, Ex, k):
+    return _Factored(W, Ex, k)
+
+
+def eigh_batched(mats, k=None, all_values=False):
+    return [eigh(a, k, all_values) for a in mats]
+
+
 def matmul(a, b, bias=None, alpha=1.0, out_dtype=None):
     c = (a @ b) * alpha if alpha != 1.0 else a @ b
     if bias is not None:
@@ -80,8 +103,8 @@ def installed(monkeypatch):
     import ptdeco_amd
     from ptdeco_amd import _engine, ops
 
-    for name in ("syrk_accumulate", "colsum_accumulate", "cov_finalize", "eigh", "eigh_factored", "matmul",
-                 "lowrank_forward", "nsr", "sym_kl"):
+    for name in ("syrk_accumulate", "colsum_accumulate", "cov_finalize", "eigh", "eigh_factored", "eigh_factored_prepare",
+                 "eigh_batched", "matmul", "lowrank_forward", "nsr", "sym_kl"):
         monkeypatch.setattr(ops, name, globals()[name])
     monkeypatch.setattr(_engine, "require_device", lambda d: torch.device(d))
     yield ptdeco_amd

@@ -1484,68 +1484,89 @@ def test_pair_outside_the_hip_dtypes_warns_instead_of_silently_running_torch(ops
     tap.close()
 
 
-# ---------------------------------------------------------------- two-stage tridiagonalisation (opt-in route)
-@pytest.fixture
-def two_stage(monkeypatch):
-    monkeypatch.setenv("PTD_EIGH_STAGES", "2")
-    monkeypatch.setenv("PTD_EIGH_METHOD", "tridiag")
-
-
-def _spd(n, seed):
-    y = _rand((2 * n + 3, n), seed).double() * torch.logspace(0, -2, n, dtype=torch.float64)
+# ---------------------------------------------------------------- several matrices per launch (ptd_eigh_topk_batched)
+def _spd(n, seed, decay=-2.0):
+    y = _rand((2 * n + 3, n), seed).double() * torch.logspace(0, decay, n, dtype=torch.float64)
     a = y.T @ y / y.shape[0]
     return a + torch.eye(n, dtype=torch.float64) * (0.01 * torch.diag(a).mean())
 
 
-@pytest.mark.parametrize("n", [128, 160, 512])
-def test_two_stage_band_and_tridiagonal_are_orthogonally_similar(ops, two_stage, n):
-    """eigh_twostage.hip: stage 1 (CholeskyQR2 + Householder-reconstruction panels, two-sided block updates) leaves a
-    band of width 32, stage 2 (bulge chasing through the LDS window pipeline) a tridiagonal matrix, both with the
-    eigenvalues of A (LAPACK on the host) to working precision."""
-    a = _spd(n, 900 + n)
-    w_ref = torch.linalg.eigvalsh(a)
-    b1 = ops.band_reduce(a.to(DEV), 1)
-    assert torch.tril(b1, -33).abs().max().item() == 0.0
-    assert (torch.linalg.eigvalsh(b1) - w_ref).abs().max().item() <= 1e-13 * w_ref.max().item()
-    b2 = ops.band_reduce(a.to(DEV), 2)
-    assert torch.tril(b2, -2).abs().max().item() == 0.0
-    assert (torch.linalg.eigvalsh(b2) - w_ref).abs().max().item() <= 1e-13 * w_ref.max().item()
-    d, e, w = ops.tridiagonalize(a.to(DEV))
-    # (two runs: the Gram matrices of stage 1 are accumulated with f64 atomics, so they agree to rounding only)
-    assert (d.cpu() - torch.diag(b2)).abs().max().item() <= 1e-12 * w_ref.max().item()
-    assert (e.cpu()[: n - 1].abs() - torch.diag(b2, -1).abs()).abs().max().item() <= 1e-12 * w_ref.max().item()
-    assert (w.cpu() - w_ref).abs().max().item() <= 1e-12 * w_ref.max().item()
-
-
-@pytest.mark.parametrize("n,k", [(256, 64), (1024, 256), (1024, 1024)])
-def test_two_stage_eigh_top_k(ops, two_stage, n, k):
-    """The whole route (reduction, eigenpairs of T, back-transformation Z = Q1 Q2 Y) against LAPACK; the reflectors
-    keep Z orthonormal to 1e-13, two orders better than inverse iteration alone leaves the one-stage route."""
-    a = _spd(n, 70 + n)
+@pytest.mark.parametrize("n,k,count", [(300, 150, 3), (512, 512, 2), (1100, 550, 2), (1536, 768, 4), (2048, 1024, 3)])
+def test_eigh_batched_matches_single_calls(ops, n, k, count, monkeypatch):
+    """ptd_eigh_topk_batched (blockIdx.y = matrix through every kernel of the blocked reduction, dwain.py:580-633's
+    loop of eigh calls in one call) against `count` single ptd_eigh_topk calls on the same matrices and against LAPACK:
+    eigenvalues to 1e-11 relative, eigenvectors equal up to sign to 1e-8, residuals at the single route's level.  The
+    matrices have DIFFERENT spectra, so a pointer that strayed into a neighbour's workspace shows."""
+    monkeypatch.setenv("PTD_EIGH_BATCH_MIN_N", "256")
+    mats = [_spd(n, 500 + 7 * b + n, decay=-2.0 + 0.4 * b) for b in range(count)]
+    dev = [m.to(DEV) for m in mats]
     ops.EIGH_PROFILE = []
     try:
-        w, v = ops.eigh(a.to(DEV), k)
+        got = ops.eigh_batched(dev, k, all_values=False)
         prof = ops.EIGH_PROFILE[0]
     finally:
         ops.EIGH_PROFILE = None
-    assert prof["method"] == 2
-    w, v = w.cpu(), v.cpu()
-    w_ref, v_ref = torch.linalg.eigh(a)
-    assert (w - w_ref).abs().max().item() <= 1e-12 * w_ref.max().item()
-    assert (v.T @ v - torch.eye(k, dtype=torch.float64)).abs().max().item() <= 5e-9
-    assert (a @ v - v * w[n - k:]).abs().max().item() <= 1e-11 * w_ref.max().item()
-    p, p_ref = v @ v.T, v_ref[:, n - k:] @ v_ref[:, n - k:].T
-    assert (p - p_ref).norm().item() <= 1e-6 * math.sqrt(k)
+    if ops._hip.load().ptd_eigh_route(n, k, 0) == 1:
+        assert prof["method"] == 1 and prof["sweeps"] == count, prof       # the batched route ran, all matrices per launch
+    for m, d, (w, v) in zip(mats, dev, got):
+        w1, v1 = ops.eigh(d, k, all_values=False)
+        wmax = w1[-1].item()
+        assert (w[n - k:] - w1[n - k:]).abs().max().item() <= 1e-11 * wmax
+        assert (orc.canonical_sign(v.cpu()) - orc.canonical_sign(v1.cpu())).abs().max().item() <= 1e-8
+        w_ref = torch.linalg.eigvalsh(m)
+        assert (w.cpu()[n - k:] - w_ref[n - k:]).abs().max().item() <= 1e-12 * w_ref.max().item()
+        vc = v.cpu()
+        assert (m @ vc - vc * w.cpu()[n - k:]).abs().max().item() <= 1e-10 * w_ref.max().item()
+        assert (vc.T @ vc - torch.eye(k, dtype=torch.float64)).abs().max().item() <= 5e-8
 
 
-def test_two_stage_falls_back_on_a_rank_deficient_panel(ops, two_stage):
-    """A numerically singular panel breaks the Cholesky factorisation of its Gram matrix: the failure word is read at
-    the solver's host synchronisation and the matrix goes through the one-stage reduction (or Jacobi) instead."""
-    n = 256
-    y = _rand((40, n), 9).double()          # rank 40 << n, no damping
-    a = y.T @ y
-    w, v = ops.eigh(a.to(DEV), 64)
-    w, v = w.cpu(), v.cpu()
-    w_ref = torch.linalg.eigvalsh(a)
-    assert (w - w_ref).abs().max().item() <= 1e-10 * w_ref.max().item()
-    assert (a @ v - v * w[n - 64:]).abs().max().item() <= 1e-9 * w_ref.max().item()
+def test_eigh_batched_mixed_requests_and_clusters(ops, monkeypatch):
+    """One matrix, a request the filtered route serves, and a batch in which ONE matrix is rank deficient (its damping
+    floor reaches into the request: completed from the complement; or refused and handed to Jacobi) -- every matrix
+    gets the answer its single call gets."""
+    monkeypatch.setenv("PTD_EIGH_BATCH_MIN_N", "256")
+    n = 384
+    full = _spd(n, 1)
+    y = _rand((60, n), 2).double()
+    deficient = y.T @ y / 60
+    deficient = deficient + torch.eye(n, dtype=torch.float64) * (0.01 * torch.diag(deficient).mean())
+    mats = [full, deficient, _spd(n, 3, decay=-1.0)]
+    got = ops.eigh_batched([m.to(DEV) for m in mats], 192)
+    for m, (w, v) in zip(mats, got):
+        w_ref = torch.linalg.eigvalsh(m)
+        vc, wc = v.cpu(), w.cpu()
+        assert (wc[n - 192:] - w_ref[n - 192:]).abs().max().item() <= 1e-10 * w_ref.max().item()
+        assert (m @ vc - vc * wc[n - 192:]).abs().max().item() <= 1e-9 * w_ref.max().item()
+        assert (vc.T @ vc - torch.eye(192, dtype=torch.float64)).abs().max().item() <= 1e-7
+    one = ops.eigh_batched([mats[0].to(DEV)], 100)
+    w1, v1 = ops.eigh(mats[0].to(DEV), 100, all_values=False)
+    assert torch.equal(one[0][1], v1)
+    # a quarter of the spectrum at n = 2048: the filtered route's request, solved one by one inside the call
+    big = [_spd(2048, 11).to(DEV), _spd(2048, 12, decay=-3.0).to(DEV)]
+    for d, (w, v) in zip(big, ops.eigh_batched(big, 512)):
+        w1, v1 = ops.eigh(d, 512, all_values=False)
+        assert (orc.canonical_sign(v.cpu()) - orc.canonical_sign(v1.cpu())).abs().max().item() <= 1e-8
+
+
+def test_eigh_factored_in_two_halves_matches_the_one_call_form(ops):
+    """ptd_eigh_factored_prepare / _finish around an eigendecomposition of the caller (so that gate / up's inner problems
+    can share a batched call with down's covariance) against ptd_eigh_factored on the same operands."""
+    n_i, n_o, k, t = 256, 640, 128, 1024
+    g = torch.Generator(device="cuda").manual_seed(5)
+    w = torch.randn(n_o, n_i, generator=g, device=DEV) / n_i ** 0.5
+    x = torch.randn(t, n_i, generator=g, device=DEV) * torch.logspace(0, -2, n_i, device=DEV)
+    e = torch.zeros(n_i, n_i, dtype=torch.float64, device=DEV)
+    ops.syrk_accumulate(e, x, 1.0 / t)
+    ex = ops.cov_finalize(e, 1, 0.0)
+    lam, u = ops.eigh_factored(w, ex, k)
+    fp = ops.eigh_factored_prepare(w, ex, k)
+    assert fp is not None and fp.matrix.shape == (n_i, n_i)
+    ww, s = ops.eigh(fp.matrix, k, all_values=False)
+    lam2, u2 = fp.finish(ww, s)
+    assert (lam - lam2).abs().max().item() <= 1e-12 * lam[-1].item()
+    assert (orc.canonical_sign(u.cpu()) - orc.canonical_sign(u2.cpu())).abs().max().item() <= 1e-9
+    # and through a batch with an unrelated matrix of the same order
+    other = _spd(n_i, 77).to(DEV)
+    (wa, sa), _ = ops.eigh_batched([fp.matrix, other], k)
+    lam3, u3 = fp.finish(wa, sa)
+    assert (orc.canonical_sign(u.cpu()) - orc.canonical_sign(u3.cpu())).abs().max().item() <= 1e-8
