@@ -165,7 +165,7 @@ int ptd_eigh_topk_f32(const float* A, int64_t lda, int64_t n, int64_t k, int all
  * of ~2 n dependent launches per matrix, so the matrices advance column by column in lockstep and every launch
  * serves all of them (blockIdx.y = matrix) -- one host thread, one stream, one host synchronisation for the batch,
  * where round 5 ran one thread and one stream per layer.  Requests the filtered route serves (see above) and single
- * matrices are solved one after the other exactly as ptd_eigh_topk would; two matrices are batched from n = 1025 on
+ * matrices are solved one after the other exactly as ptd_eigh_topk would; two matrices are batched from n = 512 on
  * (PTD_EIGH_BATCH_MIN_N), three or more always; PTD_EIGH_BATCHED=0: never.  stats (HOST pointer, may be NULL): the
  * ptd_eigh_profiled figures of the batch (method 1: `sweeps` = matrices per launch, work[0] = algorithmic bytes of
  * all of them) or of the last matrix when solved one by one.  Workspace: ptd_eigh_batched_workspace_bytes. */
@@ -174,6 +174,13 @@ struct ptd_eigh_stats_s;
 int ptd_eigh_topk_batched(const double* const* As, int64_t lda, int count, int64_t n, int64_t k, int all_values,
                           double* const* evals, double* const* evecs, int64_t ldv, void* ws, size_t ws_bytes,
                           struct ptd_eigh_stats_s* stats, void* stream);
+
+/* The filtered route remembers LATE declines (a breakdown after its products were spent) per calling thread, device and
+ * shape, and sends the next requests of that shape straight to the direct route (1, 2, 4, ... of them after the second
+ * decline in a row).  This call clears the calling thread's memory: the drivers issue it at the start of every
+ * decompose_in_place, so that the route a layer takes depends on that call's own sequence of requests only (two runs in
+ * one process produce identical results).  No reference counterpart. */
+void ptd_eigh_forget_declines(void);
 
 /* The solver ptd_eigh_topk would try FIRST for this request: 3 = filtered subspace iteration (chip-filling f64
  * products: concurrent chains gain nothing), 1 = direct tridiagonal reduction (a latency-bound chain of short

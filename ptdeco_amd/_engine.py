@@ -94,6 +94,15 @@ def is_decomposeable_module(module: torch.nn.Module) -> bool:
             and module.groups == 1)
 
 
+def begin_run() -> None:
+    """Start of a decompose_in_place call: the eigensolver forgets the calling thread's route memory
+    (ptd_eigh_forget_declines), so that two runs in one process take the same routes and give identical results."""
+    from . import _hip
+
+    if torch.cuda.is_available():
+        _hip.load().ptd_eigh_forget_declines()
+
+
 def require_device(device) -> torch.device:
     device = torch.device(device)
     if device.type != "cuda":
@@ -910,22 +919,35 @@ def eigenvectors_from_input_moment(weight: torch.Tensor, ex: torch.Tensor, damp_
 
 
 def solve_eigenproblems(posers: list, orders: list, device: torch.device) -> list:
-    """The eigendecompositions of one precompute pass (dwain.py:580-633: a loop of get_eigenvectors calls), on the
-    caller's stream from the caller's thread.  posers[i]() -> EighProblem, orders[i] = (n, k) it will have.  Problems of
-    one (n, k) are formed and solved PTD_EIGH_BATCH_MAX (default 4) at a time by one ops.eigh_batched call -- their
-    reductions advance in lockstep, every launch serves all of them -- and finished before the next chunk is formed, so at
-    most that many matrices and factored workspaces are alive at once.  Groups are taken in the order of their first
-    member; the result list is in the order of `posers`."""
+    """The eigendecompositions of one precompute pass (dwain.py:580-633: a loop of get_eigenvectors calls).
+    posers[i]() -> EighProblem, orders[i] = (n, k) it will have.  The result list is in the order of `posers`.
+
+    Work units: problems of one (n, k) that the direct reduction serves are formed and solved PTD_EIGH_BATCH_MAX (default
+    4) at a time by ONE ops.eigh_batched call -- their reductions advance in lockstep, every launch serves all of them --
+    and finished before the next chunk is formed (at most that many matrices and factored workspaces alive at once);
+    every other problem (the filtered route's requests, lone orders) is a unit of its own.  Lanes (PTD_EIGH_PLAN):
+      "split" (default)  two lanes, each a fixed list of units run in order on its own stream by its own host thread: the
+                         batched direct reductions (a chain of short launches bound by latency and by the stream of the
+                         trailing triangle from HBM) beside everything else (the filtered route's f64 products on the
+                         matrix cores): the two kinds of work overlap, the members of a lane never compete;
+      "seq"              one lane: every unit on the caller's stream from the caller's thread.
+    Which unit runs in which lane, and in which order, is decided from the orders alone -- not by which chain happens to
+    finish first (round 5 dealt seven jobs to four worker threads dynamically) --, and the eigensolver's route memory is
+    per host thread (ptd_eigh_forget_declines), so the results do not depend on scheduling."""
     import os
 
+    from . import _hip
+
     cap = max(1, int(os.environ.get("PTD_EIGH_BATCH_MAX", "4")))
+    plan = os.environ.get("PTD_EIGH_PLAN", "split").lower()
+    lib = _hip.load()
     groups: dict = {}
     for i, key in enumerate(orders):
         groups.setdefault(tuple(key), []).append(i)
     out: list = [None] * len(posers)
-    for key, members in groups.items():
-        for c0 in range(0, len(members), cap):
-            chunk = members[c0:c0 + cap]
+
+    def batch_unit(chunk):
+        def run():
             problems = [posers[i]() for i in chunk]
             # (a poser may fall back to another order -- a refused factored problem: those are solved alone)
             same = [j for j, p in enumerate(problems) if p.key == problems[0].key]
@@ -938,7 +960,39 @@ def solve_eigenproblems(posers: list, orders: list, device: torch.device) -> lis
             for j, p in enumerate(problems):
                 if j not in same:
                     out[chunk[j]] = p.solve()
-            del problems
+        return run
+
+    def single_unit(i):
+        def run():
+            out[i] = posers[i]().solve()
+        return run
+
+    direct_units, other_units = [], []
+    for (n, k), members in groups.items():
+        route = int(lib.ptd_eigh_route(n, k, 0)) if device.type == "cuda" else 1
+        if route == 1 and len(members) >= 2:
+            for c0 in range(0, len(members), cap):
+                chunk = members[c0:c0 + cap]
+                (direct_units if len(chunk) >= 2 else other_units).append(
+                    batch_unit(chunk) if len(chunk) >= 2 else single_unit(chunk[0]))
+        else:
+            other_units.extend(single_unit(i) for i in members)
+
+    def lane(units):
+        def run():
+            for u in units:
+                u()
+            return None
+        return run
+
+    if plan == "seq" or not direct_units or not other_units or device.type != "cuda":
+        lane(direct_units + other_units)()
+    else:
+        run_concurrently([lane(direct_units), lane(other_units)], device, max_streams=2)
+        cur = torch.cuda.current_stream(device)
+        for t in out:       # (allocated on a lane's stream, used from here on under the caller's)
+            if isinstance(t, torch.Tensor) and t.is_cuda:
+                t.record_stream(cur)
     return out
 
 

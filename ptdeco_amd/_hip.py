@@ -38,6 +38,7 @@ SIGNATURES = {
     "ptd_eigh_topk": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int64, c_void_p,
                               c_size_t, ctypes.POINTER(c_int), c_void_p]),
     "ptd_eigh_route": (c_int, [c_int64, c_int64, c_int]),
+    "ptd_eigh_forget_declines": (None, []),
     "ptd_eigh_f32_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "ptd_eigh_topk_f32": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_void_p, c_int64, c_void_p,
                                   c_size_t, ctypes.POINTER(c_int), c_void_p]),

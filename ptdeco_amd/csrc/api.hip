@@ -149,6 +149,8 @@ static int eigh_dispatch(const double* A, int64_t lda, int64_t n, int64_t k, dou
   return eigh_jacobi(A, lda, n, k, evals, evecs, ldv, ws, ws_bytes, sweeps_out, stats, st);
 }
 
+void ptd_eigh_forget_declines(void) { eigh_filtered_forget_declines(); }
+
 int ptd_eigh_route(int64_t n, int64_t k, int all_values) {
   // what eigh_dispatch would try first for this request (the filtered route may still decline at run time)
   const int method = eigh_method();
@@ -158,11 +160,12 @@ int ptd_eigh_route(int64_t n, int64_t k, int all_values) {
 }
 
 // ---- several matrices of one order in one call
-// count == 2 matrices are batched from this order on (below it two single calls with their resident kernels, ~3-5 us a
-// column and matrix on one XCD, are as fast as a shared blocked column of ~10 us); count >= 3: always
+// count == 2 matrices are batched from this order on (two matrices of order 1024 take 8.3 ms either way -- a shared
+// blocked column of ~8 us against two resident ones of ~4 -- but the batched pair keeps that time beside another
+// stream's work, where single calls lose their resident kernels: 9 ms each); count >= 3: always
 static int batch_min_n() {
   const char* e = getenv("PTD_EIGH_BATCH_MIN_N");
-  return e ? atoi(e) : 1025;
+  return e ? atoi(e) : 512;
 }
 
 static bool batch_route(int count, int64_t n, int64_t k, bool all_values) {

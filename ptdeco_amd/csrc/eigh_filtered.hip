@@ -741,16 +741,19 @@ int chol_inverse(double* G, int64_t m, double* Wt, void* ws, size_t ws_bytes, hi
   return PTD_OK;
 }
 
-// ---- late declines are remembered (per device and shape)
+// ---- late declines are remembered (per calling thread, device and shape)
 // A decline after the density estimate costs 1.5 ms of a 55 ms direct reduction; a LATE one -- a Cholesky breakdown, a
 // residual that does not come down, clustered Ritz values -- has spent some fifteen products and a Rayleigh-Ritz solve
 // first.  The layers of one model share shapes and tend to share the character of their spectra, so after a late
 // decline THAT FOLLOWS ANOTHER (no success in between) the next 1, 2, 4, ... 64 requests of the same (device, n, k) go
 // straight to the direct route; a success resets the count.
+// The memory belongs to the CALLING THREAD and the caller can clear it (ptd_eigh_forget_declines: the drivers do at
+// the start of every decompose_in_place): which route a layer takes is then a function of the sequence of requests
+// that one caller made since -- not of what other threads of the process were solving, nor of an earlier run (round 5
+// kept one table per process, written by whichever concurrent chain finished first).
 namespace {
 struct DeclineNote { int device; int64_t n, k; int fails; int skip; };
-std::mutex g_decline_mu;
-std::vector<DeclineNote> g_declines;
+thread_local std::vector<DeclineNote> g_declines;
 DeclineNote* decline_note(int device, int64_t n, int64_t k, bool create) {
   for (auto& d : g_declines)
     if (d.device == device && d.n == n && d.k == k) return &d;
@@ -773,7 +776,6 @@ bool backoff_enabled() {     // PTD_EIGH_FILTER_BACKOFF=0: every request is trie
 // true: the filtered route should not be tried for this request (a recent late decline of the same shape)
 bool eigh_filtered_backed_off(int64_t n, int64_t k) {
   if (!backoff_enabled()) return false;
-  std::lock_guard<std::mutex> lock(g_decline_mu);
   DeclineNote* d = decline_note(current_device(), n, k, false);
   if (!d || d->skip <= 0) return false;
   --d->skip;
@@ -781,7 +783,6 @@ bool eigh_filtered_backed_off(int64_t n, int64_t k) {
 }
 static void note_outcome(int64_t n, int64_t k, bool late_decline) {
   if (!backoff_enabled()) return;
-  std::lock_guard<std::mutex> lock(g_decline_mu);
   DeclineNote* d = decline_note(current_device(), n, k, late_decline);
   if (!d) return;
   if (late_decline) {
@@ -795,6 +796,8 @@ static void note_outcome(int64_t n, int64_t k, bool late_decline) {
     d->skip = 0;
   }
 }
+
+void eigh_filtered_forget_declines() { g_declines.clear(); }
 
 // The widest block the route accepts at order n: n / 2 (the subspace must stay well below the matrix order);
 // PTD_EIGH_FILTER_BLOCK_EIGHTHS=5 admits 5 n / 8 -- k = n / 2 with a quarter more: 2560 of 4096 -- (experiments)

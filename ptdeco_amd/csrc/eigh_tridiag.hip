@@ -29,6 +29,9 @@ int gemm_f64(const double* A, int64_t sam, int64_t sak, const double* B, int64_t
 int gemm_f64_pair(const double* A, const double* B, const double* A2, const double* B2, int64_t sam, int64_t sak,
                   int64_t sbk, int64_t sbn, double* C, int64_t ldc, int64_t M, int64_t N, int64_t K, double alpha,
                   double* row0_out, hipStream_t st, int batch = 1, int64_t bstride_elems = 0);
+int gemm_f64_slabs(const double* A, int64_t sam, int64_t sak, const double* B, int64_t sbk, int64_t sbn, double* C,
+                   int64_t ldc, int64_t slab, int64_t M, int64_t N, int64_t K, double alpha, int ksplit, int* nslabs,
+                   bool lower_only, hipStream_t st);
 
 namespace {
 
@@ -3098,6 +3101,15 @@ int tridiag_eigenvalues(const TridiagPlan& p, char* base, int first, hipStream_t
 
 // eigenvectors of T for all eigenvalues into Y (= evecs, [n][ldv]), then Y <- Q Y
 namespace {
+// out = slab_0 + slab_1 + ... (index order: a deterministic K split); slab q at S + q * total
+__global__ void sum_slabs_kernel(double* __restrict__ out, const double* __restrict__ S, int64_t total, int ns) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    double acc = S[i];
+    for (int q = 1; q < ns; ++q) acc += S[(int64_t)q * total + i];
+    out[i] = acc;
+  }
+}
+
 // G (mp x mp) <- identity outside its leading nvec x nvec block (which the Gram product fills)
 __global__ void gram_pad_kernel(double* __restrict__ G, int mp, int nvec) {
   for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < (int64_t)mp * mp; e += (int64_t)gridDim.x * blockDim.x) {
@@ -3250,10 +3262,25 @@ int tridiag_vectors_and_backtransform(const TridiagPlan& p, char* base, int nvec
     const double* Vp = Vall + (size_t)pn * NB * ld;
     const double* TVp = TVall + (size_t)pn * NB * ld;
     double* Wp2 = grouped ? Wg : W2;
-    // W = TV_g Y  (rows x nvec)
-    PTD_CHECK_HIP(hipMemsetAsync(Wp2, 0, (size_t)rows * nvec * 8, st));
-    // (K ranges added with atomics: 16 for a 64-row panel, 8 for a group's 256 rows -- 4 x the tiles per range)
-    int rc = gemm_f64(TVp + r0, ld, 1, Y + (int64_t)r0 * ldy, ldy, 1, Wp2, nvec, rows, nvec, mr, 1.0, true, grouped ? 8 : 16, st);
+    // W = TV_g Y  (rows x nvec): the K range (up to n rows) is cut into slabs -- 16 for a 64-row panel, 8 for a group's
+    // 256 rows: 4 x the tiles per range -- that are summed IN INDEX ORDER (round 5 added the ranges with f64 atomics:
+    // the eigenvectors then differed in their last bits from run to run).  The slabs live in the second inverse-iteration
+    // buffer (n x n doubles, dead by now); the split shrinks where they would not fit.
+    int ksplit = grouped ? 8 : 16;
+    while (ksplit > 1 && (size_t)ksplit * rows * nvec > (size_t)n * n) ksplit /= 2;
+    int rc;
+    if (ksplit > 1) {
+      double* slabs = reinterpret_cast<double*>(base + p.off_u2);
+      int nslabs = 0;
+      rc = gemm_f64_slabs(TVp + r0, ld, 1, Y + (int64_t)r0 * ldy, ldy, 1, slabs, nvec, (int64_t)rows * nvec, rows, nvec, mr,
+                          1.0, ksplit, &nslabs, false, st);
+      if (rc != PTD_OK) return rc;
+      const int64_t total = (int64_t)rows * nvec;
+      hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(total, 256), 4096)), dim3(256), 0, st,
+                         Wp2, slabs, total, nslabs);
+    } else {
+      rc = gemm_f64(TVp + r0, ld, 1, Y + (int64_t)r0 * ldy, ldy, 1, Wp2, nvec, rows, nvec, mr, 1.0, false, 1, st);
+    }
     if (rc != PTD_OK) return rc;
     // Y[r0:, :] -= V_g^T W
     rc = gemm_f64(Vp + r0, 1, ld, Wp2, nvec, 1, Y + (int64_t)r0 * ldy, ldy, mr, nvec, rows, -1.0, true, 1, st);

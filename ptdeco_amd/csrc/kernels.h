@@ -64,7 +64,8 @@ int eigh_tridiag_batched(const double* const* As, int64_t lda, int count, int64_
 bool eigh_filtered_applies(int64_t n, int64_t k, bool all_values);
 size_t eigh_filtered_workspace_bytes(int64_t n);              // an upper bound over every k the route accepts at n
 size_t eigh_filtered_workspace_bytes(int64_t n, int64_t k);   // what eigh_filtered(n, k) needs (0: does not apply)
-bool eigh_filtered_backed_off(int64_t n, int64_t k);          // a recent late decline of this shape on this device
+bool eigh_filtered_backed_off(int64_t n, int64_t k);          // a recent late decline of this shape (calling thread, device)
+void eigh_filtered_forget_declines();                          // ... forgotten: ptd_eigh_forget_declines
 int eigh_filtered(const double* A, int64_t lda, int64_t n, int64_t k, double* evals, double* evecs, int64_t ldv,
                   void* ws, size_t ws_bytes, ptd_eigh_stats* stats, hipStream_t st);
 

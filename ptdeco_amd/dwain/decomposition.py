@@ -422,6 +422,7 @@ def decompose_in_place(
     start_time = time.perf_counter()
     device = eng.require_device(device)
     shard = Shard.from_env(process_group)
+    eng.begin_run()     # (route memory of the eigensolver: this call's own requests decide, not an earlier run's)
     num_params = utils.get_num_params(module)
     current_params = num_params
     blacklisted = blacklisted_module_names or []

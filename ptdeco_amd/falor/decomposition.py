@@ -216,6 +216,7 @@ def decompose_in_place(
     start_time = time.perf_counter()
     device = eng.require_device(device)
     shard = Shard.from_env(process_group)
+    eng.begin_run()     # (route memory of the eigensolver: this call's own requests decide, not an earlier run's)
     blacklisted = blacklisted_module_names or []
 
     names = [name for name, mod in module.named_modules() if is_decomposeable_module(mod)]

@@ -686,16 +686,18 @@ def test_llama_shaped_stack_shares_input_moments_and_matches_oracle(monkeypatch)
 
 
 def test_dwain_stack_under_the_production_backoff_setting_takes_the_same_decisions(monkeypatch):
-    """the late-decline memory of the filtered eigensolver (`eigh_filtered_backed_off`, keyed by device and
-    shape) is process-wide state that concurrent chains update in whatever order they finish, and the suite pins it off
-    (conftest: PTD_EIGH_FILTER_BACKOFF=0).  Here the DEFAULT setting runs: the 8-layer stack of bench.py (its deeper
-    layers decline late on some boxes), three times in one process, against a run with the memory off -- which route a
-    layer takes may differ from run to run, the (layer, rank, accepted) decisions may not, and the metrics agree to the
-    two routes' agreement (nsr 1e-6 relative; ppl_diff, an f32 quantity, to its rounding)."""
+    """The late-decline memory of the filtered eigensolver (`eigh_filtered_backed_off`): per calling thread since round 6
+    and cleared at the start of every decompose_in_place (ptd_eigh_forget_declines), where round 5 kept one table per
+    process that concurrent chains updated in whatever order they finished.  The suite pins it off (conftest:
+    PTD_EIGH_FILTER_BACKOFF=0); here the DEFAULT setting runs an 8-layer stack of 4096 x 4096 layers (its deeper layers
+    decline late on some boxes), three times in one process: the runs are BIT-IDENTICAL to each other (same routes, same
+    eigenvectors, same metrics), and against a run with the memory off the (layer, rank, accepted) decisions agree and the
+    metrics agree to the two routes' agreement (nsr 1e-6 relative; ppl_diff, an f32 quantity, to its rounding)."""
     import bench
     import ptdeco_amd
 
-    model, data, metric = bench.make_workload(8, "cpu", bench.STACK_D_STEPS, 7 * bench.M_STEPS)
+    d_steps = 8
+    model, data, metric = bench.make_workload(8, "cpu", d_steps, 7 * bench.M_STEPS)
     cpu = torch.device("cpu")
     data_c, metric_c = bench.with_targets(model, data, cpu), bench.with_targets(model, metric, cpu)
     data_g = [{k: v.to(DEV) for k, v in b.items()} for b in data_c]
@@ -707,12 +709,13 @@ def test_dwain_stack_under_the_production_backoff_setting_takes_the_same_decisio
         ptdeco_amd.dwain.decompose_in_place(
             module=m, device=DEV, data_iterator=itertools.cycle(data_g), loss_fn=bench.ce_loss,
             metric_iterator=itertools.cycle(metric_g), finetune_fn=lambda mm, d, n: mm, trace=trace,
-            precomputing_covariance_num_splits=1, **dict(bench.DWAIN_KW, num_data_steps=bench.STACK_D_STEPS))
+            precomputing_covariance_num_splits=1, **dict(bench.DWAIN_KW, num_data_steps=d_steps))
         return trace
 
     monkeypatch.setenv("PTD_EIGH_FILTER_BACKOFF", "0")
     ref = run()
     monkeypatch.delenv("PTD_EIGH_FILTER_BACKOFF")
+    first = None
     for _ in range(3):
         got = run()
         assert [(t["layer"], t["rank"], t["accepted"]) for t in got] == [(t["layer"], t["rank"], t["accepted"]) for t in ref]
@@ -720,3 +723,22 @@ def test_dwain_stack_under_the_production_backoff_setting_takes_the_same_decisio
             assert abs(a["nsr"] - b["nsr"]) <= 1e-6 * abs(a["nsr"]) + 1e-12
             # (ppl_diff is formed in the loss dtype, f32: the routes' 1e-11 shows as rounding noise of the perplexities)
             assert abs(a["ppl_diff"] - b["ppl_diff"]) <= 1e-4 * abs(a["ppl_diff"]) + 2e-6
+        if first is None:
+            first = got
+        assert got == first, "two runs in one process differ"
+
+
+def test_llama_block_twice_in_one_process_is_bit_identical():
+    """one full-width Llama-3-8B block (bench.py's c4_block, bf16 model: the batched direct reductions
+    of down / gate / up beside the filtered q / o and the k / v pair on a second stream) decomposed twice in one process:
+    the two traces -- every candidate's nsr, perplexities and decision -- and the installed factors are bit-identical.
+    Which lane a problem runs in is fixed by its order, the route memory is per thread and per call, no f64 sum of the
+    eigensolver is formed with atomics."""
+    import bench
+
+    step, _kw = bench.llama_workload(torch.device("cuda", 0), 1, torch.bfloat16)
+    t1, t2 = [], []
+    c1 = step(t1)
+    c2 = step(t2)
+    assert len(t1) >= 30 and t1 == t2
+    assert c1 == c2

@@ -1,5 +1,5 @@
-"""B_eigh of bench.py's full-width Llama block (bf16) over several passes, with the concurrent chains started longest
-first (default) and in model order (PTD_EIGH_LONGEST_FIRST=0).  Usage: python tools/block_b_eigh.py [passes]"""
+"""B_eigh of bench.py's full-width Llama block (bf16) over several passes under the engine's plans (CONFIGS=split,seq,threads).
+Usage: python tools/block_b_eigh.py [passes]"""
 import copy, itertools, json, os, sys, time, torch
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root)
@@ -38,6 +38,9 @@ def step():
 import gc
 if os.environ.get("NOGC"): gc.disable()
 step()
-for mode in ("1", "0", "1", "0"):
-    os.environ["PTD_EIGH_LONGEST_FIRST"] = mode
-    print(json.dumps({"longest_first": mode == "1", "step_ms, B_eigh_ms": [step() for _ in range(passes)]}), flush=True)
+configs = [c for c in os.environ.get("CONFIGS", "split,seq,threads,split").split(",")]
+for cfg in configs:
+    # split / seq: PTD_EIGH_PLAN of the batched engine; threads: round 5's one thread and stream per chain
+    os.environ["PTD_EIGH_BATCHED"] = "0" if cfg == "threads" else "1"
+    os.environ["PTD_EIGH_PLAN"] = cfg if cfg != "threads" else "seq"
+    print(json.dumps({"config": cfg, "step_ms, B_eigh_ms": [step() for _ in range(passes)]}), flush=True)
