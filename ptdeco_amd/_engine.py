@@ -221,7 +221,10 @@ class PrefixMemo:
         self.bytes = 0
         self.budget = budget_bytes
         self.check = check
+        import weakref
+
         self.root_id = id(root)
+        self._root_ref = weakref.ref(root)
         self.self_check = self_check   # the first `second()` of this memo's life compares; cleared after it
         self.disabled = PrefixMemo.level.get(self.root_id, 0) >= 2
         if PrefixMemo.level.get(self.root_id, 0) >= 1:
@@ -314,6 +317,12 @@ class PrefixMemo:
         import logging
 
         PrefixMemo.level[self.root_id] = 2
+        root = self._root_ref()
+        if root is not None:
+            # (keyed by id: the entry goes with the model, so that a later model at the same address does not inherit it)
+            import weakref
+
+            weakref.finalize(root, PrefixMemo.level.pop, self.root_id, None)
         logging.getLogger(__name__).warning(
             "ptdeco_amd: the model does not compute the same values ahead of the analysed layer in both forwards of a "
             "metric step (%s %s): the prefix memo is off for this model -- both forwards of every metric step run whole, "
@@ -723,10 +732,23 @@ class StepBatch:
     def __init__(self, E: torch.Tensor):
         import os
 
+        import weakref
+
         self.E = E
         self.max_steps = max(1, int(os.environ.get("PTD_SYRK_STEPS", "8")))
         self.budget = int(os.environ.get("PTD_SYRK_BUFFER_MB", "4096")) << 20
         self.pending: list = []
+        # a batch dropped with steps still held (an exception during calibration, a layer skipped before its
+        # eigenvectors) gives its bytes back: the counter is process-wide and would otherwise stay raised for good,
+        # until every later batch fell back to one call per step
+        self._held = [0]
+        weakref.finalize(self, StepBatch._release, self._held)
+
+    @staticmethod
+    def _release(held: list) -> None:
+        with StepBatch._lock:
+            StepBatch.held_bytes -= held[0]
+            held[0] = 0
 
     @staticmethod
     def holdable(y: torch.Tensor) -> bool:
@@ -745,6 +767,7 @@ class StepBatch:
         self.pending.append(y if private else y.clone(memory_format=torch.contiguous_format))
         with StepBatch._lock:
             StepBatch.held_bytes += nbytes
+            self._held[0] += nbytes
         if len(self.pending) >= self.max_steps:
             self.flush()
 
@@ -753,7 +776,8 @@ class StepBatch:
             return
         ys, self.pending = self.pending, []
         with StepBatch._lock:
-            StepBatch.held_bytes -= sum(y.numel() * y.element_size() for y in ys)
+            StepBatch.held_bytes -= self._held[0]
+            self._held[0] = 0
         ops.syrk_accumulate_multi(self.E, ys, 1.0 / ys[0].shape[0])
         # (a flush from a worker thread of run_concurrently runs on that thread's side stream while the matrices were
         # allocated on the caller's: the allocator must not hand their memory out again before this stream is done
@@ -918,29 +942,34 @@ def eigenvectors_from_input_moment(weight: torch.Tensor, ex: torch.Tensor, damp_
     return problem_from_input_moment(weight, ex, damp_factor, top_k, factored).solve()
 
 
-def solve_eigenproblems(posers: list, orders: list, device: torch.device) -> list:
+def solve_eigenproblems(posers: list, orders: list, device: torch.device, costs: Optional[list] = None) -> list:
     """The eigendecompositions of one precompute pass (dwain.py:580-633: a loop of get_eigenvectors calls).
-    posers[i]() -> EighProblem, orders[i] = (n, k) it will have.  The result list is in the order of `posers`.
+    posers[i]() -> EighProblem, orders[i] = (n, k) it will have, costs[i] its relative cost (eigh_cost_hint).  The result
+    list is in the order of `posers`.
 
     Work units: problems of one (n, k) that the direct reduction serves are formed and solved PTD_EIGH_BATCH_MAX (default
-    4) at a time by ONE ops.eigh_batched call -- their reductions advance in lockstep, every launch serves all of them --
-    and finished before the next chunk is formed (at most that many matrices and factored workspaces alive at once);
-    every other problem (the filtered route's requests, lone orders) is a unit of its own.  Lanes (PTD_EIGH_PLAN):
-      "split" (default)  two lanes, each a fixed list of units run in order on its own stream by its own host thread: the
-                         batched direct reductions (a chain of short launches bound by latency and by the stream of the
-                         trailing triangle from HBM) beside everything else (the filtered route's f64 products on the
-                         matrix cores): the two kinds of work overlap, the members of a lane never compete;
-      "seq"              one lane: every unit on the caller's stream from the caller's thread.
-    Which unit runs in which lane, and in which order, is decided from the orders alone -- not by which chain happens to
-    finish first (round 5 dealt seven jobs to four worker threads dynamically) --, and the eigensolver's route memory is
-    per host thread (ptd_eigh_forget_declines), so the results do not depend on scheduling."""
+    2) at a time by ONE ops.eigh_batched call -- their reductions advance in lockstep, every launch serves all of them --
+    and finished before the next chunk is formed (few matrices and factored workspaces alive at once); every other
+    problem (the filtered route's requests, lone orders) is a unit of its own.
+    Lanes: PTD_EIGH_LANES (default 2) fixed lists of units, each run in order on its own stream by its own host thread.
+    The units are dealt longest first to the lane with the least work so far (costs from the orders alone), so a lane
+    of batched direct reductions -- chains of short launches bound by latency and by the stream of the trailing triangle
+    from HBM -- runs beside the filtered route's f64 products on the matrix cores, and two batched chains beside each
+    other interleave their columns.  Measured on one Llama-3-8B-width block (three (4096, 2048) direct problems, two
+    filtered (4096, 1024), two (1024, 512); B_eigh): everything on one stream 238 ms, batches of <= 4 in one lane beside
+    the rest 206, round 5's seven chains dealt dynamically to four threads 184-192.
+    Which unit runs in which lane, and in which order, is decided before anything runs -- not by which chain happens to
+    finish first --, and the eigensolver's route memory is per host thread (ptd_eigh_forget_declines), so the results
+    do not depend on scheduling.  PTD_EIGH_LANES=1: every unit on the caller's stream from the caller's thread."""
     import os
 
     from . import _hip
 
-    cap = max(1, int(os.environ.get("PTD_EIGH_BATCH_MAX", "4")))
-    plan = os.environ.get("PTD_EIGH_PLAN", "split").lower()
-    lib = _hip.load()
+    cap = max(1, int(os.environ.get("PTD_EIGH_BATCH_MAX", "2")))
+    nlanes = max(1, int(os.environ.get("PTD_EIGH_LANES", "2")))
+    lib = _hip.load() if device.type == "cuda" else None
+    if costs is None:
+        costs = [float(n) ** 3 for n, _k in orders]
     groups: dict = {}
     for i, key in enumerate(orders):
         groups.setdefault(tuple(key), []).append(i)
@@ -967,28 +996,43 @@ def solve_eigenproblems(posers: list, orders: list, device: torch.device) -> lis
             out[i] = posers[i]().solve()
         return run
 
-    direct_units, other_units = [], []
+    units: list = []        # (cost, first member, run)
     for (n, k), members in groups.items():
-        route = int(lib.ptd_eigh_route(n, k, 0)) if device.type == "cuda" else 1
-        if route == 1 and len(members) >= 2:
-            for c0 in range(0, len(members), cap):
-                chunk = members[c0:c0 + cap]
-                (direct_units if len(chunk) >= 2 else other_units).append(
-                    batch_unit(chunk) if len(chunk) >= 2 else single_unit(chunk[0]))
+        route = int(lib.ptd_eigh_route(n, k, 0)) if lib is not None else 1
+        if route == 1 and len(members) >= 2 and cap >= 2:
+            # chunks of `cap`; a lone last member joins the chunk before it (three matrices: one batch of three at cap 2)
+            chunks = [members[c0:c0 + cap] for c0 in range(0, len(members), cap)]
+            if len(chunks) >= 2 and len(chunks[-1]) == 1 and cap >= 3:
+                chunks[-2].extend(chunks.pop())
+            for chunk in chunks:
+                if len(chunk) >= 2:
+                    units.append((0.85 * sum(costs[i] for i in chunk), chunk[0], batch_unit(chunk)))
+                else:
+                    units.append((costs[chunk[0]], chunk[0], single_unit(chunk[0])))
         else:
-            other_units.extend(single_unit(i) for i in members)
+            units.extend((costs[i], i, single_unit(i)) for i in members)
+    # longest first (ties: model order) to the lane with the least work so far; inside a lane in dealing order
+    units.sort(key=lambda u: (-u[0], u[1]))
+    if device.type != "cuda":
+        nlanes = 1
+    lanes: list = [[] for _ in range(min(nlanes, max(len(units), 1)))]
+    load = [0.0] * len(lanes)
+    for cost, _first, run in units:
+        j = min(range(len(lanes)), key=lambda q: (load[q], q))
+        lanes[j].append(run)
+        load[j] += cost
 
-    def lane(units):
+    def lane(runs):
         def run():
-            for u in units:
-                u()
+            for r in runs:
+                r()
             return None
         return run
 
-    if plan == "seq" or not direct_units or not other_units or device.type != "cuda":
-        lane(direct_units + other_units)()
+    if len(lanes) == 1:
+        lane(lanes[0])()
     else:
-        run_concurrently([lane(direct_units), lane(other_units)], device, max_streams=2)
+        run_concurrently([lane(r) for r in lanes], device, max_streams=len(lanes))
         cur = torch.cuda.current_stream(device)
         for t in out:       # (allocated on a lane's stream, used from here on under the caller's)
             if isinstance(t, torch.Tensor) and t.is_cuda:

@@ -176,7 +176,9 @@ def _precompute_covariance_matrix_decompositions(*, module, submodule_names, num
             return pose
 
         with eng.phase("B_eigh"):
-            got = eng.solve_eigenproblems([poser(i) for i in owned], [stand_ins[i].eigen_order() for i in owned], device)
+            got = eng.solve_eigenproblems(
+                [poser(i) for i in owned], [stand_ins[i].eigen_order() for i in owned], device,
+                costs=[eng.eigh_cost_hint(stand_ins[i].cov, stand_ins[i].out_features, stand_ins[i].top_k) for i in owned])
     else:
         # round 5's form: one host thread and one stream per chain (PTD_EIGH_BATCHED=0, kept for A/B)
         routes = [eng.eigh_route_hint(stand_ins[i].cov, stand_ins[i].out_features, stand_ins[i].top_k) for i in owned]

@@ -11,6 +11,11 @@ Traffic: only the layer's owner runs the eigendecomposition, 
 covariance sums are REDUCED to the owner (half the bytes a ring all-reduce moves per link) and
 only the live lower triangle travels (half again); the owner sends back the top-k eigenvectors in
 the weight dtype (n k elements instead of n^2 f64).
+
+PTD_COV_COLLECTIVE=allreduce switches the covariance exchange to north_star's literal collective -- an all-reduce of the
+packed lower triangle, every rank receives the sum, only the owner uses it -- so that the two forms can be compared on
+a node (bench.py reports `cov_collective`); the default is "reduce" (to the owner).  Results are identical: the same
+sums reach the same owners.
 """
 
 from __future__ import annotations
@@ -42,9 +47,14 @@ def unpack_lower(packed: torch.Tensor, E: torch.Tensor, block: int = PACK_BLOCK)
 
 class Shard:
     def __init__(self, group: Any = None, rank: int = 0, world: int = 1):
+        import os
+
         self.group = group
         self.rank = rank
         self.world = world
+        self.collective = os.environ.get("PTD_COV_COLLECTIVE", "reduce").lower()
+        if self.collective not in ("reduce", "allreduce"):
+            raise ValueError(f"PTD_COV_COLLECTIVE={self.collective!r}: expected reduce or allreduce")
 
     @classmethod
     def from_env(cls, group: Any = None) -> "Shard":
@@ -87,7 +97,10 @@ class Shard:
         import torch.distributed as dist
 
         packed = pack_lower(E)
-        dist.reduce(packed, dst=self._global_rank(self.owner(index)), op=dist.ReduceOp.SUM, group=self.group)
+        if self.collective == "allreduce":
+            dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=self.group)
+        else:
+            dist.reduce(packed, dst=self._global_rank(self.owner(index)), op=dist.ReduceOp.SUM, group=self.group)
         if self.owns(index):
             unpack_lower(packed, E)
 
@@ -100,8 +113,11 @@ class Shard:
         import torch.distributed as dist
 
         packed = pack_lower(E)
-        work = dist.reduce(packed, dst=self._global_rank(self.owner(index)), op=dist.ReduceOp.SUM, group=self.group,
-                           async_op=True)
+        if self.collective == "allreduce":
+            work = dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            work = dist.reduce(packed, dst=self._global_rank(self.owner(index)), op=dist.ReduceOp.SUM, group=self.group,
+                               async_op=True)
 
         def complete() -> None:
             work.wait()

@@ -1001,3 +1001,23 @@ def test_step_batch_holds_calibration_steps_and_adds_them_in_one_call(monkeypatc
     calls.clear()
     cov4.add_features(ys[0].clone())
     assert calls == [("single", 1)]
+
+
+def test_step_batch_dropped_with_pending_steps_gives_its_bytes_back(monkeypatch):
+    """StepBatch.held_bytes is process-wide; a Covariance dropped with steps still held (an exception during
+    calibration, a layer skipped before its eigenvectors) must not leave its bytes in the counter -- once the leaked
+    total passed PTD_SYRK_BUFFER_MB every later batch would silently add step by step."""
+    import gc
+
+    from ptdeco_amd import _engine as eng, ops
+
+    monkeypatch.setattr(ops, "syrk_accumulate_multi", lambda E, ys, s: None)
+    monkeypatch.setattr(eng.StepBatch, "holdable", staticmethod(lambda y: y.dtype == torch.bfloat16 and y.dim() == 2))
+    held0 = eng.StepBatch.held_bytes
+    cov = eng.Covariance(8, torch.device("cpu"), True)
+    for _ in range(3):
+        cov.add_features(torch.zeros(16, 8).bfloat16())
+    assert eng.StepBatch.held_bytes == held0 + 3 * 16 * 8 * 2
+    del cov
+    gc.collect()
+    assert eng.StepBatch.held_bytes == held0

@@ -30,7 +30,8 @@ class _Patch:
         setattr(obj, name, value)
 
 
-def _worker(rank, world, port, name, outdir):
+def _worker(rank, world, port, name, outdir, collective="reduce"):
+    os.environ["PTD_COV_COLLECTIVE"] = collective
     for p in (ROOT, HERE, os.path.join(ROOT, "oracle")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -65,9 +66,9 @@ def _worker(rank, world, port, name, outdir):
     dist.destroy_process_group()
 
 
-def _run(name, world=2):
+def _run(name, world=2, collective="reduce"):
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_worker, args=(world, _free_port(), name, d), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, _free_port(), name, d, collective), nprocs=world, join=True)
         return [torch.load(os.path.join(d, f"rank{r}.pt"), weights_only=False) for r in range(world)]
 
 
@@ -93,6 +94,19 @@ def test_dwain_two_ranks_match_sequential_golden(name):
         assert torch.equal(r0["state"][k], r1["state"][k]), k
     ref = gio.t(gio.npz("e2e")[f"{name}.final_out"])
     assert (r0["out"] - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("name", ["dwain_mlp_split2", "falor_mlp_r9"])
+def test_all_reduce_form_of_the_covariance_exchange_gives_the_same_run(name):
+    """PTD_COV_COLLECTIVE=allreduce (north_star's literal collective: every rank receives the covariance sum) against the
+    default reduce-to-owner: same decisions, same config, bit-identical final weights on both ranks."""
+    a0, a1 = _run(name, collective="allreduce")
+    r0, r1 = _run(name, collective="reduce")
+    key = (lambda s: (s["layer"], s["rank"], s.get("accepted")))
+    assert sorted(map(key, a0["trace"] + a1["trace"])) == sorted(map(key, r0["trace"] + r1["trace"]))
+    assert a0["cfg"] == r0["cfg"] and a1["cfg"] == r1["cfg"]
+    for k in r0["state"]:
+        assert torch.equal(a0["state"][k], r0["state"][k]) and torch.equal(a1["state"][k], r1["state"][k]), k
 
 
 @pytest.mark.parametrize("name", ["falor_mlp_r9", "falor_conv"])

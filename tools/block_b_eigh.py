@@ -9,7 +9,7 @@ dev = torch.device("cuda", 0)
 passes = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 g = torch.Generator(device=dev).manual_seed(0)
 with torch.device(dev):
-    model0 = bench.LlamaStack(1)
+    model0 = bench.LlamaStack(int(os.environ.get('BLOCKS', '1')))
 with torch.no_grad():
     for prm in model0.parameters():
         prm.copy_(torch.randn(prm.shape, generator=g, device=dev) / prm.shape[1] ** 0.5)
@@ -28,7 +28,7 @@ def step():
     t0 = time.perf_counter()
     ptdeco_amd.dwain.decompose_in_place(module=m, device=dev, data_iterator=itertools.cycle(bt), loss_fn=bench.seq_ce,
                                         metric_iterator=itertools.cycle(bt[8:]), finetune_fn=lambda mm, d, n: mm,
-                                        **bench.C4_BLOCK_KW)
+                                        **dict(bench.C4_BLOCK_KW, trade_off_factor=20.0 * int(os.environ.get('BLOCKS', '1'))))
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     ph, eng.PHASES = eng.PHASES.totals_ms(), None
@@ -38,9 +38,10 @@ def step():
 import gc
 if os.environ.get("NOGC"): gc.disable()
 step()
-configs = [c for c in os.environ.get("CONFIGS", "split,seq,threads,split").split(",")]
+configs = [c for c in os.environ.get("CONFIGS", "2x2,3x2,2x3,2x4,1x4,threads").split(",")]
 for cfg in configs:
-    # split / seq: PTD_EIGH_PLAN of the batched engine; threads: round 5's one thread and stream per chain
+    # LxC: PTD_EIGH_LANES x PTD_EIGH_BATCH_MAX of the batched engine; threads: round 5's one thread and stream per chain
     os.environ["PTD_EIGH_BATCHED"] = "0" if cfg == "threads" else "1"
-    os.environ["PTD_EIGH_PLAN"] = cfg if cfg != "threads" else "seq"
+    if cfg != "threads":
+        os.environ["PTD_EIGH_LANES"], os.environ["PTD_EIGH_BATCH_MAX"] = cfg.split("x")
     print(json.dumps({"config": cfg, "step_ms, B_eigh_ms": [step() for _ in range(passes)]}), flush=True)
