@@ -951,13 +951,17 @@ def solve_eigenproblems(posers: list, orders: list, device: torch.device, costs:
     2) at a time by ONE ops.eigh_batched call -- their reductions advance in lockstep, every launch serves all of them --
     and finished before the next chunk is formed (few matrices and factored workspaces alive at once); every other
     problem (the filtered route's requests, lone orders) is a unit of its own.
-    Lanes: PTD_EIGH_LANES (default 2) fixed lists of units, each run in order on its own stream by its own host thread.
+    Lanes: PTD_EIGH_LANES (default 3) fixed lists of units, each run in order on its own stream by its own host thread.
     The units are dealt longest first to the lane with the least work so far (costs from the orders alone), so a lane
     of batched direct reductions -- chains of short launches bound by latency and by the stream of the trailing triangle
     from HBM -- runs beside the filtered route's f64 products on the matrix cores, and two batched chains beside each
     other interleave their columns.  Measured on one Llama-3-8B-width block (three (4096, 2048) direct problems, two
-    filtered (4096, 1024), two (1024, 512); B_eigh): everything on one stream 238 ms, batches of <= 4 in one lane beside
-    the rest 206, round 5's seven chains dealt dynamically to four threads 184-192.
+    filtered (4096, 1024), two (1024, 512); B_eigh, gpurun_out/r06_block_c.txt): everything on one stream 238 ms; two
+    lanes with batches of <= 2 / 3 / 4: 247 / 196 / 196; three lanes with batches of <= 2: 193.5 +- 0.2 (two blocks:
+    400.6 +- 0.1); round 5's seven chains dealt dynamically to four threads 184-190 (two blocks 397-404).  The three
+    direct problems stream 275 GB of trailing triangles whatever the arrangement (~57 ms at the rate the SYMV reaches),
+    and every arrangement lands within 5 % of the others once three chains share the chip: what the lanes buy is that
+    the time no longer depends on which hardware queue a stream happens to sit on or on which chain finishes first.
     Which unit runs in which lane, and in which order, is decided before anything runs -- not by which chain happens to
     finish first --, and the eigensolver's route memory is per host thread (ptd_eigh_forget_declines), so the results
     do not depend on scheduling.  PTD_EIGH_LANES=1: every unit on the caller's stream from the caller's thread."""
@@ -966,7 +970,7 @@ def solve_eigenproblems(posers: list, orders: list, device: torch.device, costs:
     from . import _hip
 
     cap = max(1, int(os.environ.get("PTD_EIGH_BATCH_MAX", "2")))
-    nlanes = max(1, int(os.environ.get("PTD_EIGH_LANES", "2")))
+    nlanes = max(1, int(os.environ.get("PTD_EIGH_LANES", "3")))
     lib = _hip.load() if device.type == "cuda" else None
     if costs is None:
         costs = [float(n) ** 3 for n, _k in orders]

@@ -275,6 +275,14 @@ __global__ __launch_bounds__(256) void nsr_final_kernel(const double* __restrict
       // written through to memory and acknowledged before the ticket is drawn; the last block reads the sums past its
       // caches (device-scope loads).  A __threadfence() here is a write-back of the whole L2 -- behind the layer
       // products of a metric forward it made this 4-us kernel take 16 (rocprofv3, C2 workload).
+      // What this relies on: the hand-off of MI355X_MICROARCH.md's table "Hand-offs measured with sc1 loads
+      // in place of the acquire", first row, in every cell -- ONE lane of each storing workgroup makes the workgroup's
+      // only store (8 bytes, agent scope = sc1, to hipMalloc memory), waits vmcnt(0) for its acknowledgement, then adds
+      // to ONE unsharded agent-scope counter; the workgroup whose add came last (the value returned) loads the sums with
+      // agent-scope (sc1) loads after its add has returned, its other waves behind the workgroup barrier that lane
+      // joins; one workgroup per CU (the launch asks for more than half a CU's LDS).  Measured on gfx950 / ROCm 7.2, not
+      // an architectural guarantee: tests/test_kernels_gpu.py::test_nsr_back_to_back_with_blocks_on_every_xcd compares
+      // hundreds of alternating calls bit for bit.
       __hip_atomic_store(&blocksum[blockIdx.x], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
@@ -493,7 +501,11 @@ int nsr(const void* x, const void* y, int64_t R, int64_t C, int dtype, double ep
     return PTD_ERR_UNSUPPORTED;
   }
   const unsigned fblocks = (unsigned)ceil_div(C, 64);
-  hipLaunchKernelGGL(nsr_final_kernel, dim3(fblocks), dim3(256), 0, st, part, R, C, p.nchunk, eps, blocksum, ticket, out);
+  // (81 KiB of dynamic LDS nobody touches: at most ONE of these workgroups per CU, the condition of the hand-off's row)
+  static const bool lds_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(nsr_final_kernel),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 81 * 1024) == hipSuccess;
+  hipLaunchKernelGGL(nsr_final_kernel, dim3(fblocks), dim3(256), lds_ok ? 81 * 1024 : 0, st, part, R, C, p.nchunk, eps,
+                     blocksum, ticket, out);
   PTD_CHECK_LAUNCH("nsr");
   return PTD_OK;
 }

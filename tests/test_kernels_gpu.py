@@ -71,13 +71,15 @@ def test_syrk_bf16_lds_dma_kernel_is_exact_on_small_integers(ops, T, n, ld, edt)
 
 
 @pytest.mark.parametrize("T,n,ld,steps", [
-    (192, 4096, 4096, 1),      # TS = 128 ring at its shortest (3 K steps), 512 items = two per CU
+    (192, 4096, 4096, 1),      # 3 K steps: below the ring's minimum (NBUF = 4 K steps at TS = 128) -> the one-step kernels
+    (256, 4096, 4096, 1),      # TS = 128 ring at its shortest (4 K steps = NBUF), 512 items = two per CU
     (2048, 4096, 4096, 1),     # the calibration shape of a Llama q / o layer
     (2048, 1024, 1024, 1),     # TS = 64 ring (k / v): 128 items
-    (448, 2048, 2056, 1),      # TS = 64 ring at its shortest (7 K steps), padded row pitch, 512 items
+    (448, 2048, 2056, 1),      # 7 K steps, n = 2048: TS = 128 ring (136 items < 192 -> TS = 64 needs 8 K steps: generic)
+    (512, 2048, 2056, 1),      # TS = 64 ring at its shortest (8 K steps = NBUF), padded row pitch, 528 items
     (333, 2560, 2568, 3),      # TS = 128, 200 items (fewer than CUs), ragged rows through the generic kernel, 3 steps
     (128, 4096, 4096, 8),      # 8 steps of 2 K steps each in one launch
-    (64, 4224, 4224, 11),      # 11 steps: one launch of 8 and one of 3 (3 K steps: the shortest ring)
+    (64, 4224, 4224, 11),      # 11 steps: one ring launch of 8 and a last chunk of 3 K steps (below the minimum: generic)
     (64, 1088, 1088, 9),       # TS = 64: a launch of 8 steps and a last step too short for the ring (generic kernel)
     (576, 4160, 4160, 2),      # n a multiple of 64 only -> TS = 64, 2113 items over 256 workgroups
     (256, 14336, 14336, 2),    # 112 tile rows: 6272 items
@@ -1186,6 +1188,28 @@ def test_nsr_random(ops, shape, chan, dtype):
     ref = orc.nsr(x=x.double(), y=y.double(), non_channel_dim=dims).item()
     got = ops.nsr(x.to(DEV), y.to(DEV), chan).item()
     assert got == pytest.approx(ref, rel=1e-9)
+
+
+def test_nsr_back_to_back_with_blocks_on_every_xcd(ops):
+    """nsr_final_kernel publishes its block sums with relaxed agent-scope stores + vmcnt(0) + a relaxed
+    ticket add (no release / acquire fences: the hand-off row of MI355X_MICROARCH.md).  A stale block sum would be a
+    silently wrong NSR -- the value that accepts or rejects a rank.  300 calls back to back on two alternating inputs
+    whose final launch has 2004 / 512 workgroups (every XCD takes part), each result compared BIT FOR BIT with the
+    first result of its input, which itself is checked against f64 arithmetic."""
+    for rows, chans, dt in ((256, 128256, torch.bfloat16), (512, 32768, torch.float32)):
+        ya = _rand((rows, chans), 31, dt).to(DEV)
+        yb = _rand((rows, chans), 32, dt).to(DEV)
+        xa = (ya.float() * 1.01 + 0.01).to(dt)
+        xb = (yb.float() * 0.97 - 0.02).to(dt)
+        want = []
+        for x, y in ((xa, ya), (xb, yb)):
+            ref = orc.nsr(x=x.double().cpu(), y=y.double().cpu(), non_channel_dim=(0,), eps=1e-3).item()
+            got = ops.nsr(x, y, chans).item()
+            assert got == pytest.approx(ref, rel=1e-9)
+            want.append(got)
+        outs = [ops.nsr(xa if i % 2 == 0 else xb, ya if i % 2 == 0 else yb, chans) for i in range(300)]
+        vals = torch.stack(outs).cpu().tolist()
+        assert all(v == want[i % 2] for i, v in enumerate(vals)), [i for i, v in enumerate(vals) if v != want[i % 2]][:5]
 
 
 def test_nsr_workspace_contract(ops):
