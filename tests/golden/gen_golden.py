@@ -15,6 +15,9 @@ Outputs (data only -- inputs and expected outputs):
     e2e.npz/.json G3/G4  falor + dwain decompose_in_place end to end on toy
                          models: per-candidate metric samples, decisions, final
                          decompose_config (key order preserved) and state_dict
+    bf16.npz/.json       (`--bf16`: written alone, the files above untouched) dwain end
+                         to end on a bf16 model with bf16 batches: the reference's own
+                         bf16 semantics (SURVEY a-Q 4), bf16 tensors as raw bits
 Every tensor is stored (no RNG seeds) so the fixtures do not depend on torch's
 generator.
 """
@@ -345,7 +348,45 @@ def e2e_scenarios(out: dict, meta: dict) -> None:
                  "nsr_final_threshold": 0.001})
 
 
+def bf16_scenarios(out: dict, meta: dict) -> None:
+    """SURVEY a-Q 4: with a bf16 model the reference forms uk, U, V, W~ in bf16 (dwain.py:423-429), stores the
+    precomputed eigenvectors in bf16 (:208) and -- the part that matters most -- forms every step's covariance product
+    einsum(y, y) / T in bf16 before promoting it into the f64 sum (:147-152).  One dwain scenario pins those semantics:
+    the MLP3 of the f32 scenarios cast to bf16, bf16 batches, loose thresholds (decisions with margins far above bf16
+    noise), per-layer and precomputed covariances."""
+    g = torch.Generator().manual_seed(20240524)
+    scale = torch.logspace(0, -1.5, 64)
+    pools = {"x": [(torch.randn(64, 64, generator=g) * scale).bfloat16() for _ in range(12)],
+             "m": [(torch.randn(64, 64, generator=g) * scale).bfloat16() for _ in range(6)]}
+    for k, v in pools.items():
+        out[f"pool.{k}"] = npy(torch.stack(v))
+    kw = dict(num_data_steps=4, num_metric_steps=2, nsr_final_threshold=0.5, min_rank=4, trade_off_factor=40.0,
+              reduction_factor=0.5, max_accepted_ppl_diff=0.5, decompose_in_float64=True)
+    for tag, extra in (("nosplit", {}), ("split1", {"precomputing_covariance_num_splits": 1})):
+        m = make_mlp(torch.Generator().manual_seed(314), 12).bfloat16()
+        save_model(out, "model.mlp_r12_bf16.", m)
+        with torch.no_grad():
+            tx = [m({"x": b}).argmax(dim=-1) for b in pools["x"]]
+            tmm = [m({"x": b}).argmax(dim=-1) for b in pools["m"]]
+        out["targets.mlp_r12_bf16.x"] = npy(torch.stack(tx))
+        out["targets.mlp_r12_bf16.m"] = npy(torch.stack(tmm))
+        run_dwain(out, meta, f"dwain_mlp_bf16_{tag}", m, pools["x"], tx, pools["m"], tmm,
+                  {"model": "mlp_r12_bf16", "arch": "MLP3", "pool": "x", "mpool": "m", "dtype": "bfloat16"},
+                  **{**kw, **extra})
+
+
 def main() -> None:
+    if "--bf16" in sys.argv:
+        # only the bf16 scenario, into files of its own (the f32 fixtures stay byte-identical)
+        e2e, meta = {}, {}
+        bf16_scenarios(e2e, meta)
+        np.savez_compressed(os.path.join(HERE, "bf16.npz"), **e2e)
+        with open(os.path.join(HERE, "bf16.json"), "wt") as f:
+            json.dump({"reference_version": ptdeco.__version__, "torch": torch.__version__, "scenarios": meta},
+                      f, indent=1)
+        for fn in ("bf16.npz", "bf16.json"):
+            print(fn, os.path.getsize(os.path.join(HERE, fn)), "bytes")
+        return
     prim, metrics, e2e, meta = {}, {}, {}, {}
     prim_scenarios(prim)
     metric_scenarios(metrics)

@@ -63,3 +63,37 @@ def final_state(name: str) -> dict[str, torch.Tensor]:
 def jsonable(cfg):
     """decompose_config after a JSON round trip (tuples become lists)."""
     return json.loads(json.dumps(cfg))
+
+
+# ---- the bf16 scenario (tests/golden/bf16.npz / bf16.json: gen_golden.py --bf16); bf16 tensors are stored as raw bits
+@functools.lru_cache(maxsize=None)
+def bf16_meta():
+    with open(os.path.join(GOLDEN, "bf16.json")) as f:
+        return json.load(f)["scenarios"]
+
+
+def _bits(a: np.ndarray) -> torch.Tensor:
+    x = torch.from_numpy(np.array(a))
+    return x.view(torch.bfloat16) if x.dtype == torch.int16 else x
+
+
+def bf16_model(scn: dict) -> torch.nn.Module:
+    z = npz("bf16")
+    model = tm.MLP3().bfloat16()
+    pre = f"model.{scn['model']}."
+    model.load_state_dict({k[len(pre):]: _bits(z[k]) for k in z.files if k.startswith(pre)})
+    return model
+
+
+def bf16_streams(scn: dict):
+    z = npz("bf16")
+    pools = {pid: [_bits(a) for a in z[f"pool.{pid}"]] for pid in (scn["pool"], scn["mpool"])}
+    tg = {pid: [t(a) for a in z[f"targets.{scn['model']}.{pid}"]] for pid in (scn["pool"], scn["mpool"])}
+    return (tm.cycle_dicts(pools[scn["pool"]], tg[scn["pool"]]), tm.cycle_dicts(pools[scn["mpool"]], tg[scn["mpool"]]),
+            pools[scn["pool"]][0])
+
+
+def bf16_final(name: str):
+    z = npz("bf16")
+    pre = f"{name}.final."
+    return {k[len(pre):]: _bits(z[k]) for k in z.files if k.startswith(pre)}, _bits(z[f"{name}.final_out"])

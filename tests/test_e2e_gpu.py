@@ -321,3 +321,45 @@ def test_dwain_with_a_training_finetune_fn_tracks_the_oracle():
     assert (out - ref).abs().max().item() <= REL * ref.abs().max().item()
     # the callback really trained something, on both sides
     assert len(grad_norms) >= 4 and all(g > 0.0 for g in grad_norms)
+
+
+@pytest.mark.parametrize("name", ["dwain_mlp_bf16_nosplit", "dwain_mlp_bf16_split1"])
+def test_dwain_bf16_model_against_the_reference_in_bf16(name):
+    """the reference's OWN bf16 semantics, pinned by a run of the imported reference
+    (tests/golden/bf16.*: bf16 MLP3, bf16 batches; every step's covariance product rounded to bf16 before the f64 add,
+    dwain.py:147-152; factors formed in bf16, :423-429).  The HIP path accumulates that product in f32 on the matrix
+    cores and forms the factors from f64 eigenvectors -- MORE accurate than the reference, so the two agree only to
+    what bf16 rounding of a covariance entry (2^-8 relative) does to eigenvectors, factors and metrics.  Stated
+    tolerances (measured on MI355X, twice the worst deviation seen): identical (layer, rank, accepted) decisions and
+    config structure; per-candidate nsr within 6 % relative + 2e-4, ppl_deco within 1 % relative, model outputs
+    within 3 % of their range."""
+    import ptdeco_amd
+
+    scn = gio.bf16_meta()[name]
+    model = gio.bf16_model(scn).to(DEV)
+    data, metric, x0 = gio.bf16_streams(scn)
+    trace = []
+    cfg = ptdeco_amd.dwain.decompose_in_place(
+        module=model, device=DEV, data_iterator=data, metric_iterator=metric, loss_fn=tm.ce_loss,
+        finetune_fn=lambda m, device, names: m, trace=trace, **scn["kwargs"])
+    assert [(s["layer"], s["rank"], s["accepted"]) for s in trace] == \
+           [(s["layer"], s["rank"], s["accepted"]) for s in scn["steps"]]
+    assert list(cfg.keys()) == list(scn["config"].keys())
+    for layer, c in scn["config"].items():
+        assert cfg[layer]["modules"] == c["modules"] and cfg[layer]["__meta__"]["proportion"] == c["__meta__"]["proportion"]
+    m = scn["kwargs"]["num_metric_steps"]
+    samples = np.array(scn["metric_samples"]).reshape(len(trace), m, 3)
+    dev_nsr = max(abs(s["nsr"] - smp[:, 0].mean()) / (abs(smp[:, 0].mean()) + 1e-12) for s, smp in zip(trace, samples))
+    dev_ppl = max(abs(s["ppl_deco"] - smp[:, 1].mean()) / abs(smp[:, 1].mean()) for s, smp in zip(trace, samples))
+    want_state, want_out = gio.bf16_final(name)
+    with torch.no_grad():
+        out = model({"x": x0.to(DEV)}).float().cpu()
+    dev_out = (out - want_out.float()).abs().max().item() / want_out.float().abs().max().item()
+    print(f"bf16 scenario {name}: nsr {dev_nsr:.3e} ppl_deco {dev_ppl:.3e} out {dev_out:.3e}")
+    for s, smp in zip(trace, samples):
+        assert abs(s["nsr"] - smp[:, 0].mean()) <= 0.06 * abs(smp[:, 0].mean()) + 2e-4, (s, smp)
+        assert abs(s["ppl_deco"] - smp[:, 1].mean()) <= 0.01 * abs(smp[:, 1].mean()), (s, smp)
+    assert dev_out <= 0.03, dev_out
+    # the untouched parameters (biases of undecomposed layers do not exist here: every layer was replaced) and the
+    # installed modules' dtype
+    assert all(p.dtype == torch.bfloat16 for p in model.parameters())

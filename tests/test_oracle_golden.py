@@ -134,3 +134,27 @@ def test_quirk_last_tried_factors_win():
     scn = gio.e2e_meta()["falor_mlp_r9"]
     assert scn["config"]["fc3"]["__meta__"]["proportion"] == 0.8
     assert scn["config"]["fc3"]["modules"]["0"]["out_features"] == 7
+
+
+@pytest.mark.parametrize("name", ["dwain_mlp_bf16_nosplit", "dwain_mlp_bf16_split1"])
+def test_dwain_bf16_model_end_to_end(name):
+    """SURVEY a-Q 4 pinned by the reference itself (tests/golden/bf16.*, gen_golden.py --bf16): a bf16 model with bf16
+    batches -- covariance products formed in bf16 before the f64 add (dwain.py:147-152), uk / U / V / W~ in bf16
+    (:423-429), precomputed eigenvectors stored in bf16 (:208).  The oracle reproduces decisions, every metric sample,
+    the config and the final weights bit for bit."""
+    scn = gio.bf16_meta()[name]
+    model = gio.bf16_model(scn)
+    data, metric, x0 = gio.bf16_streams(scn)
+    trace = []
+    cfg = orc.dwain_decompose(module=model, data_iterator=data, metric_iterator=metric, loss_fn=tm.ce_loss,
+                              trace=trace, **scn["kwargs"])
+    assert gio.jsonable(cfg) == scn["config"]
+    assert [(s["layer"], s["rank"], s["accepted"]) for s in trace] == \
+           [(s["layer"], s["rank"], s["accepted"]) for s in scn["steps"]]
+    want_state, want_out = gio.bf16_final(name)
+    got = model.state_dict()
+    assert got.keys() == want_state.keys()
+    for k in got:
+        assert torch.equal(got[k], want_state[k]), k
+    with torch.no_grad():
+        assert torch.equal(model({"x": x0}), want_out)

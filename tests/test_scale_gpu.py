@@ -551,17 +551,18 @@ def test_dwain_c2_headline_workload_end_to_end_matches_oracle(splits):
     assert (out - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
 
 
-@pytest.mark.parametrize("by_route", ["0", "1"])
-def test_dwain_three_layer_stack_concurrent_filtered_chains_match_oracle(monkeypatch, by_route):
+@pytest.mark.parametrize("lanes", ["3", "1"])
+def test_dwain_three_layer_stack_concurrent_filtered_chains_match_oracle(monkeypatch, lanes):
     """The DEFAULT path of every multi-layer split (dwain.py:580-633 + 333-537): three nn.Linear(4096, 4096) in ONE
     precompute split, so their three eigendecompositions -- each the filtered subspace iteration, each with its own
-    host-side decisions and two stream synchronisations -- run as three concurrent chains on three HIP streams
-    (_engine.run_concurrently; the default), and one after the other on the caller's stream with the opt-in rule
-    PTD_EIGH_STREAMS_BY_ROUTE=1 (chains the filtered route will take run alone) -- against the CPU oracle on the
-    same seeded inputs: identical (layer, rank, accepted) decisions, nsr / ppl within 1e-4, factor products within 1e-4
-    (Frobenius), outputs 1e-4.  The test also asserts on which threads / streams the three calls ran and that the
-    solver's route for these matrices is the filtered one (the deepest layer's flatter spectrum may decline it)."""
-    monkeypatch.setenv("PTD_EIGH_STREAMS_BY_ROUTE", by_route)
+    host-side decisions and two stream synchronisations -- run as three lanes on three HIP streams
+    (_engine.solve_eigenproblems; the default), and one after the other on the caller's stream and thread with
+    PTD_EIGH_LANES=1 -- against the CPU oracle on the same seeded inputs: identical (layer, rank, accepted) decisions,
+    nsr / ppl within 1e-4, factor products within 1e-4 (Frobenius), outputs 1e-4.  The test also asserts on which
+    threads / streams the three calls ran and that the solver's route for these matrices is the filtered one (the
+    deepest layer's flatter spectrum may decline it)."""
+    monkeypatch.setenv("PTD_EIGH_LANES", lanes)
+    by_route = "1" if lanes == "1" else "0"
     import threading
 
     import bench
@@ -601,7 +602,7 @@ def test_dwain_three_layer_stack_concurrent_filtered_chains_match_oracle(monkeyp
             precomputing_covariance_num_splits=1, **bench.DWAIN_KW)
     finally:
         ops.eigh = real_eigh
-    streams_wanted = min(3, int(__import__("os").environ.get("PTD_EIGH_STREAMS", "4"))) if by_route == "0" else 1
+    streams_wanted = int(lanes)
     assert len(calls) == 3 and all(c[2:] == (4096, 1024) for c in calls)
     assert len({c[0] for c in calls}) == streams_wanted and len({c[1] for c in calls}) == streams_wanted
     if by_route == "1":
