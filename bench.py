@@ -534,7 +534,7 @@ def pmc_traffic(n):
     pmc = pmc_file("pmc_symv_r*.json", ("eigh_tridiag.hip",))
     if pmc and pmc["data"].get("n") == n:
         d = pmc["data"]
-        return {"traffic": d["traffic_bytes_per_launch"],
+        return {"traffic": d["traffic_bytes_per_launch"], "matrices_per_launch": d.get("matrices_per_launch", 1),
                 "traffic_source": pmc["source"] + ": (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per launch, "
                                   "%.3f x the algorithmic bytes" % d["traffic_over_algorithmic"],
                 "traffic_stale": pmc["stale"]}
@@ -678,8 +678,8 @@ def roofline_from_profile(prof, device):
     n, cnt, ms, byts = p["n"], p["launches"][0], p["ms"][0], p["work"][0]
     mats = p.get("count", 1) if p.get("sweeps", 0) > 1 else 1      # matrices per launch (work[0] counts all of them)
     tr = pmc_traffic(n)
-    if tr.get("traffic") and mats > 1:
-        tr["traffic"] = tr["traffic"] * mats        # (the committed counter pass is per matrix)
+    if tr.get("traffic") and mats != tr.get("matrices_per_launch", 1):
+        tr["traffic"] = tr["traffic"] * mats / tr.get("matrices_per_launch", 1)   # (the committed pass had another batch size)
     red_ms = p["ms"][0] + p["ms"][1]
     all_bytes = mats * sum(8.0 * (n - j - 1) * (n - j - 2) for j in range(n - 1))
     out = {"bound": "hbm", "achieved": byts / (ms * 1e-3) / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
@@ -984,14 +984,17 @@ def main(argv=None, measure_fn=None) -> int:
         full = dict(result)
         detail_path = args.detail
         blob = json.dumps(full, indent=1)
-        for path in (detail_path, os.path.join(ROOT, "gpurun_out", "bench_detail.json")):
+        default_path = os.path.join(ROOT, "bench_detail.json")
+        # (the copy under gpurun_out/ travels back from the GPU box; only for the default location -- tests pass their own)
+        for path in (detail_path,) + ((os.path.join(ROOT, "gpurun_out", "bench_detail.json"),)
+                                      if os.path.abspath(detail_path) == default_path else ()):
             try:
                 os.makedirs(os.path.dirname(path), exist_ok=True)
                 with open(path, "w") as fh:
                     fh.write(blob)
             except OSError as exc:      # a read-only tree must not cost the line
                 print(f"bench.py: could not write {path}: {exc}", file=sys.stderr)
-        print(f"bench.py: detail blocks written to {detail_path} (and gpurun_out/bench_detail.json)", flush=True)
+        print(f"bench.py: detail blocks written to {detail_path}", flush=True)
     print(compact_line(result, detail_path), flush=True)
     return 0
 

@@ -131,7 +131,43 @@ static int run_eigh() {
   return 0;
 }
 
+// mode "batched [count]": ptd_eigh_topk_batched on `count` (default 2) symmetric matrices of order 4096, k = 2048 -- the unit
+// of the headline step's direct lane (blockIdx.y = matrix through the blocked reduction): every column has a SYMV launch
+//   rocprofv3 --pmc FETCH_SIZE --kernel-include-regex sytrd_symv --kernel-trace --output-format csv -d out -- tools/pmc_driver batched 2
+static int run_batched(int count) {
+  const int64_t n = 4096, k = 2048;
+  std::vector<double> h((size_t)n * n);
+  unsigned long long s = 0x9E3779B97F4A7C15ull;
+  auto rnd = [&]() {
+    s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+    return (double)(s >> 11) * (2.0 / 9007199254740992.0) - 1.0;
+  };
+  std::vector<const double*> As(count);
+  std::vector<double*> evals(count), evecs(count);
+  for (int b = 0; b < count; ++b) {
+    for (int64_t i = 0; i < n; ++i)
+      for (int64_t j = 0; j <= i; ++j) {
+        const double v = rnd() + (i == j ? (double)n * 0.01 * (1.0 + (double)i / (double)n) : 0.0);
+        h[i * n + j] = v;
+        h[j * n + i] = v;
+      }
+    double *A, *w, *v;
+    if (hipMalloc(&A, h.size() * 8) || hipMalloc(&w, n * 8) || hipMalloc(&v, n * k * 8)) return 2;
+    (void)hipMemcpy(A, h.data(), h.size() * 8, hipMemcpyHostToDevice);
+    As[b] = A; evals[b] = w; evecs[b] = v;
+  }
+  void* ws;
+  const size_t wsb = ptd_eigh_batched_workspace_bytes(n, k, count);
+  if (hipMalloc(&ws, wsb)) return 2;
+  const int rc = ptd_eigh_topk_batched(As.data(), n, count, n, k, 0, evals.data(), evecs.data(), k, ws, wsb, nullptr, nullptr);
+  if (rc) { fprintf(stderr, "batched mode rc=%d: %s\n", rc, ptd_last_error()); return 1; }
+  (void)hipDeviceSynchronize();
+  printf("batched mode done (%d matrices)\n", count);
+  return 0;
+}
+
 int main(int argc, char** argv) {
+  if (argc > 1 && !strcmp(argv[1], "batched")) return run_batched(argc > 2 ? atoi(argv[2]) : 2);
   if (argc > 1 && !strcmp(argv[1], "mfma")) return run_mfma();
   if (argc > 1 && !strcmp(argv[1], "eigh")) return run_eigh();
   if (argc > 1 && !strcmp(argv[1], "syrk")) return run_syrk();

@@ -12,6 +12,7 @@ import csv, glob, json, os, sys
 
 rnd = sys.argv[1] if len(sys.argv) > 1 else "01"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+count = int(sys.argv[3]) if len(sys.argv) > 3 else 1      # matrices per launch (tools/pmc_driver batched <count>)
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -33,7 +34,7 @@ assert L == len(write) == len(hit) == len(miss) and L <= n - 1, (L, len(write), 
 rows = []
 for j in range(L):
     m = n - j - 1
-    alg = 8.0 * m * (m - 1)                      # rows j+1.., columns j+2.. of the trailing matrix, f64
+    alg = count * 8.0 * m * (m - 1)              # rows j+1.., columns j+2.. of the trailing matrix, f64, every matrix
     rd = 2.0 * fetch[j][1] * 1024.0              # gfx950 correction
     wr = write[j][1] * 1024.0
     rows.append((j, m, alg, rd, wr, hit[j][1], miss[j][1]))
@@ -47,8 +48,8 @@ tot_wr = sum(r[4] for r in rows)
 big = [r for r in rows if r[1] >= 2048]
 summary = {
     "kernel": "sytrd_symv2_kernel (trailing order >= 1024: lower triangle only) + sytrd_symv_kernel (smaller trailing orders)",
-    "n": n, "launches": L, "columns_without_a_launch": n - 1 - L,
-    "command": "rocprofv3 --pmc <COUNTER> --kernel-include-regex sytrd_symv --kernel-trace --output-format csv -- tools/pmc_driver %d (separate passes: FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum)" % n,
+    "n": n, "matrices_per_launch": count, "launches": L, "columns_without_a_launch": n - 1 - L,
+    "command": "rocprofv3 --pmc <COUNTER> --kernel-include-regex sytrd_symv --kernel-trace --output-format csv -- tools/pmc_driver %s (separate passes: FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum)" % (n if count == 1 else "batched %d" % count),
     "correction": "read bytes = 2 x FETCH_SIZE KiB x 1024 (gfx950 tallies 128-B requests at 64 B); WRITE_SIZE exact",
     "algorithmic_bytes_per_launch": tot_alg / L,
     "read_bytes_per_launch": tot_rd / L,
