@@ -75,6 +75,16 @@ int ptd_stream_pair_wall_us(void* stream_a, void* stream_b, int spin_us, double*
  * verified distinct early on, two of them serialised a minute later). */
 int ptd_streams_wall_us(void* const* streams, int count, int spin_us, double* wall_us);
 
+/* A HIP stream with a hardware queue OF ITS OWN (ABI 4): hipExtStreamCreateWithCUMask over CUs [cu_first, cu_first +
+ * cu_count) of the current device, cu_count = 0: every CU.  The runtime multiplexes ordinary streams onto four hardware
+ * queues per priority (see above) and which streams share one cannot be told without measuring; a stream created with a
+ * CU mask gets a queue that no other stream uses.  ptdeco_amd._engine runs the lanes of a precompute pass -- independent
+ * chains of dependent launches, dwain.py:580-633's eigendecompositions -- on such streams, so that their overlap does not
+ * depend on the creation order of every stream in the process.  *stream_out is a hipStream_t; the caller destroys it
+ * with ptd_stream_destroy (or hipStreamDestroy).  No reference counterpart. */
+int ptd_stream_create_dedicated(int cu_first, int cu_count, void** stream_out);
+int ptd_stream_destroy(void* stream);
+
 /* ---- covariance accumulation ------------------------------------------- */
 
 /* E[i][j] += scale * sum_t Y[t][i] * Y[t][j]  for i >= j  (LOWER triangle only;

@@ -1296,6 +1296,44 @@ def eigh_cost_hint(cov, n_out: int, top_k: Optional[int]) -> float:
     return cost
 
 
+_DEDICATED_STREAMS: dict = {}  # (device index, CU split) -> streams with hardware queues of their own
+
+
+def dedicated_streams(device: torch.device, want: int) -> list:
+    """`want` HIP streams of `device` that each own a hardware queue (ptd_stream_create_dedicated:
+    hipExtStreamCreateWithCUMask), created once per device and kept for the life of the process.  Round 5 took streams
+    from torch's pool and MEASURED which of them shared one of the runtime's four hardware queues (chain_streams below,
+    still there behind PTD_LANE_STREAMS=pool): two chains on one queue run packet by packet, and which streams share
+    depends on the creation order of every stream in the process.  A stream created with a CU mask is given a queue no
+    other stream uses: the lanes overlap by construction, nothing to probe, nothing that can change mid-process.
+    PTD_LANE_CUS = "a,b,c" gives lane i a contiguous range of that many CUs (experiments); default: every lane sees the
+    whole chip."""
+    import ctypes
+    import os
+    import threading
+
+    from . import _hip
+
+    global _CHAIN_STREAMS_LOCK
+    if _CHAIN_STREAMS_LOCK is None:
+        _CHAIN_STREAMS_LOCK = threading.Lock()
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    split = os.environ.get("PTD_LANE_CUS", "")
+    counts = [int(c) for c in split.split(",") if c.strip()] if split else []
+    with _CHAIN_STREAMS_LOCK:
+        have = _DEDICATED_STREAMS.setdefault((index, split), [])
+        lib = _hip.load()
+        with torch.cuda.device(index):
+            while len(have) < want:
+                i = len(have)
+                first = sum(counts[:i]) if i < len(counts) else 0
+                count = counts[i] if i < len(counts) else 0
+                ptr = ctypes.c_void_p(0)
+                _hip.check(lib.ptd_stream_create_dedicated(first, count, ctypes.byref(ptr)), "ptd_stream_create_dedicated")
+                have.append(torch.cuda.ExternalStream(ptr.value, device=torch.device("cuda", index)))
+        return list(have[:want])
+
+
 _CHAIN_STREAMS: dict = {}      # device index -> (streams on pairwise distinct hardware queues, candidates exhausted?)
 CHAIN_STREAM_STATS = {"calls": 0, "selections": 0, "rechecks_failed": 0}     # (bench.py reports them)
 _CHAIN_STREAMS_LOCK = None
@@ -1328,6 +1366,8 @@ def chain_streams(device: torch.device, want: int) -> list:
     index = device.index if device.index is not None else torch.cuda.current_device()
     device = torch.device("cuda", index)
     want = max(1, int(want))
+    if os.environ.get("PTD_LANE_STREAMS", "dedicated") != "pool":
+        return dedicated_streams(device, want)
     if os.environ.get("PTD_CHAIN_STREAMS_VERIFY", "1") == "0":
         return [torch.cuda.Stream(device=device) for _ in range(want)]
     with _CHAIN_STREAMS_LOCK:

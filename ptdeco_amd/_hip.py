@@ -23,6 +23,8 @@ SIGNATURES = {
     "ptd_set_concurrent_chains": (c_int, [c_int]),
     "ptd_stream_pair_wall_us": (c_int, [c_void_p, c_void_p, c_int, ctypes.POINTER(c_double)]),
     "ptd_streams_wall_us": (c_int, [c_void_p, c_int, c_int, ctypes.POINTER(c_double)]),
+    "ptd_stream_create_dedicated": (c_int, [c_int, c_int, ctypes.POINTER(c_void_p)]),
+    "ptd_stream_destroy": (c_int, [c_void_p]),
     "ptd_syrk_accumulate": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p, c_int64, c_int,
                                     c_double, c_void_p]),
     "ptd_syrk_accumulate_multi": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int64, c_int, c_void_p, c_int64, c_int,

@@ -51,6 +51,26 @@ int ptd_streams_wall_us(void* const* streams, int count, int spin_us, double* wa
   return PTD_OK;
 }
 
+int ptd_stream_create_dedicated(int cu_first, int cu_count, void** stream_out) {
+  PTD_REQUIRE(stream_out && cu_first >= 0 && cu_count >= 0, "ptd_stream_create_dedicated: bad argument");
+  int dev = 0, cus = 0;
+  PTD_CHECK_HIP(hipGetDevice(&dev));
+  PTD_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  if (cu_count == 0) { cu_first = 0; cu_count = cus; }
+  PTD_REQUIRE(cu_first + cu_count <= cus, "ptd_stream_create_dedicated: CUs [%d, %d) of %d", cu_first, cu_first + cu_count, cus);
+  uint32_t mask[32] = {0};
+  for (int c = cu_first; c < cu_first + cu_count && c < 1024; ++c) mask[c >> 5] |= 1u << (c & 31);
+  hipStream_t st = nullptr;
+  PTD_CHECK_HIP(hipExtStreamCreateWithCUMask(&st, (uint32_t)((cus + 31) / 32), mask));
+  *stream_out = st;
+  return PTD_OK;
+}
+
+int ptd_stream_destroy(void* stream) {
+  PTD_CHECK_HIP(hipStreamDestroy(static_cast<hipStream_t>(stream)));
+  return PTD_OK;
+}
+
 int ptd_stream_pair_wall_us(void* stream_a, void* stream_b, int spin_us, double* wall_us) {
   void* pair[2] = {stream_a, stream_b};
   return ptd_streams_wall_us(pair, 2, spin_us, wall_us);

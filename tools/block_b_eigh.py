@@ -43,5 +43,10 @@ for cfg in configs:
     # LxC: PTD_EIGH_LANES x PTD_EIGH_BATCH_MAX of the batched engine; threads: round 5's one thread and stream per chain
     os.environ["PTD_EIGH_BATCHED"] = "0" if cfg == "threads" else "1"
     if cfg != "threads":
-        os.environ["PTD_EIGH_LANES"], os.environ["PTD_EIGH_BATCH_MAX"] = cfg.split("x")
+        # LxC[:pool | :a,b,c]  -- lanes x batch cap, then the lane streams: torch pool streams (probed), or dedicated streams
+        # with that many CUs each
+        lc, _, extra = cfg.partition(":")
+        os.environ["PTD_EIGH_LANES"], os.environ["PTD_EIGH_BATCH_MAX"] = lc.split("x")
+        os.environ["PTD_LANE_STREAMS"] = "pool" if extra == "pool" else "dedicated"
+        os.environ["PTD_LANE_CUS"] = extra.replace("-", ",") if extra not in ("", "pool") else ""
     print(json.dumps({"config": cfg, "step_ms, B_eigh_ms": [step() for _ in range(passes)]}), flush=True)

@@ -12,3 +12,5 @@ print("total kernel time %.3f ms" % (tot / 1e6))
 for r in rows[:28]:
     print("%-70s %6s calls %9.1f us total %8.2f us avg %5.1f %%" % (r["Name"][:70].replace("ptd::(anonymous namespace)::","").replace("ptd::",""), r["Calls"], float(r["TotalDurationNs"]) / 1e3, float(r["AverageNs"]) / 1e3, 100 * float(r["TotalDurationNs"]) / tot))
 PY
+# (the raw trace is hundreds of MB: gpurun copies back at most 64 MiB)
+rm -f gpurun_out/prof_$tag/*/*kernel_trace.csv
