@@ -91,7 +91,7 @@ constexpr int SROWS = 4;  // rows per workgroup; its four waves split the column
 
 // symv: rows 0 .. m-1 are matrix rows j+1 .. n-1, rows m .. m+i-1 are W_k (k = i-1: w_raw of the
 // previous column), rows m+i .. m+2i-1 are V_k.
-__device__ __forceinline__ void sytrd_symv_body(const double* __restrict__ A, int64_t ld, int n, int j,
+__global__ __launch_bounds__(256) void sytrd_symv_kernel(const double* __restrict__ A, int64_t ld, int n, int j,
                                                          int i, const double* __restrict__ colbuf,
                                                          const double* __restrict__ Vp,
                                                          const double* __restrict__ Wp, int64_t ldv,
@@ -100,9 +100,10 @@ __device__ __forceinline__ void sytrd_symv_body(const double* __restrict__ A, in
                                                          const double* __restrict__ taus,
                                                          double* __restrict__ sd, double* __restrict__ qv,
                                                          double* __restrict__ cb, double* __restrict__ px2,
-                                                         ColState* __restrict__ cs, const int bx_, const size_t boff_) {
+                                                         ColState* __restrict__ cs, size_t bstride) {
   __shared__ double part[4][SROWS];
   __shared__ double delta_s;
+  const size_t boff_ = (size_t)blockIdx.y * bstride;
   PTD_BATCH(A); PTD_BATCH(colbuf); PTD_BATCH(Vp); PTD_BATCH(Wp); PTD_BATCH(wraw_prev); PTD_BATCH(partial2);
   PTD_BATCH(taus); PTD_BATCH(sd); PTD_BATCH(qv); PTD_BATCH(cb); PTD_BATCH(px2); PTD_BATCH(cs);
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -119,7 +120,7 @@ __device__ __forceinline__ void sytrd_symv_body(const double* __restrict__ A, in
   const double* vprev = Vp + (int64_t)max(i - 1, 0) * ldv;  // multiplied by delta == 0 when i == 0
   const int m = n - j - 1;
   const int total = m + 2 * i;
-  const int g0 = bx_ * SROWS;
+  const int g0 = blockIdx.x * SROWS;
   const double* rp[SROWS];
   double acc[SROWS];
 #pragma unroll
@@ -195,27 +196,13 @@ __device__ __forceinline__ void sytrd_symv_body(const double* __restrict__ A, in
     }
     x2 = wave_sum_d(x2);
     if (lane == 0) {
-      px2[bx_] = x2;
-      if (bx_ == 0) {
+      px2[blockIdx.x] = x2;
+      if (blockIdx.x == 0) {
         cs->delta = delta;
         cs->alpha = colbuf[j + 1] - delta * vprev[j + 1];
       }
     }
   }
-}
-
-__global__ __launch_bounds__(256) void sytrd_symv_kernel(const double* __restrict__ A, int64_t ld, int n, int j,
-                                                         int i, const double* __restrict__ colbuf,
-                                                         const double* __restrict__ Vp,
-                                                         const double* __restrict__ Wp, int64_t ldv,
-                                                         const double* __restrict__ wraw_prev,
-                                                         const double* __restrict__ partial2, int nparts2,
-                                                         const double* __restrict__ taus,
-                                                         double* __restrict__ sd, double* __restrict__ qv,
-                                                         double* __restrict__ cb, double* __restrict__ px2,
-                                                         ColState* __restrict__ cs, size_t bstride) {
-  sytrd_symv_body(A, ld, n, j, i, colbuf, Vp, Wp, ldv, wraw_prev, partial2, nparts2, taus, sd, qv, cb, px2, cs,
-                  (int)blockIdx.x, (size_t)blockIdx.y * bstride);
 }
 
 // ---- symmetric SYMV: only the lower triangle of the trailing matrix is read.
@@ -306,7 +293,7 @@ extern "C" void ptd_debug_symv(int v) { (void)hipMemcpyToSymbol(HIP_SYMBOL(symv_
 #else
 #define SYMV_DBG(BIT) false
 #endif
-__device__ __forceinline__ void sytrd_symv2_body(const double* __restrict__ A, int64_t ld, int n, int j, int i,
+__global__ __launch_bounds__(256) void sytrd_symv2_kernel(const double* __restrict__ A, int64_t ld, int n, int j, int i,
                                                           const double* __restrict__ colbuf,
                                                           const double* __restrict__ Vp,
                                                           const double* __restrict__ Wp, int64_t ldv,
@@ -315,7 +302,8 @@ __device__ __forceinline__ void sytrd_symv2_body(const double* __restrict__ A, i
                                                           const double* __restrict__ taus, SymPart sp, int ntiles,
                                                           int nextra, double* __restrict__ qv,
                                                           double* __restrict__ cb, double* __restrict__ px2,
-                                                          ColState* __restrict__ cs, const int bx_, const size_t boff_) {
+                                                          ColState* __restrict__ cs, size_t bstride) {
+  const size_t boff_ = (size_t)blockIdx.y * bstride;
   PTD_BATCH(A); PTD_BATCH(colbuf); PTD_BATCH(Vp); PTD_BATCH(Wp); PTD_BATCH(wraw_prev); PTD_BATCH(partial2);
   PTD_BATCH(taus); PTD_BATCH(sp.rowpart); PTD_BATCH(sp.colpart); PTD_BATCH(qv); PTD_BATCH(cb); PTD_BATCH(px2);
   PTD_BATCH(cs);
@@ -323,7 +311,7 @@ __device__ __forceinline__ void sytrd_symv2_body(const double* __restrict__ A, i
   __shared__ __attribute__((aligned(16))) double colred[4][TC];
   __shared__ double part[4][SROWS];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int b = bx_;
+  const int b = blockIdx.x;
   const double* vprev = Vp + (int64_t)max(i - 1, 0) * ldv;  // multiplied by delta == 0 when i == 0
   if (SYMV_DBG(1)) return;
   if (b < ntiles) {
@@ -455,23 +443,9 @@ __device__ __forceinline__ void sytrd_symv2_body(const double* __restrict__ A, i
   }
 }
 
-__global__ __launch_bounds__(256) void sytrd_symv2_kernel(const double* __restrict__ A, int64_t ld, int n, int j, int i,
-                                                          const double* __restrict__ colbuf,
-                                                          const double* __restrict__ Vp,
-                                                          const double* __restrict__ Wp, int64_t ldv,
-                                                          const double* __restrict__ wraw_prev,
-                                                          const double* __restrict__ partial2, int nparts2,
-                                                          const double* __restrict__ taus, SymPart sp, int ntiles,
-                                                          int nextra, double* __restrict__ qv,
-                                                          double* __restrict__ cb, double* __restrict__ px2,
-                                                          ColState* __restrict__ cs, size_t bstride) {
-  sytrd_symv2_body(A, ld, n, j, i, colbuf, Vp, Wp, ldv, wraw_prev, partial2, nparts2, taus, sp, ntiles, nextra, qv, cb,
-                   px2, cs, (int)blockIdx.x, (size_t)blockIdx.y * bstride);
-}
-
 // alpha(jn): finishes column j = jn - 1 (panel index i = in - 1 >= 0) and, if do_next, forms the
 // updated column jn.  Grid ceil((n - jn) / 64) x 256 threads; lane = row, the four waves split k.
-__device__ __forceinline__ void sytrd_alpha_body(const double* __restrict__ A, int64_t ld, int n, int jn,
+__global__ __launch_bounds__(256) void sytrd_alpha_kernel(const double* __restrict__ A, int64_t ld, int n, int jn,
                                                           int in, int do_next, double* __restrict__ Vp,
                                                           double* __restrict__ Wp, int64_t ldv,
                                                           const double* __restrict__ wraw_prev,
@@ -483,7 +457,8 @@ __device__ __forceinline__ void sytrd_alpha_body(const double* __restrict__ A, i
                                                           const ColState* __restrict__ cs,
                                                           double* __restrict__ partial2, double* __restrict__ d,
                                                           double* __restrict__ e, double* __restrict__ taus,
-                                                          SymPart sp, const int bx_, const size_t boff_) {
+                                                          SymPart sp, size_t bstride) {
+  const size_t boff_ = (size_t)blockIdx.y * bstride;
   PTD_BATCH(A); PTD_BATCH(Vp); PTD_BATCH(Wp); PTD_BATCH(wraw_prev); PTD_BATCH(wraw_cur); PTD_BATCH(colbuf);
   PTD_BATCH(sd); PTD_BATCH(qv); PTD_BATCH(cb); PTD_BATCH(px2); PTD_BATCH(cs); PTD_BATCH(partial2); PTD_BATCH(d);
   PTD_BATCH(e); PTD_BATCH(taus); PTD_BATCH(sp.rowpart); PTD_BATCH(sp.colpart);
@@ -495,7 +470,7 @@ __device__ __forceinline__ void sytrd_alpha_body(const double* __restrict__ A, i
   __shared__ double wrj_s;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int j = jn - 1, i = in - 1;
-  const int r = jn + bx_ * 64 + lane;
+  const int r = jn + blockIdx.x * 64 + lane;
   // ---- phase 0: every global operand of the prologue is requested up front (one latency)
   double px = 0.0;
   for (int q = tid; q < npx2; q += 256) px += px2[q];
@@ -579,7 +554,7 @@ __device__ __forceinline__ void sytrd_alpha_body(const double* __restrict__ A, i
     scale = 1.0 / (alpha - beta);
   }
   const double a2prev = 0.5 * delta;
-  if (bx_ == 0 && tid == 0) {
+  if (blockIdx.x == 0 && tid == 0) {
     taus[j] = tau;
     e[j] = beta;
     d[j] = colbuf[j] - delta;  // x_j[j] = base_j[j] - delta v_{j-1}[j], v_{j-1}[j] = 1 (delta = 0 if i == 0)
@@ -653,66 +628,8 @@ __device__ __forceinline__ void sytrd_alpha_body(const double* __restrict__ A, i
       }
     }
     dot = wave_sum_d(dot);
-    if (lane == 0) partial2[bx_] = dot;
+    if (lane == 0) partial2[blockIdx.x] = dot;
   }
-}
-
-__global__ __launch_bounds__(256) void sytrd_alpha_kernel(const double* __restrict__ A, int64_t ld, int n, int jn,
-                                                          int in, int do_next, double* __restrict__ Vp,
-                                                          double* __restrict__ Wp, int64_t ldv,
-                                                          const double* __restrict__ wraw_prev,
-                                                          double* __restrict__ wraw_cur,
-                                                          double* __restrict__ colbuf, const double* __restrict__ sd,
-                                                          const double* __restrict__ qv,
-                                                          const double* __restrict__ cb,
-                                                          const double* __restrict__ px2, int npx2,
-                                                          const ColState* __restrict__ cs,
-                                                          double* __restrict__ partial2, double* __restrict__ d,
-                                                          double* __restrict__ e, double* __restrict__ taus,
-                                                          SymPart sp, size_t bstride) {
-  sytrd_alpha_body(A, ld, n, jn, in, do_next, Vp, Wp, ldv, wraw_prev, wraw_cur, colbuf, sd, qv, cb, px2, npx2, cs,
-                   partial2, d, e, taus, sp, (int)blockIdx.x, (size_t)blockIdx.y * bstride);
-}
-
-// ---- two column steps of DIFFERENT matrices in one launch (the staggered batch, eigh_tridiag_batched)
-// A matrix's reduction is a strict chain alpha(j) -> symv(j) -> alpha(j + 1) -> ...: alpha is bound by latency (two
-// dependent rounds of loads and three barriers: ~6 us alone, ~10 us beside other work), the SYMV by the stream of the
-// trailing triangle.  In a batch the matrices of the second half run ONE LAUNCH BEHIND those of the first half, so that
-// every launch carries the alpha step of one half and the SYMV of the other: the latency of alpha hides under the
-// stream of the SYMV instead of standing between two SYMVs.  The alpha workgroups come first in the grid (dispatched
-// first).  Each role's arguments are the ones its own kernel takes; `mat0` is the first matrix of the role's half.
-struct AlphaArgs {
-  const double* A; int64_t ld; int n, jn, in, do_next; double* Vp; double* Wp; int64_t ldv; const double* wraw_prev;
-  double* wraw_cur; double* colbuf; const double* sd; const double* qv; const double* cb; const double* px2; int npx2;
-  const ColState* cs; double* partial2; double* d; double* e; double* taus; SymPart sp;
-  int blocks, mats, mat0;
-};
-struct SymvArgs {
-  int kind;      // 2: symmetric tiles (sytrd_symv2), 3: full rows (sytrd_symv)
-  const double* A; int64_t ld; int n, j, i; const double* colbuf; const double* Vp; const double* Wp; int64_t ldv;
-  const double* wraw_prev; const double* partial2; int nparts2; const double* taus; SymPart sp; int ntiles, nextra;
-  double* sd; double* qv; double* cb; double* px2; ColState* cs;
-  int blocks, mats, mat0;
-};
-
-__global__ __launch_bounds__(256) void sytrd_fused_kernel(const AlphaArgs a, const SymvArgs s, const size_t bstride) {
-  int b = blockIdx.x;
-  const int nalpha = a.blocks * a.mats;
-  if (b < nalpha) {
-    const int mat = a.mat0 + b / a.blocks;
-    sytrd_alpha_body(a.A, a.ld, a.n, a.jn, a.in, a.do_next, a.Vp, a.Wp, a.ldv, a.wraw_prev, a.wraw_cur, a.colbuf, a.sd,
-                     a.qv, a.cb, a.px2, a.npx2, a.cs, a.partial2, a.d, a.e, a.taus, a.sp, b % a.blocks,
-                     (size_t)mat * bstride);
-    return;
-  }
-  b -= nalpha;
-  const int mat = s.mat0 + b / s.blocks;
-  if (s.kind == 2)
-    sytrd_symv2_body(s.A, s.ld, s.n, s.j, s.i, s.colbuf, s.Vp, s.Wp, s.ldv, s.wraw_prev, s.partial2, s.nparts2, s.taus,
-                     s.sp, s.ntiles, s.nextra, s.qv, s.cb, s.px2, s.cs, b % s.blocks, (size_t)mat * bstride);
-  else
-    sytrd_symv_body(s.A, s.ld, s.n, s.j, s.i, s.colbuf, s.Vp, s.Wp, s.ldv, s.wraw_prev, s.partial2, s.nparts2, s.taus,
-                    s.sd, s.qv, s.cb, s.px2, s.cs, b % s.blocks, (size_t)mat * bstride);
 }
 
 // end of panel: w_last = w_raw + alpha2 v_last on the rows the rank-2k update reads
@@ -3159,202 +3076,6 @@ int sytrd_f64(const TridiagPlan& p, char* base, SymvTimer* timer, bool resident,
   return PTD_OK;
 }
 
-// ---- the staggered batch: `count` >= 2 matrices, the second half one launch behind the first (sytrd_fused_kernel)
-// The launches of one matrix's reduction depend on its order alone, so the list of them is built once (exactly the
-// launches sytrd_f64 issues on the blocked path) and played twice: step t of the list for matrices [0, c0), step t - 1
-// for matrices [c0, count).  Where one half is at an alpha step and the other at a SYMV, the two go out as ONE launch.
-namespace {
-enum SytrdOpKind { OP_COLINIT, OP_ALPHA, OP_SYMV2, OP_SYMV, OP_LAST, OP_WFIX, OP_GEMM };
-struct SytrdOp {
-  int kind, pn, j, i, do_next, blocks, nparts2, npx2, ntiles, nextra, sym, wa, wb, cols, t0, mt;
-};
-}  // namespace
-
-int sytrd_f64_staggered(const TridiagPlan& p, char* base, SymvTimer* timer, hipStream_t st, int count, size_t bstride) {
-  const int n = p.n;
-  const int64_t ld = p.ld;
-  const char* symv_env = getenv("PTD_SYMV");
-  const char* symv_min_env = getenv("PTD_SYMV_MIN");
-  const int sym_min = (symv_env && !strcmp(symv_env, "full")) ? INT32_MAX
-                      : std::max(512, symv_min_env ? atoi(symv_min_env) : 1024);
-  // ---- the launch list of ONE matrix (see sytrd_f64: same kernels, same arguments, same order)
-  std::vector<SytrdOp> ops;
-  ops.reserve((size_t)2 * n + 4 * p.npanels + 8);
-  {
-    bool prev_sym = false, colbuf_ready = false;
-    for (int pn = 0; pn < p.npanels; ++pn) {
-      const int j0 = pn * NB, cols = std::min(NB, n - j0);
-      int nparts2 = 0, npx2 = 0;
-      bool open = false;
-      for (int i = 0; i < cols; ++i) {
-        const int j = j0 + i;
-        if (i == 0) {
-          if (!colbuf_ready) ops.push_back(SytrdOp{OP_COLINIT, pn, j, i, 0, (int)ceil_div(n - j, 256)});
-          colbuf_ready = false;
-        } else {
-          const int blocks = (int)ceil_div(n - j, 64);
-          ops.push_back(SytrdOp{OP_ALPHA, pn, j, i, 1, blocks, nparts2, npx2, 0, 0, prev_sym ? 1 : 0, i & 1, (i - 1) & 1});
-          nparts2 = blocks;
-        }
-        const int m = n - j - 1;
-        if (m >= sym_min && n >= 512) {
-          const int U = (int)ceil_div(n, TC) - (j + 1) / TC;
-          const int ntiles = TQ / 2 * U * (U + 1), nextra = (int)ceil_div(2 * i, SROWS);
-          npx2 = (int)ceil_div(m, 256);
-          ops.push_back(SytrdOp{OP_SYMV2, pn, j, i, 0, ntiles + nextra + npx2, nparts2, npx2, ntiles, nextra, 1, (i + 1) & 1});
-          prev_sym = true;
-          open = true;
-        } else if (m > 0) {
-          prev_sym = false;
-          npx2 = (int)ceil_div(m + 2 * i, SROWS);
-          ops.push_back(SytrdOp{OP_SYMV, pn, j, i, 0, npx2, nparts2, npx2, 0, 0, 0, (i + 1) & 1});
-          open = true;
-        } else {
-          ops.push_back(SytrdOp{OP_LAST, pn, j, i, 0, 1, nparts2});
-          open = false;
-        }
-      }
-      const int t0 = j0 + cols;
-      if (open) {
-        const int blocks = std::max((int)ceil_div(n - t0, 64), 1);
-        ops.push_back(SytrdOp{OP_ALPHA, pn, t0, cols, 0, blocks, nparts2, npx2, 0, 0, prev_sym ? 1 : 0, cols & 1, (cols - 1) & 1});
-        const int mt = n - t0;
-        if (mt > 0) {
-          ops.push_back(SytrdOp{OP_WFIX, pn, t0 - 1, cols - 1, 0, (int)ceil_div(mt, 256), blocks, 0, 0, 0, 0, (cols - 1) & 1, 0, cols, t0, mt});
-          ops.push_back(SytrdOp{OP_GEMM, pn, t0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, cols, t0, mt});
-          colbuf_ready = true;
-        }
-      }
-    }
-  }
-  // ---- pointers of matrix 0 (matrix b: + b * bstride, inside the kernels)
-  double* Aw = reinterpret_cast<double*>(base + p.off_A);
-  double* Vall = reinterpret_cast<double*>(base + p.off_V);
-  double* Wp = reinterpret_cast<double*>(base + p.off_W);
-  double* colbuf = reinterpret_cast<double*>(base + p.off_col);
-  double* sd = reinterpret_cast<double*>(base + p.off_p);
-  double* d = reinterpret_cast<double*>(base + p.off_d);
-  double* e = reinterpret_cast<double*>(base + p.off_e);
-  double* taus = reinterpret_cast<double*>(base + p.off_tau);
-  double* wr[2] = {reinterpret_cast<double*>(base + p.off_wraw), reinterpret_cast<double*>(base + p.off_wraw2)};
-  double* partial2 = reinterpret_cast<double*>(base + p.off_part2);
-  double* cbuf = reinterpret_cast<double*>(base + p.off_cbuf);
-  double* qv = reinterpret_cast<double*>(base + p.off_qv);
-  double* px2 = reinterpret_cast<double*>(base + p.off_px2);
-  ColState* cs = reinterpret_cast<ColState*>(base + p.off_refl);
-  const SymPart sp{reinterpret_cast<double*>(base + p.off_rowpart), reinterpret_cast<double*>(base + p.off_colpart), p.ldp,
-                   (int)ceil_div(n, TR), 0};
-  for (int b = 0; b < count; ++b) {
-    const size_t bo = (size_t)b * bstride;
-    PTD_CHECK_HIP(hipMemsetAsync(batch_host(Vall, bo), 0, (size_t)p.npanels * NB * ld * 8, st));
-    PTD_CHECK_HIP(hipMemsetAsync(batch_host(taus, bo), 0, (size_t)n * 8, st));
-    PTD_CHECK_HIP(hipMemsetAsync(batch_host(e, bo), 0, (size_t)n * 8, st));
-    PTD_CHECK_HIP(hipMemsetAsync(batch_host(colbuf, bo), 0, (size_t)(p.ldp + 8) * 8, st));
-    PTD_CHECK_HIP(hipMemsetAsync(batch_host(Wp, bo), 0, (size_t)NB * ld * 8, st));
-    PTD_CHECK_HIP(hipMemsetAsync(batch_host(wr[0], bo), 0, (size_t)(n + 8) * 8, st));
-    PTD_CHECK_HIP(hipMemsetAsync(batch_host(wr[1], bo), 0, (size_t)(n + 8) * 8, st));
-    PTD_CHECK_HIP(hipMemsetAsync(batch_host(reinterpret_cast<ResCtl*>(base + p.off_res), bo), 0, sizeof(ResCtl), st));
-  }
-  if (timer) timer->limit = n;
-  auto alpha_args = [&](const SytrdOp& o, int mat0, int mats) {
-    SymPart spa = sp;
-    spa.enabled = o.sym;
-    double* Vp = Vall + (size_t)o.pn * NB * ld;
-    return AlphaArgs{Aw, ld, n, o.j, o.i, o.do_next, Vp, Wp, ld, wr[o.wa], wr[o.wb], colbuf, sd, qv, cbuf, px2, o.npx2, cs,
-                     partial2, d, e, taus, spa, o.blocks, mats, mat0};
-  };
-  auto symv_args = [&](const SytrdOp& o, int mat0, int mats) {
-    const double* Vp = Vall + (size_t)o.pn * NB * ld;
-    return SymvArgs{o.kind == OP_SYMV2 ? 2 : 3, Aw, ld, n, o.j, o.i, colbuf, Vp, Wp, ld, wr[o.wa], partial2, o.nparts2, taus,
-                    sp, o.ntiles, o.nextra, sd, qv, cbuf, px2, cs, o.blocks, mats, mat0};
-  };
-  // one op alone, for matrices [mat0, mat0 + mats): the ordinary kernels with the workspace pointers moved to mat0
-  auto launch_alone = [&](const SytrdOp& o, int mat0, int mats, hipEvent_t ev0, hipEvent_t ev1) -> int {
-    const size_t bo = (size_t)mat0 * bstride;
-    const unsigned nb = (unsigned)mats;
-    double* Vp = batch_host(Vall + (size_t)o.pn * NB * ld, bo);
-    SymPart spm = sp;
-    spm.rowpart = batch_host(sp.rowpart, bo);
-    spm.colpart = batch_host(sp.colpart, bo);
-    switch (o.kind) {
-      case OP_COLINIT:
-        hipLaunchKernelGGL(sytrd_colinit_kernel, dim3((unsigned)o.blocks, nb), dim3(256), 0, st, batch_host(Aw, bo), ld, n,
-                           o.j, batch_host(colbuf, bo), bstride);
-        break;
-      case OP_ALPHA: {
-        SymPart spa = spm;
-        spa.enabled = o.sym;
-        hipLaunchKernelGGL(sytrd_alpha_kernel, dim3((unsigned)o.blocks, nb), dim3(256), 0, st, batch_host(Aw, bo), ld, n,
-                           o.j, o.i, o.do_next, Vp, batch_host(Wp, bo), ld, batch_host(wr[o.wa], bo),
-                           batch_host(wr[o.wb], bo), batch_host(colbuf, bo), batch_host(sd, bo), batch_host(qv, bo),
-                           batch_host(cbuf, bo), batch_host(px2, bo), o.npx2, batch_host(cs, bo),
-                           batch_host(partial2, bo), batch_host(d, bo), batch_host(e, bo), batch_host(taus, bo), spa,
-                           bstride);
-        break;
-      }
-      case OP_SYMV2:
-        hipExtLaunchKernelGGL(sytrd_symv2_kernel, dim3((unsigned)o.blocks, nb), dim3(256), 0, st, ev0, ev1, 0,
-                              batch_host(Aw, bo), ld, n, o.j, o.i, batch_host(colbuf, bo), Vp, batch_host(Wp, bo), ld,
-                              batch_host(wr[o.wa], bo), batch_host(partial2, bo), o.nparts2, batch_host(taus, bo), spm,
-                              o.ntiles, o.nextra, batch_host(qv, bo), batch_host(cbuf, bo), batch_host(px2, bo),
-                              batch_host(cs, bo), bstride);
-        break;
-      case OP_SYMV:
-        hipExtLaunchKernelGGL(sytrd_symv_kernel, dim3((unsigned)o.blocks, nb), dim3(256), 0, st, ev0, ev1, 0,
-                              batch_host(Aw, bo), ld, n, o.j, o.i, batch_host(colbuf, bo), Vp, batch_host(Wp, bo), ld,
-                              batch_host(wr[o.wa], bo), batch_host(partial2, bo), o.nparts2, batch_host(taus, bo),
-                              batch_host(sd, bo), batch_host(qv, bo), batch_host(cbuf, bo), batch_host(px2, bo),
-                              batch_host(cs, bo), bstride);
-        break;
-      case OP_LAST:
-        hipLaunchKernelGGL(sytrd_last_kernel, dim3(1, nb), dim3(64), 0, st, n, o.i, batch_host(colbuf, bo),
-                           batch_host(partial2, bo), o.nparts2, batch_host(taus, bo), batch_host(d, bo), bstride);
-        break;
-      case OP_WFIX:
-        hipLaunchKernelGGL(sytrd_wfix_kernel, dim3((unsigned)o.blocks, nb), dim3(256), 0, st, n, o.t0, o.i, o.j, Vp,
-                           batch_host(Wp, bo), ld, batch_host(wr[o.wa], bo), batch_host(partial2, bo), o.nparts2,
-                           batch_host(taus, bo), bstride);
-        break;
-      case OP_GEMM: {
-        double* Wm = batch_host(Wp, bo);
-        double* At = batch_host(Aw, bo) + (int64_t)o.t0 * ld + o.t0;
-        const int rc = gemm_f64_pair(Vp + o.t0, Wm + o.t0, Wm + o.t0, Vp + o.t0, 1, ld, ld, 1, At, ld, o.mt, o.mt, o.cols, -1.0,
-                                     batch_host(colbuf, bo) + o.t0, st, mats, (int64_t)(bstride / 8));
-        if (rc != PTD_OK) return rc;
-        break;
-      }
-    }
-    return PTD_OK;
-  };
-  const int c0 = (count + 1) / 2, c1 = count - c0;      // the leading half, the half one launch behind
-  const size_t nops = ops.size();
-  for (size_t t = 0; t <= nops; ++t) {
-    const SytrdOp* a = t < nops ? &ops[t] : nullptr;                    // matrices [0, c0)
-    const SytrdOp* b = (t >= 1 && c1 > 0) ? &ops[t - 1] : nullptr;      // matrices [c0, count)
-    const bool timed = timer && a && (a->kind == OP_SYMV2 || a->kind == OP_SYMV) && timer->sampled(a->j);
-    hipEvent_t ev0 = timed ? timer->start(a->j) : nullptr, ev1 = timed ? timer->stop(a->j) : nullptr;
-    auto is_symv = [](const SytrdOp* o) { return o->kind == OP_SYMV2 || o->kind == OP_SYMV; };
-    if (a && b && ((a->kind == OP_ALPHA && is_symv(b)) || (b->kind == OP_ALPHA && is_symv(a)))) {
-      const bool a_alpha = a->kind == OP_ALPHA;
-      const AlphaArgs aa = a_alpha ? alpha_args(*a, 0, c0) : alpha_args(*b, c0, c1);
-      const SymvArgs ss = a_alpha ? symv_args(*b, c0, c1) : symv_args(*a, 0, c0);
-      const unsigned grid = (unsigned)(aa.blocks * aa.mats + ss.blocks * ss.mats);
-      hipExtLaunchKernelGGL(sytrd_fused_kernel, dim3(grid), dim3(256), 0, st, ev0, ev1, 0, aa, ss, bstride);
-      continue;
-    }
-    if (a) {
-      const int rc = launch_alone(*a, 0, c0, ev0, ev1);
-      if (rc != PTD_OK) return rc;
-    }
-    if (b) {
-      const int rc = launch_alone(*b, c0, c1, nullptr, nullptr);
-      if (rc != PTD_OK) return rc;
-    }
-  }
-  PTD_CHECK_LAUNCH("sytrd_f64_staggered");
-  return PTD_OK;
-}
-
 // eigenvalues first .. n-1 of T (ascending order) into lam[first ..]; lam[0 .. first) becomes NaN
 int tridiag_eigenvalues(const TridiagPlan& p, char* base, int first, hipStream_t st) {
   const int n = p.n;
@@ -3878,12 +3599,8 @@ int eigh_tridiag_batched(const double* const* As, int64_t lda, int count, int64_
   for (int b = 0; b < count; ++b)
     hipLaunchKernelGGL(copy_pad_kernel, dim3(2048), dim3(256), 0, st, As[b], lda, (int)n,
                        reinterpret_cast<double*>(base + b * bstride + p.off_A), p.ld);
-  // PTD_EIGH_STAGGER=0: every launch serves all matrices at the same column (lockstep, as built first this round)
-  static const bool lockstep = getenv("PTD_EIGH_STAGGER") && atoi(getenv("PTD_EIGH_STAGGER")) == 0;
-  int rc = lockstep ? sytrd_f64(p, base, stats ? &timer : nullptr, false, st, count, bstride)
-                    : sytrd_f64_staggered(p, base, stats ? &timer : nullptr, st, count, bstride);
+  int rc = sytrd_f64(p, base, stats ? &timer : nullptr, false, st, count, bstride);
   if (rc != PTD_OK) { cleanup(); return rc; }
-  const int per_symv = lockstep ? count : (count + 1) / 2;      // matrices a sampled SYMV launch serves
   if (stats) PTD_CHECK_HIP(hipEventRecord(e1, st));
   const int first = (int)std::max<int64_t>(0, n - k - 1);
   std::vector<double> gaps(2 * (size_t)count, 0.0);
@@ -3923,9 +3640,8 @@ int eigh_tridiag_batched(const double* const* As, int64_t lda, int count, int64_
       }
       stats->launches[0] += 1;
       const double m = (double)(n - j - 1);
-      stats->work[0] += (double)per_symv * 8.0 * m * (m - 1.0);
+      stats->work[0] += (double)count * 8.0 * m * (m - 1.0);
     }
-    stats->launches[2] = per_symv;
     stats->ms[0] = (float)timed_ms;
     stats->ms[1] = t_red - stats->ms[0];
     stats->launches[1] = 2 * (int)n;
