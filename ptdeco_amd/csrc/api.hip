@@ -351,10 +351,25 @@ int ptd_gemm(const void* A, int64_t sam, int64_t sak, const void* B, int64_t sbk
 
 static size_t elt_bytes(int dtype) { return dtype == PTD_F32 ? 4 : 2; }
 
+// bf16 ranks that are not a multiple of 128 (a dwain search ends at 32 .. 96 on wide layers: Llama gate / up): the first
+// product's output would have fewer than 128 columns -- a handful of 128-row tiles for the whole chip (x A^T at
+// T = 2048, r = 32: 98 us on 16 workgroups, the library 20) -- and K = r of the second product no whole 64-deep step.
+// The pair then runs on the rank padded with zeros: A's rows to a multiple of 128 (a copy in the workspace: the first
+// product takes the split-K path of a 128-column tile row and leaves h [T, r128] with exact zeros behind column r),
+// K of the second product to a multiple of 64 (B is read in place: its pieces behind column r are fetched from the
+// row's start, h is zero there).  The results are those of the unpadded products: the padding adds exact zeros.
+static int64_t lowrank_pad128(int64_t r, int dtype) {
+  static const bool off = getenv("PTD_LOWRANK_PAD") && atoi(getenv("PTD_LOWRANK_PAD")) == 0;
+  if (off || dtype != PTD_BF16 || r % 8 != 0 || r % 128 == 0 || r > 1024) return r;
+  return (int64_t)align_up((size_t)r, 128);
+}
+
 size_t ptd_lowrank_forward_workspace_bytes(int64_t T, int64_t n_i, int64_t r, int dtype) {
-  size_t b = align_up((size_t)T * (size_t)r * elt_bytes(dtype), 256);
+  const int64_t rp = lowrank_pad128(r, dtype);
+  size_t b = align_up((size_t)T * (size_t)rp * elt_bytes(dtype), 256);
+  if (rp != r) b += align_up((size_t)rp * (size_t)n_i * elt_bytes(dtype), 256);
   if (dtype == PTD_F32) b += gemm_f32_workspace_bytes(T, r, n_i);
-  else b += gemm_bf16_workspace_bytes(T, r, n_i);
+  else b += gemm_bf16_workspace_bytes(T, rp, n_i);
   return b;
 }
 
@@ -364,6 +379,29 @@ int ptd_lowrank_forward(const void* x, int64_t ldx, int64_t T, int64_t n_i, cons
   PTD_REQUIRE(x && A && B && y && ws, "ptd_lowrank_forward: null pointer");
   PTD_REQUIRE(ldx >= n_i && lda >= n_i && ldb >= r && ldy >= n_o, "ptd_lowrank_forward: bad leading dimension");
   PTD_REQUIRE(dtype == PTD_F32 || dtype == PTD_BF16, "ptd_lowrank_forward: dtype must be f32 or bf16");
+  const int64_t rp = lowrank_pad128(r, dtype);
+  if (rp != r && n_i % 8 == 0 && lda % 8 == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0 &&
+      ws_bytes >= ptd_lowrank_forward_workspace_bytes(T, n_i, r, dtype)) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    typedef unsigned short u16;
+    const size_t hp_bytes = align_up((size_t)T * (size_t)rp * 2, 256), ap_bytes = align_up((size_t)rp * (size_t)n_i * 2, 256);
+    u16* hp = static_cast<u16*>(ws);
+    u16* Ap = reinterpret_cast<u16*>(static_cast<char*>(ws) + hp_bytes);
+    char* rest = static_cast<char*>(ws) + hp_bytes + ap_bytes;
+    int rc = pad_rows_bf16(static_cast<const u16*>(A), lda, r, n_i, Ap, rp, st);
+    if (rc != PTD_OK) return rc;
+    rc = gemm_bf16(static_cast<const u16*>(x), ldx, 1, Ap, 1, n_i, hp, rp, T, rp, n_i, true, 1.0, nullptr, rest,
+                   ws_bytes - hp_bytes - ap_bytes, st);
+    if (rc != PTD_OK) return rc;
+    // y = h B^T + bias with K padded to whole 64-deep steps where a short-K kernel serves the shape, else with K = r
+    const int64_t k64 = (int64_t)align_up((size_t)r, 64);
+    if (k64 != r && k64 <= 256) {
+      rc = gemm_bf16(hp, rp, 1, static_cast<const u16*>(B), 1, ldb, y, ldy, T, n_o, k64, true, 1.0,
+                     static_cast<const u16*>(bias), nullptr, 0, st, r);
+      if (rc != PTD_ERR_UNSUPPORTED) return rc;
+    }
+    return ptd_gemm(hp, rp, 1, B, 1, ldb, y, ldy, T, n_o, r, dtype, dtype, 1.0, bias, stream);
+  }
   const size_t h_bytes = align_up((size_t)T * (size_t)r * elt_bytes(dtype), 256);
   if (ws_bytes < h_bytes) {
     set_error("ptd_lowrank_forward: workspace %zu < required %zu bytes", ws_bytes, h_bytes);

@@ -56,7 +56,15 @@ struct GemmBf16Args {
   int64_t cslab;  // split K of the LDS-DMA kernel: blockIdx.y writes its f32 partial tile to C + y * cslab
   int64_t zsa, zsb, zsc;  // batched products (generic kernel only): blockIdx.z advances A, B, C by these element strides
   int bias_rows;          // bias indexed by the output ROW (an NCHW 1x1 convolution's channel) instead of the column
+  int kvalid;             // short-K kernels: > 0 = B's rows hold only kvalid (< K) values -- the 16-byte pieces at k >= kvalid
+                          // are fetched from k = 0 instead (in bounds; A is zero there, so they add nothing): a rank that
+                          // is not a multiple of 64 runs on the 64-deep kernels (ptd_lowrank_forward)
 };
+
+// element offset of a 16-byte piece of B's K range (see GemmBf16Args::kvalid)
+__device__ __forceinline__ int b_koff(const GemmBf16Args& a, int koff) {
+  return (a.kvalid > 0 && koff >= a.kvalid) ? 0 : koff;
+}
 
 // f32 -> bf16, round to nearest even, NaN stays NaN: gfx950's v_cvt_pk_bf16_f32 (one VALU instruction
 // per pair).  The bit-twiddling form costs ~12 VALU per element -- on a short-K product that is more
@@ -1847,7 +1855,7 @@ __global__ __launch_bounds__(256, (shortk_lds_bytes(KC, NB, EPI) <= 80 * 1024 ? 
       const int sub = q / (TW / 8), r0 = (q % (TW / 8)) * 8;
       const int r = r0 + srow;
       const int c = spos ^ ((r >> 1) & 7);
-      const unsigned short* sb = a.B + (int64_t)(n0 + r) * a.sbn + sub * 64 + c * 8;
+      const unsigned short* sb = a.B + (int64_t)(n0 + r) * a.sbn + b_koff(a, sub * 64 + c * 8);
       __builtin_amdgcn_global_load_lds((glb_void*)sb, (lds_void*)(Bs + sub * SUB + r0 * 128), 16, 0, 0);
     }
   };
@@ -1955,7 +1963,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_shortk2_kernel(const GemmBf1
       const int sub = q >> 3, r0 = (q & 7) * 8;
       const int r = r0 + srow;
       const int c = spos ^ ((r >> 1) & 7);
-      const unsigned short* sb = a.B + (int64_t)(n0 + half * 64 + r) * a.sbn + sub * 64 + c * 8;
+      const unsigned short* sb = a.B + (int64_t)(n0 + half * 64 + r) * a.sbn + b_koff(a, sub * 64 + c * 8);
       __builtin_amdgcn_global_load_lds((glb_void*)sb, (lds_void*)(lds + sub * 8192 + r0 * 128), 16, 0, 0);
     }
     __syncthreads();
@@ -2111,7 +2119,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_shortk3_kernel(const GemmBf1
       const int sub = q >> 3, r0 = (q & 7) * 8;
       const int r = r0 + srow;
       const int c = spos ^ ((r >> 1) & 7);
-      const unsigned short* sb = a.B + (int64_t)(n0 + chunk * 64 + r) * a.sbn + sub * 64 + c * 8;
+      const unsigned short* sb = a.B + (int64_t)(n0 + chunk * 64 + r) * a.sbn + b_koff(a, sub * 64 + c * 8);
       __builtin_amdgcn_global_load_lds((glb_void*)sb, (lds_void*)(lds + chunk * BUF + sub * SUB + r0 * 128), 16, 0, 0);
     }
   }
@@ -2330,7 +2338,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_shortk4_kernel(const GemmBf1
       const int sub = q >> 3, r0 = (q & 7) * 8;
       const int r = r0 + srow;
       const int c = spos ^ ((r >> 1) & 7);
-      const unsigned short* sb = a.B + (int64_t)(n0 + chunk * 64 + r) * a.sbn + sub * 64 + c * 8;
+      const unsigned short* sb = a.B + (int64_t)(n0 + chunk * 64 + r) * a.sbn + b_koff(a, sub * 64 + c * 8);
       __builtin_amdgcn_global_load_lds((glb_void*)sb, (lds_void*)(lds + chunk * BUF + sub * SUB + r0 * 128), 16, 0, 0);
     }
   }
@@ -2571,9 +2579,12 @@ size_t gemm_bf16_workspace_bytes(int64_t M, int64_t N, int64_t K) {
   return ks > 1 ? (size_t)ks * (size_t)M * (size_t)N * sizeof(float) : 0;
 }
 
+// b_kvalid > 0: B's rows hold only b_kvalid < K values (K a multiple of 64 up to 256, A zero in the columns beyond
+// b_kvalid): served by the short-K kernels alone -- PTD_ERR_UNSUPPORTED where none of them applies (the caller then
+// multiplies with K = b_kvalid on the generic path)
 int gemm_bf16(const unsigned short* A, int64_t sam, int64_t sak, const unsigned short* B, int64_t sbk, int64_t sbn,
               void* C, int64_t ldc, int64_t M, int64_t N, int64_t K, bool c_bf16, double alpha,
-              const unsigned short* bias, void* ws, size_t ws_bytes, hipStream_t st) {
+              const unsigned short* bias, void* ws, size_t ws_bytes, hipStream_t st, int64_t b_kvalid) {
   PTD_REQUIRE((sam == 1) != (sak == 1) || (M == 1 || K == 1), "ptd_gemm: exactly one stride of A must be 1");
   PTD_REQUIRE((sbk == 1) != (sbn == 1) || (N == 1 || K == 1), "ptd_gemm: exactly one stride of B must be 1");
   if (M == 0 || N == 0) return PTD_OK;
@@ -2585,6 +2596,7 @@ int gemm_bf16(const unsigned short* A, int64_t sam, int64_t sak, const unsigned 
   a.alpha = (float)alpha; a.scale = 1.0; a.bias = bias;
   a.tiles_m = (int)ceil_div(M, BM);
   a.tri = 0; a.kchunk = (int)align_up((size_t)(K > 0 ? K : 1), BK); a.atomic = 0;
+  a.kvalid = (b_kvalid > 0 && b_kvalid < K) ? (int)b_kvalid : 0;
   const bool akc = (sak == 1), bkc = (sbk == 1);
   a.vecA = aligned16(A) && ((akc ? sam : sak) % 8 == 0);
   a.vecB = aligned16(B) && ((bkc ? sbn : sbk) % 8 == 0);
@@ -2593,7 +2605,11 @@ int gemm_bf16(const unsigned short* A, int64_t sam, int64_t sak, const unsigned 
   static const bool no_shortk = getenv("PTD_GEMM_NO_SHORTK") != nullptr;
   const bool c_vec = aligned16(C) && (ldc * (c_bf16 ? 2 : 4)) % 16 == 0;  // 16-byte row-contiguous output stores
   a.cslab = 0;
-  if (ws && !no_glds && akc && bkc && a.vecA && a.vecB && c_vec && ldc % 8 == 0) {
+  if (a.kvalid && (K % 64 != 0 || K > 256 || a.kvalid % 8 != 0)) {
+    set_error("gemm_bf16: a partial K range needs K a multiple of 64 up to 256 and 8 | kvalid");
+    return PTD_ERR_UNSUPPORTED;
+  }
+  if (!a.kvalid && ws && !no_glds && akc && bkc && a.vecA && a.vecB && c_vec && ldc % 8 == 0) {
     const int ks = gemm_bf16_ksplit(M, N, K);
     if (ks > 1 && (size_t)ks * (size_t)M * (size_t)N * sizeof(float) <= ws_bytes && aligned16(ws)) {
       // few output tiles: K range over blockIdx.y into f32 slabs, then the slabs are added in index order
@@ -2656,11 +2672,16 @@ int gemm_bf16(const unsigned short* A, int64_t sam, int64_t sak, const unsigned 
     PTD_CHECK_LAUNCH("gemm_bf16 (short K, B panel resident)");
     return PTD_OK;
   }
+  if (a.kvalid && !(!no_glds && !no_shortk && akc && bkc && a.vecA && a.vecB && M % 128 == 0 && N % 64 == 0 && N >= 256 &&
+                    M >= 1024 && aligned16(C) && (ldc * (c_bf16 ? 2 : 4)) % 16 == 0)) {
+    set_error("gemm_bf16: no short-K kernel for this shape with a partial K range");
+    return PTD_ERR_UNSUPPORTED;
+  }
   // (K of 384 / 512 on 256-aligned shapes: the 256^2 kernel below matches or beats the A-panel-resident short-K form)
   static const int mode_8ph = getenv("PTD_GEMM_8PH") ? atoi(getenv("PTD_GEMM_8PH")) : 2;  // 0 off, 1 lockstep, 2 staggered
   const char* mf_env = getenv("PTD_GEMM_8PH_MFMA");   // read per call: 32 keeps v_mfma_f32_32x32x16_bf16
   const bool mf16 = !(mf_env && atoi(mf_env) == 32);
-  if (!no_glds && mode_8ph && akc && bkc && a.vecA && a.vecB && c_vec && M % 256 == 0 && N % 256 == 0 && K % 128 == 0 &&
+  if (!a.kvalid && !no_glds && mode_8ph && akc && bkc && a.vecA && a.vecB && c_vec && M % 256 == 0 && N % 256 == 0 && K % 128 == 0 &&
       K >= 256 && (M / 256) * (N / 256) >= 192) {
     a.tiles_m = (int)(M / 256);
     dim3 g8((unsigned)((M / 256) * (N / 256)), 1);
@@ -2895,6 +2916,29 @@ int syrk_bf16_multi(const unsigned short* const* Ys, int steps, int64_t T, int64
 int syrk_bf16(const unsigned short* Y, int64_t T, int64_t n, int64_t ldy, void* E, int64_t ldE, bool e_f64,
               double scale, hipStream_t st) {
   return syrk_bf16_multi(&Y, 1, T, n, ldy, E, ldE, e_f64, scale, st);
+}
+
+namespace {
+__global__ void pad_rows_bf16_kernel(const unsigned short* __restrict__ src, int64_t ld, int rows, int cols8,
+                                     unsigned short* __restrict__ dst, int rows_out) {
+  const int64_t total = (int64_t)rows_out * cols8;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / cols8), c = (int)(i % cols8);
+    uint4 v = uint4{0u, 0u, 0u, 0u};
+    if (r < rows) v = *reinterpret_cast<const uint4*>(src + (int64_t)r * ld + 8 * c);
+    *reinterpret_cast<uint4*>(dst + ((int64_t)r * cols8 + c) * 8) = v;
+  }
+}
+}  // namespace
+
+int pad_rows_bf16(const unsigned short* src, int64_t ld, int64_t rows, int64_t cols, unsigned short* dst, int64_t rows_out,
+                  hipStream_t st) {
+  PTD_REQUIRE(cols % 8 == 0 && ld % 8 == 0 && aligned16(src) && aligned16(dst) && rows <= rows_out, "pad_rows_bf16: bad argument");
+  const int64_t total = rows_out * (cols / 8);
+  hipLaunchKernelGGL(pad_rows_bf16_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(total, 256), 2048)), dim3(256), 0, st, src,
+                     ld, (int)rows, (int)(cols / 8), dst, (int)rows_out);
+  PTD_CHECK_LAUNCH("pad_rows_bf16");
+  return PTD_OK;
 }
 
 }  // namespace ptd

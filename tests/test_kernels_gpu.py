@@ -1436,6 +1436,32 @@ def test_lowrank_forward_bf16_c5_shapes_exact(ops, r, T):
     assert torch.equal(ops.lowrank_forward(x, a, b, bias), want_b), r
 
 
+@pytest.mark.parametrize("T,n_i,n_o,r", [(2048, 4096, 14336, 32), (2048, 4096, 14336, 16), (2048, 4096, 4096, 48),
+                                         (2048, 14336, 4096, 32), (2048, 4096, 4096, 96), (1024, 4096, 2048, 160),
+                                         (2048, 768, 3072, 24), (4096, 4096, 4096, 200), (256, 4096, 4096, 32),
+                                         (2048, 4096, 14400, 32), (2048, 4096, 4096, 72)])
+def test_lowrank_forward_bf16_small_ranks_exact(ops, T, n_i, n_o, r, monkeypatch):
+    """Ranks that are not a multiple of 128 -- where a dwain search ends on wide layers (Llama gate / up: 32) -- run on
+    the rank padded with zeros (A's rows to 128 in the workspace, K of the second product to 64 with B read in place,
+    its pieces behind column r fetched from the row's start): exact zeros are added, so on integer operands the
+    result equals the unpadded integer product bit for bit; with and without bias, against the unpadded path
+    (PTD_LOWRANK_PAD=0 in a fresh process is not available here: the reference is torch f32 arithmetic), shapes the
+    short-K kernels serve (N a multiple of 256 / 128 / 64) and shapes they refuse (T = 256; N = 14400, a multiple of
+    64 only; r = 72 -> K 128 with 8 | 72), the last rows of B included (no read past the end: B is the LAST tensor
+    allocated before the call)."""
+    g = torch.Generator().manual_seed(7 * r + n_o)
+    x = torch.randint(-2, 3, (T, n_i), generator=g).to(torch.bfloat16).to(DEV)
+    a = torch.randint(-2, 3, (r, n_i), generator=g).to(torch.bfloat16).to(DEV)
+    bias = torch.randint(-3, 4, (n_o,), generator=g).to(torch.bfloat16).to(DEV)
+    b = torch.randint(-1, 2, (n_o, r), generator=g).to(torch.bfloat16).to(DEV)
+    h = (x.float() @ a.float().T).to(torch.bfloat16).float()
+    want = (h @ b.float().T).to(torch.bfloat16)
+    want_b = (h @ b.float().T + bias.float()).to(torch.bfloat16)
+    for rep in range(2):
+        assert torch.equal(ops.lowrank_forward(x, a, b, None), want), (r, rep)
+    assert torch.equal(ops.lowrank_forward(x, a, b, bias), want_b), r
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("shape", [(2, 64, 7, 7, 24, 40), (3, 96, 16, 16, 32, 130), (1, 256, 14, 14, 64, 512),
                                    (5, 10, 3, 5, 3, 7)])
