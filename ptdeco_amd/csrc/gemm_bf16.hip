@@ -260,14 +260,26 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmBf16Args a)
 // the 16 rows of every ds_read_b128 lane group 16 distinct 16-B slots.)
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_n() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
 
 // NBUF = 2: one barrier per K step that also drains the DMA (two workgroups per CU overlap each other).
 // NBUF = 4: for grids of at most one workgroup per CU (skinny outputs such as x A^T with N = rank 256),
 // where nothing else hides the staging latency: three K steps stay in flight across raw barriers and a
 // counted vmcnt retires only the step about to be read.
-template <int EPI, int NBUF>
+// NT = 32-column blocks per wave: 2 -> the 128 x 128 tile; 1 -> a 128 x 64 tile (TN = 64) for outputs with few 128-wide
+// tile columns (x A^T at T = 4096, r = 512: 128 tiles of 128^2 need a K split and a reduction pass, 256 tiles of
+// 128 x 64 cover the chip in one launch -- the tiling the library runs there).
+template <int EPI, int NBUF, int NT = 2>
 __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 1) void gemm_bf16_nt_glds_kernel(const GemmBf16Args a) {
-  __shared__ __attribute__((aligned(16))) char lds[NBUF * 2 * 16384 + (NBUF == 2 ? 2048 : 0)];
+  constexpr int TN = 64 * NT;                   // tile columns
+  constexpr int BBYTES = TN * 128;              // B image of one K step: TN rows of 64 bf16
+  constexpr int STEP = 16384 + BBYTES;          // A image + B image
+  constexpr int DPS = 4 + 2 * NT;               // DMA instructions per wave and K step
+  __shared__ __attribute__((aligned(16))) char lds[NBUF * STEP + (NBUF == 2 ? 2048 : 0) > 128 * (TN * 4 + 16)
+                                                       ? NBUF * STEP + (NBUF == 2 ? 2048 : 0) : 128 * (TN * 4 + 16)];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid >> 1, wn = wid & 1;
@@ -281,7 +293,7 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 1) void gemm_bf16_nt_glds_kern
   const int tiles_n = nwg / a.tiles_m, width = 8 * tiles_n, first = (wg / width) * 8;
   const int gsz = min(a.tiles_m - first, 8);
   const int ti = first + (wg % width) % gsz, tj = (wg % width) / gsz;
-  const int m0 = ti * BM, n0 = tj * BN;
+  const int m0 = ti * BM, n0 = tj * TN;
   const int nk = a.kchunk / BK;                 // blockIdx.y = K range (split K: partial tiles to f32 slabs)
   const unsigned short* Ag = a.A + (int64_t)m0 * a.sam + (int64_t)blockIdx.y * a.kchunk;
   const unsigned short* Bg = a.B + (int64_t)n0 * a.sbn + (int64_t)blockIdx.y * a.kchunk;
@@ -289,7 +301,7 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 1) void gemm_bf16_nt_glds_kern
   // this lane's share of a staging instruction: row (lane >> 3) of an 8-row group, position lane & 7
   const int srow = lane >> 3, spos = lane & 7;
   auto stage = [&](int buf, int kt) {
-    char* As = lds + buf * 32768;
+    char* As = lds + buf * STEP;
     char* Bs = As + 16384;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -297,17 +309,22 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 1) void gemm_bf16_nt_glds_kern
       const int r = r0 + srow;
       const int c = spos ^ ((r >> 1) & 7);       // source chunk that belongs at position spos
       const unsigned short* sa = Ag + (int64_t)r * a.sam + kt * BK + c * 8;
-      const unsigned short* sb = Bg + (int64_t)r * a.sbn + kt * BK + c * 8;
       __builtin_amdgcn_global_load_lds((glb_void*)sa, (lds_void*)(As + r0 * 128), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((glb_void*)sb, (lds_void*)(Bs + r0 * 128), 16, 0, 0);
+      if (q < 2 * NT) {
+        const int rb0 = (wid * 2 * NT + q) * 8;  // (TN rows of B: 2 NT pieces a wave)
+        const int rb = rb0 + srow;
+        const int cb = spos ^ ((rb >> 1) & 7);
+        const unsigned short* sb = Bg + (int64_t)rb * a.sbn + kt * BK + cb * 8;
+        __builtin_amdgcn_global_load_lds((glb_void*)sb, (lds_void*)(Bs + rb0 * 128), 16, 0, 0);
+      }
     }
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][NT];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NT; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -325,33 +342,38 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 1) void gemm_bf16_nt_glds_kern
     if (NBUF == 2) {
       if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
     } else {
-      // retire this wave's pieces of step kt (8 DMA instructions per step), then the barrier: every
+      // retire this wave's pieces of step kt (DPS DMA instructions per step), then the barrier: every
       // piece of step kt has landed, and every wave has finished reading step kt - 1, whose buffer
       // the stage below refills
-      if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-      else if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (kt + 2 < nk) wait_vmcnt_n<2 * DPS>();
+      else if (kt + 1 < nk) wait_vmcnt_n<DPS>();
+      else wait_vmcnt_n<0>();
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       if (kt + 3 < nk) stage((kt + 3) & 3, kt + 3);
     }
-    const char* As = lds + cur * 32768;
+    const char* As = lds + cur * STEP;
     const char* Bs = As + 16384;
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 16) {
       const int c = (kk >> 3) + fh;
-      s16x8 af[2], bf[2];
+      s16x8 af[2], bf[NT];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const int ra = wm * 64 + i * 32 + fr, rb = wn * 64 + i * 32 + fr;
+        const int ra = wm * 64 + i * 32 + fr;
         af[i] = *reinterpret_cast<const s16x8*>(As + ra * 128 + ((c ^ ((ra >> 1) & 7)) << 4));
-        bf[i] = *reinterpret_cast<const s16x8*>(Bs + rb * 128 + ((c ^ ((rb >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int rb = wn * 32 * NT + j * 32 + fr;
+        bf[j] = *reinterpret_cast<const s16x8*>(Bs + rb * 128 + ((c ^ ((rb >> 1) & 7)) << 4));
       }
       // B fragment first: the accumulator is the transposed block (see the epilogue)
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[0], af[0], acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[1], af[0], acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[0], af[1], acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[1], af[1], acc[1][1], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
     }
     if (NBUF == 2) __syncthreads();  // retires this step's LDS-DMA (vmcnt(0)) and the reads of buffer `cur`
   }
@@ -360,18 +382,18 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 1) void gemm_bf16_nt_glds_kern
   // Epilogue through LDS (the staging buffers are free after the loop's last barrier).  With the B
   // fragment as first MFMA operand lane l holds output row (l & 31) and, per group of four registers,
   // four consecutive output columns: one 8-byte (bf16, v_cvt_pk_bf16_f32) or 16-byte (f32) LDS write per
-  // group; staged as a [128][128] tile they leave as 16-byte row-contiguous global stores.
+  // group; staged as a [128][TN] tile they leave as 16-byte row-contiguous global stores.
   constexpr int ES = (EPI == EPI_STORE_BF16) ? 2 : 4;       // bytes per output element
-  constexpr int CP = 128 * ES + 16;                          // LDS pitch of a tile row (+16 B: rows rotate banks)
-  static_assert(128 * (128 * 4 + 16) <= sizeof(lds), "C tile must fit the staging buffers");
+  constexpr int CP = TN * ES + 16;                           // LDS pitch of a tile row (+16 B: rows rotate banks)
+  static_assert(128 * (TN * 4 + 16) <= sizeof(lds), "C tile must fit the staging buffers");
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NT; ++j) {
       const int lr = wm * 64 + i * 32 + (lane & 31);
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int lc = wn * 64 + j * 32 + 8 * g + 4 * (lane >> 5);
+        const int lc = wn * 32 * NT + j * 32 + 8 * g + 4 * (lane >> 5);
         float o[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e)
@@ -387,7 +409,7 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 1) void gemm_bf16_nt_glds_kern
       }
     }
   __syncthreads();
-  constexpr int CHUNKS = 128 * ES / 16;                      // 16-byte chunks per tile row
+  constexpr int CHUNKS = TN * ES / 16;                       // 16-byte chunks per tile row
 #pragma unroll
   for (int p = 0; p < 128 * CHUNKS / 256; ++p) {
     const int q = tid + 256 * p;
@@ -2605,6 +2627,16 @@ int gemm_bf16(const unsigned short* A, int64_t sam, int64_t sak, const unsigned 
   static const bool no_shortk = getenv("PTD_GEMM_NO_SHORTK") != nullptr;
   const bool c_vec = aligned16(C) && (ldc * (c_bf16 ? 2 : 4)) % 16 == 0;  // 16-byte row-contiguous output stores
   a.cslab = 0;
+  // few 128-wide tile columns but enough 128 x 64 tiles for one round of the chip: no K split, no reduction pass
+  static const bool no_t64 = getenv("PTD_GEMM_T64") && atoi(getenv("PTD_GEMM_T64")) == 0;
+  if (!no_t64 && !b_kvalid && !no_glds && akc && bkc && a.vecA && a.vecB && c_vec && M % BM == 0 && N % 64 == 0 && K % BK == 0 &&
+      K >= 8 * BK && (M / BM) * ((N + BN - 1) / BN) < 192 && (M / BM) * (N / 64) >= 192 && (M / BM) * (N / 64) <= 256) {
+    dim3 g64((unsigned)((M / BM) * (N / 64)), 1);
+    if (c_bf16) hipLaunchKernelGGL((gemm_bf16_nt_glds_kernel<EPI_STORE_BF16, 4, 1>), g64, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((gemm_bf16_nt_glds_kernel<EPI_STORE_F32, 4, 1>), g64, dim3(256), 0, st, a);
+    PTD_CHECK_LAUNCH("gemm_bf16 (128 x 64 tiles)");
+    return PTD_OK;
+  }
   if (a.kvalid && (K % 64 != 0 || K > 256 || a.kvalid % 8 != 0)) {
     set_error("gemm_bf16: a partial K range needs K a multiple of 64 up to 256 and 8 | kvalid");
     return PTD_ERR_UNSUPPORTED;

@@ -946,6 +946,25 @@ def test_gemm_bf16_direct_to_lds_path_exact(ops):
         assert torch.equal(got16.float(), (a.float() @ b.float().T).to(torch.bfloat16).float()), (M, N, K)
 
 
+def test_gemm_bf16_128x64_tile_path_exact(ops):
+    """Outputs with few 128-wide tile columns but 192 .. 256 tiles of 128 x 64 (x A^T of the decomposed forward at
+    T = 4096, r = 512; ptd_gemm has no workspace, so without this path the product runs unsplit on half the chip): the
+    TN = 64 form of the LDS-DMA kernel -- two B pieces a wave and K step, counted vmcnt of 6 instead of 8 per step, a
+    64-column C tile in the epilogue.  Exact integer products, f32 and bf16 outputs, bias; K from the 8-step minimum up."""
+    g = torch.Generator().manual_seed(17)
+    for (M, N, K) in [(4096, 512, 4096), (3072, 512, 512), (2048, 832, 1024), (4096, 448, 576), (32768, 64, 640)]:
+        assert (M // 128) * ((N + 127) // 128) < 192 <= (M // 128) * (N // 64) <= 256
+        a = torch.randint(-3, 4, (M, K), generator=g).to(torch.bfloat16)
+        b = torch.randint(-3, 4, (N, K), generator=g).to(torch.bfloat16)
+        bias = torch.randint(-3, 4, (N,), generator=g).to(torch.bfloat16)
+        ref = a.float() @ b.float().T
+        got = ops.matmul(a.to(DEV), b.to(DEV).T, bias=bias.to(DEV), out_dtype=torch.float32).cpu()
+        assert torch.equal(got, ref + bias.float()), (M, N, K)
+        for _ in range(2):
+            got16 = ops.matmul(a.to(DEV), b.to(DEV).T).cpu()
+            assert torch.equal(got16.float(), ref.to(torch.bfloat16).float()), (M, N, K)
+
+
 def test_gemm_bf16_short_k_persistent_path_exact(ops):
     """K <= 512 with M >= 1024: the persistent-over-N kernel (A panel as register fragments, B tiles
     streamed through the swizzled LDS-DMA image, N cut into ranges).  Exact integer products for every
