@@ -952,7 +952,7 @@ def test_gemm_bf16_128x64_tile_path_exact(ops):
     TN = 64 form of the LDS-DMA kernel -- two B pieces a wave and K step, counted vmcnt of 6 instead of 8 per step, a
     64-column C tile in the epilogue.  Exact integer products, f32 and bf16 outputs, bias; K from the 8-step minimum up."""
     g = torch.Generator().manual_seed(17)
-    for (M, N, K) in [(4096, 512, 4096), (3072, 512, 512), (2048, 832, 1024), (4096, 448, 576), (32768, 64, 640)]:
+    for (M, N, K) in [(4096, 512, 4096), (3072, 512, 512), (2048, 832, 1024), (4096, 448, 576), (3072, 576, 640)]:
         assert (M // 128) * ((N + 127) // 128) < 192 <= (M // 128) * (N // 64) <= 256
         a = torch.randint(-3, 4, (M, K), generator=g).to(torch.bfloat16)
         b = torch.randint(-3, 4, (N, K), generator=g).to(torch.bfloat16)
