@@ -1330,8 +1330,33 @@ def dedicated_streams(device: torch.device, want: int) -> list:
                 count = counts[i] if i < len(counts) else 0
                 ptr = ctypes.c_void_p(0)
                 _hip.check(lib.ptd_stream_create_dedicated(first, count, ctypes.byref(ptr)), "ptd_stream_create_dedicated")
+                if not _DEDICATED_RAW:
+                    import atexit
+
+                    atexit.register(_destroy_dedicated_streams)
+                _DEDICATED_RAW.append((index, ptr.value))
                 have.append(torch.cuda.ExternalStream(ptr.value, device=torch.device("cuda", index)))
         return list(have[:want])
+
+
+_DEDICATED_RAW: list = []      # (device index, hipStream_t) of every dedicated stream: destroyed at interpreter exit
+
+
+def _destroy_dedicated_streams() -> None:
+    """The streams are the library's own (torch only wraps them): left to the runtime's teardown they outlive a
+    profiler's tool (rocprofv3 aborted in its finalisation, round 6); destroyed here, in order, while everything lives."""
+    from . import _hip
+
+    try:
+        lib = _hip.load()
+        for index, raw in _DEDICATED_RAW:
+            with torch.cuda.device(index):
+                torch.cuda.synchronize(index)
+                lib.ptd_stream_destroy(raw)
+    except Exception:  # noqa: BLE001  (exit path: nothing to report to)
+        pass
+    _DEDICATED_RAW.clear()
+    _DEDICATED_STREAMS.clear()
 
 
 _CHAIN_STREAMS: dict = {}      # device index -> (streams on pairwise distinct hardware queues, candidates exhausted?)
