@@ -698,12 +698,39 @@ print("ok")
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
 
 
-def test_chain_streams_sit_on_distinct_hardware_queues(ops):
-    """the streams of concurrent eigendecompositions are measured to overlap pairwise
-    (ptd_stream_pair_wall_us: two single-wave kernels that hold their queue for 150 us), are kept per device, and a
-    stream paired with itself reads as serialised."""
+def test_lane_streams_own_their_hardware_queues(ops):
+    """Round 6: the lanes of a precompute pass run on streams created with a CU mask (ptd_stream_create_dedicated:
+    hipExtStreamCreateWithCUMask over every CU), which the runtime gives a hardware queue of their own -- no probing:
+    three such streams overlap pairwise by construction (ptd_stream_pair_wall_us: two single-wave kernels that hold their
+    queue for 150 us run side by side), are kept per device, and a stream paired with itself reads as serialised."""
     import ctypes
     from ptdeco_amd import _engine as eng, _hip
+    dev = torch.device("cuda", 0)
+    st = eng.chain_streams(dev, 3)
+    assert len(st) == 3 and len({s.cuda_stream for s in st}) == 3
+    again = eng.chain_streams(dev, 3)
+    assert [s.cuda_stream for s in again] == [s.cuda_stream for s in st]
+    lib, wall = _hip.load(), ctypes.c_double(0.0)
+    for i in range(3):
+        for j in range(i + 1, 3):
+            _hip.check(lib.ptd_stream_pair_wall_us(st[i].cuda_stream, st[j].cuda_stream, 150, ctypes.byref(wall)), "pair")
+            assert wall.value < 240.0, (i, j, wall.value)
+    _hip.check(lib.ptd_stream_pair_wall_us(st[0].cuda_stream, st[0].cuda_stream, 150, ctypes.byref(wall)), "pair")
+    assert wall.value > 280.0, wall.value
+    # work issued on a dedicated stream is ordinary stream work
+    with torch.cuda.stream(st[1]):
+        t = torch.ones(1 << 20, device=dev) * 3
+    st[1].synchronize()
+    assert t.sum().item() == 3 * (1 << 20)
+    assert lib.ptd_stream_pair_wall_us(None, None, 0, ctypes.byref(wall)) == -1
+
+
+def test_chain_streams_sit_on_distinct_hardware_queues(ops, monkeypatch):
+    """VERDICT r4 item 2 (PTD_LANE_STREAMS=pool, round 5's form): streams from torch's pool are measured to overlap
+    pairwise (ptd_stream_pair_wall_us), are kept per device, and a stream paired with itself reads as serialised."""
+    import ctypes
+    from ptdeco_amd import _engine as eng, _hip
+    monkeypatch.setenv("PTD_LANE_STREAMS", "pool")
     dev = torch.device("cuda", 0)
     st = eng.chain_streams(dev, 4)
     assert len(st) == 4 and len({s.cuda_stream for s in st}) == 4
@@ -714,11 +741,8 @@ def test_chain_streams_sit_on_distinct_hardware_queues(ops):
         for j in range(i + 1, 4):
             _hip.check(lib.ptd_stream_pair_wall_us(st[i].cuda_stream, st[j].cuda_stream, 150, ctypes.byref(wall)), "pair")
             assert wall.value < 240.0, (i, j, wall.value)
-    _hip.check(lib.ptd_stream_pair_wall_us(st[0].cuda_stream, st[0].cuda_stream, 150, ctypes.byref(wall)), "pair")
-    assert wall.value > 280.0, wall.value
     more = eng.chain_streams(dev, 7)      # the runtime has 4 queues per priority level: 5 to 7 distinct ones exist
     assert 4 <= len(more) <= 7 and [s.cuda_stream for s in more[:4]] == [s.cuda_stream for s in st]
-    assert lib.ptd_stream_pair_wall_us(None, None, 0, ctypes.byref(wall)) == -1
 
 
 @pytest.mark.parametrize("n,k", [(96, 96), (512, 128), (2048, 512)])
