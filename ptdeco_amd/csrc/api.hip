@@ -361,7 +361,7 @@ static size_t elt_bytes(int dtype) { return dtype == PTD_F32 ? 4 : 2; }
 static int64_t lowrank_pad128(int64_t r, int dtype) {
   static const bool off = getenv("PTD_LOWRANK_PAD") && atoi(getenv("PTD_LOWRANK_PAD")) == 0;
   if (off || dtype != PTD_BF16 || r % 8 != 0 || r % 128 == 0 || r > 1024) return r;
-  return (int64_t)align_up((size_t)r, 128);
+  return r <= 64 ? 64 : (int64_t)align_up((size_t)r, 128);     // (one column of 128 x 64 tiles serves a rank up to 64)
 }
 
 size_t ptd_lowrank_forward_workspace_bytes(int64_t T, int64_t n_i, int64_t r, int dtype) {
@@ -388,10 +388,17 @@ int ptd_lowrank_forward(const void* x, int64_t ldx, int64_t T, int64_t n_i, cons
     u16* hp = static_cast<u16*>(ws);
     u16* Ap = reinterpret_cast<u16*>(static_cast<char*>(ws) + hp_bytes);
     char* rest = static_cast<char*>(ws) + hp_bytes + ap_bytes;
-    int rc = pad_rows_bf16(static_cast<const u16*>(A), lda, r, n_i, Ap, rp, st);
-    if (rc != PTD_OK) return rc;
-    rc = gemm_bf16(static_cast<const u16*>(x), ldx, 1, Ap, 1, n_i, hp, rp, T, rp, n_i, true, 1.0, nullptr, rest,
-                   ws_bytes - hp_bytes - ap_bytes, st);
+    // the first product on the padded rank: A read in place -- its rows behind r are fetched from row 0 and the columns
+    // they would produce are written as zeros (GemmBf16Args::nvalid); where no LDS-DMA kernel serves the shape, on a
+    // zero-padded copy of A
+    int rc = gemm_bf16(static_cast<const u16*>(x), ldx, 1, static_cast<const u16*>(A), 1, lda, hp, rp, T, rp, n_i, true, 1.0,
+                       nullptr, rest, ws_bytes - hp_bytes - ap_bytes, st, 0, r);
+    if (rc == PTD_ERR_UNSUPPORTED) {
+      rc = pad_rows_bf16(static_cast<const u16*>(A), lda, r, n_i, Ap, rp, st);
+      if (rc != PTD_OK) return rc;
+      rc = gemm_bf16(static_cast<const u16*>(x), ldx, 1, Ap, 1, n_i, hp, rp, T, rp, n_i, true, 1.0, nullptr, rest,
+                     ws_bytes - hp_bytes - ap_bytes, st);
+    }
     if (rc != PTD_OK) return rc;
     // y = h B^T + bias with K padded to whole 64-deep steps where a short-K kernel serves the shape, else with K = r
     const int64_t k64 = (int64_t)align_up((size_t)r, 64);

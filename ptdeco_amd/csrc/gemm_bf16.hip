@@ -56,6 +56,9 @@ struct GemmBf16Args {
   int64_t cslab;  // split K of the LDS-DMA kernel: blockIdx.y writes its f32 partial tile to C + y * cslab
   int64_t zsa, zsb, zsc;  // batched products (generic kernel only): blockIdx.z advances A, B, C by these element strides
   int bias_rows;          // bias indexed by the output ROW (an NCHW 1x1 convolution's channel) instead of the column
+  int nvalid;             // LDS-DMA 128 x (128 | 64) kernel: > 0 = B has only nvalid (< N) rows -- the rows behind them are
+                          // fetched from row 0 (in bounds) and their output columns are written as exact zeros: a rank
+                          // below the tile width runs without a padded copy of the factor (ptd_lowrank_forward)
   int kvalid;             // short-K kernels: > 0 = B's rows hold only kvalid (< K) values -- the 16-byte pieces at k >= kvalid
                           // are fetched from k = 0 instead (in bounds; A is zero there, so they add nothing): a rank that
                           // is not a multiple of 64 runs on the 64-deep kernels (ptd_lowrank_forward)
@@ -314,7 +317,8 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 1) void gemm_bf16_nt_glds_kern
         const int rb0 = (wid * 2 * NT + q) * 8;  // (TN rows of B: 2 NT pieces a wave)
         const int rb = rb0 + srow;
         const int cb = spos ^ ((rb >> 1) & 7);
-        const unsigned short* sb = Bg + (int64_t)rb * a.sbn + kt * BK + cb * 8;
+        const int rsrc = (a.nvalid > 0 && n0 + rb >= a.nvalid) ? -n0 : rb;      // (row 0 of B: see GemmBf16Args::nvalid)
+        const unsigned short* sb = Bg + (int64_t)rsrc * a.sbn + kt * BK + cb * 8;
         __builtin_amdgcn_global_load_lds((glb_void*)sb, (lds_void*)(Bs + rb0 * 128), 16, 0, 0);
       }
     }
@@ -396,8 +400,10 @@ __global__ __launch_bounds__(256, NBUF == 2 ? 2 : 1) void gemm_bf16_nt_glds_kern
         const int lc = wn * 32 * NT + j * 32 + 8 * g + 4 * (lane >> 5);
         float o[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
+        for (int e = 0; e < 4; ++e) {
           o[e] = a.alpha * acc[i][j][4 * g + e] + (a.bias ? bf16_to_f32(a.bias[n0 + lc + e]) : 0.f);
+          if (a.nvalid > 0 && n0 + lc + e >= a.nvalid) o[e] = 0.f;
+        }
         if (EPI == EPI_STORE_BF16) {
           typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
           const u32x2 pk = {pack2_bf16(o[0], o[1]), pack2_bf16(o[2], o[3])};
@@ -2552,12 +2558,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_bf16_kernel(const float* __
 
 // K split of a skinny nn.Linear-layout product (x A^T at a few thousand rows: 64 tiles for T = 4096, r = 256 leave
 // three quarters of the CUs idle): 1 = no split
+// (N = 64: ONE column of 128 x 64 tiles -- the first product of a pair whose rank is at most 64.  With 16 tiles or fewer
+// -- x A^T at a couple of thousand rows -- the ranges go down to four K steps: 256 workgroups instead of 128)
 int gemm_bf16_ksplit(int64_t M, int64_t N, int64_t K) {
-  if (M % BM || N % BN || K % BK || K < 1024) return 1;
-  const int64_t tiles = (M / BM) * (N / BN);
+  if (M % BM || (N % BN && N != 64) || K % BK || K < 1024) return 1;
+  const int64_t tiles = (M / BM) * ((N + BN - 1) / BN);
   if (tiles > 128) return 1;
+  const int64_t min_range = tiles <= 16 ? 256 : 512;
   int ks = 1;
-  while (ks * 2 * tiles <= 256 && K % (ks * 2 * BK) == 0 && K / (ks * 2) >= 512) ks *= 2;
+  while (ks * 2 * tiles <= 256 && K % (ks * 2 * BK) == 0 && K / (ks * 2) >= min_range) ks *= 2;
   return ks;
 }
 
@@ -2606,7 +2615,7 @@ size_t gemm_bf16_workspace_bytes(int64_t M, int64_t N, int64_t K) {
 // multiplies with K = b_kvalid on the generic path)
 int gemm_bf16(const unsigned short* A, int64_t sam, int64_t sak, const unsigned short* B, int64_t sbk, int64_t sbn,
               void* C, int64_t ldc, int64_t M, int64_t N, int64_t K, bool c_bf16, double alpha,
-              const unsigned short* bias, void* ws, size_t ws_bytes, hipStream_t st, int64_t b_kvalid) {
+              const unsigned short* bias, void* ws, size_t ws_bytes, hipStream_t st, int64_t b_kvalid, int64_t b_nvalid) {
   PTD_REQUIRE((sam == 1) != (sak == 1) || (M == 1 || K == 1), "ptd_gemm: exactly one stride of A must be 1");
   PTD_REQUIRE((sbk == 1) != (sbn == 1) || (N == 1 || K == 1), "ptd_gemm: exactly one stride of B must be 1");
   if (M == 0 || N == 0) return PTD_OK;
@@ -2619,6 +2628,7 @@ int gemm_bf16(const unsigned short* A, int64_t sam, int64_t sak, const unsigned 
   a.tiles_m = (int)ceil_div(M, BM);
   a.tri = 0; a.kchunk = (int)align_up((size_t)(K > 0 ? K : 1), BK); a.atomic = 0;
   a.kvalid = (b_kvalid > 0 && b_kvalid < K) ? (int)b_kvalid : 0;
+  a.nvalid = (b_nvalid > 0 && b_nvalid < N) ? (int)b_nvalid : 0;
   const bool akc = (sak == 1), bkc = (sbk == 1);
   a.vecA = aligned16(A) && ((akc ? sam : sak) % 8 == 0);
   a.vecB = aligned16(B) && ((bkc ? sbn : sbk) % 8 == 0);
@@ -2629,7 +2639,7 @@ int gemm_bf16(const unsigned short* A, int64_t sam, int64_t sak, const unsigned 
   a.cslab = 0;
   // few 128-wide tile columns but enough 128 x 64 tiles for one round of the chip: no K split, no reduction pass
   static const bool no_t64 = getenv("PTD_GEMM_T64") && atoi(getenv("PTD_GEMM_T64")) == 0;
-  if (!no_t64 && !b_kvalid && !no_glds && akc && bkc && a.vecA && a.vecB && c_vec && M % BM == 0 && N % 64 == 0 && K % BK == 0 &&
+  if (!no_t64 && !b_kvalid && !b_nvalid && !no_glds && akc && bkc && a.vecA && a.vecB && c_vec && M % BM == 0 && N % 64 == 0 && K % BK == 0 &&
       K >= 8 * BK && (M / BM) * ((N + BN - 1) / BN) < 192 && (M / BM) * (N / 64) >= 192 && (M / BM) * (N / 64) <= 256) {
     dim3 g64((unsigned)((M / BM) * (N / 64)), 1);
     if (c_bf16) hipLaunchKernelGGL((gemm_bf16_nt_glds_kernel<EPI_STORE_BF16, 4, 1>), g64, dim3(256), 0, st, a);
@@ -2648,7 +2658,8 @@ int gemm_bf16(const unsigned short* A, int64_t sam, int64_t sak, const unsigned 
       GemmBf16Args p = a;
       p.C = ws; p.ldc = N; p.cslab = M * N; p.kchunk = (int)(K / ks); p.alpha = 1.f; p.bias = nullptr;
       dim3 g2(grid.x, (unsigned)ks);
-      if (K / ks >= 4 * BK) hipLaunchKernelGGL((gemm_bf16_nt_glds_kernel<EPI_STORE_F32, 4>), g2, dim3(256), 0, st, p);
+      if (N == 64) hipLaunchKernelGGL((gemm_bf16_nt_glds_kernel<EPI_STORE_F32, 4, 1>), g2, dim3(256), 0, st, p);
+      else if (K / ks >= 4 * BK) hipLaunchKernelGGL((gemm_bf16_nt_glds_kernel<EPI_STORE_F32, 4>), g2, dim3(256), 0, st, p);
       else hipLaunchKernelGGL((gemm_bf16_nt_glds_kernel<EPI_STORE_F32, 2>), g2, dim3(256), 0, st, p);
       const int64_t items = M * (N / 8);
       if (c_bf16)
@@ -2660,6 +2671,21 @@ int gemm_bf16(const unsigned short* A, int64_t sam, int64_t sak, const unsigned 
       PTD_CHECK_LAUNCH("gemm_bf16 (split K)");
       return PTD_OK;
     }
+  }
+  if (a.nvalid) {
+    // (no K split: the same kernels write the product directly, the columns behind nvalid as zeros)
+    if (!no_glds && akc && bkc && a.vecA && a.vecB && c_vec && M % BM == 0 && K % BK == 0 && K >= 4 * BK && (N == 64 || N % BN == 0)) {
+      dim3 gn((unsigned)((M / BM) * (N == 64 ? 1 : N / BN)), 1);
+      if (N == 64) {
+        if (c_bf16) hipLaunchKernelGGL((gemm_bf16_nt_glds_kernel<EPI_STORE_BF16, 4, 1>), gn, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((gemm_bf16_nt_glds_kernel<EPI_STORE_F32, 4, 1>), gn, dim3(256), 0, st, a);
+      } else if (c_bf16) hipLaunchKernelGGL((gemm_bf16_nt_glds_kernel<EPI_STORE_BF16, 2>), gn, dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((gemm_bf16_nt_glds_kernel<EPI_STORE_F32, 2>), gn, dim3(256), 0, st, a);
+      PTD_CHECK_LAUNCH("gemm_bf16 (partial N range)");
+      return PTD_OK;
+    }
+    set_error("gemm_bf16: no LDS-DMA kernel for this shape with a partial N range");
+    return PTD_ERR_UNSUPPORTED;
   }
   static const bool shortk_old = getenv("PTD_GEMM_SHORTK_OLD") != nullptr;
   static const bool shortk_4w = getenv("PTD_GEMM_SHORTK_4W") != nullptr;

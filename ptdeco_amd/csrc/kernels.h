@@ -19,7 +19,8 @@ int syrk_f32(const float* Y, int64_t T, int64_t n, int64_t ldy, void* E, int64_t
 // gemm_bf16.hip
 int gemm_bf16(const unsigned short* A, int64_t sam, int64_t sak, const unsigned short* B, int64_t sbk, int64_t sbn,
               void* C, int64_t ldc, int64_t M, int64_t N, int64_t K, bool c_bf16, double alpha,
-              const unsigned short* bias, void* ws, size_t ws_bytes, hipStream_t st, int64_t b_kvalid = 0);
+              const unsigned short* bias, void* ws, size_t ws_bytes, hipStream_t st, int64_t b_kvalid = 0,
+              int64_t b_nvalid = 0);
 size_t gemm_bf16_workspace_bytes(int64_t M, int64_t N, int64_t K);
 // [rows_out][cols] <- the first `rows` rows of src (row pitch ld), zero rows behind them
 int pad_rows_bf16(const unsigned short* src, int64_t ld, int64_t rows, int64_t cols, unsigned short* dst, int64_t rows_out,
