@@ -64,3 +64,21 @@ def test_deep_pipelined_kernels_do_not_spill(tmp_path):
             found += 1
             assert int(m.group(2)) == 0, f"{m.group(1)} spills {m.group(2)} bytes of scratch"
         assert found >= 2, src
+
+
+def test_register_limit_kernels_do_not_spill(tmp_path):
+    """the kernels that sit at the register limit -- the persistent covariance ring (`syrk_bf16_ring`, 512
+    registers a lane in its four-wave form), the four-wave resident tridiagonalisation kernels (`sytrd_resident4`), the
+    other resident kernels -- and round 6's one-launch small-rank forward must not touch scratch."""
+    wanted = {"gemm_bf16.hip": (r"syrk_bf16_ring", 4), "eigh_tridiag.hip": (r"sytrd_resident", 6),
+              "lowrank_small.hip": (r"lowrank_small_kernel", 4)}
+    for src, (pat, least) in wanted.items():
+        text = "\n".join(_device_asm(src, tmp_path))
+        found = 0
+        for m in re.finditer(r"\.set (\S*" + pat + r"\S*)\.private_seg_size, (\d+)", text):
+            found += 1
+            # (known since round 5: the 15-row form of the four-wave kernel, <3840>, keeps 164 bytes of a lane's 2 KiB of
+            # registers in scratch -- a handful of address temporaries outside its column loop; anything beyond that is new)
+            allowed = 192 if "sytrd_resident4_kernelILi3840" in m.group(1) else 0
+            assert int(m.group(2)) <= allowed, f"{m.group(1)} spills {m.group(2)} bytes of scratch"
+        assert found >= least, (src, found)

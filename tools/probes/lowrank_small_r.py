@@ -8,7 +8,7 @@ from ptdeco_amd import ops
 
 dev = torch.device("cuda", 0)
 out = {}
-for T, n_i, n_o in ((2048, 4096, 14336), (2048, 4096, 4096), (2048, 14336, 4096), (16384, 4096, 4096)):
+for T, n_i, n_o in ((2048, 4096, 14336), (2048, 4096, 4096), (2048, 14336, 4096), (4096, 4096, 4096), (16384, 4096, 4096)):
     x = torch.randn(T, n_i, device=dev).bfloat16()
     for r in (16, 32, 48, 64, 96, 128, 256):
         a = (torch.randn(r, n_i, device=dev) / 64).bfloat16()
