@@ -379,8 +379,6 @@ int ptd_lowrank_forward(const void* x, int64_t ldx, int64_t T, int64_t n_i, cons
   PTD_REQUIRE(x && A && B && y && ws, "ptd_lowrank_forward: null pointer");
   PTD_REQUIRE(ldx >= n_i && lda >= n_i && ldb >= r && ldy >= n_o, "ptd_lowrank_forward: bad leading dimension");
   PTD_REQUIRE(dtype == PTD_F32 || dtype == PTD_BF16, "ptd_lowrank_forward: dtype must be f32 or bf16");
-  if (dtype == PTD_BF16 && lowrank_small_applies(T, n_i, r, n_o, ldx, lda, ldb, ldy, x, A, B, y))
-    return lowrank_small_bf16(x, ldx, T, n_i, A, lda, r, B, ldb, n_o, bias, y, ldy, static_cast<hipStream_t>(stream));
   const int64_t rp = lowrank_pad128(r, dtype);
   if (rp != r && n_i % 8 == 0 && lda % 8 == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0 &&
       ws_bytes >= ptd_lowrank_forward_workspace_bytes(T, n_i, r, dtype)) {

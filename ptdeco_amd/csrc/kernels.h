@@ -34,12 +34,6 @@ int syrk_bf16(const unsigned short* Y, int64_t T, int64_t n, int64_t ldy, void* 
 int syrk_bf16_multi(const unsigned short* const* Ys, int steps, int64_t T, int64_t n, int64_t ldy, void* E, int64_t ldE,
                     bool e_f64, double scale, hipStream_t st);
 
-// lowrank_small.hip: the decomposed forward at r = 32 / 64 / 96 / 128 (bf16) in one launch
-bool lowrank_small_applies(int64_t T, int64_t n_i, int64_t r, int64_t n_o, int64_t ldx, int64_t lda, int64_t ldb,
-                           int64_t ldy, const void* x, const void* A, const void* B, const void* y);
-int lowrank_small_bf16(const void* x, int64_t ldx, int64_t T, int64_t n_i, const void* A, int64_t lda, int64_t r,
-                       const void* B, int64_t ldb, int64_t n_o, const void* bias, void* y, int64_t ldy, hipStream_t st);
-
 // eigh_jacobi.hip
 size_t eigh_workspace_bytes(int64_t n);
 int eigh_jacobi(const double* A, int64_t lda, int64_t n, int64_t k, double* evals, double* evecs, int64_t ldv,

@@ -69,9 +69,8 @@ def test_deep_pipelined_kernels_do_not_spill(tmp_path):
 def test_register_limit_kernels_do_not_spill(tmp_path):
     """the kernels that sit at the register limit -- the persistent covariance ring (`syrk_bf16_ring`, 512
     registers a lane in its four-wave form), the four-wave resident tridiagonalisation kernels (`sytrd_resident4`), the
-    other resident kernels -- and round 6's one-launch small-rank forward must not touch scratch."""
-    wanted = {"gemm_bf16.hip": (r"syrk_bf16_ring", 4), "eigh_tridiag.hip": (r"sytrd_resident", 6),
-              "lowrank_small.hip": (r"lowrank_small_kernel", 4)}
+    other resident kernels -- must not touch scratch."""
+    wanted = {"gemm_bf16.hip": (r"syrk_bf16_ring", 4), "eigh_tridiag.hip": (r"sytrd_resident", 6)}
     for src, (pat, least) in wanted.items():
         text = "\n".join(_device_asm(src, tmp_path))
         found = 0

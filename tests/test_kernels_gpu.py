@@ -1491,9 +1491,7 @@ def test_lowrank_forward_bf16_c5_shapes_exact(ops, r, T):
                                          (2048, 14336, 4096, 32), (2048, 4096, 4096, 96), (1024, 4096, 2048, 160),
                                          (2048, 768, 3072, 24), (4096, 4096, 4096, 200), (256, 4096, 4096, 32),
                                          (2048, 4096, 14400, 32), (2048, 4096, 4096, 72),
-                                         # the one-launch kernel (lowrank_small.hip: r = 32 / 64 / 96 / 128, T % 16 = 0,
-                                         # n_i % 128 = 0, n_o % 64 = 0): column splits that do not divide the chunks (65
-                                         # chunks), a single row block, many row blocks without a split, n_i = 14336
+                                         # ranks of 32 / 64 / 96 / 128 at other row counts and widths
                                          (2048, 4096, 4096, 64), (2048, 4096, 14336, 128), (16, 4096, 4160, 32),
                                          (48, 1024, 4160, 96), (16384, 4096, 4096, 32), (2048, 14336, 4096, 64),
                                          (4096, 128, 64, 128)])
