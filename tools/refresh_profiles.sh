@@ -10,7 +10,8 @@ if [ "$PART" = all ] || [ "$PART" = main ]; then
   timeout -k 10 1100 python -m pytest tests -q -m gpu > gpurun_out/gpu_tests_r$R.log 2>&1; echo "tests rc=$?"; tail -2 gpurun_out/gpu_tests_r$R.log
 fi
 if [ "$PART" = all ] || [ "$PART" = main ] || [ "$PART" = bench ]; then
-  timeout -k 10 500 python bench.py --steps 5 --warmup 1 > gpurun_out/bench_r$R.json 2> gpurun_out/bench_r$R.err; echo "bench rc=$?"
+  timeout -k 10 500 python bench.py --steps 5 --warmup 1 > gpurun_out/bench_r$R.txt 2> gpurun_out/bench_r$R.err; echo "bench rc=$?"
+  tail -1 gpurun_out/bench_r$R.txt > gpurun_out/bench_r$R.json; cp bench_detail.json gpurun_out/bench_detail_r$R.json
   cut -c1-200 gpurun_out/bench_r$R.json
   rm -rf $GRAFT_REPO_ROOT/gpurun_out/prof_r$R   # (earlier runs leave PID-named files beside the new ones)
   (cd /tmp && export TMPDIR=/tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_r$R -- python3 $GRAFT_REPO_ROOT/bench.py --workload c2 --steps 3 --warmup 1 --no-extras > $GRAFT_REPO_ROOT/gpurun_out/prof_r$R.log 2>&1); echo "rocprof rc=$?"
@@ -55,7 +56,8 @@ if [ "$PART" = all ] || [ "$PART" = pmc ]; then
   G=$GRAFT_REPO_ROOT
   for c in FETCH_SIZE:pmc_fetch WRITE_SIZE:pmc_write "TCC_HIT_sum TCC_MISS_sum":pmc_tcc; do
     ctr=${c%%:*}; dir=${c##*:}
-    timeout -k 10 300 rocprofv3 --pmc $ctr --kernel-include-regex sytrd_symv --kernel-trace --output-format csv -d $G/gpurun_out/$dir -- $G/tools/pmc_driver 4096 > $G/gpurun_out/$dir.log 2>&1; echo "$dir rc=$?"
+    # (round 6: the unit of the headline step's direct lane -- two (4096, 2048) matrices per launch, every column blocked)
+    timeout -k 10 300 rocprofv3 --pmc $ctr --kernel-include-regex sytrd_symv --kernel-trace --output-format csv -d $G/gpurun_out/$dir -- $G/tools/pmc_driver batched 2 > $G/gpurun_out/$dir.log 2>&1; echo "$dir rc=$?"
   done
   timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-include-regex "syrk|gemm" --kernel-trace --output-format csv -d $G/gpurun_out/pmc_mfma -- $G/tools/pmc_driver mfma > $G/gpurun_out/pmc_mfma.log 2>&1; echo "pmc_mfma rc=$?"
   timeout -k 10 300 rocprofv3 --pmc MfmaUtil --kernel-include-regex "syrk|gemm" --kernel-trace --output-format csv -d $G/gpurun_out/pmc_mfma2 -- $G/tools/pmc_driver mfma > $G/gpurun_out/pmc_mfma2.log 2>&1; echo "pmc_mfma2 rc=$?"
@@ -70,7 +72,7 @@ if [ "$PART" = all ] || [ "$PART" = pmc ]; then
   done
   # condense on the box (gpurun copies back at most 64 MiB: the raw counter tables stay here), summaries -> gpurun_out/
   cd $G
-  python3 tools/pmc_summary.py $R > gpurun_out/pmc_summary.log 2>&1; echo "pmc_summary rc=$?"
+  python3 tools/pmc_summary.py $R 4096 2 > gpurun_out/pmc_summary.log 2>&1; echo "pmc_summary rc=$?"
   python3 tools/pmc_mfma_summary.py $R > gpurun_out/pmc_mfma_summary.log 2>&1; echo "pmc_mfma_summary rc=$?"
   python3 tools/pmc_syrk_summary.py $R > gpurun_out/pmc_syrk_summary.log 2>&1; echo "pmc_syrk_summary rc=$?"
   python3 tools/pmc_filtered_summary.py $R > gpurun_out/pmc_filtered_summary.log 2>&1; echo "pmc_filtered_summary rc=$?"
