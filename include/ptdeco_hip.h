@@ -282,6 +282,16 @@ int ptd_gemm(const void* A, int64_t sam, int64_t sak, const void* B, int64_t sbk
              void* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int ab_dtype, int c_dtype,
              double alpha, const void* bias, void* stream);
 
+/* The same product with a workspace (ABI 4).  A product with few output tiles -- T = 1576 rows of a ViT batch
+ * against a 768-column layer are 78 tiles of 128 x 128 for 256 CUs -- has its K range split over workgroups; the
+ * partial tiles go to f32 slabs in the workspace and a second launch adds them in index order (results do not
+ * depend on scheduling).  ptd_gemm_workspace_bytes returns 0 where no split would be made; ws may be NULL
+ * (= ptd_gemm). */
+size_t ptd_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K, int ab_dtype, int c_dtype);
+int ptd_gemm_ws(const void* A, int64_t sam, int64_t sak, const void* B, int64_t sbk, int64_t sbn,
+                void* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int ab_dtype, int c_dtype,
+                double alpha, const void* bias, void* ws, size_t ws_bytes, void* stream);
+
 /* y[T,n_o] = (x[T,n_i] @ A[r,n_i]^T) @ B[n_o,r]^T (+ bias[n_o]).  The workspace holds the
  * [T, r] intermediate of the operand dtype and, for f32 operands with a small rank, the partial
  * tiles of the first product's K split (added in a fixed order: results do not depend on

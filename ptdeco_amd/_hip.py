@@ -63,6 +63,9 @@ SIGNATURES = {
                                   c_void_p, c_int64, c_void_p, c_size_t, c_void_p]),
     "ptd_gemm": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
                          c_int64, c_int64, c_int, c_int, c_double, c_void_p, c_void_p]),
+    "ptd_gemm_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int64, c_int, c_int]),
+    "ptd_gemm_ws": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
+                            c_int64, c_int64, c_int, c_int, c_double, c_void_p, c_void_p, c_size_t, c_void_p]),
     "ptd_lowrank_forward_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int64, c_int]),
     "ptd_lowrank_forward": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p,
                                     c_int64, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_size_t, c_int,

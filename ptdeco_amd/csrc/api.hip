@@ -328,20 +328,33 @@ int ptd_tridiagonalize(const double* A, int64_t lda, int64_t n, double* d, doubl
   return tridiagonalize_f64(A, lda, n, d, e, evals, ws, ws_bytes, static_cast<hipStream_t>(stream));
 }
 
+size_t ptd_gemm_workspace_bytes(int64_t M, int64_t N, int64_t K, int ab_dtype, int c_dtype) {
+  if (ab_dtype == PTD_F32 && c_dtype == PTD_F32) return gemm_f32_workspace_bytes(M, N, K);
+  if (ab_dtype == PTD_BF16 && (c_dtype == PTD_BF16 || c_dtype == PTD_F32)) return gemm_bf16_workspace_bytes(M, N, K);
+  return 0;
+}
+
 int ptd_gemm(const void* A, int64_t sam, int64_t sak, const void* B, int64_t sbk, int64_t sbn, void* C, int64_t ldc,
              int64_t M, int64_t N, int64_t K, int ab_dtype, int c_dtype, double alpha, const void* bias,
              void* stream) {
+  return ptd_gemm_ws(A, sam, sak, B, sbk, sbn, C, ldc, M, N, K, ab_dtype, c_dtype, alpha, bias, nullptr, 0, stream);
+}
+
+int ptd_gemm_ws(const void* A, int64_t sam, int64_t sak, const void* B, int64_t sbk, int64_t sbn, void* C, int64_t ldc,
+                int64_t M, int64_t N, int64_t K, int ab_dtype, int c_dtype, double alpha, const void* bias, void* ws,
+                size_t ws_bytes, void* stream) {
   PTD_REQUIRE(A && B && C, "ptd_gemm: null pointer");
   PTD_REQUIRE(M >= 0 && N >= 0 && K >= 0 && ldc >= N, "ptd_gemm: bad shape");
   PTD_REQUIRE(M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31), "ptd_gemm: dimension too large");
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (!ws) ws_bytes = 0;
   if (ab_dtype == PTD_F32 && c_dtype == PTD_F32)
     return gemm_f32(static_cast<const float*>(A), sam, sak, static_cast<const float*>(B), sbk, sbn,
-                    static_cast<float*>(C), ldc, M, N, K, alpha, static_cast<const float*>(bias), nullptr, 0, st);
+                    static_cast<float*>(C), ldc, M, N, K, alpha, static_cast<const float*>(bias), ws, ws_bytes, st);
   if (ab_dtype == PTD_BF16 && (c_dtype == PTD_BF16 || c_dtype == PTD_F32))
     return gemm_bf16(static_cast<const unsigned short*>(A), sam, sak, static_cast<const unsigned short*>(B), sbk,
                      sbn, C, ldc, M, N, K, c_dtype == PTD_BF16, alpha, static_cast<const unsigned short*>(bias),
-                     nullptr, 0, st);
+                     ws, ws_bytes, st);
   if (ab_dtype == PTD_F64 && c_dtype == PTD_F64 && !bias)
     return gemm_f64(static_cast<const double*>(A), sam, sak, static_cast<const double*>(B), sbk, sbn,
                     static_cast<double*>(C), ldc, M, N, K, alpha, false, 1, st);

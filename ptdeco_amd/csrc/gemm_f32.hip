@@ -474,9 +474,12 @@ __global__ __launch_bounds__(512, 1) void gemm_f32_nt_8ph_kernel(const GemmF32Ar
 // K split of the generic kernel for products with few output tiles: the partial tiles are added in index
 // order, so the result does not depend on scheduling.  Returns 1 when splitting does not pay.
 int gemm_f32_ksplit(int64_t M, int64_t N, int64_t K) {
+  // 512 workgroups are resident at once (two per CU); a workgroup keeps at least four K steps (its prologue and
+  // its 64 KiB of partial tile are paid once).  T = 1576 rows of a ViT batch against 768 columns are 78 tiles:
+  // unsplit, 78 CUs worked through K = 3072 alone (270 us; six ranges of 16 steps: 80).
   const int64_t tiles = ceil_div(M, BM) * ceil_div(N, BN);
-  if (tiles >= 160 || K < 16 * BK) return 1;
-  const int64_t ks = std::min<int64_t>(std::min<int64_t>(ceil_div(256, tiles), K / (8 * BK)), 16);
+  if (tiles >= 256 || K < 8 * BK) return 1;
+  const int64_t ks = std::min<int64_t>(std::min<int64_t>(512 / tiles, K / (4 * BK)), 16);
   return (int)std::max<int64_t>(ks, 1);
 }
 

@@ -4,6 +4,7 @@ PyTorch-ROCm; all arithmetic happens in libptdeco_hip.so)."""
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Optional
 
 import torch
@@ -299,6 +300,9 @@ def tridiagonalize(A: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor, torch.T
     return d, e, w
 
 
+_GEMM_WS = os.environ.get("PTD_GEMM_WS", "1") != "0"
+
+
 def matmul(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = None, alpha: float = 1.0,
            out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
     """a [M, K] @ b [K, N] (+ bias[N]); a and b may be transposed views (no copies are made
@@ -313,9 +317,13 @@ def matmul(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = None
     c = torch.empty((M, N), dtype=out_dtype, device=a.device)
     if bias is not None:
         bias = bias.to(a.dtype).contiguous()
+    lib = _hip.load()
+    # few output tiles (a ViT batch's 1576 rows against 768 columns): the K range is split through a workspace
+    ws_bytes = lib.ptd_gemm_workspace_bytes(M, N, K, _code(a), _DT[out_dtype]) if _GEMM_WS else 0
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a.device) if ws_bytes else None
     with torch.cuda.device(a.device):
-        rc = _hip.load().ptd_gemm(a.data_ptr(), sam, sak, b.data_ptr(), sbk, sbn, c.data_ptr(), N, M, N, K, _code(a),
-                                  _DT[out_dtype], float(alpha), _ptr(bias), _stream(a))
+        rc = lib.ptd_gemm_ws(a.data_ptr(), sam, sak, b.data_ptr(), sbk, sbn, c.data_ptr(), N, M, N, K, _code(a),
+                             _DT[out_dtype], float(alpha), _ptr(bias), _ptr(ws), ws_bytes, _stream(a))
     _hip.check(rc, "ptd_gemm")
     return c
 
