@@ -445,11 +445,21 @@ C4_BLOCK_KW = dict(num_data_steps=8, num_metric_steps=2, nsr_final_threshold=1.0
                    blacklisted_module_names=["head"], precomputing_covariance_num_splits=1)
 
 
-def llama_workload(device, blocks, dt):
+METRIC_POOL = 16    # metric batches the headline's iterator cycles over: more than the 14 draws of a layer's rank search
+
+
+def llama_workload(device, blocks, dt, metric_pool=METRIC_POOL):
     """BASELINE configs[3] in small: a stack of `blocks` full-width Llama-3-8B blocks (q, k, v, o, gate, up, down at 4096 /
     1024 / 14336 + the blacklisted head), seeded weights and [1, 2048, 4096] batches already on the device, and
     step(trace=None) -> decompose_config of ONE dwain.decompose_in_place call on a fresh copy (precompute pass, one split).
-    Identical on every rank (same seeds).  Returns (step, keyword arguments)."""
+    Identical on every rank (same seeds).  Returns (step, keyword arguments).
+
+    The metric iterator cycles over `metric_pool` batches.  The default, 16, is more than the 7 candidates x M = 2 draws
+    of one layer's rank search, so NO batch comes round again within a layer -- what the reference's trainers feed
+    (one infinite iterator over a DataLoader for both arguments, examples/trainer_llm/run_decompose_dwain.py:203-223) --
+    and every (candidate, batch) pair runs its candidate and its original forward.  metric_pool = 4 is the side line
+    `metric_batches_recurring`: batches recur within a layer, and the engine then runs the model ahead of the layer and the
+    original model once per batch and layer (PrefixMemo across candidates) -- never part of `value`."""
     import ptdeco_amd
 
     # (a layer's share of the parameters shrinks with the depth: the trade-off factor scales with the number of blocks)
@@ -462,13 +472,13 @@ def llama_workload(device, blocks, dt):
             prm.copy_(torch.randn(prm.shape, generator=g, device=device) / prm.shape[1] ** 0.5)
     model0.to(dt)
     scale = torch.logspace(0, -2, D_MODEL, device=device)
-    xs = [(torch.randn(1, 2048, D_MODEL, generator=g, device=device) * scale).to(dt) for _ in range(12)]
+    xs = [(torch.randn(1, 2048, D_MODEL, generator=g, device=device) * scale).to(dt) for _ in range(8 + metric_pool)]
     with torch.no_grad():
         bt = [{"x": x, "targets": model0({"x": x}).argmax(-1)} for x in xs]
 
     def step(trace=None):
         m = copy.deepcopy(model0)
-        return ptdeco_amd.dwain.decompose_in_place(module=m, device=device, data_iterator=itertools.cycle(bt),
+        return ptdeco_amd.dwain.decompose_in_place(module=m, device=device, data_iterator=itertools.cycle(bt[:12]),
                                                    loss_fn=seq_ce, metric_iterator=itertools.cycle(bt[8:]),
                                                    finetune_fn=lambda mm, d, n: mm, trace=trace, **kw)
     return step, kw
@@ -477,9 +487,9 @@ def llama_workload(device, blocks, dt):
 def llama_workload_text(blocks, kw, dt):
     name = dt if isinstance(dt, str) else ("bf16" if dt == torch.bfloat16 else "f32")
     return ("dwain.decompose_in_place, %d Llama-3-8B-width block(s) (%d layers) + blacklisted head, %s model, f64 "
-            "covariance + eigh, [1, 2048, 4096] batches, D = 8, M = 2, precompute pass (1 split), trade_off_factor %g, "
-            "max_accepted_ppl_diff 0.4; layers are replaced as the search goes"
-            % (blocks, 7 * blocks, name, kw["trade_off_factor"]))
+            "covariance + eigh, [1, 2048, 4096] batches, D = 8, M = 2 (metric iterator over %d batches: none recurs "
+            "within a layer's search), precompute pass (1 split), trade_off_factor %g, max_accepted_ppl_diff 0.4; layers "
+            "are replaced as the search goes" % (blocks, 7 * blocks, name, METRIC_POOL, kw["trade_off_factor"]))
 
 
 def phase_split(step):
@@ -623,12 +633,15 @@ def c1_cpu_line():
     return {"seconds": time.perf_counter() - t0, "layers": 4, "decomposed": len(cfg), "cores": cores}
 
 
-def c3_line(device, depth=12, batch=8):
+def c3_line(device, depth=12, batch=8, pool_size=64):
     """BASELINE configs[2]: falor.decompose_in_place (reference falor.py:424-511) on the ViT-B/16-shaped clone
     (tests/toy_models.ViT: timm vit_base_patch16_224 layer names and shapes, 48 block Linears + head = 49 layers at depth 12),
     random weights, synthetic [8, 3, 224, 224] images, the reference trainer's settings: D = 5, M = 5
     (decompose_falor.yaml:21-22), thresholds 0.01 (:18-19), proportion_threshold 0.9, use_float64, use_mean=False,
-    use_damping=True (run_decompose_falor.py:92-93).  One warm-up call at depth 1, then ONE timed call at full depth."""
+    use_damping=True (run_decompose_falor.py:92-93).  One warm-up call at depth 1, then ONE timed call at full depth.
+    The data iterator cycles over `pool_size` batches; a layer draws 5 + 9 x 5 = 50 of them, so with the default 64 no
+    batch recurs within a layer (the reference trainer streams a DataLoader); pool_size = 24 is the side line
+    `c3_recurring_batches`, where the engine's reuse across candidates engages."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import ptdeco_amd
     import toy_models as tm
@@ -637,7 +650,7 @@ def c3_line(device, depth=12, batch=8):
     kw = dict(proportion_threshold=0.9, nsr_final_threshold=0.01, kl_final_threshold=0.01, num_data_steps=5,
               num_metric_steps=5, use_float64=True, use_mean=False, use_damping=True)
     g = torch.Generator().manual_seed(1)
-    pool = [torch.randn(batch, 3, 224, 224, generator=g).to(device) for _ in range(24)]
+    pool = [torch.randn(batch, 3, 224, 224, generator=g).to(device) for _ in range(pool_size)]
 
     def run(d, phases):
         model = tm.ViT(depth=d)
@@ -663,8 +676,8 @@ def c3_line(device, depth=12, batch=8):
     return {"seconds": dt, "layers": layers, "layers_per_s": layers / dt, "candidates_evaluated": len(trace),
             "decomposed": len(cfg), "phases_ms": ph,
             "workload": "falor.decompose_in_place, ViT-B/16-shaped clone depth %d (%d Linear layers), f32 model, f64 covariance "
-                        "+ eigh, [%d,3,224,224] images, D=5, M=5, use_mean=False, use_damping=True, thresholds 0.01 / 0.9"
-                        % (depth, layers, batch)}
+                        "+ eigh, [%d,3,224,224] images (iterator over %d batches), D=5, M=5, use_mean=False, use_damping=True, thresholds 0.01 / 0.9"
+                        % (depth, layers, batch, pool_size)}
 
 
 def roofline_from_profile(prof, device):
@@ -828,7 +841,10 @@ def measure(args):
     detail = {"step_ms": marks, "replaced": kept(cfg),
               "metric_forwards": "every (candidate, batch) pair runs the stack twice as the reference does; the second run "
                                  "reuses the layer outputs ahead of the analysed layer that the first run of the SAME pair just "
-                                 "computed (PTD_PREFIX_MEMO_MB=0 switches that off); nothing is kept across pairs, layers or steps"}
+                                 "computed (PTD_PREFIX_MEMO_MB=0 switches that off).  The metric iterator cycles over %d "
+                                 "batches, a layer's search draws 14: no batch recurs within a layer, so nothing is reused "
+                                 "across pairs, layers or steps (the engine's reuse across candidates for recurring batches "
+                                 "is measured apart: metric_batches_recurring)" % METRIC_POOL}
 
     # ---- one more, untimed step with the phase spans (every rank takes part: the step contains collectives)
     if not args.no_extras:
@@ -889,12 +905,37 @@ def measure(args):
             return None
 
     if not args.no_extras:
+        def recurring():
+            # the same stack with a metric iterator over FOUR batches: batches recur within a layer's search and the engine
+            # runs the model ahead of the layer and the original model once per batch and layer (never part of `value`)
+            from ptdeco_amd._engine import PrefixMemo
+            step4, _kw = llama_workload(device, args.blocks, torch.bfloat16, metric_pool=4)
+            step4()
+            torch.cuda.synchronize()
+            marks4 = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                step4()
+                torch.cuda.synchronize()
+                marks4.append(round((time.perf_counter() - t0) * 1e3, 1))
+            ph4, _trace, _cfg = phase_split(step4)
+            return {"metric_pool": 4, "step_ms": marks4, "ms_per_step": sorted(marks4)[1], "phases_ms": ph4,
+                    "what": "PrefixMemo across candidates (SURVEY 8f-2): per layer the prefix and the original output of a "
+                            "batch are computed at its first visit; PTD_MEMO_ACROSS_CANDIDATES=0 switches it off"}
+        rec = side("metric_batches_recurring", recurring)
+        if rec:
+            detail["metric_batches_recurring"] = rec
+            result["recurring_batches_ms_per_step"] = rec["ms_per_step"]
         if not args.no_c3:
             c3 = side("c3", lambda: c3_line(device))
             if c3:
                 result["c3_s"] = c3["seconds"]
                 result["c3_layers_per_s"] = c3["layers_per_s"]
                 detail["c3"] = c3
+            c3r = side("c3_recurring", lambda: c3_line(device, pool_size=24))
+            if c3r:
+                result["c3_recurring_batches_s"] = c3r["seconds"]
+                detail["c3_recurring_batches"] = c3r
         kl = side("kernels", lambda: kernel_lines(device))
         if kl:
             detail["kernels"] = kl

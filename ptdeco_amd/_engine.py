@@ -194,6 +194,19 @@ class PrefixMemo:
     the subtree as it found them; otherwise its products are kept one by one as in (1).
     ``PTD_PREFIX_MEMO_UNITS=products`` keeps to (1).
 
+    Across candidates (round 6; SURVEY 8f-2 "share the y_orig forward across candidates").  The rank search of one layer
+    evaluates candidate after candidate on metric batches that come round again (an iterator cycling over a few
+    batches), and between two candidates of a layer nothing of the model changes but the tapped layer: what ran ahead of
+    it for batch b is the same for every candidate, and so is the ORIGINAL model's output on b.  With a batch key
+    (`batch_key`: the identities, version counters and addresses of the batch's tensors, a sampled fingerprint of host
+    tensors; the batch object is pinned while its entries live) the prefix outputs of a batch are kept for the layer's
+    whole search (`first(key)` replays them for the next candidate) and the original output is kept beside them
+    (`orig_get` / `orig_put`: the second forward of a pair is not run at all).  The first replay of either kind in a
+    memo's life is recomputed and compared like the in-pair self-check.  At most half the byte budget holds such
+    persistent entries (PTD_MEMO_KEYS batches, default 64); a batch that does not fit is handled as before (kept for
+    its own pair only).  Everything is dropped when the layer's search ends (`close`).  PTD_MEMO_ACROSS_CANDIDATES=0:
+    nothing outlives a pair.
+
     Guards: recording stops at the tapped layer's first call and when the byte budget is spent; entries are keyed by
     the call index of their module within the forward (weight sharing, a module called again behind the tapped layer);
     a kept tensor that was modified in place since (``relu_`` on a conv output: the version counter), an inference
@@ -232,6 +245,21 @@ class PrefixMemo:
         self.hits = 0
         self.unit_hits = 0
         self._gen = 0            # forward counter
+        import collections
+        import os
+
+        self._key = None         # store of the running forward: a batch key, or ("pair", n) for a pair of its own
+        self._stores: "collections.OrderedDict" = collections.OrderedDict()   # key -> {as_unit, bytes, persistent, done, pin, slots}
+        self._pending = None     # a non-persistent store whose pair has not released it yet
+        self.persist_bytes = 0
+        self.across = os.environ.get("PTD_MEMO_ACROSS_CANDIDATES", "1") != "0"
+        self.max_keys = max(0, int(os.environ.get("PTD_MEMO_KEYS", "64")))
+        self._verify = False     # this forward recomputes what it is about to hand back
+        self.cross_check = self_check    # the first replay in a FIRST forward (another candidate's prefix) compares
+        self.orig_check = self_check     # the first original output handed back compares
+        self._orig: dict = {}    # batch key -> (output nest, its tensors, their versions, pinned batch)
+        self.orig_hits = 0
+        self.prefix_replays = 0  # first forwards that ran on another candidate's prefix
         self._seq = 0            # calls that reached a patched forward at depth 0 in this forward: the entries' keys
         self._as_unit: set = set()   # keys of the calls that ran a subtree as ONE unit while recording
         self._depth = 0          # > 0 while a subtree runs as a unit: the patched modules inside it are transparent
@@ -423,20 +451,25 @@ class PrefixMemo:
                     return out
                 nbytes = sum(t.numel() * t.element_size() for t in {id(t): t for t in flat}.values())
                 if self.bytes + nbytes <= self.budget:
-                    kept[idx] = (out, flat, [t._version for t in flat], self._first_shape(args, kwargs))
+                    kept[(self._key, idx)] = (out, flat, [t._version for t in flat], self._first_shape(args, kwargs))
                     self.bytes += nbytes
+                    store = self._stores[self._key]
+                    store["bytes"] += nbytes
+                    store["slots"].append((kept, (self._key, idx)))
+                    if store["persistent"] and self.persist_bytes + store["bytes"] > self.budget // 2:
+                        store["persistent"] = False      # (does not fit the persistent half: this pair only)
                 else:
                     self.full = True
                 return out
             # REPLAY
             as_unit = unit and idx in self._as_unit
-            entry = kept.pop(idx, None)
+            entry = kept.get((self._key, idx))
             if entry is not None:
                 out, flat, versions, shape = entry
                 if all(t._version == v for t, v in zip(flat, versions)) and self._first_shape(args, kwargs) == shape:
                     if self.check:
                         self._compare(m, whole(args, kwargs) if as_unit else inner(*args, **kwargs), out)
-                    elif self.self_check:
+                    elif self._verify:
                         again = whole(args, kwargs) if as_unit else inner(*args, **kwargs)
                         if not self._same(again, out):
                             self._step_down(m, unit)
@@ -454,29 +487,72 @@ class PrefixMemo:
     def _drop(self) -> None:
         for _, kept in self._patched:
             kept.clear()
+        self._stores.clear()
+        self._orig.clear()
+        self._pending = None
         self.bytes = 0
+        self.persist_bytes = 0
 
-    def first(self):
-        """Context of the first forward of a metric step: outputs are kept."""
+    def _release(self, key) -> None:
+        store = self._stores.pop(key, None)
+        if store is None:
+            return
+        for kept, slot in store["slots"]:
+            kept.pop(slot, None)
+        self.bytes -= store["bytes"]
+        if store["done"] and store["persistent"]:
+            self.persist_bytes -= store["bytes"]
+
+    def first(self, key=None, pin=None):
+        """Context of the first forward of a metric step: outputs are kept -- or, with a batch `key` whose prefix an
+        earlier candidate recorded, handed back."""
         import contextlib
 
         @contextlib.contextmanager
         def cm():
-            self._drop()
+            if self._pending is not None:       # (a pair that ended without its second forward)
+                self._release(self._pending)
+                self._pending = None
             self.reached = self.full = False
             self._gen += 1
             self._seq = 0
-            self._as_unit = set()
             self._depth = 0
-            self.mode = self.IDLE if self.disabled else self.RECORD
+            k = key if (self.across and key is not None) else None
+            store = self._stores.get(k) if k is not None else None
+            if self.disabled:
+                self.mode = self.IDLE
+            elif store is not None and store["done"] and store["persistent"]:
+                self._key, self._as_unit = k, store["as_unit"]
+                self.mode = self.REPLAY
+                self._verify = self.cross_check
+                self.prefix_replays += 1
+            else:
+                if store is not None:
+                    self._release(k)
+                self._key = k if k is not None else ("pair", self._gen)
+                self._as_unit = set()
+                self._stores[self._key] = {"as_unit": self._as_unit, "bytes": 0, "done": False, "pin": pin, "slots": [],
+                                           "persistent": k is not None and len(self._stores) < self.max_keys}
+                self.mode = self.RECORD
             try:
                 yield
             finally:
+                if self.mode == self.REPLAY:
+                    self.cross_check = False
+                elif self.mode == self.RECORD:
+                    store = self._stores.get(self._key)
+                    if store is not None and not store["done"]:
+                        store["done"] = True
+                        if store["persistent"]:
+                            self.persist_bytes += store["bytes"]
+                        else:
+                            self._pending = self._key
+                self._verify = False
                 self.mode = self.IDLE
         return cm()
 
-    def second(self):
-        """Context of the second forward: kept outputs are handed back, then released."""
+    def second(self, key=None):
+        """Context of the second forward: kept outputs are handed back; what was kept for this pair alone is released."""
         import contextlib
 
         @contextlib.contextmanager
@@ -484,14 +560,48 @@ class PrefixMemo:
             self._gen += 1
             self._seq = 0
             self._depth = 0
-            self.mode = self.IDLE if self.disabled else self.REPLAY
+            store = self._stores.get(self._key)
+            if self.disabled or store is None:
+                self.mode = self.IDLE
+            else:
+                self._as_unit = store["as_unit"]
+                self.mode = self.REPLAY
+                self._verify = self.self_check
             try:
                 yield
             finally:
                 self.mode = self.IDLE
                 self.self_check = False
-                self._drop()
+                self._verify = False
+                if self._pending is not None:
+                    self._release(self._pending)
+                    self._pending = None
         return cm()
+
+    # the ORIGINAL model's output on a batch, kept for the other candidates of the layer (see the class comment)
+    def orig_get(self, key):
+        if not self.across or self.disabled or key is None:
+            return None
+        entry = self._orig.get(key)
+        if entry is None:
+            return None
+        out, flat, versions, _pin = entry
+        if not all(t._version == v for t, v in zip(flat, versions)):
+            self._orig.pop(key, None)
+            return None
+        return out
+
+    def orig_put(self, key, out, pin=None) -> None:
+        if not self.across or self.disabled or key is None or key in self._orig or len(self._orig) >= self.max_keys:
+            return
+        flat: list = []
+        if not _flat_tensors(out, flat) or not flat or any(t.is_inference() for t in flat):
+            return
+        nbytes = sum(t.numel() * t.element_size() for t in {id(t): t for t in flat}.values())
+        if self.bytes + nbytes > self.budget:
+            return
+        self.bytes += nbytes
+        self._orig[key] = (out, flat, [t._version for t in flat], pin)
 
     def close(self) -> None:
         self._drop()
@@ -500,18 +610,53 @@ class PrefixMemo:
         self._patched = []
 
 
-def forward_pair(root: torch.nn.Module, tap: "LayerTap", x, first_setup, second_setup):
+def batch_key(batch):
+    """Identity of a batch as the data iterator handed it over: for every tensor in it (id, version counter, address, shape,
+    dtype) and, for host tensors, 64 sampled values (a buffer refilled from outside torch -- numpy writing into
+    `torch.from_numpy` memory -- does not bump the counter).  None when the batch holds anything but tensors and plain
+    values.  The caller pins the batch object while it uses the key, so an id cannot come round on another tensor."""
+    flat: list = []
+    if not _flat_tensors(batch, flat) or not flat:
+        return None
+    parts = []
+    for t in flat:
+        if t.is_inference():
+            return None
+        part = (id(t), t._version, t.data_ptr(), tuple(t.shape), t.dtype, t.device.type)
+        if t.device.type == "cpu" and t.numel() > 0 and t.layout == torch.strided:
+            v = t.detach().reshape(-1) if t.is_contiguous() else t.detach().flatten()
+            sample = v[:: max(1, v.numel() // 64)][:64]
+            part += (tuple(sample.to(torch.float64).tolist()) if not sample.is_complex() else (),)
+        parts.append(part)
+    return tuple(parts)
+
+
+def forward_pair(root: torch.nn.Module, tap: "LayerTap", x, first_setup, second_setup, key=None, pin=None):
     """The two forwards of one metric step: ``first_setup()``, model, ``second_setup()``, model -- the second reusing
-    what the first computed ahead of the tapped layer (PrefixMemo) when the tap carries a memo."""
+    what the first computed ahead of the tapped layer (PrefixMemo) when the tap carries a memo.  With a batch `key`
+    (batch_key of the batch `pin` as the iterator yielded it) the first forward runs on the prefix an earlier candidate
+    of this layer recorded for the same batch, and the second -- the original model on that batch, the same for every
+    candidate -- is run once per batch and layer."""
     import contextlib
 
     memo = tap.memo
     first_setup()
-    with memo.first() if memo is not None else contextlib.nullcontext():
+    with memo.first(key, pin) if memo is not None else contextlib.nullcontext():
         y_first = root(x)
+    cached = memo.orig_get(key) if memo is not None else None
+    if cached is not None and not memo.orig_check:
+        memo.orig_hits += 1
+        return y_first, cached
     second_setup()
-    with memo.second() if memo is not None else contextlib.nullcontext():
+    with memo.second(key) if memo is not None else contextlib.nullcontext():
         y_second = root(x)
+    if memo is not None and key is not None:
+        if cached is not None:      # the first original output about to be handed back in this memo's life: compared
+            memo.orig_check = False
+            if not memo._same(y_second, cached):
+                memo._step_down(root, True)
+        else:
+            memo.orig_put(key, y_second, pin)
     return y_first, y_second
 
 
@@ -1000,7 +1145,22 @@ def solve_eigenproblems(posers: list, orders: list, device: torch.device, costs:
             out[i] = posers[i]().solve()
         return run
 
-    units: list = []        # (cost, first member, run)
+    timeline = os.environ.get("PTD_EIGH_TIMELINE") == "1" and device.type == "cuda"
+    marks: list = []        # (label, start event, end event): PTD_EIGH_TIMELINE=1, read back through LAST_TIMELINE
+
+    def timed(label, run):
+        if not timeline:
+            return run
+
+        def wrapped():
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            run()
+            e1.record()
+            marks.append((label, e0, e1))
+        return wrapped
+
+    units: list = []        # (cost, first member, run, matrix-core-bound?)
     for (n, k), members in groups.items():
         route = int(lib.ptd_eigh_route(n, k, 0)) if lib is not None else 1
         if route == 1 and len(members) >= 2 and cap >= 2:
@@ -1010,21 +1170,24 @@ def solve_eigenproblems(posers: list, orders: list, device: torch.device, costs:
                 chunks[-2].extend(chunks.pop())
             for chunk in chunks:
                 if len(chunk) >= 2:
-                    units.append((0.85 * sum(costs[i] for i in chunk), chunk[0], batch_unit(chunk)))
+                    units.append((0.85 * sum(costs[i] for i in chunk), chunk[0],
+                                  timed(f"batch{len(chunk)} n={n} k={k}", batch_unit(chunk)), False))
                 else:
-                    units.append((costs[chunk[0]], chunk[0], single_unit(chunk[0])))
+                    units.append((costs[chunk[0]], chunk[0], timed(f"single n={n} k={k}", single_unit(chunk[0])), False))
         else:
-            units.extend((costs[i], i, single_unit(i)) for i in members)
+            units.extend((costs[i], i, timed(f"single n={n} k={k} route={route}", single_unit(i)), route == 3) for i in members)
     # longest first (ties: model order) to the lane with the least work so far; inside a lane in dealing order
     units.sort(key=lambda u: (-u[0], u[1]))
     if device.type != "cuda":
         nlanes = 1
     lanes: list = [[] for _ in range(min(nlanes, max(len(units), 1)))]
     load = [0.0] * len(lanes)
-    for cost, _first, run in units:
+    for cost, _first, run, _heavy in units:
         j = min(range(len(lanes)), key=lambda q: (load[q], q))
         lanes[j].append(run)
         load[j] += cost
+        if timeline:
+            marks.append((f"plan lane {j} cost {cost:.3g}", None, None))
 
     def lane(runs):
         def run():
@@ -1033,6 +1196,10 @@ def solve_eigenproblems(posers: list, orders: list, device: torch.device, costs:
             return None
         return run
 
+    t_begin = None
+    if timeline:
+        t_begin = torch.cuda.Event(enable_timing=True)
+        t_begin.record()
     if len(lanes) == 1:
         lane(lanes[0])()
     else:
@@ -1041,7 +1208,16 @@ def solve_eigenproblems(posers: list, orders: list, device: torch.device, costs:
         for t in out:       # (allocated on a lane's stream, used from here on under the caller's)
             if isinstance(t, torch.Tensor) and t.is_cuda:
                 t.record_stream(cur)
+    if timeline:
+        global LAST_TIMELINE
+        torch.cuda.synchronize(device)
+        LAST_TIMELINE = [label for label, e0, _e1 in marks if e0 is None] + \
+            sorted((round(t_begin.elapsed_time(e0), 1), round(t_begin.elapsed_time(e1), 1), label)
+                   for label, e0, e1 in marks if e0 is not None)
     return out
+
+
+LAST_TIMELINE: list = []
 
 
 class InputMoment:
@@ -1512,8 +1688,6 @@ def run_concurrently(jobs, device: torch.device, max_streams: Optional[int] = No
     workers = len(streams)
     if workers == 1:
         return [job() for job in jobs]
-    for st in streams:
-        st.wait_stream(main)
     out: list = [None] * len(jobs)
     errors: list = []
     lock = threading.Lock()

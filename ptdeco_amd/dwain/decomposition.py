@@ -257,7 +257,7 @@ def _compute_covariance_matrix_decomposition(*, root_module, tap: eng.LayerTap, 
                                           device)
 
 
-def _compute_metrics(*, input_dict, root_module, tap: eng.LayerTap, orig_weight, candidate, loss_fn):
+def _compute_metrics(*, input_dict, root_module, tap: eng.LayerTap, orig_weight, candidate, loss_fn, key=None, pin=None):
     """:247-278 -- (nsr, ppl_deco, ppl_diff) as one f64 device tensor (single host sync per step).
     `candidate` = (uk, U, W~): evaluated through the rank-r pair when the layer qualifies
     (LayerTap.use_pair), else by copying W~ into the layer like the reference."""
@@ -266,10 +266,10 @@ def _compute_metrics(*, input_dict, root_module, tap: eng.LayerTap, orig_weight,
     uk, big_u, deco_weight = candidate
     if deco_weight is None:
         y_deco, y_orig = eng.forward_pair(root_module, tap, input_dict, lambda: tap.use_pair(big_u, uk),
-                                          lambda: tap.use_dense(orig_weight))
+                                          lambda: tap.use_dense(orig_weight), key=key, pin=pin)
     else:
         y_deco, y_orig = eng.forward_pair(root_module, tap, input_dict, lambda: tap.set_weight(deco_weight),
-                                          lambda: tap.set_weight(orig_weight))
+                                          lambda: tap.set_weight(orig_weight), key=key, pin=pin)
     loss_deco = loss_fn(input_dict, y_deco)
     loss_orig = loss_fn(input_dict, y_orig)
     nsr = utils.calc_per_channel_noise_to_signal_ratio(y=y_orig, x=y_deco, non_channel_dim=(0, 1), mode="mean")
@@ -342,9 +342,11 @@ def _process_module(*, root_module, decomposed_submodule_name, data_iterator, lo
                     with eng.phase("C_factors"):
                         candidate = bank.get(rank_new, dense=not fast)
                 with eng.phase("D_metrics"):
+                    # (a batch that comes round again within this layer's search meets the prefix and the original
+                    # output kept from its first visit: eng.PrefixMemo)
                     sums[c] += _compute_metrics(input_dict=utils.to_device(batch, device), root_module=root_module,
                                                 tap=tap, orig_weight=orig_weight, candidate=candidate,
-                                                loss_fn=loss_fn)
+                                                loss_fn=loss_fn, key=eng.batch_key(batch), pin=batch)
         if shard.active:
             with eng.phase("comm"):
                 shard.all_reduce_small(sums)

@@ -73,17 +73,17 @@ def _compute_decompositon_of_covariance_matrix(*, root_module, tap: eng.LayerTap
         return cov.eigenvectors(damp, use_mean=use_mean, top_k=top_k)
 
 
-def _compute_metrics(*, x, root_module, tap: eng.LayerTap, orig_weight, candidate) -> torch.Tensor:
+def _compute_metrics(*, x, root_module, tap: eng.LayerTap, orig_weight, candidate, key=None, pin=None) -> torch.Tensor:
     """:211-233 -- (nsr, kl) as one f64 device tensor.  `candidate` = (uk, U, W~); W~ None means
     "evaluate through the rank-r pair" (see LayerTap.use_pair)."""
     root_module.eval()
     uk, big_u, deco_weight = candidate
     if deco_weight is None:
         y_deco, y_orig = eng.forward_pair(root_module, tap, x, lambda: tap.use_pair(big_u, uk),
-                                          lambda: tap.use_dense(orig_weight))
+                                          lambda: tap.use_dense(orig_weight), key=key, pin=pin)
     else:
         y_deco, y_orig = eng.forward_pair(root_module, tap, x, lambda: tap.set_weight(deco_weight),
-                                          lambda: tap.set_weight(orig_weight))
+                                          lambda: tap.set_weight(orig_weight), key=key, pin=pin)
     nsr = utils.calc_per_channel_noise_to_signal_ratio(y=y_orig, x=y_deco, non_channel_dim=(0,))
     kl = utils.calc_kl_loss(y_deco, y_orig)
     return torch.stack([nsr, kl])
@@ -135,8 +135,12 @@ def _process_module(*, root_module, decomposed_submodule_name, data_iterator, ns
             with eng.phase("D_metrics"):
                 acc = torch.zeros(2, dtype=torch.float64, device=device)
                 for _ in range(num_metric_steps):
-                    acc += _compute_metrics(x=next(data_iterator).to(device), root_module=root_module, tap=tap,
-                                            orig_weight=orig_weight, candidate=candidate)
+                    # (a batch that comes round again within this layer's search -- an iterator cycling over a few
+                    # batches -- meets the prefix and the original output kept from its first visit: eng.PrefixMemo)
+                    batch = next(data_iterator)
+                    acc += _compute_metrics(x=batch.to(device), root_module=root_module, tap=tap,
+                                            orig_weight=orig_weight, candidate=candidate, key=eng.batch_key(batch),
+                                            pin=batch)
                 nsr_new, kl_new = (acc / num_metric_steps).tolist()
                 eng.warn_if_not_finite([nsr_new], decomposed_submodule_name)
             accepted = nsr_new < nsr_final_threshold and kl_new < kl_final_threshold

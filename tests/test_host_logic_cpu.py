@@ -1021,3 +1021,90 @@ def test_step_batch_dropped_with_pending_steps_gives_its_bytes_back(monkeypatch)
     del cov
     gc.collect()
     assert eng.StepBatch.held_bytes == held0
+
+
+class _StackNet(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.pre = torch.nn.Sequential(torch.nn.Linear(8, 8), torch.nn.Tanh(), torch.nn.Linear(8, 8))
+        self.tapped = torch.nn.Linear(8, 8)
+        self.post = torch.nn.Linear(8, 4)
+
+    def forward(self, x):
+        return self.post(torch.relu(self.tapped(self.pre(x))))
+
+
+def test_prefix_memo_across_candidates_keeps_prefix_and_original_output_per_batch():
+    """Round 6: candidates of one layer evaluated on batches that come round again.  Per batch the prefix
+    runs once for the whole search and the original model once; the values are those of running everything; a batch
+    modified in place (version counter) or refilled behind torch's back (sampled fingerprint of host tensors) is a new
+    batch; PTD_MEMO_ACROSS_CANDIDATES=0 keeps nothing beyond a pair."""
+    from ptdeco_amd import _engine as eng
+
+    torch.manual_seed(0)
+    model = _StackNet().eval()
+    batches = [torch.randn(6, 8) for _ in range(2)]
+    w_orig = model.tapped.weight.detach().clone()
+    cands = [w_orig * s for s in (0.5, 0.25, 0.125)]
+    runs = {"pre": 0, "post": 0}
+    for name in runs:
+        mod = getattr(model, name)
+        inner = type(mod).forward
+
+        def fwd(self_, *a, _n=name, _inner=inner, **k):
+            runs[_n] += 1
+            return _inner(self_, *a, **k)
+        mod.__class__ = type(f"Spy{name}", (type(mod),), {"forward": fwd})
+
+    def set_w(w):
+        def go():
+            with torch.no_grad():
+                model.tapped.weight.copy_(w)
+        return go
+
+    def search(memo_on, self_check=False):
+        tap = eng.LayerTap(model, "tapped")
+        tap.memo = eng.PrefixMemo(model, tap.layer, 1 << 30, self_check=self_check)
+        tap.memo.across = memo_on
+        out = []
+        with torch.no_grad():
+            for w in cands:
+                for b in batches:
+                    y1, y2 = eng.forward_pair(model, tap, b, set_w(w), set_w(w_orig), key=eng.batch_key(b), pin=b)
+                    out.append((y1.clone(), y2.clone()))
+        memo = tap.memo
+        stats = (memo.prefix_replays, memo.orig_hits)
+        tap.close()
+        set_w(w_orig)()
+        return out, stats
+
+    with torch.no_grad():
+        want = []
+        for w in cands:
+            for b in batches:
+                set_w(w)()
+                y1 = model(b)
+                set_w(w_orig)()
+                want.append((y1, model(b)))
+    runs.update(pre=0, post=0)
+    got, stats = search(True)
+    for (a1, a2), (b1, b2) in zip(got, want):
+        assert torch.equal(a1, b1) and torch.equal(a2, b2)
+    # 6 pairs: the prefix ran once per batch (2), the original model once per batch (2 of the 8 suffix runs)
+    assert runs == {"pre": 2, "post": 6 + 2} and stats == (4, 4)
+    runs.update(pre=0, post=0)
+    got, stats = search(True, self_check=True)      # the first replay of each kind is recomputed and compared
+    assert all(torch.equal(a1, b1) and torch.equal(a2, b2) for (a1, a2), (b1, b2) in zip(got, want))
+    assert runs == {"pre": 2 + 2, "post": 6 + 2 + 1} and stats == (4, 3)
+    runs.update(pre=0, post=0)
+    got, stats = search(False)
+    assert all(torch.equal(a1, b1) and torch.equal(a2, b2) for (a1, a2), (b1, b2) in zip(got, want))
+    assert runs == {"pre": 6, "post": 12} and stats == (0, 0)
+    # a batch changed in place, or refilled through numpy, is another batch
+    b = torch.randn(6, 8)
+    k0 = eng.batch_key(b)
+    b.add_(1.0)
+    k1 = eng.batch_key(b)
+    b.numpy()[:] = 3.0
+    assert k0 != k1 and k1 != eng.batch_key(b)
+    assert eng.batch_key({"x": b, "n": 3}) is not None and eng.batch_key({"x": b, "cache": object()}) is None

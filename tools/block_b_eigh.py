@@ -50,3 +50,6 @@ for cfg in configs:
         os.environ["PTD_LANE_STREAMS"] = "pool" if extra == "pool" else "dedicated"
         os.environ["PTD_LANE_CUS"] = extra.replace("-", ",") if extra not in ("", "pool") else ""
     print(json.dumps({"config": cfg, "step_ms, B_eigh_ms": [step() for _ in range(passes)]}), flush=True)
+    if os.environ.get("PTD_EIGH_TIMELINE") == "1":
+        for row in eng.LAST_TIMELINE:
+            print("   ", row, flush=True)

@@ -4,7 +4,7 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from ptdeco_amd import ops
 dev = torch.device("cuda", 0)
-n_o, n_i, k = 14336, 4096, 2048
+n_o, n_i, k = 14336, 4096, int(os.environ.get("K", "2048"))
 g = torch.Generator(device=dev).manual_seed(1)
 w = (torch.randn(n_o, n_i, generator=g, device=dev) / n_i ** 0.5).bfloat16()
 scale = torch.logspace(0, -2, n_i, device=dev)
