@@ -7,6 +7,10 @@ import itertools, json, os, sys, threading, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import transformers
 import ptdeco_amd
+
+# metric batches the iterator cycles over: 16 > the 14 draws of a layer's search (none recurs within a layer, as with a
+# streamed DataLoader); METRIC_POOL=4: batches recur and the engine's reuse across candidates engages
+METRIC_POOL = int(os.environ.get("METRIC_POOL", "16"))
 from ptdeco_amd import _engine as eng
 
 dev = torch.device("cuda", 0)
@@ -55,7 +59,7 @@ def ce(b, y):
     return torch.nn.functional.cross_entropy(y.float().reshape(-1, y.shape[-1]), b["targets"].reshape(-1), reduction="none")
 
 
-ids = [torch.randint(0, 128256, (1, 2048), generator=g, device=dev) for _ in range(12)]
+ids = [torch.randint(0, 128256, (1, 2048), generator=g, device=dev) for _ in range(8 + METRIC_POOL)]
 with torch.no_grad():
     bt = [{"ids": i, "targets": model({"ids": i}).argmax(-1)} for i in ids]
 torch.cuda.synchronize()
@@ -79,7 +83,7 @@ def heartbeat():
 threading.Thread(target=heartbeat, daemon=True).start()
 hits0 = eng.PrefixMemo.total_hits
 cfg = ptdeco_amd.dwain.decompose_in_place(
-    module=model, device=dev, data_iterator=itertools.cycle(bt), loss_fn=ce, metric_iterator=itertools.cycle(bt[8:]),
+    module=model, device=dev, data_iterator=itertools.cycle(bt[:12]), loss_fn=ce, metric_iterator=itertools.cycle(bt[8:]),
     num_data_steps=8, num_metric_steps=2, nsr_final_threshold=1.0, finetune_fn=lambda m, d, n: m,
     trade_off_factor=trade_off, max_accepted_ppl_diff=max_ppl, blacklisted_module_names=["m.lm_head"],
     precomputing_covariance_num_splits=4, trace=trace)
@@ -92,7 +96,7 @@ if eng.PHASES is not None:
     phases["other_host_and_gaps"] = round(dt * 1e3 - sum(phases.values()), 1)
 n_layers = 7 * layers
 checked = sample_check.verify(armed, model, cfg)
-print(json.dumps({"sample_check": checked,
+print(json.dumps({"sample_check": checked, "metric_pool": METRIC_POOL,
                   "workload": f"dwain.decompose_in_place, transformers.LlamaForCausalLM (transformers {transformers.__version__}), "
                               f"Llama-3-8B architecture at {layers} decoder layers ({n_layers} Linear layers; lm_head 4096 -> 128256 "
                               f"blacklisted), attention = {attn}, random bf16 weights, token batches [1, 2048], D = 8, M = 2, "

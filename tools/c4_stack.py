@@ -7,6 +7,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import ptdeco_amd
 
+# metric batches the iterator cycles over: 16 > the 14 draws of a layer's search (none recurs within a layer, as with a
+# streamed DataLoader); METRIC_POOL=4: batches recur and the engine's reuse across candidates engages
+METRIC_POOL = int(os.environ.get("METRIC_POOL", "16"))
+
 dev = torch.device("cuda", 0)
 blocks = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 dtype = torch.bfloat16 if "bf16" in sys.argv else torch.float32
@@ -65,7 +69,7 @@ with torch.device(dev):
 with torch.no_grad():
     for p in model.parameters():
         p.copy_((torch.randn(p.shape, generator=g, device=dev) / p.shape[1] ** 0.5).to(dtype))
-xs = [torch.randn(1, 2048, D, generator=g, device=dev).to(dtype) for _ in range(12)]
+xs = [torch.randn(1, 2048, D, generator=g, device=dev).to(dtype) for _ in range(8 + METRIC_POOL)]
 with torch.no_grad():
     bt = [{"x": x, "targets": model({"x": x}).argmax(-1)} for x in xs]
 torch.cuda.synchronize()
@@ -86,7 +90,7 @@ done = threading.Event()
 t0 = time.perf_counter()
 threading.Thread(target=heartbeat, daemon=True).start()
 cfg = ptdeco_amd.dwain.decompose_in_place(
-    module=model, device=dev, data_iterator=itertools.cycle(bt), loss_fn=ce, metric_iterator=itertools.cycle(bt[8:]),
+    module=model, device=dev, data_iterator=itertools.cycle(bt[:12]), loss_fn=ce, metric_iterator=itertools.cycle(bt[8:]),
     num_data_steps=8, num_metric_steps=2, nsr_final_threshold=1.0, finetune_fn=lambda m, d, n: m,
     trade_off_factor=trade_off, max_accepted_ppl_diff=max_ppl,
     blacklisted_module_names=["head"], precomputing_covariance_num_splits=4, trace=trace)
@@ -99,7 +103,7 @@ if eng.PHASES is not None:
     phases["other_host_and_gaps"] = round(dt * 1e3 - sum(phases.values()), 1)
 layers = 7 * blocks
 checked = sample_check.verify(armed, model, cfg)
-print(json.dumps({"sample_check": checked,
+print(json.dumps({"sample_check": checked, "metric_pool": METRIC_POOL,
                   "workload": f"dwain.decompose_in_place, Llama-3-8B-shaped stack, {blocks} blocks x (q, k, v, o, gate, up, down) at "
                               "4096 / 1024 / 14336 + blacklisted head, [1, 2048, 4096] calibration batches, D = 8, M = 2, "
                               "precomputing_covariance_num_splits = 4, f64 covariance + eigh, one MI355X",
