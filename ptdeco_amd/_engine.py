@@ -219,6 +219,7 @@ class PrefixMemo:
     UNKNOWN, PURE, IMPURE, RANDOM = 0, 1, 2, 3     # RANDOM: the subtree drew from a global random generator -- what runs
                                                    # behind it sees other values in the second forward: recording stops there
     total_hits = 0      # outputs handed back since the process started (tests, tools)
+    total_orig_hits = 0   # second forwards not run: the original output of the batch was kept from an earlier candidate
     # Self-check (round 5): the FIRST metric step of every layer recomputes each output it is about to hand back and
     # compares (one extra partial forward per layer).  A mismatch -- a model that is not a function of its input ahead
     # of the layer in a way the purity test did not see -- costs nothing but speed: the recomputed value is used, one
@@ -646,6 +647,7 @@ def forward_pair(root: torch.nn.Module, tap: "LayerTap", x, first_setup, second_
     cached = memo.orig_get(key) if memo is not None else None
     if cached is not None and not memo.orig_check:
         memo.orig_hits += 1
+        PrefixMemo.total_orig_hits += 1
         return y_first, cached
     second_setup()
     with memo.second(key) if memo is not None else contextlib.nullcontext():

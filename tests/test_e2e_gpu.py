@@ -131,16 +131,19 @@ def test_dwain_end_to_end(name):
                                          ("falor", "falor_mlp_r9"), ("falor", "falor_conv")])
 def test_metric_steps_with_and_without_the_prefix_memo_are_bit_identical(method, name, monkeypatch):
     """The second forward of a metric step reuses the products ahead of the analysed layer (_engine.PrefixMemo):
-    every reused output is recomputed and compared (CHECK), and the metrics equal the ones of a run without it."""
+    every reused output is recomputed and compared (CHECK), and the metrics equal the ones of a run without it.
+    Round 6: the scenarios' iterators cycle over a few batches, so batches recur within a layer's search and the prefix
+    and the original output of a batch are kept across the layer's candidates -- same metrics bit for bit with that
+    switched off (PTD_MEMO_ACROSS_CANDIDATES=0) and with no memo at all."""
     import ptdeco_amd
     from ptdeco_amd import _engine as eng
 
     scn = gio.e2e_meta()[name]
     traces = []
-    for env in ({"PTD_PREFIX_MEMO_CHECK": "1"}, {"PTD_PREFIX_MEMO_MB": "0"}):
+    for env in ({"PTD_PREFIX_MEMO_CHECK": "1"}, {"PTD_PREFIX_MEMO_MB": "0"}, {"PTD_MEMO_ACROSS_CANDIDATES": "0"}, {}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
-        hits0 = eng.PrefixMemo.total_hits
+        hits0, orig0 = eng.PrefixMemo.total_hits, eng.PrefixMemo.total_orig_hits
         model = gio.build_model(scn).to(DEV)
         trace = []
         if method == "dwain":
@@ -152,14 +155,37 @@ def test_metric_steps_with_and_without_the_prefix_memo_are_bit_identical(method,
             ptdeco_amd.falor.decompose_in_place(
                 module=model, device=DEV, data_iterator=tm.cycle_tensors(gio.pool(scn["pool"])), trace=trace,
                 **scn["kwargs"])
-        traces.append((trace, eng.PrefixMemo.total_hits - hits0))
+        traces.append((trace, eng.PrefixMemo.total_hits - hits0, eng.PrefixMemo.total_orig_hits - orig0))
         for k in env:
             monkeypatch.delenv(k)
         assert all("forward" not in m.__dict__ for m in model.modules())
-    assert traces[0][0] == traces[1][0]
-    assert traces[1][1] == 0
+    assert traces[0][0] == traces[1][0] == traces[2][0] == traces[3][0]
+    assert traces[1][1] == 0 and traces[1][2] == 0 and traces[2][2] == 0
+    if method == "dwain":
+        assert traces[3][2] > 0    # the default: second forwards were saved on recurring batches
     if name.endswith("nosplit") or name.endswith("r9"):
         assert traces[0][1] > 0       # the MLPs have layers ahead of fc2 / fc3
+
+
+def test_falor_on_a_two_batch_iterator_reuses_prefix_and_original_output_across_candidates(monkeypatch):
+    """falor's bisection draws M batches per candidate from the data iterator; with an iterator over TWO batches every
+    candidate after the first meets batches the layer has seen: the same trace bit for bit as with
+    PTD_MEMO_ACROSS_CANDIDATES=0, with second forwards saved."""
+    import ptdeco_amd
+    from ptdeco_amd import _engine as eng
+
+    scn = gio.e2e_meta()["falor_mlp_r9"]
+    runs = []
+    for across in ("1", "0"):
+        monkeypatch.setenv("PTD_MEMO_ACROSS_CANDIDATES", across)
+        orig0 = eng.PrefixMemo.total_orig_hits
+        model = gio.build_model(scn).to(DEV)
+        trace = []
+        ptdeco_amd.falor.decompose_in_place(module=model, device=DEV, trace=trace,
+                                            data_iterator=tm.cycle_tensors(list(gio.pool(scn["pool"]))[:2]), **scn["kwargs"])
+        runs.append((trace, eng.PrefixMemo.total_orig_hits - orig0))
+    assert runs[0][0] == runs[1][0] and len(runs[0][0]) > 2
+    assert runs[0][1] > 0 and runs[1][1] == 0
 
 
 @pytest.mark.parametrize("method,name", [("dwain", "dwain_mlp_nosplit"), ("falor", "falor_mlp_r9"), ("falor", "falor_conv")])
