@@ -1105,7 +1105,8 @@ def solve_eigenproblems(posers: list, orders: list, device: torch.device, costs:
     other interleave their columns.  Measured on one Llama-3-8B-width block (three (4096, 2048) direct problems, two
     filtered (4096, 1024), two (1024, 512); B_eigh, gpurun_out/r06_block_c.txt): everything on one stream 238 ms; two
     lanes with batches of <= 2 / 3 / 4: 247 / 196 / 196; three lanes with batches of <= 2: 193.5 +- 0.2 (two blocks:
-    400.6 +- 0.1); round 5's seven chains dealt dynamically to four threads 184-190 (two blocks 397-404).  The three
+    400.6 +- 0.1; with the filtered problems costed like direct ones, eigh_cost_hint: 184 / 389); round 5's seven chains
+    dealt dynamically to four threads 184-190 (two blocks 397-404).  The three
     direct problems stream 275 GB of trailing triangles whatever the arrangement (~57 ms at the rate the SYMV reaches),
     and every arrangement lands within 5 % of the others once three chains share the chip: what the lanes buy is that
     the time no longer depends on which hardware queue a stream happens to sit on or on which chain finishes first.
@@ -1462,13 +1463,19 @@ def eigh_route_hint(cov, n_out: int, top_k: Optional[int]) -> int:
 
 
 def eigh_cost_hint(cov, n_out: int, top_k: Optional[int]) -> float:
-    """Relative cost of the eigendecomposition behind `cov`, for the order in which concurrent chains are started
-    (longest first): the order of the eigenproblem cubed, the filtered route at about half of a direct reduction, the
-    factored route (Llama gate / up) with its products over the n_out rows on top."""
+    """Relative cost of the eigendecomposition behind `cov`, for the dealing of units to lanes (longest first): the order
+    of the eigenproblem cubed, the factored route (Llama gate / up) with its products over the n_out rows on top.  A
+    filtered-route problem counts like a direct one of its order (PTD_FILTERED_COST, default 1.0): alone it takes half
+    the time, but in a pass it runs beside other lanes' work and its f64 products share the matrix cores -- 65-117 ms
+    against 210-236 for a batch of two direct reductions (PTD_EIGH_TIMELINE=1); at round 5's 0.45 the four filtered
+    problems of two Llama blocks were dealt two and two to the lanes whose batches end first and the third lane idled
+    for 100 ms (B_eigh 403 ms; 389 with 1.0, one block 195 -> 184)."""
     n = cov.weight.shape[1] if isinstance(cov, MomentCovariance) and cov.factored else \
         (n_out if isinstance(cov, MomentCovariance) else cov.E.shape[0])
     route = eigh_route_hint(cov, n_out, top_k)
-    cost = float(n) ** 3 * (0.45 if route == 3 else 1.0)
+    import os
+
+    cost = float(n) ** 3 * (float(os.environ.get("PTD_FILTERED_COST", "1.0")) if route == 3 else 1.0)
     if isinstance(cov, MomentCovariance) and cov.factored:
         cost += 0.25 * float(n_out) * float(n) ** 2
     return cost
