@@ -2639,7 +2639,11 @@ int gemm_bf16(const unsigned short* A, int64_t sam, int64_t sak, const unsigned 
   a.cslab = 0;
   // few 128-wide tile columns but enough 128 x 64 tiles for one round of the chip: no K split, no reduction pass
   static const bool no_t64 = getenv("PTD_GEMM_T64") && atoi(getenv("PTD_GEMM_T64")) == 0;
-  if (!no_t64 && !b_kvalid && !b_nvalid && !no_glds && akc && bkc && a.vecA && a.vecB && c_vec && M % BM == 0 && N % 64 == 0 && K % BK == 0 &&
+  // (a long K with a workspace at hand goes to the K split below instead: a 128 x 64 tile takes in 192 rows of operands per
+  // K step, two 128 x 128 half ranges 128 each -- x A^T of Llama's down projection at T = 2048, r = 1024, K = 14336: 95 -> 79 us,
+  // the pair 118 -> 103; at K = 4096 the two forms measure the same)
+  const bool long_k_split = ws && K >= 8192 && gemm_bf16_ksplit(M, N, K) > 1;
+  if (!no_t64 && !long_k_split && !b_kvalid && !b_nvalid && !no_glds && akc && bkc && a.vecA && a.vecB && c_vec && M % BM == 0 && N % 64 == 0 && K % BK == 0 &&
       K >= 8 * BK && (M / BM) * ((N + BN - 1) / BN) < 192 && (M / BM) * (N / 64) >= 192 && (M / BM) * (N / 64) <= 256) {
     dim3 g64((unsigned)((M / BM) * (N / 64)), 1);
     if (c_bf16) hipLaunchKernelGGL((gemm_bf16_nt_glds_kernel<EPI_STORE_BF16, 4, 1>), g64, dim3(256), 0, st, a);
