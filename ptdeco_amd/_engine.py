@@ -717,6 +717,8 @@ class LayerTap:
         # around the layer do behind their inner forward: with a hook or an instance-level forward on any ancestor
         # (accelerate's offload hooks are such wrappers) the forwards stay whole
         revalidate = self._cal_forwards % 8 == 0
+        if revalidate:
+            self._plain_ancestors = None      # (a hook registered on an ancestor since the last look is seen)
         if (self._single_call_seen and not revalidate and self._ancestors_plain(root)
                 and os.environ.get("PTD_CALIBRATION_EARLY_STOP", "1") != "0"):
             self._stop_at_input = True

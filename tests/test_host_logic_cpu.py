@@ -942,6 +942,19 @@ def test_calibration_forwards_stop_at_the_analysed_layer_after_the_first_one(mon
             tap.calibration_forward(wrapped, x)
         tap.close()
     assert len(done) == 3
+    #  a hook registered on an ancestor AFTER the first forwards is seen at the next revalidation forward
+    # (every 8th): from then on the forwards stay whole and the hook's post-forward work happens
+    late = _MemoStack().eval()
+    fired = []
+    with torch.no_grad():
+        tap = eng.LayerTap(late, "blocks.1.fc2")
+        for _ in range(3):
+            tap.calibration_forward(late, x)         # 1 whole, 2 and 3 cut at the layer
+        late.blocks[1].register_forward_hook(lambda m, a, o: fired.append(tap._cal_forwards))
+        for _ in range(9):
+            tap.calibration_forward(late, x)         # 4 .. 7 still cut (the look is cached), 8 re-looks: 8 .. 12 whole
+        tap.close()
+    assert fired == [8, 9, 10, 11, 12]
 
 
 def test_step_batch_holds_calibration_steps_and_adds_them_in_one_call(monkeypatch):
