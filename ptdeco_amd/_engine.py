@@ -616,19 +616,35 @@ def batch_key(batch):
     dtype) and, for host tensors, 64 sampled values (a buffer refilled from outside torch -- numpy writing into
     `torch.from_numpy` memory -- does not bump the counter).  None when the batch holds anything but tensors and plain
     values.  The caller pins the batch object while it uses the key, so an id cannot come round on another tensor."""
-    flat: list = []
-    if not _flat_tensors(batch, flat) or not flat:
+    parts: list = []
+    seen_tensor = [False]
+
+    def walk(obj) -> bool:
+        if isinstance(obj, torch.Tensor):
+            t = obj
+            if t.is_inference():
+                return False
+            seen_tensor[0] = True
+            part = (id(t), t._version, t.data_ptr(), tuple(t.shape), t.dtype, t.device.type)
+            if t.device.type == "cpu" and t.numel() > 0 and t.layout == torch.strided and not t.is_complex():
+                v = t.detach().reshape(-1) if t.is_contiguous() else t.detach().flatten()
+                sample = v[:: max(1, v.numel() // 64)][:64]
+                part += (tuple(sample.to(torch.float64).tolist()),)
+            parts.append(part)
+            return True
+        if obj is None or isinstance(obj, (bool, int, float, str, torch.dtype, torch.device, torch.Size)):
+            parts.append(("value", obj))      # (a plain value the model may read: part of the batch's identity)
+            return True
+        if isinstance(obj, (tuple, list)):
+            parts.append(("seq", len(obj)))
+            return all(walk(o) for o in obj)
+        if isinstance(obj, dict):
+            parts.append(("dict", tuple(obj.keys()) if all(isinstance(k, str) for k in obj) else None))
+            return all(isinstance(k, str) and walk(v) for k, v in obj.items())
+        return False
+
+    if not walk(batch) or not seen_tensor[0]:
         return None
-    parts = []
-    for t in flat:
-        if t.is_inference():
-            return None
-        part = (id(t), t._version, t.data_ptr(), tuple(t.shape), t.dtype, t.device.type)
-        if t.device.type == "cpu" and t.numel() > 0 and t.layout == torch.strided:
-            v = t.detach().reshape(-1) if t.is_contiguous() else t.detach().flatten()
-            sample = v[:: max(1, v.numel() // 64)][:64]
-            part += (tuple(sample.to(torch.float64).tolist()) if not sample.is_complex() else (),)
-        parts.append(part)
     return tuple(parts)
 
 

@@ -1121,3 +1121,5 @@ def test_prefix_memo_across_candidates_keeps_prefix_and_original_output_per_batc
     b.numpy()[:] = 3.0
     assert k0 != k1 and k1 != eng.batch_key(b)
     assert eng.batch_key({"x": b, "n": 3}) is not None and eng.batch_key({"x": b, "cache": object()}) is None
+    # plain values the model may read are part of the identity; a batch without tensors has none
+    assert eng.batch_key({"x": b, "n": 3}) != eng.batch_key({"x": b, "n": 4}) and eng.batch_key({"n": 3}) is None
