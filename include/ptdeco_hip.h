@@ -176,9 +176,15 @@ int ptd_eigh_topk_f32(const float* A, int64_t lda, int64_t n, int64_t k, int all
  * serves all of them (blockIdx.y = matrix) -- one host thread, one stream, one host synchronisation for the batch,
  * where round 5 ran one thread and one stream per layer.  Requests the filtered route serves (see above) and single
  * matrices are solved one after the other exactly as ptd_eigh_topk would; two matrices are batched from n = 512 on
- * (PTD_EIGH_BATCH_MIN_N), three or more always; PTD_EIGH_BATCHED=0: never.  stats (HOST pointer, may be NULL): the
+ * (PTD_EIGH_BATCH_MIN_N), three or more always; PTD_EIGH_BATCHED=0: never.  `all_values` is a set of flags: bit 0 = every
+ * eigenvalue is wanted (as in ptd_eigh_topk), bit 1 (PTD_EIGH_FLAG_DIRECT) = take the direct reduction also where the
+ * filtered route would serve the request, so that the matrices are batched: for a caller whose pass already runs
+ * latency-bound reductions of this order on other streams, beside which the filter's f64 products only share the matrix
+ * cores (two Llama blocks: q / o as two filtered problems each 75-127 ms in the pass, as one more batch 40).  stats (HOST pointer, may be NULL): the
  * ptd_eigh_profiled figures of the batch (method 1: `sweeps` = matrices per launch, work[0] = algorithmic bytes of
  * all of them) or of the last matrix when solved one by one.  Workspace: ptd_eigh_batched_workspace_bytes. */
+#define PTD_EIGH_FLAG_ALL_VALUES 1
+#define PTD_EIGH_FLAG_DIRECT 2
 size_t ptd_eigh_batched_workspace_bytes(int64_t n, int64_t k, int count);
 struct ptd_eigh_stats_s;
 int ptd_eigh_topk_batched(const double* const* As, int64_t lda, int count, int64_t n, int64_t k, int all_values,

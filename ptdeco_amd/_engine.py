@@ -1135,7 +1135,6 @@ def solve_eigenproblems(posers: list, orders: list, device: torch.device, costs:
 
     from . import _hip
 
-    cap = max(1, int(os.environ.get("PTD_EIGH_BATCH_MAX", "2")))
     nlanes = max(1, int(os.environ.get("PTD_EIGH_LANES", "3")))
     lib = _hip.load() if device.type == "cuda" else None
     if costs is None:
@@ -1144,14 +1143,34 @@ def solve_eigenproblems(posers: list, orders: list, device: torch.device, costs:
     for i, key in enumerate(orders):
         groups.setdefault(tuple(key), []).append(i)
     out: list = [None] * len(posers)
+    routes = {key: (int(lib.ptd_eigh_route(key[0], key[1], 0)) if lib is not None else 1) for key in groups}
+    # A group the filtered route would serve joins the direct batches when the pass ALREADY runs direct reductions of its
+    # order in other lanes (and there are lanes): beside them the filter's f64 products only share the matrix cores --
+    # q / o of two Llama blocks: four filtered problems of 75-127 ms each in the pass (one of them declining late into a
+    # 141-ms reduction of its own) against one more batch of four at ~40 ms a matrix; B_eigh 389 -> 338 ms.  Alone (one
+    # layer, PTD_EIGH_LANES=1, a pass of filtered problems only) the filtered route keeps its 25 ms against 45.
+    # PTD_EIGH_DIRECT_IN_PASS=0: never.
+    direct_orders = {key[0] for key, r in routes.items() if r == 1 and len(groups[key]) >= 1 and key[0] >= 2048}
+    forced: set = set()
+    if nlanes > 1 and device.type == "cuda" and os.environ.get("PTD_EIGH_DIRECT_IN_PASS", "1") != "0":
+        forced = {key for key, r in routes.items() if r == 3 and len(groups[key]) >= 2 and key[0] in direct_orders}
+    # matrices per launch: PTD_EIGH_BATCH_MAX, by default what fills the lanes evenly -- the large direct problems of the
+    # pass over the lanes, between 2 and 4 (one Llama block: 5 problems of order 4096, batches of <= 2, 184 ms; two
+    # blocks: 10, batches of <= 4, 338 ms against 357 with pairs)
+    if os.environ.get("PTD_EIGH_BATCH_MAX"):
+        cap = max(1, int(os.environ["PTD_EIGH_BATCH_MAX"]))
+    else:
+        big = sum(len(groups[key]) for key, r in routes.items() if key[0] >= 2048 and (r == 1 or key in forced))
+        cap = min(4, max(2, -(-big // nlanes)))
 
-    def batch_unit(chunk):
+    def batch_unit(chunk, direct=False):
         def run():
             problems = [posers[i]() for i in chunk]
             # (a poser may fall back to another order -- a refused factored problem: those are solved alone)
             same = [j for j, p in enumerate(problems) if p.key == problems[0].key]
             if len(same) >= 2:
-                pairs = ops.eigh_batched([problems[j].matrix for j in same], problems[0].k, all_values=False)
+                pairs = ops.eigh_batched([problems[j].matrix for j in same], problems[0].k, all_values=False,
+                                         direct=direct)
                 for j, (w, v) in zip(same, pairs):
                     out[chunk[j]] = problems[j].finish(w, v)
             else:
@@ -1183,7 +1202,7 @@ def solve_eigenproblems(posers: list, orders: list, device: torch.device, costs:
 
     units: list = []        # (cost, first member, run, matrix-core-bound?)
     for (n, k), members in groups.items():
-        route = int(lib.ptd_eigh_route(n, k, 0)) if lib is not None else 1
+        route = 1 if (n, k) in forced else routes[(n, k)]
         if route == 1 and len(members) >= 2 and cap >= 2:
             # chunks of `cap`; a lone last member joins the chunk before it (three matrices: one batch of three at cap 2)
             chunks = [members[c0:c0 + cap] for c0 in range(0, len(members), cap)]
@@ -1192,7 +1211,7 @@ def solve_eigenproblems(posers: list, orders: list, device: torch.device, costs:
             for chunk in chunks:
                 if len(chunk) >= 2:
                     units.append((0.85 * sum(costs[i] for i in chunk), chunk[0],
-                                  timed(f"batch{len(chunk)} n={n} k={k}", batch_unit(chunk)), False))
+                                  timed(f"batch{len(chunk)} n={n} k={k}", batch_unit(chunk, (n, k) in forced)), False))
                 else:
                     units.append((costs[chunk[0]], chunk[0], timed(f"single n={n} k={k}", single_unit(chunk[0])), False))
         else:

@@ -143,8 +143,8 @@ size_t ptd_eigh_workspace_bytes(int64_t n) {
 
 static int eigh_dispatch(const double* A, int64_t lda, int64_t n, int64_t k, double* evals, double* evecs,
                          int64_t ldv, void* ws, size_t ws_bytes, int* sweeps_out, bool all_values,
-                         ptd_eigh_stats* stats, hipStream_t st) {
-  const int method = eigh_method();
+                         ptd_eigh_stats* stats, hipStream_t st, bool direct = false) {
+  const int method = direct && eigh_method() == 2 ? 1 : eigh_method();
   // a quarter of the spectrum of a large matrix: filtered subspace iteration on the f64 matrix cores; it declines
   // (flat spectrum, breakdown, residual above tolerance) with PTD_ERR_UNSUPPORTED and the direct route below runs
   if (method == 2 && A && evals && evecs && ws && lda >= n && k >= 1 && k <= n && ldv >= k && (lda % 2) == 0 &&
@@ -188,10 +188,11 @@ static int batch_min_n() {
   return e ? atoi(e) : 512;
 }
 
-static bool batch_route(int count, int64_t n, int64_t k, bool all_values) {
+static bool batch_route(int count, int64_t n, int64_t k, bool all_values, bool direct = false) {
   const int method = eigh_method();
   if (count < 2 || method == 0 || n < 256) return false;
-  if (method == 2 && eigh_filtered_applies(n, k, all_values)) return false;   // chip-filling f64 products: one by one
+  // (the filtered route's f64 products fill the chip: one by one -- unless the caller asks for the direct reduction)
+  if (!direct && method == 2 && eigh_filtered_applies(n, k, all_values)) return false;
   const char* off = getenv("PTD_EIGH_BATCHED");
   if (off && atoi(off) == 0) return false;
   return count >= 3 || n >= batch_min_n();
@@ -216,12 +217,17 @@ int ptd_eigh_topk_batched(const double* const* As, int64_t lda, int count, int64
   }
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (stats) memset(stats, 0, sizeof(*stats));
-  if (!batch_route(count, n, k, all_values != 0)) {
+  // all_values is a set of flags: bit 0 = every eigenvalue, bit 1 (PTD_EIGH_FLAG_DIRECT) = the direct reduction also
+  // where the filtered route would serve the request (a caller whose pass already runs latency-bound reductions of
+  // this order beside this call: the filter's products would share the matrix cores with them)
+  const bool direct = (all_values & 2) != 0;
+  all_values &= 1;
+  if (!batch_route(count, n, k, all_values != 0, direct)) {
     // one by one, each with the whole chip (the filtered route's products fill it; a single direct reduction keeps
     // its resident kernels); stats describe the LAST matrix
     for (int b = 0; b < count; ++b) {
       const int rc = eigh_dispatch(As[b], lda, n, k, evals[b], evecs[b], ldv, ws, ws_bytes, nullptr, all_values != 0,
-                                   stats, st);
+                                   stats, st, direct);
       if (rc != PTD_OK) return rc;
     }
     return PTD_OK;

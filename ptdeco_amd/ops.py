@@ -182,12 +182,13 @@ def eigh_factored(W: torch.Tensor, Ex: torch.Tensor, k: int) -> Optional[tuple[t
     return w, u
 
 
-def eigh_batched(mats, k: Optional[int] = None, all_values: bool = False) -> list:
+def eigh_batched(mats, k: Optional[int] = None, all_values: bool = False, direct: bool = False) -> list:
     """ops.eigh for several f64 matrices of ONE order in one ptd_eigh_topk_batched call: a list of (eigenvalues [n],
     eigenvectors [n, k]) in the order of `mats`.  The loop of torch.linalg.eigh calls of dwain's precompute pass
     (dwain.py:580-633, :162) -- the matrices advance through the tridiagonalisation in lockstep, every launch serves all of
     them (one stream, one host thread).  One matrix, or a request the filtered route serves: solved one by one by the
-    library, exactly as ops.eigh would."""
+    library, exactly as ops.eigh would -- unless `direct` (PTD_EIGH_FLAG_DIRECT): then the matrices take the direct
+    reduction together also where the filtered route applies."""
     mats = list(mats)
     assert mats, "eigh_batched: no matrix"
     a0 = mats[0]
@@ -208,7 +209,7 @@ def eigh_batched(mats, k: Optional[int] = None, all_values: bool = False) -> lis
     v_ptrs = arr(*[v.data_ptr() for v in vs])
     st = _hip.EighStats() if EIGH_PROFILE is not None else None
     with torch.cuda.device(a0.device):
-        rc = lib.ptd_eigh_topk_batched(a_ptrs, a0.stride(0), count, n, k, int(all_values), w_ptrs, v_ptrs, k,
+        rc = lib.ptd_eigh_topk_batched(a_ptrs, a0.stride(0), count, n, k, int(all_values) | (2 if direct else 0), w_ptrs, v_ptrs, k,
                                        ws.data_ptr(), ws.numel(), ctypes.byref(st) if st is not None else None,
                                        _stream(a0))
     _hip.check(rc, "ptd_eigh_topk_batched")

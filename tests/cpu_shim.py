@@ -72,7 +72,7 @@ def eigh_factored_prepare(W, Ex, k):
     return _Factored(W, Ex, k)
 
 
-def eigh_batched(mats, k=None, all_values=False):
+def eigh_batched(mats, k=None, all_values=False, direct=False):
     return [eigh(a, k, all_values) for a in mats]
 
 

@@ -42,7 +42,11 @@ configs = [c for c in os.environ.get("CONFIGS", "2x2,3x2,2x3,2x4,1x4,threads").s
 for cfg in configs:
     # LxC: PTD_EIGH_LANES x PTD_EIGH_BATCH_MAX of the batched engine; threads: round 5's one thread and stream per chain
     os.environ["PTD_EIGH_BATCHED"] = "0" if cfg == "threads" else "1"
-    if cfg != "threads":
+    if cfg == "auto":       # the engine's defaults: three lanes, matrices per launch from the pass
+        for v in ("PTD_EIGH_LANES", "PTD_EIGH_BATCH_MAX", "PTD_LANE_CUS"):
+            os.environ.pop(v, None)
+        os.environ["PTD_LANE_STREAMS"] = "dedicated"
+    elif cfg != "threads":
         # LxC[:pool | :a,b,c]  -- lanes x batch cap, then the lane streams: torch pool streams (probed), or dedicated streams
         # with that many CUs each
         lc, _, extra = cfg.partition(":")
