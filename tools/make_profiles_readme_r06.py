@@ -33,7 +33,7 @@ o.append("Files (round 6):\n\n"
          "* `rocprofv3_kernel_stats_default_r06.csv` -- `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --gpus 1 --steps 5 --warmup 1 --no-cpu-baseline`: the kernel summary of the DEFAULT command (kernels of concurrent lanes overlap, so their durations read longer than alone; the `Cijk_*` / `attn_fwd` kernels are the CALLER's model and the library side of the comparison lines)\n"
          "* `rocprofv3_headline_steps_r06.txt` -- `tools/prof_kernels.sh headline2 bench.py --steps 3 --warmup 1 --no-extras`: the headline steps alone\n"
          "* `rocprofv3_kernel_stats_r06.csv`, `roofline_kernel_split_r06.json` -- the same for `bench.py --workload c2 --steps 3 --warmup 1 --no-extras` (BASELINE configs[1]); the filtered route's dominant kernel split by duration\n"
-         "* `pmc_symv_r06.json/.csv` (the batched SYMV, two matrices per launch), `pmc_gemm_f64_r06.json`, `pmc_mfma_r06.json`, `pmc_syrk_r06.json` -- separate `rocprofv3 --pmc` passes over the torch-free `tools/pmc_driver batched 2 | eigh | mfma | syrk`, condensed on the box (`tools/pmc_*_summary.py`); FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950; each carries the sha256 of the kernel sources it was measured on\n"
+         "* `pmc_symv_r06.json/.csv` (the batched SYMV, four matrices per launch), `pmc_gemm_f64_r06.json`, `pmc_mfma_r06.json`, `pmc_syrk_r06.json` -- separate `rocprofv3 --pmc` passes over the torch-free `tools/pmc_driver batched 4 | eigh | mfma | syrk`, condensed on the box (`tools/pmc_*_summary.py`); FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950; each carries the sha256 of the kernel sources it was measured on\n"
          "* `batched_eigh_*_r06.*`, `lanes_ab_r06.txt` -- `tools/probes/batched_eigh.py`, `tools/block_b_eigh.py`: 1-4 matrices per launch, lockstep / staggered, lanes x batch caps, CU-partitioned lanes, pool streams\n"
          "* `c4_stack_32blocks_bf16_r06.json`, `c4_hf_llama3_8b_r06.json` -- the full-depth runs (`tools/c4_stack.py 32 bf16 --trade-off 640 --max-ppl 0.4`, `tools/c4_hf_llama.py 32`; metric iterator over 16 batches: none recurs within a layer) with a sample check of one replaced layer (`tests/factor_checks.py`); `*_recurring_r06.json` -- the same with `METRIC_POOL=4` (batches recur within a layer: PrefixMemo across candidates)\n"
          "* `bench_r06_rehearsal_2ranks_1gpu.json` -- `PTD_BENCH_REHEARSE=1 python bench.py --gpus 2 --steps 2 --warmup 1`: the N = 2 code path with BOTH ranks on the one GPU of the box (gloo): a check that the path runs and what its line carries (`comm_ms`, `b_eigh_ms_max`, `d_metrics_ms_max`, `cov_collective`), not a scaling number\n"

@@ -56,8 +56,8 @@ if [ "$PART" = all ] || [ "$PART" = pmc ]; then
   G=$GRAFT_REPO_ROOT
   for c in FETCH_SIZE:pmc_fetch WRITE_SIZE:pmc_write "TCC_HIT_sum TCC_MISS_sum":pmc_tcc; do
     ctr=${c%%:*}; dir=${c##*:}
-    # (round 6: the unit of the headline step's direct lane -- two (4096, 2048) matrices per launch, every column blocked)
-    timeout -k 10 300 rocprofv3 --pmc $ctr --kernel-include-regex sytrd_symv --kernel-trace --output-format csv -d $G/gpurun_out/$dir -- $G/tools/pmc_driver batched 2 > $G/gpurun_out/$dir.log 2>&1; echo "$dir rc=$?"
+    # (round 6: the unit of the headline step's direct lane -- four (4096, 2048) matrices per launch, every column blocked)
+    timeout -k 10 300 rocprofv3 --pmc $ctr --kernel-include-regex sytrd_symv --kernel-trace --output-format csv -d $G/gpurun_out/$dir -- $G/tools/pmc_driver batched 4 > $G/gpurun_out/$dir.log 2>&1; echo "$dir rc=$?"
   done
   timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-include-regex "syrk|gemm" --kernel-trace --output-format csv -d $G/gpurun_out/pmc_mfma -- $G/tools/pmc_driver mfma > $G/gpurun_out/pmc_mfma.log 2>&1; echo "pmc_mfma rc=$?"
   timeout -k 10 300 rocprofv3 --pmc MfmaUtil --kernel-include-regex "syrk|gemm" --kernel-trace --output-format csv -d $G/gpurun_out/pmc_mfma2 -- $G/tools/pmc_driver mfma > $G/gpurun_out/pmc_mfma2.log 2>&1; echo "pmc_mfma2 rc=$?"
@@ -72,7 +72,7 @@ if [ "$PART" = all ] || [ "$PART" = pmc ]; then
   done
   # condense on the box (gpurun copies back at most 64 MiB: the raw counter tables stay here), summaries -> gpurun_out/
   cd $G
-  python3 tools/pmc_summary.py $R 4096 2 > gpurun_out/pmc_summary.log 2>&1; echo "pmc_summary rc=$?"
+  python3 tools/pmc_summary.py $R 4096 4 > gpurun_out/pmc_summary.log 2>&1; echo "pmc_summary rc=$?"
   python3 tools/pmc_mfma_summary.py $R > gpurun_out/pmc_mfma_summary.log 2>&1; echo "pmc_mfma_summary rc=$?"
   python3 tools/pmc_syrk_summary.py $R > gpurun_out/pmc_syrk_summary.log 2>&1; echo "pmc_syrk_summary rc=$?"
   python3 tools/pmc_filtered_summary.py $R > gpurun_out/pmc_filtered_summary.log 2>&1; echo "pmc_filtered_summary rc=$?"
