@@ -327,11 +327,30 @@ __global__ __launch_bounds__(256) void sytrd_symv2_kernel(const double* __restri
     const int cA = C0 + 2 * lane, cB = cA + 128;
     const int rbase = R0 + 16 * wid;
     double2 a0[16], a1[16];
+    // A 128-column half of the tile is not fetched when nothing in it is read: left of column j + 1 (the tile column
+    // that holds it starts at a multiple of 256: on average 128 dead columns over all m rows) or right of the tile's
+    // last row (the upper halves of the 256 x 256 diagonal blocks).  Wave-uniform tests; 0.64 -> 0.59 of the full-square
+    // bytes at n = 4096.
+    // ... and inside a live half a lane whose two columns lie left of column j + 1 asks for nothing (whole 128-byte lines
+    // at the left edge of the first tile column are then not requested), nor -- in the tiles on the diagonal -- for the
+    // rows above its columns.
+    const bool liveA = (C0 + 127 >= j + 1) && (C0 <= R0 + TR - 1) && (cA + 1 >= j + 1);
+    const bool liveB = (C0 + 255 >= j + 1) && (C0 + 128 <= R0 + TR - 1) && (cB + 1 >= j + 1);
+    if (C0 + TC - 1 > R0) {      // a tile on the diagonal: elements with c > r are never read
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      const double* rowp = A + (int64_t)min(rbase + t, n - 1) * ld;
-      a0[t] = *reinterpret_cast<const double2*>(rowp + cA);
-      a1[t] = *reinterpret_cast<const double2*>(rowp + cB);
+      for (int t = 0; t < 16; ++t) {
+        const int rr = min(rbase + t, n - 1);
+        const double* rowp = A + (int64_t)rr * ld;
+        a0[t] = (liveA && cA <= rr) ? *reinterpret_cast<const double2*>(rowp + cA) : double2{0.0, 0.0};
+        a1[t] = (liveB && cB <= rr) ? *reinterpret_cast<const double2*>(rowp + cB) : double2{0.0, 0.0};
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const double* rowp = A + (int64_t)min(rbase + t, n - 1) * ld;
+        a0[t] = liveA ? *reinterpret_cast<const double2*>(rowp + cA) : double2{0.0, 0.0};
+        a1[t] = liveB ? *reinterpret_cast<const double2*>(rowp + cB) : double2{0.0, 0.0};
+      }
     }
     if (SYMV_DBG(2)) {
       double sink = 0.0;
