@@ -1651,6 +1651,21 @@ def test_eigh_batched_mixed_requests_and_clusters(ops, monkeypatch):
     for d, (w, v) in zip(big, ops.eigh_batched(big, 512)):
         w1, v1 = ops.eigh(d, 512, all_values=False)
         assert (orc.canonical_sign(v.cpu()) - orc.canonical_sign(v1.cpu())).abs().max().item() <= 1e-8
+    # PTD_EIGH_FLAG_DIRECT (what a busy pass asks for): the same request through the batched direct reduction -- the
+    # eigenpairs of the matrices themselves, to the direct route's accuracy
+    st_before = ops.EIGH_PROFILE
+    ops.EIGH_PROFILE = []
+    try:
+        got = ops.eigh_batched(big, 512, direct=True)
+        assert ops.EIGH_PROFILE[-1]["method"] == 1 and ops.EIGH_PROFILE[-1]["count"] == 2     # one batched call, tridiagonal route
+    finally:
+        ops.EIGH_PROFILE = st_before
+    for d, (w, v) in zip(big, got):
+        dc, vc, wc = d.cpu(), v.cpu(), w.cpu()
+        w_ref = torch.linalg.eigvalsh(dc)
+        assert (wc[2048 - 512:] - w_ref[2048 - 512:]).abs().max().item() <= 1e-10 * w_ref.max().item()
+        assert (dc @ vc - vc * wc[2048 - 512:]).abs().max().item() <= 1e-9 * w_ref.max().item()
+        assert (vc.T @ vc - torch.eye(512, dtype=torch.float64)).abs().max().item() <= 1e-7
 
 
 def test_eigh_factored_in_two_halves_matches_the_one_call_form(ops):
